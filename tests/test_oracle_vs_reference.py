@@ -1,0 +1,103 @@
+"""Pins the CPU oracle (oracle/lf_oracle.c) to the REAL reference: every check compares the
+oracle against fixtures that oracle/make_golden.py produced by running the reference's own code
+(oracle/_ref/ref_dump).  CPU only."""
+import os
+
+import numpy as np
+import pytest
+
+from goldenlib import GOLD, Case, FRAME_CASES, aperture_stats_golden, load_red, load_texels
+from oracle import lfo
+
+# reference and oracle run the same libm in the same container: doubles agree to rounding noise
+TOL = 1e-12
+
+
+def test_aperture_texture_matches_reference():
+    """CameraApertureTexture::init (camera.h:26-83): texels, bbox and total_value, all 17 PNGs."""
+    import hashlib
+    gold = aperture_stats_golden()
+    assert len(gold) == 17
+    for name, g in gold.items():
+        tex, st = lfo.aperture_from_red(load_red(name))
+        assert hashlib.sha256(tex.tobytes()).hexdigest() == g["sha256_f32"], name
+        assert np.array_equal(tex, load_texels(name))
+        assert (st.width, st.height) == (g["width"], g["height"])
+        assert (st.min_x, st.min_y, st.max_x, st.max_y) == (g["min_x"], g["min_y"], g["max_x"], g["max_y"]), name
+        assert st.total_value == float.fromhex(g["total_value"]), name
+
+
+def test_paraxial_trace_bit_exact():
+    """trace_ray_auto_before/after (pathtracer.cpp:588-689): 7 angles x 3 colours x 13 pairs x 2 rays."""
+    L = lfo.default_lens()
+    n = 0
+    for line in open(os.path.join(GOLD, "paraxial_trace.txt")):
+        kind, th, c, i, j, r, x, y = line.split()
+        got = lfo.trace(L, kind, float.fromhex(r), float.fromhex(th), int(i), int(j), int(c))
+        assert got == (float.fromhex(x), float.fromhex(y)), line
+        n += 1
+    assert n == 7 * 3 * 13 * 2
+
+
+def test_convert_coordinate_bit_exact():
+    for line in open(os.path.join(GOLD, "convert_coordinate.txt")):
+        length, yflag, p, v = line.split()
+        assert lfo.convert_coordinate(int(p), int(length), int(yflag)) == float.fromhex(v)
+
+
+def _frame(case):
+    m = case.meta
+    f = lfo.make_frame(case.W, case.H, ns_aa=m["ns_aa"], flare_radius=m["flare_radius"],
+                       flare_intensity=m["flare_intensity"])
+    lfo.find_sun_pos(m["c2w"], m["cam_pos"], m["hFov"], m["vFov"], m["lights"], f)
+    return f
+
+
+@pytest.mark.parametrize("name", FRAME_CASES + ["f64x64_no_sun"])
+def test_find_sun_pos_bit_exact(name):
+    """find_sun_pos + analyze_world_coord (pathtracer.cpp:32-64, camera.cpp:245-273)."""
+    case = Case(name)
+    f = _frame(case)
+    assert f.n_flares == case.meta["n_flares"]
+    for k, fl in enumerate(case.flares):
+        assert (f.flare_origin[k][0], f.flare_origin[k][1]) == (fl[0], fl[1])
+        assert tuple(f.flare_radiance[k]) == tuple(fl[2:])
+    if f.n_flares:
+        assert tuple(f.axis_ray) == tuple(case.meta["axis_ray"])
+        assert f.angle_to_sun == case.meta["angle_to_sun"]
+
+
+@pytest.mark.parametrize("name", FRAME_CASES + ["f64x64_no_sun"])
+def test_ghost_buffer_bit_exact(name):
+    """generate_ghost_buffer (pathtracer.cpp:714-817): 39 textured quads, every pixel bit-exact."""
+    case = Case(name)
+    f = _frame(case)
+    ghost = lfo.ghost_buffer(lfo.default_lens(), f, load_texels(case.meta["ghost_aperture"]))
+    assert np.array_equal(ghost, case.ghost)
+
+
+@pytest.mark.parametrize("name", FRAME_CASES)
+def test_raytrace_pixel_matches_reference(name):
+    """raytrace_pixel (pathtracer.cpp:819-899) = ghost + starburst + falloff, in visit order."""
+    case = Case(name)
+    f = _frame(case)
+    tex, st = lfo.aperture_from_red(load_red(case.meta["aperture"]))
+    order = case.order if case.order is not None else lfo.tile_order(case.W, case.H)
+    got = lfo.render_pixels(f, tex, st, case.ghost, order, n_threads=8)
+    if case.order is not None:
+        # a repeated pixel keeps its last visit, like the reference buffer
+        got_o, ref_o = got.reshape(-1, 3)[order], case.sample_at_order
+    else:
+        got_o, ref_o = got, case.sample
+    err = np.abs(got_o - ref_o) / np.abs(ref_o)
+    assert err.max() <= TOL, (name, err.max())
+    rgba = lfo.to_color(got)
+    ref_rgba = case.rgba_at_order if case.order is not None else case.rgba
+    got_rgba = rgba.reshape(-1)[order] if case.order is not None else rgba
+    assert np.array_equal(got_rgba, ref_rgba)
+
+
+def test_mt19937_known_answer():
+    """std::mt19937 default seed: the 10000th output is 4123659995 (C++11 [rand.predef])."""
+    raw = lfo.mt19937_raw(5489, 9999, 1)
+    assert int(raw[0]) == 4123659995
