@@ -1,0 +1,183 @@
+/* lensflare.h -- C ABI of liblensflare_hip.so, the MI355X (gfx950) implementation of the
+ * lens-flare hot path of aatifjiwani/lens-flare (src/pathtracer).
+ *
+ * This is the drop-in boundary: plain pointers and sizes, no C++ types, no exceptions, every
+ * entry point returns an lf_status.  Each function names the reference interface it replaces
+ * (file:line relative to the reference checkout).  The reference itself has no C ABI -- its
+ * boundary is the public surface of `class PathTracer` inside libpt31.so
+ * (CMakeLists.txt:20-33,139-142; src/pathtracer/pathtracer.h:25-143) -- so the C++ shim in
+ * lens-flare_amd/host/ maps that surface 1:1 onto these calls.
+ *
+ * Threading contract (mirrors src/pathtracer/raytraced_renderer.cpp:300-311, :637-646): the
+ * set-up and render calls are made from one thread per context; lf_read_* may then be called
+ * concurrently from any number of threads.  One context drives one GPU; multi-GPU = one context
+ * (and normally one process) per GPU, each rendering its own band of sensor rows.
+ */
+#ifndef LENSFLARE_H
+#define LENSFLARE_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define LF_ABI_VERSION 1
+#define LF_MAX_SURFACES 16   /* interfaces per prescription (incl. the stop) */
+#define LF_MAX_LAMBDA 8      /* wavelengths per prescription */
+#define LF_MAX_FLARES 8      /* in-frame directional lights */
+#define LF_MAX_PAIRS 128     /* ghost pairs per trace call */
+
+typedef struct lf_ctx lf_ctx;
+
+typedef enum {
+  LF_OK = 0,
+  LF_ERR_INVALID = 1,   /* bad argument (null pointer, size out of range, ...) */
+  LF_ERR_NO_DEVICE = 2, /* no gfx950 device / device index out of range */
+  LF_ERR_HIP = 3,       /* a HIP runtime call failed; see lf_last_error */
+  LF_ERR_STATE = 4,     /* call order violated (e.g. render before set_frame) */
+  LF_ERR_OOM = 5
+} lf_status;
+
+typedef enum { LF_APERTURE_STARBURST = 0, LF_APERTURE_GHOST = 1 } lf_aperture_slot;
+
+/* CameraApertureTexture (src/pathtracer/camera.h:18-88) */
+typedef struct {
+  int width, height;
+  int min_x, min_y, max_x, max_y; /* bbox of texels > 0 (camera.h:54-72) */
+  double total_value;             /* camera.h:61 */
+} lf_aperture_stats;
+
+/* device-side counters of the geometric march */
+typedef struct {
+  uint64_t rays_launched;   /* (sample, wavelength, pair) rays started */
+  uint64_t surface_events;  /* executed ray-surface events (intersect + refract|reflect + Fresnel) */
+  uint64_t rays_clipped_stop;   /* killed by the aperture mask at the stop */
+  uint64_t rays_vignetted;      /* outside a semi-aperture or missed a surface */
+  uint64_t rays_tir;            /* total internal reflection */
+  uint64_t rays_reached_scene;  /* left the front element */
+  uint64_t rays_hit_light;      /* ... inside the light's angular lobe (non-zero radiance) */
+} lf_counters;
+
+/* ---------------------------------------------------------------- life cycle ------------- */
+/* replaces: PathTracer::PathTracer / ~PathTracer (pathtracer.cpp:14-30).  device = HIP ordinal. */
+lf_status lf_create(lf_ctx** out, int device);
+lf_status lf_destroy(lf_ctx* ctx);
+/* text of the last error on this context (never NULL); valid until the next call */
+const char* lf_last_error(const lf_ctx* ctx);
+int lf_abi_version(void);
+/* optional: run every launch on a caller-owned hipStream_t (e.g. torch's current stream) */
+lf_status lf_set_stream(lf_ctx* ctx, void* hip_stream);
+lf_status lf_synchronize(lf_ctx* ctx);
+
+/* ---------------------------------------------------------------- frame ------------------ */
+/* replaces: PathTracer::set_frame_size (pathtracer.cpp:66-69) + clear (:71-79) */
+lf_status lf_set_frame(lf_ctx* ctx, int width, int height);
+/* multi-GPU sharding: this context renders sensor rows [y0, y1) only (default: all rows).
+ * Mirrors the tile queue of raytraced_renderer.cpp:314-328, one band of tile rows per GPU. */
+lf_status lf_set_band(lf_ctx* ctx, int y0, int y1);
+/* replaces the public fields PathTracer::ns_aa, flare_radius, flare_intensity
+ * (pathtracer.h:93-94,107) */
+lf_status lf_set_params(lf_ctx* ctx, int ns_aa, double flare_radius, double flare_intensity);
+
+/* ---------------------------------------------------------------- inputs ----------------- */
+/* replaces: CameraApertureTexture::init (camera.h:26-83) minus the PNG decode: texels are the
+ * float values the reference derives from the red channel (CGL/src/color.cpp:16-21).  bbox and
+ * total_value are computed on the device. */
+lf_status lf_set_aperture(lf_ctx* ctx, lf_aperture_slot slot, const float* texels, int width,
+                          int height);
+lf_status lf_get_aperture_stats(lf_ctx* ctx, lf_aperture_slot slot, lf_aperture_stats* out);
+
+/* replaces the lens-table globals of pathtracer.cpp:541-556 (Ts, red/green/blue_refr,
+ * curvatures) and the constants of trace_ray_auto_* (:619-633): n interfaces, ior[3][n] row-major.
+ * Passing NULL arrays restores the reference's hard-coded table. */
+lf_status lf_set_paraxial_lens(lf_ctx* ctx, int n, int stop_index, const float* thickness,
+                               const float* curvature, const float* ior_rgb);
+
+/* replaces Camera state read by find_sun_pos (camera.h:171-180; camera.cpp:245-273):
+ * c2w row-major 3x3, position, fields of view in DEGREES (already fitted to the aspect ratio) */
+lf_status lf_set_camera(lf_ctx* ctx, const double c2w[9], const double pos[3], double hfov_deg,
+                        double vfov_deg);
+/* replaces: PathTracer::find_sun_pos (pathtracer.cpp:32-64).  lights: n x {posLight xyz,
+ * radiance rgb} of the scene's DirectionalLights (src/scene/light.h:16-29). */
+lf_status lf_find_sun_pos(lf_ctx* ctx, const double* lights, int n_lights);
+/* direct write / read of the public fields flare_origins, flare_radiance, axis_ray,
+ * angle_to_sun (pathtracer.h:128-135).  origins: n x 2, radiance: n x 3. */
+lf_status lf_set_flares(lf_ctx* ctx, int n, const double* origins, const double* radiance,
+                        const double axis_ray[2], float angle_to_sun);
+lf_status lf_get_flares(lf_ctx* ctx, int* n, double* origins, double* radiance,
+                        double axis_ray[2], float* angle_to_sun);
+
+/* sub-pixel jitter of calculate_irradiance_falloff (pathtracer.cpp:1043-1063).
+ * MT19937: reproduce the reference's shared std::mt19937 (util/random_util.h:10-22) for a single
+ * worker visiting `order` (pixel index x + y*W; NULL = the reference's 32x32 tile order,
+ * raytraced_renderer.cpp:314-328,:637-641).  COUNTER: order-free Philox4x32-10 keyed by `key`. */
+lf_status lf_set_jitter_mt19937(lf_ctx* ctx, uint32_t seed, const uint32_t* order, size_t n_order);
+lf_status lf_set_jitter_counter(lf_ctx* ctx, uint64_t key);
+
+/* optional scene-radiance term (est_radiance_global_illumination averaged as in
+ * pathtracer.cpp:841-875) computed by the host: W*H*3 doubles, NULL = zero */
+lf_status lf_set_scene_term(lf_ctx* ctx, const double* rgb);
+
+/* ---------------------------------------------------------------- render ----------------- */
+/* replaces: PathTracer::generate_ghost_buffer (pathtracer.cpp:714-817): paraxial trace of the
+ * 13 reflection pairs x 3 colours and rasterisation of the 39 textured quads */
+lf_status lf_generate_ghost_buffer(lf_ctx* ctx);
+/* replaces: PathTracer::raytrace_pixel (pathtracer.cpp:819-899) for every pixel of the band:
+ * sample = scene + ghost_buffer + raytrace_starburst (incl. calculate_irradiance_falloff) */
+lf_status lf_render_flare_layer(lf_ctx* ctx);
+
+/* ---------------------------------------------------------------- read back -------------- */
+/* replaces reads of PathTracer::sampleBuffer / ghost_buffer (util/image.h:139-151).
+ * which: 0 = sampleBuffer, 1 = ghost_buffer.  dst receives (x1-x0)*(y1-y0) pixels, each
+ * `pixel_stride` doubles apart (3 = packed Vector3D, 4 = the AVX build's 32-byte Vector3D). */
+lf_status lf_read_tile(lf_ctx* ctx, int which, int x0, int y0, int x1, int y1, double* dst,
+                       size_t pixel_stride);
+lf_status lf_read_pixel(lf_ctx* ctx, int which, int x, int y, double rgb[3]);
+/* replaces: PathTracer::write_to_framebuffer -> HDRImageBuffer::toColor (util/image.h:208-223,
+ * :53-62): RGBA8 of the tile, dst rows `row_stride` uint32 apart */
+lf_status lf_write_to_framebuffer(lf_ctx* ctx, int x0, int y0, int x1, int y1, uint32_t* dst,
+                                  size_t row_stride);
+/* device pointer of a buffer (for RCCL gathers over xGMI without a host hop);
+ * which as in lf_read_tile; layout W*H*3 doubles row-major */
+lf_status lf_device_buffer(lf_ctx* ctx, int which, void** dptr, size_t* bytes);
+
+/* ---------------------------------------------------------------- geometric lens --------- */
+/* The north-star path: real ray march through spherical interfaces.  The reference has no
+ * counterpart (its lens is paraxial, pathtracer.cpp:511-689; Camera::generate_ray_for_thin_lens
+ * is a stub, camera_lens.cpp:22-30), so this replaces `generate_ghost_buffer` when selected.
+ *   radius[k]      signed radius of curvature in mm (0 = flat; the stop is flat)
+ *   thickness[k]   axial distance vertex k -> vertex k+1 (last: to the sensor)
+ *   ior[l*n + k]   index of the medium BEHIND interface k at wavelength l
+ *   semi_ap[k]     clear semi-aperture in mm
+ * Interface order: scene side first.  */
+lf_status lf_set_lens(lf_ctx* ctx, int n_surfaces, int stop_index, int n_lambda,
+                      const float* radius, const float* thickness, const float* ior,
+                      const float* semi_aperture, float sensor_width_mm);
+/* RGB weight of each wavelength (n_lambda x 3); default: identity for n_lambda == 3 */
+lf_status lf_set_lambda_rgb(lf_ctx* ctx, const float* weights);
+/* the light: unit direction from the lens towards the sun in lens space (z < 0), radiance,
+ * angular radius of its (smooth) lobe in radians */
+lf_status lf_set_sun(lf_ctx* ctx, const float dir[3], const float radiance[3],
+                     float angular_radius);
+/* ghost pairs to enumerate: pairs = n x {i, j} interface indices (i < j, neither the stop);
+ * i = j = -1 is the primary (no reflection) path.  n = 0 / NULL = all glass pairs. */
+lf_status lf_set_ghost_pairs(lf_ctx* ctx, const int* pairs, int n_pairs, int include_primary);
+/* march `spp` sensor samples per pixel of the band through every selected pair and wavelength and
+ * accumulate into ghost_buffer (replacing its content).  key seeds the counter RNG. */
+lf_status lf_trace_ghosts(lf_ctx* ctx, int spp, uint64_t key);
+lf_status lf_get_counters(lf_ctx* ctx, lf_counters* out);
+lf_status lf_reset_counters(lf_ctx* ctx);
+
+/* ---------------------------------------------------------------- measurement ------------ */
+/* HIP-event timing of the kernels launched since the last reset, on the context's stream.
+ * kernel: "march", "flare_layer", "ghost_raster", "dft", "frame_setup", "tonemap". */
+lf_status lf_timing_enable(lf_ctx* ctx, int on);
+lf_status lf_timing_reset(lf_ctx* ctx);
+lf_status lf_timing_get(lf_ctx* ctx, const char* kernel, int* launches, double* total_ms);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* LENSFLARE_H */

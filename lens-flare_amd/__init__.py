@@ -1,0 +1,301 @@
+"""lens_flare_amd: Python plumbing over the C ABI of liblensflare_hip.so (include/lensflare.h).
+
+The product is the C-ABI library (hand-written gfx950 kernels); the C++ host shim that mirrors the
+reference's PathTracer surface lives in host/.  This module only binds the same entry points with
+ctypes so tests/ and bench.py can drive them; it contains no compute and no fallback: if the
+library (or a GPU) is missing every call fails loudly.
+
+The directory is named `lens-flare_amd` (not importable by name); load it with
+`__graft_entry__.load_package()` which registers it as `lens_flare_amd`.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(HERE, "liblensflare_hip.so")
+DATA = os.path.join(HERE, "data")
+
+STATUS = {0: "LF_OK", 1: "LF_ERR_INVALID", 2: "LF_ERR_NO_DEVICE", 3: "LF_ERR_HIP",
+          4: "LF_ERR_STATE", 5: "LF_ERR_OOM"}
+APERTURE_STARBURST, APERTURE_GHOST = 0, 1
+SAMPLE_BUFFER, GHOST_BUFFER = 0, 1
+
+# every symbol include/lensflare.h declares
+ABI_SYMBOLS = [
+    "lf_create", "lf_destroy", "lf_last_error", "lf_abi_version", "lf_set_stream", "lf_synchronize",
+    "lf_set_frame", "lf_set_band", "lf_set_params", "lf_set_aperture", "lf_get_aperture_stats",
+    "lf_set_paraxial_lens", "lf_set_camera", "lf_find_sun_pos", "lf_set_flares", "lf_get_flares",
+    "lf_set_jitter_mt19937", "lf_set_jitter_counter", "lf_set_scene_term",
+    "lf_generate_ghost_buffer", "lf_render_flare_layer", "lf_read_tile", "lf_read_pixel",
+    "lf_write_to_framebuffer", "lf_device_buffer", "lf_set_lens", "lf_set_lambda_rgb", "lf_set_sun",
+    "lf_set_ghost_pairs", "lf_trace_ghosts", "lf_get_counters", "lf_reset_counters",
+    "lf_timing_enable", "lf_timing_reset", "lf_timing_get",
+]
+
+
+class LensFlareError(RuntimeError):
+    def __init__(self, status, msg):
+        super().__init__(f"{STATUS.get(status, status)}: {msg}")
+        self.status = status
+
+
+class ApertureStats(C.Structure):
+    _fields_ = [("width", C.c_int), ("height", C.c_int), ("min_x", C.c_int), ("min_y", C.c_int),
+                ("max_x", C.c_int), ("max_y", C.c_int), ("total_value", C.c_double)]
+
+
+class Counters(C.Structure):
+    _fields_ = [(n, C.c_uint64) for n in ("rays_launched", "surface_events", "rays_clipped_stop",
+                                          "rays_vignetted", "rays_tir", "rays_reached_scene",
+                                          "rays_hit_light")]
+
+    def as_dict(self):
+        return {n: int(getattr(self, n)) for n, _ in self._fields_}
+
+
+_lib = None
+
+
+def load_library():
+    """dlopen the in-tree library.  Raises if it has not been built (no silent fallback)."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise FileNotFoundError(f"{LIB_PATH} is missing: run __graft_entry__.build() "
+                                    "(make -C lens-flare_amd)")
+        lib = C.CDLL(LIB_PATH)
+        lib.lf_last_error.restype = C.c_char_p
+        lib.lf_last_error.argtypes = [C.c_void_p]
+        _lib = lib
+    return _lib
+
+
+def _fp(a, t):
+    return a.ctypes.data_as(C.POINTER(t))
+
+
+def load_lens_file(path):
+    """Parse a .lens prescription (see data/dgauss11.lens) -> dict of float32 arrays."""
+    if not os.path.isabs(path) and not os.path.exists(path):
+        path = os.path.join(DATA, path)
+    rows, sensor_w = [], 36.0
+    for line in open(path):
+        line = line.split("#")[0].strip()
+        if not line:
+            continue
+        t = line.split()
+        if t[0] == "sensor_width_mm":
+            sensor_w = float(t[1])
+            continue
+        rows.append([float(v) for v in t])
+    rows = np.array(rows, np.float64)
+    n = len(rows)
+    stop = [k for k in range(n) if rows[k, 0] == 0 and rows[k, 3] == 0]
+    ior = rows[:, 2:-1].T.copy()  # n_lambda x n
+    if stop:
+        ior[:, stop[0]] = 1.0
+    return dict(n=n, stop=stop[0] if stop else -1, radius=rows[:, 0].astype(np.float32),
+                thickness=rows[:, 1].astype(np.float32), ior=ior.astype(np.float32),
+                semi_aperture=rows[:, -1].astype(np.float32), sensor_width_mm=float(sensor_w))
+
+
+class LensFlare:
+    """One context = one GPU.  Thin, checked wrappers; names follow include/lensflare.h."""
+
+    def __init__(self, device=0):
+        self.lib = load_library()
+        self.ctx = C.c_void_p()
+        st = self.lib.lf_create(C.byref(self.ctx), int(device))
+        if st != 0:
+            self.ctx = C.c_void_p()
+            raise LensFlareError(st, "lf_create failed (no gfx950 device visible?)")
+        self.W = self.H = 0
+
+    def close(self):
+        if self.ctx:
+            self.lib.lf_destroy(self.ctx)
+            self.ctx = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _ck(self, st):
+        if st != 0:
+            raise LensFlareError(st, self.lib.lf_last_error(self.ctx).decode())
+
+    # ---- frame / params
+    def set_stream(self, stream_ptr):
+        self._ck(self.lib.lf_set_stream(self.ctx, C.c_void_p(stream_ptr)))
+
+    def synchronize(self):
+        self._ck(self.lib.lf_synchronize(self.ctx))
+
+    def set_frame(self, W, H):
+        self._ck(self.lib.lf_set_frame(self.ctx, int(W), int(H)))
+        self.W, self.H = int(W), int(H)
+
+    def set_band(self, y0, y1):
+        self._ck(self.lib.lf_set_band(self.ctx, int(y0), int(y1)))
+
+    def set_params(self, ns_aa=1, flare_radius=25.0, flare_intensity=1.0):
+        self._ck(self.lib.lf_set_params(self.ctx, int(ns_aa), C.c_double(flare_radius),
+                                        C.c_double(flare_intensity)))
+
+    # ---- inputs
+    def set_aperture(self, slot, texels):
+        texels = np.ascontiguousarray(texels, np.float32)
+        h, w = texels.shape
+        self._ck(self.lib.lf_set_aperture(self.ctx, int(slot), _fp(texels, C.c_float), w, h))
+
+    def aperture_stats(self, slot):
+        st = ApertureStats()
+        self._ck(self.lib.lf_get_aperture_stats(self.ctx, int(slot), C.byref(st)))
+        return st
+
+    def set_paraxial_lens(self, n=None, stop=None, thickness=None, curvature=None, ior_rgb=None):
+        if thickness is None:
+            self._ck(self.lib.lf_set_paraxial_lens(self.ctx, 0, 0, None, None, None))
+            return
+        th = np.ascontiguousarray(thickness, np.float32)
+        cu = np.ascontiguousarray(curvature, np.float32)
+        io = np.ascontiguousarray(ior_rgb, np.float32)
+        self._ck(self.lib.lf_set_paraxial_lens(self.ctx, int(n), int(stop), _fp(th, C.c_float),
+                                               _fp(cu, C.c_float), _fp(io, C.c_float)))
+
+    def set_camera(self, c2w, pos, hfov_deg, vfov_deg):
+        c2w = np.ascontiguousarray(c2w, np.float64).reshape(9)
+        pos = np.ascontiguousarray(pos, np.float64).reshape(3)
+        self._ck(self.lib.lf_set_camera(self.ctx, _fp(c2w, C.c_double), _fp(pos, C.c_double),
+                                        C.c_double(hfov_deg), C.c_double(vfov_deg)))
+
+    def find_sun_pos(self, lights):
+        lights = np.ascontiguousarray(lights, np.float64).reshape(-1, 6)
+        self._ck(self.lib.lf_find_sun_pos(self.ctx, _fp(lights, C.c_double), len(lights)))
+
+    def set_flares(self, origins, radiance, axis_ray, angle_to_sun):
+        o = np.ascontiguousarray(origins, np.float64).reshape(-1, 2)
+        r = np.ascontiguousarray(radiance, np.float64).reshape(-1, 3)
+        a = np.ascontiguousarray(axis_ray, np.float64).reshape(2)
+        self._ck(self.lib.lf_set_flares(self.ctx, len(o), _fp(o, C.c_double), _fp(r, C.c_double),
+                                        _fp(a, C.c_double), C.c_float(angle_to_sun)))
+
+    def get_flares(self):
+        n = C.c_int()
+        o = np.zeros((8, 2), np.float64)
+        r = np.zeros((8, 3), np.float64)
+        a = np.zeros(2, np.float64)
+        ang = C.c_float()
+        self._ck(self.lib.lf_get_flares(self.ctx, C.byref(n), _fp(o, C.c_double), _fp(r, C.c_double),
+                                        _fp(a, C.c_double), C.byref(ang)))
+        return dict(n=n.value, origins=o[:n.value], radiance=r[:n.value], axis_ray=a,
+                    angle_to_sun=ang.value)
+
+    def set_jitter_mt19937(self, seed=5489, order=None):
+        if order is None:
+            self._ck(self.lib.lf_set_jitter_mt19937(self.ctx, C.c_uint32(seed), None, C.c_size_t(0)))
+        else:
+            order = np.ascontiguousarray(order, np.uint32)
+            self._ck(self.lib.lf_set_jitter_mt19937(self.ctx, C.c_uint32(seed),
+                                                    _fp(order, C.c_uint32), C.c_size_t(len(order))))
+
+    def set_jitter_counter(self, key):
+        self._ck(self.lib.lf_set_jitter_counter(self.ctx, C.c_uint64(key)))
+
+    def set_scene_term(self, rgb):
+        if rgb is None:
+            self._ck(self.lib.lf_set_scene_term(self.ctx, None))
+        else:
+            rgb = np.ascontiguousarray(rgb, np.float64)
+            assert rgb.size == self.W * self.H * 3
+            self._ck(self.lib.lf_set_scene_term(self.ctx, _fp(rgb, C.c_double)))
+
+    # ---- render
+    def generate_ghost_buffer(self):
+        self._ck(self.lib.lf_generate_ghost_buffer(self.ctx))
+
+    def render_flare_layer(self):
+        self._ck(self.lib.lf_render_flare_layer(self.ctx))
+
+    # ---- read back
+    def read_tile(self, which, x0, y0, x1, y1, pixel_stride=3):
+        out = np.zeros((y1 - y0, x1 - x0, pixel_stride), np.float64)
+        self._ck(self.lib.lf_read_tile(self.ctx, int(which), x0, y0, x1, y1, _fp(out, C.c_double),
+                                       C.c_size_t(pixel_stride)))
+        return out
+
+    def read_buffer(self, which):
+        return self.read_tile(which, 0, 0, self.W, self.H)
+
+    def read_pixel(self, which, x, y):
+        rgb = (C.c_double * 3)()
+        self._ck(self.lib.lf_read_pixel(self.ctx, int(which), int(x), int(y), rgb))
+        return np.array(rgb[:])
+
+    def write_to_framebuffer(self, x0, y0, x1, y1):
+        out = np.zeros((y1 - y0, x1 - x0), np.uint32)
+        self._ck(self.lib.lf_write_to_framebuffer(self.ctx, x0, y0, x1, y1, _fp(out, C.c_uint32),
+                                                  C.c_size_t(x1 - x0)))
+        return out
+
+    def device_buffer(self, which):
+        p = C.c_void_p()
+        n = C.c_size_t()
+        self._ck(self.lib.lf_device_buffer(self.ctx, int(which), C.byref(p), C.byref(n)))
+        return p.value, n.value
+
+    # ---- geometric lens
+    def set_lens(self, lens):
+        r = np.ascontiguousarray(lens["radius"], np.float32)
+        t = np.ascontiguousarray(lens["thickness"], np.float32)
+        i = np.ascontiguousarray(lens["ior"], np.float32)
+        h = np.ascontiguousarray(lens["semi_aperture"], np.float32)
+        self._ck(self.lib.lf_set_lens(self.ctx, int(lens["n"]), int(lens["stop"]), int(i.shape[0]),
+                                      _fp(r, C.c_float), _fp(t, C.c_float), _fp(i, C.c_float),
+                                      _fp(h, C.c_float), C.c_float(lens["sensor_width_mm"])))
+
+    def set_lambda_rgb(self, weights):
+        w = np.ascontiguousarray(weights, np.float32)
+        self._ck(self.lib.lf_set_lambda_rgb(self.ctx, _fp(w, C.c_float)))
+
+    def set_sun(self, direction, radiance, angular_radius):
+        d = np.ascontiguousarray(direction, np.float32)
+        r = np.ascontiguousarray(radiance, np.float32)
+        self._ck(self.lib.lf_set_sun(self.ctx, _fp(d, C.c_float), _fp(r, C.c_float),
+                                     C.c_float(angular_radius)))
+
+    def set_ghost_pairs(self, pairs=None, include_primary=True):
+        if pairs is None or len(pairs) == 0:
+            self._ck(self.lib.lf_set_ghost_pairs(self.ctx, None, 0, int(include_primary)))
+        else:
+            p = np.ascontiguousarray(pairs, np.int32).reshape(-1, 2)
+            self._ck(self.lib.lf_set_ghost_pairs(self.ctx, _fp(p, C.c_int), len(p),
+                                                 int(include_primary)))
+
+    def trace_ghosts(self, spp, key=0x1e45f1a4e):
+        self._ck(self.lib.lf_trace_ghosts(self.ctx, int(spp), C.c_uint64(key)))
+
+    def counters(self):
+        c = Counters()
+        self._ck(self.lib.lf_get_counters(self.ctx, C.byref(c)))
+        return c.as_dict()
+
+    def reset_counters(self):
+        self._ck(self.lib.lf_reset_counters(self.ctx))
+
+    # ---- measurement
+    def timing_enable(self, on=True):
+        self._ck(self.lib.lf_timing_enable(self.ctx, int(on)))
+
+    def timing_reset(self):
+        self._ck(self.lib.lf_timing_reset(self.ctx))
+
+    def timing_get(self, kernel):
+        n = C.c_int()
+        ms = C.c_double()
+        self._ck(self.lib.lf_timing_get(self.ctx, kernel.encode(), C.byref(n), C.byref(ms)))
+        return n.value, ms.value

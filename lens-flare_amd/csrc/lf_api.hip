@@ -1,0 +1,631 @@
+// lf_api.hip -- the extern "C" entry points of liblensflare_hip.so (include/lensflare.h).
+// Host-side orchestration only: validation, device buffers, stream/event handling.  Every
+// number that reaches a sensor pixel is computed by the gfx950 kernels in lf_flare_kernels.hip /
+// lf_march.hip; there is no CPU fallback -- without a device lf_create fails.
+#include <algorithm>
+#include <cmath>
+#include <cstring>
+
+#include "lf_internal.h"
+
+lf_status lf_fail(const lf_ctx* ctx, lf_status st, const std::string& msg) {
+  if (ctx) ctx->err = msg;
+  return st;
+}
+
+hipEvent_t lf_timing_begin(lf_ctx* ctx, int kernel) {
+  if (!ctx->timing) return nullptr;
+  hipEvent_t e = nullptr;
+  if (hipEventCreate(&e) != hipSuccess) return nullptr;
+  (void)hipEventRecord(e, ctx->stream);
+  (void)kernel;
+  return e;
+}
+
+void lf_timing_end(lf_ctx* ctx, int kernel, hipEvent_t start) {
+  if (!ctx->timing || !start) return;
+  hipEvent_t e = nullptr;
+  if (hipEventCreate(&e) != hipSuccess) { (void)hipEventDestroy(start); return; }
+  (void)hipEventRecord(e, ctx->stream);
+  ctx->timed.push_back(LfTimedLaunch{kernel, start, e});
+}
+
+namespace {
+
+const char* kKernelNames[LFK_COUNT] = {"march", "flare_layer", "ghost_raster", "dft",
+                                       "frame_setup", "tonemap"};
+
+// the reference's hard-coded prescription (pathtracer.cpp:541-556); literals narrowed to float
+// where the reference narrows them
+void default_paraxial_lens(LfParaxialLens& L) {
+  static const double th[9] = {7.700, 1.850, 3.520, 1.850, 4.180, 3.000, 1.850, 7.270, 83.91};
+  static const double rgb[3][9] = {{1.652, 1.5991, 1, 1.6396, 1, 1, 1.5776, 1.68990, 1},
+                                   {1.652, 1.6113, 1, 1.65, 1, 1, 1.5885, 1.6999, 1},
+                                   {1.652, 1.6164, 1, 1.6542, 1, 1, 1.5930, 1.7040, 1}};
+  static const double radii[9] = {30.810, -89.350, 580.380, -80.630, 28.340, 0, 0, 32.190, -52.990};
+  std::memset(&L, 0, sizeof(L));
+  L.n = 9;
+  L.stop = 5;
+  for (int k = 0; k < 9; k++) {
+    L.thickness[k] = (float)th[k];
+    for (int c = 0; c < 3; c++) L.ior[c][k] = (float)rgb[c][k];
+    L.curvature[k] = radii[k] == 0 ? 0.0f : (float)(1 / radii[k]);
+  }
+  L.clip = 11.6;
+  L.recast_pos = 11.6f;
+  L.recast_neg = -11.5f;
+  L.marginal = 14.5f;
+}
+
+template <typename T>
+lf_status dev_alloc(lf_ctx* ctx, T** p, size_t count) {
+  if (*p) { (void)hipFree(*p); *p = nullptr; }
+  if (count == 0) return LF_OK;
+  hipError_t e = hipMalloc(reinterpret_cast<void**>(p), count * sizeof(T));
+  if (e != hipSuccess) return lf_fail(ctx, LF_ERR_OOM, std::string("hipMalloc: ") + hipGetErrorString(e));
+  return LF_OK;
+}
+
+// std::mt19937 (util/random_util.h:10-14), written from the algorithm's definition
+struct Mt19937 {
+  uint32_t s[624];
+  int idx;
+  explicit Mt19937(uint32_t seed) {
+    s[0] = seed;
+    for (int i = 1; i < 624; i++) s[i] = 1812433253u * (s[i - 1] ^ (s[i - 1] >> 30)) + (uint32_t)i;
+    idx = 624;
+  }
+  uint32_t next() {
+    if (idx >= 624) {
+      for (int k = 0; k < 624; k++) {
+        uint32_t y = (s[k] & 0x80000000u) | (s[(k + 1) % 624] & 0x7fffffffu);
+        s[k] = s[(k + 397) % 624] ^ (y >> 1) ^ ((y & 1u) ? 0x9908b0dfu : 0u);
+      }
+      idx = 0;
+    }
+    uint32_t y = s[idx++];
+    y ^= (y >> 11);
+    y ^= (y << 7) & 0x9d2c5680u;
+    y ^= (y << 15) & 0xefc60000u;
+    y ^= (y >> 18);
+    return y;
+  }
+};
+
+void free_frame_buffers(lf_ctx* ctx) {
+  if (ctx->sample) (void)hipFree(ctx->sample);
+  if (ctx->ghost) (void)hipFree(ctx->ghost);
+  if (ctx->scene) (void)hipFree(ctx->scene);
+  if (ctx->rgba) (void)hipFree(ctx->rgba);
+  if (ctx->jitter_raw) (void)hipFree(ctx->jitter_raw);
+  ctx->sample = ctx->ghost = ctx->scene = nullptr;
+  ctx->rgba = nullptr;
+  ctx->jitter_raw = nullptr;
+  ctx->jitter_table_valid = ctx->ghost_valid = ctx->sample_valid = ctx->rgba_valid = false;
+}
+
+lf_status upload_paraxial(lf_ctx* ctx) {
+  LF_HIP(ctx, hipMemcpyAsync(ctx->pl_dev, &ctx->pl, sizeof(LfParaxialLens), hipMemcpyHostToDevice,
+                             ctx->stream));
+  LF_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  return LF_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int lf_abi_version(void) { return LF_ABI_VERSION; }
+
+const char* lf_last_error(const lf_ctx* ctx) { return ctx ? ctx->err.c_str() : "null context"; }
+
+lf_status lf_create(lf_ctx** out, int device) {
+  if (!out) return LF_ERR_INVALID;
+  *out = nullptr;
+  int n = 0;
+  if (hipGetDeviceCount(&n) != hipSuccess || n <= 0) return LF_ERR_NO_DEVICE;
+  if (device < 0 || device >= n) return LF_ERR_NO_DEVICE;
+  if (hipSetDevice(device) != hipSuccess) return LF_ERR_NO_DEVICE;
+  lf_ctx* ctx = new lf_ctx();
+  ctx->device = device;
+  if (hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking) != hipSuccess) {
+    delete ctx;
+    return LF_ERR_HIP;
+  }
+  ctx->own_stream = true;
+  default_paraxial_lens(ctx->pl);
+  bool ok = hipMalloc((void**)&ctx->flares, sizeof(LfFlares)) == hipSuccess &&
+            hipMalloc((void**)&ctx->ghosts, sizeof(LfGhostList)) == hipSuccess &&
+            hipMalloc((void**)&ctx->pl_dev, sizeof(LfParaxialLens)) == hipSuccess &&
+            hipMalloc((void**)&ctx->lens_dev, sizeof(LfLensDev)) == hipSuccess &&
+            hipMalloc((void**)&ctx->pairs_dev, sizeof(LfPairsDev)) == hipSuccess &&
+            hipMalloc((void**)&ctx->counters_dev, 8 * sizeof(unsigned long long)) == hipSuccess;
+  for (int s = 0; s < 2 && ok; s++)
+    ok = hipMalloc((void**)&ctx->ap[s].stats, sizeof(lf_aperture_stats)) == hipSuccess;
+  if (!ok) { lf_destroy(ctx); return LF_ERR_OOM; }
+  (void)hipMemset(ctx->flares, 0, sizeof(LfFlares));
+  (void)hipMemset(ctx->ghosts, 0, sizeof(LfGhostList));
+  (void)hipMemset(ctx->counters_dev, 0, 8 * sizeof(unsigned long long));
+  if (upload_paraxial(ctx) != LF_OK) { lf_destroy(ctx); return LF_ERR_HIP; }
+  *out = ctx;
+  return LF_OK;
+}
+
+lf_status lf_destroy(lf_ctx* ctx) {
+  if (!ctx) return LF_ERR_INVALID;
+  (void)hipSetDevice(ctx->device);
+  (void)hipDeviceSynchronize();
+  free_frame_buffers(ctx);
+  for (auto& t : ctx->timed) { (void)hipEventDestroy(t.start); (void)hipEventDestroy(t.stop); }
+  for (int s = 0; s < 2; s++) {
+    if (ctx->ap[s].texels) (void)hipFree(ctx->ap[s].texels);
+    if (ctx->ap[s].stats) (void)hipFree(ctx->ap[s].stats);
+  }
+  void* ptrs[] = {ctx->spectrum, ctx->twiddle, ctx->dft_rows, ctx->flares, ctx->ghosts, ctx->pl_dev,
+                  ctx->lens_dev, ctx->pairs_dev, ctx->counters_dev, ctx->accum};
+  for (void* p : ptrs) if (p) (void)hipFree(p);
+  if (ctx->own_stream && ctx->stream) (void)hipStreamDestroy(ctx->stream);
+  delete ctx;
+  return LF_OK;
+}
+
+lf_status lf_set_stream(lf_ctx* ctx, void* hip_stream) {
+  if (!ctx) return LF_ERR_INVALID;
+  LF_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  if (ctx->own_stream && ctx->stream) (void)hipStreamDestroy(ctx->stream);
+  ctx->stream = reinterpret_cast<hipStream_t>(hip_stream);
+  ctx->own_stream = false;
+  return LF_OK;
+}
+
+lf_status lf_synchronize(lf_ctx* ctx) {
+  if (!ctx) return LF_ERR_INVALID;
+  LF_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  return LF_OK;
+}
+
+lf_status lf_set_frame(lf_ctx* ctx, int width, int height) {
+  if (!ctx) return LF_ERR_INVALID;
+  if (width <= 0 || height <= 0 || width > (1 << 15) || height > (1 << 15))
+    return lf_fail(ctx, LF_ERR_INVALID, "frame size out of range");
+  LF_HIP(ctx, hipSetDevice(ctx->device));
+  LF_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  free_frame_buffers(ctx);
+  ctx->W = width; ctx->H = height; ctx->y0 = 0; ctx->y1 = height;
+  size_t n = (size_t)width * height;
+  lf_status st;
+  if ((st = dev_alloc(ctx, &ctx->sample, 3 * n)) != LF_OK) return st;
+  if ((st = dev_alloc(ctx, &ctx->ghost, 3 * n)) != LF_OK) return st;
+  if ((st = dev_alloc(ctx, &ctx->rgba, n)) != LF_OK) return st;
+  LF_HIP(ctx, hipMemsetAsync(ctx->sample, 0, 3 * n * sizeof(double), ctx->stream));
+  LF_HIP(ctx, hipMemsetAsync(ctx->ghost, 0, 3 * n * sizeof(double), ctx->stream));
+  LF_HIP(ctx, hipMemsetAsync(ctx->rgba, 0, n * sizeof(uint32_t), ctx->stream));
+  return LF_OK;
+}
+
+lf_status lf_set_band(lf_ctx* ctx, int y0, int y1) {
+  if (!ctx) return LF_ERR_INVALID;
+  if (ctx->W == 0) return lf_fail(ctx, LF_ERR_STATE, "lf_set_band before lf_set_frame");
+  if (y0 < 0 || y1 > ctx->H || y0 > y1) return lf_fail(ctx, LF_ERR_INVALID, "band out of range");
+  ctx->y0 = y0; ctx->y1 = y1;
+  return LF_OK;
+}
+
+lf_status lf_set_params(lf_ctx* ctx, int ns_aa, double flare_radius, double flare_intensity) {
+  if (!ctx || ns_aa < 0) return LF_ERR_INVALID;
+  ctx->ns_aa = ns_aa;
+  ctx->flare_radius = flare_radius;
+  ctx->flare_intensity = flare_intensity;
+  return LF_OK;
+}
+
+lf_status lf_set_aperture(lf_ctx* ctx, lf_aperture_slot slot, const float* texels, int width,
+                          int height) {
+  if (!ctx || !texels || (slot != LF_APERTURE_STARBURST && slot != LF_APERTURE_GHOST))
+    return LF_ERR_INVALID;
+  if (width <= 0 || height <= 0 || width > 4096 || height > 4096)
+    return lf_fail(ctx, LF_ERR_INVALID, "aperture size out of range (1..4096)");
+  LF_HIP(ctx, hipSetDevice(ctx->device));
+  LfApertureDev& a = ctx->ap[slot];
+  a.valid = false;
+  lf_status st;
+  if ((st = dev_alloc(ctx, &a.texels, (size_t)width * height)) != LF_OK) return st;
+  a.w = width; a.h = height;
+  LF_HIP(ctx, hipMemcpyAsync(a.texels, texels, sizeof(float) * (size_t)width * height,
+                             hipMemcpyHostToDevice, ctx->stream));
+  if ((st = lfk_aperture_stats(ctx, slot)) != LF_OK) return st;
+  a.valid = true;
+  if (slot == LF_APERTURE_STARBURST) {
+    ctx->spectrum_valid = false;
+    size_t rows = a.host_stats.max_y >= a.host_stats.min_y
+                      ? (size_t)(a.host_stats.max_y - a.host_stats.min_y + 1) : 1;
+    if ((st = dev_alloc(ctx, &ctx->spectrum, (size_t)width * width)) != LF_OK) return st;
+    if ((st = dev_alloc(ctx, &ctx->twiddle, (size_t)width)) != LF_OK) return st;
+    if ((st = dev_alloc(ctx, &ctx->dft_rows, rows * width)) != LF_OK) return st;
+    if ((st = lfk_build_spectrum(ctx)) != LF_OK) return st;
+  }
+  return LF_OK;
+}
+
+lf_status lf_get_aperture_stats(lf_ctx* ctx, lf_aperture_slot slot, lf_aperture_stats* out) {
+  if (!ctx || !out || (slot != 0 && slot != 1)) return LF_ERR_INVALID;
+  if (!ctx->ap[slot].valid) return lf_fail(ctx, LF_ERR_STATE, "aperture not set");
+  *out = ctx->ap[slot].host_stats;
+  return LF_OK;
+}
+
+lf_status lf_set_paraxial_lens(lf_ctx* ctx, int n, int stop_index, const float* thickness,
+                               const float* curvature, const float* ior_rgb) {
+  if (!ctx) return LF_ERR_INVALID;
+  if (!thickness || !curvature || !ior_rgb) {
+    default_paraxial_lens(ctx->pl);
+  } else {
+    if (n < 2 || n > LF_MAX_SURFACES || stop_index < 0 || stop_index >= n)
+      return lf_fail(ctx, LF_ERR_INVALID, "paraxial lens: bad n / stop index");
+    LfParaxialLens L;
+    default_paraxial_lens(L);
+    L.n = n; L.stop = stop_index;
+    for (int k = 0; k < n; k++) {
+      L.thickness[k] = thickness[k];
+      L.curvature[k] = curvature[k];
+      for (int c = 0; c < 3; c++) L.ior[c][k] = ior_rgb[c * n + k];
+    }
+    ctx->pl = L;
+  }
+  ctx->ghost_valid = false;
+  return upload_paraxial(ctx);
+}
+
+lf_status lf_set_camera(lf_ctx* ctx, const double c2w[9], const double pos[3], double hfov_deg,
+                        double vfov_deg) {
+  if (!ctx || !c2w || !pos) return LF_ERR_INVALID;
+  std::memcpy(ctx->cam.c2w, c2w, 9 * sizeof(double));
+  std::memcpy(ctx->cam.pos, pos, 3 * sizeof(double));
+  ctx->cam.hfov_deg = hfov_deg;
+  ctx->cam.vfov_deg = vfov_deg;
+  ctx->cam_valid = true;
+  return LF_OK;
+}
+
+lf_status lf_find_sun_pos(lf_ctx* ctx, const double* lights, int n_lights) {
+  if (!ctx || n_lights < 0 || (n_lights > 0 && !lights)) return LF_ERR_INVALID;
+  if (!ctx->cam_valid) return lf_fail(ctx, LF_ERR_STATE, "lf_find_sun_pos before lf_set_camera");
+  if (ctx->W == 0) return lf_fail(ctx, LF_ERR_STATE, "lf_find_sun_pos before lf_set_frame");
+  LF_HIP(ctx, hipSetDevice(ctx->device));
+  double* dl = nullptr;
+  if (n_lights > 0) {
+    LF_HIP(ctx, hipMalloc((void**)&dl, sizeof(double) * 6 * n_lights));
+    LF_HIP(ctx, hipMemcpyAsync(dl, lights, sizeof(double) * 6 * n_lights, hipMemcpyHostToDevice,
+                               ctx->stream));
+  }
+  // flare_origins.clear(); flare_radiance.clear() (raytraced_renderer.cpp:306-307); axis_ray and
+  // angle_to_sun keep their previous values, exactly like the reference's members
+  lf_status st = lfk_frame_setup(ctx, dl, n_lights, true);
+  hipError_t e = hipStreamSynchronize(ctx->stream);
+  if (dl) (void)hipFree(dl);
+  if (st != LF_OK) return st;
+  LF_HIP(ctx, e);
+  ctx->flares_valid = true;
+  ctx->ghost_valid = false;
+  return LF_OK;
+}
+
+lf_status lf_set_flares(lf_ctx* ctx, int n, const double* origins, const double* radiance,
+                        const double axis_ray[2], float angle_to_sun) {
+  if (!ctx || n < 0 || n > LF_MAX_FLARES || (n > 0 && (!origins || !radiance)) || !axis_ray)
+    return LF_ERR_INVALID;
+  LfFlares f;
+  std::memset(&f, 0, sizeof(f));
+  f.n_flares = n;
+  f.angle_to_sun = angle_to_sun;
+  for (int k = 0; k < n; k++) {
+    f.origin[k][0] = origins[2 * k]; f.origin[k][1] = origins[2 * k + 1];
+    for (int c = 0; c < 3; c++) f.radiance[k][c] = radiance[3 * k + c];
+  }
+  f.axis_ray[0] = axis_ray[0]; f.axis_ray[1] = axis_ray[1];
+  LF_HIP(ctx, hipMemcpyAsync(ctx->flares, &f, sizeof(f), hipMemcpyHostToDevice, ctx->stream));
+  LF_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  ctx->flares_valid = true;
+  ctx->ghost_valid = false;
+  return LF_OK;
+}
+
+lf_status lf_get_flares(lf_ctx* ctx, int* n, double* origins, double* radiance, double axis_ray[2],
+                        float* angle_to_sun) {
+  if (!ctx || !n) return LF_ERR_INVALID;
+  LfFlares f;
+  LF_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  LF_HIP(ctx, hipMemcpy(&f, ctx->flares, sizeof(f), hipMemcpyDeviceToHost));
+  *n = f.n_flares;
+  for (int k = 0; k < f.n_flares; k++) {
+    if (origins) { origins[2 * k] = f.origin[k][0]; origins[2 * k + 1] = f.origin[k][1]; }
+    if (radiance) for (int c = 0; c < 3; c++) radiance[3 * k + c] = f.radiance[k][c];
+  }
+  if (axis_ray) { axis_ray[0] = f.axis_ray[0]; axis_ray[1] = f.axis_ray[1]; }
+  if (angle_to_sun) *angle_to_sun = f.angle_to_sun;
+  return LF_OK;
+}
+
+lf_status lf_set_jitter_mt19937(lf_ctx* ctx, uint32_t seed, const uint32_t* order, size_t n_order) {
+  if (!ctx) return LF_ERR_INVALID;
+  if (ctx->W == 0) return lf_fail(ctx, LF_ERR_STATE, "lf_set_jitter_mt19937 before lf_set_frame");
+  LF_HIP(ctx, hipSetDevice(ctx->device));
+  const size_t n = (size_t)ctx->W * ctx->H;
+  std::vector<uint32_t> own;
+  if (!order) {  // the reference's tile queue: 32x32 tiles, y-major; pixels y-major inside a tile
+    own.reserve(n);
+    const int T = 32;
+    for (int ty = 0; ty < ctx->H; ty += T)
+      for (int tx = 0; tx < ctx->W; tx += T)
+        for (int y = ty; y < std::min(ty + T, ctx->H); y++)
+          for (int x = tx; x < std::min(tx + T, ctx->W); x++)
+            own.push_back((uint32_t)(x + y * ctx->W));
+    order = own.data();
+    n_order = own.size();
+  }
+  // Each visited pixel consumes 2*ns_aa draws (pixel jitter, pathtracer.cpp:844) and then the 32
+  // draws of calculate_irradiance_falloff (:1050).  Only the latter reach the device, stored
+  // pixel-major; a pixel visited twice keeps its last visit, like the reference's buffer.
+  std::vector<uint32_t> table(n * 32, 0u);
+  Mt19937 mt(seed);
+  for (size_t v = 0; v < n_order; v++) {
+    if (order[v] >= n) return lf_fail(ctx, LF_ERR_INVALID, "visit order: pixel index out of range");
+    for (int k = 0; k < 2 * ctx->ns_aa; k++) (void)mt.next();
+    uint32_t* dst = table.data() + (size_t)order[v] * 32;
+    for (int k = 0; k < 32; k++) dst[k] = mt.next();
+  }
+  lf_status st;
+  if ((st = dev_alloc(ctx, &ctx->jitter_raw, n * 32)) != LF_OK) return st;
+  LF_HIP(ctx, hipMemcpy(ctx->jitter_raw, table.data(), table.size() * sizeof(uint32_t),
+                        hipMemcpyHostToDevice));
+  ctx->jitter_mode = 0;
+  ctx->jitter_table_valid = true;
+  return LF_OK;
+}
+
+lf_status lf_set_jitter_counter(lf_ctx* ctx, uint64_t key) {
+  if (!ctx) return LF_ERR_INVALID;
+  ctx->jitter_mode = 1;
+  ctx->jitter_key = key;
+  return LF_OK;
+}
+
+lf_status lf_set_scene_term(lf_ctx* ctx, const double* rgb) {
+  if (!ctx) return LF_ERR_INVALID;
+  if (ctx->W == 0) return lf_fail(ctx, LF_ERR_STATE, "lf_set_scene_term before lf_set_frame");
+  LF_HIP(ctx, hipSetDevice(ctx->device));
+  size_t n = (size_t)ctx->W * ctx->H * 3;
+  if (!rgb) {
+    if (ctx->scene) { LF_HIP(ctx, hipStreamSynchronize(ctx->stream)); (void)hipFree(ctx->scene); }
+    ctx->scene = nullptr;
+    return LF_OK;
+  }
+  lf_status st;
+  if (!ctx->scene && (st = dev_alloc(ctx, &ctx->scene, n)) != LF_OK) return st;
+  LF_HIP(ctx, hipMemcpy(ctx->scene, rgb, n * sizeof(double), hipMemcpyHostToDevice));
+  return LF_OK;
+}
+
+lf_status lf_generate_ghost_buffer(lf_ctx* ctx) {
+  if (!ctx) return LF_ERR_INVALID;
+  if (ctx->W == 0) return lf_fail(ctx, LF_ERR_STATE, "lf_generate_ghost_buffer before lf_set_frame");
+  if (!ctx->flares_valid) return lf_fail(ctx, LF_ERR_STATE, "no flare state: call lf_find_sun_pos or lf_set_flares");
+  if (!ctx->ap[LF_APERTURE_GHOST].valid) return lf_fail(ctx, LF_ERR_STATE, "ghost aperture not set");
+  LF_HIP(ctx, hipSetDevice(ctx->device));
+  lf_status st;
+  if ((st = lfk_frame_setup(ctx, nullptr, 0, false)) != LF_OK) return st;
+  if ((st = lfk_ghost_raster(ctx)) != LF_OK) return st;
+  ctx->ghost_valid = true;
+  return LF_OK;
+}
+
+lf_status lf_render_flare_layer(lf_ctx* ctx) {
+  if (!ctx) return LF_ERR_INVALID;
+  if (ctx->W == 0) return lf_fail(ctx, LF_ERR_STATE, "lf_render_flare_layer before lf_set_frame");
+  if (!ctx->flares_valid) return lf_fail(ctx, LF_ERR_STATE, "no flare state: call lf_find_sun_pos or lf_set_flares");
+  if (!ctx->ap[LF_APERTURE_STARBURST].valid || !ctx->spectrum_valid)
+    return lf_fail(ctx, LF_ERR_STATE, "starburst aperture not set");
+  if (ctx->jitter_mode == 0 && !ctx->jitter_table_valid)
+    return lf_fail(ctx, LF_ERR_STATE, "MT19937 jitter selected but no table (frame was resized?)");
+  LF_HIP(ctx, hipSetDevice(ctx->device));
+  lf_status st;
+  if ((st = lfk_flare_layer(ctx)) != LF_OK) return st;
+  ctx->sample_valid = true;
+  ctx->rgba_valid = false;
+  return LF_OK;
+}
+
+lf_status lf_read_tile(lf_ctx* ctx, int which, int x0, int y0, int x1, int y1, double* dst,
+                       size_t pixel_stride) {
+  if (!ctx || !dst || (which != 0 && which != 1) || pixel_stride < 3) return LF_ERR_INVALID;
+  if (ctx->W == 0) return lf_fail(ctx, LF_ERR_STATE, "lf_read_tile before lf_set_frame");
+  if (x0 < 0 || y0 < 0 || x1 > ctx->W || y1 > ctx->H || x0 > x1 || y0 > y1)
+    return lf_fail(ctx, LF_ERR_INVALID, "tile out of range");
+  if (x0 == x1 || y0 == y1) return LF_OK;
+  const double* src = which == 0 ? ctx->sample : ctx->ghost;
+  LF_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  const size_t tw = (size_t)(x1 - x0);
+  if (pixel_stride == 3) {
+    LF_HIP(ctx, hipMemcpy2D(dst, tw * 3 * sizeof(double), src + 3 * ((size_t)y0 * ctx->W + x0),
+                            (size_t)ctx->W * 3 * sizeof(double), tw * 3 * sizeof(double),
+                            (size_t)(y1 - y0), hipMemcpyDeviceToHost));
+  } else {
+    std::vector<double> tmp(tw * 3 * (size_t)(y1 - y0));
+    LF_HIP(ctx, hipMemcpy2D(tmp.data(), tw * 3 * sizeof(double),
+                            src + 3 * ((size_t)y0 * ctx->W + x0), (size_t)ctx->W * 3 * sizeof(double),
+                            tw * 3 * sizeof(double), (size_t)(y1 - y0), hipMemcpyDeviceToHost));
+    for (size_t i = 0; i < tw * (size_t)(y1 - y0); i++)
+      for (int c = 0; c < 3; c++) dst[i * pixel_stride + c] = tmp[3 * i + c];
+  }
+  return LF_OK;
+}
+
+lf_status lf_read_pixel(lf_ctx* ctx, int which, int x, int y, double rgb[3]) {
+  return lf_read_tile(ctx, which, x, y, x + 1, y + 1, rgb, 3);
+}
+
+lf_status lf_write_to_framebuffer(lf_ctx* ctx, int x0, int y0, int x1, int y1, uint32_t* dst,
+                                  size_t row_stride) {
+  if (!ctx || !dst) return LF_ERR_INVALID;
+  if (ctx->W == 0) return lf_fail(ctx, LF_ERR_STATE, "lf_write_to_framebuffer before lf_set_frame");
+  if (x0 < 0 || y0 < 0 || x1 > ctx->W || y1 > ctx->H || x0 > x1 || y0 > y1)
+    return lf_fail(ctx, LF_ERR_INVALID, "tile out of range");
+  if (row_stride < (size_t)(x1 - x0)) return lf_fail(ctx, LF_ERR_INVALID, "row_stride < tile width");
+  if (x0 == x1 || y0 == y1) return LF_OK;
+  LF_HIP(ctx, hipSetDevice(ctx->device));
+  if (!ctx->rgba_valid) {
+    lf_status st = lfk_tonemap(ctx);
+    if (st != LF_OK) return st;
+    ctx->rgba_valid = true;
+  }
+  LF_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  LF_HIP(ctx, hipMemcpy2D(dst, row_stride * sizeof(uint32_t), ctx->rgba + (size_t)y0 * ctx->W + x0,
+                          (size_t)ctx->W * sizeof(uint32_t), (size_t)(x1 - x0) * sizeof(uint32_t),
+                          (size_t)(y1 - y0), hipMemcpyDeviceToHost));
+  return LF_OK;
+}
+
+lf_status lf_device_buffer(lf_ctx* ctx, int which, void** dptr, size_t* bytes) {
+  if (!ctx || !dptr || (which != 0 && which != 1)) return LF_ERR_INVALID;
+  if (ctx->W == 0) return lf_fail(ctx, LF_ERR_STATE, "lf_device_buffer before lf_set_frame");
+  *dptr = which == 0 ? ctx->sample : ctx->ghost;
+  if (bytes) *bytes = (size_t)ctx->W * ctx->H * 3 * sizeof(double);
+  return LF_OK;
+}
+
+// ---------------------------------------------------------------- geometric lens -------------
+lf_status lf_set_lens(lf_ctx* ctx, int n_surfaces, int stop_index, int n_lambda,
+                      const float* radius, const float* thickness, const float* ior,
+                      const float* semi_aperture, float sensor_width_mm) {
+  if (!ctx || !radius || !thickness || !ior || !semi_aperture) return LF_ERR_INVALID;
+  if (n_surfaces < 1 || n_surfaces > LF_MAX_SURFACES || n_lambda < 1 || n_lambda > LF_MAX_LAMBDA ||
+      stop_index < -1 || stop_index >= n_surfaces || !(sensor_width_mm > 0))
+    return lf_fail(ctx, LF_ERR_INVALID, "lens: bad sizes");
+  if (ctx->W == 0) return lf_fail(ctx, LF_ERR_STATE, "lf_set_lens before lf_set_frame");
+  for (int k = 0; k < n_surfaces; k++) {
+    if (!(semi_aperture[k] > 0)) return lf_fail(ctx, LF_ERR_INVALID, "lens: semi-aperture <= 0");
+    if (k == stop_index && radius[k] != 0) return lf_fail(ctx, LF_ERR_INVALID, "lens: the stop must be flat");
+    for (int l = 0; l < n_lambda; l++)
+      if (!(ior[l * n_surfaces + k] >= 1.0f) && k != stop_index)
+        return lf_fail(ctx, LF_ERR_INVALID, "lens: index of refraction < 1");
+  }
+  lf_derive_lens(ctx, n_surfaces, stop_index, n_lambda, radius, thickness, ior, semi_aperture,
+                 sensor_width_mm);
+  ctx->lens_valid = true;
+  // default pair set: every pair of glass surfaces + the primary path
+  return lf_set_ghost_pairs(ctx, nullptr, 0, 1);
+}
+
+lf_status lf_set_lambda_rgb(lf_ctx* ctx, const float* weights) {
+  if (!ctx || !weights) return LF_ERR_INVALID;
+  if (!ctx->lens_valid) return lf_fail(ctx, LF_ERR_STATE, "lf_set_lambda_rgb before lf_set_lens");
+  for (int l = 0; l < ctx->lens.n_lambda; l++)
+    for (int c = 0; c < 3; c++) ctx->lens.lambda_rgb[l][c] = weights[3 * l + c];
+  return LF_OK;
+}
+
+lf_status lf_set_sun(lf_ctx* ctx, const float dir[3], const float radiance[3],
+                     float angular_radius) {
+  if (!ctx || !dir || !radiance) return LF_ERR_INVALID;
+  double n = std::sqrt((double)dir[0] * dir[0] + (double)dir[1] * dir[1] + (double)dir[2] * dir[2]);
+  if (!(n > 0) || !(dir[2] < 0) || !(angular_radius > 0) || angular_radius > 1.5f)
+    return lf_fail(ctx, LF_ERR_INVALID, "sun: direction must have z < 0, 0 < angular radius <= 1.5");
+  for (int c = 0; c < 3; c++) {
+    ctx->lens.sun_dir[c] = (float)(dir[c] / n);
+    ctx->lens.sun_radiance[c] = radiance[c];
+  }
+  ctx->lens.sun_inv_one_minus_cos = (float)(1.0 / (1.0 - std::cos((double)angular_radius)));
+  ctx->sun_valid = true;
+  return LF_OK;
+}
+
+lf_status lf_set_ghost_pairs(lf_ctx* ctx, const int* pairs, int n_pairs, int include_primary) {
+  if (!ctx || n_pairs < 0) return LF_ERR_INVALID;
+  if (!ctx->lens_valid) return lf_fail(ctx, LF_ERR_STATE, "lf_set_ghost_pairs before lf_set_lens");
+  LfPairsDev P;
+  std::memset(&P, 0, sizeof(P));
+  const int ns = ctx->lens.n_surf, stop = ctx->lens.stop;
+  if (include_primary) { P.ij[P.n][0] = -1; P.ij[P.n][1] = -1; P.n++; }
+  if (!pairs || n_pairs == 0) {
+    for (int i = 0; i < ns; i++)
+      for (int j = i + 1; j < ns; j++) {
+        if (i == stop || j == stop) continue;
+        if (P.n >= LF_MAX_PAIRS + 1) return lf_fail(ctx, LF_ERR_INVALID, "too many ghost pairs");
+        P.ij[P.n][0] = i; P.ij[P.n][1] = j; P.n++;
+      }
+  } else {
+    if (n_pairs > LF_MAX_PAIRS) return lf_fail(ctx, LF_ERR_INVALID, "too many ghost pairs");
+    for (int q = 0; q < n_pairs; q++) {
+      int i = pairs[2 * q], j = pairs[2 * q + 1];
+      if (i < 0 || j <= i || j >= ns || i == stop || j == stop)
+        return lf_fail(ctx, LF_ERR_INVALID, "ghost pair must satisfy 0 <= i < j < n, neither the stop");
+      P.ij[P.n][0] = i; P.ij[P.n][1] = j; P.n++;
+    }
+  }
+  if (P.n == 0) return lf_fail(ctx, LF_ERR_INVALID, "empty pair set");
+  ctx->pairs = P;
+  return LF_OK;
+}
+
+lf_status lf_trace_ghosts(lf_ctx* ctx, int spp, uint64_t key) {
+  if (!ctx || spp <= 0) return LF_ERR_INVALID;
+  if (!ctx->lens_valid || !ctx->sun_valid)
+    return lf_fail(ctx, LF_ERR_STATE, "lf_trace_ghosts needs lf_set_lens and lf_set_sun");
+  if (!ctx->ap[LF_APERTURE_GHOST].valid) return lf_fail(ctx, LF_ERR_STATE, "ghost aperture (stop mask) not set");
+  LF_HIP(ctx, hipSetDevice(ctx->device));
+  lf_status st = lfk_march(ctx, spp, key);
+  if (st != LF_OK) return st;
+  ctx->ghost_valid = true;
+  return LF_OK;
+}
+
+lf_status lf_get_counters(lf_ctx* ctx, lf_counters* out) {
+  if (!ctx || !out) return LF_ERR_INVALID;
+  unsigned long long c[8];
+  LF_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  LF_HIP(ctx, hipMemcpy(c, ctx->counters_dev, sizeof(c), hipMemcpyDeviceToHost));
+  out->rays_launched = c[0]; out->surface_events = c[1]; out->rays_clipped_stop = c[2];
+  out->rays_vignetted = c[3]; out->rays_tir = c[4]; out->rays_reached_scene = c[5];
+  out->rays_hit_light = c[6];
+  return LF_OK;
+}
+
+lf_status lf_reset_counters(lf_ctx* ctx) {
+  if (!ctx) return LF_ERR_INVALID;
+  LF_HIP(ctx, hipMemsetAsync(ctx->counters_dev, 0, 8 * sizeof(unsigned long long), ctx->stream));
+  return LF_OK;
+}
+
+// ---------------------------------------------------------------- measurement ----------------
+lf_status lf_timing_enable(lf_ctx* ctx, int on) {
+  if (!ctx) return LF_ERR_INVALID;
+  ctx->timing = on != 0;
+  return LF_OK;
+}
+
+lf_status lf_timing_reset(lf_ctx* ctx) {
+  if (!ctx) return LF_ERR_INVALID;
+  LF_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  for (auto& t : ctx->timed) { (void)hipEventDestroy(t.start); (void)hipEventDestroy(t.stop); }
+  ctx->timed.clear();
+  return LF_OK;
+}
+
+lf_status lf_timing_get(lf_ctx* ctx, const char* kernel, int* launches, double* total_ms) {
+  if (!ctx || !kernel || !launches || !total_ms) return LF_ERR_INVALID;
+  int id = -1;
+  for (int k = 0; k < LFK_COUNT; k++) if (std::strcmp(kernel, kKernelNames[k]) == 0) id = k;
+  if (id < 0) return lf_fail(ctx, LF_ERR_INVALID, "unknown kernel name");
+  LF_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  *launches = 0; *total_ms = 0.0;
+  for (auto& t : ctx->timed) {
+    if (t.kernel != id) continue;
+    float ms = 0.f;
+    LF_HIP(ctx, hipEventElapsedTime(&ms, t.start, t.stop));
+    (*launches)++;
+    *total_ms += ms;
+  }
+  return LF_OK;
+}
+
+}  // extern "C"

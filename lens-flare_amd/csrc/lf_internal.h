@@ -1,0 +1,182 @@
+// lf_internal.h -- shared declarations of liblensflare_hip.so (host + gfx950 device code).
+// Nothing here is part of the ABI; the ABI is include/lensflare.h.
+#pragma once
+
+#include <hip/hip_runtime.h>
+
+#include <cstdint>
+#include <string>
+#include <vector>
+
+#include "lensflare.h"
+
+// ---- limits -------------------------------------------------------------------------------
+constexpr int kMaxParaxialGhosts = 3 * 105;          // 3 colours x C(15,2) pairs
+constexpr int kMaxGhostTris = 2 * kMaxParaxialGhosts; // two triangles per quad
+
+// ---- device-resident frame state ----------------------------------------------------------
+// Mirrors the public per-frame fields of PathTracer (pathtracer.h:93-94,128-135).  Written either
+// by the frame-setup kernel (find_sun_pos on the device) or by lf_set_flares.
+struct LfFlares {
+  int n_flares;
+  float angle_to_sun;
+  double origin[LF_MAX_FLARES][2];
+  double radiance[LF_MAX_FLARES][3];
+  double axis_ray[2];
+};
+
+// One rasterisable ghost triangle, vertices already y-sorted and shifted by -0.5
+// (rasterize_textured_triangle, pathtracer.cpp:346-394).
+struct LfGhostTri {
+  float x0, y0, u0, v0, x1, y1, u1, v1, x2, y2, u2, v2;
+  int bx0, bx1, by0, by1;  // loops run x in [bx0,bx1), y in [by0,by1)  (:402-403)
+  int channel;             // 0,1,2 = red, green, blue
+  int pad;
+  double colour;           // 10 / scale_amt^2 widened (:492-494)
+};
+
+struct LfGhostList {
+  int n_tris;
+  int pad;
+  LfGhostTri tri[kMaxGhostTris];
+};
+
+// Paraxial prescription (globals of pathtracer.cpp:541-556 + constants of :619-633, :737)
+struct LfParaxialLens {
+  int n, stop;
+  float thickness[LF_MAX_SURFACES];
+  float curvature[LF_MAX_SURFACES];
+  float ior[3][LF_MAX_SURFACES];
+  double clip;
+  float recast_pos, recast_neg, marginal;
+};
+
+struct LfCamera {
+  double c2w[9];  // row-major
+  double pos[3];
+  double hfov_deg, vfov_deg;
+};
+
+struct LfApertureDev {
+  float* texels = nullptr;  // w*h
+  int w = 0, h = 0;
+  lf_aperture_stats* stats = nullptr;  // device copy
+  lf_aperture_stats host_stats{};
+  bool valid = false;
+};
+
+// ---- geometric lens (north-star march) -------------------------------------------------------
+// One entry per interface and wavelength, everything the march needs, pre-derived on the host in
+// float from the raw prescription (see lf_march.hip for the formulas).
+struct LfSurfaceDev {
+  float zv;        // vertex z (scene side first, light travels +z)
+  float curv;      // 1/R, 0 for flats and the stop
+  float h2;        // semi-aperture squared
+  float is_stop;   // 1.0f for the stop
+  float eta_fwd[LF_MAX_LAMBDA];  // n_before / n_after   (ray travelling +z refracts with this)
+  float eta_bwd[LF_MAX_LAMBDA];  // n_after / n_before   (ray travelling -z)
+};
+
+struct LfLensDev {
+  int n_surf, stop, n_lambda, pad;
+  float z_sensor;      // sensor plane z
+  float pitch;         // mm per pixel
+  float pupil_h;       // semi-aperture of the rear-most surface (pupil sampling disc)
+  float pupil_z;       // z of the rear-most vertex
+  float geom_norm;     // pupil area / (pupil_z - z_sensor)^2
+  float stop_h;        // semi-aperture of the stop
+  float sun_dir[3];    // unit, towards the sun (z < 0)
+  float sun_radiance[3];
+  float sun_inv_one_minus_cos;  // 1 / (1 - cos(angular radius))
+  float lambda_rgb[LF_MAX_LAMBDA][3];
+  LfSurfaceDev surf[LF_MAX_SURFACES];
+};
+
+struct LfPairsDev {
+  int n;
+  int pad;
+  int ij[LF_MAX_PAIRS + 1][2];  // (-1,-1) = primary path
+};
+
+// ---- timing ---------------------------------------------------------------------------------
+enum LfKernelId { LFK_MARCH = 0, LFK_FLARE_LAYER, LFK_GHOST_RASTER, LFK_DFT, LFK_FRAME_SETUP,
+                  LFK_TONEMAP, LFK_COUNT };
+
+struct LfTimedLaunch { int kernel; hipEvent_t start, stop; };
+
+// ---- the context ----------------------------------------------------------------------------
+struct lf_ctx {
+  int device = 0;
+  hipStream_t stream = nullptr;
+  bool own_stream = false;
+  mutable std::string err;
+
+  int W = 0, H = 0, y0 = 0, y1 = 0;
+  int ns_aa = 1;
+  double flare_radius = 25.0, flare_intensity = 1.0;
+
+  LfApertureDev ap[2];
+  // starburst spectrum |DFT2(aperture)| / total_value, aw*aw doubles; twiddles; row pass scratch
+  double* spectrum = nullptr;
+  double2* twiddle = nullptr;
+  double2* dft_rows = nullptr;
+  bool spectrum_valid = false;
+
+  LfParaxialLens pl{};
+  LfCamera cam{};
+  bool cam_valid = false;
+  LfFlares* flares = nullptr;      // device
+  LfGhostList* ghosts = nullptr;   // device
+  LfParaxialLens* pl_dev = nullptr;
+  bool flares_valid = false;
+
+  double* sample = nullptr;  // W*H*3
+  double* ghost = nullptr;   // W*H*3
+  double* scene = nullptr;   // W*H*3 or null
+  uint32_t* rgba = nullptr;  // W*H
+  bool ghost_valid = false, sample_valid = false, rgba_valid = false;
+
+  // jitter
+  int jitter_mode = 1;          // 0 = MT19937 table, 1 = counter
+  uint64_t jitter_key = 0x1e45f1a4eULL;
+  uint32_t* jitter_raw = nullptr;  // W*H*32 raw draws, pixel-major (MT mode)
+  bool jitter_table_valid = false;
+
+  // geometric
+  LfLensDev lens{};
+  bool lens_valid = false, sun_valid = false;
+  LfLensDev* lens_dev = nullptr;
+  LfPairsDev pairs{};
+  LfPairsDev* pairs_dev = nullptr;
+  unsigned long long* counters_dev = nullptr;  // 8 x u64
+  unsigned long long* accum = nullptr;         // unused for now
+
+  bool timing = false;
+  std::vector<LfTimedLaunch> timed;
+  std::vector<hipEvent_t> event_pool;
+};
+
+// implemented in lf_api.hip
+lf_status lf_fail(const lf_ctx* ctx, lf_status st, const std::string& msg);
+hipEvent_t lf_timing_begin(lf_ctx* ctx, int kernel);
+void lf_timing_end(lf_ctx* ctx, int kernel, hipEvent_t start);
+
+#define LF_HIP(ctx, expr)                                                                     \
+  do {                                                                                        \
+    hipError_t e_ = (expr);                                                                   \
+    if (e_ != hipSuccess)                                                                     \
+      return lf_fail(ctx, LF_ERR_HIP, std::string(#expr) + ": " + hipGetErrorString(e_));     \
+  } while (0)
+
+// kernels launchers (lf_flare_kernels.hip)
+lf_status lfk_aperture_stats(lf_ctx* ctx, int slot);
+lf_status lfk_build_spectrum(lf_ctx* ctx);
+lf_status lfk_frame_setup(lf_ctx* ctx, const double* lights_dev, int n_lights, bool project);
+lf_status lfk_ghost_raster(lf_ctx* ctx);
+lf_status lfk_flare_layer(lf_ctx* ctx);
+lf_status lfk_tonemap(lf_ctx* ctx);
+// lf_march.hip
+lf_status lfk_march(lf_ctx* ctx, int spp, uint64_t key);
+void lf_derive_lens(lf_ctx* ctx, int n, int stop, int n_lambda, const float* radius,
+                    const float* thickness, const float* ior, const float* semi_ap,
+                    float sensor_w_mm);

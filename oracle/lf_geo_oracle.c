@@ -1,0 +1,309 @@
+/* TEST INFRASTRUCTURE -- CPU oracle of the GEOMETRIC lens march.  Never linked into, imported by
+ * or shipped with the product library.  Only tests/, __graft_entry__.smoke() and bench.py's
+ * cpu_baseline leg may load this.
+ *
+ * PARITY STATUS: **parity unpinned**.  The reference has no geometric lens (its ghosts are
+ * paraxial ABCD matrices, src/pathtracer/pathtracer.cpp:511-689; its thin-lens camera is a stub,
+ * src/pathtracer/camera_lens.cpp:22-30; BSDF::refract is empty, advanced_bsdf.cpp:156-169), so no
+ * reference output exists for this path.  This file restates the *specification* in DESIGN.md
+ * ("march arithmetic") and is itself pinned by analytic known-answer tests
+ * (tests/test_geo_oracle_kat.py): Snell's law, Fresnel at normal incidence / Brewster / TIR, the
+ * lensmaker's focal length, and agreement with the reference's own paraxial T/R/L formalism
+ * (pathtracer.cpp:527-537) in the small-angle limit.
+ *
+ * Arithmetic contract: float32; fused multiply-adds are explicit fmaf(); division and sqrt are the
+ * IEEE correctly rounded ones; built with -ffp-contract=off -mfma so nothing else fuses.
+ */
+#define _GNU_SOURCE
+#include <math.h>
+#include <stdint.h>
+#include <stdlib.h>
+#include <string.h>
+
+#define GEO_MAX_SURF 16
+#define GEO_MAX_LAMBDA 8
+
+typedef struct {
+  int n_surf, stop, n_lambda;
+  float radius[GEO_MAX_SURF], thickness[GEO_MAX_SURF], semi_ap[GEO_MAX_SURF];
+  float ior[GEO_MAX_LAMBDA][GEO_MAX_SURF];
+  float sensor_w_mm;
+  float sun_dir[3], sun_radiance[3], sun_angular_radius;
+  float lambda_rgb[GEO_MAX_LAMBDA][3];
+} geo_lens;
+
+typedef struct {
+  uint64_t rays_launched, surface_events, rays_clipped_stop, rays_vignetted, rays_tir,
+      rays_reached_scene, rays_hit_light;
+} geo_counters;
+
+/* ---- Philox4x32-10, Salmon et al., "Parallel random numbers: as easy as 1, 2, 3" (SC'11) ---- */
+static void philox(const uint32_t ctr_in[4], const uint32_t key_in[2], uint32_t out[4]) {
+  uint32_t c0 = ctr_in[0], c1 = ctr_in[1], c2 = ctr_in[2], c3 = ctr_in[3];
+  uint32_t k0 = key_in[0], k1 = key_in[1];
+  for (int r = 0; r < 10; r++) {
+    uint64_t p0 = (uint64_t)0xD2511F53u * c0, p1 = (uint64_t)0xCD9E8D57u * c2;
+    uint32_t n0 = (uint32_t)(p1 >> 32) ^ c1 ^ k0, n1 = (uint32_t)p1;
+    uint32_t n2 = (uint32_t)(p0 >> 32) ^ c3 ^ k1, n3 = (uint32_t)p0;
+    c0 = n0; c1 = n1; c2 = n2; c3 = n3;
+    k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
+  }
+  out[0] = c0; out[1] = c1; out[2] = c2; out[3] = c3;
+}
+void geo_philox(const uint32_t ctr[4], const uint32_t key[2], uint32_t out[4]) { philox(ctr, key, out); }
+
+static float unit24(uint32_t r) { return (float)(r >> 8) * 5.9604644775390625e-8f; }
+
+/* ---- derived per-interface constants ------------------------------------------------------ */
+typedef struct {
+  float zv[GEO_MAX_SURF], curv[GEO_MAX_SURF], h2[GEO_MAX_SURF];
+  float eta_fwd[GEO_MAX_LAMBDA][GEO_MAX_SURF], eta_bwd[GEO_MAX_LAMBDA][GEO_MAX_SURF];
+  float z_sensor, pitch, pupil_h, pupil_z, geom_norm, inv_stop_h, inv_1mc;
+} geo_derived;
+
+static void derive(const geo_lens* L, int W, geo_derived* D) {
+  float z = 0.0f;
+  for (int k = 0; k < L->n_surf; k++) {
+    D->zv[k] = z;
+    z = z + L->thickness[k];
+    D->curv[k] = L->radius[k] == 0.0f ? 0.0f : 1.0f / L->radius[k];
+    D->h2[k] = L->semi_ap[k] * L->semi_ap[k];
+  }
+  D->z_sensor = z;
+  for (int l = 0; l < L->n_lambda; l++) {
+    float nb = 1.0f;
+    for (int k = 0; k < L->n_surf; k++) {
+      float na = (k == L->stop) ? nb : L->ior[l][k];
+      D->eta_fwd[l][k] = nb / na;
+      D->eta_bwd[l][k] = na / nb;
+      nb = na;
+    }
+  }
+  D->pitch = L->sensor_w_mm / (float)W;
+  D->pupil_h = L->semi_ap[L->n_surf - 1];
+  D->pupil_z = D->zv[L->n_surf - 1];
+  double dist = (double)D->z_sensor - (double)D->pupil_z;
+  D->geom_norm = (float)((3.14159265358979323846 * (double)D->pupil_h * (double)D->pupil_h) / (dist * dist));
+  D->inv_stop_h = 1.0f / (L->stop >= 0 ? L->semi_ap[L->stop] : 1.0f);
+  D->inv_1mc = (float)(1.0 / (1.0 - cos((double)L->sun_angular_radius)));
+}
+
+/* ---- one ray ---------------------------------------------------------------------------- */
+typedef struct { float p[3], d[3], w; } geo_ray;
+enum { OK_ = 0, CLIPPED = 1, VIGNETTED = 2, TIR = 3 };
+
+/* DESIGN.md "march arithmetic", glass interface.  reflect: 0 = Snell refraction, 1 = mirror.
+ * forward: the ray travels +z (scene -> sensor). */
+static int glass_event(geo_ray* r, float zv, float c, float h2, float eta, int reflect, int forward) {
+  float oz = r->p[2] - zv;
+  float od = fmaf(r->p[0], r->d[0], fmaf(r->p[1], r->d[1], oz * r->d[2]));
+  float oo = fmaf(r->p[0], r->p[0], fmaf(r->p[1], r->p[1], oz * oz));
+  float F = fmaf(c, oo, -2.0f * oz);
+  float G = fmaf(-c, od, r->d[2]);
+  float disc = fmaf(G, G, -(c * F));
+  if (disc < 0.0f) return VIGNETTED;
+  float root = sqrtf(disc);
+  float t = F / (forward ? G + root : G - root);
+  float hx = fmaf(t, r->d[0], r->p[0]), hy = fmaf(t, r->d[1], r->p[1]), hz = fmaf(t, r->d[2], oz);
+  if (!(fmaf(hx, hx, hy * hy) <= h2)) return VIGNETTED;
+  float n[3] = {-c * hx, -c * hy, fmaf(-c, hz, 1.0f)};
+  float mu = fmaf(r->d[0], n[0], fmaf(r->d[1], n[1], r->d[2] * n[2]));
+  float ci = fabsf(mu);
+  float k2 = fmaf(-(eta * eta), fmaf(-mu, mu, 1.0f), 1.0f);
+  float refl = 1.0f, ct = 0.0f;
+  if (k2 >= 0.0f) {
+    ct = sqrtf(k2);
+    float a = fmaf(eta, ci, -ct), b = fmaf(eta, ci, ct);
+    float e = fmaf(-eta, ct, ci), f = fmaf(eta, ct, ci);
+    float af = a * f, eb = e * b, bf = b * f;
+    refl = (0.5f * fmaf(af, af, eb * eb)) / (bf * bf);
+  } else if (!reflect) {
+    return TIR;
+  }
+  if (!reflect) {
+    r->w *= (1.0f - refl);
+    float g = fmaf(-eta, mu, copysignf(ct, mu));
+    for (int a = 0; a < 3; a++) r->d[a] = fmaf(eta, r->d[a], g * n[a]);
+  } else {
+    r->w *= refl;
+    float m2 = -2.0f * mu;
+    for (int a = 0; a < 3; a++) r->d[a] = fmaf(m2, n[a], r->d[a]);
+  }
+  r->p[0] = hx; r->p[1] = hy; r->p[2] = zv + hz;
+  return OK_;
+}
+
+static int stop_event(geo_ray* r, float zv, float h2, float inv_h, const float* mask, int mw, int mh) {
+  float t = (zv - r->p[2]) / r->d[2];
+  float hx = fmaf(t, r->d[0], r->p[0]), hy = fmaf(t, r->d[1], r->p[1]);
+  if (!(fmaf(hx, hx, hy * hy) <= h2)) return CLIPPED;
+  float fu = fmaf(hx, inv_h, 1.0f) * (0.5f * (float)mw);
+  float fv = fmaf(hy, inv_h, 1.0f) * (0.5f * (float)mh);
+  int ix = (int)fu, iy = (int)fv;
+  if (ix < 0) ix = 0; if (ix > mw - 1) ix = mw - 1;
+  if (iy < 0) iy = 0; if (iy > mh - 1) iy = mh - 1;
+  float a = mask[iy * mw + ix];
+  if (!(a > 0.0f)) return CLIPPED;
+  r->w *= a;
+  r->p[0] = hx; r->p[1] = hy; r->p[2] = zv;
+  return OK_;
+}
+
+/* exported for the known-answer tests: one event on a caller-supplied ray */
+int geo_glass_event(float p[3], float d[3], float* w, float zv, float c, float h2, float eta,
+                    int reflect, int forward) {
+  geo_ray r = {{p[0], p[1], p[2]}, {d[0], d[1], d[2]}, *w};
+  int st = glass_event(&r, zv, c, h2, eta, reflect, forward);
+  memcpy(p, r.p, sizeof(r.p)); memcpy(d, r.d, sizeof(r.d)); *w = r.w;
+  return st;
+}
+
+/* the interface sequence of one ghost pair, in the order the backward ray meets it */
+typedef struct { int k, reflect, forward; } geo_step;
+static int build_sequence(int n_surf, int i, int j, geo_step* seq) {
+  int n = 0;
+  if (i < 0) {
+    for (int k = n_surf - 1; k >= 0; k--) seq[n++] = (geo_step){k, 0, 0};
+    return n;
+  }
+  for (int k = n_surf - 1; k > i; k--) seq[n++] = (geo_step){k, 0, 0};
+  seq[n++] = (geo_step){i, 1, 0};
+  for (int k = i + 1; k < j; k++) seq[n++] = (geo_step){k, 0, 1};
+  seq[n++] = (geo_step){j, 1, 1};
+  for (int k = j - 1; k >= 0; k--) seq[n++] = (geo_step){k, 0, 0};
+  return n;
+}
+
+/* sensor sample -> ray on the sensor aimed at the rear pupil.  Returns the start weight. */
+static float start_ray(const geo_derived* D, int W, int H, int x, int y, const uint32_t rnd[4],
+                       geo_ray* r) {
+  float jx = unit24(rnd[0]), jy = unit24(rnd[1]);
+  float pa = fmaf(2.0f, unit24(rnd[2]), -1.0f), pb = fmaf(2.0f, unit24(rnd[3]), -1.0f);
+  float X = -(((float)x + jx) - 0.5f * (float)W) * D->pitch;
+  float Y = -(((float)y + jy) - 0.5f * (float)H) * D->pitch;
+  float qx = 0.0f, qy = 0.0f;
+  if (pa != 0.0f || pb != 0.0f) {
+    int wide = fabsf(pa) > fabsf(pb);
+    float rr = wide ? pa : pb;
+    float th = 0.78539816339744831f * ((wide ? pb : pa) / rr);
+    float t2 = th * th;
+    float sn = th * fmaf(t2, fmaf(t2, fmaf(t2, fmaf(t2, 2.7557319e-6f, -1.9841270e-4f), 8.3333333e-3f),
+                                  -1.6666667e-1f), 1.0f);
+    float cs = fmaf(t2, fmaf(t2, fmaf(t2, fmaf(t2, 2.4801587e-5f, -1.3888889e-3f), 4.1666667e-2f),
+                             -0.5f), 1.0f);
+    qx = wide ? rr * cs : rr * sn;
+    qy = wide ? rr * sn : rr * cs;
+  }
+  float vx = fmaf(D->pupil_h, qx, -X), vy = fmaf(D->pupil_h, qy, -Y), vz = D->pupil_z - D->z_sensor;
+  float len = sqrtf(fmaf(vx, vx, fmaf(vy, vy, vz * vz)));
+  float rl = 1.0f / len;
+  r->p[0] = X; r->p[1] = Y; r->p[2] = D->z_sensor;
+  r->d[0] = vx * rl; r->d[1] = vy * rl; r->d[2] = vz * rl;
+  float c2 = r->d[2] * r->d[2];
+  r->w = D->geom_norm * (c2 * c2);
+  return r->w;
+}
+
+/* March `spp` samples of every pixel in rows [y0, y1); pairs = n x (i, j), (-1,-1) = primary.
+ * ghost: W*H*3 doubles (only the band is written).  Returns counters. */
+void geo_trace(const geo_lens* L, int W, int H, int y0, int y1, int spp, const uint32_t key[2],
+               const int* pairs, int n_pairs, const float* mask, int mw, int mh, double* ghost,
+               geo_counters* cnt, int n_threads) {
+  geo_derived D;
+  derive(L, W, &D);
+  geo_counters total;
+  memset(&total, 0, sizeof(total));
+  if (n_threads < 1) n_threads = 1;
+#pragma omp parallel num_threads(n_threads)
+  {
+    geo_counters c;
+    memset(&c, 0, sizeof(c));
+    geo_step seq[3 * GEO_MAX_SURF];
+#pragma omp for schedule(dynamic, 64)
+    for (long long p = (long long)y0 * W; p < (long long)y1 * W; p++) {
+      int x = (int)(p % W), y = (int)(p / W);
+      uint64_t acc[3] = {0, 0, 0};
+      for (int s = 0; s < spp; s++) {
+        uint32_t ctr[4] = {(uint32_t)p, (uint32_t)s, 0x6e5f1a2eu, 0u}, rnd[4];
+        philox(ctr, key, rnd);
+        geo_ray r0;
+        start_ray(&D, W, H, x, y, rnd, &r0);
+        for (int l = 0; l < L->n_lambda; l++)
+          for (int q = 0; q < n_pairs; q++) {
+            int n = build_sequence(L->n_surf, pairs[2 * q], pairs[2 * q + 1], seq);
+            geo_ray r = r0;
+            int st = OK_;
+            c.rays_launched++;
+            for (int e = 0; e < n; e++) {
+              int k = seq[e].k;
+              if (k == L->stop)
+                st = stop_event(&r, D.zv[k], D.h2[k], D.inv_stop_h, mask, mw, mh);
+              else
+                st = glass_event(&r, D.zv[k], D.curv[k], D.h2[k],
+                                 seq[e].forward ? D.eta_fwd[l][k] : D.eta_bwd[l][k], seq[e].reflect,
+                                 seq[e].forward);
+              if (st != OK_) break;
+              c.surface_events++;
+            }
+            if (st == CLIPPED) { c.rays_clipped_stop++; continue; }
+            if (st == VIGNETTED) { c.rays_vignetted++; continue; }
+            if (st == TIR) { c.rays_tir++; continue; }
+            c.rays_reached_scene++;
+            float cg = fmaf(r.d[0], L->sun_dir[0], fmaf(r.d[1], L->sun_dir[1], r.d[2] * L->sun_dir[2]));
+            float qq = (1.0f - cg) * D.inv_1mc;
+            if (qq < 1.0f) {
+              float om = 1.0f - qq;
+              float contrib = r.w * (om * om);
+              if (contrib > 0.0f) {
+                c.rays_hit_light++;
+                for (int ch = 0; ch < 3; ch++) {
+                  float v = contrib * (L->sun_radiance[ch] * L->lambda_rgb[l][ch]);
+                  acc[ch] += (uint64_t)(v * 68719476736.0f);
+                }
+              }
+            }
+          }
+      }
+      for (int ch = 0; ch < 3; ch++)
+        ghost[3 * p + ch] = ((double)acc[ch] * (1.0 / 68719476736.0)) / (double)spp;
+    }
+#pragma omp critical
+    {
+      total.rays_launched += c.rays_launched; total.surface_events += c.surface_events;
+      total.rays_clipped_stop += c.rays_clipped_stop; total.rays_vignetted += c.rays_vignetted;
+      total.rays_tir += c.rays_tir; total.rays_reached_scene += c.rays_reached_scene;
+      total.rays_hit_light += c.rays_hit_light;
+    }
+  }
+  if (cnt) *cnt = total;
+}
+
+/* Trace ONE explicit ray (position/direction given) through an explicit sequence; for the KATs.
+ * Returns status; p/d/w updated; events executed in *n_events. */
+int geo_trace_ray(const geo_lens* L, int lambda, int i, int j, float p[3], float d[3], float* w,
+                  const float* mask, int mw, int mh, int* n_events) {
+  geo_derived D;
+  derive(L, 64, &D);
+  geo_step seq[3 * GEO_MAX_SURF];
+  int n = build_sequence(L->n_surf, i, j, seq);
+  geo_ray r = {{p[0], p[1], p[2]}, {d[0], d[1], d[2]}, *w};
+  int st = OK_, ev = 0;
+  for (int e = 0; e < n; e++) {
+    int k = seq[e].k;
+    if (k == L->stop) st = stop_event(&r, D.zv[k], D.h2[k], D.inv_stop_h, mask, mw, mh);
+    else st = glass_event(&r, D.zv[k], D.curv[k], D.h2[k],
+                          seq[e].forward ? D.eta_fwd[lambda][k] : D.eta_bwd[lambda][k],
+                          seq[e].reflect, seq[e].forward);
+    if (st != OK_) break;
+    ev++;
+  }
+  memcpy(p, r.p, sizeof(r.p)); memcpy(d, r.d, sizeof(r.d)); *w = r.w;
+  if (n_events) *n_events = ev;
+  return st;
+}
+
+float geo_z_sensor(const geo_lens* L) {
+  geo_derived D;
+  derive(L, 64, &D);
+  return D.z_sensor;
+}

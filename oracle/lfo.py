@@ -176,3 +176,122 @@ def to_color(sample):
     out = np.empty(n, np.uint32)
     lib().lfo_to_color(_p(sample, C.c_double), C.c_size_t(n), _p(out, C.c_uint32))
     return out.reshape(sample.shape[:-1])
+
+
+# ------------------------------------------------------------------------------------------------
+# geometric march oracle (oracle/lf_geo_oracle.c) -- PARITY UNPINNED, see that file's header
+# ------------------------------------------------------------------------------------------------
+GEO_MAX_SURF, GEO_MAX_LAMBDA = 16, 8
+
+
+class GeoLens(C.Structure):
+    _fields_ = [("n_surf", C.c_int), ("stop", C.c_int), ("n_lambda", C.c_int),
+                ("radius", C.c_float * GEO_MAX_SURF), ("thickness", C.c_float * GEO_MAX_SURF),
+                ("semi_ap", C.c_float * GEO_MAX_SURF),
+                ("ior", (C.c_float * GEO_MAX_SURF) * GEO_MAX_LAMBDA), ("sensor_w_mm", C.c_float),
+                ("sun_dir", C.c_float * 3), ("sun_radiance", C.c_float * 3),
+                ("sun_angular_radius", C.c_float),
+                ("lambda_rgb", (C.c_float * 3) * GEO_MAX_LAMBDA)]
+
+
+class GeoCounters(C.Structure):
+    _fields_ = [(n, C.c_uint64) for n in ("rays_launched", "surface_events", "rays_clipped_stop",
+                                          "rays_vignetted", "rays_tir", "rays_reached_scene",
+                                          "rays_hit_light")]
+
+
+def geo_lens(lens, sun_dir=(0, 0, -1), sun_radiance=(1, 1, 1), sun_angular_radius=0.05,
+             lambda_rgb=None):
+    """lens: dict as lens_flare_amd.load_lens_file returns (raw prescription)."""
+    import math
+    L = GeoLens()
+    L.n_surf, L.stop = int(lens["n"]), int(lens["stop"])
+    ior = np.asarray(lens["ior"], np.float32)
+    L.n_lambda = ior.shape[0]
+    for k in range(L.n_surf):
+        L.radius[k] = float(lens["radius"][k])
+        L.thickness[k] = float(lens["thickness"][k])
+        L.semi_ap[k] = float(lens["semi_aperture"][k])
+        for l in range(L.n_lambda):
+            L.ior[l][k] = float(ior[l, k])
+    L.sensor_w_mm = float(lens["sensor_width_mm"])
+    # same normalisation as lf_set_sun: double sqrt of the float components' squares, then narrow
+    d = [float(np.float32(v)) for v in sun_dir]
+    n = math.sqrt(d[0] * d[0] + d[1] * d[1] + d[2] * d[2])
+    for c in range(3):
+        L.sun_dir[c] = float(np.float32(d[c] / n))
+        L.sun_radiance[c] = float(np.float32(sun_radiance[c]))
+    L.sun_angular_radius = float(np.float32(sun_angular_radius))
+    for l in range(L.n_lambda):
+        for c in range(3):
+            if lambda_rgb is not None:
+                L.lambda_rgb[l][c] = float(np.float32(lambda_rgb[l][c]))
+            else:
+                L.lambda_rgb[l][c] = (1.0 if l == c else 0.0) if L.n_lambda == 3 else float(
+                    np.float32(1.0) / np.float32(L.n_lambda))
+    return L
+
+
+def all_pairs(lens, include_primary=True):
+    n, stop = int(lens["n"]), int(lens["stop"])
+    out = [(-1, -1)] if include_primary else []
+    out += [(i, j) for i in range(n) for j in range(i + 1, n) if i != stop and j != stop]
+    return np.array(out, np.int32)
+
+
+def geo_trace(lens, W, H, y0, y1, spp, key, pairs, include_primary, mask, sun_dir, sun_radiance,
+              sun_angular_radius, n_threads=8, lambda_rgb=None):
+    L = geo_lens(lens, sun_dir, sun_radiance, sun_angular_radius, lambda_rgb)
+    if pairs is None:
+        pairs = all_pairs(lens, include_primary)
+    else:
+        pairs = np.asarray(pairs, np.int32).reshape(-1, 2)
+        if include_primary:
+            pairs = np.concatenate([np.array([[-1, -1]], np.int32), pairs])
+    pairs = np.ascontiguousarray(pairs, np.int32)
+    mask = np.ascontiguousarray(mask, np.float32)
+    ghost = np.zeros((H, W, 3), np.float64)
+    cnt = GeoCounters()
+    k = (C.c_uint32 * 2)(key & 0xffffffff, (key >> 32) & 0xffffffff)
+    lib().geo_trace(C.byref(L), W, H, y0, y1, spp, k, _p(pairs, C.c_int), len(pairs),
+                    _p(mask, C.c_float), mask.shape[1], mask.shape[0], _p(ghost, C.c_double),
+                    C.byref(cnt), n_threads)
+    return ghost, {n: int(getattr(cnt, n)) for n, _ in cnt._fields_}
+
+
+def geo_glass_event(p, d, w, zv, c, h2, eta, reflect, forward):
+    pp = (C.c_float * 3)(*p)
+    dd = (C.c_float * 3)(*d)
+    ww = C.c_float(w)
+    lib().geo_glass_event.restype = C.c_int
+    st = lib().geo_glass_event(pp, dd, C.byref(ww), C.c_float(zv), C.c_float(c), C.c_float(h2),
+                               C.c_float(eta), int(reflect), int(forward))
+    return st, np.array(pp[:], np.float32), np.array(dd[:], np.float32), ww.value
+
+
+def geo_trace_ray(lens, lam, i, j, p, d, w=1.0, mask=None):
+    L = geo_lens(lens)
+    if mask is None:
+        mask = np.ones((4, 4), np.float32)
+    mask = np.ascontiguousarray(mask, np.float32)
+    pp = (C.c_float * 3)(*p)
+    dd = (C.c_float * 3)(*d)
+    ww = C.c_float(w)
+    ne = C.c_int()
+    st = lib().geo_trace_ray(C.byref(L), int(lam), int(i), int(j), pp, dd, C.byref(ww),
+                             _p(mask, C.c_float), mask.shape[1], mask.shape[0], C.byref(ne))
+    return st, np.array(pp[:], np.float64), np.array(dd[:], np.float64), ww.value, ne.value
+
+
+def geo_z_sensor(lens):
+    L = geo_lens(lens)
+    lib().geo_z_sensor.restype = C.c_float
+    return lib().geo_z_sensor(C.byref(L))
+
+
+def geo_philox(ctr, key):
+    c = (C.c_uint32 * 4)(*ctr)
+    k = (C.c_uint32 * 2)(*key)
+    o = (C.c_uint32 * 4)()
+    lib().geo_philox(c, k, o)
+    return list(o)

@@ -1,0 +1,62 @@
+"""CPU-only checks of the drop-in boundary: the C-ABI library loads without a GPU, exports every
+symbol include/lensflare.h declares, and fails loudly (no CPU fallback) when no device exists."""
+import ctypes as C
+import os
+import re
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _pkg():
+    import __graft_entry__ as g
+    return g.load_package()
+
+
+def test_header_symbols_exported():
+    pkg = _pkg()
+    header = open(os.path.join(ROOT, "include", "lensflare.h")).read()
+    declared = set(re.findall(r"\b(lf_[a-z0-9_]+)\s*\(", header))
+    declared -= {"lf_ctx"}
+    assert declared == set(pkg.ABI_SYMBOLS), declared ^ set(pkg.ABI_SYMBOLS)
+    lib = pkg.load_library()
+    for sym in sorted(declared):
+        assert hasattr(lib, sym), sym
+    assert lib.lf_abi_version() == 1
+
+
+def test_no_device_fails_loudly():
+    """Without a GPU lf_create must return LF_ERR_NO_DEVICE -- never a CPU fallback."""
+    import torch
+    if torch.cuda.is_available():
+        import pytest
+        pytest.skip("a GPU is present")
+    pkg = _pkg()
+    lib = pkg.load_library()
+    ctx = C.c_void_p()
+    assert lib.lf_create(C.byref(ctx), 0) == 2
+    assert not ctx.value
+    try:
+        pkg.LensFlare(0)
+        raise AssertionError("LensFlare() must raise without a device")
+    except pkg.LensFlareError as e:
+        assert e.status == 2
+
+
+def test_product_never_references_oracle():
+    """The product tree must not import, link or open anything under oracle/."""
+    for dirpath, _, files in os.walk(os.path.join(ROOT, "lens-flare_amd")):
+        if "build" in dirpath:
+            continue
+        for f in files:
+            if f.endswith((".py", ".hip", ".h", ".cpp", "Makefile")):
+                text = open(os.path.join(dirpath, f), errors="ignore").read()
+                for needle in ("lf_oracle", "lfo.", "from oracle", "import oracle", "oracle/_", "liblf_oracle"):
+                    assert needle not in text, (f, needle)
+
+
+def test_lens_files_parse():
+    pkg = _pkg()
+    dg = pkg.load_lens_file("dgauss11.lens")
+    assert dg["n"] == 11 and dg["stop"] == 5 and dg["ior"].shape == (3, 11)
+    tl = pkg.load_lens_file("thinlens.lens")
+    assert tl["n"] == 2 and tl["stop"] == -1

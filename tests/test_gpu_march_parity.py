@@ -1,0 +1,127 @@
+"""GPU parity of the geometric march (lf_trace_ghosts) against the CPU oracle
+(oracle/lf_geo_oracle.c, PARITY UNPINNED: there is no reference implementation of this path).
+Both follow the same float32 arithmetic contract, so pixels AND event counters are compared bit for
+bit; at full size the test falls back to size-independent properties."""
+import numpy as np
+import pytest
+
+from goldenlib import load_texels
+from oracle import lfo
+
+pytestmark = pytest.mark.gpu
+
+SUN = dict(direction=[0.03, 0.02, -1.0], radiance=[1.0, 0.9, 0.5], angular_radius=0.05)
+
+
+@pytest.fixture(scope="module")
+def pkg():
+    import __graft_entry__ as g
+    return g.load_package()
+
+
+@pytest.fixture(scope="module")
+def lf(pkg):
+    ctx = pkg.LensFlare(0)
+    yield ctx
+    ctx.close()
+
+
+def _run(pkg, lf, lens, W, H, spp, key, mask, pairs=None, primary=True, band=None, sun=SUN):
+    lf.set_frame(W, H)
+    lf.set_aperture(pkg.APERTURE_STARBURST, mask)
+    lf.set_lens(lens)
+    lf.set_sun(sun["direction"], sun["radiance"], sun["angular_radius"])
+    lf.set_ghost_pairs(pairs, primary)
+    if band:
+        lf.set_band(*band)
+    lf.reset_counters()
+    lf.trace_ghosts(spp, key)
+    y0, y1 = band if band else (0, H)
+    g = lf.read_buffer(pkg.GHOST_BUFFER)
+    og, ocnt = lfo.geo_trace(lens, W, H, y0, y1, spp, key, pairs, primary, mask, sun["direction"],
+                             sun["radiance"], sun["angular_radius"])
+    return g, lf.counters(), og, ocnt
+
+
+@pytest.mark.parametrize("W,H,spp", [(48, 32, 16), (33, 17, 5), (8, 4, 300), (16, 8, 256), (20, 6, 1)])
+def test_dgauss_all_pairs_bit_exact(pkg, lf, W, H, spp):
+    """Double-Gauss, primary + all 45 glass pairs, 3 wavelengths, pentagon mask."""
+    lens = pkg.load_lens_file("dgauss11.lens")
+    mask = load_texels("pentbig500_14.png")
+    g, cnt, og, ocnt = _run(pkg, lf, lens, W, H, spp, 0xC0FFEE + spp, mask)
+    assert cnt["rays_launched"] == W * H * spp * 3 * 46
+    assert cnt == ocnt
+    assert np.array_equal(g, og)
+    assert cnt["rays_hit_light"] > 0 and og.max() > 0  # the test is not vacuous
+
+
+def test_thin_lens_config_c1(pkg, lf):
+    """Config C1: single biconvex lens, no stop, one ghost pair (0,1) + primary."""
+    lens = pkg.load_lens_file("thinlens.lens")
+    mask = np.ones((8, 8), np.float32)
+    g, cnt, og, ocnt = _run(pkg, lf, lens, 64, 64, 4, 99, mask,
+                            sun=dict(direction=[0.0, 0.0, -1.0], radiance=[1, 1, 1], angular_radius=0.1))
+    assert cnt == ocnt and np.array_equal(g, og)
+    assert cnt["rays_launched"] == 64 * 64 * 4 * 3 * 2
+    assert og.max() > 0
+
+
+def test_reference_pair_subset_and_no_primary(pkg, lf):
+    """The reference's own enumeration (pathtracer.cpp:735-762): pairs on one side of the stop."""
+    lens = pkg.load_lens_file("dgauss11.lens")
+    stop = lens["stop"]
+    pairs = [(i, j) for i in range(stop) for j in range(i + 1, stop)] + \
+            [(i, j) for i in range(stop + 1, lens["n"]) for j in range(i + 1, lens["n"])]
+    mask = load_texels("pentbiglines.png")
+    g, cnt, og, ocnt = _run(pkg, lf, lens, 40, 24, 8, 5, mask, pairs=pairs, primary=False)
+    assert cnt["rays_launched"] == 40 * 24 * 8 * 3 * len(pairs)
+    assert cnt == ocnt and np.array_equal(g, og)
+
+
+def test_band_sharding(pkg, lf):
+    """Rows [y0,y1) only: identical to the same rows of the full frame (the multi-GPU shard)."""
+    lens = pkg.load_lens_file("dgauss11.lens")
+    mask = load_texels("pentbig500_14.png")
+    g, cnt, og, ocnt = _run(pkg, lf, lens, 32, 24, 8, 11, mask, band=(5, 17))
+    assert cnt == ocnt
+    assert np.array_equal(g[5:17], og[5:17])
+    full, _ = lfo.geo_trace(lens, 32, 24, 0, 24, 8, 11, None, True, mask, SUN["direction"],
+                            SUN["radiance"], SUN["angular_radius"])
+    assert np.array_equal(g[5:17], full[5:17])
+
+
+def test_full_size_properties(pkg, lf):
+    """1080p, 4 spp, all pairs: too big for the oracle -> properties.
+    (a) counters are conserved: launched = clipped + vignetted + tir + reached_scene;
+    (b) executed events never exceed the nominal sum_pairs (N + 2(j-i)) = 875 + 11 per sample-lambda;
+    (c) determinism: same key -> identical bits; (d) linearity in the sun's radiance (x2, exact
+    in fixed point up to one ulp of the 2^-36 grid per contributing ray);
+    (e) a 64x36 crop of rows equals the oracle on those rows."""
+    lens = pkg.load_lens_file("dgauss11.lens")
+    mask = load_texels("pentbig500_14.png")
+    W, H, spp = 1920, 1080, 4
+    lf.set_frame(W, H)
+    lf.set_aperture(pkg.APERTURE_STARBURST, mask)
+    lf.set_lens(lens)
+    lf.set_sun(SUN["direction"], SUN["radiance"], SUN["angular_radius"])
+    lf.set_ghost_pairs(None, True)
+    lf.reset_counters()
+    lf.trace_ghosts(spp, 42)
+    a = lf.read_buffer(pkg.GHOST_BUFFER)
+    c = lf.counters()
+    assert c["rays_launched"] == W * H * spp * 3 * 46
+    assert c["rays_launched"] == (c["rays_clipped_stop"] + c["rays_vignetted"] + c["rays_tir"] +
+                                  c["rays_reached_scene"])
+    assert c["surface_events"] <= W * H * spp * 3 * (875 + 11)
+    assert c["rays_hit_light"] <= c["rays_reached_scene"]
+    lf.trace_ghosts(spp, 42)
+    assert np.array_equal(a, lf.read_buffer(pkg.GHOST_BUFFER))
+    lf.set_sun(SUN["direction"], [2 * v for v in SUN["radiance"]], SUN["angular_radius"])
+    lf.trace_ghosts(spp, 42)
+    b = lf.read_buffer(pkg.GHOST_BUFFER)
+    tol = 46 * 3 * 2.0 ** -36  # one grid step per contributing ray of a sample
+    assert np.all(np.abs(b - 2 * a) <= tol)
+    rows = (500, 502)
+    og, _ = lfo.geo_trace(lens, W, H, rows[0], rows[1], spp, 42, None, True, mask, SUN["direction"],
+                          SUN["radiance"], SUN["angular_radius"])
+    assert np.array_equal(a[rows[0]:rows[1]], og[rows[0]:rows[1]])
