@@ -1,0 +1,249 @@
+#!/usr/bin/env python3
+"""bench.py -- headline benchmark of the lens-flare hot path on MI355X.
+
+    python bench.py [--gpus N --steps K --warmup W]          (N=1)
+    python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N --steps K --warmup W
+
+Workload (BASELINE.json configs[2], the one its metric is quoted on): Double-Gauss 11-interface
+prescription (lens-flare_amd/data/dgauss11.lens), primary path + all 45 ghost pairs, 3 wavelengths,
+pentagon aperture mask (final_apertures/pentbig500_14.png), 1920x1080, 256 sensor samples/pixel,
+one synthetic sun at normalised screen position (0.521445, 0.517156).
+
+One step = one full frame of the hot path: find_sun_pos -> geometric ghost march (the dominant
+kernel) -> starburst/falloff/compose flare layer -> tonemap; with N > 1 the sensor rows are dealt to
+the ranks in interleaved 15-row chunks (strong scaling: the frame is fixed) and the finished chunks
+are exchanged with RCCL all-gathers over xGMI.  `value` = executed ray-surface events of the whole
+job per second (device counters, not an upper bound).  Inputs are resident in HBM before the timed
+region starts.
+"""
+import argparse
+import json
+import math
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+HBM_PEAK_GBS = 8000.0            # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
+VALU_PEAK_LANEOPS = 256 * 4 * 32 * 2.4e9   # 1024 SIMD-32 x 2.4 GHz (one wave64 VALU op / 2 clk)
+SUN_NS = (0.521445, 0.517156)
+CHUNK_ROWS = 15
+
+
+def load_mask():
+    from goldenlib import load_texels
+    return load_texels("pentbig500_14.png")
+
+
+def sun_direction(lens, W, H):
+    """Lens-space direction towards a sun that a pinhole of the lens' focal length images at
+    normalised screen position SUN_NS (same convention as Camera::analyze_world_coord)."""
+    efl = 50.358
+    ex = 0.5 * lens["sensor_width_mm"] / efl
+    ey = ex * H / W
+    return [(2 * SUN_NS[0] - 1) * ex, (2 * SUN_NS[1] - 1) * ey, -1.0]
+
+
+class DevView:
+    """Expose a device allocation of the library to torch (zero copy) for the RCCL gather."""
+
+    def __init__(self, ptr, n_doubles):
+        self.__cuda_array_interface__ = {"shape": (n_doubles,), "typestr": "<f8",
+                                         "data": (ptr, False), "version": 2}
+
+
+def cpu_baseline(lens, mask, sun, W, H, target_s):
+    """The CPU oracle (kind 'port': oracle/lf_geo_oracle.c) timed on this host's cores on a bounded
+    sample of the same workload: a band of rows of the same frame at reduced spp."""
+    from oracle import lfo
+    cores = min(os.cpu_count() or 1, 64)
+    rows = (H // 2 - 32, H // 2 + 32)
+    t0 = time.time()
+    _, c = lfo.geo_trace(lens, W, H, rows[0], rows[0] + 4, 1, 1, None, True, mask, sun,
+                         [1.0, 0.9, 0.5], 0.05, n_threads=cores)
+    dt = max(time.time() - t0, 1e-3)
+    rate = c["surface_events"] / dt
+    per_sample = c["surface_events"] / (4 * W)
+    spp = int(max(1, min(64, target_s * rate / (per_sample * (rows[1] - rows[0]) * W))))
+    t0 = time.time()
+    _, c = lfo.geo_trace(lens, W, H, rows[0], rows[1], spp, 1, None, True, mask, sun,
+                         [1.0, 0.9, 0.5], 0.05, n_threads=cores)
+    dt = time.time() - t0
+    return {"value": c["surface_events"] / dt / 1e6, "unit": "Mray-surface-intersections/s",
+            "cores": cores, "kind": "port",
+            "sample": f"rows {rows[0]}..{rows[1]} of the {W}x{H} frame, {spp} of the spp, "
+                      f"46 paths x 3 wavelengths, {c['surface_events']} events in {dt:.1f} s "
+                      f"(oracle/lf_geo_oracle.c, OpenMP)"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--width", type=int, default=1920)
+    ap.add_argument("--height", type=int, default=1080)
+    ap.add_argument("--spp", type=int, default=256)
+    ap.add_argument("--cpu-seconds", type=float, default=15.0)
+    ap.add_argument("--no-cpu", action="store_true")
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+    import __graft_entry__ as g
+    pkg = g.load_package()
+
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.gpus > 1 and world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} needs WORLD_SIZE={args.gpus} (launch with torch.distributed.run)")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU: the hot path has no CPU fallback")
+    torch.cuda.set_device(local)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+
+    W, H, spp = args.width, args.height, args.spp
+    lens = pkg.load_lens_file("dgauss11.lens")
+    mask = load_mask()
+    sun = sun_direction(lens, W, H)
+
+    cpu = None
+    if rank == 0 and world == 1 and not args.no_cpu:
+        cpu = cpu_baseline(lens, mask, sun, W, H, args.cpu_seconds)
+
+    lf = pkg.LensFlare(local)
+    lf.set_frame(W, H)
+    lf.set_params(1, 25.0, 1.0)
+    lf.set_aperture(pkg.APERTURE_STARBURST, mask)       # stop mask + starburst spectrum (set-up)
+    lf.set_aperture(pkg.APERTURE_GHOST, mask)
+    lf.set_lens(lens)
+    lf.set_sun(sun, [1.0, 0.9, 0.5], 0.05)
+    lf.set_ghost_pairs(None, True)
+    lf.set_jitter_counter(0x1e45f1a4e)
+    # camera looking down -z from the origin; the sun where analyze_world_coord puts SUN_NS
+    hf = 2 * math.degrees(math.atan(0.5 * lens["sensor_width_mm"] / 50.358))
+    vf = 2 * math.degrees(math.atan(math.tan(math.radians(hf) / 2) * H / W))
+    lf.set_camera(np.eye(3), [0, 0, 0], hf, vf)
+    ex, ey = math.tan(math.radians(hf) / 2), math.tan(math.radians(vf) / 2)
+    lights = [[(2 * SUN_NS[0] - 1) * ex * 10, (2 * SUN_NS[1] - 1) * ey * 10, -10.0, 1.0, 0.9, 0.5]]
+
+    # interleaved row chunks: chunk c belongs to rank c % world
+    n_chunks = (H + CHUNK_ROWS - 1) // CHUNK_ROWS
+    my_chunks = [c for c in range(n_chunks) if c % world == rank]
+    gather_ok = world > 1 and H % (CHUNK_ROWS * world) == 0
+    frames = {}
+    if world > 1:
+        for which in (pkg.SAMPLE_BUFFER,):
+            ptr, nbytes = lf.device_buffer(which)
+            frames[which] = torch.as_tensor(DevView(ptr, nbytes // 8), device=f"cuda:{local}")
+
+    def one_frame():
+        lf.find_sun_pos(lights)
+        for c in my_chunks:
+            lf.set_band(c * CHUNK_ROWS, min(H, (c + 1) * CHUNK_ROWS))
+            lf.trace_ghosts(spp, 0x1e45f1a4e)
+            lf.render_flare_layer()
+        lf.set_band(0, H)
+        if world > 1:
+            lf.synchronize()
+            t = frames[pkg.SAMPLE_BUFFER]
+            e = CHUNK_ROWS * W * 3
+            if gather_ok:
+                for grp in range(n_chunks // world):
+                    out = t[grp * world * e:(grp + 1) * world * e]
+                    dist.all_gather_into_tensor(out, out[rank * e:(rank + 1) * e])
+            else:
+                for c in range(n_chunks):
+                    sl = t[c * e:min((c + 1) * e, t.numel())]
+                    dist.broadcast(sl, src=c % world)
+
+    def barrier():
+        lf.synchronize()
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+            torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        one_frame()
+    barrier()
+    lf.reset_counters()
+    lf.timing_reset()
+    lf.timing_enable(True)
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        one_frame()
+    barrier()
+    dt = time.perf_counter() - t0
+    lf.timing_enable(False)
+
+    cnt = lf.counters()
+    n_launch, march_ms = lf.timing_get("march")
+    ev = torch.tensor([float(cnt["surface_events"]), float(cnt["rays_launched"]), dt],
+                      dtype=torch.float64, device=f"cuda:{local}")
+    if world > 1:
+        tot = ev.clone()
+        dist.all_reduce(tot[:2], op=dist.ReduceOp.SUM)
+        mx = ev[2:].clone()
+        dist.all_reduce(mx, op=dist.ReduceOp.MAX)
+        events, rays, dt = float(tot[0]), float(tot[1]), float(mx[0])
+    else:
+        events, rays = float(ev[0]), float(ev[1])
+
+    if rank == 0:
+        # roofline of the dominant kernel (the march): algorithmic HBM bytes per launch =
+        # framebuffer rows it writes (f64 RGB) + the aperture mask + the lens/pair tables it reads
+        rows_per_launch = min(CHUNK_ROWS, H)
+        alg_bytes = rows_per_launch * W * 24 + mask.size * 4 + 4096
+        avg_ms = march_ms / max(n_launch, 1)
+        achieved = alg_bytes / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0
+        traffic = None
+        tf = os.path.join(ROOT, "profiles", "r01_march_pmc.json")
+        if os.path.exists(tf):
+            try:
+                traffic = json.load(open(tf)).get("hbm_bytes_per_launch")
+            except Exception:
+                traffic = None
+        ev_per_launch = events / max(1, n_launch * world)
+        out = {
+            "metric": "Mray-surface-intersections/s + frame time, 1080p 256spp double-Gauss",
+            "value": events / dt / 1e6,
+            "unit": "Mray-surface-intersections/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": dt / args.steps * 1e3,
+            "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
+            "dtype": "f32", "data": "synthetic",
+            "config": {"workload": f"double-Gauss 11 interfaces (dgauss11.lens), primary + 45 ghost "
+                                   f"pairs x 3 wavelengths, pentagon mask pentbig500_14, {W}x{H}, "
+                                   f"{spp} spp, one sun (BASELINE.json configs[2])",
+                       "parallelism": f"{world} GPU(s), interleaved {CHUNK_ROWS}-row sensor chunks"
+                                      + (", RCCL all_gather" if world > 1 else ""),
+                       "rays_per_frame": rays / args.steps,
+                       "events_per_frame": events / args.steps},
+            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+                         "kernel": "k_march", "launches": n_launch, "avg_launch_ms": avg_ms,
+                         "algorithmic_bytes_per_launch": alg_bytes,
+                         "note": "register-resident march: compulsory traffic is O(frame); the "
+                                 "binding resource is FP32 VALU issue, see valu"},
+            "valu": {"events_per_s_per_gpu": ev_per_launch / (avg_ms * 1e-3) if avg_ms > 0 else 0.0,
+                     "lane_ops_peak_per_s": VALU_PEAK_LANEOPS},
+            "cpu_baseline": cpu,
+        }
+        print(json.dumps(out), flush=True)
+    lf.close()
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -571,7 +571,8 @@ lf_status lf_trace_ghosts(lf_ctx* ctx, int spp, uint64_t key) {
   if (!ctx || spp <= 0) return LF_ERR_INVALID;
   if (!ctx->lens_valid || !ctx->sun_valid)
     return lf_fail(ctx, LF_ERR_STATE, "lf_trace_ghosts needs lf_set_lens and lf_set_sun");
-  if (!ctx->ap[LF_APERTURE_GHOST].valid) return lf_fail(ctx, LF_ERR_STATE, "ghost aperture (stop mask) not set");
+  if (!ctx->ap[LF_APERTURE_STARBURST].valid)
+    return lf_fail(ctx, LF_ERR_STATE, "aperture mask (LF_APERTURE_STARBURST slot) not set");
   LF_HIP(ctx, hipSetDevice(ctx->device));
   lf_status st = lfk_march(ctx, spp, key);
   if (st != LF_OK) return st;

@@ -12,7 +12,7 @@
 // leaves the front element collects the sun's radiance through a smooth angular lobe.
 //
 // Arithmetic contract (DESIGN.md "march arithmetic"): float32, every multiply-add written as an
-// explicit fmaf, IEEE-correct division and square root (__fdiv_rn / __fsqrt_rn), no other libm.
+// explicit fmaf, IEEE-correct division and square root (__fdiv_rn / lf_sqrt), no other libm.
 // Contributions are accumulated as 2^-36 fixed point in 64-bit integers, so the result does not
 // depend on the order in which lanes finish.  The CPU oracle (oracle/lf_geo_oracle.c) follows the
 // same contract, which makes pixels and event counters comparable bit for bit.
@@ -37,6 +37,11 @@ __device__ __forceinline__ uint4 philox4x32_10(uint4 ctr, uint2 key) {
   return ctr;
 }
 
+// IEEE correctly rounded sqrt: plain sqrt under -fhip-fp32-correctly-rounded-divide-sqrt.
+// (ROCm's __fsqrt_rn maps to the 1-ulp hardware approximation unless
+// OCML_BASIC_ROUNDED_OPERATIONS is defined, which broke bit parity with the CPU in 1 ray of 10^4.)
+__device__ __forceinline__ float lf_sqrt(float x) { return __builtin_sqrtf(x); }
+
 __device__ __forceinline__ float u01(unsigned r) { return (float)(r >> 8) * 5.9604644775390625e-8f; }
 
 struct Ray {
@@ -58,7 +63,7 @@ __device__ __forceinline__ int surface_event(Ray& r, float zv, float c, float h2
   const float cF = c * F;
   const float disc = fmaf(G, G, -cF);
   if (disc < 0.0f) return DEAD_VIGNETTE;
-  const float sq = __fsqrt_rn(disc);
+  const float sq = lf_sqrt(disc);
   const float den = fwd ? G + sq : G - sq;
   const float t = __fdiv_rn(F, den);
   const float hx = fmaf(t, r.dx, r.px), hy = fmaf(t, r.dy, r.py), hz = fmaf(t, r.dz, oz);
@@ -71,7 +76,7 @@ __device__ __forceinline__ int surface_event(Ray& r, float zv, float c, float h2
   const float k2 = fmaf(-(eta * eta), s2, 1.0f);
   float R = 1.0f, ct = 0.0f;
   if (k2 >= 0.0f) {
-    ct = __fsqrt_rn(k2);
+    ct = lf_sqrt(k2);
     const float a = fmaf(eta, ci, -ct), b = fmaf(eta, ci, ct);
     const float e = fmaf(-eta, ct, ci), f = fmaf(eta, ct, ci);
     const float af = a * f, eb = e * b, bf = b * f;
@@ -171,7 +176,7 @@ __global__ __launch_bounds__(256) void k_march(const LfLensDev* __restrict__ len
       qy = wide ? rr * sn : rr * cs;
     }
     const float vx = fmaf(pupil_h, qx, -X), vy = fmaf(pupil_h, qy, -Y), vz = pupil_z - z_sensor;
-    const float len = __fsqrt_rn(fmaf(vx, vx, fmaf(vy, vy, vz * vz)));
+    const float len = lf_sqrt(fmaf(vx, vx, fmaf(vy, vy, vz * vz)));
     const float rl = __fdiv_rn(1.0f, len);
     const float d0x = vx * rl, d0y = vy * rl, d0z = vz * rl;
     const float c2 = d0z * d0z;
