@@ -302,6 +302,39 @@ int geo_trace_ray(const geo_lens* L, int lambda, int i, int j, float p[3], float
   return st;
 }
 
+/* Diagnostics for kernel design: alive[q][e] = rays of pair q still alive after e events
+ * (e = 0 .. 32), over `spp` samples of the pixels in rows [y0,y1), wavelength 1. */
+void geo_survival(const geo_lens* L, int W, int H, int y0, int y1, int spp, const uint32_t key[2],
+                  const int* pairs, int n_pairs, const float* mask, int mw, int mh,
+                  uint64_t* alive /* n_pairs x 33 */) {
+  geo_derived D;
+  derive(L, W, &D);
+  geo_step seq[3 * GEO_MAX_SURF];
+  memset(alive, 0, sizeof(uint64_t) * 33 * (size_t)n_pairs);
+  int l = L->n_lambda > 1 ? 1 : 0;
+  for (long long p = (long long)y0 * W; p < (long long)y1 * W; p++)
+    for (int s = 0; s < spp; s++) {
+      uint32_t ctr[4] = {(uint32_t)p, (uint32_t)s, 0x6e5f1a2eu, 0u}, rnd[4];
+      philox(ctr, key, rnd);
+      geo_ray r0;
+      start_ray(&D, W, H, (int)(p % W), (int)(p / W), rnd, &r0);
+      for (int q = 0; q < n_pairs; q++) {
+        int n = build_sequence(L->n_surf, pairs[2 * q], pairs[2 * q + 1], seq);
+        geo_ray r = r0;
+        alive[q * 33]++;
+        for (int e = 0; e < n; e++) {
+          int k = seq[e].k, st;
+          if (k == L->stop) st = stop_event(&r, D.zv[k], D.h2[k], D.inv_stop_h, mask, mw, mh);
+          else st = glass_event(&r, D.zv[k], D.curv[k], D.h2[k],
+                                seq[e].forward ? D.eta_fwd[l][k] : D.eta_bwd[l][k], seq[e].reflect,
+                                seq[e].forward);
+          if (st != OK_) break;
+          alive[q * 33 + e + 1]++;
+        }
+      }
+    }
+}
+
 float geo_z_sensor(const geo_lens* L) {
   geo_derived D;
   derive(L, 64, &D);
