@@ -10,9 +10,9 @@ pentagon aperture mask (final_apertures/pentbig500_14.png), 1920x1080, 256 senso
 one synthetic sun at normalised screen position (0.521445, 0.517156).
 
 One step = one full frame of the hot path: find_sun_pos -> geometric ghost march (the dominant
-kernel) -> starburst/falloff/compose flare layer -> tonemap; with N > 1 the sensor rows are dealt to
-the ranks in interleaved 15-row chunks (strong scaling: the frame is fixed) and the finished chunks
-are exchanged with RCCL all-gathers over xGMI.  `value` = executed ray-surface events of the whole
+kernel) -> starburst/falloff/compose flare layer; with N > 1 the 8-row sensor tile rows are dealt
+round-robin to the ranks (strong scaling: the frame is fixed) and the finished tile rows are
+exchanged with in-place RCCL all-gathers over xGMI.  `value` = executed ray-surface events of the whole
 job per second (device counters, not an upper bound).  Inputs are resident in HBM before the timed
 region starts.
 """
@@ -32,7 +32,7 @@ sys.path.insert(0, os.path.join(ROOT, "tests"))
 HBM_PEAK_GBS = 8000.0            # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
 VALU_PEAK_LANEOPS = 256 * 4 * 32 * 2.4e9   # 1024 SIMD-32 x 2.4 GHz (one wave64 VALU op / 2 clk)
 SUN_NS = (0.521445, 0.517156)
-CHUNK_ROWS = 15
+TILE_ROWS = 8   # the march kernel's sensor tile is 8x8 pixels
 
 
 def load_mask():
@@ -135,35 +135,30 @@ def main():
     ex, ey = math.tan(math.radians(hf) / 2), math.tan(math.radians(vf) / 2)
     lights = [[(2 * SUN_NS[0] - 1) * ex * 10, (2 * SUN_NS[1] - 1) * ey * 10, -10.0, 1.0, 0.9, 0.5]]
 
-    # interleaved row chunks: chunk c belongs to rank c % world
-    n_chunks = (H + CHUNK_ROWS - 1) // CHUNK_ROWS
-    my_chunks = [c for c in range(n_chunks) if c % world == rank]
-    gather_ok = world > 1 and H % (CHUNK_ROWS * world) == 0
-    frames = {}
+    # sensor tile rows (8 rows each) are dealt round-robin: tile row t belongs to rank t % world.
+    # One march launch per frame covers all of this rank's tile rows.
+    n_trows = (H + TILE_ROWS - 1) // TILE_ROWS
+    my_trows = len([t for t in range(n_trows) if t % world == rank])
+    lf.set_band(0, H)
+    lf.set_row_interleave(rank, world)
+    frame_t = None
     if world > 1:
-        for which in (pkg.SAMPLE_BUFFER,):
-            ptr, nbytes = lf.device_buffer(which)
-            frames[which] = torch.as_tensor(DevView(ptr, nbytes // 8), device=f"cuda:{local}")
+        ptr, nbytes = lf.device_buffer(pkg.SAMPLE_BUFFER)
+        frame_t = torch.as_tensor(DevView(ptr, nbytes // 8), device=f"cuda:{local}")
 
     def one_frame():
         lf.find_sun_pos(lights)
-        for c in my_chunks:
-            lf.set_band(c * CHUNK_ROWS, min(H, (c + 1) * CHUNK_ROWS))
-            lf.trace_ghosts(spp, 0x1e45f1a4e)
-            lf.render_flare_layer()
-        lf.set_band(0, H)
+        lf.trace_ghosts(spp, 0x1e45f1a4e)
+        lf.render_flare_layer()
         if world > 1:
+            # the real exchange step: every rank ends up with the whole frame.  A group of `world`
+            # consecutive tile rows is one in-place all-gather (rank r owns slot r of the group);
+            # the buffer is padded to 64 rows so the last group never runs past the end.
             lf.synchronize()
-            t = frames[pkg.SAMPLE_BUFFER]
-            e = CHUNK_ROWS * W * 3
-            if gather_ok:
-                for grp in range(n_chunks // world):
-                    out = t[grp * world * e:(grp + 1) * world * e]
-                    dist.all_gather_into_tensor(out, out[rank * e:(rank + 1) * e])
-            else:
-                for c in range(n_chunks):
-                    sl = t[c * e:min((c + 1) * e, t.numel())]
-                    dist.broadcast(sl, src=c % world)
+            e = TILE_ROWS * W * 3
+            for grp in range((n_trows + world - 1) // world):
+                out = frame_t[grp * world * e:(grp + 1) * world * e]
+                dist.all_gather_into_tensor(out, out[rank * e:(rank + 1) * e])
 
     def barrier():
         lf.synchronize()
@@ -202,7 +197,7 @@ def main():
     if rank == 0:
         # roofline of the dominant kernel (the march): algorithmic HBM bytes per launch =
         # framebuffer rows it writes (f64 RGB) + the aperture mask + the lens/pair tables it reads
-        rows_per_launch = min(CHUNK_ROWS, H)
+        rows_per_launch = min(my_trows * TILE_ROWS, H)
         alg_bytes = rows_per_launch * W * 24 + mask.size * 4 + 4096
         avg_ms = march_ms / max(n_launch, 1)
         achieved = alg_bytes / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0
@@ -225,8 +220,9 @@ def main():
             "config": {"workload": f"double-Gauss 11 interfaces (dgauss11.lens), primary + 45 ghost "
                                    f"pairs x 3 wavelengths, pentagon mask pentbig500_14, {W}x{H}, "
                                    f"{spp} spp, one sun (BASELINE.json configs[2])",
-                       "parallelism": f"{world} GPU(s), interleaved {CHUNK_ROWS}-row sensor chunks"
-                                      + (", RCCL all_gather" if world > 1 else ""),
+                       "parallelism": f"{world} GPU(s), 8-row sensor tile rows dealt round-robin"
+                                      + (", RCCL in-place all_gather per tile-row group"
+                                         if world > 1 else ""),
                        "rays_per_frame": rays / args.steps,
                        "events_per_frame": events / args.steps},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",

@@ -77,6 +77,10 @@ lf_status lf_set_frame(lf_ctx* ctx, int width, int height);
 /* multi-GPU sharding: this context renders sensor rows [y0, y1) only (default: all rows).
  * Mirrors the tile queue of raytraced_renderer.cpp:314-328, one band of tile rows per GPU. */
 lf_status lf_set_band(lf_ctx* ctx, int y0, int y1);
+/* finer multi-GPU sharding for the geometric march: of the band's 8-row sensor tile rows t = y/8
+ * this context marches only those with t % period == phase (default period 1 = all).  Dealing
+ * tile rows round-robin to the GPUs balances the vignetting-dependent ray survival. */
+lf_status lf_set_row_interleave(lf_ctx* ctx, int phase, int period);
 /* replaces the public fields PathTracer::ns_aa, flare_radius, flare_intensity
  * (pathtracer.h:93-94,107) */
 lf_status lf_set_params(lf_ctx* ctx, int ns_aa, double flare_radius, double flare_intensity);
@@ -140,7 +144,9 @@ lf_status lf_read_pixel(lf_ctx* ctx, int which, int x, int y, double rgb[3]);
 lf_status lf_write_to_framebuffer(lf_ctx* ctx, int x0, int y0, int x1, int y1, uint32_t* dst,
                                   size_t row_stride);
 /* device pointer of a buffer (for RCCL gathers over xGMI without a host hop);
- * which as in lf_read_tile; layout W*H*3 doubles row-major */
+ * which as in lf_read_tile; layout W*H*3 doubles row-major.  The allocation is padded to a
+ * multiple of 64 rows (bytes reports the padded size) so that in-place all-gathers of whole
+ * tile-row groups never run past the end. */
 lf_status lf_device_buffer(lf_ctx* ctx, int which, void** dptr, size_t* bytes);
 
 /* ---------------------------------------------------------------- geometric lens --------- */

@@ -25,7 +25,7 @@ SAMPLE_BUFFER, GHOST_BUFFER = 0, 1
 # every symbol include/lensflare.h declares
 ABI_SYMBOLS = [
     "lf_create", "lf_destroy", "lf_last_error", "lf_abi_version", "lf_set_stream", "lf_synchronize",
-    "lf_set_frame", "lf_set_band", "lf_set_params", "lf_set_aperture", "lf_get_aperture_stats",
+    "lf_set_frame", "lf_set_band", "lf_set_row_interleave", "lf_set_params", "lf_set_aperture", "lf_get_aperture_stats",
     "lf_set_paraxial_lens", "lf_set_camera", "lf_find_sun_pos", "lf_set_flares", "lf_get_flares",
     "lf_set_jitter_mt19937", "lf_set_jitter_counter", "lf_set_scene_term",
     "lf_generate_ghost_buffer", "lf_render_flare_layer", "lf_read_tile", "lf_read_pixel",
@@ -141,6 +141,9 @@ class LensFlare:
 
     def set_band(self, y0, y1):
         self._ck(self.lib.lf_set_band(self.ctx, int(y0), int(y1)))
+
+    def set_row_interleave(self, phase, period):
+        self._ck(self.lib.lf_set_row_interleave(self.ctx, int(phase), int(period)))
 
     def set_params(self, ns_aa=1, flare_radius=25.0, flare_intensity=1.0):
         self._ck(self.lib.lf_set_params(self.ctx, int(ns_aa), C.c_double(flare_radius),

@@ -192,7 +192,9 @@ lf_status lf_set_frame(lf_ctx* ctx, int width, int height) {
   LF_HIP(ctx, hipStreamSynchronize(ctx->stream));
   free_frame_buffers(ctx);
   ctx->W = width; ctx->H = height; ctx->y0 = 0; ctx->y1 = height;
-  size_t n = (size_t)width * height;
+  ctx->H_alloc = (height + 63) / 64 * 64;
+  ctx->row_period = 1; ctx->row_phase = 0;
+  size_t n = (size_t)width * ctx->H_alloc;
   lf_status st;
   if ((st = dev_alloc(ctx, &ctx->sample, 3 * n)) != LF_OK) return st;
   if ((st = dev_alloc(ctx, &ctx->ghost, 3 * n)) != LF_OK) return st;
@@ -208,6 +210,14 @@ lf_status lf_set_band(lf_ctx* ctx, int y0, int y1) {
   if (ctx->W == 0) return lf_fail(ctx, LF_ERR_STATE, "lf_set_band before lf_set_frame");
   if (y0 < 0 || y1 > ctx->H || y0 > y1) return lf_fail(ctx, LF_ERR_INVALID, "band out of range");
   ctx->y0 = y0; ctx->y1 = y1;
+  return LF_OK;
+}
+
+lf_status lf_set_row_interleave(lf_ctx* ctx, int phase, int period) {
+  if (!ctx) return LF_ERR_INVALID;
+  if (period < 1 || phase < 0 || phase >= period)
+    return lf_fail(ctx, LF_ERR_INVALID, "row interleave: need 0 <= phase < period");
+  ctx->row_phase = phase; ctx->row_period = period;
   return LF_OK;
 }
 
@@ -489,7 +499,7 @@ lf_status lf_device_buffer(lf_ctx* ctx, int which, void** dptr, size_t* bytes) {
   if (!ctx || !dptr || (which != 0 && which != 1)) return LF_ERR_INVALID;
   if (ctx->W == 0) return lf_fail(ctx, LF_ERR_STATE, "lf_device_buffer before lf_set_frame");
   *dptr = which == 0 ? ctx->sample : ctx->ghost;
-  if (bytes) *bytes = (size_t)ctx->W * ctx->H * 3 * sizeof(double);
+  if (bytes) *bytes = (size_t)ctx->W * ctx->H_alloc * 3 * sizeof(double);
   return LF_OK;
 }
 

@@ -112,6 +112,8 @@ struct lf_ctx {
   mutable std::string err;
 
   int W = 0, H = 0, y0 = 0, y1 = 0;
+  int H_alloc = 0;                     // rows allocated (H rounded up to 64) for in-place gathers
+  int row_period = 1, row_phase = 0;   // tile rows t (8 sensor rows) with t % period == phase
   int ns_aa = 1;
   double flare_radius = 25.0, flare_intensity = 1.0;
 

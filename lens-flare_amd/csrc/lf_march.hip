@@ -11,6 +11,19 @@
 // stop is a flat pass-through interface whose event is the aperture-mask lookup.  A ray that
 // leaves the front element collects the sun's radiance through a smooth angular lobe.
 //
+// Mapping to CDNA4 (v2, "coherent wavefronts by construction"):
+//   * one wave = one 8x8 sensor tile, one lane = one pixel; the wave walks sample index s,
+//     wavelength and ghost pair together, so the interface sequence is wave-uniform and every
+//     per-interface constant comes from the scalar cache into SGPRs (no LDS/VGPR traffic for the
+//     lens table at all);
+//   * the pupil is stratified (G x G cells, G = floor(sqrt(spp))): sample s of EVERY pixel aims at
+//     cell s, jittered per pixel.  All 64 lanes of a wave therefore cross the stop in the same
+//     1/G^2 patch of the aperture mask and are clipped (or not) together -- the profile of v1
+//     (profiles/r01_v1_*) showed 58 % of VALU lanes idle because random pupil points made lanes
+//     die at different events; a wave whose lanes are all dead leaves the sequence at once;
+//   * the 4 waves of a workgroup share the tile and split the sample indices; per-pixel sums are
+//     64-bit fixed point in registers, merged through LDS, written once per tile.
+//
 // Arithmetic contract (DESIGN.md "march arithmetic"): float32, every multiply-add written as an
 // explicit fmaf, IEEE-correct division and square root (__fdiv_rn / lf_sqrt), no other libm.
 // Contributions are accumulated as 2^-36 fixed point in 64-bit integers, so the result does not
@@ -49,12 +62,11 @@ struct Ray {
 };
 
 enum { EV_REFRACT = 0, EV_REFLECT = 1 };
-// death causes (per-lane bookkeeping for the counters)
 enum { ALIVE = 0, DEAD_STOP = 1, DEAD_VIGNETTE = 2, DEAD_TIR = 3 };
 
 // one glass-surface event; returns the new liveness
 __device__ __forceinline__ int surface_event(Ray& r, float zv, float c, float h2, float eta,
-                                             int mode, bool fwd) {
+                                             bool reflect, bool fwd) {
   const float oz = r.pz - zv;
   const float od = fmaf(r.px, r.dx, fmaf(r.py, r.dy, oz * r.dz));
   const float oo = fmaf(r.px, r.px, fmaf(r.py, r.py, oz * oz));
@@ -81,10 +93,10 @@ __device__ __forceinline__ int surface_event(Ray& r, float zv, float c, float h2
     const float e = fmaf(-eta, ct, ci), f = fmaf(eta, ct, ci);
     const float af = a * f, eb = e * b, bf = b * f;
     R = __fdiv_rn(0.5f * fmaf(af, af, eb * eb), bf * bf);
-  } else if (mode == EV_REFRACT) {
+  } else if (!reflect) {
     return DEAD_TIR;
   }
-  if (mode == EV_REFRACT) {
+  if (!reflect) {
     r.w *= (1.0f - R);
     const float g = fmaf(-eta, mu, copysignf(ct, mu));
     r.dx = fmaf(eta, r.dx, g * nx);
@@ -120,146 +132,152 @@ __device__ __forceinline__ int stop_event(Ray& r, float zv, float h2, float inv_
   return ALIVE;
 }
 
-struct LaneStats {
-  unsigned events = 0, launched = 0, clip = 0, vign = 0, tir = 0, scene = 0, light = 0;
+struct MarchArgs {
+  int mw, mh, W, H, y0, y1;
+  int spp, G;          // G x G pupil strata, G = floor(sqrt(spp))
+  float inv_G;
+  int trow0, tperiod;  // tile rows handled: trow0 + j * tperiod, j = 0 ..
+  uint2 key;
 };
 
 __global__ __launch_bounds__(256) void k_march(const LfLensDev* __restrict__ lens,
                                                const LfPairsDev* __restrict__ pairs,
-                                               const float* __restrict__ mask, int mw, int mh,
-                                               int W, int H, int y0, int y1, int spp, int ppb,
-                                               uint2 key, double* __restrict__ ghost,
+                                               const float* __restrict__ mask, MarchArgs a,
+                                               double* __restrict__ ghost,
                                                unsigned long long* __restrict__ counters) {
-  __shared__ unsigned long long s_acc[256 * 3];
+  __shared__ unsigned long long s_acc[64 * 3];
   __shared__ unsigned long long s_cnt[8];
-  const int tid = threadIdx.x;
-  for (int i = tid; i < ppb * 3; i += 256) s_acc[i] = 0ull;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  if (tid < 64 * 3) s_acc[tid] = 0ull;
   if (tid < 8) s_cnt[tid] = 0ull;
   __syncthreads();
 
-  const size_t band_px = (size_t)(y1 - y0) * W;
-  const size_t first_px = (size_t)blockIdx.x * ppb;  // band-relative
+  const int tiles_x = (a.W + 7) >> 3;
+  const int tx = blockIdx.x % tiles_x, tj = blockIdx.x / tiles_x;
+  const int x = tx * 8 + (lane & 7);
+  const int y = (a.trow0 + tj * a.tperiod) * 8 + (lane >> 3);
+  const bool active = x < a.W && y >= a.y0 && y < a.y1;
+  const unsigned p = (unsigned)y * (unsigned)a.W + (unsigned)x;
+
   const int n_surf = lens->n_surf, n_lambda = lens->n_lambda, n_pairs = pairs->n;
   const float z_sensor = lens->z_sensor, pitch = lens->pitch, pupil_h = lens->pupil_h;
   const float pupil_z = lens->pupil_z, geom_norm = lens->geom_norm;
   const float inv_stop_h = __fdiv_rn(1.0f, lens->stop_h);
   const float sx = lens->sun_dir[0], sy = lens->sun_dir[1], sz = lens->sun_dir[2];
   const float inv_1mc = lens->sun_inv_one_minus_cos;
-  LaneStats st;
+  const int GG = a.G * a.G;
 
-  const int block_samples = ppb * spp;
-  for (int id = tid; id < block_samples; id += 256) {
-    const int lp = id / spp, s = id - lp * spp;
-    const size_t bp = first_px + lp;
-    if (bp >= band_px) break;
-    const size_t p = (size_t)y0 * W + bp;
-    const int x = (int)(p % W), y = (int)(p / W);
+  unsigned events = 0, n_clip = 0, n_vign = 0, n_tir = 0, n_scene = 0, n_light = 0, n_launched = 0;
+  unsigned long long acc[3] = {0ull, 0ull, 0ull};
 
-    // ---- sensor sample -> initial ray ----------------------------------------------------
-    const uint4 rnd = philox4x32_10(make_uint4((unsigned)p, (unsigned)s, kDomainMarch, 0u), key);
-    const float jx = u01(rnd.x), jy = u01(rnd.y);
-    const float pa = fmaf(2.0f, u01(rnd.z), -1.0f), pb = fmaf(2.0f, u01(rnd.w), -1.0f);
-    const float X = -(((float)x + jx) - 0.5f * (float)W) * pitch;
-    const float Y = -(((float)y + jy) - 0.5f * (float)H) * pitch;
-    // concentric square -> disc map; sin/cos of (pi/4)*t by fixed polynomials (fmaf only)
-    float qx = 0.0f, qy = 0.0f;
-    if (pa != 0.0f || pb != 0.0f) {
-      const bool wide = fabsf(pa) > fabsf(pb);
-      const float rr = wide ? pa : pb;
-      const float th = 0.78539816339744831f * __fdiv_rn(wide ? pb : pa, rr);
-      const float t2 = th * th;
-      const float sn = th * fmaf(t2, fmaf(t2, fmaf(t2, fmaf(t2, 2.7557319e-6f, -1.9841270e-4f),
-                                                   8.3333333e-3f), -1.6666667e-1f), 1.0f);
-      const float cs = fmaf(t2, fmaf(t2, fmaf(t2, fmaf(t2, 2.4801587e-5f, -1.3888889e-3f),
-                                              4.1666667e-2f), -0.5f), 1.0f);
-      qx = wide ? rr * cs : rr * sn;
-      qy = wide ? rr * sn : rr * cs;
-    }
-    const float vx = fmaf(pupil_h, qx, -X), vy = fmaf(pupil_h, qy, -Y), vz = pupil_z - z_sensor;
-    const float len = lf_sqrt(fmaf(vx, vx, fmaf(vy, vy, vz * vz)));
-    const float rl = __fdiv_rn(1.0f, len);
-    const float d0x = vx * rl, d0y = vy * rl, d0z = vz * rl;
-    const float c2 = d0z * d0z;
-    const float w0 = geom_norm * (c2 * c2);
+  if (active) {
+    for (int s = wave; s < a.spp; s += 4) {  // wave-uniform
+      // ---- sensor sample -> initial ray --------------------------------------------------
+      const uint4 rnd = philox4x32_10(make_uint4(p, (unsigned)s, kDomainMarch, 0u), a.key);
+      const float jx = u01(rnd.x), jy = u01(rnd.y);
+      float ua = u01(rnd.z), ub = u01(rnd.w);
+      if (s < GG) {  // stratum (s % G, s / G) of the pupil square
+        const int cy = s / a.G, cx = s - cy * a.G;
+        ua = ((float)cx + ua) * a.inv_G;
+        ub = ((float)cy + ub) * a.inv_G;
+      }
+      const float pa = fmaf(2.0f, ua, -1.0f), pb = fmaf(2.0f, ub, -1.0f);
+      const float X = -(((float)x + jx) - 0.5f * (float)a.W) * pitch;
+      const float Y = -(((float)y + jy) - 0.5f * (float)a.H) * pitch;
+      // concentric square -> disc map; sin/cos of (pi/4)*t by fixed polynomials (fmaf only)
+      float qx = 0.0f, qy = 0.0f;
+      if (pa != 0.0f || pb != 0.0f) {
+        const bool wide = fabsf(pa) > fabsf(pb);
+        const float rr = wide ? pa : pb;
+        const float th = 0.78539816339744831f * __fdiv_rn(wide ? pb : pa, rr);
+        const float t2 = th * th;
+        const float sn = th * fmaf(t2, fmaf(t2, fmaf(t2, fmaf(t2, 2.7557319e-6f, -1.9841270e-4f),
+                                                     8.3333333e-3f), -1.6666667e-1f), 1.0f);
+        const float cs = fmaf(t2, fmaf(t2, fmaf(t2, fmaf(t2, 2.4801587e-5f, -1.3888889e-3f),
+                                                4.1666667e-2f), -0.5f), 1.0f);
+        qx = wide ? rr * cs : rr * sn;
+        qy = wide ? rr * sn : rr * cs;
+      }
+      const float vx = fmaf(pupil_h, qx, -X), vy = fmaf(pupil_h, qy, -Y), vz = pupil_z - z_sensor;
+      const float len = lf_sqrt(fmaf(vx, vx, fmaf(vy, vy, vz * vz)));
+      const float rl = __fdiv_rn(1.0f, len);
+      const float d0x = vx * rl, d0y = vy * rl, d0z = vz * rl;
+      const float c2 = d0z * d0z;
+      const float w0 = geom_norm * (c2 * c2);
+      n_launched += (unsigned)(n_lambda * n_pairs);
 
-    unsigned long long acc[3] = {0ull, 0ull, 0ull};
-    for (int l = 0; l < n_lambda; l++) {
-      float lobe_sum = 0.0f;  // per-wavelength radiance factor is applied once per pair below
-      (void)lobe_sum;
-      for (int q = 0; q < n_pairs; q++) {
-        const int pi = pairs->ij[q][0], pj = pairs->ij[q][1];  // wave-uniform
-        Ray r{X, Y, z_sensor, d0x, d0y, d0z, w0};
-        int dead = ALIVE;
-        st.launched++;
-        // leg boundaries: backwards N-1..lo1, [reflect i], forwards i+1..j-1, [reflect j],
-        // backwards j-1..0.  The primary path is one backward leg N-1..0.
-        const int n_legs = pi < 0 ? 1 : 3;
-        for (int leg = 0; leg < n_legs && dead == ALIVE; leg++) {
-          const bool fwd = (leg == 1);
-          int k, k_end, refl;
-          if (leg == 0) { k = n_surf - 1; k_end = pi < 0 ? 0 : pi; refl = pi; }
-          else if (leg == 1) { k = pi + 1; k_end = pj; refl = pj; }
-          else { k = pj - 1; k_end = 0; refl = -1; }
-          const int step = fwd ? 1 : -1;
-          for (;; k += step) {
-            if (fwd ? k > k_end : k < k_end) break;
-            const LfSurfaceDev& sf = lens->surf[k];
-            if (sf.is_stop != 0.0f) {
-              dead = stop_event(r, sf.zv, sf.h2, inv_stop_h, mask, mw, mh);
-            } else {
-              const float eta = fwd ? sf.eta_fwd[l] : sf.eta_bwd[l];
-              dead = surface_event(r, sf.zv, sf.curv, sf.h2, eta,
-                                   k == refl ? EV_REFLECT : EV_REFRACT, fwd);
+      for (int l = 0; l < n_lambda; l++) {
+        for (int q = 0; q < n_pairs; q++) {
+          const int pi = pairs->ij[q][0], pj = pairs->ij[q][1];  // wave-uniform (SGPR)
+          Ray r{X, Y, z_sensor, d0x, d0y, d0z, w0};
+          int dead = ALIVE;
+          // legs: backwards N-1..i (reflect at i), forwards i+1..j (reflect at j), backwards
+          // j-1..0.  The primary path (i < 0) is one backward leg N-1..0.
+          const int n_legs = pi < 0 ? 1 : 3;
+          for (int leg = 0; leg < n_legs; leg++) {
+            const bool fwd = (leg == 1);
+            int k, k_end, refl;
+            if (leg == 0) { k = n_surf - 1; k_end = pi < 0 ? 0 : pi; refl = pi; }
+            else if (leg == 1) { k = pi + 1; k_end = pj; refl = pj; }
+            else { k = pj - 1; k_end = 0; refl = -1; }
+            const int step = fwd ? 1 : -1;
+            for (; fwd ? k <= k_end : k >= k_end; k += step) {
+              const LfSurfaceDev& sf = lens->surf[k];  // wave-uniform -> s_load
+              if (sf.is_stop != 0.0f) {
+                dead = stop_event(r, sf.zv, sf.h2, inv_stop_h, mask, a.mw, a.mh);
+              } else {
+                const float eta = fwd ? sf.eta_fwd[l] : sf.eta_bwd[l];
+                dead = surface_event(r, sf.zv, sf.curv, sf.h2, eta, k == refl, fwd);
+              }
+              if (dead != ALIVE) break;
+              events++;
             }
             if (dead != ALIVE) break;
-            st.events++;
           }
-        }
-        if (dead == ALIVE) {
-          st.scene++;
-          const float cg = fmaf(r.dx, sx, fmaf(r.dy, sy, r.dz * sz));
-          const float qq = (1.0f - cg) * inv_1mc;
-          if (qq < 1.0f) {
-            const float om = 1.0f - qq;
-            const float contrib = r.w * (om * om);
-            if (contrib > 0.0f) {
-              st.light++;
+          if (dead == ALIVE) {
+            n_scene++;
+            const float cg = fmaf(r.dx, sx, fmaf(r.dy, sy, r.dz * sz));
+            const float qq = (1.0f - cg) * inv_1mc;
+            if (qq < 1.0f) {
+              const float om = 1.0f - qq;
+              const float contrib = r.w * (om * om);
+              if (contrib > 0.0f) {
+                n_light++;
 #pragma unroll
-              for (int c = 0; c < 3; c++) {
-                const float v = contrib * (lens->sun_radiance[c] * lens->lambda_rgb[l][c]);
-                acc[c] += (unsigned long long)(v * kFixScale);
+                for (int c = 0; c < 3; c++) {
+                  const float v = contrib * (lens->sun_radiance[c] * lens->lambda_rgb[l][c]);
+                  acc[c] += (unsigned long long)(v * kFixScale);
+                }
               }
             }
-          }
-        } else if (dead == DEAD_STOP) st.clip++;
-        else if (dead == DEAD_VIGNETTE) st.vign++;
-        else st.tir++;
+          } else if (dead == DEAD_STOP) n_clip++;
+          else if (dead == DEAD_VIGNETTE) n_vign++;
+          else n_tir++;
+        }
       }
     }
 #pragma unroll
     for (int c = 0; c < 3; c++)
-      if (acc[c]) atomicAdd(&s_acc[lp * 3 + c], acc[c]);
+      if (acc[c]) atomicAdd(&s_acc[lane * 3 + c], acc[c]);
   }
 
   // ---- counters: wave reduce, one LDS add per wave, one global add per workgroup ------------
-  unsigned vals[7] = {st.launched, st.events, st.clip, st.vign, st.tir, st.scene, st.light};
+  unsigned vals[7] = {n_launched, events, n_clip, n_vign, n_tir, n_scene, n_light};
 #pragma unroll
   for (int i = 0; i < 7; i++) {
     unsigned long long v = vals[i];
     for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off);
-    if ((tid & 63) == 0 && v) atomicAdd(&s_cnt[i], v);
+    if (lane == 0 && v) atomicAdd(&s_cnt[i], v);
   }
   __syncthreads();
   if (tid < 7 && s_cnt[tid]) atomicAdd(&counters[tid], s_cnt[tid]);
 
-  // ---- one coalesced write of the tile's pixels ---------------------------------------------
-  for (int i = tid; i < ppb * 3; i += 256) {
-    const size_t bp = first_px + i / 3;
-    if (bp < band_px) {
-      const size_t p = (size_t)y0 * W + bp;
-      ghost[3 * p + (i % 3)] =
-          ((double)s_acc[i] * (1.0 / 68719476736.0)) / (double)spp;
-    }
+  // ---- the tile's pixels: 8 rows of 8 x 24 contiguous bytes -----------------------------------
+  if (wave == 0 && active) {
+#pragma unroll
+    for (int c = 0; c < 3; c++)
+      ghost[3 * (size_t)p + c] =
+          ((double)s_acc[lane * 3 + c] * (1.0 / 68719476736.0)) / (double)a.spp;
   }
 }
 
@@ -271,7 +289,7 @@ void lf_derive_lens(lf_ctx* ctx, int n, int stop, int n_lambda, const float* rad
                     const float* thickness, const float* ior, const float* semi_ap,
                     float sensor_w_mm) {
   LfLensDev& L = ctx->lens;
-  // keep the sun / lambda weights across a lens change
+  // keep the sun across a lens change
   float keep_sun_dir[3], keep_sun_rad[3], keep_inv = L.sun_inv_one_minus_cos;
   for (int c = 0; c < 3; c++) { keep_sun_dir[c] = L.sun_dir[c]; keep_sun_rad[c] = L.sun_radiance[c]; }
   std::memset(&L, 0, sizeof(L));
@@ -314,16 +332,27 @@ lf_status lfk_march(lf_ctx* ctx, int spp, uint64_t key) {
                              ctx->stream));
   LF_HIP(ctx, hipMemcpyAsync(ctx->pairs_dev, &ctx->pairs, sizeof(LfPairsDev), hipMemcpyHostToDevice,
                              ctx->stream));
-  const int ppb = spp >= 256 ? 1 : 256 / spp;
-  const size_t band_px = (size_t)(ctx->y1 - ctx->y0) * ctx->W;
-  if (band_px == 0) return LF_OK;
-  const size_t blocks = (band_px + ppb - 1) / ppb;
+  if (ctx->y1 <= ctx->y0) return LF_OK;
+  MarchArgs a;
+  a.mw = m.w; a.mh = m.h; a.W = ctx->W; a.H = ctx->H; a.y0 = ctx->y0; a.y1 = ctx->y1;
+  a.spp = spp;
+  a.G = (int)std::floor(std::sqrt((double)spp));
+  while ((a.G + 1) * (a.G + 1) <= spp) a.G++;
+  while (a.G * a.G > spp) a.G--;
+  a.inv_G = 1.0f / (float)a.G;
+  a.key = make_uint2((unsigned)key, (unsigned)(key >> 32));
+  // tile rows (8 sensor rows each) of the band that belong to this context's interleave phase
+  const int t_lo = ctx->y0 / 8, t_hi = (ctx->y1 + 7) / 8;  // [t_lo, t_hi)
+  const int period = ctx->row_period, phase = ctx->row_phase;
+  int first = t_lo + ((phase - t_lo) % period + period) % period;
+  if (first >= t_hi) return LF_OK;
+  const int n_trows = (t_hi - 1 - first) / period + 1;
+  a.trow0 = first; a.tperiod = period;
+  const size_t blocks = (size_t)n_trows * ((ctx->W + 7) / 8);
   if (blocks > 0x7fffffffull) return lf_fail(ctx, LF_ERR_INVALID, "band too large for one launch");
   hipEvent_t ev = lf_timing_begin(ctx, LFK_MARCH);
   hipLaunchKernelGGL(k_march, dim3((unsigned)blocks), dim3(256), 0, ctx->stream, ctx->lens_dev,
-                     ctx->pairs_dev, m.texels, m.w, m.h, ctx->W, ctx->H, ctx->y0, ctx->y1, spp, ppb,
-                     make_uint2((unsigned)key, (unsigned)(key >> 32)), ctx->ghost,
-                     ctx->counters_dev);
+                     ctx->pairs_dev, m.texels, a, ctx->ghost, ctx->counters_dev);
   lf_timing_end(ctx, LFK_MARCH, ev);
   LF_HIP(ctx, hipGetLastError());
   return LF_OK;

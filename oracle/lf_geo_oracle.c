@@ -175,10 +175,25 @@ static int build_sequence(int n_surf, int i, int j, geo_step* seq) {
 }
 
 /* sensor sample -> ray on the sensor aimed at the rear pupil.  Returns the start weight. */
-static float start_ray(const geo_derived* D, int W, int H, int x, int y, const uint32_t rnd[4],
-                       geo_ray* r) {
+/* pupil strata: G x G cells, G = floor(sqrt(spp)); sample s < G*G aims at cell (s % G, s / G) */
+static int strata(int spp) {
+  int g = (int)floor(sqrt((double)spp));
+  while ((g + 1) * (g + 1) <= spp) g++;
+  while (g * g > spp) g--;
+  return g;
+}
+
+static float start_ray(const geo_derived* D, int W, int H, int x, int y, int s, int G,
+                       const uint32_t rnd[4], geo_ray* r) {
   float jx = unit24(rnd[0]), jy = unit24(rnd[1]);
-  float pa = fmaf(2.0f, unit24(rnd[2]), -1.0f), pb = fmaf(2.0f, unit24(rnd[3]), -1.0f);
+  float ua = unit24(rnd[2]), ub = unit24(rnd[3]);
+  if (s < G * G) {
+    float inv_g = 1.0f / (float)G;
+    int cy = s / G, cx = s - cy * G;
+    ua = ((float)cx + ua) * inv_g;
+    ub = ((float)cy + ub) * inv_g;
+  }
+  float pa = fmaf(2.0f, ua, -1.0f), pb = fmaf(2.0f, ub, -1.0f);
   float X = -(((float)x + jx) - 0.5f * (float)W) * D->pitch;
   float Y = -(((float)y + jy) - 0.5f * (float)H) * D->pitch;
   float qx = 0.0f, qy = 0.0f;
@@ -227,7 +242,7 @@ void geo_trace(const geo_lens* L, int W, int H, int y0, int y1, int spp, const u
         uint32_t ctr[4] = {(uint32_t)p, (uint32_t)s, 0x6e5f1a2eu, 0u}, rnd[4];
         philox(ctr, key, rnd);
         geo_ray r0;
-        start_ray(&D, W, H, x, y, rnd, &r0);
+        start_ray(&D, W, H, x, y, s, strata(spp), rnd, &r0);
         for (int l = 0; l < L->n_lambda; l++)
           for (int q = 0; q < n_pairs; q++) {
             int n = build_sequence(L->n_surf, pairs[2 * q], pairs[2 * q + 1], seq);
@@ -317,7 +332,7 @@ void geo_survival(const geo_lens* L, int W, int H, int y0, int y1, int spp, cons
       uint32_t ctr[4] = {(uint32_t)p, (uint32_t)s, 0x6e5f1a2eu, 0u}, rnd[4];
       philox(ctr, key, rnd);
       geo_ray r0;
-      start_ray(&D, W, H, (int)(p % W), (int)(p / W), rnd, &r0);
+      start_ray(&D, W, H, (int)(p % W), (int)(p / W), s, strata(spp), rnd, &r0);
       for (int q = 0; q < n_pairs; q++) {
         int n = build_sequence(L->n_surf, pairs[2 * q], pairs[2 * q + 1], seq);
         geo_ray r = r0;

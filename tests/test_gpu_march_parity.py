@@ -125,3 +125,23 @@ def test_full_size_properties(pkg, lf):
     og, _ = lfo.geo_trace(lens, W, H, rows[0], rows[1], spp, 42, None, True, mask, SUN["direction"],
                           SUN["radiance"], SUN["angular_radius"])
     assert np.array_equal(a[rows[0]:rows[1]], og[rows[0]:rows[1]])
+
+
+def test_tile_row_interleave_reassembles_frame(pkg, lf):
+    """lf_set_row_interleave (the N-GPU deal of 8-row tile rows): phases 0..2 of period 3, rendered
+    one after the other into the same buffer, give exactly the single-launch frame; counters add."""
+    lens = pkg.load_lens_file("dgauss11.lens")
+    mask = load_texels("pentbig500_14.png")
+    W, H, spp = 40, 52, 9   # 7 tile rows, the last one partial
+    g, cnt, og, ocnt = _run(pkg, lf, lens, W, H, spp, 3, mask)
+    assert np.array_equal(g, og) and cnt == ocnt
+    lf.set_frame(W, H)
+    lf.set_lens(lens)
+    lf.set_ghost_pairs(None, True)
+    lf.reset_counters()
+    for phase in range(3):
+        lf.set_row_interleave(phase, 3)
+        lf.trace_ghosts(spp, 3)
+    lf.set_row_interleave(0, 1)
+    assert np.array_equal(lf.read_buffer(pkg.GHOST_BUFFER), og)
+    assert lf.counters() == ocnt
