@@ -57,16 +57,19 @@ __device__ __forceinline__ float lf_sqrt(float x) { return __builtin_sqrtf(x); }
 
 __device__ __forceinline__ float u01(unsigned r) { return (float)(r >> 8) * 5.9604644775390625e-8f; }
 
+// The transmitted weight is carried as a fraction wn / wd: every Fresnel factor is a ratio of
+// two cheap products, so the march multiplies numerators and denominators separately and divides
+// ONCE, and only for the ~0.02 % of rays that end inside the sun's lobe.
 struct Ray {
-  float px, py, pz, dx, dy, dz, w;
+  float px, py, pz, dx, dy, dz, wn, wd;
 };
 
-enum { EV_REFRACT = 0, EV_REFLECT = 1 };
-enum { ALIVE = 0, DEAD_STOP = 1, DEAD_VIGNETTE = 2, DEAD_TIR = 3 };
-
-// one glass-surface event; returns the new liveness
-__device__ __forceinline__ int surface_event(Ray& r, float zv, float c, float h2, float eta,
-                                             bool reflect, bool fwd) {
+// One glass-surface event, straight-line (no divergent branches): a lane that misses the surface,
+// leaves the clear aperture or is totally reflected just gets ok = false -- its ray state turns
+// into garbage/NaN that nobody reads again.  geom_ok tells a vignetted ray from a TIR one.
+// sgn = +1 for a ray travelling +z, -1 for -z (wave-uniform, lives in an SGPR).
+__device__ __forceinline__ bool surface_event(Ray& r, float zv, float c, float h2, float eta,
+                                              bool reflect, float sgn, bool& geom_ok) {
   const float oz = r.pz - zv;
   const float od = fmaf(r.px, r.dx, fmaf(r.py, r.dy, oz * r.dz));
   const float oo = fmaf(r.px, r.px, fmaf(r.py, r.py, oz * oz));
@@ -74,62 +77,61 @@ __device__ __forceinline__ int surface_event(Ray& r, float zv, float c, float h2
   const float G = fmaf(-c, od, r.dz);
   const float cF = c * F;
   const float disc = fmaf(G, G, -cF);
-  if (disc < 0.0f) return DEAD_VIGNETTE;
   const float sq = lf_sqrt(disc);
-  const float den = fwd ? G + sq : G - sq;
+  const float den = fmaf(sgn, sq, G);  // == G + sq (forward) or G - sq (backward), one rounding
   const float t = __fdiv_rn(F, den);
   const float hx = fmaf(t, r.dx, r.px), hy = fmaf(t, r.dy, r.py), hz = fmaf(t, r.dz, oz);
   const float r2 = fmaf(hx, hx, hy * hy);
-  if (!(r2 <= h2)) return DEAD_VIGNETTE;
+  geom_ok = (disc >= 0.0f) && (r2 <= h2);
   const float nx = -c * hx, ny = -c * hy, nz = fmaf(-c, hz, 1.0f);
   const float mu = fmaf(r.dx, nx, fmaf(r.dy, ny, r.dz * nz));
-  const float ci = fabsf(mu);
   const float s2 = fmaf(-mu, mu, 1.0f);
   const float k2 = fmaf(-(eta * eta), s2, 1.0f);
-  float R = 1.0f, ct = 0.0f;
-  if (k2 >= 0.0f) {
-    ct = lf_sqrt(k2);
-    const float a = fmaf(eta, ci, -ct), b = fmaf(eta, ci, ct);
-    const float e = fmaf(-eta, ct, ci), f = fmaf(eta, ct, ci);
-    const float af = a * f, eb = e * b, bf = b * f;
-    R = __fdiv_rn(0.5f * fmaf(af, af, eb * eb), bf * bf);
-  } else if (!reflect) {
-    return DEAD_TIR;
-  }
-  if (!reflect) {
-    r.w *= (1.0f - R);
-    const float g = fmaf(-eta, mu, copysignf(ct, mu));
-    r.dx = fmaf(eta, r.dx, g * nx);
-    r.dy = fmaf(eta, r.dy, g * ny);
-    r.dz = fmaf(eta, r.dz, g * nz);
-  } else {
-    r.w *= R;
+  const bool no_tir = k2 >= 0.0f;
+  const float ct = lf_sqrt(fmaxf(k2, 0.0f));
+  // unpolarised Fresnel on half-scaled cosines (keeps the running denominator near 1):
+  //   R = Rn / D,  Rn = (af^2 + eb^2)/2,  D = (bf)^2
+  const float ch = 0.5f * fabsf(mu), th = 0.5f * ct;
+  const float a = fmaf(eta, ch, -th), b = fmaf(eta, ch, th);
+  const float e = fmaf(-eta, th, ch), f = fmaf(eta, th, ch);
+  const float af = a * f, eb = e * b, bf = b * f;
+  const float Rn = 0.5f * fmaf(af, af, eb * eb), D = bf * bf;
+  bool ok = geom_ok;
+  if (reflect) {  // wave-uniform
+    r.wn *= no_tir ? Rn : 1.0f;  // total reflection: R = 1
+    r.wd *= no_tir ? D : 1.0f;
     const float m2 = -2.0f * mu;
     r.dx = fmaf(m2, nx, r.dx);
     r.dy = fmaf(m2, ny, r.dy);
     r.dz = fmaf(m2, nz, r.dz);
+  } else {
+    ok = ok && no_tir;
+    r.wn *= D - Rn;
+    r.wd *= D;
+    const float g = fmaf(-eta, mu, copysignf(ct, mu));
+    r.dx = fmaf(eta, r.dx, g * nx);
+    r.dy = fmaf(eta, r.dy, g * ny);
+    r.dz = fmaf(eta, r.dz, g * nz);
   }
   r.px = hx; r.py = hy; r.pz = zv + hz;
-  return ALIVE;
+  return ok;
 }
 
 // the stop: flat pass-through, clipped by its housing and by the aperture mask
-__device__ __forceinline__ int stop_event(Ray& r, float zv, float h2, float inv_h,
-                                          const float* __restrict__ mask, int mw, int mh) {
+__device__ __forceinline__ bool stop_event(Ray& r, float zv, float h2, float inv_h,
+                                           const float* __restrict__ mask, int mw, int mh) {
   const float t = __fdiv_rn(zv - r.pz, r.dz);
   const float hx = fmaf(t, r.dx, r.px), hy = fmaf(t, r.dy, r.py);
   const float r2 = fmaf(hx, hx, hy * hy);
-  if (!(r2 <= h2)) return DEAD_STOP;
   const float fu = fmaf(hx, inv_h, 1.0f) * (0.5f * (float)mw);
   const float fv = fmaf(hy, inv_h, 1.0f) * (0.5f * (float)mh);
-  int ix = (int)fu, iy = (int)fv;
+  int ix = (int)fu, iy = (int)fv;  // NaN / out-of-range of a dead lane is clamped, never faults
   ix = min(max(ix, 0), mw - 1);
   iy = min(max(iy, 0), mh - 1);
   const float a = mask[iy * mw + ix];
-  if (!(a > 0.0f)) return DEAD_STOP;
-  r.w *= a;
+  r.wn *= a;
   r.px = hx; r.py = hy; r.pz = zv;
-  return ALIVE;
+  return (r2 <= h2) && (a > 0.0f);
 }
 
 struct MarchArgs {
@@ -167,10 +169,11 @@ __global__ __launch_bounds__(256) void k_march(const LfLensDev* __restrict__ len
   const float inv_1mc = lens->sun_inv_one_minus_cos;
   const int GG = a.G * a.G;
 
-  unsigned events = 0, n_clip = 0, n_vign = 0, n_tir = 0, n_scene = 0, n_light = 0, n_launched = 0;
+  unsigned n_clip = 0, n_vign = 0, n_tir = 0, n_scene = 0, n_light = 0, n_launched = 0;
+  unsigned long long events = 0;  // wave-uniform: counted once per wave with s_bcnt1 (SALU)
   unsigned long long acc[3] = {0ull, 0ull, 0ull};
 
-  if (active) {
+  {
     for (int s = wave; s < a.spp; s += 4) {  // wave-uniform
       // ---- sensor sample -> initial ray --------------------------------------------------
       const uint4 rnd = philox4x32_10(make_uint4(p, (unsigned)s, kDomainMarch, 0u), a.key);
@@ -204,18 +207,21 @@ __global__ __launch_bounds__(256) void k_march(const LfLensDev* __restrict__ len
       const float d0x = vx * rl, d0y = vy * rl, d0z = vz * rl;
       const float c2 = d0z * d0z;
       const float w0 = geom_norm * (c2 * c2);
-      n_launched += (unsigned)(n_lambda * n_pairs);
+      if (active) n_launched += (unsigned)(n_lambda * n_pairs);
 
       for (int l = 0; l < n_lambda; l++) {
         for (int q = 0; q < n_pairs; q++) {
           const int pi = pairs->ij[q][0], pj = pairs->ij[q][1];  // wave-uniform (SGPR)
-          Ray r{X, Y, z_sensor, d0x, d0y, d0z, w0};
-          int dead = ALIVE;
+          Ray r{X, Y, z_sensor, d0x, d0y, d0z, w0, 1.0f};
+          bool alive = active;
+          // how the ray died (read once, after the sequence): at the stop / geometrically / TIR
+          bool died_at_stop = false, died_geom = false;
           // legs: backwards N-1..i (reflect at i), forwards i+1..j (reflect at j), backwards
           // j-1..0.  The primary path (i < 0) is one backward leg N-1..0.
           const int n_legs = pi < 0 ? 1 : 3;
           for (int leg = 0; leg < n_legs; leg++) {
             const bool fwd = (leg == 1);
+            const float sgn = fwd ? 1.0f : -1.0f;
             int k, k_end, refl;
             if (leg == 0) { k = n_surf - 1; k_end = pi < 0 ? 0 : pi; refl = pi; }
             else if (leg == 1) { k = pi + 1; k_end = pj; refl = pj; }
@@ -223,24 +229,31 @@ __global__ __launch_bounds__(256) void k_march(const LfLensDev* __restrict__ len
             const int step = fwd ? 1 : -1;
             for (; fwd ? k <= k_end : k >= k_end; k += step) {
               const LfSurfaceDev& sf = lens->surf[k];  // wave-uniform -> s_load
-              if (sf.is_stop != 0.0f) {
-                dead = stop_event(r, sf.zv, sf.h2, inv_stop_h, mask, a.mw, a.mh);
+              bool ok, geom_ok = true;
+              const bool is_stop = sf.is_stop != 0.0f;
+              if (is_stop) {
+                ok = stop_event(r, sf.zv, sf.h2, inv_stop_h, mask, a.mw, a.mh);
               } else {
                 const float eta = fwd ? sf.eta_fwd[l] : sf.eta_bwd[l];
-                dead = surface_event(r, sf.zv, sf.curv, sf.h2, eta, k == refl, fwd);
+                ok = surface_event(r, sf.zv, sf.curv, sf.h2, eta, k == refl, sgn, geom_ok);
               }
-              if (dead != ALIVE) break;
-              events++;
+              const bool dies = alive && !ok;
+              died_at_stop = died_at_stop || (dies && is_stop);
+              died_geom = died_geom || (dies && !geom_ok);
+              alive = alive && ok;
+              const unsigned long long live = __ballot(alive);
+              if (live == 0ull) break;         // the whole wave is dead: leave the sequence
+              events += __popcll(live);        // SALU
             }
-            if (dead != ALIVE) break;
+            if (__ballot(alive) == 0ull) break;
           }
-          if (dead == ALIVE) {
+          if (alive) {
             n_scene++;
             const float cg = fmaf(r.dx, sx, fmaf(r.dy, sy, r.dz * sz));
             const float qq = (1.0f - cg) * inv_1mc;
             if (qq < 1.0f) {
               const float om = 1.0f - qq;
-              const float contrib = r.w * (om * om);
+              const float contrib = __fdiv_rn(r.wn, r.wd) * (om * om);
               if (contrib > 0.0f) {
                 n_light++;
 #pragma unroll
@@ -250,23 +263,28 @@ __global__ __launch_bounds__(256) void k_march(const LfLensDev* __restrict__ len
                 }
               }
             }
-          } else if (dead == DEAD_STOP) n_clip++;
-          else if (dead == DEAD_VIGNETTE) n_vign++;
-          else n_tir++;
+          } else if (active) {
+            if (died_at_stop) n_clip++;
+            else if (died_geom) n_vign++;
+            else n_tir++;
+          }
         }
       }
     }
+    if (active) {
 #pragma unroll
-    for (int c = 0; c < 3; c++)
-      if (acc[c]) atomicAdd(&s_acc[lane * 3 + c], acc[c]);
+      for (int c = 0; c < 3; c++)
+        if (acc[c]) atomicAdd(&s_acc[lane * 3 + c], acc[c]);
+    }
   }
 
   // ---- counters: wave reduce, one LDS add per wave, one global add per workgroup ------------
-  unsigned vals[7] = {n_launched, events, n_clip, n_vign, n_tir, n_scene, n_light};
+  unsigned vals[7] = {n_launched, 0u, n_clip, n_vign, n_tir, n_scene, n_light};
 #pragma unroll
   for (int i = 0; i < 7; i++) {
     unsigned long long v = vals[i];
     for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off);
+    if (i == 1) v = events;  // already a per-wave total
     if (lane == 0 && v) atomicAdd(&s_cnt[i], v);
   }
   __syncthreads();

@@ -89,7 +89,8 @@ static void derive(const geo_lens* L, int W, geo_derived* D) {
 }
 
 /* ---- one ray ---------------------------------------------------------------------------- */
-typedef struct { float p[3], d[3], w; } geo_ray;
+/* the weight is carried as the fraction wn / wd (one division at the very end) */
+typedef struct { float p[3], d[3], wn, wd; } geo_ray;
 enum { OK_ = 0, CLIPPED = 1, VIGNETTED = 2, TIR = 3 };
 
 /* DESIGN.md "march arithmetic", glass interface.  reflect: 0 = Snell refraction, 1 = mirror.
@@ -108,26 +109,24 @@ static int glass_event(geo_ray* r, float zv, float c, float h2, float eta, int r
   if (!(fmaf(hx, hx, hy * hy) <= h2)) return VIGNETTED;
   float n[3] = {-c * hx, -c * hy, fmaf(-c, hz, 1.0f)};
   float mu = fmaf(r->d[0], n[0], fmaf(r->d[1], n[1], r->d[2] * n[2]));
-  float ci = fabsf(mu);
   float k2 = fmaf(-(eta * eta), fmaf(-mu, mu, 1.0f), 1.0f);
-  float refl = 1.0f, ct = 0.0f;
-  if (k2 >= 0.0f) {
-    ct = sqrtf(k2);
-    float a = fmaf(eta, ci, -ct), b = fmaf(eta, ci, ct);
-    float e = fmaf(-eta, ct, ci), f = fmaf(eta, ct, ci);
-    float af = a * f, eb = e * b, bf = b * f;
-    refl = (0.5f * fmaf(af, af, eb * eb)) / (bf * bf);
-  } else if (!reflect) {
-    return TIR;
-  }
+  if (k2 < 0.0f && !reflect) return TIR;
+  float ct = k2 >= 0.0f ? sqrtf(k2) : 0.0f;
+  /* unpolarised Fresnel R = Rn / D on half-scaled cosines (DESIGN.md "march arithmetic") */
+  float ch = 0.5f * fabsf(mu), th = 0.5f * ct;
+  float a = fmaf(eta, ch, -th), b = fmaf(eta, ch, th);
+  float e = fmaf(-eta, th, ch), f = fmaf(eta, th, ch);
+  float af = a * f, eb = e * b, bf = b * f;
+  float Rn = 0.5f * fmaf(af, af, eb * eb), D = bf * bf;
   if (!reflect) {
-    r->w *= (1.0f - refl);
+    r->wn *= D - Rn;
+    r->wd *= D;
     float g = fmaf(-eta, mu, copysignf(ct, mu));
-    for (int a = 0; a < 3; a++) r->d[a] = fmaf(eta, r->d[a], g * n[a]);
+    for (int q = 0; q < 3; q++) r->d[q] = fmaf(eta, r->d[q], g * n[q]);
   } else {
-    r->w *= refl;
+    if (k2 >= 0.0f) { r->wn *= Rn; r->wd *= D; } /* else total reflection: R = 1 */
     float m2 = -2.0f * mu;
-    for (int a = 0; a < 3; a++) r->d[a] = fmaf(m2, n[a], r->d[a]);
+    for (int q = 0; q < 3; q++) r->d[q] = fmaf(m2, n[q], r->d[q]);
   }
   r->p[0] = hx; r->p[1] = hy; r->p[2] = zv + hz;
   return OK_;
@@ -144,7 +143,7 @@ static int stop_event(geo_ray* r, float zv, float h2, float inv_h, const float* 
   if (iy < 0) iy = 0; if (iy > mh - 1) iy = mh - 1;
   float a = mask[iy * mw + ix];
   if (!(a > 0.0f)) return CLIPPED;
-  r->w *= a;
+  r->wn *= a;
   r->p[0] = hx; r->p[1] = hy; r->p[2] = zv;
   return OK_;
 }
@@ -152,9 +151,9 @@ static int stop_event(geo_ray* r, float zv, float h2, float inv_h, const float* 
 /* exported for the known-answer tests: one event on a caller-supplied ray */
 int geo_glass_event(float p[3], float d[3], float* w, float zv, float c, float h2, float eta,
                     int reflect, int forward) {
-  geo_ray r = {{p[0], p[1], p[2]}, {d[0], d[1], d[2]}, *w};
+  geo_ray r = {{p[0], p[1], p[2]}, {d[0], d[1], d[2]}, *w, 1.0f};
   int st = glass_event(&r, zv, c, h2, eta, reflect, forward);
-  memcpy(p, r.p, sizeof(r.p)); memcpy(d, r.d, sizeof(r.d)); *w = r.w;
+  memcpy(p, r.p, sizeof(r.p)); memcpy(d, r.d, sizeof(r.d)); *w = r.wn / r.wd;
   return st;
 }
 
@@ -215,8 +214,9 @@ static float start_ray(const geo_derived* D, int W, int H, int x, int y, int s, 
   r->p[0] = X; r->p[1] = Y; r->p[2] = D->z_sensor;
   r->d[0] = vx * rl; r->d[1] = vy * rl; r->d[2] = vz * rl;
   float c2 = r->d[2] * r->d[2];
-  r->w = D->geom_norm * (c2 * c2);
-  return r->w;
+  r->wn = D->geom_norm * (c2 * c2);
+  r->wd = 1.0f;
+  return r->wn;
 }
 
 /* March `spp` samples of every pixel in rows [y0, y1); pairs = n x (i, j), (-1,-1) = primary.
@@ -268,7 +268,7 @@ void geo_trace(const geo_lens* L, int W, int H, int y0, int y1, int spp, const u
             float qq = (1.0f - cg) * D.inv_1mc;
             if (qq < 1.0f) {
               float om = 1.0f - qq;
-              float contrib = r.w * (om * om);
+              float contrib = (r.wn / r.wd) * (om * om);
               if (contrib > 0.0f) {
                 c.rays_hit_light++;
                 for (int ch = 0; ch < 3; ch++) {
@@ -301,7 +301,7 @@ int geo_trace_ray(const geo_lens* L, int lambda, int i, int j, float p[3], float
   derive(L, 64, &D);
   geo_step seq[3 * GEO_MAX_SURF];
   int n = build_sequence(L->n_surf, i, j, seq);
-  geo_ray r = {{p[0], p[1], p[2]}, {d[0], d[1], d[2]}, *w};
+  geo_ray r = {{p[0], p[1], p[2]}, {d[0], d[1], d[2]}, *w, 1.0f};
   int st = OK_, ev = 0;
   for (int e = 0; e < n; e++) {
     int k = seq[e].k;
@@ -312,7 +312,7 @@ int geo_trace_ray(const geo_lens* L, int lambda, int i, int j, float p[3], float
     if (st != OK_) break;
     ev++;
   }
-  memcpy(p, r.p, sizeof(r.p)); memcpy(d, r.d, sizeof(r.d)); *w = r.w;
+  memcpy(p, r.p, sizeof(r.p)); memcpy(d, r.d, sizeof(r.d)); *w = r.wn / r.wd;
   if (n_events) *n_events = ev;
   return st;
 }
