@@ -137,8 +137,8 @@ def main():
 
     # sensor tile rows (8 rows each) are dealt round-robin: tile row t belongs to rank t % world.
     # One march launch per frame covers all of this rank's tile rows.
-    n_trows = (H + TILE_ROWS - 1) // TILE_ROWS
-    my_trows = len([t for t in range(n_trows) if t % world == rank])
+    from lens_flare_amd import sharding
+    my_trows = len(sharding.my_tile_rows(H, rank, world))
     lf.set_band(0, H)
     lf.set_row_interleave(rank, world)
     frame_t = None
@@ -155,10 +155,7 @@ def main():
             # consecutive tile rows is one in-place all-gather (rank r owns slot r of the group);
             # the buffer is padded to 64 rows so the last group never runs past the end.
             lf.synchronize()
-            e = TILE_ROWS * W * 3
-            for grp in range((n_trows + world - 1) // world):
-                out = frame_t[grp * world * e:(grp + 1) * world * e]
-                dist.all_gather_into_tensor(out, out[rank * e:(rank + 1) * e])
+            sharding.gather_frame_inplace(frame_t, W, H, rank, world, dist)
 
     def barrier():
         lf.synchronize()

@@ -1,0 +1,88 @@
+"""The N>1 path on CPU: world_size 2 and 3 over gloo.  Each rank fills its round-robin tile rows of
+a frame (with the CPU oracle standing in for the GPU march, which the -m gpu tests already pin to
+it bit for bit), then the product's own exchange step (lens_flare_amd.sharding, the code bench.py
+runs over RCCL) must rebuild the complete frame on every rank."""
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, W, H, spp, out_dir):
+    import torch
+    import torch.distributed as dist
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import __graft_entry__ as g
+    pkg = g.load_package()
+    from lens_flare_amd import sharding
+    from oracle import lfo
+    from goldenlib import load_texels
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    lens = pkg.load_lens_file("dgauss11.lens")
+    mask = load_texels("pentbig500_14.png")
+    sun = ([0.03, 0.02, -1.0], [1.0, 0.9, 0.5], 0.05)
+    rows = sharding.padded_rows(H, world)
+    frame = torch.zeros(rows * W * 3, dtype=torch.float64)
+    view = frame.numpy().reshape(rows, W, 3)
+    events = 0
+    for t in sharding.my_tile_rows(H, rank, world):
+        y0, y1 = t * 8, min(H, t * 8 + 8)
+        g_, c = lfo.geo_trace(lens, W, H, y0, y1, spp, 5, None, True, mask, *sun, n_threads=2)
+        view[y0:y1] = g_[y0:y1]
+        events += c["surface_events"]
+    sharding.gather_frame_inplace(frame, W, H, rank, world, dist)
+    ev = torch.tensor([float(events)], dtype=torch.float64)
+    dist.all_reduce(ev)
+    np.save(os.path.join(out_dir, f"frame_{rank}.npy"), view[:H].copy())
+    np.save(os.path.join(out_dir, f"events_{rank}.npy"), ev.numpy())
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_tile_row_deal_and_inplace_gather(world, tmp_path):
+    import torch.multiprocessing as mp
+    sys.path.insert(0, ROOT)
+    import __graft_entry__ as g
+    pkg = g.load_package()
+    from oracle import lfo
+    from goldenlib import load_texels
+    W, H, spp = 24, 44, 4   # 6 tile rows, the last one partial (4 rows)
+    mp.spawn(_worker, args=(world, _free_port(), W, H, spp, str(tmp_path)), nprocs=world, join=True)
+    lens = pkg.load_lens_file("dgauss11.lens")
+    mask = load_texels("pentbig500_14.png")
+    full, cnt = lfo.geo_trace(lens, W, H, 0, H, spp, 5, None, True, mask, [0.03, 0.02, -1.0],
+                              [1.0, 0.9, 0.5], 0.05, n_threads=4)
+    assert full.max() > 0
+    for r in range(world):
+        got = np.load(tmp_path / f"frame_{r}.npy")
+        assert np.array_equal(got, full), f"rank {r} did not end up with the complete frame"
+        assert np.load(tmp_path / f"events_{r}.npy")[0] == cnt["surface_events"]
+
+
+def test_sharding_helpers():
+    sys.path.insert(0, ROOT)
+    import __graft_entry__ as g
+    g.load_package()
+    from lens_flare_amd import sharding
+    assert sharding.n_tile_rows(1080) == 135
+    for world in (1, 2, 4, 8):
+        rows = [sharding.my_tile_rows(1080, r, world) for r in range(world)]
+        assert sorted(sum(rows, [])) == list(range(135))
+        assert max(map(len, rows)) - min(map(len, rows)) <= 1
+        assert sharding.padded_rows(1080, world) <= 1088  # fits the library's 64-row padding
