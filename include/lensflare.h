@@ -134,7 +134,10 @@ lf_status lf_render_flare_layer(lf_ctx* ctx);
 
 /* ---------------------------------------------------------------- read back -------------- */
 /* replaces reads of PathTracer::sampleBuffer / ghost_buffer (util/image.h:139-151).
- * which: 0 = sampleBuffer, 1 = ghost_buffer.  dst receives (x1-x0)*(y1-y0) pixels, each
+ * which: 0 = sampleBuffer, 1 = ghost_buffer, 2 = the value of raytrace_starburst(x,y)
+ * (pathtracer.cpp:947-1004: starburst + irradiance falloff) on its own, so that a host which
+ * computes its scene radiance per pixel can form (scene + ghost) + starburst exactly like
+ * pathtracer.cpp:891.  dst receives (x1-x0)*(y1-y0) pixels, each
  * `pixel_stride` doubles apart (3 = packed Vector3D, 4 = the AVX build's 32-byte Vector3D). */
 lf_status lf_read_tile(lf_ctx* ctx, int which, int x0, int y0, int x1, int y1, double* dst,
                        size_t pixel_stride);

@@ -95,10 +95,11 @@ struct Mt19937 {
 void free_frame_buffers(lf_ctx* ctx) {
   if (ctx->sample) (void)hipFree(ctx->sample);
   if (ctx->ghost) (void)hipFree(ctx->ghost);
+  if (ctx->star) (void)hipFree(ctx->star);
   if (ctx->scene) (void)hipFree(ctx->scene);
   if (ctx->rgba) (void)hipFree(ctx->rgba);
   if (ctx->jitter_raw) (void)hipFree(ctx->jitter_raw);
-  ctx->sample = ctx->ghost = ctx->scene = nullptr;
+  ctx->sample = ctx->ghost = ctx->scene = ctx->star = nullptr;
   ctx->rgba = nullptr;
   ctx->jitter_raw = nullptr;
   ctx->jitter_table_valid = ctx->ghost_valid = ctx->sample_valid = ctx->rgba_valid = false;
@@ -198,9 +199,11 @@ lf_status lf_set_frame(lf_ctx* ctx, int width, int height) {
   lf_status st;
   if ((st = dev_alloc(ctx, &ctx->sample, 3 * n)) != LF_OK) return st;
   if ((st = dev_alloc(ctx, &ctx->ghost, 3 * n)) != LF_OK) return st;
+  if ((st = dev_alloc(ctx, &ctx->star, 3 * n)) != LF_OK) return st;
   if ((st = dev_alloc(ctx, &ctx->rgba, n)) != LF_OK) return st;
   LF_HIP(ctx, hipMemsetAsync(ctx->sample, 0, 3 * n * sizeof(double), ctx->stream));
   LF_HIP(ctx, hipMemsetAsync(ctx->ghost, 0, 3 * n * sizeof(double), ctx->stream));
+  LF_HIP(ctx, hipMemsetAsync(ctx->star, 0, 3 * n * sizeof(double), ctx->stream));
   LF_HIP(ctx, hipMemsetAsync(ctx->rgba, 0, n * sizeof(uint32_t), ctx->stream));
   return LF_OK;
 }
@@ -447,12 +450,12 @@ lf_status lf_render_flare_layer(lf_ctx* ctx) {
 
 lf_status lf_read_tile(lf_ctx* ctx, int which, int x0, int y0, int x1, int y1, double* dst,
                        size_t pixel_stride) {
-  if (!ctx || !dst || (which != 0 && which != 1) || pixel_stride < 3) return LF_ERR_INVALID;
+  if (!ctx || !dst || which < 0 || which > 2 || pixel_stride < 3) return LF_ERR_INVALID;
   if (ctx->W == 0) return lf_fail(ctx, LF_ERR_STATE, "lf_read_tile before lf_set_frame");
   if (x0 < 0 || y0 < 0 || x1 > ctx->W || y1 > ctx->H || x0 > x1 || y0 > y1)
     return lf_fail(ctx, LF_ERR_INVALID, "tile out of range");
   if (x0 == x1 || y0 == y1) return LF_OK;
-  const double* src = which == 0 ? ctx->sample : ctx->ghost;
+  const double* src = which == 0 ? ctx->sample : which == 1 ? ctx->ghost : ctx->star;
   LF_HIP(ctx, hipStreamSynchronize(ctx->stream));
   const size_t tw = (size_t)(x1 - x0);
   if (pixel_stride == 3) {
@@ -496,9 +499,9 @@ lf_status lf_write_to_framebuffer(lf_ctx* ctx, int x0, int y0, int x1, int y1, u
 }
 
 lf_status lf_device_buffer(lf_ctx* ctx, int which, void** dptr, size_t* bytes) {
-  if (!ctx || !dptr || (which != 0 && which != 1)) return LF_ERR_INVALID;
+  if (!ctx || !dptr || which < 0 || which > 2) return LF_ERR_INVALID;
   if (ctx->W == 0) return lf_fail(ctx, LF_ERR_STATE, "lf_device_buffer before lf_set_frame");
-  *dptr = which == 0 ? ctx->sample : ctx->ghost;
+  *dptr = which == 0 ? ctx->sample : which == 1 ? ctx->ghost : ctx->star;
   if (bytes) *bytes = (size_t)ctx->W * ctx->H_alloc * 3 * sizeof(double);
   return LF_OK;
 }

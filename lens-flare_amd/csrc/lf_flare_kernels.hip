@@ -399,7 +399,7 @@ __global__ __launch_bounds__(256) void k_flare_layer(
     const double* __restrict__ S, const double* __restrict__ ghost,
     const double* __restrict__ scene, const uint32_t* __restrict__ jitter_raw, int jitter_mode,
     uint64_t key, int W, int H, int y0, int y1, int ns_aa, double flare_radius,
-    double flare_intensity, double* __restrict__ sample) {
+    double flare_intensity, double* __restrict__ sample, double* __restrict__ star_out) {
   const size_t p = (size_t)y0 * W + (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (p >= (size_t)y1 * W) return;
   const int x = (int)(p % W), y = (int)(p / W);
@@ -475,6 +475,7 @@ __global__ __launch_bounds__(256) void k_flare_layer(
   for (int c = 0; c < 3; c++) {
     double sc = scene ? scene[3 * p + c] : 0.0 * (1. / (double)(ns_aa + 1));
     sample[3 * p + c] = (sc + ghost[3 * p + c]) + star[c];
+    star_out[3 * p + c] = star[c];
   }
 }
 
@@ -568,7 +569,7 @@ lf_status lfk_flare_layer(lf_ctx* ctx) {
                      ctx->flares, ctx->ap[LF_APERTURE_STARBURST].stats, ctx->spectrum, ctx->ghost,
                      ctx->scene, ctx->jitter_raw, ctx->jitter_mode, ctx->jitter_key, ctx->W, ctx->H,
                      ctx->y0, ctx->y1, ctx->ns_aa, ctx->flare_radius, ctx->flare_intensity,
-                     ctx->sample);
+                     ctx->sample, ctx->star);
   lf_timing_end(ctx, LFK_FLARE_LAYER, ev);
   LF_HIP(ctx, hipGetLastError());
   return LF_OK;

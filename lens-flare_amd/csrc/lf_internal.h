@@ -135,6 +135,7 @@ struct lf_ctx {
   double* sample = nullptr;  // W*H*3
   double* ghost = nullptr;   // W*H*3
   double* scene = nullptr;   // W*H*3 or null
+  double* star = nullptr;    // W*H*3: raytrace_starburst(x,y) alone (starburst + falloff)
   uint32_t* rgba = nullptr;  // W*H
   bool ghost_valid = false, sample_valid = false, rgba_valid = false;
 
