@@ -148,6 +148,7 @@ struct lf_ctx {
   // geometric
   LfLensDev lens{};
   bool lens_valid = false, sun_valid = false;
+  int march_sub_bits = 2;  // pupil sub-cells per stratum = 4 x 4 (part of the sampling spec)
   LfLensDev* lens_dev = nullptr;
   LfPairsDev pairs{};
   LfPairsDev* pairs_dev = nullptr;

@@ -37,6 +37,7 @@ namespace {
 
 constexpr float kFixScale = 68719476736.0f;  // 2^36
 constexpr unsigned kDomainMarch = 0x6e5f1a2eu;
+constexpr unsigned kDomainSubcell = 0x51bce110u;
 
 __device__ __forceinline__ uint4 philox4x32_10(uint4 ctr, uint2 key) {
 #pragma unroll
@@ -53,7 +54,23 @@ __device__ __forceinline__ uint4 philox4x32_10(uint4 ctr, uint2 key) {
 // IEEE correctly rounded sqrt: plain sqrt under -fhip-fp32-correctly-rounded-divide-sqrt.
 // (ROCm's __fsqrt_rn maps to the 1-ulp hardware approximation unless
 // OCML_BASIC_ROUNDED_OPERATIONS is defined, which broke bit parity with the CPU in 1 ray of 10^4.)
-__device__ __forceinline__ float lf_sqrt(float x) { return __builtin_sqrtf(x); }
+//
+// lf_sqrt below is that correctly rounded sqrt written out: the hardware's 1-ulp v_sqrt_f32, then
+// pick among {s-1ulp, s, s+1ulp} with two exact fma residuals -- the same selection LLVM emits
+// for an IEEE f32 sqrt, minus its 2^32 pre-scaling for denormal inputs and its 0/inf class check,
+// neither of which can trigger here: every argument is 0, NaN (dead lane) or >= 2^-54 (it is the
+// fma-rounded difference of O(1) products of 24-bit floats).  Saves 6 VALU per sqrt; bit-exact
+// with sqrtf() on the CPU for those inputs (tests compare every pixel and counter).
+__device__ __forceinline__ float lf_sqrt(float x) {
+  const float s = __builtin_amdgcn_sqrtf(x);
+  const float s_dn = __uint_as_float(__float_as_uint(s) - 1u);
+  const float s_up = __uint_as_float(__float_as_uint(s) + 1u);
+  const float r_dn = fmaf(-s_dn, s, x);
+  const float r_up = fmaf(-s_up, s, x);
+  float r = (r_dn <= 0.0f) ? s_dn : s;
+  r = (r_up > 0.0f) ? s_up : r;
+  return r;
+}
 
 __device__ __forceinline__ float u01(unsigned r) { return (float)(r >> 8) * 5.9604644775390625e-8f; }
 
@@ -138,6 +155,8 @@ struct MarchArgs {
   int mw, mh, W, H, y0, y1;
   int spp, G;          // G x G pupil strata, G = floor(sqrt(spp))
   float inv_G;
+  int sub_bits;        // each stratum is split into 2^sub_bits x 2^sub_bits sub-cells
+  float inv_sub;
   int trow0, tperiod;  // tile rows handled: trow0 + j * tperiod, j = 0 ..
   uint2 key;
 };
@@ -160,6 +179,7 @@ __global__ __launch_bounds__(256) void k_march(const LfLensDev* __restrict__ len
   const int y = (a.trow0 + tj * a.tperiod) * 8 + (lane >> 3);
   const bool active = x < a.W && y >= a.y0 && y < a.y1;
   const unsigned p = (unsigned)y * (unsigned)a.W + (unsigned)x;
+  const unsigned tile_id = (unsigned)((a.trow0 + tj * a.tperiod) * tiles_x + tx);  // frame-absolute
 
   const int n_surf = lens->n_surf, n_lambda = lens->n_lambda, n_pairs = pairs->n;
   const float z_sensor = lens->z_sensor, pitch = lens->pitch, pupil_h = lens->pupil_h;
@@ -181,8 +201,15 @@ __global__ __launch_bounds__(256) void k_march(const LfLensDev* __restrict__ len
       float ua = u01(rnd.z), ub = u01(rnd.w);
       if (s < GG) {  // stratum (s % G, s / G) of the pupil square
         const int cy = s / a.G, cx = s - cy * a.G;
-        ua = ((float)cx + ua) * a.inv_G;
-        ub = ((float)cy + ub) * a.inv_G;
+        // ... and inside it ONE of sub x sub sub-cells, drawn per (tile, s): wave-uniform, so the
+        // compiler keeps this Philox on the scalar unit.  Each pixel still covers its stratum
+        // uniformly (the sub-cell is uniformly random), but the 64 lanes of the wave now cross the
+        // stop within 1/(G*sub) of its width and share their fate at the mask even more often.
+        const uint4 r2 = philox4x32_10(make_uint4(tile_id, (unsigned)s, kDomainSubcell, 0u), a.key);
+        const unsigned sxi = a.sub_bits ? (r2.x >> (32 - a.sub_bits)) : 0u;
+        const unsigned syi = a.sub_bits ? (r2.y >> (32 - a.sub_bits)) : 0u;
+        ua = ((float)cx + ((float)sxi + ua) * a.inv_sub) * a.inv_G;
+        ub = ((float)cy + ((float)syi + ub) * a.inv_sub) * a.inv_G;
       }
       const float pa = fmaf(2.0f, ua, -1.0f), pb = fmaf(2.0f, ub, -1.0f);
       const float X = -(((float)x + jx) - 0.5f * (float)a.W) * pitch;
@@ -358,7 +385,9 @@ lf_status lfk_march(lf_ctx* ctx, int spp, uint64_t key) {
   while ((a.G + 1) * (a.G + 1) <= spp) a.G++;
   while (a.G * a.G > spp) a.G--;
   a.inv_G = 1.0f / (float)a.G;
-  a.key = make_uint2((unsigned)key, (unsigned)(key >> 32));
+  a.sub_bits = ctx->march_sub_bits;
+  a.inv_sub = 1.0f / (float)(1 << a.sub_bits);
+  a.key =make_uint2((unsigned)key, (unsigned)(key >> 32));
   // tile rows (8 sensor rows each) of the band that belong to this context's interleave phase
   const int t_lo = ctx->y0 / 8, t_hi = (ctx->y1 + 7) / 8;  // [t_lo, t_hi)
   const int period = ctx->row_period, phase = ctx->row_phase;

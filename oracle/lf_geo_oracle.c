@@ -182,15 +182,25 @@ static int strata(int spp) {
   return g;
 }
 
+/* each stratum is split into 2^SUB_BITS x 2^SUB_BITS sub-cells; the sub-cell of sample s is drawn
+ * once per 8x8 sensor tile: Philox(ctr = (tile id, s, 0x51bce110, 0), key) */
+static int g_sub_bits = 2;
+void geo_set_sub_bits(int b) { g_sub_bits = b; }
+
 static float start_ray(const geo_derived* D, int W, int H, int x, int y, int s, int G,
-                       const uint32_t rnd[4], geo_ray* r) {
+                       const uint32_t key[2], const uint32_t rnd[4], geo_ray* r) {
   float jx = unit24(rnd[0]), jy = unit24(rnd[1]);
   float ua = unit24(rnd[2]), ub = unit24(rnd[3]);
   if (s < G * G) {
-    float inv_g = 1.0f / (float)G;
+    float inv_g = 1.0f / (float)G, inv_sub = 1.0f / (float)(1 << g_sub_bits);
     int cy = s / G, cx = s - cy * G;
-    ua = ((float)cx + ua) * inv_g;
-    ub = ((float)cy + ub) * inv_g;
+    uint32_t tile = (uint32_t)((y >> 3) * ((W + 7) >> 3) + (x >> 3));
+    uint32_t ctr[4] = {tile, (uint32_t)s, 0x51bce110u, 0u}, r2[4];
+    philox(ctr, key, r2);
+    uint32_t sxi = g_sub_bits ? (r2[0] >> (32 - g_sub_bits)) : 0u;
+    uint32_t syi = g_sub_bits ? (r2[1] >> (32 - g_sub_bits)) : 0u;
+    ua = ((float)cx + ((float)sxi + ua) * inv_sub) * inv_g;
+    ub = ((float)cy + ((float)syi + ub) * inv_sub) * inv_g;
   }
   float pa = fmaf(2.0f, ua, -1.0f), pb = fmaf(2.0f, ub, -1.0f);
   float X = -(((float)x + jx) - 0.5f * (float)W) * D->pitch;
@@ -242,7 +252,7 @@ void geo_trace(const geo_lens* L, int W, int H, int y0, int y1, int spp, const u
         uint32_t ctr[4] = {(uint32_t)p, (uint32_t)s, 0x6e5f1a2eu, 0u}, rnd[4];
         philox(ctr, key, rnd);
         geo_ray r0;
-        start_ray(&D, W, H, x, y, s, strata(spp), rnd, &r0);
+        start_ray(&D, W, H, x, y, s, strata(spp), key, rnd, &r0);
         for (int l = 0; l < L->n_lambda; l++)
           for (int q = 0; q < n_pairs; q++) {
             int n = build_sequence(L->n_surf, pairs[2 * q], pairs[2 * q + 1], seq);
@@ -332,7 +342,7 @@ void geo_survival(const geo_lens* L, int W, int H, int y0, int y1, int spp, cons
       uint32_t ctr[4] = {(uint32_t)p, (uint32_t)s, 0x6e5f1a2eu, 0u}, rnd[4];
       philox(ctr, key, rnd);
       geo_ray r0;
-      start_ray(&D, W, H, (int)(p % W), (int)(p / W), s, strata(spp), rnd, &r0);
+      start_ray(&D, W, H, (int)(p % W), (int)(p / W), s, strata(spp), key, rnd, &r0);
       for (int q = 0; q < n_pairs; q++) {
         int n = build_sequence(L->n_surf, pairs[2 * q], pairs[2 * q + 1], seq);
         geo_ray r = r0;

@@ -1,0 +1,101 @@
+// Microbenchmark: what VALU issue rate can a gfx950 SIMD actually sustain for the instruction
+// mixes of the march kernel?  (DESIGN.md section 3 quotes the result.)
+//   hipcc --offload-arch=gfx950 -O3 -o valu_issue valu_issue.hip && ./valu_issue
+#include <hip/hip_runtime.h>
+
+#include <cstdio>
+#include <vector>
+
+template <int MODE>
+__global__ __launch_bounds__(256) void k(float* out, int iters, float seed) {
+  float a0 = seed + threadIdx.x, a1 = a0 + 1, a2 = a0 + 2, a3 = a0 + 3, a4 = a0 + 4, a5 = a0 + 5,
+        a6 = a0 + 6, a7 = a0 + 7;
+  const float m = 0.999f, c = 0.001f;
+  int sacc = 0;
+  for (int i = 0; i < iters; i++) {
+#pragma unroll
+    for (int u = 0; u < 8; u++) {
+      if (MODE == 0) {  // 8 independent chains
+        asm volatile("v_fma_f32 %0, %0, %8, %9\n v_fma_f32 %1, %1, %8, %9\n v_fma_f32 %2, %2, %8, %9\n"
+                     "v_fma_f32 %3, %3, %8, %9\n v_fma_f32 %4, %4, %8, %9\n v_fma_f32 %5, %5, %8, %9\n"
+                     "v_fma_f32 %6, %6, %8, %9\n v_fma_f32 %7, %7, %8, %9\n"
+                     : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7)
+                     : "v"(m), "v"(c));
+      } else if (MODE == 1) {  // one dependent chain
+        asm volatile("v_fma_f32 %0, %0, %1, %2\n v_fma_f32 %0, %0, %1, %2\n v_fma_f32 %0, %0, %1, %2\n"
+                     "v_fma_f32 %0, %0, %1, %2\n v_fma_f32 %0, %0, %1, %2\n v_fma_f32 %0, %0, %1, %2\n"
+                     "v_fma_f32 %0, %0, %1, %2\n v_fma_f32 %0, %0, %1, %2\n"
+                     : "+v"(a0) : "v"(m), "v"(c));
+      } else if (MODE == 2) {  // 2 dependent chains interleaved (ILP 2)
+        asm volatile("v_fma_f32 %0, %0, %2, %3\n v_fma_f32 %1, %1, %2, %3\n v_fma_f32 %0, %0, %2, %3\n"
+                     "v_fma_f32 %1, %1, %2, %3\n v_fma_f32 %0, %0, %2, %3\n v_fma_f32 %1, %1, %2, %3\n"
+                     "v_fma_f32 %0, %0, %2, %3\n v_fma_f32 %1, %1, %2, %3\n"
+                     : "+v"(a0), "+v"(a1) : "v"(m), "v"(c));
+      } else if (MODE == 3) {  // 8 VALU (independent) + 4 SALU
+        asm volatile("v_fma_f32 %0, %0, %9, %10\n s_add_u32 %8, %8, 1\n v_fma_f32 %1, %1, %9, %10\n"
+                     "v_fma_f32 %2, %2, %9, %10\n s_add_u32 %8, %8, 1\n v_fma_f32 %3, %3, %9, %10\n"
+                     "v_fma_f32 %4, %4, %9, %10\n s_add_u32 %8, %8, 1\n v_fma_f32 %5, %5, %9, %10\n"
+                     "v_fma_f32 %6, %6, %9, %10\n s_add_u32 %8, %8, 1\n v_fma_f32 %7, %7, %9, %10\n"
+                     : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7),
+                       "+s"(sacc)
+                     : "v"(m), "v"(c));
+      } else if (MODE == 4) {  // dependent chain + 4 SALU
+        asm volatile("v_fma_f32 %0, %0, %2, %3\n s_add_u32 %1, %1, 1\n v_fma_f32 %0, %0, %2, %3\n"
+                     "v_fma_f32 %0, %0, %2, %3\n s_add_u32 %1, %1, 1\n v_fma_f32 %0, %0, %2, %3\n"
+                     "v_fma_f32 %0, %0, %2, %3\n s_add_u32 %1, %1, 1\n v_fma_f32 %0, %0, %2, %3\n"
+                     "v_fma_f32 %0, %0, %2, %3\n s_add_u32 %1, %1, 1\n v_fma_f32 %0, %0, %2, %3\n"
+                     : "+v"(a0), "+s"(sacc) : "v"(m), "v"(c));
+      } else if (MODE == 5) {  // 6 fma (dependent) + v_sqrt + v_rcp (transcendental, dependent)
+        asm volatile("v_fma_f32 %0, %0, %1, %2\n v_fma_f32 %0, %0, %1, %2\n v_fma_f32 %0, %0, %1, %2\n"
+                     "v_sqrt_f32 %0, %0\n v_fma_f32 %0, %0, %1, %2\n v_fma_f32 %0, %0, %1, %2\n"
+                     "v_rcp_f32 %0, %0\n v_fma_f32 %0, %0, %1, %2\n"
+                     : "+v"(a0) : "v"(m), "v"(c));
+      } else if (MODE == 6) {  // cmp + cndmask pairs through VCC, dependent
+        asm volatile("v_cmp_gt_f32 vcc, %0, %2\n v_cndmask_b32 %0, %0, %1, vcc\n v_fma_f32 %0, %0, %1, %2\n"
+                     "v_cmp_gt_f32 vcc, %0, %2\n v_cndmask_b32 %0, %0, %1, vcc\n v_fma_f32 %0, %0, %1, %2\n"
+                     "v_fma_f32 %0, %0, %1, %2\n v_fma_f32 %0, %0, %1, %2\n"
+                     : "+v"(a0) : "v"(m), "v"(c) : "vcc");
+      }
+    }
+  }
+  out[blockIdx.x * 256 + threadIdx.x] = a0 + a1 + a2 + a3 + a4 + a5 + a6 + a7 + sacc;
+}
+
+template <int MODE>
+double run(float* d, int blocks, int iters, int valu_per_iter) {
+  hipEvent_t e0, e1;
+  hipEventCreate(&e0); hipEventCreate(&e1);
+  hipLaunchKernelGGL(k<MODE>, dim3(blocks), dim3(256), 0, 0, d, 100, 1.0f);
+  hipDeviceSynchronize();
+  hipEventRecord(e0);
+  hipLaunchKernelGGL(k<MODE>, dim3(blocks), dim3(256), 0, 0, d, iters, 1.0f);
+  hipEventRecord(e1);
+  hipEventSynchronize(e1);
+  float ms;
+  hipEventElapsedTime(&ms, e0, e1);
+  double winst = (double)blocks * 4 * iters * 8.0 * valu_per_iter;
+  return winst / (ms * 1e-3);
+}
+
+int main() {
+  float* d;
+  hipMalloc(&d, sizeof(float) * 256 * 256 * 16);
+  const char* names[] = {"8 independent fma chains", "1 dependent fma chain", "2 interleaved chains",
+                         "8 indep fma + 4 SALU per 8", "dependent fma + 4 SALU per 8",
+                         "dependent: 6 fma + sqrt + rcp", "dependent: 2x(cmp+cndmask) + 4 fma"};
+  for (int wps : {1, 2, 4, 8}) {  // waves per SIMD = blocks per CU (256 threads = 4 waves = 1/SIMD)
+    int blocks = 256 * wps;
+    double r[7];
+    r[0] = run<0>(d, blocks, 20000, 8);
+    r[1] = run<1>(d, blocks, 20000, 8);
+    r[2] = run<2>(d, blocks, 20000, 8);
+    r[3] = run<3>(d, blocks, 20000, 8);
+    r[4] = run<4>(d, blocks, 20000, 8);
+    r[5] = run<5>(d, blocks, 20000, 8);
+    r[6] = run<6>(d, blocks, 20000, 8);
+    for (int i = 0; i < 7; i++)
+      printf("waves/SIMD %d  %-36s %.3e VALU wave-instr/s  (%.2f cyc/instr/SIMD @2.4GHz)\n", wps, names[i],
+             r[i], 1024 * 2.4e9 / r[i]);
+  }
+  return 0;
+}
