@@ -134,6 +134,11 @@ lf_status lf_create(lf_ctx** out, int device) {
     return LF_ERR_HIP;
   }
   ctx->own_stream = true;
+  // tuning knob for experiments only (changes the sampling pattern; the oracle/tests use 2)
+  if (const char* sb = std::getenv("LF_MARCH_SUB_BITS")) {
+    int v = std::atoi(sb);
+    if (v >= 0 && v <= 8) ctx->march_sub_bits = v;
+  }
   default_paraxial_lens(ctx->pl);
   bool ok = hipMalloc((void**)&ctx->flares, sizeof(LfFlares)) == hipSuccess &&
             hipMalloc((void**)&ctx->ghosts, sizeof(LfGhostList)) == hipSuccess &&
@@ -163,7 +168,7 @@ lf_status lf_destroy(lf_ctx* ctx) {
     if (ctx->ap[s].stats) (void)hipFree(ctx->ap[s].stats);
   }
   void* ptrs[] = {ctx->spectrum, ctx->twiddle, ctx->dft_rows, ctx->flares, ctx->ghosts, ctx->pl_dev,
-                  ctx->lens_dev, ctx->pairs_dev, ctx->counters_dev, ctx->accum};
+                  ctx->lens_dev, ctx->pairs_dev, ctx->counters_dev, ctx->accum, ctx->events_dev};
   for (void* p : ptrs) if (p) (void)hipFree(p);
   if (ctx->own_stream && ctx->stream) (void)hipStreamDestroy(ctx->stream);
   delete ctx;
@@ -525,6 +530,7 @@ lf_status lf_set_lens(lf_ctx* ctx, int n_surfaces, int stop_index, int n_lambda,
   lf_derive_lens(ctx, n_surfaces, stop_index, n_lambda, radius, thickness, ior, semi_aperture,
                  sensor_width_mm);
   ctx->lens_valid = true;
+  ctx->events_dirty = true;
   // default pair set: every pair of glass surfaces + the primary path
   return lf_set_ghost_pairs(ctx, nullptr, 0, 1);
 }
@@ -577,6 +583,7 @@ lf_status lf_set_ghost_pairs(lf_ctx* ctx, const int* pairs, int n_pairs, int inc
   }
   if (P.n == 0) return lf_fail(ctx, LF_ERR_INVALID, "empty pair set");
   ctx->pairs = P;
+  ctx->events_dirty = true;
   return LF_OK;
 }
 

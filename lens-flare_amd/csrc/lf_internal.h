@@ -94,9 +94,22 @@ struct LfLensDev {
 
 struct LfPairsDev {
   int n;
-  int pad;
-  int ij[LF_MAX_PAIRS + 1][2];  // (-1,-1) = primary path
+  int total_events;              // rows of the event table per wavelength
+  int ij[LF_MAX_PAIRS + 1][2];   // (-1,-1) = primary path
+  int ev_off[LF_MAX_PAIRS + 1];  // first row of pair q in the event table
+  int ev_cnt[LF_MAX_PAIRS + 1];  // N + 2(j - i) rows
 };
+
+// One pre-expanded surface event of one (wavelength, pair) sequence: everything the march needs for
+// it in ONE 32-byte scalar load.  The table (n_lambda x total_events rows, ~85 KB for the bench
+// lens) is walked linearly, so the next row is prefetched while the current event computes.
+struct alignas(32) LfEventRow {
+  float zv, curv, h2, eta;
+  float sgn;       // +1: the ray travels +z (towards the sensor), -1: -z
+  int flags;       // bit 0: mirror reflection, bit 1: the stop
+  int pad[2];
+};
+enum { LF_EV_REFLECT = 1, LF_EV_STOP = 2 };
 
 // ---- timing ---------------------------------------------------------------------------------
 enum LfKernelId { LFK_MARCH = 0, LFK_FLARE_LAYER, LFK_GHOST_RASTER, LFK_DFT, LFK_FRAME_SETUP,
@@ -154,6 +167,9 @@ struct lf_ctx {
   LfPairsDev* pairs_dev = nullptr;
   unsigned long long* counters_dev = nullptr;  // 8 x u64
   unsigned long long* accum = nullptr;         // unused for now
+  LfEventRow* events_dev = nullptr;            // n_lambda x total_events
+  size_t events_cap = 0;
+  bool events_dirty = true;
 
   bool timing = false;
   std::vector<LfTimedLaunch> timed;

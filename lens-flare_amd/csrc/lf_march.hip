@@ -83,10 +83,15 @@ struct Ray {
 
 // One glass-surface event, straight-line (no divergent branches): a lane that misses the surface,
 // leaves the clear aperture or is totally reflected just gets ok = false -- its ray state turns
-// into garbage/NaN that nobody reads again.  geom_ok tells a vignetted ray from a TIR one.
+// into garbage/NaN that nobody reads again.  Liveness is kept as explicit 64-bit wave masks (one
+// SGPR pair, plain s_and/s_or), not as per-lane bools: the compiler lowers loop-carried bools to
+// exec-merge triples that tripled the scalar-unit load of the loop.  geom_ok tells a vignetted ray
+// from a TIR one.
 // sgn = +1 for a ray travelling +z, -1 for -z (wave-uniform, lives in an SGPR).
-__device__ __forceinline__ bool surface_event(Ray& r, float zv, float c, float h2, float eta,
-                                              bool reflect, float sgn, bool& geom_ok) {
+typedef unsigned long long lanemask;
+
+__device__ __forceinline__ lanemask surface_event(Ray& r, float zv, float c, float h2, float eta,
+                                                  bool reflect, float sgn, lanemask& geom_ok) {
   const float oz = r.pz - zv;
   const float od = fmaf(r.px, r.dx, fmaf(r.py, r.dy, oz * r.dz));
   const float oo = fmaf(r.px, r.px, fmaf(r.py, r.py, oz * oz));
@@ -99,7 +104,7 @@ __device__ __forceinline__ bool surface_event(Ray& r, float zv, float c, float h
   const float t = __fdiv_rn(F, den);
   const float hx = fmaf(t, r.dx, r.px), hy = fmaf(t, r.dy, r.py), hz = fmaf(t, r.dz, oz);
   const float r2 = fmaf(hx, hx, hy * hy);
-  geom_ok = (disc >= 0.0f) && (r2 <= h2);
+  geom_ok = __ballot(disc >= 0.0f) & __ballot(r2 <= h2);
   const float nx = -c * hx, ny = -c * hy, nz = fmaf(-c, hz, 1.0f);
   const float mu = fmaf(r.dx, nx, fmaf(r.dy, ny, r.dz * nz));
   const float s2 = fmaf(-mu, mu, 1.0f);
@@ -113,7 +118,7 @@ __device__ __forceinline__ bool surface_event(Ray& r, float zv, float c, float h
   const float e = fmaf(-eta, th, ch), f = fmaf(eta, th, ch);
   const float af = a * f, eb = e * b, bf = b * f;
   const float Rn = 0.5f * fmaf(af, af, eb * eb), D = bf * bf;
-  bool ok = geom_ok;
+  lanemask ok = geom_ok;
   if (reflect) {  // wave-uniform
     r.wn *= no_tir ? Rn : 1.0f;  // total reflection: R = 1
     r.wd *= no_tir ? D : 1.0f;
@@ -122,7 +127,7 @@ __device__ __forceinline__ bool surface_event(Ray& r, float zv, float c, float h
     r.dy = fmaf(m2, ny, r.dy);
     r.dz = fmaf(m2, nz, r.dz);
   } else {
-    ok = ok && no_tir;
+    ok &= __ballot(no_tir);
     r.wn *= D - Rn;
     r.wd *= D;
     const float g = fmaf(-eta, mu, copysignf(ct, mu));
@@ -135,8 +140,8 @@ __device__ __forceinline__ bool surface_event(Ray& r, float zv, float c, float h
 }
 
 // the stop: flat pass-through, clipped by its housing and by the aperture mask
-__device__ __forceinline__ bool stop_event(Ray& r, float zv, float h2, float inv_h,
-                                           const float* __restrict__ mask, int mw, int mh) {
+__device__ __forceinline__ lanemask stop_event(Ray& r, float zv, float h2, float inv_h,
+                                               const float* __restrict__ mask, int mw, int mh) {
   const float t = __fdiv_rn(zv - r.pz, r.dz);
   const float hx = fmaf(t, r.dx, r.px), hy = fmaf(t, r.dy, r.py);
   const float r2 = fmaf(hx, hx, hy * hy);
@@ -148,7 +153,7 @@ __device__ __forceinline__ bool stop_event(Ray& r, float zv, float h2, float inv
   const float a = mask[iy * mw + ix];
   r.wn *= a;
   r.px = hx; r.py = hy; r.pz = zv;
-  return (r2 <= h2) && (a > 0.0f);
+  return __ballot(r2 <= h2) & __ballot(a > 0.0f);
 }
 
 struct MarchArgs {
@@ -163,6 +168,7 @@ struct MarchArgs {
 
 __global__ __launch_bounds__(256) void k_march(const LfLensDev* __restrict__ lens,
                                                const LfPairsDev* __restrict__ pairs,
+                                               const LfEventRow* __restrict__ ev_table,
                                                const float* __restrict__ mask, MarchArgs a,
                                                double* __restrict__ ghost,
                                                unsigned long long* __restrict__ counters) {
@@ -181,13 +187,14 @@ __global__ __launch_bounds__(256) void k_march(const LfLensDev* __restrict__ len
   const unsigned p = (unsigned)y * (unsigned)a.W + (unsigned)x;
   const unsigned tile_id = (unsigned)((a.trow0 + tj * a.tperiod) * tiles_x + tx);  // frame-absolute
 
-  const int n_surf = lens->n_surf, n_lambda = lens->n_lambda, n_pairs = pairs->n;
+  const int n_lambda = lens->n_lambda, n_pairs = pairs->n, total_events = pairs->total_events;
   const float z_sensor = lens->z_sensor, pitch = lens->pitch, pupil_h = lens->pupil_h;
   const float pupil_z = lens->pupil_z, geom_norm = lens->geom_norm;
   const float inv_stop_h = __fdiv_rn(1.0f, lens->stop_h);
   const float sx = lens->sun_dir[0], sy = lens->sun_dir[1], sz = lens->sun_dir[2];
   const float inv_1mc = lens->sun_inv_one_minus_cos;
   const int GG = a.G * a.G;
+  const lanemask active_mask = __ballot(active);
 
   unsigned n_clip = 0, n_vign = 0, n_tir = 0, n_scene = 0, n_light = 0, n_launched = 0;
   unsigned long long events = 0;  // wave-uniform: counted once per wave with s_bcnt1 (SALU)
@@ -237,44 +244,37 @@ __global__ __launch_bounds__(256) void k_march(const LfLensDev* __restrict__ len
       if (active) n_launched += (unsigned)(n_lambda * n_pairs);
 
       for (int l = 0; l < n_lambda; l++) {
+        const LfEventRow* __restrict__ ev_l = ev_table + (size_t)l * (size_t)total_events;
         for (int q = 0; q < n_pairs; q++) {
-          const int pi = pairs->ij[q][0], pj = pairs->ij[q][1];  // wave-uniform (SGPR)
+          // the pair's pre-expanded interface sequence (backwards N-1..i, reflect at i, forwards
+          // i+1..j, reflect at j, backwards j-1..0): one 32-byte scalar load per event, the next
+          // row is requested before the current event computes
+          const LfEventRow* __restrict__ ev = ev_l + pairs->ev_off[q];  // wave-uniform (SGPR)
+          const int n_ev = pairs->ev_cnt[q];
           Ray r{X, Y, z_sensor, d0x, d0y, d0z, w0, 1.0f};
-          bool alive = active;
-          // how the ray died (read once, after the sequence): at the stop / geometrically / TIR
-          bool died_at_stop = false, died_geom = false;
-          // legs: backwards N-1..i (reflect at i), forwards i+1..j (reflect at j), backwards
-          // j-1..0.  The primary path (i < 0) is one backward leg N-1..0.
-          const int n_legs = pi < 0 ? 1 : 3;
-          for (int leg = 0; leg < n_legs; leg++) {
-            const bool fwd = (leg == 1);
-            const float sgn = fwd ? 1.0f : -1.0f;
-            int k, k_end, refl;
-            if (leg == 0) { k = n_surf - 1; k_end = pi < 0 ? 0 : pi; refl = pi; }
-            else if (leg == 1) { k = pi + 1; k_end = pj; refl = pj; }
-            else { k = pj - 1; k_end = 0; refl = -1; }
-            const int step = fwd ? 1 : -1;
-            for (; fwd ? k <= k_end : k >= k_end; k += step) {
-              const LfSurfaceDev& sf = lens->surf[k];  // wave-uniform -> s_load
-              bool ok, geom_ok = true;
-              const bool is_stop = sf.is_stop != 0.0f;
-              if (is_stop) {
-                ok = stop_event(r, sf.zv, sf.h2, inv_stop_h, mask, a.mw, a.mh);
-              } else {
-                const float eta = fwd ? sf.eta_fwd[l] : sf.eta_bwd[l];
-                ok = surface_event(r, sf.zv, sf.curv, sf.h2, eta, k == refl, sgn, geom_ok);
-              }
-              const bool dies = alive && !ok;
-              died_at_stop = died_at_stop || (dies && is_stop);
-              died_geom = died_geom || (dies && !geom_ok);
-              alive = alive && ok;
-              const unsigned long long live = __ballot(alive);
-              if (live == 0ull) break;         // the whole wave is dead: leave the sequence
-              events += __popcll(live);        // SALU
+          lanemask alive = active_mask;
+          // how the rays died (read once, after the sequence): at the stop / geometrically / TIR
+          lanemask died_at_stop = 0ull, died_geom = 0ull;
+          LfEventRow cur = ev[0];
+          for (int e = 0; e < n_ev; e++) {
+            const LfEventRow nxt = ev[min(e + 1, n_ev - 1)];
+            if (cur.flags & LF_EV_STOP) {
+              const lanemask ok = stop_event(r, cur.zv, cur.h2, inv_stop_h, mask, a.mw, a.mh);
+              died_at_stop |= alive & ~ok;
+              alive &= ok;
+            } else {
+              lanemask geom_ok;
+              const lanemask ok = surface_event(r, cur.zv, cur.curv, cur.h2, cur.eta,
+                                                (cur.flags & LF_EV_REFLECT) != 0, cur.sgn, geom_ok);
+              died_geom |= alive & ~geom_ok;
+              alive &= ok;
             }
-            if (__ballot(alive) == 0ull) break;
+            if (alive == 0ull) break;         // the whole wave is dead: leave the sequence
+            events += __popcll(alive);        // s_bcnt1
+            cur = nxt;
           }
-          if (alive) {
+          const bool lane_alive = (alive >> lane) & 1ull;
+          if (lane_alive) {
             n_scene++;
             const float cg = fmaf(r.dx, sx, fmaf(r.dy, sy, r.dz * sz));
             const float qq = (1.0f - cg) * inv_1mc;
@@ -291,8 +291,8 @@ __global__ __launch_bounds__(256) void k_march(const LfLensDev* __restrict__ len
               }
             }
           } else if (active) {
-            if (died_at_stop) n_clip++;
-            else if (died_geom) n_vign++;
+            if ((died_at_stop >> lane) & 1ull) n_clip++;
+            else if ((died_geom >> lane) & 1ull) n_vign++;
             else n_tir++;
           }
         }
@@ -371,8 +371,63 @@ void lf_derive_lens(lf_ctx* ctx, int n, int stop, int n_lambda, const float* rad
                                                                       : 1.0f / (float)n_lambda;
 }
 
+// host: expand every selected pair into its event rows (per wavelength), see LfEventRow
+static lf_status build_event_table(lf_ctx* ctx) {
+  const LfLensDev& L = ctx->lens;
+  LfPairsDev& P = ctx->pairs;
+  int total = 0;
+  for (int q = 0; q < P.n; q++) {
+    const int i = P.ij[q][0], j = P.ij[q][1];
+    P.ev_off[q] = total;
+    P.ev_cnt[q] = i < 0 ? L.n_surf : L.n_surf + 2 * (j - i);
+    total += P.ev_cnt[q];
+  }
+  P.total_events = total;
+  std::vector<LfEventRow> rows((size_t)total * L.n_lambda);
+  for (int l = 0; l < L.n_lambda; l++)
+    for (int q = 0; q < P.n; q++) {
+      LfEventRow* out = rows.data() + (size_t)l * total + P.ev_off[q];
+      const int i = P.ij[q][0], j = P.ij[q][1];
+      int n = 0;
+      auto put = [&](int k, bool reflect, bool fwd) {
+        const LfSurfaceDev& s = L.surf[k];
+        LfEventRow r;
+        r.zv = s.zv; r.curv = s.curv; r.h2 = s.h2;
+        r.eta = fwd ? s.eta_fwd[l] : s.eta_bwd[l];
+        r.sgn = fwd ? 1.0f : -1.0f;
+        r.flags = (reflect ? LF_EV_REFLECT : 0) | (s.is_stop != 0.0f ? LF_EV_STOP : 0);
+        r.pad[0] = r.pad[1] = 0;
+        out[n++] = r;
+      };
+      if (i < 0) {
+        for (int k = L.n_surf - 1; k >= 0; k--) put(k, false, false);
+      } else {
+        for (int k = L.n_surf - 1; k > i; k--) put(k, false, false);
+        put(i, true, false);
+        for (int k = i + 1; k < j; k++) put(k, false, true);
+        put(j, true, true);
+        for (int k = j - 1; k >= 0; k--) put(k, false, false);
+      }
+      if (n != P.ev_cnt[q]) return lf_fail(ctx, LF_ERR_STATE, "event table: sequence length mismatch");
+    }
+  if (rows.size() > ctx->events_cap) {
+    if (ctx->events_dev) { LF_HIP(ctx, hipStreamSynchronize(ctx->stream)); (void)hipFree(ctx->events_dev); }
+    ctx->events_dev = nullptr;
+    LF_HIP(ctx, hipMalloc((void**)&ctx->events_dev, rows.size() * sizeof(LfEventRow)));
+    ctx->events_cap = rows.size();
+  }
+  LF_HIP(ctx, hipMemcpy(ctx->events_dev, rows.data(), rows.size() * sizeof(LfEventRow),
+                        hipMemcpyHostToDevice));
+  ctx->events_dirty = false;
+  return LF_OK;
+}
+
 lf_status lfk_march(lf_ctx* ctx, int spp, uint64_t key) {
   const LfApertureDev& m = ctx->ap[LF_APERTURE_STARBURST];
+  if (ctx->events_dirty) {
+    lf_status st = build_event_table(ctx);
+    if (st != LF_OK) return st;
+  }
   LF_HIP(ctx, hipMemcpyAsync(ctx->lens_dev, &ctx->lens, sizeof(LfLensDev), hipMemcpyHostToDevice,
                              ctx->stream));
   LF_HIP(ctx, hipMemcpyAsync(ctx->pairs_dev, &ctx->pairs, sizeof(LfPairsDev), hipMemcpyHostToDevice,
@@ -399,7 +454,7 @@ lf_status lfk_march(lf_ctx* ctx, int spp, uint64_t key) {
   if (blocks > 0x7fffffffull) return lf_fail(ctx, LF_ERR_INVALID, "band too large for one launch");
   hipEvent_t ev = lf_timing_begin(ctx, LFK_MARCH);
   hipLaunchKernelGGL(k_march, dim3((unsigned)blocks), dim3(256), 0, ctx->stream, ctx->lens_dev,
-                     ctx->pairs_dev, m.texels, a, ctx->ghost, ctx->counters_dev);
+                     ctx->pairs_dev, ctx->events_dev, m.texels, a, ctx->ghost, ctx->counters_dev);
   lf_timing_end(ctx, LFK_MARCH, ev);
   LF_HIP(ctx, hipGetLastError());
   return LF_OK;

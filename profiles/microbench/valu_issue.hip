@@ -12,6 +12,8 @@ __global__ __launch_bounds__(256) void k(float* out, int iters, float seed) {
         a6 = a0 + 6, a7 = a0 + 7;
   const float m = 0.999f, c = 0.001f;
   int sacc = 0;
+  typedef float float2v __attribute__((ext_vector_type(2)));
+  float2v p0 = {a0, a1}, p1 = {a2, a3}, p2 = {a4, a5}, p3 = {a6, a7}, pm = {m, m}, pc = {c, c};
   for (int i = 0; i < iters; i++) {
 #pragma unroll
     for (int u = 0; u < 8; u++) {
@@ -50,6 +52,16 @@ __global__ __launch_bounds__(256) void k(float* out, int iters, float seed) {
                      "v_sqrt_f32 %0, %0\n v_fma_f32 %0, %0, %1, %2\n v_fma_f32 %0, %0, %1, %2\n"
                      "v_rcp_f32 %0, %0\n v_fma_f32 %0, %0, %1, %2\n"
                      : "+v"(a0) : "v"(m), "v"(c));
+      } else if (MODE == 7) {  // packed fp32: 4 independent v_pk_fma_f32 chains (2 flops-pairs per lane)
+        asm volatile("v_pk_fma_f32 %0, %0, %4, %5\n v_pk_fma_f32 %1, %1, %4, %5\n v_pk_fma_f32 %2, %2, %4, %5\n"
+                     "v_pk_fma_f32 %3, %3, %4, %5\n v_pk_fma_f32 %0, %0, %4, %5\n v_pk_fma_f32 %1, %1, %4, %5\n"
+                     "v_pk_fma_f32 %2, %2, %4, %5\n v_pk_fma_f32 %3, %3, %4, %5\n"
+                     : "+v"(p0), "+v"(p1), "+v"(p2), "+v"(p3) : "v"(pm), "v"(pc));
+      } else if (MODE == 8) {  // v_pk_mul_f32 + v_pk_add_f32 alternating, 4 chains
+        asm volatile("v_pk_mul_f32 %0, %0, %4\n v_pk_add_f32 %1, %1, %5\n v_pk_mul_f32 %2, %2, %4\n"
+                     "v_pk_add_f32 %3, %3, %5\n v_pk_mul_f32 %0, %0, %4\n v_pk_add_f32 %1, %1, %5\n"
+                     "v_pk_mul_f32 %2, %2, %4\n v_pk_add_f32 %3, %3, %5\n"
+                     : "+v"(p0), "+v"(p1), "+v"(p2), "+v"(p3) : "v"(pm), "v"(pc));
       } else if (MODE == 6) {  // cmp + cndmask pairs through VCC, dependent
         asm volatile("v_cmp_gt_f32 vcc, %0, %2\n v_cndmask_b32 %0, %0, %1, vcc\n v_fma_f32 %0, %0, %1, %2\n"
                      "v_cmp_gt_f32 vcc, %0, %2\n v_cndmask_b32 %0, %0, %1, vcc\n v_fma_f32 %0, %0, %1, %2\n"
@@ -58,7 +70,7 @@ __global__ __launch_bounds__(256) void k(float* out, int iters, float seed) {
       }
     }
   }
-  out[blockIdx.x * 256 + threadIdx.x] = a0 + a1 + a2 + a3 + a4 + a5 + a6 + a7 + sacc;
+  out[blockIdx.x * 256 + threadIdx.x] = a0 + a1 + a2 + a3 + a4 + a5 + a6 + a7 + sacc + p0.x + p0.y + p1.x + p1.y + p2.x + p2.y + p3.x + p3.y;
 }
 
 template <int MODE>
@@ -82,10 +94,11 @@ int main() {
   hipMalloc(&d, sizeof(float) * 256 * 256 * 16);
   const char* names[] = {"8 independent fma chains", "1 dependent fma chain", "2 interleaved chains",
                          "8 indep fma + 4 SALU per 8", "dependent fma + 4 SALU per 8",
-                         "dependent: 6 fma + sqrt + rcp", "dependent: 2x(cmp+cndmask) + 4 fma"};
-  for (int wps : {1, 2, 4, 8}) {  // waves per SIMD = blocks per CU (256 threads = 4 waves = 1/SIMD)
+                         "dependent: 6 fma + sqrt + rcp", "dependent: 2x(cmp+cndmask) + 4 fma",
+                         "4 indep v_pk_fma_f32 chains", "v_pk_mul/v_pk_add alternating"};
+  for (int wps : {2, 8}) {  // waves per SIMD = blocks per CU (256 threads = 4 waves = 1/SIMD)
     int blocks = 256 * wps;
-    double r[7];
+    double r[9];
     r[0] = run<0>(d, blocks, 20000, 8);
     r[1] = run<1>(d, blocks, 20000, 8);
     r[2] = run<2>(d, blocks, 20000, 8);
@@ -93,8 +106,10 @@ int main() {
     r[4] = run<4>(d, blocks, 20000, 8);
     r[5] = run<5>(d, blocks, 20000, 8);
     r[6] = run<6>(d, blocks, 20000, 8);
-    for (int i = 0; i < 7; i++)
-      printf("waves/SIMD %d  %-36s %.3e VALU wave-instr/s  (%.2f cyc/instr/SIMD @2.4GHz)\n", wps, names[i],
+    r[7] = run<7>(d, blocks, 20000, 8);
+    r[8] = run<8>(d, blocks, 20000, 8);
+    for (int i = 0; i < 9; i++)
+      if (i != 3 && i != 4) printf("waves/SIMD %d  %-36s %.3e VALU wave-instr/s  (%.2f cyc/instr/SIMD @2.4GHz)\n", wps, names[i],
              r[i], 1024 * 2.4e9 / r[i]);
   }
   return 0;
