@@ -71,6 +71,7 @@ struct LfApertureDev {
 struct LfSurfaceDev {
   float zv;        // vertex z (scene side first, light travels +z)
   float curv;      // 1/R, 0 for flats and the stop
+  float radius;    // R as given (0 for flats)
   float h2;        // semi-aperture squared
   float is_stop;   // 1.0f for the stop
   float eta_fwd[LF_MAX_LAMBDA];  // n_before / n_after   (ray travelling +z refracts with this)
@@ -106,10 +107,11 @@ struct LfPairsDev {
 struct alignas(32) LfEventRow {
   float zv, curv, h2, eta;
   float sgn;       // +1: the ray travels +z (towards the sensor), -1: -z
-  int flags;       // bit 0: mirror reflection, bit 1: the stop
-  int pad[2];
+  int flags;       // bit 0: mirror reflection, bit 1: the stop, bit 2: flat (curv == 0)
+  float radius;    // 1 / curv as given in the prescription (0 for flats)
+  int pad;
 };
-enum { LF_EV_REFLECT = 1, LF_EV_STOP = 2 };
+enum { LF_EV_REFLECT = 1, LF_EV_STOP = 2, LF_EV_FLAT = 4 };
 
 // ---- timing ---------------------------------------------------------------------------------
 enum LfKernelId { LFK_MARCH = 0, LFK_FLARE_LAYER, LFK_GHOST_RASTER, LFK_DFT, LFK_FRAME_SETUP,

@@ -90,8 +90,9 @@ struct Ray {
 // sgn = +1 for a ray travelling +z, -1 for -z (wave-uniform, lives in an SGPR).
 typedef unsigned long long lanemask;
 
-__device__ __forceinline__ lanemask surface_event(Ray& r, float zv, float c, float h2, float eta,
-                                                  bool reflect, float sgn, lanemask& geom_ok) {
+__device__ __forceinline__ lanemask surface_event(Ray& r, float zv, float c, float rad, float h2,
+                                                  float eta, bool reflect, bool flat, float sgn,
+                                                  lanemask& geom_ok) {
   const float oz = r.pz - zv;
   const float od = fmaf(r.px, r.dx, fmaf(r.py, r.dy, oz * r.dz));
   const float oo = fmaf(r.px, r.px, fmaf(r.py, r.py, oz * oz));
@@ -100,8 +101,14 @@ __device__ __forceinline__ lanemask surface_event(Ray& r, float zv, float c, flo
   const float cF = c * F;
   const float disc = fmaf(G, G, -cF);
   const float sq = lf_sqrt(disc);
-  const float den = fmaf(sgn, sq, G);  // == G + sq (forward) or G - sq (backward), one rounding
-  const float t = __fdiv_rn(F, den);
+  // the root next to the vertex, t = F / (G + sgn sqrt(disc)).  For a curved interface the same
+  // root is (G - sgn sqrt(disc)) * R with R = 1/c from the prescription: one fma + one multiply
+  // instead of an IEEE division (12 VALU incl. v_rcp).  The subtraction cancels at most
+  // log2(2 G^2 / (c F)) bits (<= 8 for this lens: <= 3e-5 mm on the hit point), which both the
+  // kernel and the oracle do identically.  Flat glass (c = 0) keeps the quotient.
+  float t;
+  if (flat) t = __fdiv_rn(F, fmaf(sgn, sq, G));   // wave-uniform branch
+  else t = fmaf(-sgn, sq, G) * rad;
   const float hx = fmaf(t, r.dx, r.px), hy = fmaf(t, r.dy, r.py), hz = fmaf(t, r.dz, oz);
   const float r2 = fmaf(hx, hx, hy * hy);
   geom_ok = __ballot(disc >= 0.0f) & __ballot(r2 <= h2);
@@ -264,8 +271,9 @@ __global__ __launch_bounds__(256) void k_march(const LfLensDev* __restrict__ len
               alive &= ok;
             } else {
               lanemask geom_ok;
-              const lanemask ok = surface_event(r, cur.zv, cur.curv, cur.h2, cur.eta,
-                                                (cur.flags & LF_EV_REFLECT) != 0, cur.sgn, geom_ok);
+              const lanemask ok = surface_event(r, cur.zv, cur.curv, cur.radius, cur.h2, cur.eta,
+                                                (cur.flags & LF_EV_REFLECT) != 0,
+                                                (cur.flags & LF_EV_FLAT) != 0, cur.sgn, geom_ok);
               died_geom |= alive & ~geom_ok;
               alive &= ok;
             }
@@ -347,6 +355,7 @@ void lf_derive_lens(lf_ctx* ctx, int n, int stop, int n_lambda, const float* rad
     s.zv = z;
     z = z + thickness[k];
     s.curv = radius[k] == 0.0f ? 0.0f : 1.0f / radius[k];
+    s.radius = radius[k];
     s.h2 = semi_ap[k] * semi_ap[k];
     s.is_stop = (k == stop) ? 1.0f : 0.0f;
   }
@@ -395,8 +404,10 @@ static lf_status build_event_table(lf_ctx* ctx) {
         r.zv = s.zv; r.curv = s.curv; r.h2 = s.h2;
         r.eta = fwd ? s.eta_fwd[l] : s.eta_bwd[l];
         r.sgn = fwd ? 1.0f : -1.0f;
-        r.flags = (reflect ? LF_EV_REFLECT : 0) | (s.is_stop != 0.0f ? LF_EV_STOP : 0);
-        r.pad[0] = r.pad[1] = 0;
+        r.flags = (reflect ? LF_EV_REFLECT : 0) | (s.is_stop != 0.0f ? LF_EV_STOP : 0) |
+                  (s.curv == 0.0f ? LF_EV_FLAT : 0);
+        r.radius = s.radius;
+        r.pad = 0;
         out[n++] = r;
       };
       if (i < 0) {

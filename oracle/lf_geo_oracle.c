@@ -95,7 +95,8 @@ enum { OK_ = 0, CLIPPED = 1, VIGNETTED = 2, TIR = 3 };
 
 /* DESIGN.md "march arithmetic", glass interface.  reflect: 0 = Snell refraction, 1 = mirror.
  * forward: the ray travels +z (scene -> sensor). */
-static int glass_event(geo_ray* r, float zv, float c, float h2, float eta, int reflect, int forward) {
+static int glass_event(geo_ray* r, float zv, float c, float rad, float h2, float eta, int reflect,
+                       int forward) {
   float oz = r->p[2] - zv;
   float od = fmaf(r->p[0], r->d[0], fmaf(r->p[1], r->d[1], oz * r->d[2]));
   float oo = fmaf(r->p[0], r->p[0], fmaf(r->p[1], r->p[1], oz * oz));
@@ -104,7 +105,10 @@ static int glass_event(geo_ray* r, float zv, float c, float h2, float eta, int r
   float disc = fmaf(G, G, -(c * F));
   if (disc < 0.0f) return VIGNETTED;
   float root = sqrtf(disc);
-  float t = F / (forward ? G + root : G - root);
+  /* vertex-side root: (G -+ root) * R for a curved interface (R = 1/c as given in the
+   * prescription), the quotient F / (G +- root) for flat glass -- DESIGN.md "march arithmetic" */
+  float sgn = forward ? 1.0f : -1.0f;
+  float t = (c == 0.0f) ? F / fmaf(sgn, root, G) : fmaf(-sgn, root, G) * rad;
   float hx = fmaf(t, r->d[0], r->p[0]), hy = fmaf(t, r->d[1], r->p[1]), hz = fmaf(t, r->d[2], oz);
   if (!(fmaf(hx, hx, hy * hy) <= h2)) return VIGNETTED;
   float n[3] = {-c * hx, -c * hy, fmaf(-c, hz, 1.0f)};
@@ -152,7 +156,7 @@ static int stop_event(geo_ray* r, float zv, float h2, float inv_h, const float* 
 int geo_glass_event(float p[3], float d[3], float* w, float zv, float c, float h2, float eta,
                     int reflect, int forward) {
   geo_ray r = {{p[0], p[1], p[2]}, {d[0], d[1], d[2]}, *w, 1.0f};
-  int st = glass_event(&r, zv, c, h2, eta, reflect, forward);
+  int st = glass_event(&r, zv, c, c == 0.0f ? 0.0f : 1.0f / c, h2, eta, reflect, forward);
   memcpy(p, r.p, sizeof(r.p)); memcpy(d, r.d, sizeof(r.d)); *w = r.wn / r.wd;
   return st;
 }
@@ -264,7 +268,7 @@ void geo_trace(const geo_lens* L, int W, int H, int y0, int y1, int spp, const u
               if (k == L->stop)
                 st = stop_event(&r, D.zv[k], D.h2[k], D.inv_stop_h, mask, mw, mh);
               else
-                st = glass_event(&r, D.zv[k], D.curv[k], D.h2[k],
+                st = glass_event(&r, D.zv[k], D.curv[k], L->radius[k], D.h2[k],
                                  seq[e].forward ? D.eta_fwd[l][k] : D.eta_bwd[l][k], seq[e].reflect,
                                  seq[e].forward);
               if (st != OK_) break;
@@ -316,7 +320,7 @@ int geo_trace_ray(const geo_lens* L, int lambda, int i, int j, float p[3], float
   for (int e = 0; e < n; e++) {
     int k = seq[e].k;
     if (k == L->stop) st = stop_event(&r, D.zv[k], D.h2[k], D.inv_stop_h, mask, mw, mh);
-    else st = glass_event(&r, D.zv[k], D.curv[k], D.h2[k],
+    else st = glass_event(&r, D.zv[k], D.curv[k], L->radius[k], D.h2[k],
                           seq[e].forward ? D.eta_fwd[lambda][k] : D.eta_bwd[lambda][k],
                           seq[e].reflect, seq[e].forward);
     if (st != OK_) break;
@@ -350,7 +354,7 @@ void geo_survival(const geo_lens* L, int W, int H, int y0, int y1, int spp, cons
         for (int e = 0; e < n; e++) {
           int k = seq[e].k, st;
           if (k == L->stop) st = stop_event(&r, D.zv[k], D.h2[k], D.inv_stop_h, mask, mw, mh);
-          else st = glass_event(&r, D.zv[k], D.curv[k], D.h2[k],
+          else st = glass_event(&r, D.zv[k], D.curv[k], L->radius[k], D.h2[k],
                                 seq[e].forward ? D.eta_fwd[l][k] : D.eta_bwd[l][k], seq[e].reflect,
                                 seq[e].forward);
           if (st != OK_) break;
