@@ -156,6 +156,7 @@ def main():
             # the buffer is padded to 64 rows so the last group never runs past the end.
             lf.synchronize()
             sharding.gather_frame_inplace(frame_t, W, H, rank, world, dist)
+            torch.cuda.synchronize()   # the next frame rewrites these rows on the library's stream
 
     def barrier():
         lf.synchronize()

@@ -262,9 +262,10 @@ __global__ __launch_bounds__(256) void k_march(const LfLensDev* __restrict__ len
           lanemask alive = active_mask;
           // how the rays died (read once, after the sequence): at the stop / geometrically / TIR
           lanemask died_at_stop = 0ull, died_geom = 0ull;
-          LfEventRow cur = ev[0];
-          for (int e = 0; e < n_ev; e++) {
-            const LfEventRow nxt = ev[min(e + 1, n_ev - 1)];
+          for (int left = n_ev; left > 0; --left, ++ev) {
+            // (no software prefetch: 7 waves per SIMD hide the scalar-cache latency, and carrying a
+            // `next` row costs 8 SGPR copies per event on the shared scalar unit)
+            const LfEventRow cur = *ev;
             if (cur.flags & LF_EV_STOP) {
               const lanemask ok = stop_event(r, cur.zv, cur.h2, inv_stop_h, mask, a.mw, a.mh);
               died_at_stop |= alive & ~ok;
@@ -279,7 +280,6 @@ __global__ __launch_bounds__(256) void k_march(const LfLensDev* __restrict__ len
             }
             if (alive == 0ull) break;         // the whole wave is dead: leave the sequence
             events += __popcll(alive);        // s_bcnt1
-            cur = nxt;
           }
           const bool lane_alive = (alive >> lane) & 1ull;
           if (lane_alive) {
