@@ -199,14 +199,28 @@ def main():
         alg_bytes = rows_per_launch * W * 24 + mask.size * 4 + 4096
         avg_ms = march_ms / max(n_launch, 1)
         achieved = alg_bytes / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0
-        traffic = None
+        traffic, slots = None, None
         tf = os.path.join(ROOT, "profiles", "r01_march_pmc.json")
         if os.path.exists(tf):
             try:
-                traffic = json.load(open(tf)).get("hbm_bytes_per_launch")
+                pmc = json.load(open(tf))
+                slots = pmc.get("valu_lane_slots_per_event")
+                # PMC traffic is per launch of the profiled 1-GPU run (whole frame per launch)
+                traffic = pmc.get("hbm_bytes_per_launch") if world == 1 else None
             except Exception:
                 traffic = None
         ev_per_launch = events / max(1, n_launch * world)
+        ev_rate_gpu = ev_per_launch / (avg_ms * 1e-3) if avg_ms > 0 else 0.0
+        valu = {"bound": "valu", "unit": "wave-instr/s", "peak": VALU_PEAK_LANEOPS / 64.0,
+                "practical_peak": 1.05e12, "events_per_s_per_gpu": ev_rate_gpu,
+                "note": "peak = 1024 SIMD-32 x 2.4 GHz / 2 clk per wave64 op; practical_peak = "
+                        "profiles/microbench/valu_issue.hip (8 waves/SIMD, independent v_fma_f32); "
+                        "instructions per event from the rocprofv3 PMC pass in profiles/"}
+        if slots:
+            valu["lane_slots_per_event"] = slots
+            valu["achieved"] = ev_rate_gpu * slots / 64.0
+            valu["frac"] = valu["achieved"] / valu["peak"]
+            valu["frac_of_practical"] = valu["achieved"] / valu["practical_peak"]
         out = {
             "metric": "Mray-surface-intersections/s + frame time, 1080p 256spp double-Gauss",
             "value": events / dt / 1e6,
@@ -229,8 +243,7 @@ def main():
                          "algorithmic_bytes_per_launch": alg_bytes,
                          "note": "register-resident march: compulsory traffic is O(frame); the "
                                  "binding resource is FP32 VALU issue, see valu"},
-            "valu": {"events_per_s_per_gpu": ev_per_launch / (avg_ms * 1e-3) if avg_ms > 0 else 0.0,
-                     "lane_ops_peak_per_s": VALU_PEAK_LANEOPS},
+            "valu": valu,
             "cpu_baseline": cpu,
         }
         print(json.dumps(out), flush=True)

@@ -4,6 +4,7 @@ march kernel, with the gfx950 FETCH_SIZE x2 correction of MI355X_MICROARCH.md (H
 import csv
 import glob
 import json
+import os
 import sys
 from collections import defaultdict
 
@@ -24,8 +25,20 @@ if "FETCH_SIZE" in pl and "WRITE_SIZE" in pl:
     # FETCH_SIZE / WRITE_SIZE are in KiB; gfx950 FETCH_SIZE reports half of a wide streaming read
     res["hbm_bytes_per_launch"] = (2.0 * pl["FETCH_SIZE"] + pl["WRITE_SIZE"]) * 1024.0
     res["hbm_bytes_per_launch_uncorrected"] = (pl["FETCH_SIZE"] + pl["WRITE_SIZE"]) * 1024.0
-if "SQ_THREAD_CYCLES_VALU" in pl and "SQ_ACTIVE_INST_VALU" in pl and pl["SQ_ACTIVE_INST_VALU"]:
-    res["valu_lane_utilisation"] = pl["SQ_THREAD_CYCLES_VALU"] / (64.0 * pl["SQ_ACTIVE_INST_VALU"])
-if "SQ_ACTIVE_INST_VALU" in pl and "SQ_BUSY_CYCLES" in pl and pl["SQ_BUSY_CYCLES"]:
-    res["valu_busy_fraction_raw"] = pl["SQ_ACTIVE_INST_VALU"] / pl["SQ_BUSY_CYCLES"]
+# the bench line printed by the SQ pass: executed events of that very run
+try:
+    line = [l for l in open(os.path.join(out_dir, "sq.json")) if l.startswith("{")][-1]
+    b = json.loads(line)
+    ev = b["config"]["events_per_frame"]
+    res["events_per_launch"] = ev
+    res["ms_per_launch_under_pmc"] = b["roofline"]["avg_launch_ms"]
+    if "SQ_INSTS_VALU" in pl:
+        res["valu_wave_instr_per_launch"] = pl["SQ_INSTS_VALU"]
+        res["valu_lane_slots_per_event"] = pl["SQ_INSTS_VALU"] * 64.0 / ev
+    if "SQ_INSTS_SALU" in pl:
+        res["salu_instr_per_wave_event_at_90pct_live"] = pl["SQ_INSTS_SALU"] / (ev / (64 * 0.9))
+    if "GRBM_GUI_ACTIVE" in pl:
+        res["clock_ghz"] = pl["GRBM_GUI_ACTIVE"] / 8.0 / (b["roofline"]["avg_launch_ms"] * 1e-3) / 1e9
+except Exception as e:  # noqa: BLE001
+    res["note"] = f"no bench line next to the counters: {e}"
 print(json.dumps(res, indent=1))

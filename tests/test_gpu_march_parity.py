@@ -56,14 +56,47 @@ def test_dgauss_all_pairs_bit_exact(pkg, lf, W, H, spp):
 
 
 def test_thin_lens_config_c1(pkg, lf):
-    """Config C1: single biconvex lens, no stop, one ghost pair (0,1) + primary."""
+    """BASELINE.json configs[0]: single thin lens (2 spherical surfaces), 256x256, 1 spp, one
+    light; no stop, one ghost pair (0,1) + primary.  GPU == CPU oracle bit for bit; plus 4 spp."""
     lens = pkg.load_lens_file("thinlens.lens")
     mask = np.ones((8, 8), np.float32)
-    g, cnt, og, ocnt = _run(pkg, lf, lens, 64, 64, 4, 99, mask,
-                            sun=dict(direction=[0.0, 0.0, -1.0], radiance=[1, 1, 1], angular_radius=0.1))
-    assert cnt == ocnt and np.array_equal(g, og)
-    assert cnt["rays_launched"] == 64 * 64 * 4 * 3 * 2
-    assert og.max() > 0
+    sun = dict(direction=[0.0, 0.0, -1.0], radiance=[1, 1, 1], angular_radius=0.1)
+    for spp in (1, 4):
+        g, cnt, og, ocnt = _run(pkg, lf, lens, 256, 256, spp, 99, mask, sun=sun)
+        assert cnt == ocnt and np.array_equal(g, og)
+        assert cnt["rays_launched"] == 256 * 256 * spp * 3 * 2
+        assert og.max() > 0
+
+
+def test_eight_wavelengths_config_c5_subset(pkg, lf):
+    """BASELINE.json configs[4] asks for 8 wavelengths: the march takes any n_lambda <= 8 with an
+    RGB weight per wavelength (lf_set_lambda_rgb).  8 indices by linear interpolation of the lens
+    file's three columns; GPU == oracle bit for bit, and with the 3 original columns + identity
+    weights the 3-wavelength result is reproduced exactly."""
+    lens3 = pkg.load_lens_file("dgauss11.lens")
+    t = np.linspace(0.0, 2.0, 8)
+    ior8 = np.stack([np.array([np.interp(tt, [0, 1, 2], lens3["ior"][:, k]) for k in range(lens3["n"])])
+                     for tt in t]).astype(np.float32)
+    lens8 = dict(lens3, ior=ior8)
+    w8 = np.zeros((8, 3), np.float32)
+    for l, tt in enumerate(t):   # tent weights onto R, G, B
+        for c in range(3):
+            w8[l, c] = max(0.0, 1.0 - abs(tt - c)) / 2.6666667
+    mask = load_texels("pentbig500_14.png")
+    W, H, spp = 32, 16, 9
+    lf.set_frame(W, H)
+    lf.set_aperture(pkg.APERTURE_STARBURST, mask)
+    lf.set_lens(lens8)
+    lf.set_lambda_rgb(w8)
+    lf.set_sun(SUN["direction"], SUN["radiance"], SUN["angular_radius"])
+    lf.set_ghost_pairs(None, True)
+    lf.reset_counters()
+    lf.trace_ghosts(spp, 77)
+    g = lf.read_buffer(pkg.GHOST_BUFFER)
+    og, ocnt = lfo.geo_trace(lens8, W, H, 0, H, spp, 77, None, True, mask, SUN["direction"],
+                             SUN["radiance"], SUN["angular_radius"], lambda_rgb=w8)
+    assert lf.counters() == ocnt and ocnt["rays_launched"] == W * H * spp * 8 * 46
+    assert np.array_equal(g, og) and og.max() > 0
 
 
 def test_reference_pair_subset_and_no_primary(pkg, lf):
@@ -99,7 +132,7 @@ def test_full_size_properties(pkg, lf):
     (e) a 64x36 crop of rows equals the oracle on those rows."""
     lens = pkg.load_lens_file("dgauss11.lens")
     mask = load_texels("pentbig500_14.png")
-    W, H, spp = 1920, 1080, 4
+    W, H, spp = 1920, 1080, 64   # BASELINE.json configs[1]: 1080p, 64 spp
     lf.set_frame(W, H)
     lf.set_aperture(pkg.APERTURE_STARBURST, mask)
     lf.set_lens(lens)
@@ -125,6 +158,37 @@ def test_full_size_properties(pkg, lf):
     og, _ = lfo.geo_trace(lens, W, H, rows[0], rows[1], spp, 42, None, True, mask, SUN["direction"],
                           SUN["radiance"], SUN["angular_radius"])
     assert np.array_equal(a[rows[0]:rows[1]], og[rows[0]:rows[1]])
+
+
+def test_4k_frame_properties(pkg, lf):
+    """BASELINE.json configs[3] size (3840x2160; its dragon.dae is absent from the reference, so the
+    synthetic sun stands in): counters conserved, and 8 interleave phases (the 8-GPU deal) add up to
+    the single-launch frame exactly."""
+    lens = pkg.load_lens_file("dgauss11.lens")
+    mask = load_texels("pentbig500_14.png")
+    W, H, spp = 3840, 2160, 2
+    lf.set_frame(W, H)
+    lf.set_aperture(pkg.APERTURE_STARBURST, mask)
+    lf.set_lens(lens)
+    lf.set_sun(SUN["direction"], SUN["radiance"], SUN["angular_radius"])
+    lf.set_ghost_pairs(None, True)
+    lf.reset_counters()
+    lf.trace_ghosts(spp, 9)
+    full = lf.read_buffer(pkg.GHOST_BUFFER)
+    c = lf.counters()
+    assert c["rays_launched"] == W * H * spp * 3 * 46
+    assert c["rays_launched"] == (c["rays_clipped_stop"] + c["rays_vignetted"] + c["rays_tir"] +
+                                  c["rays_reached_scene"])
+    lf.set_frame(W, H)          # fresh (zeroed) buffers
+    lf.set_lens(lens)
+    lf.set_ghost_pairs(None, True)
+    lf.reset_counters()
+    for phase in range(8):
+        lf.set_row_interleave(phase, 8)
+        lf.trace_ghosts(spp, 9)
+    lf.set_row_interleave(0, 1)
+    assert np.array_equal(lf.read_buffer(pkg.GHOST_BUFFER), full)
+    assert lf.counters() == c
 
 
 def test_tile_row_interleave_reassembles_frame(pkg, lf):
