@@ -124,6 +124,31 @@ lf_status lf_set_jitter_counter(lf_ctx* ctx, uint64_t key);
  * pathtracer.cpp:841-875) computed by the host: W*H*3 doubles, NULL = zero */
 lf_status lf_set_scene_term(lf_ctx* ctx, const double* rgb);
 
+/* ---------------------------------------------------------------- scene term (row f2) ---- */
+/* The static scene the sample loop of raytrace_pixel shades (pathtracer.cpp:841-875): replaces
+ * PathTracer::bvh / scene (pathtracer.h:116-124) for spheres (scene/sphere.h), triangles
+ * (scene/triangle.h) with DiffuseBSDF / EmissionBSDF materials (pathtracer/bsdf.h:122-153,
+ * :271-288) and DirectionalLight / PointLight (scene/light.h:16-29, :47-58).
+ *   spheres        n x {cx, cy, cz, r}
+ *   tri_positions  n x 9 (p1 p2 p3), tri_normals n x 9 (vertex normals n1 n2 n3)
+ *   materials      n x {kind, r, g, b}: kind 0 = diffuse reflectance, 1 = emitted radiance
+ *   lights         n x {type, x, y, z, r, g, b}: type 0 = directional (xyz = dirToLight, unit),
+ *                  1 = point (xyz = position); rgb = radiance.  Order = order in scene->lights.
+ * Other light and BSDF types are refused (LF_ERR_INVALID): see lf_scene.hip. */
+lf_status lf_set_scene(lf_ctx* ctx, int n_spheres, const double* spheres, const int* sphere_material,
+                       int n_triangles, const double* tri_positions, const double* tri_normals,
+                       const int* tri_material, int n_materials, const double* materials,
+                       int n_lights, const double* lights);
+/* replaces the public fields samplesPerBatch / maxTolerance (pathtracer.h:112-113) and
+ * Camera::nClip / fClip (camera.h:188) */
+lf_status lf_set_sampling(lf_ctx* ctx, int samples_per_batch, double max_tolerance, double n_clip,
+                          double f_clip);
+/* replaces the sample loop of PathTracer::raytrace_pixel (pathtracer.cpp:831-875) for every pixel
+ * of the band: ns_aa jittered pinhole rays -> closest hit -> emission + direct lighting, adaptive
+ * early-out, divided by the loop variable (ns_aa + 1 without early-out).  The result becomes the
+ * scene term lf_render_flare_layer composes.  Pixel jitter follows lf_set_jitter_*. */
+lf_status lf_render_scene_term(lf_ctx* ctx);
+
 /* ---------------------------------------------------------------- render ----------------- */
 /* replaces: PathTracer::generate_ghost_buffer (pathtracer.cpp:714-817): paraxial trace of the
  * 13 reflection pairs x 3 colours and rasterisation of the 39 textured quads */
@@ -146,6 +171,10 @@ lf_status lf_read_pixel(lf_ctx* ctx, int which, int x, int y, double rgb[3]);
  * :53-62): RGBA8 of the tile, dst rows `row_stride` uint32 apart */
 lf_status lf_write_to_framebuffer(lf_ctx* ctx, int x0, int y0, int x1, int y1, uint32_t* dst,
                                   size_t row_stride);
+/* replaces the pixel preparation of RaytracedRenderer::save_image
+ * (raytraced_renderer.cpp:739-746): the whole tonemapped frame with rows flipped (PNG is top-down)
+ * and alpha forced to 0xFF, W*H uint32 ready for lodepng::encode (the encoder stays with the host) */
+lf_status lf_save_image_rgba(lf_ctx* ctx, uint32_t* dst);
 /* device pointer of a buffer (for RCCL gathers over xGMI without a host hop);
  * which as in lf_read_tile; layout W*H*3 doubles row-major.  The allocation is padded to a
  * multiple of 64 rows (bytes reports the padded size) so that in-place all-gathers of whole

@@ -27,9 +27,10 @@ ABI_SYMBOLS = [
     "lf_create", "lf_destroy", "lf_last_error", "lf_abi_version", "lf_set_stream", "lf_synchronize",
     "lf_set_frame", "lf_set_band", "lf_set_row_interleave", "lf_set_params", "lf_set_aperture", "lf_get_aperture_stats",
     "lf_set_paraxial_lens", "lf_set_camera", "lf_find_sun_pos", "lf_set_flares", "lf_get_flares",
-    "lf_set_jitter_mt19937", "lf_set_jitter_counter", "lf_set_scene_term",
+    "lf_set_jitter_mt19937", "lf_set_jitter_counter", "lf_set_scene_term", "lf_set_scene",
+    "lf_set_sampling", "lf_render_scene_term",
     "lf_generate_ghost_buffer", "lf_render_flare_layer", "lf_read_tile", "lf_read_pixel",
-    "lf_write_to_framebuffer", "lf_device_buffer", "lf_set_lens", "lf_set_lambda_rgb", "lf_set_sun",
+    "lf_write_to_framebuffer", "lf_save_image_rgba", "lf_device_buffer", "lf_set_lens", "lf_set_lambda_rgb", "lf_set_sun",
     "lf_set_ghost_pairs", "lf_trace_ghosts", "lf_get_counters", "lf_reset_counters",
     "lf_timing_enable", "lf_timing_reset", "lf_timing_get",
 ]
@@ -217,6 +218,36 @@ class LensFlare:
             assert rgb.size == self.W * self.H * 3
             self._ck(self.lib.lf_set_scene_term(self.ctx, _fp(rgb, C.c_double)))
 
+    # ---- scene term
+    def set_scene(self, spheres=(), tris=(), lights=()):
+        """spheres: (cx,cy,cz,r,kind,a,b,c); tris: 18 numbers + (kind,a,b,c), kind 'd'|'e';
+        lights: (type, x,y,z, r,g,b) with type 0 = directional (dirToLight), 1 = point."""
+        mats, sp, spm, tp, tn, tm = [], [], [], [], [], []
+
+        def mat(kind, a, b, c):
+            mats.append([1.0 if kind == "e" else 0.0, a, b, c])
+            return len(mats) - 1
+
+        for s in spheres:
+            sp.append(list(s[:4])); spm.append(mat(*s[4:8]))
+        for t in tris:
+            tp.append(list(t[:9])); tn.append(list(t[9:18])); tm.append(mat(*t[18:22]))
+        arr = lambda a, t: np.ascontiguousarray(np.array(a, t).reshape(-1))  # noqa: E731
+        spa, spma = arr(sp, np.float64), arr(spm, np.int32)
+        tpa, tna, tma = arr(tp, np.float64), arr(tn, np.float64), arr(tm, np.int32)
+        ma, la = arr(mats, np.float64), arr(lights, np.float64)
+        self._ck(self.lib.lf_set_scene(self.ctx, len(sp), _fp(spa, C.c_double), _fp(spma, C.c_int),
+                                       len(tp), _fp(tpa, C.c_double), _fp(tna, C.c_double),
+                                       _fp(tma, C.c_int), len(mats), _fp(ma, C.c_double),
+                                       len(lights), _fp(la, C.c_double)))
+
+    def set_sampling(self, samples_per_batch=32, max_tolerance=0.05, n_clip=0.01, f_clip=100.0):
+        self._ck(self.lib.lf_set_sampling(self.ctx, int(samples_per_batch), C.c_double(max_tolerance),
+                                          C.c_double(n_clip), C.c_double(f_clip)))
+
+    def render_scene_term(self):
+        self._ck(self.lib.lf_render_scene_term(self.ctx))
+
     # ---- render
     def generate_ghost_buffer(self):
         self._ck(self.lib.lf_generate_ghost_buffer(self.ctx))
@@ -243,6 +274,11 @@ class LensFlare:
         out = np.zeros((y1 - y0, x1 - x0), np.uint32)
         self._ck(self.lib.lf_write_to_framebuffer(self.ctx, x0, y0, x1, y1, _fp(out, C.c_uint32),
                                                   C.c_size_t(x1 - x0)))
+        return out
+
+    def save_image_rgba(self):
+        out = np.zeros((self.H, self.W), np.uint32)
+        self._ck(self.lib.lf_save_image_rgba(self.ctx, _fp(out, C.c_uint32)))
         return out
 
     def device_buffer(self, which):

@@ -99,6 +99,8 @@ void free_frame_buffers(lf_ctx* ctx) {
   if (ctx->scene) (void)hipFree(ctx->scene);
   if (ctx->rgba) (void)hipFree(ctx->rgba);
   if (ctx->jitter_raw) (void)hipFree(ctx->jitter_raw);
+  if (ctx->jitter_aa_raw) (void)hipFree(ctx->jitter_aa_raw);
+  ctx->jitter_aa_raw = nullptr;
   ctx->sample = ctx->ghost = ctx->scene = ctx->star = nullptr;
   ctx->rgba = nullptr;
   ctx->jitter_raw = nullptr;
@@ -168,7 +170,9 @@ lf_status lf_destroy(lf_ctx* ctx) {
     if (ctx->ap[s].stats) (void)hipFree(ctx->ap[s].stats);
   }
   void* ptrs[] = {ctx->spectrum, ctx->twiddle, ctx->dft_rows, ctx->flares, ctx->ghosts, ctx->pl_dev,
-                  ctx->lens_dev, ctx->pairs_dev, ctx->counters_dev, ctx->accum, ctx->events_dev};
+                  ctx->lens_dev, ctx->pairs_dev, ctx->counters_dev, ctx->accum, ctx->events_dev,
+                  ctx->scene_dev.nodes, ctx->scene_dev.prims, ctx->scene_dev.materials,
+                  ctx->scene_dev.lights};
   for (void* p : ptrs) if (p) (void)hipFree(p);
   if (ctx->own_stream && ctx->stream) (void)hipStreamDestroy(ctx->stream);
   delete ctx;
@@ -385,10 +389,13 @@ lf_status lf_set_jitter_mt19937(lf_ctx* ctx, uint32_t seed, const uint32_t* orde
   // draws of calculate_irradiance_falloff (:1050).  Only the latter reach the device, stored
   // pixel-major; a pixel visited twice keeps its last visit, like the reference's buffer.
   std::vector<uint32_t> table(n * 32, 0u);
+  const size_t naa = 2 * (size_t)ctx->ns_aa;
+  std::vector<uint32_t> aa(n * naa, 0u);
   Mt19937 mt(seed);
   for (size_t v = 0; v < n_order; v++) {
     if (order[v] >= n) return lf_fail(ctx, LF_ERR_INVALID, "visit order: pixel index out of range");
-    for (int k = 0; k < 2 * ctx->ns_aa; k++) (void)mt.next();
+    uint32_t* da = aa.data() + (size_t)order[v] * naa;
+    for (size_t k = 0; k < naa; k++) da[k] = mt.next();   // consumed by the scene-term kernel
     uint32_t* dst = table.data() + (size_t)order[v] * 32;
     for (int k = 0; k < 32; k++) dst[k] = mt.next();
   }
@@ -396,6 +403,11 @@ lf_status lf_set_jitter_mt19937(lf_ctx* ctx, uint32_t seed, const uint32_t* orde
   if ((st = dev_alloc(ctx, &ctx->jitter_raw, n * 32)) != LF_OK) return st;
   LF_HIP(ctx, hipMemcpy(ctx->jitter_raw, table.data(), table.size() * sizeof(uint32_t),
                         hipMemcpyHostToDevice));
+  if ((st = dev_alloc(ctx, &ctx->jitter_aa_raw, n * naa)) != LF_OK) return st;
+  if (naa)
+    LF_HIP(ctx, hipMemcpy(ctx->jitter_aa_raw, aa.data(), aa.size() * sizeof(uint32_t),
+                          hipMemcpyHostToDevice));
+  ctx->jitter_aa_ns = ctx->ns_aa;
   ctx->jitter_mode = 0;
   ctx->jitter_table_valid = true;
   return LF_OK;
@@ -500,6 +512,29 @@ lf_status lf_write_to_framebuffer(lf_ctx* ctx, int x0, int y0, int x1, int y1, u
   LF_HIP(ctx, hipMemcpy2D(dst, row_stride * sizeof(uint32_t), ctx->rgba + (size_t)y0 * ctx->W + x0,
                           (size_t)ctx->W * sizeof(uint32_t), (size_t)(x1 - x0) * sizeof(uint32_t),
                           (size_t)(y1 - y0), hipMemcpyDeviceToHost));
+  return LF_OK;
+}
+
+lf_status lf_save_image_rgba(lf_ctx* ctx, uint32_t* dst) {
+  if (!ctx || !dst) return LF_ERR_INVALID;
+  if (ctx->W == 0) return lf_fail(ctx, LF_ERR_STATE, "lf_save_image_rgba before lf_set_frame");
+  if (!ctx->sample_valid) return lf_fail(ctx, LF_ERR_STATE, "lf_save_image_rgba before lf_render_flare_layer");
+  LF_HIP(ctx, hipSetDevice(ctx->device));
+  const int y0 = ctx->y0, y1 = ctx->y1;
+  ctx->y0 = 0; ctx->y1 = ctx->H;                 // the saved image is always the whole frame
+  lf_status st = lfk_tonemap(ctx);
+  ctx->y0 = y0; ctx->y1 = y1;
+  if (st != LF_OK) return st;
+  ctx->rgba_valid = (y0 == 0 && y1 == ctx->H);
+  uint32_t* tmp = nullptr;
+  const size_t n = (size_t)ctx->W * ctx->H;
+  LF_HIP(ctx, hipMalloc((void**)&tmp, n * sizeof(uint32_t)));
+  st = lfk_flip_rows(ctx, tmp);
+  hipError_t e = hipStreamSynchronize(ctx->stream);
+  if (st == LF_OK && e == hipSuccess) e = hipMemcpy(dst, tmp, n * sizeof(uint32_t), hipMemcpyDeviceToHost);
+  (void)hipFree(tmp);
+  if (st != LF_OK) return st;
+  LF_HIP(ctx, e);
   return LF_OK;
 }
 

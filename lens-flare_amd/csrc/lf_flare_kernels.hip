@@ -500,11 +500,28 @@ __global__ void k_tonemap(const double* __restrict__ sample, int W, int y0, int 
   rgba[p] = px;
 }
 
+// RaytracedRenderer::save_image's pixel preparation (raytraced_renderer.cpp:739-746): rows flipped
+// (PNG is top-down, the sensor buffer bottom-up) and alpha forced to 0xFF
+__global__ void k_flip_rows(const uint32_t* __restrict__ in, int W, int H, uint32_t* __restrict__ out) {
+  const size_t p = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (p >= (size_t)W * H) return;
+  const int x = (int)(p % W), y = (int)(p / W);
+  out[(size_t)(H - 1 - y) * W + x] = in[p] | 0xFF000000u;
+}
+
 }  // namespace
 
 // =============================================================================================
 // launchers
 // =============================================================================================
+lf_status lfk_flip_rows(lf_ctx* ctx, uint32_t* out_dev) {
+  size_t n = (size_t)ctx->W * ctx->H;
+  hipLaunchKernelGGL(k_flip_rows, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream,
+                     ctx->rgba, ctx->W, ctx->H, out_dev);
+  LF_HIP(ctx, hipGetLastError());
+  return LF_OK;
+}
+
 lf_status lfk_aperture_stats(lf_ctx* ctx, int slot) {
   LfApertureDev& a = ctx->ap[slot];
   lf_aperture_stats init{a.w, a.h, a.w, a.w, -1, -1, 0.0};  // camera.h:54-56

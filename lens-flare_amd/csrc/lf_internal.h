@@ -55,6 +55,17 @@ struct LfCamera {
   double c2w[9];  // row-major
   double pos[3];
   double hfov_deg, vfov_deg;
+  double n_clip = 0.01, f_clip = 100.0;  // Camera::nClip / fClip (camera.h:188)
+};
+
+// ---- scene term (row f2) ------------------------------------------------------------------
+struct LfBvhNode { double bmin[3], bmax[3]; int left, right, first, count; };  // leaf: count > 0
+struct LfPrim { int type, material; double d[18]; };  // sphere: c(3) r r^2; triangle: 3 pos + 3 normals
+struct LfMaterial { int kind, pad; double rgb[3]; };   // 0 diffuse (reflectance), 1 emission (radiance)
+struct LfLight { int type, pad; double v[3], rgb[3]; }; // 0 directional (v = dirToLight), 1 point (v = position)
+struct LfSceneDev {
+  LfBvhNode* nodes; LfPrim* prims; LfMaterial* materials; LfLight* lights;
+  int n_nodes, n_prims, n_materials, n_lights;
 };
 
 struct LfApertureDev {
@@ -159,6 +170,14 @@ struct lf_ctx {
   uint64_t jitter_key = 0x1e45f1a4eULL;
   uint32_t* jitter_raw = nullptr;  // W*H*32 raw draws, pixel-major (MT mode)
   bool jitter_table_valid = false;
+  uint32_t* jitter_aa_raw = nullptr;  // W*H*2*ns_aa pixel-jitter draws (MT mode), pixel-major
+  int jitter_aa_ns = 0;
+
+  // scene term
+  LfSceneDev scene_dev{};
+  bool scene_valid = false;
+  int samples_per_batch = 32;     // PathTracer::samplesPerBatch default (raytraced_renderer.h:67-81)
+  double max_tolerance = 0.05;    // PathTracer::maxTolerance
 
   // geometric
   LfLensDev lens{};
@@ -197,6 +216,7 @@ lf_status lfk_frame_setup(lf_ctx* ctx, const double* lights_dev, int n_lights, b
 lf_status lfk_ghost_raster(lf_ctx* ctx);
 lf_status lfk_flare_layer(lf_ctx* ctx);
 lf_status lfk_tonemap(lf_ctx* ctx);
+lf_status lfk_flip_rows(lf_ctx* ctx, uint32_t* out_dev);
 // lf_march.hip
 lf_status lfk_march(lf_ctx* ctx, int spp, uint64_t key);
 void lf_derive_lens(lf_ctx* ctx, int n, int stop, int n_lambda, const float* radius,

@@ -1,0 +1,418 @@
+// lf_scene.hip -- the scene-radiance term of PathTracer::raytrace_pixel on the device
+// (SURVEY.md section 8 row f2): the per-pixel sample loop (pathtracer.cpp:841-875), pinhole ray
+// generation (camera.cpp:278-305), closest-hit search over spheres and triangles
+// (scene/sphere.cpp:11-111, scene/triangle.cpp:25-112, scene/bvh.cpp:201-222), emission +
+// direct lighting of diffuse surfaces by delta lights with shadow rays
+// (pathtracer.cpp:142-232, bsdf.cpp:21-60, light.cpp:11-24, :47-60).
+//
+// Everything is double precision and follows the reference expression by expression (operator
+// order of CGL::Vector3D / Matrix3x3 included) so that pixels agree with the CPU renderer far
+// inside the 1e-4 bar.  The BVH is our own (median split on the host, stack traversal on the
+// device): the closest hit does not depend on the tree, only the amount of work does.
+//
+// Not covered (the call fails loudly rather than approximating): area / hemisphere / environment
+// lights and hemisphere sampling (they draw from the shared MT19937 only when a camera ray hits
+// something, which makes every later pixel's jitter depend on every earlier pixel's hits), and the
+// Mirror/Glass/Microfacet BSDFs, which are unfilled stubs in the reference (advanced_bsdf.cpp).
+#include <algorithm>
+#include <cmath>
+#include <cstring>
+
+#include "lf_internal.h"
+
+namespace {
+
+struct V3 { double x, y, z; };
+__host__ __device__ inline V3 v3(double x, double y, double z) { V3 r{x, y, z}; return r; }
+__host__ __device__ inline V3 operator+(V3 a, V3 b) { return v3(a.x + b.x, a.y + b.y, a.z + b.z); }
+__host__ __device__ inline V3 operator-(V3 a, V3 b) { return v3(a.x - b.x, a.y - b.y, a.z - b.z); }
+__host__ __device__ inline V3 operator*(V3 a, double c) { return v3(a.x * c, a.y * c, a.z * c); }
+__host__ __device__ inline V3 operator*(double c, V3 a) { return v3(c * a.x, c * a.y, c * a.z); }
+__host__ __device__ inline V3 mulv(V3 a, V3 b) { return v3(a.x * b.x, a.y * b.y, a.z * b.z); }
+// dot(): (x*x' + y*y') + z*z' (the AVX build's _mm_dp_pd pairs x,y first; vector3D.h:256-262)
+__host__ __device__ inline double dot(V3 a, V3 b) { return (a.x * b.x + a.y * b.y) + a.z * b.z; }
+__host__ __device__ inline V3 cross(V3 u, V3 v) {
+  return v3(u.y * v.z - u.z * v.y, u.z * v.x - u.x * v.z, u.x * v.y - u.y * v.x);
+}
+__device__ inline double norm(V3 a) { return sqrt(dot(a, a)); }
+// Vector3D::unit(): multiply by 1/norm (vector3D.h:214-217); operator/(double) does the same
+__device__ inline V3 unit(V3 a) { double rn = 1. / norm(a); return a * rn; }
+__device__ inline V3 divs(V3 a, double c) { const double rc = 1.0 / c; return v3(rc * a.x, rc * a.y, rc * a.z); }
+
+struct DRay { V3 o, d; double min_t, max_t; };
+struct Hit { double t; V3 n; int material; };
+
+// ---- primitives ------------------------------------------------------------------------------
+// Sphere::test + intersect (scene/sphere.cpp:11-111)
+__device__ inline bool hit_sphere(const LfPrim& s, DRay& r, Hit* h) {
+  const V3 c = v3(s.d[0], s.d[1], s.d[2]);
+  const V3 oc = r.o - c;
+  const double a = dot(r.d, r.d);
+  const double b = 2 * dot(oc, r.d);
+  const double cc = dot(oc, oc) - s.d[4];
+  double t1;
+  if (b * b < 4.0 * a * cc) return false;
+  if (b * b == 4.0 * a * cc) {
+    const double root = (-b) / (2.0 * a);
+    if (root < r.min_t || root > r.max_t) return false;
+    t1 = root;
+  } else {
+    const double q = sqrt(b * b - 4.0 * a * cc);
+    const double r1 = (-b - q) / (2.0 * a), r2 = (-b + q) / (2.0 * a);
+    const double p1 = r2 < r1 ? r2 : r1, p2 = r1 < r2 ? r2 : r1;  // std::min / std::max
+    if (p1 > r.max_t || p2 < r.min_t) return false;
+    if (p1 < r.min_t) {
+      if (p2 > r.max_t) return false;
+      t1 = p2;
+    } else {
+      t1 = p1;
+    }
+  }
+  r.max_t = t1;
+  if (h) {
+    h->t = t1;
+    h->n = unit((r.o + t1 * r.d) - c);  // Sphere::normal (sphere.h:73-75)
+    h->material = s.material;
+  }
+  return true;
+}
+
+// moller_trumbore + is_valid_intersection + Triangle::intersect (scene/triangle.cpp:25-112)
+__device__ inline bool hit_triangle(const LfPrim& t, DRay& r, Hit* h) {
+  const V3 p0 = v3(t.d[0], t.d[1], t.d[2]), p1 = v3(t.d[3], t.d[4], t.d[5]), p2 = v3(t.d[6], t.d[7], t.d[8]);
+  const V3 e1 = p1 - p0, e2 = p2 - p0, s = r.o - p0;
+  const V3 s1 = cross(r.d, e2), s2 = cross(s, e1);
+  const double rc = 1. / dot(s1, e1);  // operator/= multiplies by the reciprocal
+  const double tt = dot(s2, e2) * rc, b1 = dot(s1, s) * rc, b2 = dot(s2, r.d) * rc;
+  if (tt < r.min_t || tt > r.max_t) return false;
+  if (b1 < 0 || b1 > 1) return false;
+  if (b2 < 0 || b2 > 1) return false;
+  if (b1 + b2 > 1) return false;
+  r.max_t = tt;
+  if (h) {
+    const double b0 = 1 - b1 - b2;
+    const V3 n1 = v3(t.d[9], t.d[10], t.d[11]), n2 = v3(t.d[12], t.d[13], t.d[14]),
+             n3 = v3(t.d[15], t.d[16], t.d[17]);
+    h->t = tt;
+    h->n = unit((b0 * n1 + b1 * n2) + b2 * n3);
+    h->material = t.material;
+  }
+  return true;
+}
+
+// closest hit (BVHAccel::intersect, scene/bvh.cpp:201-222: the recursion shrinks r.max_t as it goes,
+// so whatever the visiting order the last accepted primitive is the closest one)
+__device__ bool closest_hit(const LfBvhNode* __restrict__ nodes, const LfPrim* __restrict__ prims,
+                            DRay& r, Hit* h) {
+  int stack[64];
+  int sp = 0;
+  stack[sp++] = 0;
+  bool any = false;
+  while (sp > 0) {
+    const LfBvhNode& nd = nodes[stack[--sp]];
+    // BBox::intersect (scene/bbox.cpp:12-49); fmin/fmax drop NaNs (0/0 on a slab plane), which
+    // only makes the test more permissive
+    const double tx1 = (nd.bmin[0] - r.o.x) / r.d.x, tx2 = (nd.bmax[0] - r.o.x) / r.d.x;
+    const double ty1 = (nd.bmin[1] - r.o.y) / r.d.y, ty2 = (nd.bmax[1] - r.o.y) / r.d.y;
+    const double tz1 = (nd.bmin[2] - r.o.z) / r.d.z, tz2 = (nd.bmax[2] - r.o.z) / r.d.z;
+    const double tmin = fmax(fmax(fmin(tx1, tx2), fmin(ty1, ty2)), fmin(tz1, tz2));
+    const double tmax = fmin(fmin(fmax(tx1, tx2), fmax(ty1, ty2)), fmax(tz1, tz2));
+    if (tmin > tmax || tmax < r.min_t || tmin > r.max_t) continue;
+    if (nd.count > 0) {
+      for (int i = 0; i < nd.count; i++) {
+        const LfPrim& p = prims[nd.first + i];
+        const bool hit = p.type == 0 ? hit_sphere(p, r, h) : hit_triangle(p, r, h);
+        any = any || hit;
+      }
+    } else {
+      if (sp < 62) { stack[sp++] = nd.right; stack[sp++] = nd.left; }
+    }
+  }
+  return any;
+}
+
+// make_coord_space (pathtracer/bsdf.cpp:21-41): returns the rows of w2o = o2w.T()
+__device__ inline void make_coord_space(V3 n, V3& X, V3& Y, V3& Z) {
+  V3 z = n, hh = n;
+  if (fabs(hh.x) <= fabs(hh.y) && fabs(hh.x) <= fabs(hh.z)) hh.x = 1.0;
+  else if (fabs(hh.y) <= fabs(hh.x) && fabs(hh.y) <= fabs(hh.z)) hh.y = 1.0;
+  else hh.z = 1.0;
+  z = z * (1. / norm(z));            // normalize(): *= 1/norm
+  V3 y = cross(hh, z);
+  y = y * (1. / norm(y));
+  V3 x = cross(z, y);
+  x = x * (1. / norm(x));
+  X = x; Y = y; Z = z;
+}
+
+// est_radiance_global_illumination (pathtracer.cpp:282-302) = zero_bounce + one_bounce with
+// estimate_direct_lighting_importance (:142-213)
+__device__ V3 radiance(const LfSceneDev& sc, DRay r) {
+  Hit isect;
+  if (!closest_hit(sc.nodes, sc.prims, r, &isect)) return v3(0, 0, 0);  // no envLight
+  const LfMaterial& m = sc.materials[isect.material];
+  const V3 emission = m.kind == 1 ? v3(m.rgb[0], m.rgb[1], m.rgb[2]) : v3(0, 0, 0);
+  V3 X, Y, Z;
+  make_coord_space(isect.n, X, Y, Z);
+  const V3 hit_p = r.o + r.d * isect.t;
+  V3 L = v3(0, 0, 0);
+  const double kEpsF = (double)0.00001f;  // EPS_F (misc.h:13)
+  for (int l = 0; l < sc.n_lights; l++) {
+    const LfLight& lt = sc.lights[l];
+    V3 wi;
+    double dist;
+    const V3 emit = v3(lt.rgb[0], lt.rgb[1], lt.rgb[2]);
+    if (lt.type == 0) {  // DirectionalLight::sample_L (light.cpp:18-24)
+      wi = v3(lt.v[0], lt.v[1], lt.v[2]);
+      dist = INFINITY;
+    } else {             // PointLight::sample_L (light.cpp:52-60)
+      const V3 d = v3(lt.v[0], lt.v[1], lt.v[2]) - hit_p;
+      wi = unit(d);
+      dist = norm(d);
+    }
+    // w2o * wi: rows of w2o are the columns of o2w; Matrix3x3 * Vector3D sums column-wise:
+    // wi.x*col0 + wi.y*col1 + wi.z*col2 of w2o, i.e. component k = (wi.x*R0[k] + wi.y*R1[k]) + wi.z*R2[k]
+    const V3 wo = v3((wi.x * X.x + wi.y * X.y) + wi.z * X.z, (wi.x * Y.x + wi.y * Y.y) + wi.z * Y.z,
+                     (wi.x * Z.x + wi.y * Z.y) + wi.z * Z.z);
+    if (wo.z < 0) continue;
+    DRay sh{hit_p, wi, kEpsF, dist - kEpsF};
+    if (!closest_hit(sc.nodes, sc.prims, sh, nullptr)) {
+      const double cos_theta = unit(wo).z;
+      // DiffuseBSDF::f = Vector3D(1/PI) * reflectance (bsdf.cpp:52-60); EmissionBSDF::f = 0
+      const double ipi = 1.0 / 3.14159265358979323;
+      const V3 f = m.kind == 0 ? mulv(v3(ipi, ipi, ipi), v3(m.rgb[0], m.rgb[1], m.rgb[2])) : v3(0, 0, 0);
+      L = L + divs(mulv(f, emit) * cos_theta, 1.0);  // / pdf, pdf = 1 for delta lights
+    }
+  }
+  if (sc.n_lights > 0) L = divs(L, (double)sc.n_lights);  // L_out / total_samples (:211)
+  return emission + L;
+}
+
+__device__ inline uint4 philox4x32_10(uint4 ctr, uint2 key) {
+#pragma unroll
+  for (int r = 0; r < 10; r++) {
+    unsigned hi0 = __umulhi(0xD2511F53u, ctr.x), lo0 = 0xD2511F53u * ctr.x;
+    unsigned hi1 = __umulhi(0xCD9E8D57u, ctr.z), lo1 = 0xCD9E8D57u * ctr.z;
+    ctr = make_uint4(hi1 ^ ctr.y ^ key.x, lo1, hi0 ^ ctr.w ^ key.y, lo0);
+    key.x += 0x9E3779B9u;
+    key.y += 0xBB67AE85u;
+  }
+  return ctr;
+}
+
+__device__ inline double random_uniform_from_raw(unsigned raw) {  // util/random_util.h:15-22
+  double v = (double)raw * (1.0 / (4294967295.0 - 0.0));
+  v = v < 0.0000001 ? 0.0000001 : v;
+  v = 0.99999999 < v ? 0.99999999 : v;
+  return v;
+}
+
+// the sample loop of raytrace_pixel (pathtracer.cpp:831-875)
+__global__ __launch_bounds__(256) void k_scene_term(LfSceneDev sc, LfCamera cam, int W, int H, int y0,
+                                                    int y1, int ns_aa, int samples_per_batch,
+                                                    double max_tolerance,
+                                                    const uint32_t* __restrict__ aa_raw, int jitter_mode,
+                                                    uint64_t key, double* __restrict__ scene) {
+  const size_t p = (size_t)y0 * W + (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (p >= (size_t)y1 * W) return;
+  const int x = (int)(p % W), y = (int)(p / W);
+  const double PI_ = 3.14159265358979323;
+  const double edge_x = tan(0.5 * (cam.hfov_deg * (PI_ / 180.0)));
+  const double edge_y = tan(0.5 * (cam.vfov_deg * (PI_ / 180.0)));
+  V3 total = v3(0, 0, 0);
+  float s1 = 0.0f, s2 = 0.0f;
+  int sample;
+  for (sample = 1; sample <= ns_aa; sample++) {
+    unsigned ra, rb;
+    if (jitter_mode == 0) {
+      ra = aa_raw[p * (size_t)(2 * ns_aa) + 2 * (sample - 1)];
+      rb = aa_raw[p * (size_t)(2 * ns_aa) + 2 * (sample - 1) + 1];
+    } else {
+      const uint4 r4 = philox4x32_10(make_uint4((unsigned)p, (unsigned)sample, 0x5ce4e000u, 0u),
+                                     make_uint2((unsigned)key, (unsigned)(key >> 32)));
+      ra = r4.x; rb = r4.y;
+    }
+    // Vector2D(random_uniform(), random_uniform()): g++ evaluates right to left, the first draw is y
+    const double sy = (double)y + random_uniform_from_raw(ra);
+    const double sx = (double)x + random_uniform_from_raw(rb);
+    const double nx = sx / (double)W, ny = sy / (double)H;
+    // Camera::generate_ray (camera.cpp:278-305)
+    V3 dir = unit(v3(edge_x * (2 * nx - 1), edge_y * (2 * ny - 1), -1));
+    DRay r;
+    r.o = v3(cam.pos[0], cam.pos[1], cam.pos[2]);
+    r.d = v3((dir.x * cam.c2w[0] + dir.y * cam.c2w[1]) + dir.z * cam.c2w[2],
+             (dir.x * cam.c2w[3] + dir.y * cam.c2w[4]) + dir.z * cam.c2w[5],
+             (dir.x * cam.c2w[6] + dir.y * cam.c2w[7]) + dir.z * cam.c2w[8]);
+    r.min_t = cam.n_clip; r.max_t = cam.f_clip;
+    const V3 L = radiance(sc, r);
+    // Vector3D::illum (vector3D.h:231-233): float coefficients, double arithmetic, float result
+    const float illum = (float)((0.2126f * L.x + 0.7152f * L.y) + 0.0722f * L.z);
+    s1 += illum;
+    s2 += illum * illum;
+    total = total + L;
+    if (sample > 1 && sample % samples_per_batch == 0) {  // :862-868
+      const float sd = (float)sqrt(1.0 / (sample - 1) * (double)(s2 - s1 * s1 / (float)sample));
+      const float ci = (float)(1.96 * (double)sd / sqrt((double)sample));
+      if ((double)ci <= max_tolerance * (double)s1 / (double)sample) break;
+    }
+  }
+  const double rc = 1. / (double)sample;  // :875 -- ns_aa + 1 when the loop ran to its end
+  scene[3 * p] = total.x * rc;
+  scene[3 * p + 1] = total.y * rc;
+  scene[3 * p + 2] = total.z * rc;
+}
+
+// ---- host: BVH over the primitives (median split of the centroids along the widest axis) -----
+struct Box { double mn[3], mx[3]; };
+
+Box prim_box(const LfPrim& p) {
+  Box b;
+  if (p.type == 0) {
+    for (int a = 0; a < 3; a++) { b.mn[a] = p.d[a] - p.d[3]; b.mx[a] = p.d[a] + p.d[3]; }
+  } else {
+    for (int a = 0; a < 3; a++) {
+      b.mn[a] = std::min({p.d[a], p.d[3 + a], p.d[6 + a]});
+      b.mx[a] = std::max({p.d[a], p.d[3 + a], p.d[6 + a]});
+    }
+  }
+  return b;
+}
+
+int build_node(std::vector<LfBvhNode>& nodes, std::vector<LfPrim>& prims, int first, int count) {
+  LfBvhNode nd;
+  for (int a = 0; a < 3; a++) { nd.bmin[a] = INFINITY; nd.bmax[a] = -INFINITY; }
+  double cmn[3] = {INFINITY, INFINITY, INFINITY}, cmx[3] = {-INFINITY, -INFINITY, -INFINITY};
+  for (int i = first; i < first + count; i++) {
+    Box b = prim_box(prims[i]);
+    for (int a = 0; a < 3; a++) {
+      nd.bmin[a] = std::min(nd.bmin[a], b.mn[a]); nd.bmax[a] = std::max(nd.bmax[a], b.mx[a]);
+      double c = 0.5 * (b.mn[a] + b.mx[a]);
+      cmn[a] = std::min(cmn[a], c); cmx[a] = std::max(cmx[a], c);
+    }
+  }
+  nd.left = nd.right = -1; nd.first = first; nd.count = count;
+  const int id = (int)nodes.size();
+  nodes.push_back(nd);
+  if (count <= 4) return id;
+  int axis = 0;
+  for (int a = 1; a < 3; a++) if (cmx[a] - cmn[a] > cmx[axis] - cmn[axis]) axis = a;
+  const int mid = first + count / 2;
+  std::nth_element(prims.begin() + first, prims.begin() + mid, prims.begin() + first + count,
+                   [axis](const LfPrim& a, const LfPrim& b) {
+                     Box ba = prim_box(a), bb = prim_box(b);
+                     return ba.mn[axis] + ba.mx[axis] < bb.mn[axis] + bb.mx[axis];
+                   });
+  const int l = build_node(nodes, prims, first, mid - first);
+  const int r = build_node(nodes, prims, mid, first + count - mid);
+  nodes[id].left = l; nodes[id].right = r; nodes[id].count = 0;
+  return id;
+}
+
+}  // namespace
+
+extern "C" {
+
+lf_status lf_set_scene(lf_ctx* ctx, int n_spheres, const double* spheres, const int* sphere_material,
+                       int n_triangles, const double* tri_positions, const double* tri_normals,
+                       const int* tri_material, int n_materials, const double* materials,
+                       int n_lights, const double* lights) {
+  if (!ctx || n_spheres < 0 || n_triangles < 0 || n_materials < 0 || n_lights < 0) return LF_ERR_INVALID;
+  if ((n_spheres && (!spheres || !sphere_material)) ||
+      (n_triangles && (!tri_positions || !tri_normals || !tri_material)) ||
+      (n_materials && !materials) || (n_lights && !lights))
+    return LF_ERR_INVALID;
+  LF_HIP(ctx, hipSetDevice(ctx->device));
+  std::vector<LfPrim> prims;
+  for (int i = 0; i < n_spheres; i++) {
+    LfPrim p; std::memset(&p, 0, sizeof(p));
+    p.type = 0; p.material = sphere_material[i];
+    for (int k = 0; k < 4; k++) p.d[k] = spheres[4 * i + k];
+    p.d[4] = p.d[3] * p.d[3];  // Sphere::r2
+    prims.push_back(p);
+  }
+  for (int i = 0; i < n_triangles; i++) {
+    LfPrim p; std::memset(&p, 0, sizeof(p));
+    p.type = 1; p.material = tri_material[i];
+    for (int k = 0; k < 9; k++) { p.d[k] = tri_positions[9 * i + k]; p.d[9 + k] = tri_normals[9 * i + k]; }
+    prims.push_back(p);
+  }
+  for (auto& p : prims)
+    if (p.material < 0 || p.material >= n_materials) return lf_fail(ctx, LF_ERR_INVALID, "scene: material index out of range");
+  std::vector<LfMaterial> mats(n_materials);
+  for (int i = 0; i < n_materials; i++) {
+    mats[i].kind = (int)materials[4 * i];
+    if (mats[i].kind != 0 && mats[i].kind != 1)
+      return lf_fail(ctx, LF_ERR_INVALID, "scene: only diffuse (0) and emission (1) materials are supported");
+    for (int c = 0; c < 3; c++) mats[i].rgb[c] = materials[4 * i + 1 + c];
+  }
+  std::vector<LfLight> lts(n_lights);
+  for (int i = 0; i < n_lights; i++) {
+    lts[i].type = (int)lights[7 * i];
+    if (lts[i].type != 0 && lts[i].type != 1)
+      return lf_fail(ctx, LF_ERR_INVALID, "scene: only directional (0) and point (1) lights are supported");
+    for (int c = 0; c < 3; c++) { lts[i].v[c] = lights[7 * i + 1 + c]; lts[i].rgb[c] = lights[7 * i + 4 + c]; }
+  }
+  std::vector<LfBvhNode> nodes;
+  if (!prims.empty()) build_node(nodes, prims, 0, (int)prims.size());
+  else { LfBvhNode e; std::memset(&e, 0, sizeof(e)); e.bmin[0] = 1; e.bmax[0] = -1; e.count = 0; e.left = e.right = 0; nodes.push_back(e); }
+  LfSceneDev& S = ctx->scene_dev;
+  LF_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  void* old[] = {S.nodes, S.prims, S.materials, S.lights};
+  for (void* o : old) if (o) (void)hipFree(o);
+  std::memset(&S, 0, sizeof(S));
+  auto up = [&](void** dst, const void* src, size_t bytes) -> hipError_t {
+    hipError_t e = hipMalloc(dst, std::max<size_t>(bytes, 16));
+    if (e == hipSuccess && bytes) e = hipMemcpy(*dst, src, bytes, hipMemcpyHostToDevice);
+    return e;
+  };
+  LF_HIP(ctx, up((void**)&S.nodes, nodes.data(), nodes.size() * sizeof(LfBvhNode)));
+  LF_HIP(ctx, up((void**)&S.prims, prims.data(), prims.size() * sizeof(LfPrim)));
+  LF_HIP(ctx, up((void**)&S.materials, mats.data(), mats.size() * sizeof(LfMaterial)));
+  LF_HIP(ctx, up((void**)&S.lights, lts.data(), lts.size() * sizeof(LfLight)));
+  S.n_nodes = (int)nodes.size(); S.n_prims = (int)prims.size();
+  S.n_materials = n_materials; S.n_lights = n_lights;
+  if (prims.empty()) S.n_nodes = 1;
+  ctx->scene_valid = true;
+  return LF_OK;
+}
+
+lf_status lf_set_sampling(lf_ctx* ctx, int samples_per_batch, double max_tolerance, double n_clip,
+                          double f_clip) {
+  if (!ctx || samples_per_batch < 1 || !(f_clip > n_clip)) return LF_ERR_INVALID;
+  ctx->samples_per_batch = samples_per_batch;
+  ctx->max_tolerance = max_tolerance;
+  ctx->cam.n_clip = n_clip;
+  ctx->cam.f_clip = f_clip;
+  return LF_OK;
+}
+
+lf_status lf_render_scene_term(lf_ctx* ctx) {
+  if (!ctx) return LF_ERR_INVALID;
+  if (ctx->W == 0) return lf_fail(ctx, LF_ERR_STATE, "lf_render_scene_term before lf_set_frame");
+  if (!ctx->scene_valid) return lf_fail(ctx, LF_ERR_STATE, "lf_render_scene_term before lf_set_scene");
+  if (!ctx->cam_valid) return lf_fail(ctx, LF_ERR_STATE, "lf_render_scene_term before lf_set_camera");
+  if (ctx->jitter_mode == 0) {
+    if (!ctx->jitter_table_valid || !ctx->jitter_aa_raw || ctx->jitter_aa_ns != ctx->ns_aa)
+      return lf_fail(ctx, LF_ERR_STATE, "MT19937 jitter: call lf_set_jitter_mt19937 after lf_set_params");
+    if (ctx->ns_aa >= ctx->samples_per_batch)
+      return lf_fail(ctx, LF_ERR_INVALID,
+                     "MT19937 parity mode needs ns_aa < samplesPerBatch: the adaptive early-out makes "
+                     "every later pixel's draws depend on earlier pixels (use lf_set_jitter_counter)");
+  }
+  LF_HIP(ctx, hipSetDevice(ctx->device));
+  const size_t n = (size_t)ctx->W * ctx->H * 3;
+  if (!ctx->scene) {
+    LF_HIP(ctx, hipMalloc((void**)&ctx->scene, n * sizeof(double)));
+    LF_HIP(ctx, hipMemsetAsync(ctx->scene, 0, n * sizeof(double), ctx->stream));
+  }
+  const size_t px = (size_t)(ctx->y1 - ctx->y0) * ctx->W;
+  if (px == 0) return LF_OK;
+  hipLaunchKernelGGL(k_scene_term, dim3((unsigned)((px + 255) / 256)), dim3(256), 0, ctx->stream,
+                     ctx->scene_dev, ctx->cam, ctx->W, ctx->H, ctx->y0, ctx->y1, ctx->ns_aa,
+                     ctx->samples_per_batch, ctx->max_tolerance, ctx->jitter_aa_raw, ctx->jitter_mode,
+                     ctx->jitter_key, ctx->scene);
+  LF_HIP(ctx, hipGetLastError());
+  return LF_OK;
+}
+
+}  // extern "C"

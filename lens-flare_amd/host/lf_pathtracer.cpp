@@ -144,6 +144,17 @@ void PathTracer::use_geometric_ghosts(int n_surfaces, int stop_index, int n_lamb
   frame_ready_ = false;
 }
 
+void PathTracer::set_scene(int n_spheres, const double* spheres, const int* sphere_material,
+                           int n_triangles, const double* tri_positions, const double* tri_normals,
+                           const int* tri_material, int n_materials, const double* materials,
+                           int n_lights, const double* scene_lights) {
+  check(lf_set_scene(ctx_, n_spheres, spheres, sphere_material, n_triangles, tri_positions,
+                     tri_normals, tri_material, n_materials, materials, n_lights, scene_lights),
+        "lf_set_scene");
+  device_scene_ = true;
+  frame_ready_ = false;
+}
+
 void PathTracer::generate_ghost_buffer() {
   // pathtracer.cpp:714-817.  The reference fills ghost_buffer here and evaluates the starburst
   // later, pixel by pixel, inside raytrace_pixel; the device renders the whole flare layer now
@@ -175,6 +186,9 @@ void PathTracer::generate_ghost_buffer() {
         d[0] = t.x; d[1] = t.y; d[2] = t.z;
       }
     check(lf_set_scene_term(ctx_, scene.data()), "lf_set_scene_term");
+  } else if (device_scene_) {
+    // the sample loop of raytrace_pixel (:841-875) on the device: BVH + direct lighting
+    check(lf_render_scene_term(ctx_), "lf_render_scene_term");
   } else {
     check(lf_set_scene_term(ctx_, nullptr), "lf_set_scene_term");
   }

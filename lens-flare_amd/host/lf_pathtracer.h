@@ -121,6 +121,12 @@ class PathTracer {
                             const float* thickness, const float* ior, const float* semi_aperture,
                             float sensor_width_mm, const float sun_dir[3], float sun_angular_radius,
                             int spp);
+  // replaces PathTracer::bvh / scene (pathtracer.h:116-124): hand the static scene to the device
+  // so that the sample loop of raytrace_pixel (BVH closest hit + direct lighting) runs there too;
+  // argument layout as lf_set_scene (include/lensflare.h)
+  void set_scene(int n_spheres, const double* spheres, const int* sphere_material, int n_triangles,
+                 const double* tri_positions, const double* tri_normals, const int* tri_material,
+                 int n_materials, const double* materials, int n_lights, const double* scene_lights);
   uint32_t jitter_seed = 5489;     // std::mt19937 default, reference visit order (32x32 tiles)
   bool counter_jitter = false;     // order-free Philox jitter instead
   lf_ctx* context() { return ctx_; }
@@ -130,7 +136,7 @@ class PathTracer {
   void check(lf_status st, const char* what);
   void upload_textures();
   lf_ctx* ctx_ = nullptr;
-  bool frame_ready_ = false, textures_uploaded_ = false, geometric_ = false;
+  bool frame_ready_ = false, textures_uploaded_ = false, geometric_ = false, device_scene_ = false;
   int geo_spp_ = 0;
   std::vector<double> star_;    // host mirror of raytrace_starburst for every pixel
   std::vector<double> sample_;  // host mirror of the composed sensor buffer

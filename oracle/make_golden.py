@@ -112,7 +112,47 @@ CASES = [
     dict(name="f4k_pentbiglines_scatter", W=3840, H=2160, ns_aa=1, radius=25, intensity=1,
          ap="apertures/pentbiglines.png", gh="bokeh/octagonbokeh.png",
          lights=[((0.32, 0.71), (1, 1, 1), 10)], cam=(0, 0, (0, 0, 0)), visit="list"),
+    # ---- scene-radiance term: geometry in front of the camera, delta lights ----
+    dict(name="s96x64_spheres", W=96, H=64, ns_aa=3, radius=25, intensity=1,
+         ap="apertures/pentsmall.png", gh="bokeh/octagonbokeh.png",
+         lights=[((0.62, 0.71), (2.0, 1.8, 1.5), 30)], cam=(0, 0, (0, 0, 0)), visit="tiles",
+         scene=dict(
+             spheres=[(0, -101.0, -6, 100.0, "d", 0.6, 0.6, 0.55), (-0.9, -0.4, -5, 0.6, "d", 0.8, 0.2, 0.2),
+                      (0.7, -0.55, -4.2, 0.45, "d", 0.2, 0.7, 0.3), (0.1, 0.35, -6.5, 0.5, "e", 1.5, 1.2, 0.4),
+                      (1.6, 0.2, -7.0, 0.9, "d", 0.3, 0.3, 0.9)],
+             tris=[], points=[(-2.0, 3.0, -3.0, 6.0, 6.0, 5.0)])),
+    dict(name="s80x60_tris_rotcam", W=80, H=60, ns_aa=2, radius=20, intensity=1,
+         ap="apertures/pentsmall.png", gh="bokeh/octagonbokeh.png",
+         lights=[((0.3, 0.8), (1.5, 1.5, 1.5), 40)], cam=(0.5, -0.2, (2.0, 1.0, 1.5)), visit="tiles",
+         scene="tris"),
 ]
+
+
+def tri_scene(c2w, pos):
+    """A floor quad (2 triangles, vertex normals tilted so interpolation matters), a tilted
+    triangle, an emissive triangle and two spheres, placed in front of the (rotated) camera."""
+    R, p = np.asarray(c2w), np.asarray(pos, float)
+
+    def w(v):  # camera space -> world
+        return (R @ np.asarray(v, float) + p).tolist()
+
+    def n(v):
+        v = R @ np.asarray(v, float)
+        return (v / np.linalg.norm(v)).tolist()
+
+    q = [w((-3, -1, -2)), w((3, -1, -2)), w((3, -1.4, -9)), w((-3, -1.4, -9))]
+    qn = [n((0.1, 1, 0.05)), n((-0.1, 1, 0.05)), n((-0.1, 1, -0.1)), n((0.1, 1, -0.1))]
+    tris = [q[0] + q[1] + q[2] + qn[0] + qn[1] + qn[2] + ["d", 0.7, 0.7, 0.7],
+            q[0] + q[2] + q[3] + qn[0] + qn[2] + qn[3] + ["d", 0.7, 0.7, 0.7]]
+    t = [w((-1.5, -0.9, -5)), w((0.2, -0.8, -4.5)), w((-0.8, 1.0, -5.5))]
+    tn = n(np.cross(np.subtract((0.2, -0.8, -4.5), (-1.5, -0.9, -5)), np.subtract((-0.8, 1.0, -5.5), (-1.5, -0.9, -5))))
+    tris.append(t[0] + t[1] + t[2] + tn + tn + tn + ["d", 0.2, 0.4, 0.9])
+    e = [w((1.0, 0.8, -6)), w((1.8, 0.9, -6.2)), w((1.3, 1.6, -6.1))]
+    tris.append(e[0] + e[1] + e[2] + n((0, 0, 1)) * 3 + ["e", 0.5, 2.0, 0.5])
+    spheres = [tuple(w((1.0, -0.6, -4.0))) + (0.5, "d", 0.9, 0.5, 0.1),
+               tuple(w((-0.3, -0.2, -7.5))) + (0.8, "d", 0.5, 0.5, 0.5)]
+    points = [tuple(w((0.5, 2.5, -3.0))) + (5.0, 4.0, 3.0)]
+    return dict(spheres=spheres, tris=tris, points=points)
 
 
 def run_case(c, tmp):
@@ -148,8 +188,27 @@ def run_case(c, tmp):
     cmd = [DUMP, "frame", cam, str(W), str(H), str(c["ns_aa"]), repr(float(c["radius"])),
            repr(float(c["intensity"])), os.path.join(REF, c["ap"]), os.path.join(REF, c["gh"]),
            spec, visit, out]
+    scene = c.get("scene")
+    if scene == "tris":
+        scene = tri_scene(c2w, pos)
+    if scene:
+        sfile = os.path.join(tmp, c["name"] + ".scene")
+        with open(sfile, "w") as f:
+            for s in scene["spheres"]:
+                f.write("sphere " + " ".join(v if isinstance(v, str) else repr(float(v)) for v in s) + "\n")
+            for t in scene["tris"]:
+                f.write("tri " + " ".join(v if isinstance(v, str) else repr(float(v)) for v in t) + "\n")
+            for p in scene["points"]:
+                f.write("point " + " ".join(repr(float(v)) for v in p) + "\n")
+        cmd.append(sfile)
     subprocess.run(cmd, check=True, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
     meta = parse_meta(out + ".meta.txt")
+    if scene:
+        # what the device needs for the scene term: geometry, materials and, per light, what
+        # SceneLight::sample_L uses (DirectionalLight: dirToLight = unit(posLight), src/scene/light.cpp:11-24)
+        meta["scene"] = dict(spheres=[list(s) for s in scene["spheres"]],
+                             tris=[list(t) for t in scene["tris"]],
+                             points=[list(p) for p in scene["points"]])
     meta.update(dict(name=c["name"], flare_radius=c["radius"], flare_intensity=c["intensity"],
                      aperture=os.path.basename(c["ap"]), ghost_aperture=os.path.basename(c["gh"]),
                      hFov=hf, vFov=vf, cam_pos=list(map(float, pos)),

@@ -30,6 +30,8 @@
 #include "scene/light.h"
 #include "scene/object.h"
 #include "scene/sphere.h"
+#include "scene/triangle.h"
+#include "util/halfEdgeMesh.h"
 #include "util/image.h"
 
 using namespace CGL;
@@ -137,8 +139,50 @@ static int cmd_frame(int argc, char** argv) {
       p0 = p1 + 1;
     }
   }
-  Scene scene(objs, lights);
   std::vector<Primitive*> prims = sph->get_primitives();
+  // optional scene geometry: spheres, triangles and point lights from a text file
+  //   sphere cx cy cz r  d|e  a b c          (diffuse reflectance or emitted radiance)
+  //   tri  9 x vertex coords  9 x vertex normals  d|e  a b c
+  //   point px py pz  Lr Lg Lb
+  std::string scenefile = argc > a ? argv[a++] : "";
+  if (!scenefile.empty()) {
+    std::ifstream sf(scenefile);
+    std::string kind;
+    while (sf >> kind) {
+      if (kind == "sphere") {
+        double cx, cy, cz, rr, c0, c1, c2; std::string mk;
+        sf >> cx >> cy >> cz >> rr >> mk >> c0 >> c1 >> c2;
+        BSDF* b = mk == "e" ? (BSDF*)new EmissionBSDF(Vector3D(c0, c1, c2))
+                            : (BSDF*)new DiffuseBSDF(Vector3D(c0, c1, c2));
+        SphereObject* so = new SphereObject(Vector3D(cx, cy, cz), rr, b);
+        objs.push_back(so);
+        for (Primitive* p : so->get_primitives()) prims.push_back(p);
+      } else if (kind == "tri") {
+        double v[18], c0, c1, c2; std::string mk;
+        for (int k = 0; k < 18; k++) sf >> v[k];
+        sf >> mk >> c0 >> c1 >> c2;
+        BSDF* b = mk == "e" ? (BSDF*)new EmissionBSDF(Vector3D(c0, c1, c2))
+                            : (BSDF*)new DiffuseBSDF(Vector3D(c0, c1, c2));
+        // a Mesh built from an empty HalfedgeMesh, then pointed at our own vertex arrays:
+        // Triangle's constructor (src/scene/triangle.cpp:9-21) only reads positions/normals/bsdf
+        HalfedgeMesh* hem = new HalfedgeMesh();
+        Mesh* m = new Mesh(*hem, b);
+        m->positions = new Vector3D[3];
+        m->normals = new Vector3D[3];
+        for (int k = 0; k < 3; k++) {
+          m->positions[k] = Vector3D(v[3 * k], v[3 * k + 1], v[3 * k + 2]);
+          m->normals[k] = Vector3D(v[9 + 3 * k], v[10 + 3 * k], v[11 + 3 * k]);
+        }
+        objs.push_back(m);
+        prims.push_back(new Triangle(m, 0, 1, 2));
+      } else if (kind == "point") {
+        double px, py, pz, l0, l1, l2;
+        sf >> px >> py >> pz >> l0 >> l1 >> l2;
+        lights.push_back(new PointLight(Vector3D(l0, l1, l2), Vector3D(px, py, pz)));
+      }
+    }
+  }
+  Scene scene(objs, lights);
   BVHAccel bvh(prims, 4);
 
   PathTracer pt;

@@ -133,6 +133,9 @@ def test_read_tile_strides_and_pixel(pkg, lf):
     assert np.array_equal(lf.read_pixel(pkg.SAMPLE_BUFFER, 11, 13), full[13, 11])
     tile = lf.write_to_framebuffer(32, 0, 64, 32)
     assert np.array_equal(tile, case.rgba[0:32, 32:64])
+    # save_image's pixel preparation (raytraced_renderer.cpp:739-746): rows flipped, alpha 0xFF
+    png = lf.save_image_rgba()
+    assert np.array_equal(png, case.rgba[::-1] | np.uint32(0xFF000000))
 
 
 def test_band_sharding_matches_full_frame(pkg, lf):
