@@ -105,10 +105,17 @@ def main():
         raise SystemExit(f"--gpus {args.gpus} needs WORLD_SIZE={args.gpus} (launch with torch.distributed.run)")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the hot path has no CPU fallback")
+    # LF_BENCH_BACKEND=gloo is a REHEARSAL mode for a 1-GPU box (several ranks share GPU 0 and the
+    # tile-row exchange is staged through host memory); the real run uses nccl (= RCCL over xGMI).
+    backend = os.environ.get("LF_BENCH_BACKEND", "nccl")
+    local = local % torch.cuda.device_count() if backend == "gloo" else local
     torch.cuda.set_device(local)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+        else:
+            dist.init_process_group(backend)
 
     W, H, spp = args.width, args.height, args.spp
     lens = pkg.load_lens_file("dgauss11.lens")
@@ -155,7 +162,12 @@ def main():
             # consecutive tile rows is one in-place all-gather (rank r owns slot r of the group);
             # the buffer is padded to 64 rows so the last group never runs past the end.
             lf.synchronize()
-            sharding.gather_frame_inplace(frame_t, W, H, rank, world, dist)
+            if backend == "nccl":
+                sharding.gather_frame_inplace(frame_t, W, H, rank, world, dist)
+            else:
+                host = frame_t.cpu()
+                sharding.gather_frame_inplace(host, W, H, rank, world, dist)
+                frame_t.copy_(host)
             torch.cuda.synchronize()   # the next frame rewrites these rows on the library's stream
 
     def barrier():
@@ -182,7 +194,7 @@ def main():
     cnt = lf.counters()
     n_launch, march_ms = lf.timing_get("march")
     ev = torch.tensor([float(cnt["surface_events"]), float(cnt["rays_launched"]), dt],
-                      dtype=torch.float64, device=f"cuda:{local}")
+                      dtype=torch.float64, device=f"cuda:{local}" if backend == "nccl" else "cpu")
     if world > 1:
         tot = ev.clone()
         dist.all_reduce(tot[:2], op=dist.ReduceOp.SUM)

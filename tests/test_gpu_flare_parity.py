@@ -203,3 +203,35 @@ def test_no_sun_is_defined_noop(pkg, lf):
     lf.generate_ghost_buffer()
     lf.render_flare_layer()
     assert not lf.read_buffer(pkg.SAMPLE_BUFFER).any()
+
+
+def test_custom_paraxial_prescription(pkg, lf):
+    """lf_set_paraxial_lens with a table that is NOT the reference's hard-coded one (7 interfaces,
+    stop at 3: pairs (0,1) (0,2) (1,2) before, (4,5) (4,6) (5,6) after).  Expected values: the
+    pinned oracle run on the same table (the reference cannot take another prescription)."""
+    from oracle import lfo
+    case = Case("f97x65_odd_rotcam")
+    _setup(pkg, lf, case, via_find_sun=False)
+    n, stop = 7, 3
+    th = np.array([6.5, 2.1, 4.0, 3.3, 2.0, 5.5, 70.0], np.float32)
+    radii = [35.0, -70.0, 120.0, 0.0, -45.0, 30.0, -60.0]
+    cu = np.array([0.0 if r == 0 else np.float32(1.0 / r) for r in radii], np.float32)
+    ior = np.array([[1.60, 1.0, 1.52, 1.0, 1.62, 1.70, 1.0],
+                    [1.61, 1.0, 1.53, 1.0, 1.63, 1.71, 1.0],
+                    [1.62, 1.0, 1.54, 1.0, 1.64, 1.72, 1.0]], np.float32)
+    lf.set_paraxial_lens(n, stop, th, cu, ior)
+    lf.generate_ghost_buffer()
+    got = lf.read_buffer(pkg.GHOST_BUFFER)
+    L = lfo.default_lens()
+    L.n, L.stop = n, stop
+    for k in range(n):
+        L.thickness[k], L.curvature[k] = float(th[k]), float(cu[k])
+        for c in range(3):
+            L.ior[c][k] = float(ior[c, k])
+    f = lfo.make_frame(case.W, case.H, flares=case.flares, axis_ray=case.meta["axis_ray"],
+                       angle_to_sun=case.meta["angle_to_sun"])
+    exp = lfo.ghost_buffer(L, f, load_texels(case.meta["ghost_aperture"]))
+    assert exp.any() and np.array_equal(got, exp)
+    lf.set_paraxial_lens()   # back to the reference's table
+    lf.generate_ghost_buffer()
+    assert np.array_equal(lf.read_buffer(pkg.GHOST_BUFFER), case.ghost)
