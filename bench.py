@@ -81,6 +81,61 @@ def cpu_baseline(lens, mask, sun, W, H, target_s):
                       f"(oracle/lf_geo_oracle.c, OpenMP)"}
 
 
+def reference_flare_path(pkg):
+    """Side datum (never `value`): the REAL reference's own CPU renderer (oracle/_ref/ref_dump, the
+    reference hot path compiled from its own sources, 1 thread) on the golden 64x48 frame, next to
+    the same frame through the C ABI on the GPU.  None when the prebuilt binary is absent."""
+    import subprocess
+    import tempfile
+    from goldenlib import GOLD, Case, load_texels
+    dump = os.path.join(ROOT, "oracle", "_ref", "ref_dump")
+    if not os.path.exists(dump):
+        return None
+    try:
+        case = Case("f64x48_pentbiglines")
+        m = case.meta
+        tmp = tempfile.mkdtemp(prefix="lfref")
+        cam = os.path.join(tmp, "cam.txt")
+        sd = case.H / (2 * math.tan(math.radians(m["vFov"]) / 2))
+        with open(cam, "w") as f:
+            f.write(f"{m['hFov']!r} {m['vFov']!r} {case.W / case.H!r} 0.01 100\n")
+            f.write(" ".join(repr(float(v)) for v in m["cam_pos"]) + " 0 0 0\n1.5 0.7 5 0.5 100\n")
+            f.write(" ".join(repr(float(v)) for v in m["c2w"]) + f"\n{case.W} {case.H} {sd!r}\n4.7 0\n")
+        spec = ";".join(",".join(repr(float(v)) for v in l) for l in m["lights"])
+        ap_png = os.path.join(GOLD, "apertures", m["aperture"])
+        gh_png = os.path.join(GOLD, "apertures", m["ghost_aperture"])
+        t0 = time.time()
+        subprocess.run([dump, "frame", cam, str(case.W), str(case.H), str(m["ns_aa"]),
+                        repr(float(m["flare_radius"])), repr(float(m["flare_intensity"])), ap_png,
+                        gh_png, spec, "tiles", os.path.join(tmp, "o")], check=True,
+                       stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+        t_ref = time.time() - t0
+        got = np.fromfile(os.path.join(tmp, "o.sample.f64")).reshape(case.H, case.W, 3)
+        lf = pkg.LensFlare(0)
+        lf.set_frame(case.W, case.H)
+        lf.set_params(m["ns_aa"], m["flare_radius"], m["flare_intensity"])
+        lf.set_aperture(pkg.APERTURE_STARBURST, load_texels(m["aperture"]))
+        lf.set_aperture(pkg.APERTURE_GHOST, load_texels(m["ghost_aperture"]))
+        lf.set_camera(m["c2w"], m["cam_pos"], m["hFov"], m["vFov"])
+        lf.set_jitter_mt19937(5489, None)
+        lf.synchronize()
+        t0 = time.perf_counter()
+        lf.find_sun_pos(m["lights"])
+        lf.generate_ghost_buffer()
+        lf.render_flare_layer()
+        lf.synchronize()
+        t_gpu = time.perf_counter() - t0
+        dev = lf.read_buffer(pkg.SAMPLE_BUFFER)
+        lf.close()
+        return {"frame": "64x48, apertures/pentbiglines.png (80x78 bbox), 1 sun, ns_aa 1",
+                "reference_cpu_s": t_ref, "cores": 1, "kind": "reference",
+                "gpu_s": t_gpu, "max_rel_diff": float((np.abs(dev - got) / np.abs(got)).max()),
+                "note": "reference time includes its PNG decode; its cost is the per-pixel direct "
+                        "DFT (pathtracer.cpp:947-974), the device path gathers from one DFT of the aperture"}
+    except Exception as e:  # noqa: BLE001
+        return {"error": str(e)}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -122,9 +177,10 @@ def main():
     mask = load_mask()
     sun = sun_direction(lens, W, H)
 
-    cpu = None
+    cpu, ref_path = None, None
     if rank == 0 and world == 1 and not args.no_cpu:
         cpu = cpu_baseline(lens, mask, sun, W, H, args.cpu_seconds)
+        ref_path = reference_flare_path(pkg)
 
     lf = pkg.LensFlare(local)
     lf.set_frame(W, H)
@@ -257,6 +313,7 @@ def main():
                                  "binding resource is FP32 VALU issue, see valu"},
             "valu": valu,
             "cpu_baseline": cpu,
+            "reference_flare_path": ref_path,
         }
         print(json.dumps(out), flush=True)
     lf.close()

@@ -183,6 +183,7 @@ struct lf_ctx {
   LfLensDev lens{};
   bool lens_valid = false, sun_valid = false;
   int march_sub_bits = 2;  // pupil sub-cells per stratum = 4 x 4 (part of the sampling spec)
+  float sensor_w_mm = 36.0f;
   LfLensDev* lens_dev = nullptr;
   LfPairsDev pairs{};
   LfPairsDev* pairs_dev = nullptr;

@@ -369,7 +369,8 @@ void lf_derive_lens(lf_ctx* ctx, int n, int stop, int n_lambda, const float* rad
       n_before = n_after;
     }
   }
-  L.pitch = sensor_w_mm / (float)ctx->W;
+  ctx->sensor_w_mm = sensor_w_mm;
+  L.pitch = sensor_w_mm / (float)ctx->W;  // refreshed at every launch: the frame may be resized
   L.pupil_h = semi_ap[n - 1];
   L.pupil_z = L.surf[n - 1].zv;
   double D = (double)L.z_sensor - (double)L.pupil_z;
@@ -435,6 +436,7 @@ static lf_status build_event_table(lf_ctx* ctx) {
 
 lf_status lfk_march(lf_ctx* ctx, int spp, uint64_t key) {
   const LfApertureDev& m = ctx->ap[LF_APERTURE_STARBURST];
+  ctx->lens.pitch = ctx->sensor_w_mm / (float)ctx->W;
   if (ctx->events_dirty) {
     lf_status st = build_event_table(ctx);
     if (st != LF_OK) return st;
