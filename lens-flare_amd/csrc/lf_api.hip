@@ -101,6 +101,8 @@ void free_frame_buffers(lf_ctx* ctx) {
   if (ctx->jitter_raw) (void)hipFree(ctx->jitter_raw);
   if (ctx->jitter_aa_raw) (void)hipFree(ctx->jitter_aa_raw);
   ctx->jitter_aa_raw = nullptr;
+  if (ctx->accum) (void)hipFree(ctx->accum);  // sized by the frame
+  ctx->accum = nullptr;
   ctx->sample = ctx->ghost = ctx->scene = ctx->star = nullptr;
   ctx->rgba = nullptr;
   ctx->jitter_raw = nullptr;

@@ -170,6 +170,7 @@ struct MarchArgs {
   int sub_bits;        // each stratum is split into 2^sub_bits x 2^sub_bits sub-cells
   float inv_sub;
   int trow0, tperiod;  // tile rows handled: trow0 + j * tperiod, j = 0 ..
+  int sgroups;         // the samples of a tile are split over this many workgroups (power of two)
   uint2 key;
 };
 
@@ -178,16 +179,20 @@ __global__ __launch_bounds__(256) void k_march(const LfLensDev* __restrict__ len
                                                const LfEventRow* __restrict__ ev_table,
                                                const float* __restrict__ mask, MarchArgs a,
                                                double* __restrict__ ghost,
+                                               unsigned long long* __restrict__ accum,
                                                unsigned long long* __restrict__ counters) {
   __shared__ unsigned long long s_acc[64 * 3];
   __shared__ unsigned long long s_cnt[8];
+  __shared__ int s_next;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   if (tid < 64 * 3) s_acc[tid] = 0ull;
   if (tid < 8) s_cnt[tid] = 0ull;
+  if (tid == 0) s_next = 0;
   __syncthreads();
 
   const int tiles_x = (a.W + 7) >> 3;
-  const int tx = blockIdx.x % tiles_x, tj = blockIdx.x / tiles_x;
+  const int sg = blockIdx.x % a.sgroups, tile_lin = blockIdx.x / a.sgroups;
+  const int tx = tile_lin % tiles_x, tj = tile_lin / tiles_x;
   const int x = tx * 8 + (lane & 7);
   const int y = (a.trow0 + tj * a.tperiod) * 8 + (lane >> 3);
   const bool active = x < a.W && y >= a.y0 && y < a.y1;
@@ -208,7 +213,16 @@ __global__ __launch_bounds__(256) void k_march(const LfLensDev* __restrict__ len
   unsigned long long acc[3] = {0ull, 0ull, 0ull};
 
   {
-    for (int s = wave; s < a.spp; s += 4) {  // wave-uniform
+    // The 4 waves of the workgroup pull sample indices from one LDS counter instead of owning
+    // every 4th one: a wave whose pupil cells fall outside the aperture finishes its samples in a
+    // fraction of the time, and a static split leaves it idle until the slowest wave is done.
+    // (Which wave marches which sample does not matter: the sums are integers.)
+    for (;;) {
+      int k = 0;
+      if (lane == 0) k = atomicAdd(&s_next, 1);
+      k = __builtin_amdgcn_readfirstlane(k);
+      const int s = sg + k * a.sgroups;  // wave-uniform
+      if (s >= a.spp) break;
       // ---- sensor sample -> initial ray --------------------------------------------------
       const uint4 rnd = philox4x32_10(make_uint4(p, (unsigned)s, kDomainMarch, 0u), a.key);
       const float jx = u01(rnd.x), jy = u01(rnd.y);
@@ -327,11 +341,31 @@ __global__ __launch_bounds__(256) void k_march(const LfLensDev* __restrict__ len
 
   // ---- the tile's pixels: 8 rows of 8 x 24 contiguous bytes -----------------------------------
   if (wave == 0 && active) {
+    if (a.sgroups == 1) {
 #pragma unroll
-    for (int c = 0; c < 3; c++)
-      ghost[3 * (size_t)p + c] =
-          ((double)s_acc[lane * 3 + c] * (1.0 / 68719476736.0)) / (double)a.spp;
+      for (int c = 0; c < 3; c++)
+        ghost[3 * (size_t)p + c] =
+            ((double)s_acc[lane * 3 + c] * (1.0 / 68719476736.0)) / (double)a.spp;
+    } else {
+      // several workgroups share the tile (short launches, e.g. 1/8 of a frame per GPU, would
+      // otherwise leave the last wave of long-running workgroups running alone): integer partial
+      // sums meet in HBM, k_march_finish converts them -- the same bits as the single-group path
+#pragma unroll
+      for (int c = 0; c < 3; c++)
+        if (s_acc[lane * 3 + c]) atomicAdd(&accum[3 * (size_t)p + c], s_acc[lane * 3 + c]);
+    }
   }
+}
+
+__global__ void k_march_finish(const unsigned long long* __restrict__ accum, MarchArgs a,
+                               double* __restrict__ ghost) {
+  const size_t p = (size_t)a.y0 * a.W + (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (p >= (size_t)a.y1 * a.W) return;
+  const int t = (int)(p / a.W) >> 3;
+  if (t < a.trow0 || (t - a.trow0) % a.tperiod != 0) return;
+#pragma unroll
+  for (int c = 0; c < 3; c++)
+    ghost[3 * p + c] = ((double)accum[3 * p + c] * (1.0 / 68719476736.0)) / (double)a.spp;
 }
 
 }  // namespace
@@ -463,12 +497,35 @@ lf_status lfk_march(lf_ctx* ctx, int spp, uint64_t key) {
   if (first >= t_hi) return LF_OK;
   const int n_trows = (t_hi - 1 - first) / period + 1;
   a.trow0 = first; a.tperiod = period;
-  const size_t blocks = (size_t)n_trows * ((ctx->W + 7) / 8);
+  const size_t tiles = (size_t)n_trows * ((ctx->W + 7) / 8);
+  // keep >= ~24k workgroups in flight so the tail of the launch stays short: split each tile's
+  // samples over `sgroups` workgroups (power of two, at least one sample per wave)
+  a.sgroups = 1;
+  while (tiles * a.sgroups < 24000 && a.sgroups * 2 * 4 <= spp) a.sgroups *= 2;
+  if (const char* sgv = std::getenv("LF_MARCH_SGROUPS")) {  // experiments only
+    int v = std::atoi(sgv);
+    if (v >= 1 && v * 4 <= std::max(4, spp) && (v & (v - 1)) == 0) a.sgroups = v;
+  }
+  const size_t blocks = tiles * a.sgroups;
   if (blocks > 0x7fffffffull) return lf_fail(ctx, LF_ERR_INVALID, "band too large for one launch");
+  const size_t n_acc = (size_t)ctx->W * ctx->H_alloc * 3;
+  if (a.sgroups > 1) {
+    if (!ctx->accum) LF_HIP(ctx, hipMalloc((void**)&ctx->accum, n_acc * sizeof(unsigned long long)));
+    LF_HIP(ctx, hipMemsetAsync(ctx->accum + (size_t)ctx->y0 * ctx->W * 3, 0,
+                               (size_t)(ctx->y1 - ctx->y0) * ctx->W * 3 * sizeof(unsigned long long),
+                               ctx->stream));
+  }
   hipEvent_t ev = lf_timing_begin(ctx, LFK_MARCH);
   hipLaunchKernelGGL(k_march, dim3((unsigned)blocks), dim3(256), 0, ctx->stream, ctx->lens_dev,
-                     ctx->pairs_dev, ctx->events_dev, m.texels, a, ctx->ghost, ctx->counters_dev);
+                     ctx->pairs_dev, ctx->events_dev, m.texels, a, ctx->ghost, ctx->accum,
+                     ctx->counters_dev);
   lf_timing_end(ctx, LFK_MARCH, ev);
   LF_HIP(ctx, hipGetLastError());
+  if (a.sgroups > 1) {
+    const size_t px = (size_t)(ctx->y1 - ctx->y0) * ctx->W;
+    hipLaunchKernelGGL(k_march_finish, dim3((unsigned)((px + 255) / 256)), dim3(256), 0, ctx->stream,
+                       ctx->accum, a, ctx->ghost);
+    LF_HIP(ctx, hipGetLastError());
+  }
   return LF_OK;
 }
