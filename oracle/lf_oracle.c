@@ -533,6 +533,11 @@ size_t lfo_tile_order(int W, int H, int tile, uint32_t* order) {
   return n;
 }
 
+/* optional scene term (W*H*3, already averaged as in pathtracer.cpp:875), e.g. from
+ * lfo_scene_term in lf_scene_oracle.c; NULL = nothing is hit */
+static const double* g_scene_term = NULL;
+void lfo_set_scene_term(const double* scene) { g_scene_term = scene; }
+
 void lfo_render_pixels(const lfo_frame* f, const float* ap, const lfo_aperture_stats* st,
                        const double* ghost, const uint32_t* order, size_t n_order,
                        uint32_t mt_seed_, int n_threads, double* sample) {
@@ -552,7 +557,7 @@ void lfo_render_pixels(const lfo_frame* f, const float* ap, const lfo_aperture_s
     double total[3] = {0, 0, 0};
     double rc = 1. / (double)(f->ns_aa + 1); /* :875 divides by the loop variable = ns_aa+1 */
     for (int c = 0; c < 3; c++) {
-      double scene = total[c] * rc;
+      double scene = g_scene_term ? g_scene_term[3 * p + c] : total[c] * rc;
       double g = ghost ? ghost[3 * p + c] : 0.0;
       double star = sb[c] + fo[c];              /* :1004 */
       sample[3 * p + c] = (scene + g) + star;   /* :891 */

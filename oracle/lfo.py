@@ -295,3 +295,38 @@ def geo_philox(ctr, key):
     o = (C.c_uint32 * 4)()
     lib().geo_philox(c, k, o)
     return list(o)
+
+
+# ------------------------------------------------------------------------------------------------
+# scene-radiance term (oracle/lf_scene_oracle.c) -- pinned by the s*.npz golden frames
+# ------------------------------------------------------------------------------------------------
+def scene_term(W, H, ns_aa, c2w, pos, hfov, vfov, spheres, tris, lights, order, seed=5489,
+               samples_per_batch=32, max_tol=0.05, nclip=0.01, fclip=100.0):
+    """spheres: (cx,cy,cz,r,kind,a,b,c); tris: 18 numbers + (kind,a,b,c); lights: (type,x,y,z,r,g,b)."""
+    mats, sp, spm, tp, tn, tm = [], [], [], [], [], []
+    for s in spheres:
+        sp.append(list(s[:4])); spm.append(len(mats)); mats.append([1.0 if s[4] == "e" else 0.0] + list(s[5:8]))
+    for t in tris:
+        tp.append(list(t[:9])); tn.append(list(t[9:18])); tm.append(len(mats))
+        mats.append([1.0 if t[18] == "e" else 0.0] + list(t[19:22]))
+    f64 = lambda a: np.ascontiguousarray(np.array(a, np.float64).reshape(-1))  # noqa: E731
+    i32 = lambda a: np.ascontiguousarray(np.array(a, np.int32).reshape(-1))    # noqa: E731
+    spa, spma, tpa, tna, tma, ma, la = f64(sp), i32(spm), f64(tp), f64(tn), i32(tm), f64(mats), f64(lights)
+    c2w = f64(c2w); pos = f64(pos)
+    order = np.ascontiguousarray(order, np.uint32)
+    out = np.zeros((H, W, 3), np.float64)
+    lib().lfo_scene_term(W, H, ns_aa, samples_per_batch, C.c_double(max_tol), _p(c2w, C.c_double),
+                         _p(pos, C.c_double), C.c_double(hfov), C.c_double(vfov), C.c_double(nclip),
+                         C.c_double(fclip), len(sp), _p(spa, C.c_double), _p(spma, C.c_int), len(tp),
+                         _p(tpa, C.c_double), _p(tna, C.c_double), _p(tma, C.c_int), _p(ma, C.c_double),
+                         len(lights), _p(la, C.c_double), _p(order, C.c_uint32), C.c_size_t(len(order)),
+                         C.c_uint32(seed), _p(out, C.c_double))
+    return out
+
+
+def set_scene_term(scene):
+    """Scene term used by render_pixels (None = nothing hit).  Keep the array alive while in use."""
+    if scene is None:
+        lib().lfo_set_scene_term(None)
+    else:
+        lib().lfo_set_scene_term(_p(scene, C.c_double))

@@ -97,6 +97,35 @@ def test_raytrace_pixel_matches_reference(name):
     assert np.array_equal(got_rgba, ref_rgba)
 
 
+@pytest.mark.parametrize("name", ["s96x64_spheres", "s80x60_tris_rotcam"])
+def test_scene_term_oracle_matches_reference(name):
+    """Row f2: the sample loop of raytrace_pixel with real geometry (oracle/lf_scene_oracle.c):
+    spheres, triangles with interpolated normals, emission, sun + point light, shadow rays --
+    against frames rendered by the real reference; RGBA8 byte-exact."""
+    case = Case(name)
+    m = case.meta
+    f = _frame(case)
+    tex, st = lfo.aperture_from_red(load_red(m["aperture"]))
+    order = lfo.tile_order(case.W, case.H)
+    lights = []
+    for l in m["lights"]:   # DirectionalLight: dirToLight = unit(posLight) (src/scene/light.cpp:11-24)
+        p = np.array(l[:3])
+        lights.append([0.0] + (p / np.sqrt((p[0] * p[0] + p[1] * p[1]) + p[2] * p[2])).tolist() + list(l[3:6]))
+    lights += [[1.0] + list(p) for p in m["scene"]["points"]]
+    spheres = [(1e4, 1e4, 1e4, 1.0, "d", 0.5, 0.5, 0.5)] + [tuple(s) for s in m["scene"]["spheres"]]
+    scene = lfo.scene_term(case.W, case.H, m["ns_aa"], m["c2w"], m["cam_pos"], m["hFov"], m["vFov"],
+                           spheres, [tuple(t) for t in m["scene"]["tris"]], lights, order)
+    assert (scene.max(axis=-1) > 0.05).mean() > 0.3
+    lfo.set_scene_term(scene)
+    try:
+        got = lfo.render_pixels(f, tex, st, case.ghost, order, n_threads=8)
+    finally:
+        lfo.set_scene_term(None)
+    err = np.abs(got - case.sample) / np.abs(case.sample)
+    assert err.max() <= TOL, err.max()
+    assert np.array_equal(lfo.to_color(got), case.rgba)
+
+
 def test_mt19937_known_answer():
     """std::mt19937 default seed: the 10000th output is 4123659995 (C++11 [rand.predef])."""
     raw = lfo.mt19937_raw(5489, 9999, 1)
