@@ -205,6 +205,14 @@ lf_status lf_set_ghost_pairs(lf_ctx* ctx, const int* pairs, int n_pairs, int inc
 /* march `spp` sensor samples per pixel of the band through every selected pair and wavelength and
  * accumulate into ghost_buffer (replacing its content).  key seeds the counter RNG. */
 lf_status lf_trace_ghosts(lf_ctx* ctx, int spp, uint64_t key);
+/* replaces: LensCamera::generate_ray of the north star / Camera::generate_ray_for_thin_lens
+ * (declared camera.h:168, a stub in camera_lens.cpp:22-30), batched: for n sensor samples -- sensor
+ * position in mm (x, y; the lens inverts the image) and a rear-pupil sample in [-1,1]^2 -- march the
+ * primary path through the prescription at wavelength index `lambda`.  out: n x 8 floats
+ * {origin xyz on the front element, unit direction xyz towards the scene, transmitted weight,
+ * alive (1/0)} in lens space (optical axis = z, light travels +z, the scene lies at z < 0). */
+lf_status lf_generate_lens_rays(lf_ctx* ctx, int lambda, size_t n, const float* sensor_xy_mm,
+                                const float* pupil_uv, float* out);
 lf_status lf_get_counters(lf_ctx* ctx, lf_counters* out);
 lf_status lf_reset_counters(lf_ctx* ctx);
 

@@ -31,7 +31,7 @@ ABI_SYMBOLS = [
     "lf_set_sampling", "lf_render_scene_term",
     "lf_generate_ghost_buffer", "lf_render_flare_layer", "lf_read_tile", "lf_read_pixel",
     "lf_write_to_framebuffer", "lf_save_image_rgba", "lf_device_buffer", "lf_set_lens", "lf_set_lambda_rgb", "lf_set_sun",
-    "lf_set_ghost_pairs", "lf_trace_ghosts", "lf_get_counters", "lf_reset_counters",
+    "lf_set_ghost_pairs", "lf_trace_ghosts", "lf_generate_lens_rays", "lf_get_counters", "lf_reset_counters",
     "lf_timing_enable", "lf_timing_reset", "lf_timing_get",
 ]
 
@@ -63,6 +63,10 @@ def load_library():
     """dlopen the in-tree library.  Raises if it has not been built (no silent fallback)."""
     global _lib
     if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            # build in-tree on first use (hipcc cross-compiles gfx950 anywhere); never a fallback
+            import subprocess
+            subprocess.check_call(["make", "-s", "-j4", "-C", HERE])
         if not os.path.exists(LIB_PATH):
             raise FileNotFoundError(f"{LIB_PATH} is missing: run __graft_entry__.build() "
                                     "(make -C lens-flare_amd)")
@@ -317,6 +321,15 @@ class LensFlare:
 
     def trace_ghosts(self, spp, key=0x1e45f1a4e):
         self._ck(self.lib.lf_trace_ghosts(self.ctx, int(spp), C.c_uint64(key)))
+
+    def generate_lens_rays(self, lam, sensor_xy_mm, pupil_uv):
+        xy = np.ascontiguousarray(sensor_xy_mm, np.float32).reshape(-1, 2)
+        uv = np.ascontiguousarray(pupil_uv, np.float32).reshape(-1, 2)
+        out = np.zeros((len(xy), 8), np.float32)
+        self._ck(self.lib.lf_generate_lens_rays(self.ctx, int(lam), C.c_size_t(len(xy)),
+                                                _fp(xy, C.c_float), _fp(uv, C.c_float),
+                                                _fp(out, C.c_float)))
+        return out
 
     def counters(self):
         c = Counters()

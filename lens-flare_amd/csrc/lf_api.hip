@@ -637,6 +637,34 @@ lf_status lf_trace_ghosts(lf_ctx* ctx, int spp, uint64_t key) {
   return LF_OK;
 }
 
+lf_status lf_generate_lens_rays(lf_ctx* ctx, int lambda, size_t n, const float* sensor_xy_mm,
+                                const float* pupil_uv, float* out) {
+  if (!ctx || !sensor_xy_mm || !pupil_uv || !out) return LF_ERR_INVALID;
+  if (!ctx->lens_valid) return lf_fail(ctx, LF_ERR_STATE, "lf_generate_lens_rays before lf_set_lens");
+  if (!ctx->ap[LF_APERTURE_STARBURST].valid)
+    return lf_fail(ctx, LF_ERR_STATE, "aperture mask (LF_APERTURE_STARBURST slot) not set");
+  if (lambda < 0 || lambda >= ctx->lens.n_lambda || n > 0x7fffffffull)
+    return lf_fail(ctx, LF_ERR_INVALID, "lf_generate_lens_rays: wavelength index / count out of range");
+  if (n == 0) return LF_OK;
+  LF_HIP(ctx, hipSetDevice(ctx->device));
+  float *d_xy = nullptr, *d_uv = nullptr, *d_out = nullptr;
+  hipError_t e = hipMalloc((void**)&d_xy, n * 2 * sizeof(float));
+  if (e == hipSuccess) e = hipMalloc((void**)&d_uv, n * 2 * sizeof(float));
+  if (e == hipSuccess) e = hipMalloc((void**)&d_out, n * 8 * sizeof(float));
+  if (e == hipSuccess) e = hipMemcpy(d_xy, sensor_xy_mm, n * 2 * sizeof(float), hipMemcpyHostToDevice);
+  if (e == hipSuccess) e = hipMemcpy(d_uv, pupil_uv, n * 2 * sizeof(float), hipMemcpyHostToDevice);
+  lf_status st = LF_OK;
+  if (e == hipSuccess) st = lfk_lens_rays(ctx, lambda, (int)n, d_xy, d_uv, d_out);
+  if (e == hipSuccess && st == LF_OK) e = hipStreamSynchronize(ctx->stream);
+  if (e == hipSuccess && st == LF_OK) e = hipMemcpy(out, d_out, n * 8 * sizeof(float), hipMemcpyDeviceToHost);
+  if (d_xy) (void)hipFree(d_xy);
+  if (d_uv) (void)hipFree(d_uv);
+  if (d_out) (void)hipFree(d_out);
+  if (st != LF_OK) return st;
+  LF_HIP(ctx, e);
+  return LF_OK;
+}
+
 lf_status lf_get_counters(lf_ctx* ctx, lf_counters* out) {
   if (!ctx || !out) return LF_ERR_INVALID;
   unsigned long long c[8];

@@ -220,6 +220,8 @@ lf_status lfk_tonemap(lf_ctx* ctx);
 lf_status lfk_flip_rows(lf_ctx* ctx, uint32_t* out_dev);
 // lf_march.hip
 lf_status lfk_march(lf_ctx* ctx, int spp, uint64_t key);
+lf_status lfk_lens_rays(lf_ctx* ctx, int lambda, int n, const float* d_xy, const float* d_uv,
+                        float* d_out);
 void lf_derive_lens(lf_ctx* ctx, int n, int stop, int n_lambda, const float* radius,
                     const float* thickness, const float* ior, const float* semi_ap,
                     float sensor_w_mm);

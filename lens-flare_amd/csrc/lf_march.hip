@@ -357,6 +357,59 @@ __global__ __launch_bounds__(256) void k_march(const LfLensDev* __restrict__ len
   }
 }
 
+// LensCamera::generate_ray, batched: one lane per sensor sample, the primary path N-1 .. 0 through
+// the prescription (the same event arithmetic as the ghost march); out = {origin xyz on the front
+// element, unit direction xyz towards the scene, transmitted weight, alive flag} in lens space
+// (z along the axis, light travels +z, the scene is at z < 0).
+__global__ __launch_bounds__(256) void k_lens_rays(const LfLensDev* __restrict__ lens,
+                                                   const float* __restrict__ mask, int mw, int mh,
+                                                   int lambda, int n, const float* __restrict__ sensor_xy,
+                                                   const float* __restrict__ pupil_uv,
+                                                   float* __restrict__ out) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  const int lane = threadIdx.x & 63;
+  const bool active = i < n;
+  const float X = active ? sensor_xy[2 * i] : 0.0f, Y = active ? sensor_xy[2 * i + 1] : 0.0f;
+  const float pa = active ? pupil_uv[2 * i] : 0.0f, pb = active ? pupil_uv[2 * i + 1] : 0.0f;
+  float qx = 0.0f, qy = 0.0f;  // concentric map, as in k_march
+  if (pa != 0.0f || pb != 0.0f) {
+    const bool wide = fabsf(pa) > fabsf(pb);
+    const float rr = wide ? pa : pb;
+    const float th = 0.78539816339744831f * __fdiv_rn(wide ? pb : pa, rr);
+    const float t2 = th * th;
+    const float sn = th * fmaf(t2, fmaf(t2, fmaf(t2, fmaf(t2, 2.7557319e-6f, -1.9841270e-4f),
+                                                 8.3333333e-3f), -1.6666667e-1f), 1.0f);
+    const float cs = fmaf(t2, fmaf(t2, fmaf(t2, fmaf(t2, 2.4801587e-5f, -1.3888889e-3f),
+                                            4.1666667e-2f), -0.5f), 1.0f);
+    qx = wide ? rr * cs : rr * sn;
+    qy = wide ? rr * sn : rr * cs;
+  }
+  const float z_sensor = lens->z_sensor;
+  const float vx = fmaf(lens->pupil_h, qx, -X), vy = fmaf(lens->pupil_h, qy, -Y), vz = lens->pupil_z - z_sensor;
+  const float len = lf_sqrt(fmaf(vx, vx, fmaf(vy, vy, vz * vz)));
+  const float rl = __fdiv_rn(1.0f, len);
+  Ray r{X, Y, z_sensor, vx * rl, vy * rl, vz * rl, 1.0f, 1.0f};
+  const float c2 = r.dz * r.dz;
+  r.wn = lens->geom_norm * (c2 * c2);
+  const float inv_stop_h = __fdiv_rn(1.0f, lens->stop_h);
+  lanemask alive = __ballot(active);
+  for (int k = lens->n_surf - 1; k >= 0; k--) {  // wave-uniform
+    const LfSurfaceDev& sf = lens->surf[k];
+    lanemask ok, geom_ok;
+    if (sf.is_stop != 0.0f) ok = stop_event(r, sf.zv, sf.h2, inv_stop_h, mask, mw, mh);
+    else ok = surface_event(r, sf.zv, sf.curv, sf.radius, sf.h2, sf.eta_bwd[lambda], false,
+                            sf.curv == 0.0f, -1.0f, geom_ok);
+    alive &= ok;
+  }
+  if (active) {
+    const bool a = (alive >> lane) & 1ull;
+    float* o = out + 8 * (size_t)i;
+    o[0] = r.px; o[1] = r.py; o[2] = r.pz; o[3] = r.dx; o[4] = r.dy; o[5] = r.dz;
+    o[6] = a ? __fdiv_rn(r.wn, r.wd) : 0.0f;
+    o[7] = a ? 1.0f : 0.0f;
+  }
+}
+
 __global__ void k_march_finish(const unsigned long long* __restrict__ accum, MarchArgs a,
                                double* __restrict__ ghost) {
   const size_t p = (size_t)a.y0 * a.W + (size_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -527,5 +580,17 @@ lf_status lfk_march(lf_ctx* ctx, int spp, uint64_t key) {
                        ctx->accum, a, ctx->ghost);
     LF_HIP(ctx, hipGetLastError());
   }
+  return LF_OK;
+}
+
+lf_status lfk_lens_rays(lf_ctx* ctx, int lambda, int n, const float* d_xy, const float* d_uv,
+                        float* d_out) {
+  const LfApertureDev& m = ctx->ap[LF_APERTURE_STARBURST];
+  ctx->lens.pitch = ctx->sensor_w_mm / (float)std::max(1, ctx->W);
+  LF_HIP(ctx, hipMemcpyAsync(ctx->lens_dev, &ctx->lens, sizeof(LfLensDev), hipMemcpyHostToDevice,
+                             ctx->stream));
+  hipLaunchKernelGGL(k_lens_rays, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream,
+                     ctx->lens_dev, m.texels, m.w, m.h, lambda, n, d_xy, d_uv, d_out);
+  LF_HIP(ctx, hipGetLastError());
   return LF_OK;
 }

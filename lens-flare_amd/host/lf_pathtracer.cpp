@@ -53,6 +53,44 @@ Ray Camera::generate_ray_for_thin_lens(double x, double y, double rndR, double r
   return r;
 }
 
+void LensCamera::generate_rays(size_t n, const double* xy_pupil, std::vector<Ray>* rays,
+                               std::vector<double>* weights, int lambda) const {
+  std::vector<float> xy(2 * n), uv(2 * n), out(8 * n);
+  for (size_t i = 0; i < n; i++) {
+    // the lens inverts the image: normalised (x, y) -> sensor millimetres
+    xy[2 * i] = (float)(-(xy_pupil[4 * i] - 0.5) * sw_);
+    xy[2 * i + 1] = (float)(-(xy_pupil[4 * i + 1] - 0.5) * sh_);
+    uv[2 * i] = (float)(2.0 * xy_pupil[4 * i + 2] - 1.0);
+    uv[2 * i + 1] = (float)(2.0 * xy_pupil[4 * i + 3] - 1.0);
+  }
+  lf_status st = lf_generate_lens_rays(pt_->context(), lambda, n, xy.data(), uv.data(), out.data());
+  if (st != LF_OK) throw std::runtime_error(std::string("lf_generate_lens_rays: ") + pt_->last_error());
+  rays->resize(n);
+  if (weights) weights->resize(n);
+  for (size_t i = 0; i < n; i++) {
+    const float* o = &out[8 * i];
+    Ray r;
+    Vector3D ol = mul(c2w, Vector3D(o[0], o[1], o[2]));
+    r.o = Vector3D(pos.x + ol.x, pos.y + ol.y, pos.z + ol.z);
+    r.d = mul(c2w, Vector3D(o[3], o[4], o[5]));
+    r.min_t = nClip; r.max_t = fClip;
+    r.depth = o[7] != 0.0f ? 1 : 0;
+    (*rays)[i] = r;
+    if (weights) (*weights)[i] = o[6];
+  }
+}
+
+bool LensCamera::generate_ray(double x, double y, double pu, double pv, Ray* out, double* weight,
+                              int lambda) const {
+  const double in[4] = {x, y, pu, pv};
+  std::vector<Ray> rays;
+  std::vector<double> w;
+  generate_rays(1, in, &rays, &w, lambda);
+  if (out) *out = rays[0];
+  if (weight) *weight = w[0];
+  return rays[0].depth != 0;
+}
+
 PathTracer::PathTracer(int device) {
   lf_status st = lf_create(&ctx_, device);
   if (st != LF_OK) throw std::runtime_error("lf_create failed: no MI355X device (there is no CPU fallback)");

@@ -143,4 +143,25 @@ class PathTracer {
   std::mutex mu_;
 };
 
+// LensCamera::generate_ray of the north star: a camera ray that really went through the lens
+// prescription handed to PathTracer::use_geometric_ghosts (the reference only has the pinhole
+// Camera::generate_ray and a stub generate_ray_for_thin_lens, camera_lens.cpp:22-30).
+// (x, y) normalised sensor coordinates as for Camera::generate_ray; (pu, pv) in [0,1)^2 samples the
+// rear pupil.  The ray is marched on the GPU (lf_generate_lens_rays); a vignetted / clipped sample
+// returns false.  The lens' front vertex sits at the camera position, looking down camera -z.
+class LensCamera : public Camera {
+ public:
+  explicit LensCamera(PathTracer* pt, float sensor_width_mm = 36.0f, float sensor_height_mm = 24.0f)
+      : pt_(pt), sw_(sensor_width_mm), sh_(sensor_height_mm) {}
+  bool generate_ray(double x, double y, double pu, double pv, Ray* out, double* weight = nullptr,
+                    int lambda = 1) const;
+  // batched form: n samples {x, y, pu, pv}; rays[i].depth = 1 if alive else 0
+  void generate_rays(size_t n, const double* xy_pupil, std::vector<Ray>* rays,
+                     std::vector<double>* weights, int lambda = 1) const;
+
+ private:
+  PathTracer* pt_;
+  float sw_, sh_;
+};
+
 }  // namespace lfamd

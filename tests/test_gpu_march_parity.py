@@ -160,6 +160,57 @@ def test_full_size_properties(pkg, lf):
     assert np.array_equal(a[rows[0]:rows[1]], og[rows[0]:rows[1]])
 
 
+def test_lens_camera_generate_ray(pkg, lf):
+    """lf_generate_lens_rays (= LensCamera::generate_ray, batched): the primary path sensor ->
+    scene.  (a) every alive ray equals the CPU oracle's march of the same start ray (the oracle is
+    given the double-precision pupil direction, so the comparison is to 2e-5, not bitwise);
+    (b) thin lens: a fan from the on-axis point at the paraxial focus leaves collimated;
+    (c) directions are unit vectors, weights in (0, 1)."""
+    rng = np.random.RandomState(3)
+    n = 4096
+    lens = pkg.load_lens_file("dgauss11.lens")
+    mask = load_texels("pentbig500_14.png")
+    lf.set_frame(64, 64)
+    lf.set_aperture(pkg.APERTURE_STARBURST, mask)
+    lf.set_lens(lens)
+    xy = (rng.rand(n, 2).astype(np.float32) - 0.5) * np.float32([36.0, 24.0])
+    uv = (rng.rand(n, 2).astype(np.float32) * 2 - 1)
+    out = lf.generate_lens_rays(1, xy, uv)
+    alive = out[:, 7] > 0
+    assert 0.1 < alive.mean() < 0.6                       # the pentagon stop clips most samples
+    d = out[alive, 3:6].astype(np.float64)
+    assert np.allclose(np.linalg.norm(d, axis=1), 1.0, atol=2e-6) and (d[:, 2] < 0).all()
+    assert ((out[alive, 6] > 0) & (out[alive, 6] < 1)).all()
+    zs = lfo.geo_z_sensor(lens)
+    h, zp = float(lens["semi_aperture"][-1]), zs - float(lens["thickness"][-1])
+    checked = 0
+    for i in np.flatnonzero(alive)[:200]:
+        a, b = float(uv[i, 0]), float(uv[i, 1])   # Shirley-Chiu concentric map in double
+        if abs(a) > abs(b):
+            r, phi = a, (np.pi / 4) * (b / a)
+        else:
+            r, phi = b, np.pi / 2 - (np.pi / 4) * (a / b)
+        q = np.array([h * r * np.cos(phi), h * r * np.sin(phi), zp])
+        p0 = np.array([float(xy[i, 0]), float(xy[i, 1]), zs])
+        dd = (q - p0) / np.linalg.norm(q - p0)
+        st, p, de, w, ne = lfo.geo_trace_ray(lens, 1, -1, -1, p0, dd, mask=mask)
+        if st != 0:
+            continue   # the oracle's double-precision start ray grazes an edge the float one clears
+        # oracle weight starts at 1; the device folds in the pupil geometry factor
+        geom = np.pi * h * h / (zs - zp) ** 2 * dd[2] ** 4
+        assert np.allclose(out[i, 0:3], p, atol=3e-4) and np.allclose(out[i, 3:6], de, atol=2e-5)
+        assert abs(out[i, 6] - w * geom) <= 2e-4 * w * geom
+        checked += 1
+    assert checked > 100
+    thin = pkg.load_lens_file("thinlens.lens")
+    lf.set_lens(thin)
+    lf.set_aperture(pkg.APERTURE_STARBURST, np.ones((8, 8), np.float32))
+    uv2 = (rng.rand(256, 2).astype(np.float32) * 2 - 1) * 0.05   # a narrow fan: paraxial
+    o2 = lf.generate_lens_rays(1, np.zeros((256, 2), np.float32), uv2)
+    assert (o2[:, 7] > 0).all()
+    assert np.abs(o2[:, 3:5]).max() < 2e-4                 # collimated along -z
+
+
 def test_4k_frame_properties(pkg, lf):
     """BASELINE.json configs[3] size (3840x2160; its dragon.dae is absent from the reference, so the
     synthetic sun stands in): counters conserved, and 8 interleave phases (the 8-GPU deal) add up to
