@@ -120,7 +120,7 @@ struct alignas(32) LfEventRow {
   float sgn;       // +1: the ray travels +z (towards the sensor), -1: -z
   int flags;       // bit 0: mirror reflection, bit 1: the stop, bit 2: flat (curv == 0)
   float radius;    // 1 / curv as given in the prescription (0 for flats)
-  int pad;
+  float eta2;      // eta * eta (float product)
 };
 enum { LF_EV_REFLECT = 1, LF_EV_STOP = 2, LF_EV_FLAT = 4 };
 

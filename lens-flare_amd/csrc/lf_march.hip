@@ -91,8 +91,8 @@ struct Ray {
 typedef unsigned long long lanemask;
 
 __device__ __forceinline__ lanemask surface_event(Ray& r, float zv, float c, float rad, float h2,
-                                                  float eta, bool reflect, bool flat, float sgn,
-                                                  lanemask& geom_ok) {
+                                                  float eta, float eta2, bool reflect, bool flat,
+                                                  float sgn, lanemask& geom_ok) {
   const float oz = r.pz - zv;
   const float od = fmaf(r.px, r.dx, fmaf(r.py, r.dy, oz * r.dz));
   const float oo = fmaf(r.px, r.px, fmaf(r.py, r.py, oz * oz));
@@ -112,35 +112,41 @@ __device__ __forceinline__ lanemask surface_event(Ray& r, float zv, float c, flo
   const float hx = fmaf(t, r.dx, r.px), hy = fmaf(t, r.dy, r.py), hz = fmaf(t, r.dz, oz);
   const float r2 = fmaf(hx, hx, hy * hy);
   geom_ok = __ballot(disc >= 0.0f) & __ballot(r2 <= h2);
-  const float nx = -c * hx, ny = -c * hy, nz = fmaf(-c, hz, 1.0f);
-  const float mu = fmaf(r.dx, nx, fmaf(r.dy, ny, r.dz * nz));
-  const float s2 = fmaf(-mu, mu, 1.0f);
-  const float k2 = fmaf(-(eta * eta), s2, 1.0f);
+  // The unit normal at the hit is n = (-c hx, -c hy, 1 - c hz); it is never formed.  With |d| = 1,
+  // mu = d.n = dz - c (h.d) = dz - c (o.d + t) = G - c t: one fma.
+  const float mu = fmaf(-c, t, G);
+  const float s2 = fmaf(-mu, mu, 1.0f);          // sin^2 of the incidence angle
+  const float k2 = fmaf(-eta2, s2, 1.0f);        // cos^2 of the refraction angle (eta2 = eta^2)
   const bool no_tir = k2 >= 0.0f;
   const float ct = lf_sqrt(fmaxf(k2, 0.0f));
-  // unpolarised Fresnel on half-scaled cosines (keeps the running denominator near 1):
-  //   R = Rn / D,  Rn = (af^2 + eb^2)/2,  D = (bf)^2
-  const float ch = 0.5f * fabsf(mu), th = 0.5f * ct;
+  // unpolarised Fresnel R = (rs^2 + rp^2)/2 with rp = rs (A - B)/(A + B), A = ci ct,
+  // B = si st = eta s2, rs = a/b, a = eta ci - ct, b = eta ci + ct:
+  //   R = Rn / D,   Rn = a^2 (A^2 + B^2),   D = (b (A + B))^2
+  // (a, b on half-scaled cosines so that the running denominator stays near 1)
+  const float ci = fabsf(mu);
+  const float ch = 0.5f * ci, th = 0.5f * ct;
   const float a = fmaf(eta, ch, -th), b = fmaf(eta, ch, th);
-  const float e = fmaf(-eta, th, ch), f = fmaf(eta, th, ch);
-  const float af = a * f, eb = e * b, bf = b * f;
-  const float Rn = 0.5f * fmaf(af, af, eb * eb), D = bf * bf;
+  const float A = ci * ct, B = eta * s2;
+  const float Rn = (a * a) * fmaf(A, A, B * B);
+  const float bAB = b * (A + B);
+  const float D = bAB * bAB;
   lanemask ok = geom_ok;
-  if (reflect) {  // wave-uniform
+  if (reflect) {  // wave-uniform: d' = d - 2 mu n
     r.wn *= no_tir ? Rn : 1.0f;  // total reflection: R = 1
     r.wd *= no_tir ? D : 1.0f;
-    const float m2 = -2.0f * mu;
-    r.dx = fmaf(m2, nx, r.dx);
-    r.dy = fmaf(m2, ny, r.dy);
-    r.dz = fmaf(m2, nz, r.dz);
-  } else {
+    const float m = 2.0f * (mu * c);
+    r.dx = fmaf(m, hx, r.dx);
+    r.dy = fmaf(m, hy, r.dy);
+    r.dz = fmaf(m, hz, fmaf(-2.0f, mu, r.dz));
+  } else {        // d' = eta d + g n,  g = sgn(mu) ct - eta mu
     ok &= __ballot(no_tir);
     r.wn *= D - Rn;
     r.wd *= D;
     const float g = fmaf(-eta, mu, copysignf(ct, mu));
-    r.dx = fmaf(eta, r.dx, g * nx);
-    r.dy = fmaf(eta, r.dy, g * ny);
-    r.dz = fmaf(eta, r.dz, g * nz);
+    const float gc = g * c;
+    r.dx = fmaf(eta, r.dx, -(gc * hx));
+    r.dy = fmaf(eta, r.dy, -(gc * hy));
+    r.dz = fmaf(eta, r.dz, fmaf(-gc, hz, g));
   }
   r.px = hx; r.py = hy; r.pz = zv + hz;
   return ok;
@@ -288,7 +294,7 @@ __global__ __launch_bounds__(256) void k_march(const LfLensDev* __restrict__ len
             } else {
               lanemask geom_ok;
               const lanemask ok = surface_event(r, cur.zv, cur.curv, cur.radius, cur.h2, cur.eta,
-                                                (cur.flags & LF_EV_REFLECT) != 0,
+                                                cur.eta2, (cur.flags & LF_EV_REFLECT) != 0,
                                                 (cur.flags & LF_EV_FLAT) != 0, cur.sgn, geom_ok);
               died_geom |= alive & ~geom_ok;
               alive &= ok;
@@ -398,7 +404,8 @@ __global__ __launch_bounds__(256) void k_lens_rays(const LfLensDev* __restrict__
     const LfSurfaceDev& sf = lens->surf[k];
     lanemask ok, geom_ok;
     if (sf.is_stop != 0.0f) ok = stop_event(r, sf.zv, sf.h2, inv_stop_h, mask, mw, mh);
-    else ok = surface_event(r, sf.zv, sf.curv, sf.radius, sf.h2, sf.eta_bwd[lambda], false,
+    else ok = surface_event(r, sf.zv, sf.curv, sf.radius, sf.h2, sf.eta_bwd[lambda],
+                            sf.eta_bwd[lambda] * sf.eta_bwd[lambda], false,
                             sf.curv == 0.0f, -1.0f, geom_ok);
     alive &= ok;
   }
@@ -496,7 +503,7 @@ static lf_status build_event_table(lf_ctx* ctx) {
         r.flags = (reflect ? LF_EV_REFLECT : 0) | (s.is_stop != 0.0f ? LF_EV_STOP : 0) |
                   (s.curv == 0.0f ? LF_EV_FLAT : 0);
         r.radius = s.radius;
-        r.pad = 0;
+        r.eta2 = r.eta * r.eta;
         out[n++] = r;
       };
       if (i < 0) {

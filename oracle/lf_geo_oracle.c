@@ -111,26 +111,34 @@ static int glass_event(geo_ray* r, float zv, float c, float rad, float h2, float
   float t = (c == 0.0f) ? F / fmaf(sgn, root, G) : fmaf(-sgn, root, G) * rad;
   float hx = fmaf(t, r->d[0], r->p[0]), hy = fmaf(t, r->d[1], r->p[1]), hz = fmaf(t, r->d[2], oz);
   if (!(fmaf(hx, hx, hy * hy) <= h2)) return VIGNETTED;
-  float n[3] = {-c * hx, -c * hy, fmaf(-c, hz, 1.0f)};
-  float mu = fmaf(r->d[0], n[0], fmaf(r->d[1], n[1], r->d[2] * n[2]));
-  float k2 = fmaf(-(eta * eta), fmaf(-mu, mu, 1.0f), 1.0f);
+  /* cosine of incidence against the unit normal n = (-c hx, -c hy, 1 - c hz), for |d| = 1:
+   * mu = d.n = G - c t.  The normal itself is never formed (DESIGN.md "march arithmetic"). */
+  float mu = fmaf(-c, t, G);
+  float s2 = fmaf(-mu, mu, 1.0f);
+  float k2 = fmaf(-(eta * eta), s2, 1.0f);
   if (k2 < 0.0f && !reflect) return TIR;
   float ct = k2 >= 0.0f ? sqrtf(k2) : 0.0f;
-  /* unpolarised Fresnel R = Rn / D on half-scaled cosines (DESIGN.md "march arithmetic") */
-  float ch = 0.5f * fabsf(mu), th = 0.5f * ct;
+  /* unpolarised Fresnel: R = Rn / D, Rn = a^2 (A^2 + B^2), D = (b (A + B))^2 with
+   * a, b = eta ci/2 -+ ct/2, A = ci ct, B = eta sin^2(theta_i) */
+  float ci = fabsf(mu);
+  float ch = 0.5f * ci, th = 0.5f * ct;
   float a = fmaf(eta, ch, -th), b = fmaf(eta, ch, th);
-  float e = fmaf(-eta, th, ch), f = fmaf(eta, th, ch);
-  float af = a * f, eb = e * b, bf = b * f;
-  float Rn = 0.5f * fmaf(af, af, eb * eb), D = bf * bf;
+  float A = ci * ct, B = eta * s2;
+  float Rn = (a * a) * fmaf(A, A, B * B);
+  float bAB = b * (A + B);
+  float D = bAB * bAB;
   if (!reflect) {
     r->wn *= D - Rn;
     r->wd *= D;
-    float g = fmaf(-eta, mu, copysignf(ct, mu));
-    for (int q = 0; q < 3; q++) r->d[q] = fmaf(eta, r->d[q], g * n[q]);
+    float g = fmaf(-eta, mu, copysignf(ct, mu)), gc = g * c;
+    float nd[3] = {fmaf(eta, r->d[0], -(gc * hx)), fmaf(eta, r->d[1], -(gc * hy)),
+                   fmaf(eta, r->d[2], fmaf(-gc, hz, g))};
+    memcpy(r->d, nd, sizeof(nd));
   } else {
     if (k2 >= 0.0f) { r->wn *= Rn; r->wd *= D; } /* else total reflection: R = 1 */
-    float m2 = -2.0f * mu;
-    for (int q = 0; q < 3; q++) r->d[q] = fmaf(m2, n[q], r->d[q]);
+    float m = 2.0f * (mu * c);
+    float nd[3] = {fmaf(m, hx, r->d[0]), fmaf(m, hy, r->d[1]), fmaf(m, hz, fmaf(-2.0f, mu, r->d[2]))};
+    memcpy(r->d, nd, sizeof(nd));
   }
   r->p[0] = hx; r->p[1] = hy; r->p[2] = zv + hz;
   return OK_;
