@@ -180,8 +180,8 @@ struct MarchArgs {
   uint2 key;
 };
 
-// (capping SGPRs at 80 for 8 waves/SIMD instead of 6-7 was measured: no gain, 32 SGPR spills)
-__global__ __launch_bounds__(256) void k_march(const LfLensDev* __restrict__ lens,
+__global__ __launch_bounds__(256) __attribute__((amdgpu_num_sgpr(80)))
+void k_march(const LfLensDev* __restrict__ lens,
                                                const LfPairsDev* __restrict__ pairs,
                                                const LfEventRow* __restrict__ ev_table,
                                                const float* __restrict__ mask, MarchArgs a,
