@@ -90,6 +90,13 @@ struct Ray {
 // sgn = +1 for a ray travelling +z, -1 for -z (wave-uniform, lives in an SGPR).
 typedef unsigned long long lanemask;
 
+// W = false is the geometry-only march (positions, directions, liveness); W = true additionally
+// carries the Fresnel / aperture weight.  The frame runs W = false for every ray and repeats the
+// sequence with W = true only for the waves in which some lane ended inside the sun's lobe (~1 % of
+// the wave-sequences): the weight is 15 of the 71 VALU instructions of an event and is read by
+// 0.02 % of the rays.  Both instantiations do the same arithmetic on the ray itself, so the
+// repeated march reproduces the first one bit for bit.
+template <bool W>
 __device__ __forceinline__ lanemask surface_event(Ray& r, float zv, float c, float rad, float h2,
                                                   float eta, float eta2, bool reflect, bool flat,
                                                   float sgn, lanemask& geom_ok) {
@@ -111,37 +118,49 @@ __device__ __forceinline__ lanemask surface_event(Ray& r, float zv, float c, flo
   else t = fmaf(-sgn, sq, G) * rad;
   const float hx = fmaf(t, r.dx, r.px), hy = fmaf(t, r.dy, r.py), hz = fmaf(t, r.dz, oz);
   const float r2 = fmaf(hx, hx, hy * hy);
-  geom_ok = __ballot(disc >= 0.0f) & __ballot(r2 <= h2);
+  // a ray that misses the sphere (disc < 0) has sq = t = r2 = NaN, and NaN <= h2 is false
+  geom_ok = __ballot(r2 <= h2);
   // The unit normal at the hit is n = (-c hx, -c hy, 1 - c hz); it is never formed.  With |d| = 1,
   // mu = d.n = dz - c (h.d) = dz - c (o.d + t) = G - c t: one fma.
   const float mu = fmaf(-c, t, G);
-  const float s2 = fmaf(-mu, mu, 1.0f);          // sin^2 of the incidence angle
-  const float k2 = fmaf(-eta2, s2, 1.0f);        // cos^2 of the refraction angle (eta2 = eta^2)
-  const bool no_tir = k2 >= 0.0f;
-  const float ct = lf_sqrt(fmaxf(k2, 0.0f));
-  // unpolarised Fresnel R = (rs^2 + rp^2)/2 with rp = rs (A - B)/(A + B), A = ci ct,
-  // B = si st = eta s2, rs = a/b, a = eta ci - ct, b = eta ci + ct:
-  //   R = Rn / D,   Rn = a^2 (A^2 + B^2),   D = (b (A + B))^2
-  // (a, b on half-scaled cosines so that the running denominator stays near 1)
-  const float ci = fabsf(mu);
-  const float ch = 0.5f * ci, th = 0.5f * ct;
-  const float a = fmaf(eta, ch, -th), b = fmaf(eta, ch, th);
-  const float A = ci * ct, B = eta * s2;
-  const float Rn = (a * a) * fmaf(A, A, B * B);
-  const float bAB = b * (A + B);
-  const float D = bAB * bAB;
   lanemask ok = geom_ok;
+  float Rn = 0.0f, D = 1.0f, ct = 0.0f;
+  bool no_tir = true;
+  if (W || !reflect) {
+    const float s2 = fmaf(-mu, mu, 1.0f);          // sin^2 of the incidence angle
+    const float k2 = fmaf(-eta2, s2, 1.0f);        // cos^2 of the refraction angle (eta2 = eta^2)
+    no_tir = k2 >= 0.0f;
+    // (a totally reflected ray only survives a mirror event, and only W = true reads ct there)
+    ct = lf_sqrt(reflect ? fmaxf(k2, 0.0f) : k2);
+    if (W) {
+      // unpolarised Fresnel R = (rs^2 + rp^2)/2 with rp = rs (A - B)/(A + B), A = ci ct,
+      // B = si st = eta s2, rs = a/b, a = eta ci - ct, b = eta ci + ct:
+      //   R = Rn / D,   Rn = a^2 (A^2 + B^2),   D = (b (A + B))^2
+      // (a, b on half-scaled cosines so that the running denominator stays near 1)
+      const float ci = fabsf(mu);
+      const float ch = 0.5f * ci, th = 0.5f * ct;
+      const float a = fmaf(eta, ch, -th), b = fmaf(eta, ch, th);
+      const float A = ci * ct, B = eta * s2;
+      Rn = (a * a) * fmaf(A, A, B * B);
+      const float bAB = b * (A + B);
+      D = bAB * bAB;
+    }
+  }
   if (reflect) {  // wave-uniform: d' = d - 2 mu n
-    r.wn *= no_tir ? Rn : 1.0f;  // total reflection: R = 1
-    r.wd *= no_tir ? D : 1.0f;
+    if (W) {
+      r.wn *= no_tir ? Rn : 1.0f;  // total reflection: R = 1
+      r.wd *= no_tir ? D : 1.0f;
+    }
     const float m = 2.0f * (mu * c);
     r.dx = fmaf(m, hx, r.dx);
     r.dy = fmaf(m, hy, r.dy);
     r.dz = fmaf(m, hz, fmaf(-2.0f, mu, r.dz));
   } else {        // d' = eta d + g n,  g = sgn(mu) ct - eta mu
     ok &= __ballot(no_tir);
-    r.wn *= D - Rn;
-    r.wd *= D;
+    if (W) {
+      r.wn *= D - Rn;
+      r.wd *= D;
+    }
     const float g = fmaf(-eta, mu, copysignf(ct, mu));
     const float gc = g * c;
     r.dx = fmaf(eta, r.dx, -(gc * hx));
@@ -153,6 +172,7 @@ __device__ __forceinline__ lanemask surface_event(Ray& r, float zv, float c, flo
 }
 
 // the stop: flat pass-through, clipped by its housing and by the aperture mask
+template <bool W>
 __device__ __forceinline__ lanemask stop_event(Ray& r, float zv, float h2, float inv_h,
                                                const float* __restrict__ mask, int mw, int mh) {
   const float t = __fdiv_rn(zv - r.pz, r.dz);
@@ -164,9 +184,21 @@ __device__ __forceinline__ lanemask stop_event(Ray& r, float zv, float h2, float
   ix = min(max(ix, 0), mw - 1);
   iy = min(max(iy, 0), mh - 1);
   const float a = mask[iy * mw + ix];
-  r.wn *= a;
+  if (W) r.wn *= a;
   r.px = hx; r.py = hy; r.pz = zv;
   return __ballot(r2 <= h2) & __ballot(a > 0.0f);
+}
+
+// One event row as ONE 32-byte scalar load (left to itself the compiler sinks the eight field loads
+// into the branches that use them: 4-5 dependent scalar-cache round trips per event).
+typedef int lf_i8 __attribute__((ext_vector_type(8)));
+__device__ __forceinline__ LfEventRow load_row(const LfEventRow* __restrict__ e) {
+  const lf_i8 v = *reinterpret_cast<const lf_i8*>(e);
+  LfEventRow r;
+  r.zv = __int_as_float(v[0]); r.curv = __int_as_float(v[1]); r.h2 = __int_as_float(v[2]);
+  r.eta = __int_as_float(v[3]); r.sgn = __int_as_float(v[4]); r.flags = v[5];
+  r.radius = __int_as_float(v[6]); r.eta2 = __int_as_float(v[7]);
+  return r;
 }
 
 struct MarchArgs {
@@ -215,8 +247,9 @@ void k_march(const LfLensDev* __restrict__ lens,
   const int GG = a.G * a.G;
   const lanemask active_mask = __ballot(active);
 
-  unsigned n_clip = 0, n_vign = 0, n_tir = 0, n_scene = 0, n_light = 0, n_launched = 0;
-  unsigned long long events = 0;  // wave-uniform: counted once per wave with s_bcnt1 (SALU)
+  unsigned n_light = 0, n_launched = 0;  // per lane
+  // wave-uniform, counted once per wave with s_bcnt1 (SALU)
+  unsigned long long events = 0, n_clip = 0, n_vign = 0, n_tir = 0, n_scene = 0;
   unsigned long long acc[3] = {0ull, 0ull, 0ull};
 
   {
@@ -279,50 +312,68 @@ void k_march(const LfLensDev* __restrict__ lens,
           // row is requested before the current event computes
           const LfEventRow* __restrict__ ev = ev_l + pairs->ev_off[q];  // wave-uniform (SGPR)
           const int n_ev = pairs->ev_cnt[q];
-          Ray r{X, Y, z_sensor, d0x, d0y, d0z, w0, 1.0f};
+          Ray r{X, Y, z_sensor, d0x, d0y, d0z, 0.0f, 0.0f};
           lanemask alive = active_mask;
           // how the rays died (read once, after the sequence): at the stop / geometrically / TIR
           lanemask died_at_stop = 0ull, died_geom = 0ull;
-          for (int left = n_ev; left > 0; --left, ++ev) {
-            // (no software prefetch: 7 waves per SIMD hide the scalar-cache latency, and carrying a
+          const LfEventRow* __restrict__ e = ev;
+          for (int left = n_ev; left > 0; --left, ++e) {
+            // (no software prefetch: 8 waves per SIMD hide the scalar-cache latency, and carrying a
             // `next` row costs 8 SGPR copies per event on the shared scalar unit)
-            const LfEventRow cur = *ev;
+            const LfEventRow cur = load_row(e);
             if (cur.flags & LF_EV_STOP) {
-              const lanemask ok = stop_event(r, cur.zv, cur.h2, inv_stop_h, mask, a.mw, a.mh);
+              const lanemask ok = stop_event<false>(r, cur.zv, cur.h2, inv_stop_h, mask, a.mw, a.mh);
               died_at_stop |= alive & ~ok;
               alive &= ok;
             } else {
               lanemask geom_ok;
-              const lanemask ok = surface_event(r, cur.zv, cur.curv, cur.radius, cur.h2, cur.eta,
-                                                cur.eta2, (cur.flags & LF_EV_REFLECT) != 0,
-                                                (cur.flags & LF_EV_FLAT) != 0, cur.sgn, geom_ok);
+              const lanemask ok = surface_event<false>(r, cur.zv, cur.curv, cur.radius, cur.h2,
+                                                       cur.eta, cur.eta2,
+                                                       (cur.flags & LF_EV_REFLECT) != 0,
+                                                       (cur.flags & LF_EV_FLAT) != 0, cur.sgn, geom_ok);
               died_geom |= alive & ~geom_ok;
               alive &= ok;
             }
             if (alive == 0ull) break;         // the whole wave is dead: leave the sequence
             events += __popcll(alive);        // s_bcnt1
           }
-          const bool lane_alive = (alive >> lane) & 1ull;
-          if (lane_alive) {
-            n_scene++;
-            const float cg = fmaf(r.dx, sx, fmaf(r.dy, sy, r.dz * sz));
-            const float qq = (1.0f - cg) * inv_1mc;
-            if (qq < 1.0f) {
-              const float om = 1.0f - qq;
-              const float contrib = __fdiv_rn(r.wn, r.wd) * (om * om);
-              if (contrib > 0.0f) {
-                n_light++;
+          // fates, counted on the scalar unit
+          const lanemask dead = active_mask & ~alive;
+          n_scene += __popcll(alive);
+          n_clip += __popcll(dead & died_at_stop);
+          n_vign += __popcll(dead & ~died_at_stop & died_geom);
+          n_tir += __popcll(dead & ~died_at_stop & ~died_geom);
+          if (alive == 0ull) continue;
+          // inside the sun's lobe?
+          const float cg = fmaf(r.dx, sx, fmaf(r.dy, sy, r.dz * sz));
+          const float qq = (1.0f - cg) * inv_1mc;
+          const lanemask lit = alive & __ballot(qq < 1.0f);
+          if (lit == 0ull) continue;
+          // rare (about 1 % of the wave-sequences): march the sequence again, now with the weight
+          Ray rw{X, Y, z_sensor, d0x, d0y, d0z, w0, 1.0f};
+          e = ev;
+          for (int left = n_ev; left > 0; --left, ++e) {
+            const LfEventRow cur = load_row(e);
+            if (cur.flags & LF_EV_STOP) {
+              (void)stop_event<true>(rw, cur.zv, cur.h2, inv_stop_h, mask, a.mw, a.mh);
+            } else {
+              lanemask geom_ok;
+              (void)surface_event<true>(rw, cur.zv, cur.curv, cur.radius, cur.h2, cur.eta, cur.eta2,
+                                        (cur.flags & LF_EV_REFLECT) != 0,
+                                        (cur.flags & LF_EV_FLAT) != 0, cur.sgn, geom_ok);
+            }
+          }
+          if ((lit >> lane) & 1ull) {
+            const float om = 1.0f - qq;
+            const float contrib = __fdiv_rn(rw.wn, rw.wd) * (om * om);
+            if (contrib > 0.0f) {
+              n_light++;
 #pragma unroll
-                for (int c = 0; c < 3; c++) {
-                  const float v = contrib * (lens->sun_radiance[c] * lens->lambda_rgb[l][c]);
-                  acc[c] += (unsigned long long)(v * kFixScale);
-                }
+              for (int c = 0; c < 3; c++) {
+                const float v = contrib * (lens->sun_radiance[c] * lens->lambda_rgb[l][c]);
+                acc[c] += (unsigned long long)(v * kFixScale);
               }
             }
-          } else if (active) {
-            if ((died_at_stop >> lane) & 1ull) n_clip++;
-            else if ((died_geom >> lane) & 1ull) n_vign++;
-            else n_tir++;
           }
         }
       }
@@ -335,13 +386,15 @@ void k_march(const LfLensDev* __restrict__ lens,
   }
 
   // ---- counters: wave reduce, one LDS add per wave, one global add per workgroup ------------
-  unsigned vals[7] = {n_launched, 0u, n_clip, n_vign, n_tir, n_scene, n_light};
+  {
+    unsigned long long v0 = n_launched, v6 = n_light;
+    for (int off = 32; off > 0; off >>= 1) { v0 += __shfl_down(v0, off); v6 += __shfl_down(v6, off); }
+    const unsigned long long vals[7] = {v0, events, n_clip, n_vign, n_tir, n_scene, v6};
+    if (lane == 0) {
 #pragma unroll
-  for (int i = 0; i < 7; i++) {
-    unsigned long long v = vals[i];
-    for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off);
-    if (i == 1) v = events;  // already a per-wave total
-    if (lane == 0 && v) atomicAdd(&s_cnt[i], v);
+      for (int i = 0; i < 7; i++)
+        if (vals[i]) atomicAdd(&s_cnt[i], vals[i]);
+    }
   }
   __syncthreads();
   if (tid < 7 && s_cnt[tid]) atomicAdd(&counters[tid], s_cnt[tid]);
@@ -403,8 +456,8 @@ __global__ __launch_bounds__(256) void k_lens_rays(const LfLensDev* __restrict__
   for (int k = lens->n_surf - 1; k >= 0; k--) {  // wave-uniform
     const LfSurfaceDev& sf = lens->surf[k];
     lanemask ok, geom_ok;
-    if (sf.is_stop != 0.0f) ok = stop_event(r, sf.zv, sf.h2, inv_stop_h, mask, mw, mh);
-    else ok = surface_event(r, sf.zv, sf.curv, sf.radius, sf.h2, sf.eta_bwd[lambda],
+    if (sf.is_stop != 0.0f) ok = stop_event<true>(r, sf.zv, sf.h2, inv_stop_h, mask, mw, mh);
+    else ok = surface_event<true>(r, sf.zv, sf.curv, sf.radius, sf.h2, sf.eta_bwd[lambda],
                             sf.eta_bwd[lambda] * sf.eta_bwd[lambda], false,
                             sf.curv == 0.0f, -1.0f, geom_ok);
     alive &= ok;
