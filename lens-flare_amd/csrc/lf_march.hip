@@ -212,7 +212,7 @@ struct MarchArgs {
   uint2 key;
 };
 
-__global__ __launch_bounds__(256) __attribute__((amdgpu_num_sgpr(80)))
+__global__ __launch_bounds__(256) __attribute__((amdgpu_num_sgpr(100)))
 void k_march(const LfLensDev* __restrict__ lens,
                                                const LfPairsDev* __restrict__ pairs,
                                                const LfEventRow* __restrict__ ev_table,
@@ -303,6 +303,8 @@ void k_march(const LfLensDev* __restrict__ lens,
       const float c2 = d0z * d0z;
       const float w0 = geom_norm * (c2 * c2);
       if (active) n_launched += (unsigned)(n_lambda * n_pairs);
+      // wave-uniform 32-bit tallies of this sample (64 lanes x pairs x wavelengths x rows < 2^32)
+      unsigned ev32 = 0, clip32 = 0, vign32 = 0, tir32 = 0, scene32 = 0;
 
       for (int l = 0; l < n_lambda; l++) {
         const LfEventRow* __restrict__ ev_l = ev_table + (size_t)l * (size_t)total_events;
@@ -316,33 +318,51 @@ void k_march(const LfLensDev* __restrict__ lens,
           lanemask alive = active_mask;
           // how the rays died (read once, after the sequence): at the stop / geometrically / TIR
           lanemask died_at_stop = 0ull, died_geom = 0ull;
+          // The sequence is walked as runs of plain events (refraction at a curved interface: a
+          // straight-line body, no wave-uniform branching) separated by the few special ones (the
+          // stop, the two mirror events, flat glass); bits 8.. of a row's flags give the length of
+          // the plain run that starts there.
           const LfEventRow* __restrict__ e = ev;
-          for (int left = n_ev; left > 0; --left, ++e) {
-            // (no software prefetch: 8 waves per SIMD hide the scalar-cache latency, and carrying a
-            // `next` row costs 8 SGPR copies per event on the shared scalar unit)
+          const LfEventRow* const e_end = ev + n_ev;
+          do {
             const LfEventRow cur = load_row(e);
-            if (cur.flags & LF_EV_STOP) {
-              const lanemask ok = stop_event<false>(r, cur.zv, cur.h2, inv_stop_h, mask, a.mw, a.mh);
-              died_at_stop |= alive & ~ok;
-              alive &= ok;
+            const int run = cur.flags >> 8;
+            if (run) {
+              const LfEventRow* const run_end = e + run;
+              do {
+                const LfEventRow pl = load_row(e);
+                lanemask geom_ok;
+                const lanemask ok = surface_event<false>(r, pl.zv, pl.curv, pl.radius, pl.h2, pl.eta,
+                                                         pl.eta2, false, false, pl.sgn, geom_ok);
+                died_geom |= alive & ~geom_ok;
+                alive &= ok;
+                ev32 += __popcll(alive);      // s_bcnt1 (a dead wave adds 0)
+                ++e;
+              } while (e != run_end && alive != 0ull);
             } else {
-              lanemask geom_ok;
-              const lanemask ok = surface_event<false>(r, cur.zv, cur.curv, cur.radius, cur.h2,
-                                                       cur.eta, cur.eta2,
-                                                       (cur.flags & LF_EV_REFLECT) != 0,
-                                                       (cur.flags & LF_EV_FLAT) != 0, cur.sgn, geom_ok);
-              died_geom |= alive & ~geom_ok;
-              alive &= ok;
+              if (cur.flags & LF_EV_STOP) {
+                const lanemask ok = stop_event<false>(r, cur.zv, cur.h2, inv_stop_h, mask, a.mw, a.mh);
+                died_at_stop |= alive & ~ok;
+                alive &= ok;
+              } else {
+                lanemask geom_ok;
+                const lanemask ok = surface_event<false>(r, cur.zv, cur.curv, cur.radius, cur.h2,
+                                                         cur.eta, cur.eta2,
+                                                         (cur.flags & LF_EV_REFLECT) != 0,
+                                                         (cur.flags & LF_EV_FLAT) != 0, cur.sgn, geom_ok);
+                died_geom |= alive & ~geom_ok;
+                alive &= ok;
+              }
+              ev32 += __popcll(alive);
+              ++e;
             }
-            if (alive == 0ull) break;         // the whole wave is dead: leave the sequence
-            events += __popcll(alive);        // s_bcnt1
-          }
+          } while (e != e_end && alive != 0ull);  // a wave that is dead as a whole leaves early
           // fates, counted on the scalar unit
           const lanemask dead = active_mask & ~alive;
-          n_scene += __popcll(alive);
-          n_clip += __popcll(dead & died_at_stop);
-          n_vign += __popcll(dead & ~died_at_stop & died_geom);
-          n_tir += __popcll(dead & ~died_at_stop & ~died_geom);
+          scene32 += __popcll(alive);
+          clip32 += __popcll(dead & died_at_stop);
+          vign32 += __popcll(dead & ~died_at_stop & died_geom);
+          tir32 += __popcll(dead & ~died_at_stop & ~died_geom);
           if (alive == 0ull) continue;
           // inside the sun's lobe?
           const float cg = fmaf(r.dx, sx, fmaf(r.dy, sy, r.dz * sz));
@@ -377,6 +397,7 @@ void k_march(const LfLensDev* __restrict__ lens,
           }
         }
       }
+      events += ev32; n_clip += clip32; n_vign += vign32; n_tir += tir32; n_scene += scene32;
     }
     if (active) {
 #pragma unroll
@@ -569,6 +590,11 @@ static lf_status build_event_table(lf_ctx* ctx) {
         for (int k = j - 1; k >= 0; k--) put(k, false, false);
       }
       if (n != P.ev_cnt[q]) return lf_fail(ctx, LF_ERR_STATE, "event table: sequence length mismatch");
+      // bits 8.. : length of the run of plain rows (no flag set) that starts at this row
+      for (int k = n - 1, run = 0; k >= 0; k--) {
+        run = out[k].flags == 0 ? run + 1 : 0;
+        out[k].flags |= run << 8;
+      }
     }
   if (rows.size() > ctx->events_cap) {
     if (ctx->events_dev) { LF_HIP(ctx, hipStreamSynchronize(ctx->stream)); (void)hipFree(ctx->events_dev); }
