@@ -173,6 +173,7 @@ lf_status lf_destroy(lf_ctx* ctx) {
   }
   void* ptrs[] = {ctx->spectrum, ctx->twiddle, ctx->dft_rows, ctx->flares, ctx->ghosts, ctx->pl_dev,
                   ctx->lens_dev, ctx->pairs_dev, ctx->counters_dev, ctx->accum, ctx->events_dev,
+                  ctx->skip_dev,
                   ctx->scene_dev.nodes, ctx->scene_dev.prims, ctx->scene_dev.materials,
                   ctx->scene_dev.lights};
   for (void* p : ptrs) if (p) (void)hipFree(p);

@@ -110,6 +110,8 @@ struct LfPairsDev {
   int ij[LF_MAX_PAIRS + 1][2];   // (-1,-1) = primary path
   int ev_off[LF_MAX_PAIRS + 1];  // first row of pair q in the event table
   int ev_cnt[LF_MAX_PAIRS + 1];  // N + 2(j - i) rows
+  int prog_off;                  // first row of the shared-prefix program (wavelength 0)
+  int prog_rows;                 // rows of the program per wavelength
 };
 
 // One pre-expanded surface event of one (wavelength, pair) sequence: everything the march needs for
@@ -123,6 +125,18 @@ struct alignas(32) LfEventRow {
   float eta2;      // eta * eta (float product)
 };
 enum { LF_EV_REFLECT = 1, LF_EV_STOP = 2, LF_EV_FLAT = 4 };
+// The march does not walk the per-pair sequences one by one: every path of a (sample, wavelength)
+// starts with the same backward leg from the sensor, and all pairs (i, .) share the forward leg that
+// follows the reflection at i.  The per-wavelength *program* is that tree in depth-first order:
+// event rows as above plus, in the flags,
+//   SAVE0 / SAVE1  before the event, park the ray state in slot 0 (a prefix fork: the row is the
+//                  reflection at i) / slot 1 (a forward-leg fork: the row is the reflection at j)
+//   END            after the event the path is complete (lobe test, tallies); bits 24.. = its index
+//                  in LfPairsDev; then REST1 / REST0 take the parked state back (neither: the end)
+//   bits 8..15     length of the run of plain rows starting here (0 for any flagged row)
+//   bits 16..23    multiplicity: how many logical paths share this row (events and fates are
+//                  tallied per logical path, exactly as if each had been marched on its own)
+enum { LF_EV_REST1 = 8, LF_EV_SAVE0 = 0x10, LF_EV_SAVE1 = 0x20, LF_EV_END = 0x40, LF_EV_REST0 = 0x80 };
 
 // ---- timing ---------------------------------------------------------------------------------
 enum LfKernelId { LFK_MARCH = 0, LFK_FLARE_LAYER, LFK_GHOST_RASTER, LFK_DFT, LFK_FRAME_SETUP,
@@ -189,8 +203,10 @@ struct lf_ctx {
   LfPairsDev* pairs_dev = nullptr;
   unsigned long long* counters_dev = nullptr;  // 8 x u64
   unsigned long long* accum = nullptr;         // unused for now
-  LfEventRow* events_dev = nullptr;            // n_lambda x total_events
+  LfEventRow* events_dev = nullptr;            // n_lambda x total_events, then n_lambda x prog_rows
   size_t events_cap = 0;
+  int* skip_dev = nullptr;                     // prog_rows entries: where a dead wave jumps to
+  size_t skip_cap = 0;
   bool events_dirty = true;
 
   bool timing = false;

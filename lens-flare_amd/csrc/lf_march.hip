@@ -29,7 +29,9 @@
 // Contributions are accumulated as 2^-36 fixed point in 64-bit integers, so the result does not
 // depend on the order in which lanes finish.  The CPU oracle (oracle/lf_geo_oracle.c) follows the
 // same contract, which makes pixels and event counters comparable bit for bit.
+#include <algorithm>
 #include <cstring>
+#include <utility>
 
 #include "lf_internal.h"
 
@@ -201,6 +203,17 @@ __device__ __forceinline__ LfEventRow load_row(const LfEventRow* __restrict__ e)
   return r;
 }
 
+// parked ray state (a fork of the path tree) in LDS: the two slots would cost 12 VGPRs and the 8th
+// wave of every SIMD
+__device__ __forceinline__ void park(float* __restrict__ slot, int lane, const Ray& r) {
+  slot[lane] = r.px; slot[64 + lane] = r.py; slot[128 + lane] = r.pz;
+  slot[192 + lane] = r.dx; slot[256 + lane] = r.dy; slot[320 + lane] = r.dz;
+}
+__device__ __forceinline__ void unpark(const float* __restrict__ slot, int lane, Ray& r) {
+  r.px = slot[lane]; r.py = slot[64 + lane]; r.pz = slot[128 + lane];
+  r.dx = slot[192 + lane]; r.dy = slot[256 + lane]; r.dz = slot[320 + lane];
+}
+
 struct MarchArgs {
   int mw, mh, W, H, y0, y1;
   int spp, G;          // G x G pupil strata, G = floor(sqrt(spp))
@@ -216,6 +229,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_num_sgpr(100)))
 void k_march(const LfLensDev* __restrict__ lens,
                                                const LfPairsDev* __restrict__ pairs,
                                                const LfEventRow* __restrict__ ev_table,
+                                               const int* __restrict__ skip_tab,
                                                const float* __restrict__ mask, MarchArgs a,
                                                double* __restrict__ ghost,
                                                unsigned long long* __restrict__ accum,
@@ -223,6 +237,7 @@ void k_march(const LfLensDev* __restrict__ lens,
   __shared__ unsigned long long s_acc[64 * 3];
   __shared__ unsigned long long s_cnt[8];
   __shared__ int s_next;
+  __shared__ float s_state[4][2][6 * 64];  // parked ray states: [wave][slot][component][lane]
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   if (tid < 64 * 3) s_acc[tid] = 0ull;
   if (tid < 8) s_cnt[tid] = 0ull;
@@ -239,6 +254,7 @@ void k_march(const LfLensDev* __restrict__ lens,
   const unsigned tile_id = (unsigned)((a.trow0 + tj * a.tperiod) * tiles_x + tx);  // frame-absolute
 
   const int n_lambda = lens->n_lambda, n_pairs = pairs->n, total_events = pairs->total_events;
+  const int prog_rows = pairs->prog_rows;
   const float z_sensor = lens->z_sensor, pitch = lens->pitch, pupil_h = lens->pupil_h;
   const float pupil_z = lens->pupil_z, geom_norm = lens->geom_norm;
   const float inv_stop_h = __fdiv_rn(1.0f, lens->stop_h);
@@ -307,93 +323,102 @@ void k_march(const LfLensDev* __restrict__ lens,
       unsigned ev32 = 0, clip32 = 0, vign32 = 0, tir32 = 0, scene32 = 0;
 
       for (int l = 0; l < n_lambda; l++) {
-        const LfEventRow* __restrict__ ev_l = ev_table + (size_t)l * (size_t)total_events;
-        for (int q = 0; q < n_pairs; q++) {
-          // the pair's pre-expanded interface sequence (backwards N-1..i, reflect at i, forwards
-          // i+1..j, reflect at j, backwards j-1..0): one 32-byte scalar load per event, the next
-          // row is requested before the current event computes
-          const LfEventRow* __restrict__ ev = ev_l + pairs->ev_off[q];  // wave-uniform (SGPR)
-          const int n_ev = pairs->ev_cnt[q];
-          Ray r{X, Y, z_sensor, d0x, d0y, d0z, 0.0f, 0.0f};
-          lanemask alive = active_mask;
-          // how the rays died (read once, after the sequence): at the stop / geometrically / TIR
-          lanemask died_at_stop = 0ull, died_geom = 0ull;
-          // The sequence is walked as runs of plain events (refraction at a curved interface: a
-          // straight-line body, no wave-uniform branching) separated by the few special ones (the
-          // stop, the two mirror events, flat glass); bits 8.. of a row's flags give the length of
-          // the plain run that starts there.
-          const LfEventRow* __restrict__ e = ev;
-          const LfEventRow* const e_end = ev + n_ev;
-          do {
-            const LfEventRow cur = load_row(e);
-            const int run = cur.flags >> 8;
-            if (run) {
-              const LfEventRow* const run_end = e + run;
-              do {
-                const LfEventRow pl = load_row(e);
-                lanemask geom_ok;
-                const lanemask ok = surface_event<false>(r, pl.zv, pl.curv, pl.radius, pl.h2, pl.eta,
-                                                         pl.eta2, false, false, pl.sgn, geom_ok);
-                died_geom |= alive & ~geom_ok;
-                alive &= ok;
-                ev32 += __popcll(alive);      // s_bcnt1 (a dead wave adds 0)
-                ++e;
-              } while (e != run_end && alive != 0ull);
-            } else {
-              if (cur.flags & LF_EV_STOP) {
-                const lanemask ok = stop_event<false>(r, cur.zv, cur.h2, inv_stop_h, mask, a.mw, a.mh);
-                died_at_stop |= alive & ~ok;
-                alive &= ok;
-              } else {
-                lanemask geom_ok;
-                const lanemask ok = surface_event<false>(r, cur.zv, cur.curv, cur.radius, cur.h2,
-                                                         cur.eta, cur.eta2,
-                                                         (cur.flags & LF_EV_REFLECT) != 0,
-                                                         (cur.flags & LF_EV_FLAT) != 0, cur.sgn, geom_ok);
-                died_geom |= alive & ~geom_ok;
+        // ---- walk the wavelength's program (the tree of all paths, depth first) ----------------
+        const LfEventRow* const prog = ev_table + pairs->prog_off + (size_t)l * (size_t)prog_rows;
+        const LfEventRow* const prog_end = prog + prog_rows;
+        const LfEventRow* __restrict__ e = prog;
+        Ray r{X, Y, z_sensor, d0x, d0y, d0z, 0.0f, 0.0f};
+        lanemask alive = active_mask, alive0 = 0ull, alive1 = 0ull;
+        while (e != prog_end) {
+          const LfEventRow cur = load_row(e);
+          const unsigned fl = (unsigned)cur.flags;
+          const unsigned run = (fl >> 8) & 0xffu, mult = (fl >> 16) & 0xffu;
+          if (run) {
+            // plain events (refraction at a curved interface): straight-line body
+            const LfEventRow* const run_end = e + run;
+            do {
+              const LfEventRow pl = load_row(e);
+              lanemask geom_ok;
+              const lanemask ok = surface_event<false>(r, pl.zv, pl.curv, pl.radius, pl.h2, pl.eta,
+                                                       pl.eta2, false, false, pl.sgn, geom_ok);
+              if ((alive & ~ok) != 0ull) {  // some ray ends here, in `mult` logical paths
+                vign32 += mult * (unsigned)__popcll(alive & ~geom_ok);
+                tir32 += mult * (unsigned)__popcll(alive & geom_ok & ~ok);
                 alive &= ok;
               }
-              ev32 += __popcll(alive);
+              ev32 += mult * (unsigned)__popcll(alive);
               ++e;
-            }
-          } while (e != e_end && alive != 0ull);  // a wave that is dead as a whole leaves early
-          // fates, counted on the scalar unit
-          const lanemask dead = active_mask & ~alive;
-          scene32 += __popcll(alive);
-          clip32 += __popcll(dead & died_at_stop);
-          vign32 += __popcll(dead & ~died_at_stop & died_geom);
-          tir32 += __popcll(dead & ~died_at_stop & ~died_geom);
-          if (alive == 0ull) continue;
-          // inside the sun's lobe?
-          const float cg = fmaf(r.dx, sx, fmaf(r.dy, sy, r.dz * sz));
-          const float qq = (1.0f - cg) * inv_1mc;
-          const lanemask lit = alive & __ballot(qq < 1.0f);
-          if (lit == 0ull) continue;
-          // rare (about 1 % of the wave-sequences): march the sequence again, now with the weight
-          Ray rw{X, Y, z_sensor, d0x, d0y, d0z, w0, 1.0f};
-          e = ev;
-          for (int left = n_ev; left > 0; --left, ++e) {
-            const LfEventRow cur = load_row(e);
-            if (cur.flags & LF_EV_STOP) {
-              (void)stop_event<true>(rw, cur.zv, cur.h2, inv_stop_h, mask, a.mw, a.mh);
+            } while (e != run_end && alive != 0ull);
+          } else {
+            if (fl & LF_EV_SAVE0) { park(s_state[wave][0], lane, r); alive0 = alive; }
+            if (fl & LF_EV_SAVE1) { park(s_state[wave][1], lane, r); alive1 = alive; }
+            if (fl & LF_EV_STOP) {
+              const lanemask ok = stop_event<false>(r, cur.zv, cur.h2, inv_stop_h, mask, a.mw, a.mh);
+              clip32 += mult * (unsigned)__popcll(alive & ~ok);
+              alive &= ok;
             } else {
               lanemask geom_ok;
-              (void)surface_event<true>(rw, cur.zv, cur.curv, cur.radius, cur.h2, cur.eta, cur.eta2,
-                                        (cur.flags & LF_EV_REFLECT) != 0,
-                                        (cur.flags & LF_EV_FLAT) != 0, cur.sgn, geom_ok);
+              const lanemask ok = surface_event<false>(r, cur.zv, cur.curv, cur.radius, cur.h2,
+                                                       cur.eta, cur.eta2, (fl & LF_EV_REFLECT) != 0,
+                                                       (fl & LF_EV_FLAT) != 0, cur.sgn, geom_ok);
+              vign32 += mult * (unsigned)__popcll(alive & ~geom_ok);
+              tir32 += mult * (unsigned)__popcll(alive & geom_ok & ~ok);
+              alive &= ok;
+            }
+            ev32 += mult * (unsigned)__popcll(alive);
+            ++e;
+            if (fl & LF_EV_END) {
+              // ---- a path is complete -------------------------------------------------------
+              scene32 += (unsigned)__popcll(alive);
+              if (alive != 0ull) {
+                // inside the sun's lobe?
+                const float cg = fmaf(r.dx, sx, fmaf(r.dy, sy, r.dz * sz));
+                const float qq = (1.0f - cg) * inv_1mc;
+                const lanemask lit = alive & __ballot(qq < 1.0f);
+                if (lit != 0ull) {
+                  // rare (about 1 % of the wave-paths): march this path again, alone and with
+                  // the weight, along its own row sequence
+                  const int q = (int)(fl >> 24);
+                  const LfEventRow* __restrict__ w = ev_table + (size_t)l * (size_t)total_events +
+                                                     pairs->ev_off[q];
+                  Ray rw{X, Y, z_sensor, d0x, d0y, d0z, w0, 1.0f};
+                  for (int left = pairs->ev_cnt[q]; left > 0; --left, ++w) {
+                    const LfEventRow wr = load_row(w);
+                    if (wr.flags & LF_EV_STOP) {
+                      (void)stop_event<true>(rw, wr.zv, wr.h2, inv_stop_h, mask, a.mw, a.mh);
+                    } else {
+                      lanemask geom_ok;
+                      (void)surface_event<true>(rw, wr.zv, wr.curv, wr.radius, wr.h2, wr.eta, wr.eta2,
+                                                (wr.flags & LF_EV_REFLECT) != 0,
+                                                (wr.flags & LF_EV_FLAT) != 0, wr.sgn, geom_ok);
+                    }
+                  }
+                  if ((lit >> lane) & 1ull) {
+                    const float om = 1.0f - qq;
+                    const float contrib = __fdiv_rn(rw.wn, rw.wd) * (om * om);
+                    if (contrib > 0.0f) {
+                      n_light++;
+#pragma unroll
+                      for (int c = 0; c < 3; c++) {
+                        const float v = contrib * (lens->sun_radiance[c] * lens->lambda_rgb[l][c]);
+                        acc[c] += (unsigned long long)(v * kFixScale);
+                      }
+                    }
+                  }
+                }
+              }
+              // back to the fork this path left from (neither flag: that was the primary path)
+              if (fl & LF_EV_REST1) { unpark(s_state[wave][1], lane, r); alive = alive1; }
+              else if (fl & LF_EV_REST0) { unpark(s_state[wave][0], lane, r); alive = alive0; }
+              continue;
             }
           }
-          if ((lit >> lane) & 1ull) {
-            const float om = 1.0f - qq;
-            const float contrib = __fdiv_rn(rw.wn, rw.wd) * (om * om);
-            if (contrib > 0.0f) {
-              n_light++;
-#pragma unroll
-              for (int c = 0; c < 3; c++) {
-                const float v = contrib * (lens->sun_radiance[c] * lens->lambda_rgb[l][c]);
-                acc[c] += (unsigned long long)(v * kFixScale);
-              }
-            }
+          if (alive == 0ull) {
+            // the whole wave is dead: jump over everything only these rays would still visit
+            const int sk = skip_tab[(e - 1) - prog];
+            e = (e - 1) + (sk >> 2);
+            if ((sk & 3) == 1) { unpark(s_state[wave][1], lane, r); alive = alive1; }
+            else if ((sk & 3) == 2) { unpark(s_state[wave][0], lane, r); alive = alive0; }
           }
         }
       }
@@ -550,6 +575,101 @@ void lf_derive_lens(lf_ctx* ctx, int n, int stop, int n_lambda, const float* rad
                                                                       : 1.0f / (float)n_lambda;
 }
 
+// host: the march program of one wavelength -- the tree of all selected paths in depth-first order.
+//   for k = N-1 .. 0 (the backward leg from the sensor, shared by the primary path and by every pair
+//   that reflects below k):
+//     if pairs (k, .) exist:  [SAVE0] reflect at k, then the forward leg k+1 .. max j; at every j of
+//        a pair: [SAVE1] reflect at j, backward j-1 .. 0 [END, REST1 or REST0 after the last pair]
+//     refract backward through k
+// skip[r] = (rows to jump << 2) | restore, used when the whole wave is dead after row r: nothing of
+// what only these rays would still visit is executed (restore: 0 = program end, 1 = slot 1, 2 = slot 0)
+static void build_program(const LfLensDev& L, const LfPairsDev& P, int l, std::vector<LfEventRow>& prog,
+                          std::vector<int>& skip) {
+  prog.clear();
+  std::vector<int> target, restore;  // per row: absolute row to jump to when dead, restore kind
+  auto put = [&](int k, bool reflect, bool fwd, int extra_flags, int mult) {
+    const LfSurfaceDev& s = L.surf[k];
+    LfEventRow r;
+    r.zv = s.zv; r.curv = s.curv; r.h2 = s.h2;
+    r.eta = fwd ? s.eta_fwd[l] : s.eta_bwd[l];
+    r.sgn = fwd ? 1.0f : -1.0f;
+    r.flags = (reflect ? LF_EV_REFLECT : 0) | (s.is_stop != 0.0f ? LF_EV_STOP : 0) |
+              (s.curv == 0.0f ? LF_EV_FLAT : 0) | extra_flags | (mult << 16);
+    r.radius = s.radius;
+    r.eta2 = r.eta * r.eta;
+    prog.push_back(r);
+    target.push_back(-1);
+    restore.push_back(0);
+  };
+  const int N = L.n_surf;
+  int primary = -1;
+  std::vector<std::vector<std::pair<int, int>>> by_i(N);  // i -> (j, q), sorted by j
+  for (int q = 0; q < P.n; q++) {
+    if (P.ij[q][0] < 0) primary = q;
+    else by_i[P.ij[q][0]].push_back({P.ij[q][1], q});
+  }
+  int kmin = N;
+  for (int k = 0; k < N; k++) {
+    std::stable_sort(by_i[k].begin(), by_i[k].end());
+    if (!by_i[k].empty() && k < kmin) kmin = k;
+  }
+  if (primary >= 0) kmin = 0;
+  std::vector<int> below(N + 1, 0);  // pairs that reflect below k
+  for (int k = 0; k < N; k++) below[k + 1] = below[k] + (int)by_i[k].size();
+  std::vector<int> prefix_rows;
+  for (int k = N - 1; k >= kmin; k--) {
+    const auto& js = by_i[k];
+    if (!js.empty()) {
+      const int sub_first = (int)prog.size();
+      std::vector<int> fwd_rows;
+      put(k, true, false, LF_EV_SAVE0, (int)js.size());
+      fwd_rows.push_back(sub_first);
+      const int maxj = js.back().first;
+      size_t p = 0;
+      for (int m = k + 1; m <= maxj; m++) {
+        while (p < js.size() && js[p].first == m) {
+          const bool last = p + 1 == js.size();
+          const int leg_first = (int)prog.size();
+          put(m, true, true, last ? 0 : LF_EV_SAVE1, 1);
+          for (int t = m - 1; t >= 0; t--)
+            put(t, false, false,
+                t == 0 ? (LF_EV_END | (last ? LF_EV_REST0 : LF_EV_REST1) | (js[p].second << 24)) : 0, 1);
+          for (int r = leg_first; r < (int)prog.size(); r++) {
+            target[r] = (int)prog.size();
+            restore[r] = last ? 2 : 1;
+          }
+          p++;
+        }
+        if (m < maxj) {
+          fwd_rows.push_back((int)prog.size());
+          put(m, false, true, 0, (int)(js.size() - p));
+        }
+      }
+      for (int r : fwd_rows) { target[r] = (int)prog.size(); restore[r] = 2; }
+    }
+    const int mult = (primary >= 0 ? 1 : 0) + below[k];
+    if (mult > 0) {
+      prefix_rows.push_back((int)prog.size());
+      put(k, false, false, (k == 0 && primary >= 0) ? (LF_EV_END | (primary << 24)) : 0, mult);
+    }
+  }
+  for (int r : prefix_rows) { target[r] = (int)prog.size(); restore[r] = 0; }
+  // runs of plain rows (no flag in the low byte, the same multiplicity)
+  for (int r = (int)prog.size() - 1, run = 0; r >= 0; r--) {
+    const bool plain = (prog[r].flags & 0xff) == 0;
+    const bool chain = plain && run > 0 && run < 255 &&
+                       ((prog[r + 1].flags >> 16) & 0xff) == ((prog[r].flags >> 16) & 0xff);
+    run = plain ? (chain ? run + 1 : 1) : 0;
+    prog[r].flags |= run << 8;
+  }
+  for (size_t r = 0; r < prog.size(); r++)  // a dead wave must always move forward, inside the program
+    if (target[r] <= (int)r || target[r] > (int)prog.size()) { prog.clear(); skip.clear(); return; }
+  if (l == 0) {
+    skip.resize(prog.size());
+    for (size_t r = 0; r < prog.size(); r++) skip[r] = ((target[r] - (int)r) << 2) | restore[r];
+  }
+}
+
 // host: expand every selected pair into its event rows (per wavelength), see LfEventRow
 static lf_status build_event_table(lf_ctx* ctx) {
   const LfLensDev& L = ctx->lens;
@@ -596,6 +716,27 @@ static lf_status build_event_table(lf_ctx* ctx) {
         out[k].flags |= run << 8;
       }
     }
+  // the flat table is followed by the shared-prefix program (see LF_EV_SAVE0 in lf_internal.h)
+  std::vector<int> skip;
+  P.prog_off = (int)rows.size();
+  {
+    std::vector<LfEventRow> prog;
+    for (int l = 0; l < L.n_lambda; l++) {
+      build_program(L, P, l, prog, skip);
+      if (prog.empty()) return lf_fail(ctx, LF_ERR_STATE, "march program: inconsistent jump table");
+      if (l == 0) P.prog_rows = (int)prog.size();
+      rows.insert(rows.end(), prog.begin(), prog.end());
+    }
+  }
+  rows.push_back(LfEventRow{});  // spare
+  if (skip.size() > ctx->skip_cap) {
+    if (ctx->skip_dev) { LF_HIP(ctx, hipStreamSynchronize(ctx->stream)); (void)hipFree(ctx->skip_dev); }
+    ctx->skip_dev = nullptr;
+    LF_HIP(ctx, hipMalloc((void**)&ctx->skip_dev, skip.size() * sizeof(int)));
+    ctx->skip_cap = skip.size();
+  }
+  if (!skip.empty())
+    LF_HIP(ctx, hipMemcpy(ctx->skip_dev, skip.data(), skip.size() * sizeof(int), hipMemcpyHostToDevice));
   if (rows.size() > ctx->events_cap) {
     if (ctx->events_dev) { LF_HIP(ctx, hipStreamSynchronize(ctx->stream)); (void)hipFree(ctx->events_dev); }
     ctx->events_dev = nullptr;
@@ -657,7 +798,7 @@ lf_status lfk_march(lf_ctx* ctx, int spp, uint64_t key) {
   }
   hipEvent_t ev = lf_timing_begin(ctx, LFK_MARCH);
   hipLaunchKernelGGL(k_march, dim3((unsigned)blocks), dim3(256), 0, ctx->stream, ctx->lens_dev,
-                     ctx->pairs_dev, ctx->events_dev, m.texels, a, ctx->ghost, ctx->accum,
+                     ctx->pairs_dev, ctx->events_dev, ctx->skip_dev, m.texels, a, ctx->ghost, ctx->accum,
                      ctx->counters_dev);
   lf_timing_end(ctx, LFK_MARCH, ev);
   LF_HIP(ctx, hipGetLastError());
