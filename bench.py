@@ -249,16 +249,17 @@ def main():
 
     cnt = lf.counters()
     n_launch, march_ms = lf.timing_get("march")
-    ev = torch.tensor([float(cnt["surface_events"]), float(cnt["rays_launched"]), dt],
+    ev = torch.tensor([float(cnt["surface_events"]), float(cnt["rays_launched"]),
+                       float(lf.executed_events()), dt],
                       dtype=torch.float64, device=f"cuda:{local}" if backend == "nccl" else "cpu")
     if world > 1:
         tot = ev.clone()
-        dist.all_reduce(tot[:2], op=dist.ReduceOp.SUM)
-        mx = ev[2:].clone()
+        dist.all_reduce(tot[:3], op=dist.ReduceOp.SUM)
+        mx = ev[3:].clone()
         dist.all_reduce(mx, op=dist.ReduceOp.MAX)
-        events, rays, dt = float(tot[0]), float(tot[1]), float(mx[0])
+        events, rays, executed, dt = float(tot[0]), float(tot[1]), float(tot[2]), float(mx[0])
     else:
-        events, rays = float(ev[0]), float(ev[1])
+        events, rays, executed = float(ev[0]), float(ev[1]), float(ev[2])
 
     if rank == 0:
         # roofline of the dominant kernel (the march): algorithmic HBM bytes per launch =
@@ -277,10 +278,12 @@ def main():
                 traffic = pmc.get("hbm_bytes_per_launch") if world == 1 else None
             except Exception:
                 traffic = None
-        ev_per_launch = events / max(1, n_launch * world)
+        # the VALU accounting is on the events the device computes (shared legs once), not on the
+        # per-path count that `value` reports
+        ev_per_launch = executed / max(1, n_launch * world)
         ev_rate_gpu = ev_per_launch / (avg_ms * 1e-3) if avg_ms > 0 else 0.0
         valu = {"bound": "valu", "unit": "wave-instr/s", "peak": VALU_PEAK_LANEOPS / 64.0,
-                "practical_peak": 1.05e12, "events_per_s_per_gpu": ev_rate_gpu,
+                "practical_peak": 1.05e12, "executed_events_per_s_per_gpu": ev_rate_gpu,
                 "note": "peak = 1024 SIMD-32 x 2.4 GHz / 2 clk per wave64 op; practical_peak = "
                         "profiles/microbench/valu_issue.hip (8 waves/SIMD, independent v_fma_f32); "
                         "instructions per event from the rocprofv3 PMC pass in profiles/"}
@@ -304,7 +307,12 @@ def main():
                                       + (", RCCL in-place all_gather per tile-row group"
                                          if world > 1 else ""),
                        "rays_per_frame": rays / args.steps,
-                       "events_per_frame": events / args.steps},
+                       "events_per_frame": events / args.steps,
+                       "events_executed_per_frame": executed / args.steps,
+                       "note": "value counts every path's ray-surface intersections on their own "
+                               "(what the per-path CPU oracle counts and does); the device computes "
+                               "the legs that the paths of one sample share once "
+                               "(events_executed_per_frame)"},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                          "kernel": "k_march", "launches": n_launch, "avg_launch_ms": avg_ms,

@@ -52,7 +52,9 @@ typedef struct {
 /* device-side counters of the geometric march */
 typedef struct {
   uint64_t rays_launched;   /* (sample, wavelength, pair) rays started */
-  uint64_t surface_events;  /* executed ray-surface events (intersect + refract|reflect + Fresnel) */
+  uint64_t surface_events;  /* ray-surface events (intersect + refract|reflect) of all paths, each path
+                               counted on its own -- the legs that paths of one sample share are
+                               computed once on the device, see lf_get_executed_events */
   uint64_t rays_clipped_stop;   /* killed by the aperture mask at the stop */
   uint64_t rays_vignetted;      /* outside a semi-aperture or missed a surface */
   uint64_t rays_tir;            /* total internal reflection */
@@ -215,6 +217,10 @@ lf_status lf_generate_lens_rays(lf_ctx* ctx, int lambda, size_t n, const float* 
                                 const float* pupil_uv, float* out);
 lf_status lf_get_counters(lf_ctx* ctx, lf_counters* out);
 lf_status lf_reset_counters(lf_ctx* ctx);
+/* Ray-surface events the device actually computed since the last reset: the paths of one sensor
+ * sample start with the same backward leg and the pairs (i, .) share the forward leg after the
+ * reflection at i, and the march computes every shared leg once (no reference counterpart). */
+lf_status lf_get_executed_events(lf_ctx* ctx, uint64_t* out);
 
 /* ---------------------------------------------------------------- measurement ------------ */
 /* HIP-event timing of the kernels launched since the last reset, on the context's stream.

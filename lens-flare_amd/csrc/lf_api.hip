@@ -677,6 +677,15 @@ lf_status lf_get_counters(lf_ctx* ctx, lf_counters* out) {
   return LF_OK;
 }
 
+lf_status lf_get_executed_events(lf_ctx* ctx, uint64_t* out) {
+  if (!ctx || !out) return LF_ERR_INVALID;
+  unsigned long long c = 0;
+  LF_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  LF_HIP(ctx, hipMemcpy(&c, ctx->counters_dev + 7, sizeof(c), hipMemcpyDeviceToHost));
+  *out = c;
+  return LF_OK;
+}
+
 lf_status lf_reset_counters(lf_ctx* ctx) {
   if (!ctx) return LF_ERR_INVALID;
   LF_HIP(ctx, hipMemsetAsync(ctx->counters_dev, 0, 8 * sizeof(unsigned long long), ctx->stream));

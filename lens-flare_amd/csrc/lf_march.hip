@@ -205,13 +205,14 @@ __device__ __forceinline__ LfEventRow load_row(const LfEventRow* __restrict__ e)
 
 // parked ray state (a fork of the path tree) in LDS: the two slots would cost 12 VGPRs and the 8th
 // wave of every SIMD
-__device__ __forceinline__ void park(float* __restrict__ slot, int lane, const Ray& r) {
-  slot[lane] = r.px; slot[64 + lane] = r.py; slot[128 + lane] = r.pz;
-  slot[192 + lane] = r.dx; slot[256 + lane] = r.dy; slot[320 + lane] = r.dz;
+__device__ __forceinline__ void park(float2* __restrict__ slot, int lane, const Ray& r) {
+  slot[3 * lane] = make_float2(r.px, r.py);
+  slot[3 * lane + 1] = make_float2(r.pz, r.dx);
+  slot[3 * lane + 2] = make_float2(r.dy, r.dz);
 }
-__device__ __forceinline__ void unpark(const float* __restrict__ slot, int lane, Ray& r) {
-  r.px = slot[lane]; r.py = slot[64 + lane]; r.pz = slot[128 + lane];
-  r.dx = slot[192 + lane]; r.dy = slot[256 + lane]; r.dz = slot[320 + lane];
+__device__ __forceinline__ void unpark(const float2* __restrict__ slot, int lane, Ray& r) {
+  const float2 a = slot[3 * lane], b = slot[3 * lane + 1], c = slot[3 * lane + 2];
+  r.px = a.x; r.py = a.y; r.pz = b.x; r.dx = b.y; r.dy = c.x; r.dz = c.y;
 }
 
 struct MarchArgs {
@@ -237,7 +238,7 @@ void k_march(const LfLensDev* __restrict__ lens,
   __shared__ unsigned long long s_acc[64 * 3];
   __shared__ unsigned long long s_cnt[8];
   __shared__ int s_next;
-  __shared__ float s_state[4][2][6 * 64];  // parked ray states: [wave][slot][component][lane]
+  __shared__ float2 s_state[4][2][3 * 64];  // parked ray states: [wave][slot][lane][px py|pz dx|dy dz]
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   if (tid < 64 * 3) s_acc[tid] = 0ull;
   if (tid < 8) s_cnt[tid] = 0ull;
@@ -265,7 +266,7 @@ void k_march(const LfLensDev* __restrict__ lens,
 
   unsigned n_light = 0, n_launched = 0;  // per lane
   // wave-uniform, counted once per wave with s_bcnt1 (SALU)
-  unsigned long long events = 0, n_clip = 0, n_vign = 0, n_tir = 0, n_scene = 0;
+  unsigned long long events = 0, n_clip = 0, n_vign = 0, n_tir = 0, n_scene = 0, n_exec = 0;
   unsigned long long acc[3] = {0ull, 0ull, 0ull};
 
   {
@@ -320,7 +321,7 @@ void k_march(const LfLensDev* __restrict__ lens,
       const float w0 = geom_norm * (c2 * c2);
       if (active) n_launched += (unsigned)(n_lambda * n_pairs);
       // wave-uniform 32-bit tallies of this sample (64 lanes x pairs x wavelengths x rows < 2^32)
-      unsigned ev32 = 0, clip32 = 0, vign32 = 0, tir32 = 0, scene32 = 0;
+      unsigned ev32 = 0, clip32 = 0, vign32 = 0, tir32 = 0, scene32 = 0, exec32 = 0;
 
       for (int l = 0; l < n_lambda; l++) {
         // ---- walk the wavelength's program (the tree of all paths, depth first) ----------------
@@ -333,11 +334,14 @@ void k_march(const LfLensDev* __restrict__ lens,
           const LfEventRow cur = load_row(e);
           const unsigned fl = (unsigned)cur.flags;
           const unsigned run = (fl >> 8) & 0xffu, mult = (fl >> 16) & 0xffu;
+          unsigned endfl = 0u;  // flags of the row just executed if it completes a path
           if (run) {
-            // plain events (refraction at a curved interface): straight-line body
+            // plain events (refraction at a curved interface): straight-line body.  The last row
+            // of a run may complete a path.
             const LfEventRow* const run_end = e + run;
+            LfEventRow pl;
             do {
-              const LfEventRow pl = load_row(e);
+              pl = load_row(e);
               lanemask geom_ok;
               const lanemask ok = surface_event<false>(r, pl.zv, pl.curv, pl.radius, pl.h2, pl.eta,
                                                        pl.eta2, false, false, pl.sgn, geom_ok);
@@ -346,72 +350,41 @@ void k_march(const LfLensDev* __restrict__ lens,
                 tir32 += mult * (unsigned)__popcll(alive & geom_ok & ~ok);
                 alive &= ok;
               }
-              ev32 += mult * (unsigned)__popcll(alive);
+              const unsigned live = (unsigned)__popcll(alive);
+              ev32 += mult * live;   // logical events: one per path that shares this row
+              exec32 += live;        // computed events
               ++e;
             } while (e != run_end && alive != 0ull);
-          } else {
-            if (fl & LF_EV_SAVE0) { park(s_state[wave][0], lane, r); alive0 = alive; }
-            if (fl & LF_EV_SAVE1) { park(s_state[wave][1], lane, r); alive1 = alive; }
-            if (fl & LF_EV_STOP) {
-              const lanemask ok = stop_event<false>(r, cur.zv, cur.h2, inv_stop_h, mask, a.mw, a.mh);
+            endfl = (unsigned)pl.flags;
+          } else if (fl & LF_EV_STOP) {
+            const lanemask ok = stop_event<false>(r, cur.zv, cur.h2, inv_stop_h, mask, a.mw, a.mh);
+            if ((alive & ~ok) != 0ull) {
               clip32 += mult * (unsigned)__popcll(alive & ~ok);
               alive &= ok;
-            } else {
-              lanemask geom_ok;
-              const lanemask ok = surface_event<false>(r, cur.zv, cur.curv, cur.radius, cur.h2,
-                                                       cur.eta, cur.eta2, (fl & LF_EV_REFLECT) != 0,
-                                                       (fl & LF_EV_FLAT) != 0, cur.sgn, geom_ok);
+            }
+            const unsigned live = (unsigned)__popcll(alive);
+            ev32 += mult * live;
+            exec32 += live;
+            ++e;
+            endfl = fl;
+          } else {
+            // a mirror event (the fork of a sub-tree or of one pair) or flat glass
+            if (fl & LF_EV_SAVE0) { park(s_state[wave][0], lane, r); alive0 = alive; }
+            if (fl & LF_EV_SAVE1) { park(s_state[wave][1], lane, r); alive1 = alive; }
+            lanemask geom_ok;
+            const lanemask ok = surface_event<false>(r, cur.zv, cur.curv, cur.radius, cur.h2,
+                                                     cur.eta, cur.eta2, (fl & LF_EV_REFLECT) != 0,
+                                                     (fl & LF_EV_FLAT) != 0, cur.sgn, geom_ok);
+            if ((alive & ~ok) != 0ull) {
               vign32 += mult * (unsigned)__popcll(alive & ~geom_ok);
               tir32 += mult * (unsigned)__popcll(alive & geom_ok & ~ok);
               alive &= ok;
             }
-            ev32 += mult * (unsigned)__popcll(alive);
+            const unsigned live = (unsigned)__popcll(alive);
+            ev32 += mult * live;
+            exec32 += live;
             ++e;
-            if (fl & LF_EV_END) {
-              // ---- a path is complete -------------------------------------------------------
-              scene32 += (unsigned)__popcll(alive);
-              if (alive != 0ull) {
-                // inside the sun's lobe?
-                const float cg = fmaf(r.dx, sx, fmaf(r.dy, sy, r.dz * sz));
-                const float qq = (1.0f - cg) * inv_1mc;
-                const lanemask lit = alive & __ballot(qq < 1.0f);
-                if (lit != 0ull) {
-                  // rare (about 1 % of the wave-paths): march this path again, alone and with
-                  // the weight, along its own row sequence
-                  const int q = (int)(fl >> 24);
-                  const LfEventRow* __restrict__ w = ev_table + (size_t)l * (size_t)total_events +
-                                                     pairs->ev_off[q];
-                  Ray rw{X, Y, z_sensor, d0x, d0y, d0z, w0, 1.0f};
-                  for (int left = pairs->ev_cnt[q]; left > 0; --left, ++w) {
-                    const LfEventRow wr = load_row(w);
-                    if (wr.flags & LF_EV_STOP) {
-                      (void)stop_event<true>(rw, wr.zv, wr.h2, inv_stop_h, mask, a.mw, a.mh);
-                    } else {
-                      lanemask geom_ok;
-                      (void)surface_event<true>(rw, wr.zv, wr.curv, wr.radius, wr.h2, wr.eta, wr.eta2,
-                                                (wr.flags & LF_EV_REFLECT) != 0,
-                                                (wr.flags & LF_EV_FLAT) != 0, wr.sgn, geom_ok);
-                    }
-                  }
-                  if ((lit >> lane) & 1ull) {
-                    const float om = 1.0f - qq;
-                    const float contrib = __fdiv_rn(rw.wn, rw.wd) * (om * om);
-                    if (contrib > 0.0f) {
-                      n_light++;
-#pragma unroll
-                      for (int c = 0; c < 3; c++) {
-                        const float v = contrib * (lens->sun_radiance[c] * lens->lambda_rgb[l][c]);
-                        acc[c] += (unsigned long long)(v * kFixScale);
-                      }
-                    }
-                  }
-                }
-              }
-              // back to the fork this path left from (neither flag: that was the primary path)
-              if (fl & LF_EV_REST1) { unpark(s_state[wave][1], lane, r); alive = alive1; }
-              else if (fl & LF_EV_REST0) { unpark(s_state[wave][0], lane, r); alive = alive0; }
-              continue;
-            }
+            endfl = fl;
           }
           if (alive == 0ull) {
             // the whole wave is dead: jump over everything only these rays would still visit
@@ -419,10 +392,51 @@ void k_march(const LfLensDev* __restrict__ lens,
             e = (e - 1) + (sk >> 2);
             if ((sk & 3) == 1) { unpark(s_state[wave][1], lane, r); alive = alive1; }
             else if ((sk & 3) == 2) { unpark(s_state[wave][0], lane, r); alive = alive0; }
+          } else if (endfl & LF_EV_END) {
+            // ---- a path is complete ---------------------------------------------------------
+            scene32 += (unsigned)__popcll(alive);
+            // inside the sun's lobe?
+            const float cg = fmaf(r.dx, sx, fmaf(r.dy, sy, r.dz * sz));
+            const float qq = (1.0f - cg) * inv_1mc;
+            const lanemask lit = alive & __ballot(qq < 1.0f);
+            if (lit != 0ull) {
+              // rare (about 1 % of the wave-paths): march this path again, alone and with the
+              // weight, along its own row sequence
+              const int q = (int)(endfl >> 24);
+              const LfEventRow* __restrict__ w = ev_table + (size_t)l * (size_t)total_events +
+                                                 pairs->ev_off[q];
+              Ray rw{X, Y, z_sensor, d0x, d0y, d0z, w0, 1.0f};
+              for (int left = pairs->ev_cnt[q]; left > 0; --left, ++w) {
+                const LfEventRow wr = load_row(w);
+                if (wr.flags & LF_EV_STOP) {
+                  (void)stop_event<true>(rw, wr.zv, wr.h2, inv_stop_h, mask, a.mw, a.mh);
+                } else {
+                  lanemask geom_ok;
+                  (void)surface_event<true>(rw, wr.zv, wr.curv, wr.radius, wr.h2, wr.eta, wr.eta2,
+                                            (wr.flags & LF_EV_REFLECT) != 0,
+                                            (wr.flags & LF_EV_FLAT) != 0, wr.sgn, geom_ok);
+                }
+              }
+              if ((lit >> lane) & 1ull) {
+                const float om = 1.0f - qq;
+                const float contrib = __fdiv_rn(rw.wn, rw.wd) * (om * om);
+                if (contrib > 0.0f) {
+                  n_light++;
+#pragma unroll
+                  for (int c = 0; c < 3; c++) {
+                    const float v = contrib * (lens->sun_radiance[c] * lens->lambda_rgb[l][c]);
+                    acc[c] += (unsigned long long)(v * kFixScale);
+                  }
+                }
+              }
+            }
+            // back to the fork this path left from (neither flag: that was the primary path)
+            if (endfl & LF_EV_REST1) { unpark(s_state[wave][1], lane, r); alive = alive1; }
+            else if (endfl & LF_EV_REST0) { unpark(s_state[wave][0], lane, r); alive = alive0; }
           }
         }
       }
-      events += ev32; n_clip += clip32; n_vign += vign32; n_tir += tir32; n_scene += scene32;
+      n_exec += exec32; events += ev32; n_clip += clip32; n_vign += vign32; n_tir += tir32; n_scene += scene32;
     }
     if (active) {
 #pragma unroll
@@ -435,15 +449,15 @@ void k_march(const LfLensDev* __restrict__ lens,
   {
     unsigned long long v0 = n_launched, v6 = n_light;
     for (int off = 32; off > 0; off >>= 1) { v0 += __shfl_down(v0, off); v6 += __shfl_down(v6, off); }
-    const unsigned long long vals[7] = {v0, events, n_clip, n_vign, n_tir, n_scene, v6};
+    const unsigned long long vals[8] = {v0, events, n_clip, n_vign, n_tir, n_scene, v6, n_exec};
     if (lane == 0) {
 #pragma unroll
-      for (int i = 0; i < 7; i++)
+      for (int i = 0; i < 8; i++)
         if (vals[i]) atomicAdd(&s_cnt[i], vals[i]);
     }
   }
   __syncthreads();
-  if (tid < 7 && s_cnt[tid]) atomicAdd(&counters[tid], s_cnt[tid]);
+  if (tid < 8 && s_cnt[tid]) atomicAdd(&counters[tid], s_cnt[tid]);
 
   // ---- the tile's pixels: 8 rows of 8 x 24 contiguous bytes -----------------------------------
   if (wave == 0 && active) {
@@ -655,9 +669,11 @@ static void build_program(const LfLensDev& L, const LfPairsDev& P, int l, std::v
   }
   for (int r : prefix_rows) { target[r] = (int)prog.size(); restore[r] = 0; }
   // runs of plain rows (no flag in the low byte, the same multiplicity)
+  // (a row that only completes a path is plain as well, but nothing can follow it in its run)
+  const int special = LF_EV_REFLECT | LF_EV_STOP | LF_EV_FLAT | LF_EV_SAVE0 | LF_EV_SAVE1;
   for (int r = (int)prog.size() - 1, run = 0; r >= 0; r--) {
-    const bool plain = (prog[r].flags & 0xff) == 0;
-    const bool chain = plain && run > 0 && run < 255 &&
+    const bool plain = (prog[r].flags & special) == 0;
+    const bool chain = plain && !(prog[r].flags & LF_EV_END) && run > 0 && run < 255 &&
                        ((prog[r + 1].flags >> 16) & 0xff) == ((prog[r].flags >> 16) & 0xff);
     run = plain ? (chain ? run + 1 : 1) : 0;
     prog[r].flags |= run << 8;

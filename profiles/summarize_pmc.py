@@ -29,7 +29,7 @@ if "FETCH_SIZE" in pl and "WRITE_SIZE" in pl:
 try:
     line = [l for l in open(os.path.join(out_dir, "sq.json")) if l.startswith("{")][-1]
     b = json.loads(line)
-    ev = b["config"]["events_per_frame"]
+    ev = b["config"].get("events_executed_per_frame", b["config"]["events_per_frame"])
     res["events_per_launch"] = ev
     res["ms_per_launch_under_pmc"] = b["roofline"]["avg_launch_ms"]
     if "SQ_INSTS_VALU" in pl:
