@@ -215,6 +215,11 @@ lf_status lf_trace_ghosts(lf_ctx* ctx, int spp, uint64_t key);
  * alive (1/0)} in lens space (optical axis = z, light travels +z, the scene lies at z < 0). */
 lf_status lf_generate_lens_rays(lf_ctx* ctx, int lambda, size_t n, const float* sensor_xy_mm,
                                 const float* pupil_uv, float* out);
+/* y[k] = the square root of x[k] exactly as the march computes it (the CDNA4 v_sqrt_f32
+ * instruction, 1 ulp).  Host pointers.  No reference counterpart: the parity tests measure the
+ * instruction's deviation from the correctly rounded root with this call and hand it to the CPU
+ * oracle, which then follows the device bit for bit (oracle/lf_geo_oracle.c, geo_set_sqrt_table). */
+lf_status lf_native_sqrt(lf_ctx* ctx, const float* x, float* y, size_t n);
 lf_status lf_get_counters(lf_ctx* ctx, lf_counters* out);
 lf_status lf_reset_counters(lf_ctx* ctx);
 /* Ray-surface events the device actually computed since the last reset: the paths of one sensor

@@ -31,7 +31,7 @@ ABI_SYMBOLS = [
     "lf_set_sampling", "lf_render_scene_term",
     "lf_generate_ghost_buffer", "lf_render_flare_layer", "lf_read_tile", "lf_read_pixel",
     "lf_write_to_framebuffer", "lf_save_image_rgba", "lf_device_buffer", "lf_set_lens", "lf_set_lambda_rgb", "lf_set_sun",
-    "lf_set_ghost_pairs", "lf_trace_ghosts", "lf_generate_lens_rays", "lf_get_counters", "lf_reset_counters", "lf_get_executed_events",
+    "lf_set_ghost_pairs", "lf_trace_ghosts", "lf_generate_lens_rays", "lf_get_counters", "lf_reset_counters", "lf_get_executed_events", "lf_native_sqrt",
     "lf_timing_enable", "lf_timing_reset", "lf_timing_get",
 ]
 
@@ -335,6 +335,13 @@ class LensFlare:
         c = Counters()
         self._ck(self.lib.lf_get_counters(self.ctx, C.byref(c)))
         return c.as_dict()
+
+    def native_sqrt(self, x):
+        x = np.ascontiguousarray(x, np.float32)
+        y = np.empty_like(x)
+        self._ck(self.lib.lf_native_sqrt(self.ctx, x.ctypes.data_as(C.POINTER(C.c_float)),
+                                         y.ctypes.data_as(C.POINTER(C.c_float)), C.c_size_t(x.size)))
+        return y
 
     def executed_events(self):
         v = C.c_uint64(0)

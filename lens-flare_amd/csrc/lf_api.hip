@@ -666,6 +666,25 @@ lf_status lf_generate_lens_rays(lf_ctx* ctx, int lambda, size_t n, const float* 
   return LF_OK;
 }
 
+lf_status lf_native_sqrt(lf_ctx* ctx, const float* x, float* y, size_t n) {
+  if (!ctx || (n && (!x || !y))) return LF_ERR_INVALID;
+  if (n == 0) return LF_OK;
+  LF_HIP(ctx, hipSetDevice(ctx->device));
+  float *d_x = nullptr, *d_y = nullptr;
+  hipError_t e = hipMalloc((void**)&d_x, n * sizeof(float));
+  if (e == hipSuccess) e = hipMalloc((void**)&d_y, n * sizeof(float));
+  if (e == hipSuccess) e = hipMemcpy(d_x, x, n * sizeof(float), hipMemcpyHostToDevice);
+  lf_status st = LF_OK;
+  if (e == hipSuccess) st = lfk_native_sqrt(ctx, d_x, d_y, n);
+  if (e == hipSuccess && st == LF_OK) e = hipStreamSynchronize(ctx->stream);
+  if (e == hipSuccess && st == LF_OK) e = hipMemcpy(y, d_y, n * sizeof(float), hipMemcpyDeviceToHost);
+  if (d_x) (void)hipFree(d_x);
+  if (d_y) (void)hipFree(d_y);
+  if (st != LF_OK) return st;
+  LF_HIP(ctx, e);
+  return LF_OK;
+}
+
 lf_status lf_get_counters(lf_ctx* ctx, lf_counters* out) {
   if (!ctx || !out) return LF_ERR_INVALID;
   unsigned long long c[8];

@@ -53,26 +53,14 @@ __device__ __forceinline__ uint4 philox4x32_10(uint4 ctr, uint2 key) {
   return ctr;
 }
 
-// IEEE correctly rounded sqrt: plain sqrt under -fhip-fp32-correctly-rounded-divide-sqrt.
-// (ROCm's __fsqrt_rn maps to the 1-ulp hardware approximation unless
-// OCML_BASIC_ROUNDED_OPERATIONS is defined, which broke bit parity with the CPU in 1 ray of 10^4.)
-//
-// lf_sqrt below is that correctly rounded sqrt written out: the hardware's 1-ulp v_sqrt_f32, then
-// pick among {s-1ulp, s, s+1ulp} with two exact fma residuals -- the same selection LLVM emits
-// for an IEEE f32 sqrt, minus its 2^32 pre-scaling for denormal inputs and its 0/inf class check,
-// neither of which can trigger here: every argument is 0, NaN (dead lane) or >= 2^-54 (it is the
-// fma-rounded difference of O(1) products of 24-bit floats).  Saves 6 VALU per sqrt; bit-exact
-// with sqrtf() on the CPU for those inputs (tests compare every pixel and counter).
-__device__ __forceinline__ float lf_sqrt(float x) {
-  const float s = __builtin_amdgcn_sqrtf(x);
-  const float s_dn = __uint_as_float(__float_as_uint(s) - 1u);
-  const float s_up = __uint_as_float(__float_as_uint(s) + 1u);
-  const float r_dn = fmaf(-s_dn, s, x);
-  const float r_up = fmaf(-s_up, s, x);
-  float r = (r_dn <= 0.0f) ? s_dn : s;
-  r = (r_up > 0.0f) ? s_up : r;
-  return r;
-}
+// Square roots are the hardware's v_sqrt_f32: one transcendental-rate instruction, accurate to 1 ulp.
+// A correctly rounded root costs 8 more VALU instructions (the +-1 ulp residual test), and the two
+// roots of a surface event would then be 18 of its 48 instructions.  v_sqrt_f32 is deterministic
+// and its deviation from the correctly rounded root depends only on the significand and the parity
+// of the exponent, so the CPU oracle reproduces it exactly from a table measured once through
+// lf_native_sqrt (oracle/lf_geo_oracle.c, geo_set_sqrt_table): the march stays bit-for-bit
+// comparable with the oracle.
+__device__ __forceinline__ float lf_sqrt(float x) { return __builtin_amdgcn_sqrtf(x); }
 
 __device__ __forceinline__ float u01(unsigned r) { return (float)(r >> 8) * 5.9604644775390625e-8f; }
 
@@ -531,6 +519,11 @@ __global__ __launch_bounds__(256) void k_lens_rays(const LfLensDev* __restrict__
   }
 }
 
+__global__ void k_native_sqrt(const float* __restrict__ x, float* __restrict__ y, size_t n) {
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) y[i] = lf_sqrt(x[i]);
+}
+
 __global__ void k_march_finish(const unsigned long long* __restrict__ accum, MarchArgs a,
                                double* __restrict__ ghost) {
   const size_t p = (size_t)a.y0 * a.W + (size_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -824,6 +817,14 @@ lf_status lfk_march(lf_ctx* ctx, int spp, uint64_t key) {
                        ctx->accum, a, ctx->ghost);
     LF_HIP(ctx, hipGetLastError());
   }
+  return LF_OK;
+}
+
+lf_status lfk_native_sqrt(lf_ctx* ctx, const float* d_x, float* d_y, size_t n) {
+  if (n == 0) return LF_OK;
+  hipLaunchKernelGGL(k_native_sqrt, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream, d_x,
+                     d_y, n);
+  LF_HIP(ctx, hipGetLastError());
   return LF_OK;
 }
 

@@ -11,8 +11,14 @@
  * lensmaker's focal length, and agreement with the reference's own paraxial T/R/L formalism
  * (pathtracer.cpp:527-537) in the small-angle limit.
  *
- * Arithmetic contract: float32; fused multiply-adds are explicit fmaf(); division and sqrt are the
- * IEEE correctly rounded ones; built with -ffp-contract=off -mfma so nothing else fuses.
+ * Arithmetic contract: float32; fused multiply-adds are explicit fmaf(); division is the IEEE
+ * correctly rounded one; built with -ffp-contract=off -mfma so nothing else fuses.
+ * Square roots: the device uses the CDNA4 hardware instruction v_sqrt_f32, which is deterministic
+ * but only accurate to 1 ulp and whose deviation from the correctly rounded root depends on the
+ * significand and the exponent's parity alone.  geo_set_sqrt_table() installs that deviation
+ * (-1, 0, +1 ulp for each of the 2^24 (parity, significand) patterns, measured on the device by the
+ * test with lf_native_sqrt) and geo_sqrt() then reproduces v_sqrt_f32 bit for bit; without a table
+ * (CPU-only use: known-answer tests, bench.py's cpu_baseline) it is the correctly rounded sqrtf().
  */
 #define _GNU_SOURCE
 #include <math.h>
@@ -51,6 +57,24 @@ static void philox(const uint32_t ctr_in[4], const uint32_t key_in[2], uint32_t 
   out[0] = c0; out[1] = c1; out[2] = c2; out[3] = c3;
 }
 void geo_philox(const uint32_t ctr[4], const uint32_t key[2], uint32_t out[4]) { philox(ctr, key, out); }
+
+/* ---- sqrt as the device computes it (see the header) --------------------------------------- */
+static const int8_t* g_sqrt_dev = NULL; /* 2^24 entries, index = float bits & 0xffffff */
+void geo_set_sqrt_table(const int8_t* dev) { g_sqrt_dev = dev; }
+static float geo_sqrt(float x) {
+  float r = sqrtf(x);
+  if (g_sqrt_dev && x > 0.0f && x < INFINITY) {
+    uint32_t xb, rb;
+    memcpy(&xb, &x, 4);
+    if ((xb >> 23) != 0) { /* normal input */
+      memcpy(&rb, &r, 4);
+      rb += (uint32_t)(int32_t)g_sqrt_dev[xb & 0xffffffu];
+      memcpy(&r, &rb, 4);
+    }
+  }
+  return r;
+}
+float geo_sqrt_f32(float x) { return geo_sqrt(x); }
 
 static float unit24(uint32_t r) { return (float)(r >> 8) * 5.9604644775390625e-8f; }
 
@@ -104,7 +128,7 @@ static int glass_event(geo_ray* r, float zv, float c, float rad, float h2, float
   float G = fmaf(-c, od, r->d[2]);
   float disc = fmaf(G, G, -(c * F));
   if (disc < 0.0f) return VIGNETTED;
-  float root = sqrtf(disc);
+  float root = geo_sqrt(disc);
   /* vertex-side root: (G -+ root) * R for a curved interface (R = 1/c as given in the
    * prescription), the quotient F / (G +- root) for flat glass -- DESIGN.md "march arithmetic" */
   float sgn = forward ? 1.0f : -1.0f;
@@ -117,7 +141,7 @@ static int glass_event(geo_ray* r, float zv, float c, float rad, float h2, float
   float s2 = fmaf(-mu, mu, 1.0f);
   float k2 = fmaf(-(eta * eta), s2, 1.0f);
   if (k2 < 0.0f && !reflect) return TIR;
-  float ct = k2 >= 0.0f ? sqrtf(k2) : 0.0f;
+  float ct = k2 >= 0.0f ? geo_sqrt(k2) : 0.0f;
   /* unpolarised Fresnel: R = Rn / D, Rn = a^2 (A^2 + B^2), D = (b (A + B))^2 with
    * a, b = eta ci/2 -+ ct/2, A = ci ct, B = eta sin^2(theta_i) */
   float ci = fabsf(mu);
@@ -231,7 +255,7 @@ static float start_ray(const geo_derived* D, int W, int H, int x, int y, int s, 
     qy = wide ? rr * sn : rr * cs;
   }
   float vx = fmaf(D->pupil_h, qx, -X), vy = fmaf(D->pupil_h, qy, -Y), vz = D->pupil_z - D->z_sensor;
-  float len = sqrtf(fmaf(vx, vx, fmaf(vy, vy, vz * vz)));
+  float len = geo_sqrt(fmaf(vx, vx, fmaf(vy, vy, vz * vz)));
   float rl = 1.0f / len;
   r->p[0] = X; r->p[1] = Y; r->p[2] = D->z_sensor;
   r->d[0] = vx * rl; r->d[1] = vy * rl; r->d[2] = vz * rl;

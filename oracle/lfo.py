@@ -289,6 +289,45 @@ def geo_z_sensor(lens):
     return lib().geo_z_sensor(C.byref(L))
 
 
+_sqrt_table_keepalive = None
+
+
+def geo_set_sqrt_table(dev):
+    """Install (or with None remove) the device's v_sqrt_f32 deviation table: 2^24 int8 in
+    {-1, 0, 1}, index = float32 bits & 0xffffff (exponent parity + significand); see
+    lf_geo_oracle.c's header.  sqrt_deviation_table() builds it from a device sqrt function."""
+    global _sqrt_table_keepalive
+    if dev is None:
+        lib().geo_set_sqrt_table(None)
+        _sqrt_table_keepalive = None
+        return
+    dev = np.ascontiguousarray(dev, np.int8)
+    assert dev.shape == (1 << 24,)
+    _sqrt_table_keepalive = dev
+    lib().geo_set_sqrt_table(_p(dev, C.c_int8))
+
+
+def sqrt_table_inputs():
+    """One float32 per (exponent parity, significand) pattern, in [0.5, 2)."""
+    return (np.arange(1 << 24, dtype=np.uint32) | np.uint32(0x3F000000)).view(np.float32)
+
+
+def sqrt_deviation_table(device_sqrt):
+    """device_sqrt: float32 array -> float32 array as the device computes it (lf_native_sqrt)."""
+    x = sqrt_table_inputs()
+    hw = np.asarray(device_sqrt(x), np.float32).view(np.int32)
+    exact = np.sqrt(x).view(np.int32)           # numpy's float32 sqrt is correctly rounded
+    dev = hw - exact
+    assert np.abs(dev).max() <= 1, "v_sqrt_f32 is documented to be accurate to 1 ulp"
+    return dev.astype(np.int8)
+
+
+def geo_sqrt(x):
+    lib().geo_sqrt_f32.restype = C.c_float
+    lib().geo_sqrt_f32.argtypes = [C.c_float]
+    return np.array([lib().geo_sqrt_f32(float(v)) for v in np.asarray(x, np.float32).ravel()], np.float32)
+
+
 def geo_philox(ctr, key):
     c = (C.c_uint32 * 4)(*ctr)
     k = (C.c_uint32 * 2)(*key)

@@ -1,7 +1,12 @@
 """GPU parity of the geometric march (lf_trace_ghosts) against the CPU oracle
 (oracle/lf_geo_oracle.c, PARITY UNPINNED: there is no reference implementation of this path).
 Both follow the same float32 arithmetic contract, so pixels AND event counters are compared bit for
-bit; at full size the test falls back to size-independent properties."""
+bit; at full size the test falls back to size-independent properties.
+
+The one operation of the contract that is not IEEE is the square root: the device uses v_sqrt_f32
+(1 ulp).  The `lf` fixture measures its deviation from the correctly rounded root for all 2^24
+(exponent parity, significand) patterns with lf_native_sqrt and installs it in the oracle, which
+then reproduces the instruction exactly (test_native_sqrt_* check the premises)."""
 import numpy as np
 import pytest
 
@@ -22,8 +27,34 @@ def pkg():
 @pytest.fixture(scope="module")
 def lf(pkg):
     ctx = pkg.LensFlare(0)
+    lfo.geo_set_sqrt_table(lfo.sqrt_deviation_table(ctx.native_sqrt))
     yield ctx
+    lfo.geo_set_sqrt_table(None)
     ctx.close()
+
+
+def test_native_sqrt_is_one_ulp_and_scale_invariant(lf):
+    """Premises of the oracle's sqrt emulation: |v_sqrt_f32 - correctly rounded| <= 1 ulp, and the
+    deviation depends only on (exponent parity, significand) -- checked on 2^20 random significands
+    at exponents from 2^-60 to 2^+60 (the march feeds it 0, NaN or values >= 2^-54)."""
+    table = lfo.sqrt_deviation_table(lf.native_sqrt)
+    assert set(np.unique(table)) <= {-1, 0, 1}
+    assert (table != 0).mean() < 0.5          # mostly the correctly rounded root ...
+    assert (table != 0).any()                 # ... but not always: the emulation is needed
+    rng = np.random.default_rng(5)
+    idx = rng.integers(0, 1 << 24, 1 << 20, dtype=np.uint32)
+    for e2 in (-30, -13, -1, 0, 7, 30):       # x = pattern * 4^e2
+        bits = (idx | np.uint32(0x3F000000)).astype(np.int64) + ((2 * e2) << 23)
+        x = bits.astype(np.uint32).view(np.float32)
+        hw = lf.native_sqrt(x).view(np.int32)
+        want = np.sqrt(x).view(np.int32) + table[idx]
+        assert np.array_equal(hw, want), e2
+    # and the oracle's own sqrt follows the table
+    x = (idx[:2000] | np.uint32(0x3F000000)).view(np.float32)
+    assert np.array_equal(lfo.geo_sqrt(x).view(np.int32), lf.native_sqrt(x).view(np.int32))
+    # special values: 0 -> 0, negative -> NaN, NaN -> NaN
+    sp = lf.native_sqrt(np.array([0.0, -1.0, np.nan], np.float32))
+    assert sp[0] == 0.0 and np.isnan(sp[1]) and np.isnan(sp[2])
 
 
 def _run(pkg, lf, lens, W, H, spp, key, mask, pairs=None, primary=True, band=None, sun=SUN):
