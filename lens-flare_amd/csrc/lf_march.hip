@@ -405,17 +405,16 @@ void k_march(const LfLensDev* __restrict__ lens,
                                             (wr.flags & LF_EV_FLAT) != 0, wr.sgn, geom_ok);
                 }
               }
-              if ((lit >> lane) & 1ull) {
-                const float om = 1.0f - qq;
-                const float contrib = __fdiv_rn(rw.wn, rw.wd) * (om * om);
-                if (contrib > 0.0f) {
-                  n_light++;
+              // (selects, not branches: with no divergent branch anywhere in the walk the compiler
+              // keeps its control flow as plain scalar branches)
+              const float om = 1.0f - qq;
+              float contrib = __fdiv_rn(rw.wn, rw.wd) * (om * om);
+              contrib = (((lit >> lane) & 1ull) != 0ull && contrib > 0.0f) ? contrib : 0.0f;
+              n_light += contrib > 0.0f ? 1u : 0u;
 #pragma unroll
-                  for (int c = 0; c < 3; c++) {
-                    const float v = contrib * (lens->sun_radiance[c] * lens->lambda_rgb[l][c]);
-                    acc[c] += (unsigned long long)(v * kFixScale);
-                  }
-                }
+              for (int c = 0; c < 3; c++) {
+                const float v = contrib * (lens->sun_radiance[c] * lens->lambda_rgb[l][c]);
+                acc[c] += (unsigned long long)(v * kFixScale);
               }
             }
             // back to the fork this path left from (neither flag: that was the primary path)
