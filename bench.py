@@ -204,7 +204,7 @@ def main():
     my_trows = len(sharding.my_tile_rows(H, rank, world))
     lf.set_band(0, H)
     lf.set_row_interleave(rank, world)
-    frame_t = None
+    frame_t, scratch = None, {}
     if world > 1:
         ptr, nbytes = lf.device_buffer(pkg.SAMPLE_BUFFER)
         frame_t = torch.as_tensor(DevView(ptr, nbytes // 8), device=f"cuda:{local}")
@@ -214,15 +214,15 @@ def main():
         lf.trace_ghosts(spp, 0x1e45f1a4e)
         lf.render_flare_layer()
         if world > 1:
-            # the real exchange step: every rank ends up with the whole frame.  A group of `world`
-            # consecutive tile rows is one in-place all-gather (rank r owns slot r of the group);
-            # the buffer is padded to 64 rows so the last group never runs past the end.
+            # the real exchange step: every rank ends up with the whole frame -- ONE all-gather per
+            # frame (lens_flare_amd/sharding.py: pack this rank's tile rows, gather, unpack); the
+            # buffer is padded to 64 rows so the last group of tile rows never runs past the end.
             lf.synchronize()
             if backend == "nccl":
-                sharding.gather_frame_inplace(frame_t, W, H, rank, world, dist)
+                sharding.gather_frame(frame_t, W, H, rank, world, dist, scratch=scratch)
             else:
                 host = frame_t.cpu()
-                sharding.gather_frame_inplace(host, W, H, rank, world, dist)
+                sharding.gather_frame(host, W, H, rank, world, dist)
                 frame_t.copy_(host)
             torch.cuda.synchronize()   # the next frame rewrites these rows on the library's stream
 
@@ -304,7 +304,7 @@ def main():
                                    f"pairs x 3 wavelengths, pentagon mask pentbig500_14, {W}x{H}, "
                                    f"{spp} spp, one sun (BASELINE.json configs[2])",
                        "parallelism": f"{world} GPU(s), 8-row sensor tile rows dealt round-robin"
-                                      + (", RCCL in-place all_gather per tile-row group"
+                                      + (", one RCCL all_gather per frame"
                                          if world > 1 else ""),
                        "rays_per_frame": rays / args.steps,
                        "events_per_frame": events / args.steps,

@@ -45,7 +45,11 @@ def _worker(rank, world, port, W, H, spp, out_dir):
         g_, c = lfo.geo_trace(lens, W, H, y0, y1, spp, 5, None, True, mask, *sun, n_threads=2)
         view[y0:y1] = g_[y0:y1]
         events += c["surface_events"]
+    mine = frame.clone()
     sharding.gather_frame_inplace(frame, W, H, rank, world, dist)
+    # the single-collective variant (what bench.py runs) must produce the same frame
+    sharding.gather_frame(mine, W, H, rank, world, dist)
+    assert torch.equal(mine, frame)
     ev = torch.tensor([float(events)], dtype=torch.float64)
     dist.all_reduce(ev)
     np.save(os.path.join(out_dir, f"frame_{rank}.npy"), view[:H].copy())
