@@ -614,6 +614,14 @@ lf_status lf_set_ghost_pairs(lf_ctx* ctx, const int* pairs, int n_pairs, int inc
     if (n_pairs > LF_MAX_PAIRS) return lf_fail(ctx, LF_ERR_INVALID, "too many ghost pairs");
     for (int q = 0; q < n_pairs; q++) {
       int i = pairs[2 * q], j = pairs[2 * q + 1];
+      if (i == -1 && j == -1) {  // the primary path, listed explicitly
+        if (P.n > 0 && P.ij[0][0] < 0) return lf_fail(ctx, LF_ERR_INVALID, "primary path listed twice");
+        if (P.n > 0) {  // keep it first, like include_primary does
+          for (int k = P.n; k > 0; k--) { P.ij[k][0] = P.ij[k - 1][0]; P.ij[k][1] = P.ij[k - 1][1]; }
+        }
+        P.ij[0][0] = -1; P.ij[0][1] = -1; P.n++;
+        continue;
+      }
       if (i < 0 || j <= i || j >= ns || i == stop || j == stop)
         return lf_fail(ctx, LF_ERR_INVALID, "ghost pair must satisfy 0 <= i < j < n, neither the stop");
       P.ij[P.n][0] = i; P.ij[P.n][1] = j; P.n++;

@@ -142,6 +142,44 @@ def test_reference_pair_subset_and_no_primary(pkg, lf):
     assert cnt == ocnt and np.array_equal(g, og)
 
 
+def test_path_tree_odd_pair_lists(pkg, lf):
+    """The device walks the selected paths as one tree (shared legs once); the oracle marches every
+    path on its own.  Lists that stress the tree builder: unsorted, duplicated pairs, a single pair,
+    the primary path alone, pairs that share only i or only j."""
+    lens = pkg.load_lens_file("dgauss11.lens")
+    mask = load_texels("pentbig500_14.png")
+    cases = [
+        ([(3, 8), (0, 2), (3, 4), (0, 10), (3, 8), (7, 9), (0, 2)], True),   # unsorted + duplicates
+        ([(2, 9)], False),                                                   # one pair, no primary
+        ([(-1, -1)], False),                                                 # the primary path alone
+        ([(0, 10), (1, 10), (2, 10), (9, 10)], True),                        # same j
+        ([(4, 6), (4, 7), (4, 10)], False),                                  # same i, across the stop
+    ]
+    for k, (pairs, primary) in enumerate(cases):
+        g, cnt, og, ocnt = _run(pkg, lf, lens, 24, 16, 6, 100 + k, mask, pairs=pairs, primary=primary)
+        assert cnt == ocnt, (k, cnt, ocnt)
+        assert np.array_equal(g, og), k
+        assert cnt["rays_launched"] == 24 * 16 * 6 * 3 * (len(pairs) + int(primary))
+        assert 0 < lf.executed_events() <= cnt["surface_events"]
+
+
+def test_flat_glass_surfaces(pkg, lf):
+    """Plano-convex elements around the stop: refraction and mirror events at FLAT glass use the
+    quotient form of the intersection (the curved form multiplies by R = 1/c)."""
+    n = np.array([[1.60, 1.0, 1.0, 1.55, 1.0],
+                  [1.61, 1.0, 1.0, 1.56, 1.0],
+                  [1.62, 1.0, 1.0, 1.57, 1.0]], np.float32)
+    lens = dict(n=5, stop=2, radius=np.array([45.0, 0.0, 0.0, 0.0, -38.0], np.float32),
+                thickness=np.array([6.0, 4.0, 4.0, 5.0, 30.0], np.float32), ior=n,
+                semi_aperture=np.array([14.0, 14.0, 6.0, 13.0, 13.0], np.float32), sensor_width_mm=24.0)
+    mask = load_texels("pentbig500_14.png")
+    sun = dict(SUN, direction=[0.02, 0.01, -1.0])
+    g, cnt, og, ocnt = _run(pkg, lf, lens, 40, 24, 16, 31, mask, sun=sun)
+    assert cnt == ocnt and np.array_equal(g, og)
+    assert cnt["rays_launched"] == 40 * 24 * 16 * 3 * 7     # primary + C(4, 2) pairs
+    assert cnt["rays_reached_scene"] > 0 and cnt["surface_events"] > 0
+
+
 def test_band_sharding(pkg, lf):
     """Rows [y0,y1) only: identical to the same rows of the full frame (the multi-GPU shard)."""
     lens = pkg.load_lens_file("dgauss11.lens")
