@@ -215,6 +215,13 @@ lf_status lf_trace_ghosts(lf_ctx* ctx, int spp, uint64_t key);
  * alive (1/0)} in lens space (optical axis = z, light travels +z, the scene lies at z < 0). */
 lf_status lf_generate_lens_rays(lf_ctx* ctx, int lambda, size_t n, const float* sensor_xy_mm,
                                 const float* pupil_uv, float* out);
+/* Spectral starburst (no reference counterpart -- the reference's
+ * starburst, pathtracer.cpp:947-1000, is monochrome).  n = 0 restores the reference behaviour.
+ * Wavelength l sees the reference's diffraction pattern magnified by 1 / scale[l]
+ * (scale = lambda_ref / lambda_l), shaped like the reference's value and added with the weights
+ * rgb_weights[3 l + {0,1,2}]; n <= LF_MAX_LAMBDA.  One wavelength with scale 1 and weights
+ * (1,1,1) is the reference formula.  Takes effect at the next lf_render_flare_layer. */
+lf_status lf_set_starburst_spectrum(lf_ctx* ctx, int n, const double* scale, const double* rgb_weights);
 /* y[k] = the square root of x[k] exactly as the march computes it (the CDNA4 v_sqrt_f32
  * instruction, 1 ulp).  Host pointers.  No reference counterpart: the parity tests measure the
  * instruction's deviation from the correctly rounded root with this call and hand it to the CPU

@@ -31,7 +31,7 @@ ABI_SYMBOLS = [
     "lf_set_sampling", "lf_render_scene_term",
     "lf_generate_ghost_buffer", "lf_render_flare_layer", "lf_read_tile", "lf_read_pixel",
     "lf_write_to_framebuffer", "lf_save_image_rgba", "lf_device_buffer", "lf_set_lens", "lf_set_lambda_rgb", "lf_set_sun",
-    "lf_set_ghost_pairs", "lf_trace_ghosts", "lf_generate_lens_rays", "lf_get_counters", "lf_reset_counters", "lf_get_executed_events", "lf_native_sqrt",
+    "lf_set_ghost_pairs", "lf_trace_ghosts", "lf_generate_lens_rays", "lf_get_counters", "lf_reset_counters", "lf_get_executed_events", "lf_native_sqrt", "lf_set_starburst_spectrum",
     "lf_timing_enable", "lf_timing_reset", "lf_timing_get",
 ]
 
@@ -335,6 +335,16 @@ class LensFlare:
         c = Counters()
         self._ck(self.lib.lf_get_counters(self.ctx, C.byref(c)))
         return c.as_dict()
+
+    def set_starburst_spectrum(self, scale=None, rgb_weights=None):
+        """Row f4: per-wavelength starburst; None / empty = the reference's monochrome starburst."""
+        if scale is None or len(scale) == 0:
+            self._ck(self.lib.lf_set_starburst_spectrum(self.ctx, 0, None, None))
+            return
+        sc = np.ascontiguousarray(scale, np.float64).ravel()
+        w = np.ascontiguousarray(rgb_weights, np.float64).reshape(len(sc), 3)
+        self._ck(self.lib.lf_set_starburst_spectrum(self.ctx, len(sc), _fp(sc, C.c_double),
+                                                    _fp(w, C.c_double)))
 
     def native_sqrt(self, x):
         x = np.ascontiguousarray(x, np.float32)

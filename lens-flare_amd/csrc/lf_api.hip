@@ -674,6 +674,21 @@ lf_status lf_generate_lens_rays(lf_ctx* ctx, int lambda, size_t n, const float* 
   return LF_OK;
 }
 
+lf_status lf_set_starburst_spectrum(lf_ctx* ctx, int n, const double* scale, const double* rgb_weights) {
+  if (!ctx || n < 0 || n > LF_MAX_LAMBDA || (n > 0 && (!scale || !rgb_weights))) return LF_ERR_INVALID;
+  LfStarSpectrum sp{};
+  sp.n = n;
+  for (int l = 0; l < n; l++) {
+    if (!(scale[l] > 0.0) || !(scale[l] < 1e6))
+      return lf_fail(ctx, LF_ERR_INVALID, "lf_set_starburst_spectrum: scale must be positive and finite");
+    sp.scale[l] = scale[l];
+    for (int c = 0; c < 3; c++) sp.rgb[l][c] = rgb_weights[3 * l + c];
+  }
+  ctx->star_spec = sp;
+  ctx->sample_valid = false;
+  return LF_OK;
+}
+
 lf_status lf_native_sqrt(lf_ctx* ctx, const float* x, float* y, size_t n) {
   if (!ctx || (n && (!x || !y))) return LF_ERR_INVALID;
   if (n == 0) return LF_OK;

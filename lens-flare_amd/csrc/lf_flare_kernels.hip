@@ -399,7 +399,8 @@ __global__ __launch_bounds__(256) void k_flare_layer(
     const double* __restrict__ S, const double* __restrict__ ghost,
     const double* __restrict__ scene, const uint32_t* __restrict__ jitter_raw, int jitter_mode,
     uint64_t key, int W, int H, int y0, int y1, int ns_aa, double flare_radius,
-    double flare_intensity, double* __restrict__ sample, double* __restrict__ star_out) {
+    double flare_intensity, LfStarSpectrum spec, double* __restrict__ sample,
+    double* __restrict__ star_out) {
   const size_t p = (size_t)y0 * W + (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (p >= (size_t)y1 * W) return;
   const int x = (int)(p % W), y = (int)(p / W);
@@ -417,23 +418,47 @@ __global__ __launch_bounds__(256) void k_flare_layer(
     // every term's phase is 2*pi*((xc*a + yc*b)/Aw - (a+b)/2) with a, b integers, so the sum's
     // magnitude is |DFT2(A)[b mod Aw][a mod Aw]|
     long long a = (long long)(lr - xprime), b = (long long)(ud - yprime);
-    int ka = (int)(((a % aw) + aw) % aw), kb = (int)(((b % aw) + aw) % aw);
-    double I = S[(size_t)kb * aw + ka];
     double dx = lr0 - (double)x, dy = ud0 - (double)y;
     double d = sqrt(dx * dx + dy * dy);
-    if (d > daw / 2.0) {          // flare suppression :979-985
-      double factor = (daw / 2.0) / d;
-      I = pow(factor, 8.0) * I;
-    } else if (d <= flare_radius) {  // flare amplification :986-992
-      I = pow(I, d / flare_radius);
-    }
     double intensity = -flare_intensity + 3.0;
     if (intensity <= 0) intensity = 2.0;
-    double pw = pow(I, intensity);
-    for (int l = 0; l < n_flares; l++) {
-      star[0] += pw * fl->radiance[l][0];
-      star[1] += pw * fl->radiance[l][1];
-      star[2] += pw * fl->radiance[l][2];
+    if (spec.n == 0) {
+      int ka = (int)(((a % aw) + aw) % aw), kb = (int)(((b % aw) + aw) % aw);
+      double I = S[(size_t)kb * aw + ka];
+      if (d > daw / 2.0) {          // flare suppression :979-985
+        double factor = (daw / 2.0) / d;
+        I = pow(factor, 8.0) * I;
+      } else if (d <= flare_radius) {  // flare amplification :986-992
+        I = pow(I, d / flare_radius);
+      }
+      double pw = pow(I, intensity);
+      for (int l = 0; l < n_flares; l++) {
+        star[0] += pw * fl->radiance[l][0];
+        star[1] += pw * fl->radiance[l][1];
+        star[2] += pw * fl->radiance[l][2];
+      }
+    } else {
+      // row f4 (no reference counterpart): wavelength l reads the pattern magnified by
+      // 1 / scale[l] -- S at (a, b) * scale[l], bilinear on the periodic table -- shaped like the
+      // reference's value and weighted into R, G, B
+      for (int w = 0; w < spec.n; w++) {
+        double fa = (double)a * spec.scale[w], fb = (double)b * spec.scale[w];
+        double ia = floor(fa), ib = floor(fb);
+        double ta = fa - ia, tb = fb - ib;
+        long long ka0 = ((((long long)ia) % aw) + aw) % aw, kb0 = ((((long long)ib) % aw) + aw) % aw;
+        long long ka1 = (ka0 + 1) % aw, kb1 = (kb0 + 1) % aw;
+        double s00 = S[(size_t)kb0 * aw + ka0], s01 = S[(size_t)kb0 * aw + ka1];
+        double s10 = S[(size_t)kb1 * aw + ka0], s11 = S[(size_t)kb1 * aw + ka1];
+        double I = (1.0 - tb) * ((1.0 - ta) * s00 + ta * s01) + tb * ((1.0 - ta) * s10 + ta * s11);
+        if (d > daw / 2.0) {
+          I = pow((daw / 2.0) / d, 8.0) * I;
+        } else if (d <= flare_radius) {
+          I = pow(I, d / flare_radius);
+        }
+        double pw = pow(I, intensity);
+        for (int l = 0; l < n_flares; l++)
+          for (int c = 0; c < 3; c++) star[c] += (pw * fl->radiance[l][c]) * spec.rgb[w][c];
+      }
     }
     // ---- calculate_irradiance_falloff(x, y, 5.0) :1043-1063 ------------------------------
     double t[3] = {0.0, 0.0, 0.0};
@@ -586,7 +611,7 @@ lf_status lfk_flare_layer(lf_ctx* ctx) {
                      ctx->flares, ctx->ap[LF_APERTURE_STARBURST].stats, ctx->spectrum, ctx->ghost,
                      ctx->scene, ctx->jitter_raw, ctx->jitter_mode, ctx->jitter_key, ctx->W, ctx->H,
                      ctx->y0, ctx->y1, ctx->ns_aa, ctx->flare_radius, ctx->flare_intensity,
-                     ctx->sample, ctx->star);
+                     ctx->star_spec, ctx->sample, ctx->star);
   lf_timing_end(ctx, LFK_FLARE_LAYER, ev);
   LF_HIP(ctx, hipGetLastError());
   return LF_OK;

@@ -68,6 +68,13 @@ struct LfSceneDev {
   int n_nodes, n_prims, n_materials, n_lights;
 };
 
+// per-wavelength starburst (row f4): n = 0 is the reference's monochrome starburst
+struct LfStarSpectrum {
+  int n, pad;
+  double scale[LF_MAX_LAMBDA];     // lambda_ref / lambda_l
+  double rgb[LF_MAX_LAMBDA][3];    // weight of wavelength l in R, G, B
+};
+
 struct LfApertureDev {
   float* texels = nullptr;  // w*h
   int w = 0, h = 0;
@@ -164,6 +171,7 @@ struct lf_ctx {
   double2* dft_rows = nullptr;
   bool spectrum_valid = false;
 
+  LfStarSpectrum star_spec{};
   LfParaxialLens pl{};
   LfCamera cam{};
   bool cam_valid = false;

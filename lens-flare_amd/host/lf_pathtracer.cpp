@@ -206,6 +206,14 @@ void PathTracer::generate_ghost_buffer() {
   double ax[2] = {axis_ray.x, axis_ray.y};
   check(lf_set_flares(ctx_, (int)flare_origins.size(), o.data(), r.data(), ax, angle_to_sun), "lf_set_flares");
   check(lf_set_params(ctx_, (int)ns_aa, flare_radius, flare_intensity), "lf_set_params");
+  {
+    if (starburst_scale.size() != starburst_weight.size())
+      throw std::runtime_error("generate_ghost_buffer: starburst_scale / starburst_weight sizes differ");
+    std::vector<double> w;
+    for (auto& v : starburst_weight) { w.push_back(v.x); w.push_back(v.y); w.push_back(v.z); }
+    check(lf_set_starburst_spectrum(ctx_, (int)starburst_scale.size(), starburst_scale.data(), w.data()),
+          "lf_set_starburst_spectrum");
+  }
   if (counter_jitter) check(lf_set_jitter_counter(ctx_, 0x1e45f1a4eULL), "lf_set_jitter_counter");
   else check(lf_set_jitter_mt19937(ctx_, jitter_seed, nullptr, 0), "lf_set_jitter_mt19937");
   if (geometric_) check(lf_trace_ghosts(ctx_, geo_spp_, 0x1e45f1a4eULL), "lf_trace_ghosts");

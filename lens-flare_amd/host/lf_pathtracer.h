@@ -104,6 +104,10 @@ class PathTracer {
   // ---- the reference's public fields (pathtracer.h:93-135) ----------------------------------
   size_t ns_aa = 1;
   double flare_radius = 20, flare_intensity = 1;
+  // spectral starburst (row f4, not in the reference): empty = the reference's monochrome one;
+  // otherwise one entry per wavelength, scale = lambda_ref / lambda, weight = its share of R, G, B
+  std::vector<double> starburst_scale;
+  std::vector<Vector3D> starburst_weight;
   HDRImageBuffer sampleBuffer, ghost_buffer;
   Camera* camera = nullptr;
   std::vector<DirectionalLight> lights;   // scene->lights filtered to DirectionalLight

@@ -496,6 +496,66 @@ void lfo_starburst_pixel(const lfo_frame* f, const float* ap, const lfo_aperture
   }
 }
 
+/* ---- spectral starburst -- PARITY UNPINNED -------------------------
+ * The reference's starburst is monochrome.  The Fraunhofer pattern of the aperture scales with the
+ * wavelength, so wavelength l sees the pattern of the reference magnified by 1/scale[l]
+ * (scale = lambda_ref / lambda_l): with a = lr - x', b = ud - y' (integers)
+ * the reference reads S[b mod Aw][a mod Aw], S = |DFT2(aperture)| / total_value; wavelength l reads
+ * S at (a scale, b scale), bilinearly interpolated on the periodic table, is shaped exactly like
+ * the reference's value (:979-1000) and is added with its RGB weight.  With one wavelength,
+ * scale 1 and weight (1,1,1) this IS the reference formula, which pins the spectral form at that
+ * point (tests/test_oracle_vs_reference.py); everything else about it is this repository's
+ * specification. */
+static double spectrum_at(const float* ap, const lfo_aperture_stats* st, long long ka, long long kb) {
+  const long long aw = st->width;
+  double re = 0, im = 0;
+  for (int yc = st->min_y; yc <= st->max_y; yc++)
+    for (int xc = st->min_x; xc <= st->max_x; xc++) {
+      double v = (double)ap[(size_t)yc * st->width + xc];
+      long long k = ((long long)xc * ka + (long long)yc * kb) % aw; /* exact phase index */
+      double ph = 2.0 * M_PI * (double)k / (double)aw;
+      re += v * cos(ph);
+      im += v * sin(ph);
+    }
+  return hypot(re, im) / st->total_value;
+}
+
+void lfo_starburst_pixel_spectral(const lfo_frame* f, const float* ap, const lfo_aperture_stats* st,
+                                  size_t x, size_t y, int n_lambda, const double* scale,
+                                  const double* rgb_w, double rgb[3]) {
+  double W = (double)(size_t)f->W, H = (double)(size_t)f->H;
+  double xprime = lfo_convert_coordinate(x, f->W, 0);
+  double yprime = lfo_convert_coordinate(y, f->H, 1);
+  double lr0 = ceil(f->flare_origin[0][0] * W), ud0 = ceil(f->flare_origin[0][1] * H);
+  double lr = lr0 - W / 2.0, ud = -ud0 + H / 2.0;
+  long long a = (long long)(lr - xprime), b = (long long)(ud - yprime);
+  const long long aw = st->width;
+  double daw = (double)aw;
+  double dx = lr0 - (double)x, dy = ud0 - (double)y;
+  double d = sqrt(dx * dx + dy * dy);
+  double intensity = -f->flare_intensity + 3.0;
+  if (intensity <= 0) intensity = 2.0;
+  rgb[0] = rgb[1] = rgb[2] = 0;
+  for (int l = 0; l < n_lambda; l++) {
+    double fa = (double)a * scale[l], fb = (double)b * scale[l];
+    double ia = floor(fa), ib = floor(fb);
+    double ta = fa - ia, tb = fb - ib;
+    long long ka0 = (((long long)ia % aw) + aw) % aw, kb0 = (((long long)ib % aw) + aw) % aw;
+    long long ka1 = (ka0 + 1) % aw, kb1 = (kb0 + 1) % aw;
+    double s00 = spectrum_at(ap, st, ka0, kb0), s01 = spectrum_at(ap, st, ka1, kb0);
+    double s10 = spectrum_at(ap, st, ka0, kb1), s11 = spectrum_at(ap, st, ka1, kb1);
+    double I = (1.0 - tb) * ((1.0 - ta) * s00 + ta * s01) + tb * ((1.0 - ta) * s10 + ta * s11);
+    if (d > daw / 2.0) {
+      I = pow((daw / 2.0) / d, 8.0) * I;
+    } else if (d <= f->flare_radius) {
+      I = pow(I, d / f->flare_radius);
+    }
+    double pw = pow(I, intensity);
+    for (int k = 0; k < f->n_flares; k++)
+      for (int c = 0; c < 3; c++) rgb[c] += (pw * f->flare_radiance[k][c]) * rgb_w[3 * l + c];
+  }
+}
+
 void lfo_irradiance_falloff_pixel(const lfo_frame* f, size_t x, size_t y, double radius,
                                   const uint32_t* raw32, double rgb[3]) {
   /* :1043-1063.  UniformGridSampler2D::get_sample (sampler.cpp:8-12) builds

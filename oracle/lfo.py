@@ -148,6 +148,18 @@ def starburst_pixel(frame, ap, st, x, y):
     return np.array(rgb[:]), un.value
 
 
+def starburst_pixel_spectral(frame, ap, st, x, y, scale, rgb_w):
+    """Row f4 (parity unpinned): per-wavelength starburst, see lf_oracle.c."""
+    ap = np.ascontiguousarray(ap, np.float32)
+    scale = np.ascontiguousarray(scale, np.float64).ravel()
+    rgb_w = np.ascontiguousarray(rgb_w, np.float64).reshape(len(scale), 3)
+    rgb = (C.c_double * 3)()
+    lib().lfo_starburst_pixel_spectral(C.byref(frame), _p(ap, C.c_float), C.byref(st), C.c_size_t(x),
+                                       C.c_size_t(y), len(scale), _p(scale, C.c_double),
+                                       _p(rgb_w, C.c_double), rgb)
+    return np.array(rgb[:])
+
+
 def falloff_pixel(frame, x, y, raw32, radius=5.0):
     raw32 = np.ascontiguousarray(raw32, np.uint32)
     rgb = (C.c_double * 3)()

@@ -119,6 +119,48 @@ def test_raytrace_pixel_parity(pkg, lf, name):
     assert np.array_equal(got_rgba, ref_rgba)
 
 
+def test_spectral_starburst_row_f4(pkg, lf):
+    """Per-wavelength starburst (lf_set_starburst_spectrum; no reference counterpart, parity
+    unpinned): (a) one wavelength, scale 1, weight 1 reproduces the reference-pinned frame exactly;
+    (b) three wavelengths against the oracle's restatement of the same specification, pixel by
+    pixel (the irradiance fall-off cancels in the difference to the monochrome frame)."""
+    from oracle import lfo
+    from goldenlib import load_red
+    case = Case("f64x48_pentbiglines")
+    _setup(pkg, lf, case)
+    lf.set_jitter_mt19937(5489, case.order)
+    lf.generate_ghost_buffer()
+    lf.render_flare_layer()
+    mono = lf.read_tile(2, 0, 0, case.W, case.H)
+    lf.set_starburst_spectrum([1.0], [[1.0, 1.0, 1.0]])
+    lf.render_flare_layer()
+    assert np.array_equal(lf.read_tile(2, 0, 0, case.W, case.H), mono)
+    scale, w = [0.82, 1.0, 1.21], [[1.0, 0.0, 0.0], [0.0, 1.0, 0.0], [0.1, 0.0, 0.9]]
+    lf.set_starburst_spectrum(scale, w)
+    lf.render_flare_layer()
+    spec = lf.read_tile(2, 0, 0, case.W, case.H)
+    lf.set_starburst_spectrum(None)
+    lf.render_flare_layer()
+    assert np.array_equal(lf.read_tile(2, 0, 0, case.W, case.H), mono)   # switched off again
+    assert not np.array_equal(spec, mono)
+    m = case.meta
+    f = lfo.make_frame(case.W, case.H, ns_aa=m["ns_aa"], flare_radius=m["flare_radius"],
+                       flare_intensity=m["flare_intensity"])
+    lfo.find_sun_pos(m["c2w"], m["cam_pos"], m["hFov"], m["vFov"], m["lights"], f)
+    tex, st = lfo.aperture_from_red(load_red(m["aperture"]))
+    rng = np.random.default_rng(2)
+    worst = 0.0
+    for x, y in zip(rng.integers(0, case.W, 160), rng.integers(0, case.H, 160)):
+        o_mono, _ = lfo.starburst_pixel(f, tex, st, int(x), int(y))
+        o_spec = lfo.starburst_pixel_spectral(f, tex, st, int(x), int(y), scale, w)
+        want = o_spec - o_mono
+        got = spec[y, x] - mono[y, x]
+        tol = 1e-9 * np.maximum(np.abs(o_spec), np.abs(o_mono)) + 1e-13 * np.abs(mono[y, x])
+        assert np.all(np.abs(got - want) <= tol), (x, y, got, want)
+        worst = max(worst, float(np.max(np.abs(got - want) / np.maximum(np.abs(o_spec), 1e-300))))
+    assert worst < 1e-9
+
+
 def test_read_tile_strides_and_pixel(pkg, lf):
     case = Case("f64x48_pentbiglines")
     _setup(pkg, lf, case)

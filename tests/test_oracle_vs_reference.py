@@ -97,6 +97,25 @@ def test_raytrace_pixel_matches_reference(name):
     assert np.array_equal(got_rgba, ref_rgba)
 
 
+def test_spectral_starburst_reduces_to_the_reference_formula():
+    """Row f4 has no reference counterpart (parity unpinned), but one wavelength with scale 1 and
+    weight (1,1,1) must BE the reference's starburst: compare the spectral restatement with
+    lfo_starburst_pixel, which the golden frames above pin to the real reference."""
+    case = Case("f64x48_pentbiglines")
+    f = _frame(case)
+    tex, st = lfo.aperture_from_red(load_red(case.meta["aperture"]))
+    rng = np.random.default_rng(1)
+    for x, y in zip(rng.integers(0, case.W, 24), rng.integers(0, case.H, 24)):
+        ref, _ = lfo.starburst_pixel(f, tex, st, int(x), int(y))
+        got = lfo.starburst_pixel_spectral(f, tex, st, int(x), int(y), [1.0], [[1.0, 1.0, 1.0]])
+        assert np.all(np.abs(got - ref) <= 1e-9 * np.abs(ref)), (x, y, got, ref)
+    # and it is linear in the weights / additive over wavelengths
+    a = lfo.starburst_pixel_spectral(f, tex, st, 40, 20, [0.9], [[1.0, 0.0, 0.5]])
+    b = lfo.starburst_pixel_spectral(f, tex, st, 40, 20, [1.15], [[0.0, 2.0, 0.5]])
+    ab = lfo.starburst_pixel_spectral(f, tex, st, 40, 20, [0.9, 1.15], [[1.0, 0.0, 0.5], [0.0, 2.0, 0.5]])
+    assert np.allclose(ab, a + b, rtol=1e-13, atol=0)
+
+
 @pytest.mark.parametrize("name", ["s96x64_spheres", "s80x60_tris_rotcam"])
 def test_scene_term_oracle_matches_reference(name):
     """Row f2: the sample loop of raytrace_pixel with real geometry (oracle/lf_scene_oracle.c):
