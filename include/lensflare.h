@@ -141,6 +141,26 @@ lf_status lf_set_scene(lf_ctx* ctx, int n_spheres, const double* spheres, const 
                        int n_triangles, const double* tri_positions, const double* tri_normals,
                        const int* tri_material, int n_materials, const double* materials,
                        int n_lights, const double* lights);
+/* Row f3: a COLLADA file -> the static scene, in one call.  Replaces
+ * Collada::ColladaParser::load (src/scene/collada/collada.cpp:131-218) + Application::load
+ * (src/application/application.cpp:232-365) + the GLScene -> SceneObjects conversion behind them
+ * (gl_scene/mesh.cpp, util/halfEdgeMesh.cpp, scene/object.cpp, gl_scene/ *_light.h): parses the file
+ * on the host (lens-flare_amd/host/lf_collada.cpp; triangles, vertex normals, lights and camera come
+ * out bit-identical to the reference's, tests/test_collada_loader.py) and hands the result to
+ * lf_set_scene.  Lights are uploaded in node order, directional and point lights only.
+ *   camera          (may be NULL) what Application::load derives from the file's camera node(s)
+ *   sun_lights      (may be NULL) for lf_find_sun_pos: 6 doubles per DirectionalLight, posLight
+ *                   xyz + radiance rgb; at most max_sun_lights are written, *n_sun_lights = found
+ * LF_ERR_INVALID with a message if the file has what the device scene term refuses (area, spot or
+ * hemisphere lights, mirror / glass / microfacet / refraction BSDFs) or what the reference itself
+ * cannot load (it exits or reads uninitialised memory there). */
+typedef struct {
+  int present;
+  double hfov, vfov, nclip, fclip;
+  double pos[3], dir[3], up[3];
+} lf_collada_camera;
+lf_status lf_load_collada(lf_ctx* ctx, const char* path, lf_collada_camera* camera,
+                          double* sun_lights, int max_sun_lights, int* n_sun_lights);
 /* replaces the public fields samplesPerBatch / maxTolerance (pathtracer.h:112-113) and
  * Camera::nClip / fClip (camera.h:188) */
 lf_status lf_set_sampling(lf_ctx* ctx, int samples_per_batch, double max_tolerance, double n_clip,

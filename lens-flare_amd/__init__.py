@@ -31,7 +31,7 @@ ABI_SYMBOLS = [
     "lf_set_sampling", "lf_render_scene_term",
     "lf_generate_ghost_buffer", "lf_render_flare_layer", "lf_read_tile", "lf_read_pixel",
     "lf_write_to_framebuffer", "lf_save_image_rgba", "lf_device_buffer", "lf_set_lens", "lf_set_lambda_rgb", "lf_set_sun",
-    "lf_set_ghost_pairs", "lf_trace_ghosts", "lf_generate_lens_rays", "lf_get_counters", "lf_reset_counters", "lf_get_executed_events", "lf_native_sqrt", "lf_set_starburst_spectrum",
+    "lf_set_ghost_pairs", "lf_trace_ghosts", "lf_generate_lens_rays", "lf_get_counters", "lf_reset_counters", "lf_get_executed_events", "lf_native_sqrt", "lf_set_starburst_spectrum", "lf_load_collada",
     "lf_timing_enable", "lf_timing_reset", "lf_timing_get",
 ]
 
@@ -45,6 +45,11 @@ class LensFlareError(RuntimeError):
 class ApertureStats(C.Structure):
     _fields_ = [("width", C.c_int), ("height", C.c_int), ("min_x", C.c_int), ("min_y", C.c_int),
                 ("max_x", C.c_int), ("max_y", C.c_int), ("total_value", C.c_double)]
+
+
+class ColladaCamera(C.Structure):
+    _fields_ = [("present", C.c_int), ("hfov", C.c_double), ("vfov", C.c_double), ("nclip", C.c_double),
+                ("fclip", C.c_double), ("pos", C.c_double * 3), ("dir", C.c_double * 3), ("up", C.c_double * 3)]
 
 
 class Counters(C.Structure):
@@ -244,6 +249,20 @@ class LensFlare:
                                        len(tp), _fp(tpa, C.c_double), _fp(tna, C.c_double),
                                        _fp(tma, C.c_int), len(mats), _fp(ma, C.c_double),
                                        len(lights), _fp(la, C.c_double)))
+
+    def load_collada(self, path, max_suns=8):
+        """Row f3: parse a .dae, upload its static scene; returns (camera dict or None, sun lights
+        as [[px, py, pz, r, g, b], ...] for find_sun_pos)."""
+        cam = ColladaCamera()
+        suns = np.zeros((max_suns, 6), np.float64)
+        n = C.c_int(0)
+        self._ck(self.lib.lf_load_collada(self.ctx, os.fsencode(path), C.byref(cam), _fp(suns, C.c_double),
+                                          max_suns, C.byref(n)))
+        camera = None
+        if cam.present:
+            camera = dict(hfov=cam.hfov, vfov=cam.vfov, nclip=cam.nclip, fclip=cam.fclip,
+                          pos=list(cam.pos), dir=list(cam.dir), up=list(cam.up))
+        return camera, suns[:min(n.value, max_suns)].tolist()
 
     def set_sampling(self, samples_per_batch=32, max_tolerance=0.05, n_clip=0.01, f_clip=100.0):
         self._ck(self.lib.lf_set_sampling(self.ctx, int(samples_per_batch), C.c_double(max_tolerance),

@@ -7,6 +7,7 @@
 #include <cstring>
 
 #include "lf_internal.h"
+#include "../host/lf_collada.h"
 
 lf_status lf_fail(const lf_ctx* ctx, lf_status st, const std::string& msg) {
   if (ctx) ctx->err = msg;
@@ -672,6 +673,61 @@ lf_status lf_generate_lens_rays(lf_ctx* ctx, int lambda, size_t n, const float* 
   if (st != LF_OK) return st;
   LF_HIP(ctx, e);
   return LF_OK;
+}
+
+lf_status lf_load_collada(lf_ctx* ctx, const char* path, lf_collada_camera* camera, double* sun_lights,
+                          int max_sun_lights, int* n_sun_lights) {
+  if (!ctx || !path) return LF_ERR_INVALID;
+  lfamd::ColladaScene sc;
+  std::string err;
+  if (!lfamd::load_collada(path, sc, err)) return lf_fail(ctx, LF_ERR_INVALID, "lf_load_collada: " + err);
+  std::vector<double> sph, tp, tn, mats, lights;
+  std::vector<int> sph_m, tri_m;
+  for (const auto& m : sc.materials) {
+    // only the materials some primitive uses have to be shadeable
+    mats.push_back(m.kind == lfamd::BSDF_EMISSION ? 1.0 : 0.0);
+    mats.push_back(m.rgb.x); mats.push_back(m.rgb.y); mats.push_back(m.rgb.z);
+  }
+  auto check_mat = [&](int m) { return sc.materials[m].kind == lfamd::BSDF_DIFFUSE || sc.materials[m].kind == lfamd::BSDF_EMISSION; };
+  for (const auto& s : sc.spheres) {
+    if (!check_mat(s.material)) return lf_fail(ctx, LF_ERR_INVALID, "lf_load_collada: a sphere uses a mirror/glass/refraction/microfacet BSDF (stubs in the reference, refused here)");
+    sph.insert(sph.end(), {s.o.x, s.o.y, s.o.z, s.r});
+    sph_m.push_back(s.material);
+  }
+  for (const auto& t : sc.triangles) {
+    if (!check_mat(t.material)) return lf_fail(ctx, LF_ERR_INVALID, "lf_load_collada: a mesh uses a mirror/glass/refraction/microfacet BSDF (stubs in the reference, refused here)");
+    for (int k = 0; k < 3; k++) { tp.push_back(t.p[k].x); tp.push_back(t.p[k].y); tp.push_back(t.p[k].z); }
+    for (int k = 0; k < 3; k++) { tn.push_back(t.n[k].x); tn.push_back(t.n[k].y); tn.push_back(t.n[k].z); }
+    tri_m.push_back(t.material);
+  }
+  int n_sun = 0;
+  for (const auto& l : sc.lights) {
+    if (l.type == lfamd::LIGHT_DIRECTIONAL) {
+      lights.insert(lights.end(), {0.0, l.direction.x, l.direction.y, l.direction.z, l.radiance.x, l.radiance.y, l.radiance.z});
+      if (sun_lights && n_sun < max_sun_lights) {
+        double* o = sun_lights + 6 * n_sun;
+        o[0] = l.position.x; o[1] = l.position.y; o[2] = l.position.z;
+        o[3] = l.radiance.x; o[4] = l.radiance.y; o[5] = l.radiance.z;
+      }
+      n_sun++;
+    } else if (l.type == lfamd::LIGHT_POINT) {
+      lights.insert(lights.end(), {1.0, l.position.x, l.position.y, l.position.z, l.radiance.x, l.radiance.y, l.radiance.z});
+    } else {
+      return lf_fail(ctx, LF_ERR_INVALID, "lf_load_collada: area / spot / hemisphere lights are not supported by the device scene term");
+    }
+  }
+  if (n_sun_lights) *n_sun_lights = n_sun;
+  if (camera) {
+    std::memset(camera, 0, sizeof(*camera));
+    const auto& c = sc.camera;
+    camera->present = c.present ? 1 : 0;
+    camera->hfov = c.hFov; camera->vfov = c.vFov; camera->nclip = c.nClip; camera->fclip = c.fClip;
+    camera->pos[0] = c.pos.x; camera->pos[1] = c.pos.y; camera->pos[2] = c.pos.z;
+    camera->dir[0] = c.dir.x; camera->dir[1] = c.dir.y; camera->dir[2] = c.dir.z;
+    camera->up[0] = c.up.x; camera->up[1] = c.up.y; camera->up[2] = c.up.z;
+  }
+  return lf_set_scene(ctx, (int)sph_m.size(), sph.data(), sph_m.data(), (int)tri_m.size(), tp.data(), tn.data(),
+                      tri_m.data(), (int)sc.materials.size(), mats.data(), (int)(lights.size() / 7), lights.data());
 }
 
 lf_status lf_set_starburst_spectrum(lf_ctx* ctx, int n, const double* scale, const double* rgb_weights) {

@@ -165,6 +165,7 @@ def run_case(c, tmp):
     lights = []
     for ns, rad, dist in c["lights"]:
         lights.append(light_for(ns, c2w, pos, hf, vf, dist) + list(rad))
+    lights += [list(l) for l in c.get("raw_lights", [])]   # world-space posLight + radiance as given
     spec = ";".join(",".join(repr(float(v)) for v in l) for l in lights)
     visit = "tiles"
     order_xy = None

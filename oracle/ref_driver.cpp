@@ -16,6 +16,8 @@
 //   ref_dump frame <camfile> <W> <H> <ns_aa> <flare_radius> <flare_intensity>
 //            <aperture.png> <ghost.png> <lights: lx,ly,lz,Lr,Lg,Lb[;...]>
 //            <visit: tiles | list:<file>> <outprefix>
+//   ref_dump collada <scene.dae> <out.txt>      (row f3: the reference's ColladaParser + the
+//            GLScene -> SceneObjects conversion Application::load performs, dumped as hex floats)
 
 #include <cstdio>
 #include <cstdlib>
@@ -24,9 +26,22 @@
 #include <string>
 #include <vector>
 
+// the dump reads private members of the reference's BSDF classes (reflectance, radiance); the
+// reference's sources are left untouched, only this test tool sees them as public
+#define private public
+#include "pathtracer/bsdf.h"
+#undef private
 #include "pathtracer/pathtracer.h"
 #include "pathtracer/camera.h"
-#include "pathtracer/bsdf.h"
+#include "scene/collada/collada.h"
+#include "scene/gl_scene/scene.h"
+#include "scene/gl_scene/mesh.h"
+#include "scene/gl_scene/sphere.h"
+#include "scene/gl_scene/ambient_light.h"
+#include "scene/gl_scene/area_light.h"
+#include "scene/gl_scene/directional_light.h"
+#include "scene/gl_scene/point_light.h"
+#include "scene/gl_scene/spot_light.h"
 #include "scene/light.h"
 #include "scene/object.h"
 #include "scene/sphere.h"
@@ -272,6 +287,103 @@ static int cmd_frame(int argc, char** argv) {
   return 0;
 }
 
+// ---- row f3: COLLADA -> flat scene, through the reference's own classes ------------------------
+static void put3(FILE* o, const char* tag, const Vector3D& v) {
+  fprintf(o, " %s %a %a %a", tag, v.x, v.y, v.z);
+}
+static void put_bsdf(FILE* o, BSDF* b) {
+  if (DiffuseBSDF* d = dynamic_cast<DiffuseBSDF*>(b)) { fprintf(o, " bsdf diffuse"); put3(o, "rgb", d->reflectance); }
+  else if (EmissionBSDF* e = dynamic_cast<EmissionBSDF*>(b)) { fprintf(o, " bsdf emission"); put3(o, "rgb", e->radiance); }
+  else if (dynamic_cast<MirrorBSDF*>(b)) fprintf(o, " bsdf mirror");
+  else if (dynamic_cast<GlassBSDF*>(b)) fprintf(o, " bsdf glass");
+  else if (dynamic_cast<RefractionBSDF*>(b)) fprintf(o, " bsdf refraction");
+  else if (dynamic_cast<MicrofacetBSDF*>(b)) fprintf(o, " bsdf microfacet");
+  else fprintf(o, " bsdf other");
+}
+
+static int cmd_collada(int argc, char** argv) {
+  if (argc < 4) return 2;
+  Collada::SceneInfo* info = new Collada::SceneInfo();
+  if (Collada::ColladaParser::load(argv[2], info) < 0) { fprintf(stderr, "cannot load %s\n", argv[2]); return 1; }
+  FILE* o = fopen(argv[3], "w");
+  if (!o) return 1;
+  // the node loop of Application::load (src/application/application.cpp:232-275)
+  Vector3D c_pos = Vector3D(), c_dir = Vector3D();
+  for (size_t i = 0; i < info->nodes.size(); i++) {
+    Collada::Node& node = info->nodes[i];
+    Collada::Instance* instance = node.instance;
+    if (!instance) { fprintf(o, "node_without_instance\n"); continue; }
+    const Matrix4x4& transform = node.transform;
+    switch (instance->type) {
+      case Collada::Instance::CAMERA: {
+        Collada::CameraInfo* c = static_cast<Collada::CameraInfo*>(instance);
+        c_pos = (transform * Vector4D(c_pos, 1)).to3D();
+        c_dir = (transform * Vector4D(c->view_dir, 1)).to3D().unit();
+        fprintf(o, "camera hfov %a vfov %a nclip %a fclip %a", (double)c->hFov, (double)c->vFov,
+                (double)c->nClip, (double)c->fClip);
+        put3(o, "pos", c_pos); put3(o, "dir", c_dir); put3(o, "up", c->up_dir);
+        fprintf(o, "\n");
+        break;
+      }
+      case Collada::Instance::LIGHT: {
+        Collada::LightInfo& li = static_cast<Collada::LightInfo&>(*instance);
+        GLScene::SceneLight* gl = nullptr;   // Application::init_light (:322-343)
+        switch (li.light_type) {
+          case Collada::LightType::AMBIENT: gl = new GLScene::AmbientLight(li); break;
+          case Collada::LightType::DIRECTIONAL: gl = new GLScene::DirectionalLight(li, transform); break;
+          case Collada::LightType::AREA: gl = new GLScene::AreaLight(li, transform); break;
+          case Collada::LightType::POINT: gl = new GLScene::PointLight(li, transform); break;
+          case Collada::LightType::SPOT: gl = new GLScene::SpotLight(li, transform); break;
+          default: break;
+        }
+        if (!gl) { fprintf(o, "light none\n"); break; }
+        SceneObjects::SceneLight* sl = gl->get_static_light();
+        if (DirectionalLight* d = dynamic_cast<DirectionalLight*>(sl)) {
+          fprintf(o, "light directional"); put3(o, "rad", d->radiance); put3(o, "dir_to_light", d->dirToLight);
+          put3(o, "pos_light", d->posLight);
+        } else if (PointLight* pl = dynamic_cast<PointLight*>(sl)) {
+          fprintf(o, "light point"); put3(o, "rad", pl->radiance); put3(o, "pos", pl->position);
+        } else if (AreaLight* a = dynamic_cast<AreaLight*>(sl)) {
+          fprintf(o, "light area"); put3(o, "rad", a->radiance); put3(o, "pos", a->position);
+          put3(o, "dir", a->direction); put3(o, "dim_x", a->dim_x); put3(o, "dim_y", a->dim_y);
+        } else if (InfiniteHemisphereLight* h = dynamic_cast<InfiniteHemisphereLight*>(sl)) {
+          fprintf(o, "light hemisphere"); put3(o, "rad", h->radiance);
+        } else if (SpotLight* sp = dynamic_cast<SpotLight*>(sl)) {
+          fprintf(o, "light spot"); put3(o, "rad", sp->radiance); put3(o, "pos", sp->position);
+        } else fprintf(o, "light other");
+        fprintf(o, "\n");
+        break;
+      }
+      case Collada::Instance::SPHERE: {   // Application::init_sphere (:350-355)
+        Collada::SphereInfo& si = static_cast<Collada::SphereInfo&>(*instance);
+        const Vector3D position = (transform * Vector4D(0, 0, 0, 1)).projectTo3D();
+        double scale = (transform * Vector4D(1, 0, 0, 0)).to3D().norm();
+        GLScene::Sphere* gs = new GLScene::Sphere(si, position, scale);
+        SphereObject* so = dynamic_cast<SphereObject*>(gs->get_static_object());
+        fprintf(o, "sphere"); put3(o, "o", so->o); fprintf(o, " r %a", so->r); put_bsdf(o, so->get_bsdf());
+        fprintf(o, "\n");
+        break;
+      }
+      case Collada::Instance::POLYMESH: { // Application::init_polymesh (:357-360)
+        Collada::PolymeshInfo& pm = static_cast<Collada::PolymeshInfo&>(*instance);
+        GLScene::Mesh* gm = new GLScene::Mesh(pm, transform);
+        SceneObjects::SceneObject* obj = gm->get_static_object();
+        std::vector<Primitive*> prims = obj->get_primitives();
+        fprintf(o, "mesh %zu", prims.size()); put_bsdf(o, obj->get_bsdf()); fprintf(o, "\n");
+        for (Primitive* p : prims) {
+          Triangle* t = dynamic_cast<Triangle*>(p);
+          fprintf(o, "tri"); put3(o, "p1", t->p1); put3(o, "p2", t->p2); put3(o, "p3", t->p3);
+          put3(o, "n1", t->n1); put3(o, "n2", t->n2); put3(o, "n3", t->n3); fprintf(o, "\n");
+        }
+        break;
+      }
+      default: fprintf(o, "other_instance\n"); break;
+    }
+  }
+  fclose(o);
+  return 0;
+}
+
 int main(int argc, char** argv) {
   if (argc < 2) return 1;
   std::string c = argv[1];
@@ -279,5 +391,6 @@ int main(int argc, char** argv) {
   if (c == "trace") return cmd_trace(argc, argv);
   if (c == "convert") return cmd_convert(argc, argv);
   if (c == "frame") return cmd_frame(argc, argv);
+  if (c == "collada") return cmd_collada(argc, argv);
   return 1;
 }

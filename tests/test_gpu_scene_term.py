@@ -78,6 +78,41 @@ def test_scene_term_matches_reference(pkg, lf, name):
     assert np.array_equal(lf.write_to_framebuffer(0, 0, case.W, case.H), case.rgba)
 
 
+def test_collada_file_end_to_end(pkg, lf):
+    """Row f3 + f2 + the flare path together: lf_load_collada(pyramid.dae) -- 138 triangles with the
+    reference's half-edge vertex normals, two point lights and the sun -- rendered on the device
+    against the frame the REAL reference renders from what its own COLLADA loader made of the same
+    file (tests/golden/c96x72_pyramid_dae.npz, oracle/make_golden_collada.py)."""
+    import os
+    case = Case("c96x72_pyramid_dae")
+    m = case.meta
+    lf.set_frame(case.W, case.H)
+    lf.set_params(m["ns_aa"], m["flare_radius"], m["flare_intensity"])
+    lf.set_sampling(32, 0.05, 0.01, 100.0)
+    lf.set_paraxial_lens()
+    lf.set_aperture(pkg.APERTURE_STARBURST, load_texels(m["aperture"]))
+    lf.set_aperture(pkg.APERTURE_GHOST, load_texels(m["ghost_aperture"]))
+    lf.set_flares(np.zeros((0, 2)), np.zeros((0, 3)), (0.0, 0.0), 0.0)
+    lf.set_camera(m["c2w"], m["cam_pos"], m["hFov"], m["vFov"])
+    dae = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "collada", "pyramid.dae")
+    cam, suns = lf.load_collada(dae)
+    assert cam is not None and abs(cam["hfov"] - 39.5978) < 1e-3
+    assert suns == m["lights"]              # the sun's "position" and radiance, bit for bit
+    lf.find_sun_pos(suns)
+    lf.set_jitter_mt19937(5489, None)
+    lf.render_scene_term()
+    lf.generate_ghost_buffer()
+    lf.render_flare_layer()
+    got = lf.read_buffer(pkg.SAMPLE_BUFFER)
+    err = np.abs(got - case.sample) / np.abs(case.sample)
+    assert err.max() <= 1e-9, err.max()
+    scene = case.sample - case.ghost - lf.read_buffer(pkg.STARBURST_BUFFER)
+    assert (scene.max(axis=-1) > 0.02).mean() > 0.25     # the pyramids fill a good part of the frame
+    assert np.array_equal(lf.write_to_framebuffer(0, 0, case.W, case.H), case.rgba)
+    with pytest.raises(pkg.LensFlareError):              # glass BSDFs: refused, not approximated
+        lf.load_collada(os.path.join(os.path.dirname(dae), "CBgems.dae"))
+
+
 def test_counter_jitter_converges_to_the_same_image(pkg, lf):
     """Order-free Philox pixel jitter: same estimator, different sub-pixel positions -> interior
     pixels (away from silhouettes) agree closely with the MT19937 frame."""
