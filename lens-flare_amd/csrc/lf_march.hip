@@ -326,23 +326,37 @@ void k_march(const LfLensDev* __restrict__ lens,
           if (run) {
             // plain events (refraction at a curved interface): straight-line body.  The last row
             // of a run may complete a path.
-            const LfEventRow* const run_end = e + run;
-            LfEventRow pl;
-            do {
-              pl = load_row(e);
+            // Two rows per iteration: both scalar loads go out together (one wait), and the
+            // pointer / counter / tally work is shared by two events.
+            unsigned k = run, live_sum = 0u;
+            LfEventRow pl = cur;
+            auto plain = [&](const LfEventRow& row) {
               lanemask geom_ok;
-              const lanemask ok = surface_event<false>(r, pl.zv, pl.curv, pl.radius, pl.h2, pl.eta,
-                                                       pl.eta2, false, false, pl.sgn, geom_ok);
+              const lanemask ok = surface_event<false>(r, row.zv, row.curv, row.radius, row.h2, row.eta,
+                                                       row.eta2, false, false, row.sgn, geom_ok);
               if ((alive & ~ok) != 0ull) {  // some ray ends here, in `mult` logical paths
                 vign32 += mult * (unsigned)__popcll(alive & ~geom_ok);
                 tir32 += mult * (unsigned)__popcll(alive & geom_ok & ~ok);
                 alive &= ok;
               }
-              const unsigned live = (unsigned)__popcll(alive);
-              ev32 += mult * live;   // logical events: one per path that shares this row
-              exec32 += live;        // computed events
+              live_sum += (unsigned)__popcll(alive);
+            };
+            while (k >= 2u) {
+              const LfEventRow ra = load_row(e), rb = load_row(e + 1);
+              plain(ra);
+              pl = ra; ++e; --k;
+              if (alive == 0ull) break;
+              plain(rb);
+              pl = rb; ++e; --k;
+              if (alive == 0ull) break;
+            }
+            if (k == 1u && alive != 0ull) {
+              pl = load_row(e);
+              plain(pl);
               ++e;
-            } while (e != run_end && alive != 0ull);
+            }
+            ev32 += mult * live_sum;   // logical events: one per path that shares these rows
+            exec32 += live_sum;        // computed events
             endfl = (unsigned)pl.flags;
           } else if (fl & LF_EV_STOP) {
             const lanemask ok = stop_event<false>(r, cur.zv, cur.h2, inv_stop_h, mask, a.mw, a.mh);
