@@ -193,6 +193,20 @@ void PathTracer::set_scene(int n_spheres, const double* spheres, const int* sphe
   frame_ready_ = false;
 }
 
+lf_collada_camera PathTracer::load_collada(const std::string& path) {
+  lf_collada_camera cam;
+  double suns[6 * LF_MAX_FLARES];
+  int n = 0;
+  check(lf_load_collada(ctx_, path.c_str(), &cam, suns, LF_MAX_FLARES, &n), "lf_load_collada");
+  lights.clear();
+  for (int k = 0; k < n && k < LF_MAX_FLARES; k++)
+    lights.push_back({Vector3D(suns[6 * k], suns[6 * k + 1], suns[6 * k + 2]),
+                      Vector3D(suns[6 * k + 3], suns[6 * k + 4], suns[6 * k + 5])});
+  device_scene_ = true;
+  frame_ready_ = false;
+  return cam;
+}
+
 void PathTracer::generate_ghost_buffer() {
   // pathtracer.cpp:714-817.  The reference fills ghost_buffer here and evaluates the starburst
   // later, pixel by pixel, inside raytrace_pixel; the device renders the whole flare layer now

@@ -131,6 +131,10 @@ class PathTracer {
   void set_scene(int n_spheres, const double* spheres, const int* sphere_material, int n_triangles,
                  const double* tri_positions, const double* tri_normals, const int* tri_material,
                  int n_materials, const double* materials, int n_lights, const double* scene_lights);
+  // the same from a COLLADA file: replaces ColladaParser::load + Application::load
+  // for the static scene; fills `lights` (the DirectionalLights find_sun_pos projects) and returns
+  // the file's camera block (present = 0 if it has none)
+  lf_collada_camera load_collada(const std::string& path);
   uint32_t jitter_seed = 5489;     // std::mt19937 default, reference visit order (32x32 tiles)
   bool counter_jitter = false;     // order-free Philox jitter instead
   lf_ctx* context() { return ctx_; }
