@@ -801,14 +801,15 @@ lf_status lfk_march(lf_ctx* ctx, int spp, uint64_t key) {
   const int n_trows = (t_hi - 1 - first) / period + 1;
   a.trow0 = first; a.tperiod = period;
   const size_t tiles = (size_t)n_trows * ((ctx->W + 7) / 8);
-  // keep >= 16k workgroups in flight so the tail of the launch stays short: split each tile's
-  // samples over `sgroups` workgroups (power of two, at least one sample per wave).  Measured with
-  // profiles/share_timing.py on the bench frame (ms for 1, 1/2, 1/4, 1/8 of the tile rows):
-  // sgroups 1: 155.7 80.3 41.9 22.6 | 2: 154.3 78.6 40.1 20.9 | 4: 157.2 79.5 40.0 20.3 |
-  // 8: 169.4 85.5 42.8 21.6 -- a workgroup needs >= ~32 samples to amortise its set-up and its
-  // 192 global atomics, and two groups per tile already beat one.
-  a.sgroups = spp >= 64 ? 2 : 1;
-  while (tiles * a.sgroups < 16000 && a.sgroups * 2 * 4 <= spp) a.sgroups *= 2;
+  // A launch that covers only part of the frame (one GPU's share) keeps >= 24k workgroups in flight
+  // by splitting each tile's samples over `sgroups` workgroups (power of two), so that its tail
+  // stays short -- but a workgroup needs >= 64 samples to amortise its set-up and its 192 global
+  // atomics.  Measured with profiles/share_timing.py on the bench frame (ms for 1, 1/2, 1/4, 1/8 of
+  // the tile rows): sgroups 1: 155.7 80.3 41.9 22.6 | 2: 154.3 78.6 40.1 20.9 |
+  // 4: 157.2 79.5 40.0 20.3 | 8: 169.4 85.5 42.8 21.6.  The whole frame on one GPU stays unsplit:
+  // the split costs 5x the HBM write traffic (atomics) for 1 % of time.
+  a.sgroups = 1;
+  while (tiles * a.sgroups < 24000 && a.sgroups * 2 * 64 <= spp) a.sgroups *= 2;
   if (const char* sgv = std::getenv("LF_MARCH_SGROUPS")) {  // experiments only
     int v = std::atoi(sgv);
     if (v >= 1 && v * 4 <= std::max(4, spp) && (v & (v - 1)) == 0) a.sgroups = v;
