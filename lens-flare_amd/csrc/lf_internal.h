@@ -121,9 +121,9 @@ struct LfPairsDev {
   int prog_rows;                 // rows of the program per wavelength
 };
 
-// One pre-expanded surface event of one (wavelength, pair) sequence: everything the march needs for
-// it in ONE 32-byte scalar load.  The table (n_lambda x total_events rows, ~85 KB for the bench
-// lens) is walked linearly, so the next row is prefetched while the current event computes.
+// One pre-expanded surface event: everything the march needs for it in ONE 32-byte scalar load.
+// Two tables use it: the flat per-(wavelength, pair) sequences (n_lambda x total_events rows, read
+// only by the rare weight re-march) and the per-wavelength path-tree program (see LF_EV_SAVE0).
 struct alignas(32) LfEventRow {
   float zv, curv, h2, eta;
   float sgn;       // +1: the ray travels +z (towards the sensor), -1: -z
@@ -210,7 +210,7 @@ struct lf_ctx {
   LfPairsDev pairs{};
   LfPairsDev* pairs_dev = nullptr;
   unsigned long long* counters_dev = nullptr;  // 8 x u64
-  unsigned long long* accum = nullptr;         // unused for now
+  unsigned long long* accum = nullptr;         // W*H_alloc*3 fixed-point partial sums (split launches)
   LfEventRow* events_dev = nullptr;            // n_lambda x total_events, then n_lambda x prog_rows
   size_t events_cap = 0;
   int* skip_dev = nullptr;                     // prog_rows entries: where a dead wave jumps to

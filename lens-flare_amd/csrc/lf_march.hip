@@ -7,28 +7,32 @@
 // interfaces, once per wavelength and per ghost pair (i, j):
 //     refract N-1 .. i+1, reflect at i, refract i+1 .. j-1, reflect at j, refract j-1 .. 0
 // (N + 2(j-i) surface events; the primary path is N refractions).  Each event = intersection +
-// semi-aperture test + Snell refraction or mirror reflection + unpolarised Fresnel weight; the
+// semi-aperture test + Snell refraction or mirror reflection (+ unpolarised Fresnel weight); the
 // stop is a flat pass-through interface whose event is the aperture-mask lookup.  A ray that
 // leaves the front element collects the sun's radiance through a smooth angular lobe.
 //
-// Mapping to CDNA4 (v2, "coherent wavefronts by construction"):
+// Mapping to CDNA4 (DESIGN.md section 3 has the measurements behind each point):
 //   * one wave = one 8x8 sensor tile, one lane = one pixel; the wave walks sample index s,
-//     wavelength and ghost pair together, so the interface sequence is wave-uniform and every
+//     wavelength and path together, so the interface sequence is wave-uniform and every
 //     per-interface constant comes from the scalar cache into SGPRs (no LDS/VGPR traffic for the
 //     lens table at all);
-//   * the pupil is stratified (G x G cells, G = floor(sqrt(spp))): sample s of EVERY pixel aims at
-//     cell s, jittered per pixel.  All 64 lanes of a wave therefore cross the stop in the same
-//     1/G^2 patch of the aperture mask and are clipped (or not) together -- the profile of v1
-//     (profiles/r01_v1_*) showed 58 % of VALU lanes idle because random pupil points made lanes
-//     die at different events; a wave whose lanes are all dead leaves the sequence at once;
-//   * the 4 waves of a workgroup share the tile and split the sample indices; per-pixel sums are
-//     64-bit fixed point in registers, merged through LDS, written once per tile.
+//   * the pupil is stratified (G x G cells, G = floor(sqrt(spp)), 4 x 4 sub-cells per tile and
+//     sample): the 64 lanes of a wave cross the stop in the same small patch of the aperture mask
+//     and share their fate; a wave whose lanes are all dead skips what only they would visit;
+//   * the paths of one (sample, wavelength) are walked as ONE tree (build_program): the backward
+//     leg from the sensor and the forward leg after the reflection at i are computed once for all
+//     the pairs that share them; forks park the ray state in LDS;
+//   * the first pass carries geometry only; the Fresnel / aperture weight is computed by
+//     re-marching the one path, and only for waves in which a lane reaches the sun's lobe;
+//   * the 4 waves of a workgroup share the tile and pull sample indices from an LDS counter;
+//     per-pixel sums are 64-bit fixed point in registers, merged through LDS, written once.
 //
 // Arithmetic contract (DESIGN.md "march arithmetic"): float32, every multiply-add written as an
-// explicit fmaf, IEEE-correct division and square root (__fdiv_rn / lf_sqrt), no other libm.
-// Contributions are accumulated as 2^-36 fixed point in 64-bit integers, so the result does not
-// depend on the order in which lanes finish.  The CPU oracle (oracle/lf_geo_oracle.c) follows the
-// same contract, which makes pixels and event counters comparable bit for bit.
+// explicit fmaf, IEEE-correct division (__fdiv_rn), the hardware's v_sqrt_f32 (lf_sqrt; the oracle
+// follows it through a measured deviation table), no libm.  Contributions are accumulated as 2^-36
+// fixed point in 64-bit integers, so the result does not depend on the order in which lanes
+// finish.  The CPU oracle (oracle/lf_geo_oracle.c) follows the same contract and marches every
+// path on its own, which makes pixels and event counters comparable bit for bit.
 #include <algorithm>
 #include <cstring>
 #include <utility>
