@@ -334,6 +334,21 @@ void k_march(const LfLensDev* __restrict__ lens,
             // pointer / counter / tally work is shared by two events.
             unsigned k = run, live_sum = 0u;
             LfEventRow pl = cur;
+            if (fl & LF_EV_REFLECT) {
+              // the run starts with a (curved) mirror: the fork of a sub-tree or of one pair
+              if (fl & LF_EV_SAVE0) { park(s_state[wave][0], lane, r); alive0 = alive; }
+              if (fl & LF_EV_SAVE1) { park(s_state[wave][1], lane, r); alive1 = alive; }
+              lanemask geom_ok;
+              const lanemask ok = surface_event<false>(r, cur.zv, cur.curv, cur.radius, cur.h2, cur.eta,
+                                                       cur.eta2, true, false, cur.sgn, geom_ok);
+              if ((alive & ~ok) != 0ull) {
+                vign32 += mult * (unsigned)__popcll(alive & ~geom_ok);
+                alive &= ok;
+              }
+              live_sum += (unsigned)__popcll(alive);
+              ++e; --k;
+              if (alive == 0ull) k = 0u;
+            }
             auto plain = [&](const LfEventRow& row) {
               lanemask geom_ok;
               const lanemask ok = surface_event<false>(r, row.zv, row.curv, row.radius, row.h2, row.eta,
@@ -679,13 +694,21 @@ static void build_program(const LfLensDev& L, const LfPairsDev& P, int l, std::v
   }
   for (int r : prefix_rows) { target[r] = (int)prog.size(); restore[r] = 0; }
   // runs of plain rows (no flag in the low byte, the same multiplicity)
-  // (a row that only completes a path is plain as well, but nothing can follow it in its run)
+  // (a row that only completes a path is plain as well, but nothing can follow it in its run; a
+  // curved mirror -- the fork rows -- may START a run: the plain rows of its leg follow in the
+  // same pass of the walk)
   const int special = LF_EV_REFLECT | LF_EV_STOP | LF_EV_FLAT | LF_EV_SAVE0 | LF_EV_SAVE1;
   for (int r = (int)prog.size() - 1, run = 0; r >= 0; r--) {
-    const bool plain = (prog[r].flags & special) == 0;
-    const bool chain = plain && !(prog[r].flags & LF_EV_END) && run > 0 && run < 255 &&
-                       ((prog[r + 1].flags >> 16) & 0xff) == ((prog[r].flags >> 16) & 0xff);
-    run = plain ? (chain ? run + 1 : 1) : 0;
+    const int f = prog[r].flags;
+    const bool plain = (f & special) == 0;
+    const bool mirror = (f & LF_EV_REFLECT) && !(f & (LF_EV_STOP | LF_EV_FLAT | LF_EV_END));
+    const bool same_mult = r + 1 < (int)prog.size() &&
+                           ((prog[r + 1].flags >> 16) & 0xff) == ((f >> 16) & 0xff);
+    const bool next_plain = r + 1 < (int)prog.size() && (prog[r + 1].flags & special) == 0;
+    const bool chain = !(f & LF_EV_END) && run > 0 && run < 255 && same_mult && next_plain;
+    if (plain) run = chain ? run + 1 : 1;
+    else if (mirror) { prog[r].flags |= (chain ? run + 1 : 1) << 8; run = 0; continue; }
+    else run = 0;
     prog[r].flags |= run << 8;
   }
   for (size_t r = 0; r < prog.size(); r++)  // a dead wave must always move forward, inside the program
