@@ -235,6 +235,23 @@ lf_status lf_trace_ghosts(lf_ctx* ctx, int spp, uint64_t key);
  * alive (1/0)} in lens space (optical axis = z, light travels +z, the scene lies at z < 0). */
 lf_status lf_generate_lens_rays(lf_ctx* ctx, int lambda, size_t n, const float* sensor_xy_mm,
                                 const float* pupil_uv, float* out);
+/* Host logic of the march, inspectable WITHOUT a device (used by the CPU tests): builds what
+ * lf_trace_ghosts uploads for a prescription and a pair selection (arguments as lf_set_lens /
+ * lf_set_ghost_pairs; pairs = NULL selects every glass pair).
+ *   info   int[8 + 4 (LF_MAX_PAIRS + 1)]: {n_paths, flat rows per wavelength, first program row,
+ *          program rows per wavelength, total rows, jump-table entries, 0, 0} then per path
+ *          {i, j, first flat row, flat rows}
+ *   rows   8 x 4 bytes per row: zv, curv, h2, eta, sgn (floats), flags (int), radius, eta^2 (floats);
+ *          n_lambda x flat sequences, then n_lambda x the path-tree program, then one spare row
+ *   skip   one int per program row: (rows to jump << 2) | state to restore, for a wave that is dead
+ * flags: 1 mirror, 2 stop, 4 flat, 8 restore slot 1 after END, 0x10 / 0x20 park in slot 0 / 1
+ * before the event, 0x40 END of a path, 0x80 restore slot 0 after END; bits 8-15 run length,
+ * 16-23 number of paths sharing the row, 24-31 the path an END row completes.
+ * rows / skip may be NULL to query the sizes (info[4], info[5]) first. */
+lf_status lf_march_tables(int n_surfaces, int stop_index, int n_lambda, const float* radius,
+                          const float* thickness, const float* ior, const float* semi_aperture,
+                          const int* pairs, int n_pairs, int include_primary, int* info,
+                          float* rows, size_t rows_cap, int* skip, size_t skip_cap);
 /* Spectral starburst (no reference counterpart -- the reference's
  * starburst, pathtracer.cpp:947-1000, is monochrome).  n = 0 restores the reference behaviour.
  * Wavelength l sees the reference's diffraction pattern magnified by 1 / scale[l]

@@ -675,6 +675,37 @@ lf_status lf_generate_lens_rays(lf_ctx* ctx, int lambda, size_t n, const float* 
   return LF_OK;
 }
 
+lf_status lf_march_tables(int n_surfaces, int stop_index, int n_lambda, const float* radius,
+                          const float* thickness, const float* ior, const float* semi_aperture,
+                          const int* pairs, int n_pairs, int include_primary, int* info,
+                          float* rows, size_t rows_cap, int* skip, size_t skip_cap) {
+  if (!info) return LF_ERR_INVALID;
+  lf_ctx ctx;          // plain host state: nothing below touches the device
+  ctx.W = ctx.H = 64;
+  lf_status st = lf_set_lens(&ctx, n_surfaces, stop_index, n_lambda, radius, thickness, ior, semi_aperture, 36.0f);
+  if (st == LF_OK && (pairs || !include_primary)) st = lf_set_ghost_pairs(&ctx, pairs, n_pairs, include_primary);
+  std::vector<LfEventRow> r;
+  std::vector<int> sk;
+  if (st == LF_OK) st = lf_build_march_tables(&ctx, r, sk);
+  if (st != LF_OK) return st;
+  const LfPairsDev& P = ctx.pairs;
+  info[0] = P.n; info[1] = P.total_events; info[2] = P.prog_off; info[3] = P.prog_rows;
+  info[4] = (int)r.size(); info[5] = (int)sk.size();
+  for (int q = 0; q < P.n && q < LF_MAX_PAIRS + 1; q++) {
+    info[8 + 4 * q] = P.ij[q][0]; info[8 + 4 * q + 1] = P.ij[q][1];
+    info[8 + 4 * q + 2] = P.ev_off[q]; info[8 + 4 * q + 3] = P.ev_cnt[q];
+  }
+  if (rows) {
+    if (rows_cap < r.size() * 8) return LF_ERR_INVALID;
+    std::memcpy(rows, r.data(), r.size() * sizeof(LfEventRow));
+  }
+  if (skip) {
+    if (skip_cap < sk.size()) return LF_ERR_INVALID;
+    std::memcpy(skip, sk.data(), sk.size() * sizeof(int));
+  }
+  return LF_OK;
+}
+
 lf_status lf_load_collada(lf_ctx* ctx, const char* path, lf_collada_camera* camera, double* sun_lights,
                           int max_sun_lights, int* n_sun_lights) {
   if (!ctx || !path) return LF_ERR_INVALID;

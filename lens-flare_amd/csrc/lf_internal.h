@@ -246,6 +246,7 @@ lf_status lfk_flip_rows(lf_ctx* ctx, uint32_t* out_dev);
 lf_status lfk_march(lf_ctx* ctx, int spp, uint64_t key);
 lf_status lfk_lens_rays(lf_ctx* ctx, int lambda, int n, const float* d_xy, const float* d_uv,
                         float* d_out);
+lf_status lf_build_march_tables(lf_ctx* ctx, std::vector<LfEventRow>& rows, std::vector<int>& skip);
 lf_status lfk_native_sqrt(lf_ctx* ctx, const float* d_x, float* d_y, size_t n);
 void lf_derive_lens(lf_ctx* ctx, int n, int stop, int n_lambda, const float* radius,
                     const float* thickness, const float* ior, const float* semi_ap,

@@ -672,7 +672,7 @@ static void build_program(const LfLensDev& L, const LfPairsDev& P, int l, std::v
           put(m, true, true, last ? 0 : LF_EV_SAVE1, 1);
           for (int t = m - 1; t >= 0; t--)
             put(t, false, false,
-                t == 0 ? (LF_EV_END | (last ? LF_EV_REST0 : LF_EV_REST1) | (js[p].second << 24)) : 0, 1);
+                t == 0 ? (LF_EV_END | (last ? LF_EV_REST0 : LF_EV_REST1) | (int)((unsigned)js[p].second << 24)) : 0, 1);
           for (int r = leg_first; r < (int)prog.size(); r++) {
             target[r] = (int)prog.size();
             restore[r] = last ? 2 : 1;
@@ -689,7 +689,7 @@ static void build_program(const LfLensDev& L, const LfPairsDev& P, int l, std::v
     const int mult = (primary >= 0 ? 1 : 0) + below[k];
     if (mult > 0) {
       prefix_rows.push_back((int)prog.size());
-      put(k, false, false, (k == 0 && primary >= 0) ? (LF_EV_END | (primary << 24)) : 0, mult);
+      put(k, false, false, (k == 0 && primary >= 0) ? (LF_EV_END | (int)((unsigned)primary << 24)) : 0, mult);
     }
   }
   for (int r : prefix_rows) { target[r] = (int)prog.size(); restore[r] = 0; }
@@ -720,7 +720,9 @@ static void build_program(const LfLensDev& L, const LfPairsDev& P, int l, std::v
 }
 
 // host: expand every selected pair into its event rows (per wavelength), see LfEventRow
-static lf_status build_event_table(lf_ctx* ctx) {
+// host only (no device call): the flat sequences followed by the per-wavelength programs, and the
+// programs' jump table; fills the offsets of ctx->pairs
+lf_status lf_build_march_tables(lf_ctx* ctx, std::vector<LfEventRow>& rows, std::vector<int>& skip) {
   const LfLensDev& L = ctx->lens;
   LfPairsDev& P = ctx->pairs;
   int total = 0;
@@ -731,7 +733,7 @@ static lf_status build_event_table(lf_ctx* ctx) {
     total += P.ev_cnt[q];
   }
   P.total_events = total;
-  std::vector<LfEventRow> rows((size_t)total * L.n_lambda);
+  rows.assign((size_t)total * L.n_lambda, LfEventRow{});
   for (int l = 0; l < L.n_lambda; l++)
     for (int q = 0; q < P.n; q++) {
       LfEventRow* out = rows.data() + (size_t)l * total + P.ev_off[q];
@@ -766,7 +768,7 @@ static lf_status build_event_table(lf_ctx* ctx) {
       }
     }
   // the flat table is followed by the shared-prefix program (see LF_EV_SAVE0 in lf_internal.h)
-  std::vector<int> skip;
+  skip.clear();
   P.prog_off = (int)rows.size();
   {
     std::vector<LfEventRow> prog;
@@ -778,6 +780,14 @@ static lf_status build_event_table(lf_ctx* ctx) {
     }
   }
   rows.push_back(LfEventRow{});  // spare
+  return LF_OK;
+}
+
+static lf_status build_event_table(lf_ctx* ctx) {
+  std::vector<LfEventRow> rows;
+  std::vector<int> skip;
+  lf_status st = lf_build_march_tables(ctx, rows, skip);
+  if (st != LF_OK) return st;
   if (skip.size() > ctx->skip_cap) {
     if (ctx->skip_dev) { LF_HIP(ctx, hipStreamSynchronize(ctx->stream)); (void)hipFree(ctx->skip_dev); }
     ctx->skip_dev = nullptr;
