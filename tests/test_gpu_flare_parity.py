@@ -233,6 +233,18 @@ def test_error_codes(pkg):
     assert e.value.status == 1
     with pytest.raises(pkg.LensFlareError):
         pkg.LensFlare(99)
+    # newer entry points: bad arguments are refused with LF_ERR_INVALID and a message
+    with pytest.raises(pkg.LensFlareError) as e:
+        lf2.set_starburst_spectrum([1.0, -0.5], [[1, 1, 1], [1, 1, 1]])
+    assert e.value.status == 1 and "scale" in str(e.value)
+    with pytest.raises(pkg.LensFlareError):
+        lf2.set_starburst_spectrum([1.0] * 9, [[1, 1, 1]] * 9)      # more than LF_MAX_LAMBDA
+    with pytest.raises(pkg.LensFlareError) as e:
+        lf2.load_collada("/nonexistent/scene.dae")
+    assert e.value.status == 1 and "cannot open" in str(e.value)
+    with pytest.raises(pkg.LensFlareError) as e:
+        lf2.set_ghost_pairs([(0, 1)], True)                          # before lf_set_lens
+    assert e.value.status == 4
     lf2.close()
 
 
