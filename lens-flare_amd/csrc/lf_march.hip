@@ -70,7 +70,7 @@ __device__ __forceinline__ float u01(unsigned r) { return (float)(r >> 8) * 5.96
 
 // The transmitted weight is carried as a fraction wn / wd: every Fresnel factor is a ratio of
 // two cheap products, so the march multiplies numerators and denominators separately and divides
-// ONCE, and only for the ~0.02 % of rays that end inside the sun's lobe.
+// ONCE, and only for the ~0.4 % of rays that end inside the sun's lobe.
 struct Ray {
   float px, py, pz, dx, dy, dz, wn, wd;
 };
@@ -88,7 +88,7 @@ typedef unsigned long long lanemask;
 // carries the Fresnel / aperture weight.  The frame runs W = false for every ray and repeats the
 // sequence with W = true only for the waves in which some lane ended inside the sun's lobe (~1 % of
 // the wave-sequences): the weight is 15 of the 71 VALU instructions of an event and is read by
-// 0.02 % of the rays.  Both instantiations do the same arithmetic on the ray itself, so the
+// 0.4 % of the rays.  Both instantiations do the same arithmetic on the ray itself, so the
 // repeated march reproduces the first one bit for bit.
 template <bool W>
 __device__ __forceinline__ lanemask surface_event(Ray& r, float zv, float c, float rad, float h2,
