@@ -185,9 +185,12 @@ __device__ __forceinline__ lanemask stop_event(Ray& r, float zv, float h2, float
 
 // One event row as ONE 32-byte scalar load (left to itself the compiler sinks the eight field loads
 // into the branches that use them: 4-5 dependent scalar-cache round trips per event).
+// (read through the CONSTANT address space: such a load can never be clobbered by the kernel's own
+// stores, so it always qualifies for the scalar unit and may be scheduled freely)
 typedef int lf_i8 __attribute__((ext_vector_type(8)));
+typedef const lf_i8 __attribute__((address_space(4))) * lf_const_row_ptr;
 __device__ __forceinline__ LfEventRow load_row(const LfEventRow* __restrict__ e) {
-  const lf_i8 v = *reinterpret_cast<const lf_i8*>(e);
+  const lf_i8 v = *(lf_const_row_ptr)(e);
   LfEventRow r;
   r.zv = __int_as_float(v[0]); r.curv = __int_as_float(v[1]); r.h2 = __int_as_float(v[2]);
   r.eta = __int_as_float(v[3]); r.sgn = __int_as_float(v[4]); r.flags = v[5];
