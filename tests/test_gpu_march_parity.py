@@ -229,6 +229,31 @@ def test_full_size_properties(pkg, lf):
     assert np.array_equal(a[rows[0]:rows[1]], og[rows[0]:rows[1]])
 
 
+def test_whole_1080p_frame_bit_exact_at_2_spp(pkg, lf):
+    """The full BASELINE frame geometry -- 1920 x 1080, primary + 45 pairs, 3 wavelengths -- at 2 spp
+    is 1.1e9 rays: a few seconds for the oracle on all host cores.  Every pixel and every counter
+    of the whole frame, bit for bit (the device walks the path tree, the oracle each path)."""
+    import os
+    lens = pkg.load_lens_file("dgauss11.lens")
+    mask = load_texels("pentbig500_14.png")
+    W, H, spp = 1920, 1080, 2
+    lf.set_frame(W, H)
+    lf.set_aperture(pkg.APERTURE_STARBURST, mask)
+    lf.set_lens(lens)
+    lf.set_sun(SUN["direction"], SUN["radiance"], SUN["angular_radius"])
+    lf.set_ghost_pairs(None, True)
+    lf.reset_counters()
+    lf.trace_ghosts(spp, 2024)
+    g = lf.read_buffer(pkg.GHOST_BUFFER)
+    cnt = lf.counters()
+    og, ocnt = lfo.geo_trace(lens, W, H, 0, H, spp, 2024, None, True, mask, SUN["direction"],
+                             SUN["radiance"], SUN["angular_radius"], n_threads=os.cpu_count() or 8)
+    assert cnt == ocnt
+    assert np.array_equal(g, og)
+    assert cnt["rays_launched"] == W * H * spp * 3 * 46 and cnt["rays_hit_light"] > 10 ** 6
+    assert (g.max(axis=-1) > 0).mean() > 0.01     # the ghosts cover a visible part of the frame
+
+
 def test_lens_camera_generate_ray(pkg, lf):
     """lf_generate_lens_rays (= LensCamera::generate_ray, batched): the primary path sensor ->
     scene.  (a) every alive ray equals the CPU oracle's march of the same start ray (the oracle is
