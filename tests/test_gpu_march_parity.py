@@ -229,14 +229,15 @@ def test_full_size_properties(pkg, lf):
     assert np.array_equal(a[rows[0]:rows[1]], og[rows[0]:rows[1]])
 
 
-def test_whole_1080p_frame_bit_exact_at_2_spp(pkg, lf):
-    """The full BASELINE frame geometry -- 1920 x 1080, primary + 45 pairs, 3 wavelengths -- at 2 spp
-    is 1.1e9 rays: a few seconds for the oracle on all host cores.  Every pixel and every counter
-    of the whole frame, bit for bit (the device walks the path tree, the oracle each path)."""
+@pytest.mark.parametrize("W,H,spp", [(1920, 1080, 2), (3840, 2160, 1)])
+def test_whole_frame_bit_exact_at_low_spp(pkg, lf, W, H, spp):
+    """The full BASELINE frame geometries (configs[1-2]: 1080p, configs[3-4]: 4K) -- primary + 45
+    pairs, 3 wavelengths -- at 2 / 1 spp are 1.1e9 rays: a few seconds for the oracle on all host
+    cores.  Every pixel and every counter of the whole frame, bit for bit (the device walks the
+    path tree, the oracle each path)."""
     import os
     lens = pkg.load_lens_file("dgauss11.lens")
     mask = load_texels("pentbig500_14.png")
-    W, H, spp = 1920, 1080, 2
     lf.set_frame(W, H)
     lf.set_aperture(pkg.APERTURE_STARBURST, mask)
     lf.set_lens(lens)
