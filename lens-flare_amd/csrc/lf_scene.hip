@@ -101,31 +101,39 @@ __device__ inline bool hit_triangle(const LfPrim& t, DRay& r, Hit* h) {
 }
 
 // closest hit (BVHAccel::intersect, scene/bvh.cpp:201-222: the recursion shrinks r.max_t as it goes,
-// so whatever the visiting order the last accepted primitive is the closest one)
+// so whatever the visiting order the last accepted primitive is the closest one).  h == nullptr is
+// the shadow-ray query (has_intersection): the first accepted primitive settles it.
+// The traversal stack lives in LDS ([depth][thread]: conflict-free), not in scratch memory; the slab
+// test multiplies by the reciprocal direction (3 f64 divisions per ray instead of 6 per node) and is
+// widened by 2 ulp so that it can only be MORE permissive than the exact quotients -- the box test
+// is pure culling, every accepted leaf still runs the reference's exact primitive tests.
+constexpr int kStackDepth = 32;
 __device__ bool closest_hit(const LfBvhNode* __restrict__ nodes, const LfPrim* __restrict__ prims,
-                            DRay& r, Hit* h) {
-  int stack[64];
+                            DRay& r, Hit* h, int* __restrict__ stack /* [kStackDepth][256] + tid */) {
   int sp = 0;
-  stack[sp++] = 0;
+  stack[256 * sp++] = 0;
   bool any = false;
+  const double ix = 1.0 / r.d.x, iy = 1.0 / r.d.y, iz = 1.0 / r.d.z;
   while (sp > 0) {
-    const LfBvhNode& nd = nodes[stack[--sp]];
-    // BBox::intersect (scene/bbox.cpp:12-49); fmin/fmax drop NaNs (0/0 on a slab plane), which
+    const LfBvhNode& nd = nodes[stack[256 * --sp]];
+    // BBox::intersect (scene/bbox.cpp:12-49); fmin/fmax drop NaNs (0 * inf on a slab plane), which
     // only makes the test more permissive
-    const double tx1 = (nd.bmin[0] - r.o.x) / r.d.x, tx2 = (nd.bmax[0] - r.o.x) / r.d.x;
-    const double ty1 = (nd.bmin[1] - r.o.y) / r.d.y, ty2 = (nd.bmax[1] - r.o.y) / r.d.y;
-    const double tz1 = (nd.bmin[2] - r.o.z) / r.d.z, tz2 = (nd.bmax[2] - r.o.z) / r.d.z;
+    const double tx1 = (nd.bmin[0] - r.o.x) * ix, tx2 = (nd.bmax[0] - r.o.x) * ix;
+    const double ty1 = (nd.bmin[1] - r.o.y) * iy, ty2 = (nd.bmax[1] - r.o.y) * iy;
+    const double tz1 = (nd.bmin[2] - r.o.z) * iz, tz2 = (nd.bmax[2] - r.o.z) * iz;
     const double tmin = fmax(fmax(fmin(tx1, tx2), fmin(ty1, ty2)), fmin(tz1, tz2));
     const double tmax = fmin(fmin(fmax(tx1, tx2), fmax(ty1, ty2)), fmax(tz1, tz2));
-    if (tmin > tmax || tmax < r.min_t || tmin > r.max_t) continue;
+    const double slack = 4.5e-16 * fmax(fabs(tmin), fabs(tmax));
+    if (tmin - slack > tmax + slack || tmax + slack < r.min_t || tmin - slack > r.max_t) continue;
     if (nd.count > 0) {
       for (int i = 0; i < nd.count; i++) {
         const LfPrim& p = prims[nd.first + i];
         const bool hit = p.type == 0 ? hit_sphere(p, r, h) : hit_triangle(p, r, h);
         any = any || hit;
       }
+      if (any && !h) return true;
     } else {
-      if (sp < 62) { stack[sp++] = nd.right; stack[sp++] = nd.left; }
+      if (sp < kStackDepth - 1) { stack[256 * sp++] = nd.right; stack[256 * sp++] = nd.left; }
     }
   }
   return any;
@@ -147,9 +155,9 @@ __device__ inline void make_coord_space(V3 n, V3& X, V3& Y, V3& Z) {
 
 // est_radiance_global_illumination (pathtracer.cpp:282-302) = zero_bounce + one_bounce with
 // estimate_direct_lighting_importance (:142-213)
-__device__ V3 radiance(const LfSceneDev& sc, DRay r) {
+__device__ V3 radiance(const LfSceneDev& sc, DRay r, int* __restrict__ stack) {
   Hit isect;
-  if (!closest_hit(sc.nodes, sc.prims, r, &isect)) return v3(0, 0, 0);  // no envLight
+  if (!closest_hit(sc.nodes, sc.prims, r, &isect, stack)) return v3(0, 0, 0);  // no envLight
   const LfMaterial& m = sc.materials[isect.material];
   const V3 emission = m.kind == 1 ? v3(m.rgb[0], m.rgb[1], m.rgb[2]) : v3(0, 0, 0);
   V3 X, Y, Z;
@@ -176,7 +184,7 @@ __device__ V3 radiance(const LfSceneDev& sc, DRay r) {
                      (wi.x * Z.x + wi.y * Z.y) + wi.z * Z.z);
     if (wo.z < 0) continue;
     DRay sh{hit_p, wi, kEpsF, dist - kEpsF};
-    if (!closest_hit(sc.nodes, sc.prims, sh, nullptr)) {
+    if (!closest_hit(sc.nodes, sc.prims, sh, nullptr, stack)) {
       const double cos_theta = unit(wo).z;
       // DiffuseBSDF::f = Vector3D(1/PI) * reflectance (bsdf.cpp:52-60); EmissionBSDF::f = 0
       const double ipi = 1.0 / 3.14159265358979323;
@@ -213,6 +221,10 @@ __global__ __launch_bounds__(256) void k_scene_term(LfSceneDev sc, LfCamera cam,
                                                     double max_tolerance,
                                                     const uint32_t* __restrict__ aa_raw, int jitter_mode,
                                                     uint64_t key, double* __restrict__ scene) {
+  // traversal stacks of the 256 threads: the median-split tree of n primitives is ceil(log2(n / 4))
+  // deep (<= 29), the stack holds at most depth + 1 entries
+  __shared__ int s_stack[kStackDepth * 256];
+  int* const stack = s_stack + threadIdx.x;
   const size_t p = (size_t)y0 * W + (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (p >= (size_t)y1 * W) return;
   const int x = (int)(p % W), y = (int)(p / W);
@@ -244,7 +256,7 @@ __global__ __launch_bounds__(256) void k_scene_term(LfSceneDev sc, LfCamera cam,
              (dir.x * cam.c2w[3] + dir.y * cam.c2w[4]) + dir.z * cam.c2w[5],
              (dir.x * cam.c2w[6] + dir.y * cam.c2w[7]) + dir.z * cam.c2w[8]);
     r.min_t = cam.n_clip; r.max_t = cam.f_clip;
-    const V3 L = radiance(sc, r);
+    const V3 L = radiance(sc, r, stack);
     // Vector3D::illum (vector3D.h:231-233): float coefficients, double arithmetic, float result
     const float illum = (float)((0.2126f * L.x + 0.7152f * L.y) + 0.0722f * L.z);
     s1 += illum;
