@@ -201,12 +201,12 @@ __device__ __forceinline__ LfEventRow load_row(const LfEventRow* __restrict__ e)
 // parked ray state (a fork of the path tree) in LDS: the two slots would cost 12 VGPRs and the 8th
 // wave of every SIMD
 __device__ __forceinline__ void park(float2* __restrict__ slot, int lane, const Ray& r) {
-  slot[3 * lane] = make_float2(r.px, r.py);
-  slot[3 * lane + 1] = make_float2(r.pz, r.dx);
-  slot[3 * lane + 2] = make_float2(r.dy, r.dz);
+  slot[lane] = make_float2(r.px, r.py);          // [pair][lane]: 8-byte lane stride, conflict-free
+  slot[64 + lane] = make_float2(r.pz, r.dx);
+  slot[128 + lane] = make_float2(r.dy, r.dz);
 }
 __device__ __forceinline__ void unpark(const float2* __restrict__ slot, int lane, Ray& r) {
-  const float2 a = slot[3 * lane], b = slot[3 * lane + 1], c = slot[3 * lane + 2];
+  const float2 a = slot[lane], b = slot[64 + lane], c = slot[128 + lane];
   r.px = a.x; r.py = a.y; r.pz = b.x; r.dx = b.y; r.dy = c.x; r.dz = c.y;
 }
 
@@ -233,7 +233,7 @@ void k_march(const LfLensDev* __restrict__ lens,
   __shared__ unsigned long long s_acc[64 * 3];
   __shared__ unsigned long long s_cnt[8];
   __shared__ int s_next;
-  __shared__ float2 s_state[4][2][3 * 64];  // parked ray states: [wave][slot][lane][px py|pz dx|dy dz]
+  __shared__ float2 s_state[4][2][3 * 64];  // parked ray states: [wave][slot][px py|pz dx|dy dz][lane]
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   if (tid < 64 * 3) s_acc[tid] = 0ull;
   if (tid < 8) s_cnt[tid] = 0ull;
