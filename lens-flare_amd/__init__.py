@@ -69,12 +69,10 @@ def load_library():
     global _lib
     if _lib is None:
         if not os.path.exists(LIB_PATH):
-            # build in-tree on first use (hipcc cross-compiles gfx950 anywhere); never a fallback
-            import subprocess
-            subprocess.check_call(["make", "-s", "-j4", "-C", HERE])
-        if not os.path.exists(LIB_PATH):
+            # never built lazily: a build started from a process that has touched the GPU (or from
+            # N torchrun ranks at once, or under rocprofv3) is exactly what must not happen
             raise FileNotFoundError(f"{LIB_PATH} is missing: run __graft_entry__.build() "
-                                    "(make -C lens-flare_amd)")
+                                    "(make -C lens-flare_amd) before any GPU work")
         lib = C.CDLL(LIB_PATH)
         lib.lf_last_error.restype = C.c_char_p
         lib.lf_last_error.argtypes = [C.c_void_p]
@@ -84,6 +82,17 @@ def load_library():
 
 def _fp(a, t):
     return a.ctypes.data_as(C.POINTER(t))
+
+
+def load_aperture_png(path):
+    """An aperture PNG -> float texels exactly as CameraApertureTexture::init derives them
+    (camera.h:39-63: lodepng RGBA8, red byte x float(1/255), CGL/src/color.cpp:16-21).  The decode is
+    host plumbing (the ABI takes texels); names without a directory are looked up in data/."""
+    from PIL import Image
+    if not os.path.isabs(path) and not os.path.exists(path):
+        path = os.path.join(DATA, path)
+    red = np.ascontiguousarray(np.asarray(Image.open(path).convert("RGBA"))[:, :, 0])
+    return red.astype(np.float32) * np.float32(1.0 / 255.0)
 
 
 def load_lens_file(path):

@@ -14,19 +14,55 @@ lf_status lf_fail(const lf_ctx* ctx, lf_status st, const std::string& msg) {
   return st;
 }
 
-hipEvent_t lf_timing_begin(lf_ctx* ctx, int kernel) {
-  if (!ctx->timing) return nullptr;
+// HIP-event timing.  Events come from a pool and the list of pending launches is bounded: once it
+// holds kTimedCap entries the finished ones are folded into per-kernel totals and their events go
+// back to the pool, so a long timed run neither grows without bound nor creates events per launch.
+static constexpr size_t kTimedCap = 512;
+
+static hipEvent_t timing_event(lf_ctx* ctx) {
+  if (!ctx->event_pool.empty()) {
+    hipEvent_t e = ctx->event_pool.back();
+    ctx->event_pool.pop_back();
+    return e;
+  }
   hipEvent_t e = nullptr;
   if (hipEventCreate(&e) != hipSuccess) return nullptr;
-  (void)hipEventRecord(e, ctx->stream);
+  return e;
+}
+
+// fold every launch whose stop event has completed (all of them if `wait`)
+static void timing_fold(lf_ctx* ctx, bool wait) {
+  size_t keep = 0;
+  for (size_t i = 0; i < ctx->timed.size(); i++) {
+    LfTimedLaunch& t = ctx->timed[i];
+    const bool done = wait ? hipEventSynchronize(t.stop) == hipSuccess : hipEventQuery(t.stop) == hipSuccess;
+    float ms = 0.f;
+    if (done && hipEventElapsedTime(&ms, t.start, t.stop) == hipSuccess) {
+      ctx->timed_ms[t.kernel] += ms;
+      ctx->timed_n[t.kernel]++;
+      ctx->event_pool.push_back(t.start);
+      ctx->event_pool.push_back(t.stop);
+    } else {
+      ctx->timed[keep++] = t;
+    }
+  }
+  ctx->timed.resize(keep);
+}
+
+hipEvent_t lf_timing_begin(lf_ctx* ctx, int kernel) {
+  if (!ctx->timing) return nullptr;
   (void)kernel;
+  if (ctx->timed.size() >= kTimedCap) timing_fold(ctx, false);
+  if (ctx->timed.size() >= kTimedCap) timing_fold(ctx, true);
+  hipEvent_t e = timing_event(ctx);
+  if (e) (void)hipEventRecord(e, ctx->stream);
   return e;
 }
 
 void lf_timing_end(lf_ctx* ctx, int kernel, hipEvent_t start) {
   if (!ctx->timing || !start) return;
-  hipEvent_t e = nullptr;
-  if (hipEventCreate(&e) != hipSuccess) { (void)hipEventDestroy(start); return; }
+  hipEvent_t e = timing_event(ctx);
+  if (!e) { ctx->event_pool.push_back(start); return; }
   (void)hipEventRecord(e, ctx->stream);
   ctx->timed.push_back(LfTimedLaunch{kernel, start, e});
 }
@@ -107,7 +143,8 @@ void free_frame_buffers(lf_ctx* ctx) {
   ctx->sample = ctx->ghost = ctx->scene = ctx->star = nullptr;
   ctx->rgba = nullptr;
   ctx->jitter_raw = nullptr;
-  ctx->jitter_table_valid = ctx->ghost_valid = ctx->sample_valid = ctx->rgba_valid = false;
+  ctx->jitter_table_valid = ctx->ghost_valid = ctx->sample_valid = false;
+  ctx->rgba_y0 = ctx->rgba_y1 = 0;
 }
 
 lf_status upload_paraxial(lf_ctx* ctx) {
@@ -168,13 +205,14 @@ lf_status lf_destroy(lf_ctx* ctx) {
   (void)hipDeviceSynchronize();
   free_frame_buffers(ctx);
   for (auto& t : ctx->timed) { (void)hipEventDestroy(t.start); (void)hipEventDestroy(t.stop); }
+  for (hipEvent_t e : ctx->event_pool) (void)hipEventDestroy(e);
   for (int s = 0; s < 2; s++) {
     if (ctx->ap[s].texels) (void)hipFree(ctx->ap[s].texels);
     if (ctx->ap[s].stats) (void)hipFree(ctx->ap[s].stats);
   }
   void* ptrs[] = {ctx->spectrum, ctx->twiddle, ctx->dft_rows, ctx->flares, ctx->ghosts, ctx->pl_dev,
                   ctx->lens_dev, ctx->pairs_dev, ctx->counters_dev, ctx->accum, ctx->events_dev,
-                  ctx->skip_dev,
+                  ctx->skip_dev, ctx->sun_lights_dev,
                   ctx->scene_dev.nodes, ctx->scene_dev.prims, ctx->scene_dev.materials,
                   ctx->scene_dev.lights};
   for (void* p : ptrs) if (p) (void)hipFree(p);
@@ -198,17 +236,12 @@ lf_status lf_synchronize(lf_ctx* ctx) {
   return LF_OK;
 }
 
-lf_status lf_set_frame(lf_ctx* ctx, int width, int height) {
-  if (!ctx) return LF_ERR_INVALID;
-  if (width <= 0 || height <= 0 || width > (1 << 15) || height > (1 << 15))
-    return lf_fail(ctx, LF_ERR_INVALID, "frame size out of range");
-  LF_HIP(ctx, hipSetDevice(ctx->device));
+// (re)allocate the frame-sized buffers for `rows` rows; content is lost
+static lf_status alloc_frame_buffers(lf_ctx* ctx, int rows) {
   LF_HIP(ctx, hipStreamSynchronize(ctx->stream));
   free_frame_buffers(ctx);
-  ctx->W = width; ctx->H = height; ctx->y0 = 0; ctx->y1 = height;
-  ctx->H_alloc = (height + 63) / 64 * 64;
-  ctx->row_period = 1; ctx->row_phase = 0;
-  size_t n = (size_t)width * ctx->H_alloc;
+  ctx->H_alloc = rows;
+  size_t n = (size_t)ctx->W * ctx->H_alloc;
   lf_status st;
   if ((st = dev_alloc(ctx, &ctx->sample, 3 * n)) != LF_OK) return st;
   if ((st = dev_alloc(ctx, &ctx->ghost, 3 * n)) != LF_OK) return st;
@@ -219,6 +252,25 @@ lf_status lf_set_frame(lf_ctx* ctx, int width, int height) {
   LF_HIP(ctx, hipMemsetAsync(ctx->star, 0, 3 * n * sizeof(double), ctx->stream));
   LF_HIP(ctx, hipMemsetAsync(ctx->rgba, 0, n * sizeof(uint32_t), ctx->stream));
   return LF_OK;
+}
+
+// rows the frame buffers need so that every group of `period` 8-row tile rows is addressable
+// (the tile-row exchange of lf_gather / sharding.py views the frame as [groups][period][tile row])
+static int padded_rows(int H, int period) {
+  const int ntrows = (H + 7) / 8;
+  return (ntrows + period - 1) / period * period * 8;
+}
+
+lf_status lf_set_frame(lf_ctx* ctx, int width, int height) {
+  if (!ctx) return LF_ERR_INVALID;
+  if (width <= 0 || height <= 0 || width > (1 << 15) || height > (1 << 15))
+    return lf_fail(ctx, LF_ERR_INVALID, "frame size out of range");
+  LF_HIP(ctx, hipSetDevice(ctx->device));
+  ctx->W = width; ctx->H = height; ctx->y0 = 0; ctx->y1 = height;
+  ctx->row_period = 1; ctx->row_phase = 0;
+  // padded for every interleave period up to 8 (ceil(n/p) p <= n + p - 1); larger periods
+  // re-allocate in lf_set_row_interleave
+  return alloc_frame_buffers(ctx, ((height + 7) / 8 + 7) * 8);
 }
 
 lf_status lf_set_band(lf_ctx* ctx, int y0, int y1) {
@@ -233,6 +285,14 @@ lf_status lf_set_row_interleave(lf_ctx* ctx, int phase, int period) {
   if (!ctx) return LF_ERR_INVALID;
   if (period < 1 || phase < 0 || phase >= period)
     return lf_fail(ctx, LF_ERR_INVALID, "row interleave: need 0 <= phase < period");
+  if (ctx->W == 0) return lf_fail(ctx, LF_ERR_STATE, "lf_set_row_interleave before lf_set_frame");
+  if (padded_rows(ctx->H, period) > ctx->H_alloc) {
+    // the tile-row exchange needs ceil(tile rows / period) * period tile rows: grow the buffers
+    // (their content is lost -- set the interleave before rendering)
+    LF_HIP(ctx, hipSetDevice(ctx->device));
+    lf_status st = alloc_frame_buffers(ctx, padded_rows(ctx->H, period));
+    if (st != LF_OK) return st;
+  }
   ctx->row_phase = phase; ctx->row_period = period;
   return LF_OK;
 }
@@ -255,6 +315,7 @@ lf_status lf_set_aperture(lf_ctx* ctx, lf_aperture_slot slot, const float* texel
   LfApertureDev& a = ctx->ap[slot];
   a.valid = false;
   lf_status st;
+  LF_HIP(ctx, hipStreamSynchronize(ctx->stream));  // kernels in flight may read the old texels / spectrum
   if ((st = dev_alloc(ctx, &a.texels, (size_t)width * height)) != LF_OK) return st;
   a.w = width; a.h = height;
   LF_HIP(ctx, hipMemcpyAsync(a.texels, texels, sizeof(float) * (size_t)width * height,
@@ -318,19 +379,30 @@ lf_status lf_find_sun_pos(lf_ctx* ctx, const double* lights, int n_lights) {
   if (!ctx->cam_valid) return lf_fail(ctx, LF_ERR_STATE, "lf_find_sun_pos before lf_set_camera");
   if (ctx->W == 0) return lf_fail(ctx, LF_ERR_STATE, "lf_find_sun_pos before lf_set_frame");
   LF_HIP(ctx, hipSetDevice(ctx->device));
-  double* dl = nullptr;
-  if (n_lights > 0) {
-    LF_HIP(ctx, hipMalloc((void**)&dl, sizeof(double) * 6 * n_lights));
-    LF_HIP(ctx, hipMemcpyAsync(dl, lights, sizeof(double) * 6 * n_lights, hipMemcpyHostToDevice,
-                               ctx->stream));
-  }
   // flare_origins.clear(); flare_radiance.clear() (raytraced_renderer.cpp:306-307); axis_ray and
-  // angle_to_sun keep their previous values, exactly like the reference's members
-  lf_status st = lfk_frame_setup(ctx, dl, n_lights, true);
-  hipError_t e = hipStreamSynchronize(ctx->stream);
-  if (dl) (void)hipFree(dl);
-  if (st != LF_OK) return st;
-  LF_HIP(ctx, e);
+  // angle_to_sun keep their previous values, exactly like the reference's members.
+  // The lights travel as kernel arguments (no allocation, no copy, no synchronisation per frame);
+  // only a scene with more than kMaxSunLightArgs directional lights takes the staged path.
+  if (n_lights <= kMaxSunLightArgs) {
+    LfSunLightArgs args;
+    std::memset(&args, 0, sizeof(args));
+    if (n_lights > 0) std::memcpy(args.v, lights, sizeof(double) * 6 * (size_t)n_lights);
+    lf_status st = lfk_frame_setup(ctx, &args, nullptr, n_lights, true);
+    if (st != LF_OK) return st;
+  } else {
+    if ((size_t)n_lights > ctx->sun_lights_cap) {
+      LF_HIP(ctx, hipStreamSynchronize(ctx->stream));
+      if (ctx->sun_lights_dev) (void)hipFree(ctx->sun_lights_dev);
+      ctx->sun_lights_dev = nullptr; ctx->sun_lights_cap = 0;
+      LF_HIP(ctx, hipMalloc((void**)&ctx->sun_lights_dev, sizeof(double) * 6 * (size_t)n_lights));
+      ctx->sun_lights_cap = (size_t)n_lights;
+    }
+    LF_HIP(ctx, hipStreamSynchronize(ctx->stream));  // the previous frame may still read the buffer
+    LF_HIP(ctx, hipMemcpy(ctx->sun_lights_dev, lights, sizeof(double) * 6 * (size_t)n_lights,
+                          hipMemcpyHostToDevice));
+    lf_status st = lfk_frame_setup(ctx, nullptr, ctx->sun_lights_dev, n_lights, true);
+    if (st != LF_OK) return st;
+  }
   ctx->flares_valid = true;
   ctx->ghost_valid = false;
   return LF_OK;
@@ -404,6 +476,7 @@ lf_status lf_set_jitter_mt19937(lf_ctx* ctx, uint32_t seed, const uint32_t* orde
     for (int k = 0; k < 32; k++) dst[k] = mt.next();
   }
   lf_status st;
+  LF_HIP(ctx, hipStreamSynchronize(ctx->stream));  // a running flare layer may read the old tables
   if ((st = dev_alloc(ctx, &ctx->jitter_raw, n * 32)) != LF_OK) return st;
   LF_HIP(ctx, hipMemcpy(ctx->jitter_raw, table.data(), table.size() * sizeof(uint32_t),
                         hipMemcpyHostToDevice));
@@ -436,6 +509,9 @@ lf_status lf_set_scene_term(lf_ctx* ctx, const double* rgb) {
   }
   lf_status st;
   if (!ctx->scene && (st = dev_alloc(ctx, &ctx->scene, n)) != LF_OK) return st;
+  // the context's stream is non-blocking: a null-stream copy is NOT ordered behind a flare layer
+  // that still reads the previous scene term
+  LF_HIP(ctx, hipStreamSynchronize(ctx->stream));
   LF_HIP(ctx, hipMemcpy(ctx->scene, rgb, n * sizeof(double), hipMemcpyHostToDevice));
   return LF_OK;
 }
@@ -447,7 +523,7 @@ lf_status lf_generate_ghost_buffer(lf_ctx* ctx) {
   if (!ctx->ap[LF_APERTURE_GHOST].valid) return lf_fail(ctx, LF_ERR_STATE, "ghost aperture not set");
   LF_HIP(ctx, hipSetDevice(ctx->device));
   lf_status st;
-  if ((st = lfk_frame_setup(ctx, nullptr, 0, false)) != LF_OK) return st;
+  if ((st = lfk_frame_setup(ctx, nullptr, nullptr, 0, false)) != LF_OK) return st;
   if ((st = lfk_ghost_raster(ctx)) != LF_OK) return st;
   ctx->ghost_valid = true;
   return LF_OK;
@@ -465,7 +541,7 @@ lf_status lf_render_flare_layer(lf_ctx* ctx) {
   lf_status st;
   if ((st = lfk_flare_layer(ctx)) != LF_OK) return st;
   ctx->sample_valid = true;
-  ctx->rgba_valid = false;
+  ctx->rgba_y0 = ctx->rgba_y1 = 0;  // the tonemapped copy is stale
   return LF_OK;
 }
 
@@ -507,10 +583,14 @@ lf_status lf_write_to_framebuffer(lf_ctx* ctx, int x0, int y0, int x1, int y1, u
   if (row_stride < (size_t)(x1 - x0)) return lf_fail(ctx, LF_ERR_INVALID, "row_stride < tile width");
   if (x0 == x1 || y0 == y1) return LF_OK;
   LF_HIP(ctx, hipSetDevice(ctx->device));
-  if (!ctx->rgba_valid) {
-    lf_status st = lfk_tonemap(ctx);
+  if (y0 < ctx->rgba_y0 || y1 > ctx->rgba_y1) {
+    // tonemap the current band and whatever else the tile needs (the reference tonemaps exactly
+    // the tile, image.h:208-223; whole rows keep the launch simple), remember the rows done
+    const int ya = std::min(y0, ctx->y0 < ctx->y1 ? ctx->y0 : y0);
+    const int yb = std::max(y1, ctx->y0 < ctx->y1 ? ctx->y1 : y1);
+    lf_status st = lfk_tonemap(ctx, ya, yb);
     if (st != LF_OK) return st;
-    ctx->rgba_valid = true;
+    ctx->rgba_y0 = ya; ctx->rgba_y1 = yb;
   }
   LF_HIP(ctx, hipStreamSynchronize(ctx->stream));
   LF_HIP(ctx, hipMemcpy2D(dst, row_stride * sizeof(uint32_t), ctx->rgba + (size_t)y0 * ctx->W + x0,
@@ -524,12 +604,9 @@ lf_status lf_save_image_rgba(lf_ctx* ctx, uint32_t* dst) {
   if (ctx->W == 0) return lf_fail(ctx, LF_ERR_STATE, "lf_save_image_rgba before lf_set_frame");
   if (!ctx->sample_valid) return lf_fail(ctx, LF_ERR_STATE, "lf_save_image_rgba before lf_render_flare_layer");
   LF_HIP(ctx, hipSetDevice(ctx->device));
-  const int y0 = ctx->y0, y1 = ctx->y1;
-  ctx->y0 = 0; ctx->y1 = ctx->H;                 // the saved image is always the whole frame
-  lf_status st = lfk_tonemap(ctx);
-  ctx->y0 = y0; ctx->y1 = y1;
+  lf_status st = lfk_tonemap(ctx, 0, ctx->H);   // the saved image is always the whole frame
   if (st != LF_OK) return st;
-  ctx->rgba_valid = (y0 == 0 && y1 == ctx->H);
+  ctx->rgba_y0 = 0; ctx->rgba_y1 = ctx->H;
   uint32_t* tmp = nullptr;
   const size_t n = (size_t)ctx->W * ctx->H;
   LF_HIP(ctx, hipMalloc((void**)&tmp, n * sizeof(uint32_t)));
@@ -831,8 +908,9 @@ lf_status lf_timing_enable(lf_ctx* ctx, int on) {
 lf_status lf_timing_reset(lf_ctx* ctx) {
   if (!ctx) return LF_ERR_INVALID;
   LF_HIP(ctx, hipStreamSynchronize(ctx->stream));
-  for (auto& t : ctx->timed) { (void)hipEventDestroy(t.start); (void)hipEventDestroy(t.stop); }
+  for (auto& t : ctx->timed) { ctx->event_pool.push_back(t.start); ctx->event_pool.push_back(t.stop); }
   ctx->timed.clear();
+  for (int k = 0; k < LFK_COUNT; k++) { ctx->timed_ms[k] = 0.0; ctx->timed_n[k] = 0; }
   return LF_OK;
 }
 
@@ -842,14 +920,9 @@ lf_status lf_timing_get(lf_ctx* ctx, const char* kernel, int* launches, double* 
   for (int k = 0; k < LFK_COUNT; k++) if (std::strcmp(kernel, kKernelNames[k]) == 0) id = k;
   if (id < 0) return lf_fail(ctx, LF_ERR_INVALID, "unknown kernel name");
   LF_HIP(ctx, hipStreamSynchronize(ctx->stream));
-  *launches = 0; *total_ms = 0.0;
-  for (auto& t : ctx->timed) {
-    if (t.kernel != id) continue;
-    float ms = 0.f;
-    LF_HIP(ctx, hipEventElapsedTime(&ms, t.start, t.stop));
-    (*launches)++;
-    *total_ms += ms;
-  }
+  timing_fold(ctx, true);
+  *launches = ctx->timed_n[id];
+  *total_ms = ctx->timed_ms[id];
   return LF_OK;
 }
 

@@ -13,6 +13,9 @@
 // Built with -ffp-contract=off: the float barycentrics and the float determinant of invert2x2
 // must round exactly like the reference's (which is built without FMA) for the ghost buffer to be
 // bit-identical.  All double transcendental calls go to ROCm's device libm (<= 1 ulp).
+#include <algorithm>
+#include <cstring>
+
 #include "lf_internal.h"
 
 namespace {
@@ -225,7 +228,8 @@ __device__ void make_tri(LfGhostTri& t, float x0, float y0, float u0, float v0, 
 }
 
 __global__ void k_frame_setup(const LfParaxialLens* __restrict__ plp, LfCamera cam,
-                              const double* __restrict__ lights, int n_lights, int project, int W,
+                              LfSunLightArgs light_args, const double* __restrict__ lights_mem,
+                              int n_lights, int project, int W,
                               int H, int tex_w, int tex_h, LfFlares* __restrict__ fl,
                               LfGhostList* __restrict__ gl) {
   const LfParaxialLens& pl = *plp;
@@ -236,6 +240,7 @@ __global__ void k_frame_setup(const LfParaxialLens* __restrict__ plp, LfCamera c
       double edge_x = tan(0.5 * (cam.hfov_deg * (PI_ / 180.0)));
       double edge_y = tan(0.5 * (cam.vfov_deg * (PI_ / 180.0)));
       int n = 0;
+      const double* lights = lights_mem ? lights_mem : light_args.v;
       for (int l = 0; l < n_lights; l++) {
         double dx = lights[6 * l] - cam.pos[0], dy = lights[6 * l + 1] - cam.pos[1],
                dz = lights[6 * l + 2] - cam.pos[2];
@@ -398,12 +403,15 @@ __global__ __launch_bounds__(256) void k_flare_layer(
     const LfFlares* __restrict__ fl, const lf_aperture_stats* __restrict__ st,
     const double* __restrict__ S, const double* __restrict__ ghost,
     const double* __restrict__ scene, const uint32_t* __restrict__ jitter_raw, int jitter_mode,
-    uint64_t key, int W, int H, int y0, int y1, int ns_aa, double flare_radius,
-    double flare_intensity, LfStarSpectrum spec, double* __restrict__ sample,
+    uint64_t key, int W, int H, int y0, int y1, int row_phase, int row_period, int ns_aa,
+    double flare_radius, double flare_intensity, LfStarSpectrum spec, double* __restrict__ sample,
     double* __restrict__ star_out) {
   const size_t p = (size_t)y0 * W + (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (p >= (size_t)y1 * W) return;
   const int x = (int)(p % W), y = (int)(p / W);
+  // multi-GPU: only the 8-row tile rows this context owns (lf_set_row_interleave); the others are
+  // marched, composed and delivered by their owners
+  if (row_period > 1 && (y >> 3) % row_period != row_phase) return;
   const int n_flares = fl->n_flares;
   const double dW = (double)W, dH = (double)H;
 
@@ -582,11 +590,14 @@ lf_status lfk_build_spectrum(lf_ctx* ctx) {
   return LF_OK;
 }
 
-lf_status lfk_frame_setup(lf_ctx* ctx, const double* lights_dev, int n_lights, bool project) {
+lf_status lfk_frame_setup(lf_ctx* ctx, const LfSunLightArgs* lights_arg, const double* lights_dev,
+                          int n_lights, bool project) {
   const LfApertureDev& g = ctx->ap[LF_APERTURE_GHOST];
+  LfSunLightArgs none;
+  if (!lights_arg) { std::memset(&none, 0, sizeof(none)); lights_arg = &none; }
   hipEvent_t ev = lf_timing_begin(ctx, LFK_FRAME_SETUP);
   hipLaunchKernelGGL(k_frame_setup, dim3(1), dim3(64), 0, ctx->stream, ctx->pl_dev, ctx->cam,
-                     lights_dev, n_lights, project ? 1 : 0, ctx->W, ctx->H, g.w, g.h, ctx->flares,
+                     *lights_arg, lights_dev, n_lights, project ? 1 : 0, ctx->W, ctx->H, g.w, g.h, ctx->flares,
                      ctx->ghosts);
   lf_timing_end(ctx, LFK_FRAME_SETUP, ev);
   LF_HIP(ctx, hipGetLastError());
@@ -594,6 +605,7 @@ lf_status lfk_frame_setup(lf_ctx* ctx, const double* lights_dev, int n_lights, b
 }
 
 lf_status lfk_ghost_raster(lf_ctx* ctx) {
+  if (ctx->y1 <= ctx->y0) return LF_OK;  // empty band
   const LfApertureDev& g = ctx->ap[LF_APERTURE_GHOST];
   dim3 grid((ctx->W + kTileW - 1) / kTileW, (ctx->y1 - ctx->y0 + kTileH - 1) / kTileH);
   hipEvent_t ev = lf_timing_begin(ctx, LFK_GHOST_RASTER);
@@ -606,22 +618,24 @@ lf_status lfk_ghost_raster(lf_ctx* ctx) {
 
 lf_status lfk_flare_layer(lf_ctx* ctx) {
   size_t n = (size_t)(ctx->y1 - ctx->y0) * ctx->W;
+  if (n == 0) return LF_OK;  // empty band: nothing to render (a 0-block launch is an error)
   hipEvent_t ev = lf_timing_begin(ctx, LFK_FLARE_LAYER);
   hipLaunchKernelGGL(k_flare_layer, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream,
                      ctx->flares, ctx->ap[LF_APERTURE_STARBURST].stats, ctx->spectrum, ctx->ghost,
                      ctx->scene, ctx->jitter_raw, ctx->jitter_mode, ctx->jitter_key, ctx->W, ctx->H,
-                     ctx->y0, ctx->y1, ctx->ns_aa, ctx->flare_radius, ctx->flare_intensity,
-                     ctx->star_spec, ctx->sample, ctx->star);
+                     ctx->y0, ctx->y1, ctx->row_phase, ctx->row_period, ctx->ns_aa, ctx->flare_radius,
+                     ctx->flare_intensity, ctx->star_spec, ctx->sample, ctx->star);
   lf_timing_end(ctx, LFK_FLARE_LAYER, ev);
   LF_HIP(ctx, hipGetLastError());
   return LF_OK;
 }
 
-lf_status lfk_tonemap(lf_ctx* ctx) {
-  size_t n = (size_t)(ctx->y1 - ctx->y0) * ctx->W;
+lf_status lfk_tonemap(lf_ctx* ctx, int ya, int yb) {
+  if (yb <= ya) return LF_OK;
+  size_t n = (size_t)(yb - ya) * ctx->W;
   hipEvent_t ev = lf_timing_begin(ctx, LFK_TONEMAP);
   hipLaunchKernelGGL(k_tonemap, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream,
-                     ctx->sample, ctx->W, ctx->y0, ctx->y1, ctx->rgba);
+                     ctx->sample, ctx->W, ya, yb, ctx->rgba);
   lf_timing_end(ctx, LFK_TONEMAP, ev);
   LF_HIP(ctx, hipGetLastError());
   return LF_OK;

@@ -75,6 +75,10 @@ struct LfStarSpectrum {
   double rgb[LF_MAX_LAMBDA][3];    // weight of wavelength l in R, G, B
 };
 
+// the DirectionalLights of find_sun_pos as kernel arguments (6 doubles each: posLight, radiance)
+constexpr int kMaxSunLightArgs = 32;
+struct LfSunLightArgs { double v[6 * kMaxSunLightArgs]; };
+
 struct LfApertureDev {
   float* texels = nullptr;  // w*h
   int w = 0, h = 0;
@@ -179,13 +183,16 @@ struct lf_ctx {
   LfGhostList* ghosts = nullptr;   // device
   LfParaxialLens* pl_dev = nullptr;
   bool flares_valid = false;
+  double* sun_lights_dev = nullptr;  // staging for more than kMaxSunLightArgs directional lights
+  size_t sun_lights_cap = 0;
 
   double* sample = nullptr;  // W*H*3
   double* ghost = nullptr;   // W*H*3
   double* scene = nullptr;   // W*H*3 or null
   double* star = nullptr;    // W*H*3: raytrace_starburst(x,y) alone (starburst + falloff)
   uint32_t* rgba = nullptr;  // W*H
-  bool ghost_valid = false, sample_valid = false, rgba_valid = false;
+  bool ghost_valid = false, sample_valid = false;
+  int rgba_y0 = 0, rgba_y1 = 0;  // rows [rgba_y0, rgba_y1) of rgba hold the tonemapped sample buffer
 
   // jitter
   int jitter_mode = 1;          // 0 = MT19937 table, 1 = counter
@@ -218,8 +225,10 @@ struct lf_ctx {
   bool events_dirty = true;
 
   bool timing = false;
-  std::vector<LfTimedLaunch> timed;
-  std::vector<hipEvent_t> event_pool;
+  std::vector<LfTimedLaunch> timed;       // launches not folded yet (bounded, see lf_api.hip)
+  std::vector<hipEvent_t> event_pool;     // recycled events
+  double timed_ms[LFK_COUNT] = {};        // folded totals since lf_timing_reset
+  int timed_n[LFK_COUNT] = {};
 };
 
 // implemented in lf_api.hip
@@ -237,10 +246,11 @@ void lf_timing_end(lf_ctx* ctx, int kernel, hipEvent_t start);
 // kernels launchers (lf_flare_kernels.hip)
 lf_status lfk_aperture_stats(lf_ctx* ctx, int slot);
 lf_status lfk_build_spectrum(lf_ctx* ctx);
-lf_status lfk_frame_setup(lf_ctx* ctx, const double* lights_dev, int n_lights, bool project);
+lf_status lfk_frame_setup(lf_ctx* ctx, const LfSunLightArgs* lights_arg, const double* lights_dev,
+                          int n_lights, bool project);
 lf_status lfk_ghost_raster(lf_ctx* ctx);
 lf_status lfk_flare_layer(lf_ctx* ctx);
-lf_status lfk_tonemap(lf_ctx* ctx);
+lf_status lfk_tonemap(lf_ctx* ctx, int ya, int yb);
 lf_status lfk_flip_rows(lf_ctx* ctx, uint32_t* out_dev);
 // lf_march.hip
 lf_status lfk_march(lf_ctx* ctx, int spp, uint64_t key);

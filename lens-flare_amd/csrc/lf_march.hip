@@ -791,8 +791,12 @@ static lf_status build_event_table(lf_ctx* ctx) {
   std::vector<int> skip;
   lf_status st = lf_build_march_tables(ctx, rows, skip);
   if (st != LF_OK) return st;
+  // The context's stream is non-blocking, so the null-stream copies below are NOT ordered behind a
+  // k_march that is still walking the previous program: a program / jump-table pair that changes
+  // under a live kernel can send a wave past the program's end.  Drain the stream first.
+  LF_HIP(ctx, hipStreamSynchronize(ctx->stream));
   if (skip.size() > ctx->skip_cap) {
-    if (ctx->skip_dev) { LF_HIP(ctx, hipStreamSynchronize(ctx->stream)); (void)hipFree(ctx->skip_dev); }
+    if (ctx->skip_dev) { (void)hipFree(ctx->skip_dev); }
     ctx->skip_dev = nullptr;
     LF_HIP(ctx, hipMalloc((void**)&ctx->skip_dev, skip.size() * sizeof(int)));
     ctx->skip_cap = skip.size();
@@ -800,7 +804,7 @@ static lf_status build_event_table(lf_ctx* ctx) {
   if (!skip.empty())
     LF_HIP(ctx, hipMemcpy(ctx->skip_dev, skip.data(), skip.size() * sizeof(int), hipMemcpyHostToDevice));
   if (rows.size() > ctx->events_cap) {
-    if (ctx->events_dev) { LF_HIP(ctx, hipStreamSynchronize(ctx->stream)); (void)hipFree(ctx->events_dev); }
+    if (ctx->events_dev) { (void)hipFree(ctx->events_dev); }
     ctx->events_dev = nullptr;
     LF_HIP(ctx, hipMalloc((void**)&ctx->events_dev, rows.size() * sizeof(LfEventRow)));
     ctx->events_cap = rows.size();

@@ -290,7 +290,9 @@ Box prim_box(const LfPrim& p) {
   return b;
 }
 
-int build_node(std::vector<LfBvhNode>& nodes, std::vector<LfPrim>& prims, int first, int count) {
+// returns the node id; *depth = levels below (and including) this node
+int build_node(std::vector<LfBvhNode>& nodes, std::vector<LfPrim>& prims, int first, int count,
+               int* depth) {
   LfBvhNode nd;
   for (int a = 0; a < 3; a++) { nd.bmin[a] = INFINITY; nd.bmax[a] = -INFINITY; }
   double cmn[3] = {INFINITY, INFINITY, INFINITY}, cmx[3] = {-INFINITY, -INFINITY, -INFINITY};
@@ -305,6 +307,7 @@ int build_node(std::vector<LfBvhNode>& nodes, std::vector<LfPrim>& prims, int fi
   nd.left = nd.right = -1; nd.first = first; nd.count = count;
   const int id = (int)nodes.size();
   nodes.push_back(nd);
+  if (depth) *depth = 1;
   if (count <= 4) return id;
   int axis = 0;
   for (int a = 1; a < 3; a++) if (cmx[a] - cmn[a] > cmx[axis] - cmn[axis]) axis = a;
@@ -314,9 +317,11 @@ int build_node(std::vector<LfBvhNode>& nodes, std::vector<LfPrim>& prims, int fi
                      Box ba = prim_box(a), bb = prim_box(b);
                      return ba.mn[axis] + ba.mx[axis] < bb.mn[axis] + bb.mx[axis];
                    });
-  const int l = build_node(nodes, prims, first, mid - first);
-  const int r = build_node(nodes, prims, mid, first + count - mid);
+  int dl = 0, dr = 0;
+  const int l = build_node(nodes, prims, first, mid - first, &dl);
+  const int r = build_node(nodes, prims, mid, first + count - mid, &dr);
   nodes[id].left = l; nodes[id].right = r; nodes[id].count = 0;
+  if (depth) *depth = 1 + std::max(dl, dr);
   return id;
 }
 
@@ -365,7 +370,13 @@ lf_status lf_set_scene(lf_ctx* ctx, int n_spheres, const double* spheres, const 
     for (int c = 0; c < 3; c++) { lts[i].v[c] = lights[7 * i + 1 + c]; lts[i].rgb[c] = lights[7 * i + 4 + c]; }
   }
   std::vector<LfBvhNode> nodes;
-  if (!prims.empty()) build_node(nodes, prims, 0, (int)prims.size());
+  int depth = 0;
+  if (!prims.empty()) build_node(nodes, prims, 0, (int)prims.size(), &depth);
+  // the device traversal keeps at most depth + 1 node ids on its LDS stack and would otherwise
+  // have to drop children (= lose geometry silently); the median split is ceil(log2(n / 4)) + 1
+  // deep, so this only triggers beyond ~2^32 primitives -- but it must fail, not drop
+  if (depth + 1 > kStackDepth - 1)
+    return lf_fail(ctx, LF_ERR_INVALID, "scene: BVH deeper than the device traversal stack");
   else { LfBvhNode e; std::memset(&e, 0, sizeof(e)); e.bmin[0] = 1; e.bmax[0] = -1; e.count = 0; e.left = e.right = 0; nodes.push_back(e); }
   LfSceneDev& S = ctx->scene_dev;
   LF_HIP(ctx, hipStreamSynchronize(ctx->stream));

@@ -3,6 +3,8 @@
 # as MI355X_MICROARCH.md's HBM section prescribes.  Usage (on the GPU box, from the repo root):
 #   bash profiles/run_pmc.sh <tag>
 set -e
+# the library must exist BEFORE the profiler starts: nothing may build (exec hipcc) under rocprofv3
+[ -f lens-flare_amd/liblensflare_hip.so ] || { echo "liblensflare_hip.so missing: run __graft_entry__.build() first" >&2; exit 1; }
 TAG=${1:-r01}
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
 OUT=gpurun_out/pmc_$TAG

@@ -1,6 +1,8 @@
 #!/bin/bash
 # Extra SQ counters (issue breakdown) for the march kernel.  bash profiles/run_pmc2.sh <tag>
 set -e
+# the library must exist BEFORE the profiler starts: nothing may build (exec hipcc) under rocprofv3
+[ -f lens-flare_amd/liblensflare_hip.so ] || { echo "liblensflare_hip.so missing: run __graft_entry__.build() first" >&2; exit 1; }
 TAG=${1:-x}
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
 OUT=gpurun_out/pmc2_$TAG

@@ -355,3 +355,62 @@ def test_tile_row_interleave_reassembles_frame(pkg, lf):
     lf.set_row_interleave(0, 1)
     assert np.array_equal(lf.read_buffer(pkg.GHOST_BUFFER), og)
     assert lf.counters() == ocnt
+
+
+def test_reprogram_without_readback(pkg, lf):
+    """trace -> lf_set_ghost_pairs (same table capacity) -> trace with NO read-back in between:
+    the context's stream is non-blocking, so the second program upload must wait for the first
+    march (otherwise program and jump table change under a live kernel).  The second launch is a
+    long one (so it is certainly still running when the third set-up arrives) and the final frame
+    must be the oracle's frame for the last pair set."""
+    lens = pkg.load_lens_file("dgauss11.lens")
+    mask = load_texels("pentbig500_14.png")
+    W, H, spp = 64, 32, 16
+    lf.set_frame(W, H)
+    lf.set_aperture(pkg.APERTURE_STARBURST, mask)
+    lf.set_lens(lens)
+    lf.set_sun(SUN["direction"], SUN["radiance"], SUN["angular_radius"])
+    stop = lens["stop"]
+    before = [(i, j) for i in range(stop) for j in range(i + 1, stop)]
+    after = [(i, j) for i in range(stop + 1, lens["n"]) for j in range(i + 1, lens["n"])]
+    lf.set_ghost_pairs(None, True)          # the big table first: capacity for everything below
+    lf.trace_ghosts(spp, 1)
+    for k in range(6):                      # alternate programs of different shapes, no read-back
+        lf.set_ghost_pairs(before if k % 2 == 0 else after, k % 3 == 0)
+        lf.trace_ghosts(256 if k == 4 else spp, 100 + k)
+    lf.reset_counters()
+    lf.set_ghost_pairs(after, True)
+    lf.trace_ghosts(spp, 321)
+    g = lf.read_buffer(pkg.GHOST_BUFFER)
+    og, ocnt = lfo.geo_trace(lens, W, H, 0, H, spp, 321, after, True, mask, SUN["direction"],
+                             SUN["radiance"], SUN["angular_radius"])
+    assert lf.counters() == ocnt
+    assert np.array_equal(g, og)
+
+
+def test_empty_band_and_tonemap_rows(pkg, lf):
+    """lf_set_band(y, y) is a no-op for every launcher (a 0-block launch would be a HIP error), and
+    lf_write_to_framebuffer of a tile outside the current band tonemaps those rows instead of
+    returning stale zeros."""
+    from goldenlib import Case
+    case = Case("f64x48_pentbiglines")
+    m = case.meta
+    lf.set_frame(case.W, case.H)
+    lf.set_params(m["ns_aa"], m["flare_radius"], m["flare_intensity"])
+    lf.set_aperture(pkg.APERTURE_STARBURST, load_texels(m["aperture"]))
+    lf.set_aperture(pkg.APERTURE_GHOST, load_texels(m["ghost_aperture"]))
+    lf.set_camera(m["c2w"], m["cam_pos"], m["hFov"], m["vFov"])
+    lf.find_sun_pos(m["lights"])
+    lf.set_jitter_mt19937(5489, None)
+    lf.generate_ghost_buffer()
+    lf.render_flare_layer()
+    full = lf.write_to_framebuffer(0, 0, case.W, case.H)
+    assert np.array_equal(full, case.rgba)
+    lf.set_band(16, 16)                      # empty band: every launcher returns LF_OK
+    lf.generate_ghost_buffer()
+    lf.render_flare_layer()
+    lf.set_band(8, 16)
+    lf.render_flare_layer()                  # invalidates the tonemapped copy
+    tile = lf.write_to_framebuffer(0, 32, 32, 48)   # rows outside the band
+    assert np.array_equal(tile, case.rgba[32:48, 0:32])
+    lf.set_band(0, case.H)
