@@ -224,6 +224,12 @@ lf_status lf_set_sun(lf_ctx* ctx, const float dir[3], const float radiance[3],
 /* ghost pairs to enumerate: pairs = n x {i, j} interface indices (i < j, neither the stop);
  * i = j = -1 is the primary (no reflection) path.  n = 0 / NULL = all glass pairs. */
 lf_status lf_set_ghost_pairs(lf_ctx* ctx, const int* pairs, int n_pairs, int include_primary);
+/* Part of the sampling specification of lf_trace_ghosts (no reference
+ * counterpart): each pupil stratum is split into 2^bits x 2^bits sub-cells and all 64 pixels of an
+ * 8x8 sensor tile aim sample s at the same, randomly drawn sub-cell (coherent fate at the aperture
+ * mask).  bits = 0 draws every pixel's pupil point independently inside its stratum; every value
+ * is an unbiased estimator of the same image (tests/test_gpu_march_f64.py).  Default 2; 0..8. */
+lf_status lf_set_pupil_subcells(lf_ctx* ctx, int bits);
 /* march `spp` sensor samples per pixel of the band through every selected pair and wavelength and
  * accumulate into ghost_buffer (replacing its content).  key seeds the counter RNG. */
 lf_status lf_trace_ghosts(lf_ctx* ctx, int spp, uint64_t key);

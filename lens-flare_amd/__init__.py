@@ -31,7 +31,7 @@ ABI_SYMBOLS = [
     "lf_set_sampling", "lf_render_scene_term",
     "lf_generate_ghost_buffer", "lf_render_flare_layer", "lf_read_tile", "lf_read_pixel",
     "lf_write_to_framebuffer", "lf_save_image_rgba", "lf_device_buffer", "lf_set_lens", "lf_set_lambda_rgb", "lf_set_sun",
-    "lf_set_ghost_pairs", "lf_trace_ghosts", "lf_generate_lens_rays", "lf_get_counters", "lf_reset_counters", "lf_get_executed_events", "lf_native_sqrt", "lf_set_starburst_spectrum", "lf_load_collada", "lf_march_tables",
+    "lf_set_ghost_pairs", "lf_set_pupil_subcells", "lf_trace_ghosts", "lf_generate_lens_rays", "lf_get_counters", "lf_reset_counters", "lf_get_executed_events", "lf_native_sqrt", "lf_set_starburst_spectrum", "lf_load_collada", "lf_march_tables",
     "lf_timing_enable", "lf_timing_reset", "lf_timing_get",
 ]
 
@@ -346,6 +346,9 @@ class LensFlare:
             p = np.ascontiguousarray(pairs, np.int32).reshape(-1, 2)
             self._ck(self.lib.lf_set_ghost_pairs(self.ctx, _fp(p, C.c_int), len(p),
                                                  int(include_primary)))
+
+    def set_pupil_subcells(self, bits):
+        self._ck(self.lib.lf_set_pupil_subcells(self.ctx, int(bits)))
 
     def trace_ghosts(self, spp, key=0x1e45f1a4e):
         self._ck(self.lib.lf_trace_ghosts(self.ctx, int(spp), C.c_uint64(key)))

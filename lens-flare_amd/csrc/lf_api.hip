@@ -670,6 +670,9 @@ lf_status lf_set_sun(lf_ctx* ctx, const float dir[3], const float radiance[3],
     ctx->lens.sun_radiance[c] = radiance[c];
   }
   ctx->lens.sun_inv_one_minus_cos = (float)(1.0 / (1.0 - std::cos((double)angular_radius)));
+  ctx->lens.sun_ss = (float)((double)ctx->lens.sun_dir[0] * ctx->lens.sun_dir[0] +
+                             (double)ctx->lens.sun_dir[1] * ctx->lens.sun_dir[1] +
+                             (double)ctx->lens.sun_dir[2] * ctx->lens.sun_dir[2]);
   ctx->sun_valid = true;
   return LF_OK;
 }
@@ -708,6 +711,13 @@ lf_status lf_set_ghost_pairs(lf_ctx* ctx, const int* pairs, int n_pairs, int inc
   if (P.n == 0) return lf_fail(ctx, LF_ERR_INVALID, "empty pair set");
   ctx->pairs = P;
   ctx->events_dirty = true;
+  return LF_OK;
+}
+
+lf_status lf_set_pupil_subcells(lf_ctx* ctx, int bits) {
+  if (!ctx) return LF_ERR_INVALID;
+  if (bits < 0 || bits > 8) return lf_fail(ctx, LF_ERR_INVALID, "pupil sub-cell bits must be 0..8");
+  ctx->march_sub_bits = bits;
   return LF_OK;
 }
 

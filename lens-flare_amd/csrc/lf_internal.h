@@ -111,6 +111,7 @@ struct LfLensDev {
   float sun_dir[3];    // unit, towards the sun (z < 0)
   float sun_radiance[3];
   float sun_inv_one_minus_cos;  // 1 / (1 - cos(angular radius))
+  float sun_ss;                 // |sun_dir|^2 of the float vector as stored (exact in double, narrowed)
   float lambda_rgb[LF_MAX_LAMBDA][3];
   LfSurfaceDev surf[LF_MAX_SURFACES];
 };

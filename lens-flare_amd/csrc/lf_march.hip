@@ -210,6 +210,24 @@ __device__ __forceinline__ void unpark(const float2* __restrict__ slot, int lane
   r.px = a.x; r.py = a.y; r.pz = b.x; r.dx = b.y; r.dy = c.x; r.dz = c.y;
 }
 
+// The sun's lobe: q = (1 - cos theta) / (1 - cos alpha), theta between the ray and the sun.
+// 1 - d.s would cancel (d.s ~ 0.999: an absolute error of 1e-7 is 1e-4 of a 0.05 rad lobe, and the
+// float unit vectors are only unit to 1e-7 as well), so
+//   1 - cos theta = sin^2 theta / (1 + cos theta) = |d x s|^2 / (|d|^2 |s|^2 + sqrt(|d|^2 |s|^2) d.s)
+// which has no cancellation and does not assume |d| = |s| = 1 (ss = |s|^2 from the host).  Valid for
+// d.s > 0, which the pre-test guarantees.  (tests/test_gpu_march_f64.py checks the march against an
+// independent float64 tracer; with the plain 1 - d.s the pixels were off by up to 1e-2.)
+__device__ __forceinline__ float lobe_q(float dx, float dy, float dz, float sx, float sy, float sz,
+                                        float ss, float inv_1mc) {
+  const float cg = fmaf(dx, sx, fmaf(dy, sy, dz * sz));
+  const float cx = fmaf(dy, sz, -(dz * sy)), cy = fmaf(dz, sx, -(dx * sz)), cz = fmaf(dx, sy, -(dy * sx));
+  const float c2 = fmaf(cx, cx, fmaf(cy, cy, cz * cz));
+  const float dd = fmaf(dx, dx, fmaf(dy, dy, dz * dz));
+  const float ds = dd * ss;
+  const float den = fmaf(lf_sqrt(ds), cg, ds);
+  return __fdiv_rn(c2, den) * inv_1mc;
+}
+
 struct MarchArgs {
   int mw, mh, W, H, y0, y1;
   int spp, G;          // G x G pupil strata, G = floor(sqrt(spp))
@@ -255,7 +273,7 @@ void k_march(const LfLensDev* __restrict__ lens,
   const float pupil_z = lens->pupil_z, geom_norm = lens->geom_norm;
   const float inv_stop_h = __fdiv_rn(1.0f, lens->stop_h);
   const float sx = lens->sun_dir[0], sy = lens->sun_dir[1], sz = lens->sun_dir[2];
-  const float inv_1mc = lens->sun_inv_one_minus_cos;
+  const float inv_1mc = lens->sun_inv_one_minus_cos, sun_ss = lens->sun_ss;
   const int GG = a.G * a.G;
   const lanemask active_mask = __ballot(active);
 
@@ -420,9 +438,11 @@ void k_march(const LfLensDev* __restrict__ lens,
             // ---- a path is complete ---------------------------------------------------------
             scene32 += (unsigned)__popcll(alive);
             // inside the sun's lobe?
+            // (cheap pre-test: 1 - d.s cancels -- its absolute error of ~1e-7 is ~1e-4 of a 0.05 rad
+            // lobe -- so it only selects, with a 1/16 margin; the lobe factor itself is evaluated
+            // without cancellation after the weight re-march, see lobe_q)
             const float cg = fmaf(r.dx, sx, fmaf(r.dy, sy, r.dz * sz));
-            const float qq = (1.0f - cg) * inv_1mc;
-            const lanemask lit = alive & __ballot(qq < 1.0f);
+            const lanemask lit = alive & __ballot((1.0f - cg) * inv_1mc < 1.0625f);
             if (lit != 0ull) {
               // rare (about 1 % of the wave-paths): march this path again, alone and with the
               // weight, along its own row sequence
@@ -443,9 +463,11 @@ void k_march(const LfLensDev* __restrict__ lens,
               }
               // (selects, not branches: with no divergent branch anywhere in the walk the compiler
               // keeps its control flow as plain scalar branches)
+              // (the re-march reproduces the first pass bit for bit: rw's direction is r's)
+              const float qq = lobe_q(rw.dx, rw.dy, rw.dz, sx, sy, sz, sun_ss, inv_1mc);
               const float om = 1.0f - qq;
               float contrib = __fdiv_rn(rw.wn, rw.wd) * (om * om);
-              contrib = (((lit >> lane) & 1ull) != 0ull && contrib > 0.0f) ? contrib : 0.0f;
+              contrib = (((lit >> lane) & 1ull) != 0ull && qq < 1.0f && contrib > 0.0f) ? contrib : 0.0f;
               n_light += contrib > 0.0f ? 1u : 0u;
 #pragma unroll
               for (int c = 0; c < 3; c++) {
@@ -579,11 +601,12 @@ void lf_derive_lens(lf_ctx* ctx, int n, int stop, int n_lambda, const float* rad
                     float sensor_w_mm) {
   LfLensDev& L = ctx->lens;
   // keep the sun across a lens change
-  float keep_sun_dir[3], keep_sun_rad[3], keep_inv = L.sun_inv_one_minus_cos;
+  float keep_sun_dir[3], keep_sun_rad[3], keep_inv = L.sun_inv_one_minus_cos, keep_ss = L.sun_ss;
   for (int c = 0; c < 3; c++) { keep_sun_dir[c] = L.sun_dir[c]; keep_sun_rad[c] = L.sun_radiance[c]; }
   std::memset(&L, 0, sizeof(L));
   for (int c = 0; c < 3; c++) { L.sun_dir[c] = keep_sun_dir[c]; L.sun_radiance[c] = keep_sun_rad[c]; }
   L.sun_inv_one_minus_cos = keep_inv;
+  L.sun_ss = keep_ss;
   L.n_surf = n; L.stop = stop; L.n_lambda = n_lambda;
   float z = 0.0f;
   for (int k = 0; k < n; k++) {

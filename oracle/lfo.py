@@ -381,3 +381,115 @@ def set_scene_term(scene):
         lib().lfo_set_scene_term(None)
     else:
         lib().lfo_set_scene_term(_p(scene, C.c_double))
+
+
+# ------------------------------------------------------------------------------------------------
+# independent float64 tracer (oracle/lf_geo_f64.c): the second opinion for the geometric march.
+# Shares no code / recipe / sqrt table with lf_geo_oracle.c; parity unpinned like it (no reference
+# implementation exists), anchored by tests/test_geo_f64_kat.py
+# ------------------------------------------------------------------------------------------------
+class G64Lens(C.Structure):
+    _fields_ = [("n_surf", C.c_int), ("stop", C.c_int), ("n_lambda", C.c_int),
+                ("radius", C.c_double * GEO_MAX_SURF), ("thickness", C.c_double * GEO_MAX_SURF),
+                ("semi_ap", C.c_double * GEO_MAX_SURF),
+                ("ior", (C.c_double * GEO_MAX_SURF) * GEO_MAX_LAMBDA), ("sensor_w_mm", C.c_double),
+                ("sun_dir", C.c_double * 3), ("sun_radiance", C.c_double * 3),
+                ("sun_angular_radius", C.c_double),
+                ("lambda_rgb", (C.c_double * 3) * GEO_MAX_LAMBDA),
+                ("eps_mm", C.c_double), ("eps_texel", C.c_double), ("eps_cos", C.c_double)]
+
+
+def g64_lens(lens, sun_dir=(0, 0, -1), sun_radiance=(1, 1, 1), sun_angular_radius=0.05,
+             lambda_rgb=None, eps_mm=5e-4, eps_texel=0.02, eps_cos=1e-4):
+    """The prescription and the light exactly as the device receives them (float32 values), held
+    in doubles.  eps_*: how close to a decision boundary a ray must pass to be called fragile --
+    about 10x the float32 march's accumulated position error."""
+    import math
+    L = G64Lens()
+    L.n_surf, L.stop = int(lens["n"]), int(lens["stop"])
+    ior = np.asarray(lens["ior"], np.float32)
+    L.n_lambda = ior.shape[0]
+    for k in range(L.n_surf):
+        L.radius[k] = float(np.float32(lens["radius"][k]))
+        L.thickness[k] = float(np.float32(lens["thickness"][k]))
+        L.semi_ap[k] = float(np.float32(lens["semi_aperture"][k]))
+        for l in range(L.n_lambda):
+            L.ior[l][k] = float(ior[l, k])
+    L.sensor_w_mm = float(np.float32(lens["sensor_width_mm"]))
+    d = [float(np.float32(v)) for v in sun_dir]
+    n = math.sqrt(sum(v * v for v in d))
+    for c in range(3):
+        L.sun_dir[c] = float(np.float32(d[c] / n))        # lf_set_sun stores the unit vector as float
+        L.sun_radiance[c] = float(np.float32(sun_radiance[c]))
+    L.sun_angular_radius = float(np.float32(sun_angular_radius))
+    for l in range(L.n_lambda):
+        for c in range(3):
+            if lambda_rgb is not None:
+                L.lambda_rgb[l][c] = float(np.float32(lambda_rgb[l][c]))
+            else:
+                L.lambda_rgb[l][c] = (1.0 if l == c else 0.0) if L.n_lambda == 3 else float(
+                    np.float32(1.0) / np.float32(L.n_lambda))
+    L.eps_mm, L.eps_texel, L.eps_cos = eps_mm, eps_texel, eps_cos
+    return L
+
+
+G64_COUNTERS = ("rays_launched", "surface_events", "rays_clipped_stop", "rays_vignetted", "rays_tir",
+                "rays_reached_scene", "rays_hit_light", "rays_fragile")
+
+
+def g64_trace(lens, W, H, y0, y1, spp, key, pairs, include_primary, mask, sun_dir, sun_radiance,
+              sun_angular_radius, n_threads=8, lambda_rgb=None, sub_bits=2, **eps):
+    """-> (image, frag, counters): image / frag are H x W x 3; a faithful float32 evaluation of the
+    same estimator satisfies |pixel32 - image| <= tol * image + frag (see lf_geo_f64.c)."""
+    L = g64_lens(lens, sun_dir, sun_radiance, sun_angular_radius, lambda_rgb, **eps)
+    if pairs is None:
+        pairs = all_pairs(lens, include_primary)
+    else:
+        pairs = np.asarray(pairs, np.int32).reshape(-1, 2)
+        if include_primary:
+            pairs = np.concatenate([np.array([[-1, -1]], np.int32), pairs])
+    pairs = np.ascontiguousarray(pairs, np.int32)
+    mask = np.ascontiguousarray(mask, np.float32)
+    image = np.zeros((H, W, 3), np.float64)
+    frag = np.zeros((H, W, 3), np.float64)
+    cnt = (C.c_uint64 * 8)()
+    k = (C.c_uint32 * 2)(key & 0xffffffff, (key >> 32) & 0xffffffff)
+    lib().g64_trace(C.byref(L), W, H, y0, y1, spp, k, int(sub_bits), _p(pairs, C.c_int), len(pairs),
+                    _p(mask, C.c_float), mask.shape[1], mask.shape[0], _p(image, C.c_double),
+                    _p(frag, C.c_double), cnt, n_threads)
+    return image, frag, dict(zip(G64_COUNTERS, (int(v) for v in cnt)))
+
+
+def g64_glass_event(lens_struct, lam, k, mirror, p, d, w=1.0):
+    pp = (C.c_double * 3)(*p)
+    dd = (C.c_double * 3)(*d)
+    ww = C.c_double(w)
+    st = lib().g64_glass_event(C.byref(lens_struct), int(lam), int(k), int(mirror), pp, dd, C.byref(ww))
+    return st, np.array(pp[:]), np.array(dd[:]), ww.value
+
+
+def g64_trace_ray(lens, lam, i, j, p, d, w=1.0, mask=None):
+    L = g64_lens(lens)
+    if mask is None:
+        mask = np.ones((4, 4), np.float32)
+    mask = np.ascontiguousarray(mask, np.float32)
+    pp = (C.c_double * 3)(*p)
+    dd = (C.c_double * 3)(*d)
+    ww = C.c_double(w)
+    ne = C.c_int()
+    st = lib().g64_trace_ray(C.byref(L), int(lam), int(i), int(j), pp, dd, C.byref(ww),
+                             _p(mask, C.c_float), mask.shape[1], mask.shape[0], C.byref(ne))
+    return st, np.array(pp[:]), np.array(dd[:]), ww.value, ne.value
+
+
+def g64_sensor_z(lens):
+    lib().g64_sensor_z.restype = C.c_double
+    return lib().g64_sensor_z(C.byref(g64_lens(lens)))
+
+
+def g64_philox(ctr, key):
+    c = (C.c_uint32 * 4)(*ctr)
+    k = (C.c_uint32 * 2)(*key)
+    o = (C.c_uint32 * 4)()
+    lib().g64_philox(c, k, o)
+    return list(o)

@@ -1,0 +1,162 @@
+"""The geometric march on the GPU against an INDEPENDENT float64 tracer (oracle/lf_geo_f64.c:
+textbook sphere quadratic, vector Snell, r_s / r_p Fresnel, libm sqrt -- no code, no float32
+recipe and no sqrt table in common with the bit-exact oracle), at the north star's bar: converged
+pixels within 1e-4 relative.  Float32 and float64 can disagree about the fate of a ray that passes
+within rounding distance of an aperture edge, a mask-texel edge or the critical angle; the tracer
+bounds the weight of those rays per pixel (`frag`), and the test states how often that allowance is
+needed at all.  Also here: the coherent pupil sub-cells converge to the independent estimate."""
+import numpy as np
+import pytest
+
+from goldenlib import load_texels
+from oracle import lfo
+
+pytestmark = pytest.mark.gpu
+
+TOL = 1e-4
+# a contribution is accumulated as 2^-36 fixed point (truncated): up to 46 paths x n_lambda
+# contributions per sample can each lose 1.5e-11, i.e. <= 2e-9 per pixel -- the stated floor keeps
+# that below TOL / 10
+FLOOR = 2e-5
+
+
+@pytest.fixture(scope="module")
+def pkg():
+    import __graft_entry__ as g
+    return g.load_package()
+
+
+@pytest.fixture(scope="module")
+def lf(pkg):
+    ctx = pkg.LensFlare(0)
+    yield ctx
+    ctx.close()
+
+
+def _gpu_frame(pkg, lf, lens, W, H, spp, key, mask, sun, rad, alpha, sub_bits=2, pairs=None):
+    lf.set_frame(W, H)
+    lf.set_aperture(pkg.APERTURE_STARBURST, mask)
+    lf.set_lens(lens)
+    lf.set_sun(sun, rad, alpha)
+    lf.set_ghost_pairs(pairs, True)
+    lf.set_pupil_subcells(sub_bits)
+    lf.reset_counters()
+    lf.trace_ghosts(spp, key)
+    img = lf.read_buffer(pkg.GHOST_BUFFER)
+    cnt = lf.counters()
+    lf.set_pupil_subcells(2)
+    return img, cnt
+
+
+def _check_against_f64(img, cnt, ref, frag, c64, min_lit):
+    assert c64["rays_launched"] == cnt["rays_launched"]
+    lit = ref >= FLOOR
+    assert lit.sum() >= min_lit, "the test frame must have converged pixels above the floor"
+    rel = np.abs(img - ref)[lit] / ref[lit]
+    # the bar, with the fragile rays' weight as the only allowance
+    assert np.all(np.abs(img - ref)[lit] <= TOL * ref[lit] + 1.05 * frag[lit]), rel.max()
+    # ... and that allowance is the exception, not the rule
+    assert (rel <= TOL).mean() >= 0.98, (rel <= TOL).mean()
+    assert np.median(rel) < 2e-6
+    # dim pixels: absolute agreement at the accumulation quantum
+    assert np.all(np.abs(img - ref)[~lit] <= TOL * FLOOR + 1.05 * frag[~lit])
+    # ray fates agree except for the fragile rays
+    n_frag = c64["rays_fragile"]
+    assert n_frag < 1e-2 * c64["rays_launched"]
+    for name in ("rays_clipped_stop", "rays_vignetted", "rays_tir", "rays_reached_scene", "rays_hit_light"):
+        assert abs(c64[name] - cnt[name]) <= n_frag, (name, c64[name], cnt[name])
+    assert abs(c64["surface_events"] - cnt["surface_events"]) <= 30 * n_frag
+    return rel
+
+
+def test_dgauss_converged_pixels_within_1e4(pkg, lf):
+    """64x48, 256 spp, double-Gauss, primary + all 45 pairs, 3 wavelengths, pentagon mask."""
+    lens = pkg.load_lens_file("dgauss11.lens")
+    mask = load_texels("pentbig500_14.png")
+    W, H, spp, key = 64, 48, 256, 0xBEEF
+    sun, rad, alpha = [0.03, 0.02, -1.0], [1.0, 0.9, 0.5], 0.05
+    img, cnt = _gpu_frame(pkg, lf, lens, W, H, spp, key, mask, sun, rad, alpha)
+    ref, frag, c64 = lfo.g64_trace(lens, W, H, 0, H, spp, key, None, True, mask, sun, rad, alpha,
+                                   n_threads=16)
+    rel = _check_against_f64(img, cnt, ref, frag, c64, min_lit=150)
+    print(f"dgauss: {rel.size} converged channel values, max rel {rel.max():.2e}, median {np.median(rel):.2e}")
+
+
+def test_thin_lens_converged_pixels_within_1e4(pkg, lf):
+    """BASELINE configs[0]'s lens (2 spherical surfaces, no stop), one ghost pair + primary."""
+    lens = pkg.load_lens_file("thinlens.lens")
+    mask = np.ones((8, 8), np.float32)
+    W, H, spp, key = 64, 48, 256, 0x7117
+    sun, rad, alpha = [0.02, -0.01, -1.0], [1.0, 1.0, 1.0], 0.1
+    img, cnt = _gpu_frame(pkg, lf, lens, W, H, spp, key, mask, sun, rad, alpha)
+    ref, frag, c64 = lfo.g64_trace(lens, W, H, 0, H, spp, key, None, True, mask, sun, rad, alpha,
+                                   n_threads=16)
+    rel = _check_against_f64(img, cnt, ref, frag, c64, min_lit=1000)
+    print(f"thin lens: {rel.size} converged channel values, max rel {rel.max():.2e}")
+
+
+def test_eight_wavelengths_within_1e4(pkg, lf):
+    """C5's 8 wavelengths with RGB weights, the same bar."""
+    lens3 = pkg.load_lens_file("dgauss11.lens")
+    t = np.linspace(0.0, 2.0, 8)
+    ior8 = np.stack([np.array([np.interp(tt, [0, 1, 2], lens3["ior"][:, k]) for k in range(lens3["n"])])
+                     for tt in t]).astype(np.float32)
+    lens8 = dict(lens3, ior=ior8)
+    w8 = np.zeros((8, 3), np.float32)
+    for l, tt in enumerate(t):
+        for c in range(3):
+            w8[l, c] = max(0.0, 1.0 - abs(tt - c)) / 2.6666667
+    mask = load_texels("pentbig500_14.png")
+    W, H, spp, key = 48, 32, 144, 0x8888
+    sun, rad, alpha = [0.02, 0.03, -1.0], [1.0, 0.9, 0.5], 0.05
+    lf.set_frame(W, H)
+    lf.set_aperture(pkg.APERTURE_STARBURST, mask)
+    lf.set_lens(lens8)
+    lf.set_lambda_rgb(w8)
+    lf.set_sun(sun, rad, alpha)
+    lf.set_ghost_pairs(None, True)
+    lf.reset_counters()
+    lf.trace_ghosts(spp, key)
+    img, cnt = lf.read_buffer(pkg.GHOST_BUFFER), lf.counters()
+    ref, frag, c64 = lfo.g64_trace(lens8, W, H, 0, H, spp, key, None, True, mask, sun, rad, alpha,
+                                   n_threads=16, lambda_rgb=w8)
+    _check_against_f64(img, cnt, ref, frag, c64, min_lit=50)
+
+
+def test_pupil_subcells_converge_to_the_independent_estimate(pkg, lf):
+    """All 64 pixels of an 8x8 tile share one pupil sub-cell per sample (coherent fate at the mask):
+    per pixel that is still a uniform draw from the stratum, so the estimator is unbiased, but the
+    noise is correlated inside a tile.  Check against the fully independent estimator (bits = 0):
+    the means over 12 keys agree within the Monte-Carlo error per pixel and in total, and the two
+    estimators have the same per-pixel variance (the correlation does not cost variance)."""
+    lens = pkg.load_lens_file("dgauss11.lens")
+    mask = load_texels("pentbig500_14.png")
+    W, H, spp = 48, 32, 64
+    sun, rad, alpha = [0.03, 0.02, -1.0], [1.0, 0.9, 0.5], 0.05
+    keys = [0x1000 + 17 * k for k in range(12)]
+    runs = {}
+    for bits in (2, 0):
+        runs[bits] = np.stack([_gpu_frame(pkg, lf, lens, W, H, spp, k, mask, sun, rad, alpha,
+                                          sub_bits=bits)[0].sum(axis=2) for k in keys])
+    a, b = runs[2], runs[0]
+    ma, mb = a.mean(axis=0), b.mean(axis=0)
+    se = np.sqrt((a.var(axis=0, ddof=1) + b.var(axis=0, ddof=1)) / len(keys))
+    lit = (ma + mb) > 2 * FLOOR
+    assert lit.sum() > 100
+    z = (ma - mb)[lit] / np.maximum(se[lit], 1e-12)
+    assert np.abs(z).max() < 6.0 and (np.abs(z) < 3.0).mean() > 0.97, (np.abs(z).max(), (np.abs(z) < 3).mean())
+    assert abs(z.mean()) < 0.35, z.mean()                       # no systematic offset
+    # whole-image flux: correlated noise does not average out inside a tile, so compare the frame
+    # totals with their own run-to-run scatter
+    ta, tb = a.sum(axis=(1, 2)), b.sum(axis=(1, 2))
+    s_tot = np.sqrt((ta.var(ddof=1) + tb.var(ddof=1)) / len(keys))
+    assert abs(ta.mean() - tb.mean()) < 4.0 * s_tot
+    # per-pixel variance: the same estimator quality
+    ratio = np.median(a.var(axis=0, ddof=1)[lit] / np.maximum(b.var(axis=0, ddof=1)[lit], 1e-30))
+    assert 0.6 < ratio < 1.6, ratio
+    # ... and both converge to the float64 tracer's expectation (common key: same sample points)
+    ref, frag, _ = lfo.g64_trace(lens, W, H, 0, H, spp, keys[0], None, True, mask, sun, rad, alpha,
+                                 n_threads=16, sub_bits=0)
+    img0, _ = _gpu_frame(pkg, lf, lens, W, H, spp, keys[0], mask, sun, rad, alpha, sub_bits=0)
+    litp = ref >= FLOOR
+    assert np.all(np.abs(img0 - ref)[litp] <= TOL * ref[litp] + 1.05 * frag[litp])
