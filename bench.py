@@ -173,7 +173,7 @@ def main():
             dist.init_process_group(backend)
 
     W, H, spp = args.width, args.height, args.spp
-    lens = pkg.load_lens_file("dgauss11.lens")
+    lens = pkg.load_lens_file(os.environ.get("LF_BENCH_LENS", "dgauss11.lens"))  # env: experiments only
     mask = load_mask()
     sun = sun_direction(lens, W, H)
 

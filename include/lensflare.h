@@ -221,6 +221,22 @@ lf_status lf_set_lambda_rgb(lf_ctx* ctx, const float* weights);
  * angular radius of its (smooth) lobe in radians */
 lf_status lf_set_sun(lf_ctx* ctx, const float dir[3], const float radiance[3],
                      float angular_radius);
+/* Sun hand-over from the scene to the march: turn in-frame flare `flare` of lf_find_sun_pos /
+ * lf_set_flares (normalised screen position flare_origins[flare], radiance flare_radiance[flare];
+ * src/pathtracer/pathtracer.cpp:32-64, camera.cpp:245-273) into the lens-space light of
+ * lf_set_sun, so that the geometric ghosts and the starburst agree about where the sun is: the
+ * direction is the one a lens of focal length efl_mm images at that sensor point,
+ *   (  (nx - 1/2) sensor_w / efl,  (ny - 1/2) sensor_w (H/W) / efl,  -1  )  normalised.
+ * efl_mm <= 0 takes the paraxial focal length of the prescription (lf_paraxial_efl at the middle
+ * wavelength).  Needs lf_set_frame, lf_set_lens and a flare state.  No reference counterpart (the
+ * reference's ghosts take only `angle_to_sun`, pathtracer.cpp:50, :735-762). */
+lf_status lf_set_sun_from_flares(lf_ctx* ctx, int flare, double efl_mm, float angular_radius);
+/* Paraxial effective focal length of a prescription at one wavelength (host arithmetic, no
+ * device): the system matrix from the reference's own T / R operators (pathtracer.cpp:527-533);
+ * ior_row = the n indices of that wavelength (media BEHIND each interface).  Arguments as
+ * lf_set_lens. */
+lf_status lf_paraxial_efl(int n_surfaces, int stop_index, const float* radius, const float* thickness,
+                          const float* ior_row, double* efl_mm);
 /* ghost pairs to enumerate: pairs = n x {i, j} interface indices (i < j, neither the stop);
  * i = j = -1 is the primary (no reflection) path.  n = 0 / NULL = all glass pairs. */
 lf_status lf_set_ghost_pairs(lf_ctx* ctx, const int* pairs, int n_pairs, int include_primary);

@@ -14,7 +14,8 @@ import os
 import numpy as np
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(HERE, "liblensflare_hip.so")
+# LF_LIB: experiments only (profiles/ab_*.sh time alternative builds of the same library)
+LIB_PATH = os.environ.get("LF_LIB") or os.path.join(HERE, "liblensflare_hip.so")
 DATA = os.path.join(HERE, "data")
 
 STATUS = {0: "LF_OK", 1: "LF_ERR_INVALID", 2: "LF_ERR_NO_DEVICE", 3: "LF_ERR_HIP",
@@ -31,7 +32,7 @@ ABI_SYMBOLS = [
     "lf_set_sampling", "lf_render_scene_term",
     "lf_generate_ghost_buffer", "lf_render_flare_layer", "lf_read_tile", "lf_read_pixel",
     "lf_write_to_framebuffer", "lf_save_image_rgba", "lf_device_buffer", "lf_set_lens", "lf_set_lambda_rgb", "lf_set_sun",
-    "lf_set_ghost_pairs", "lf_set_pupil_subcells", "lf_trace_ghosts", "lf_generate_lens_rays", "lf_get_counters", "lf_reset_counters", "lf_get_executed_events", "lf_native_sqrt", "lf_set_starburst_spectrum", "lf_load_collada", "lf_march_tables",
+    "lf_set_sun_from_flares", "lf_paraxial_efl", "lf_set_ghost_pairs", "lf_set_pupil_subcells", "lf_trace_ghosts", "lf_generate_lens_rays", "lf_get_counters", "lf_reset_counters", "lf_get_executed_events", "lf_native_sqrt", "lf_set_starburst_spectrum", "lf_load_collada", "lf_march_tables",
     "lf_timing_enable", "lf_timing_reset", "lf_timing_get",
 ]
 
@@ -118,6 +119,22 @@ def load_lens_file(path):
     return dict(n=n, stop=stop[0] if stop else -1, radius=rows[:, 0].astype(np.float32),
                 thickness=rows[:, 1].astype(np.float32), ior=ior.astype(np.float32),
                 semi_aperture=rows[:, -1].astype(np.float32), sensor_width_mm=float(sensor_w))
+
+
+def paraxial_efl(lens, lam=None):
+    """Paraxial focal length of a prescription dict (host arithmetic, needs no device)."""
+    lib = load_library()
+    ior = np.ascontiguousarray(lens["ior"], np.float32)
+    lam = ior.shape[0] // 2 if lam is None else lam
+    r = np.ascontiguousarray(lens["radius"], np.float32)
+    t = np.ascontiguousarray(lens["thickness"], np.float32)
+    row = np.ascontiguousarray(ior[lam], np.float32)
+    out = C.c_double()
+    st = lib.lf_paraxial_efl(int(lens["n"]), int(lens["stop"]), _fp(r, C.c_float), _fp(t, C.c_float),
+                             _fp(row, C.c_float), C.byref(out))
+    if st != 0:
+        raise LensFlareError(st, "lf_paraxial_efl")
+    return out.value
 
 
 class LensFlare:
@@ -338,6 +355,10 @@ class LensFlare:
         r = np.ascontiguousarray(radiance, np.float32)
         self._ck(self.lib.lf_set_sun(self.ctx, _fp(d, C.c_float), _fp(r, C.c_float),
                                      C.c_float(angular_radius)))
+
+    def set_sun_from_flares(self, flare=0, efl_mm=0.0, angular_radius=0.05):
+        self._ck(self.lib.lf_set_sun_from_flares(self.ctx, int(flare), C.c_double(efl_mm),
+                                                 C.c_float(angular_radius)))
 
     def set_ghost_pairs(self, pairs=None, include_primary=True):
         if pairs is None or len(pairs) == 0:

@@ -212,7 +212,7 @@ lf_status lf_destroy(lf_ctx* ctx) {
   }
   void* ptrs[] = {ctx->spectrum, ctx->twiddle, ctx->dft_rows, ctx->flares, ctx->ghosts, ctx->pl_dev,
                   ctx->lens_dev, ctx->pairs_dev, ctx->counters_dev, ctx->accum, ctx->events_dev,
-                  ctx->skip_dev, ctx->sun_lights_dev,
+                  ctx->skip_dev, ctx->prog_dev, ctx->sun_lights_dev,
                   ctx->scene_dev.nodes, ctx->scene_dev.prims, ctx->scene_dev.materials,
                   ctx->scene_dev.lights};
   for (void* p : ptrs) if (p) (void)hipFree(p);
@@ -645,6 +645,10 @@ lf_status lf_set_lens(lf_ctx* ctx, int n_surfaces, int stop_index, int n_lambda,
   }
   lf_derive_lens(ctx, n_surfaces, stop_index, n_lambda, radius, thickness, ior, semi_aperture,
                  sensor_width_mm);
+  ctx->raw_n = n_surfaces; ctx->raw_stop = stop_index;
+  std::memcpy(ctx->raw_radius, radius, sizeof(float) * (size_t)n_surfaces);
+  std::memcpy(ctx->raw_thickness, thickness, sizeof(float) * (size_t)n_surfaces);
+  std::memcpy(ctx->raw_ior, ior, sizeof(float) * (size_t)n_surfaces * (size_t)n_lambda);
   ctx->lens_valid = true;
   ctx->events_dirty = true;
   // default pair set: every pair of glass surfaces + the primary path
@@ -675,6 +679,53 @@ lf_status lf_set_sun(lf_ctx* ctx, const float dir[3], const float radiance[3],
                              (double)ctx->lens.sun_dir[2] * ctx->lens.sun_dir[2]);
   ctx->sun_valid = true;
   return LF_OK;
+}
+
+lf_status lf_paraxial_efl(int n, int stop, const float* radius, const float* thickness,
+                          const float* ior_row, double* efl_mm) {
+  if (n < 1 || n > LF_MAX_SURFACES || !radius || !thickness || !ior_row || !efl_mm) return LF_ERR_INVALID;
+  // ray (height, angle); T(d) = [[1, d], [0, 1]], R(c, n1, n2) = [[1, 0], [c (n1 - n2) / n2, n1 / n2]]
+  double m00 = 1, m01 = 0, m10 = 0, m11 = 1, n1 = 1.0;
+  for (int k = 0; k < n; k++) {
+    if (k != stop) {
+      const double c = radius[k] == 0.0f ? 0.0 : 1.0 / (double)radius[k], n2 = ior_row[k];
+      if (!(n2 >= 1.0)) return LF_ERR_INVALID;
+      const double r10 = c * (n1 - n2) / n2, r11 = n1 / n2;
+      const double a10 = r10 * m00 + r11 * m10, a11 = r10 * m01 + r11 * m11;
+      m10 = a10; m11 = a11;
+      n1 = n2;
+    }
+    if (k + 1 < n) {  // the last thickness (to the sensor) does not change the power
+      const double d = thickness[k];
+      m00 += d * m10; m01 += d * m11;
+    }
+  }
+  if (m10 == 0.0) return LF_ERR_INVALID;  // afocal
+  *efl_mm = -1.0 / (m10 * n1);            // image-space medium n1 (air for a camera lens)
+  return LF_OK;
+}
+
+lf_status lf_set_sun_from_flares(lf_ctx* ctx, int flare, double efl_mm, float angular_radius) {
+  if (!ctx || flare < 0 || flare >= LF_MAX_FLARES) return LF_ERR_INVALID;
+  if (ctx->W == 0) return lf_fail(ctx, LF_ERR_STATE, "lf_set_sun_from_flares before lf_set_frame");
+  if (!ctx->lens_valid) return lf_fail(ctx, LF_ERR_STATE, "lf_set_sun_from_flares before lf_set_lens");
+  if (!ctx->flares_valid) return lf_fail(ctx, LF_ERR_STATE, "no flare state: call lf_find_sun_pos or lf_set_flares");
+  LF_HIP(ctx, hipSetDevice(ctx->device));
+  LfFlares f;
+  LF_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  LF_HIP(ctx, hipMemcpy(&f, ctx->flares, sizeof(f), hipMemcpyDeviceToHost));
+  if (flare >= f.n_flares) return lf_fail(ctx, LF_ERR_INVALID, "lf_set_sun_from_flares: no such flare in the frame");
+  if (!(efl_mm > 0.0)) {
+    const lf_status st = lf_paraxial_efl(ctx->raw_n, ctx->raw_stop, ctx->raw_radius, ctx->raw_thickness,
+                                         ctx->raw_ior + (size_t)(ctx->lens.n_lambda / 2) * ctx->raw_n, &efl_mm);
+    if (st != LF_OK || !(efl_mm > 0.0))
+      return lf_fail(ctx, LF_ERR_INVALID, "lf_set_sun_from_flares: the prescription has no positive focal length");
+  }
+  const double sw = ctx->sensor_w_mm, sh = sw * (double)ctx->H / (double)ctx->W;
+  const float dir[3] = {(float)((f.origin[flare][0] - 0.5) * sw / efl_mm),
+                        (float)((f.origin[flare][1] - 0.5) * sh / efl_mm), -1.0f};
+  const float rad[3] = {(float)f.radiance[flare][0], (float)f.radiance[flare][1], (float)f.radiance[flare][2]};
+  return lf_set_sun(ctx, dir, rad, angular_radius);
 }
 
 lf_status lf_set_ghost_pairs(lf_ctx* ctx, const int* pairs, int n_pairs, int include_primary) {

@@ -137,6 +137,17 @@ struct alignas(32) LfEventRow {
   float eta2;      // eta * eta (float product)
 };
 enum { LF_EV_REFLECT = 1, LF_EV_STOP = 2, LF_EV_FLAT = 4 };
+// A program row as the device walks it: the interface once, the index ratios of the up to four
+// wavelengths that march it together (lf_march.hip, k_march<K>); one 64-byte scalar load.
+struct alignas(64) LfProgRow {
+  float zv, curv, h2, radius;
+  float sgn;
+  int flags;        // as LfEventRow::flags of the per-wavelength program rows
+  int skip;         // jump-table entry of this row: (rows to jump << 2) | state to restore
+  int pad1;
+  float eta[4];     // wavelength g*K + j of group g (repeated past the group's / the lens' last one)
+  float eta2[4];
+};
 // The march does not walk the per-pair sequences one by one: every path of a (sample, wavelength)
 // starts with the same backward leg from the sensor, and all pairs (i, .) share the forward leg that
 // follows the reflection at i.  The per-wavelength *program* is that tree in depth-first order:
@@ -214,15 +225,21 @@ struct lf_ctx {
   bool lens_valid = false, sun_valid = false;
   int march_sub_bits = 2;  // pupil sub-cells per stratum = 4 x 4 (part of the sampling spec)
   float sensor_w_mm = 36.0f;
+  int raw_n = 0, raw_stop = -1;   // the prescription as handed to lf_set_lens (for lf_paraxial_efl)
+  float raw_radius[LF_MAX_SURFACES] = {}, raw_thickness[LF_MAX_SURFACES] = {};
+  float raw_ior[LF_MAX_LAMBDA * LF_MAX_SURFACES] = {};
   LfLensDev* lens_dev = nullptr;
   LfPairsDev pairs{};
   LfPairsDev* pairs_dev = nullptr;
   unsigned long long* counters_dev = nullptr;  // 8 x u64
   unsigned long long* accum = nullptr;         // W*H_alloc*3 fixed-point partial sums (split launches)
-  LfEventRow* events_dev = nullptr;            // n_lambda x total_events, then n_lambda x prog_rows
+  LfEventRow* events_dev = nullptr;            // n_lambda x total_events flat rows (weight re-march)
   size_t events_cap = 0;
   int* skip_dev = nullptr;                     // prog_rows entries: where a dead wave jumps to
-  size_t skip_cap = 0;
+  size_t skip_cap = 0;                         // capacities in BYTES
+  LfProgRow* prog_dev = nullptr;               // n_groups x prog_rows packed program rows (+ spare)
+  size_t prog_cap = 0;
+  int march_k = 1;                             // wavelengths (rays per lane) that walk together
   bool events_dirty = true;
 
   bool timing = false;

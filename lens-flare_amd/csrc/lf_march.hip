@@ -239,19 +239,50 @@ struct MarchArgs {
   uint2 key;
 };
 
-__global__ __launch_bounds__(256) __attribute__((amdgpu_num_sgpr(100)))
-void k_march(const LfLensDev* __restrict__ lens,
-                                               const LfPairsDev* __restrict__ pairs,
-                                               const LfEventRow* __restrict__ ev_table,
-                                               const int* __restrict__ skip_tab,
-                                               const float* __restrict__ mask, MarchArgs a,
-                                               double* __restrict__ ghost,
-                                               unsigned long long* __restrict__ accum,
-                                               unsigned long long* __restrict__ counters) {
+// One program row for a GROUP of up to 4 wavelengths: the geometry of the interface once, the
+// index ratios of each wavelength of the group.  64 bytes = ONE s_load_dwordx16.
+typedef int lf_i16 __attribute__((ext_vector_type(16)));
+typedef const lf_i16 __attribute__((address_space(4))) * lf_const_prow_ptr;
+__device__ __forceinline__ LfProgRow load_prow(const LfProgRow* __restrict__ e) {
+  const lf_i16 v = *(lf_const_prow_ptr)(e);
+  LfProgRow r;
+  r.zv = __int_as_float(v[0]); r.curv = __int_as_float(v[1]); r.h2 = __int_as_float(v[2]);
+  r.radius = __int_as_float(v[3]); r.sgn = __int_as_float(v[4]); r.flags = v[5];
+  r.skip = v[6]; r.pad1 = 0;
+#pragma unroll
+  for (int j = 0; j < 4; j++) { r.eta[j] = __int_as_float(v[8 + j]); r.eta2[j] = __int_as_float(v[12 + j]); }
+  return r;
+}
+
+// K = rays per lane: the K wavelengths of a group walk the program TOGETHER.  They start as the same
+// ray and differ only by dispersion, so they share their fate almost always -- and the whole scalar
+// side of the walk (row load, dispatch on the row kind, loop control, fork/join, dead-wave jumps) is
+// paid once for K events.  That side was the binding resource of the one-ray walk: 7.6e10 scalar
+// instructions per bench frame on ONE scalar unit per CU (85 % busy) against 9.5e10 vector
+// instructions on four SIMDs (53 %); profiles/r02_*.  Each ray keeps its own liveness mask, tallies
+// are per ray, so pixels and counters are exactly those of K separate walks.
+// (second launch bound = waves per SIMD the register allocation must leave room for; the LDS
+// footprint allows exactly as many: 8 / 6 / 6 / 4 workgroups of 4 waves per CU for K = 1 .. 4)
+template <int K>
+__global__ __launch_bounds__(256, (K == 1 ? 8 : K <= 3 ? 6 : 4))
+void k_march(const LfLensDev* __restrict__ lens, const LfPairsDev* __restrict__ pairs,
+             const LfEventRow* __restrict__ ev_table, const LfProgRow* __restrict__ prog_table,
+             const int* __restrict__ skip_tab, const float* __restrict__ mask, MarchArgs a,
+             double* __restrict__ ghost, unsigned long long* __restrict__ accum,
+             unsigned long long* __restrict__ counters) {
   __shared__ unsigned long long s_acc[64 * 3];
   __shared__ unsigned long long s_cnt[8];
   __shared__ int s_next;
-  __shared__ float2 s_state[4][2][3 * 64];  // parked ray states: [wave][slot][px py|pz dx|dy dz][lane]
+  // parked ray states: [wave][slot][ray][px py|pz dx|dy dz][lane]
+  // fork slot 1 (the reflection at j, parked and restored once per pair) is parked here; slot 0 (the
+  // reflection at i, once per sub-tree: 3-4x rarer, so its register copies are cheap) lives in
+  // registers: with both in LDS a K = 3 workgroup needs 38 KB and only 4 waves fit a SIMD
+  // (measured 147 -> 137 ms per bench frame)
+  __shared__ float2 s_state[4][K][3 * 64];
+  // the start of the current sample's rays per lane (sensor point, direction, start weight): only
+  // the rare weight re-march reads it back, so it need not occupy six registers during the walk
+  // (volatile: otherwise the compiler forwards the stores to the loads and keeps the registers)
+  __shared__ volatile float s_start[4][6][64];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   if (tid < 64 * 3) s_acc[tid] = 0ull;
   if (tid < 8) s_cnt[tid] = 0ull;
@@ -269,6 +300,7 @@ void k_march(const LfLensDev* __restrict__ lens,
 
   const int n_lambda = lens->n_lambda, n_pairs = pairs->n, total_events = pairs->total_events;
   const int prog_rows = pairs->prog_rows;
+  const int n_groups = (n_lambda + K - 1) / K;
   const float z_sensor = lens->z_sensor, pitch = lens->pitch, pupil_h = lens->pupil_h;
   const float pupil_z = lens->pupil_z, geom_norm = lens->geom_norm;
   const float inv_stop_h = __fdiv_rn(1.0f, lens->stop_h);
@@ -277,10 +309,10 @@ void k_march(const LfLensDev* __restrict__ lens,
   const int GG = a.G * a.G;
   const lanemask active_mask = __ballot(active);
 
-  unsigned n_light = 0, n_launched = 0;  // per lane
+  unsigned n_light = 0;     // per lane
+  unsigned n_samples = 0;   // per wave
   // wave-uniform, counted once per wave with s_bcnt1 (SALU)
   unsigned long long events = 0, n_clip = 0, n_vign = 0, n_tir = 0, n_scene = 0, n_exec = 0;
-  unsigned long long acc[3] = {0ull, 0ull, 0ull};
 
   {
     // The 4 waves of the workgroup pull sample indices from one LDS counter instead of owning
@@ -332,167 +364,256 @@ void k_march(const LfLensDev* __restrict__ lens,
       const float d0x = vx * rl, d0y = vy * rl, d0z = vz * rl;
       const float c2 = d0z * d0z;
       const float w0 = geom_norm * (c2 * c2);
-      if (active) n_launched += (unsigned)(n_lambda * n_pairs);
+      s_start[wave][0][lane] = X; s_start[wave][1][lane] = Y; s_start[wave][2][lane] = d0x;
+      s_start[wave][3][lane] = d0y; s_start[wave][4][lane] = d0z; s_start[wave][5][lane] = w0;
+      n_samples++;
       // wave-uniform 32-bit tallies of this sample (64 lanes x pairs x wavelengths x rows < 2^32)
       unsigned ev32 = 0, clip32 = 0, vign32 = 0, tir32 = 0, scene32 = 0, exec32 = 0;
 
-      for (int l = 0; l < n_lambda; l++) {
-        // ---- walk the wavelength's program (the tree of all paths, depth first) ----------------
-        const LfEventRow* const prog = ev_table + pairs->prog_off + (size_t)l * (size_t)prog_rows;
-        const LfEventRow* const prog_end = prog + prog_rows;
-        const LfEventRow* __restrict__ e = prog;
-        Ray r{X, Y, z_sensor, d0x, d0y, d0z, 0.0f, 0.0f};
-        lanemask alive = active_mask, alive0 = 0ull, alive1 = 0ull;
+      for (int g = 0; g < n_groups; g++) {
+        // ---- walk the group's program (the tree of all paths, depth first) ---------------------
+        const LfProgRow* const prog = prog_table + (size_t)g * (size_t)prog_rows;
+        const LfProgRow* const prog_end = prog + prog_rows;
+        const LfProgRow* __restrict__ e = prog;
+        Ray r[K];
+        lanemask alive[K], alive0[K], alive1[K];
+#pragma unroll
+        for (int j = 0; j < K; j++) {
+          r[j] = Ray{X, Y, z_sensor, d0x, d0y, d0z, 0.0f, 0.0f};
+          alive[j] = (g * K + j < n_lambda) ? active_mask : 0ull;  // a short last group: dead rays
+          alive0[j] = 0ull; alive1[j] = 0ull;
+        }
+        auto live_count = [&]() {
+          unsigned n = 0;
+#pragma unroll
+          for (int j = 0; j < K; j++) n += (unsigned)__popcll(alive[j]);
+          return n;
+        };
+        auto none_alive = [&]() {
+          lanemask m = alive[0];
+#pragma unroll
+          for (int j = 1; j < K; j++) m |= alive[j];
+          return m == 0ull;
+        };
+        Ray r0[K];   // fork slot 0
+        auto park_all = [&](int slot, lanemask* keep) {
+#pragma unroll
+          for (int j = 0; j < K; j++) {
+            if (slot == 0) r0[j] = r[j];
+            else park(s_state[wave][j], lane, r[j]);
+            keep[j] = alive[j];
+          }
+        };
+        auto unpark_all = [&](int slot, const lanemask* keep) {
+#pragma unroll
+          for (int j = 0; j < K; j++) {
+            if (slot == 0) r[j] = r0[j];
+            else unpark(s_state[wave][j], lane, r[j]);
+            alive[j] = keep[j];
+          }
+        };
+        // `cur` always holds the row at e: whoever moves e loads the row it lands on, so a run's
+        // last iteration has already fetched the row the dispatch below looks at next
+        LfProgRow cur = load_prow(e);
         while (e != prog_end) {
-          const LfEventRow cur = load_row(e);
           const unsigned fl = (unsigned)cur.flags;
           const unsigned run = (fl >> 8) & 0xffu, mult = (fl >> 16) & 0xffu;
           unsigned endfl = 0u;  // flags of the row just executed if it completes a path
+          bool dead = false;    // no ray of the group is alive any more
+          int sk = 0;           // ... then: the jump-table entry of the row they died at
           if (run) {
-            // plain events (refraction at a curved interface): straight-line body.  The last row
-            // of a run may complete a path.
-            // Two rows per iteration: both scalar loads go out together (one wait), and the
-            // pointer / counter / tally work is shared by two events.
-            unsigned k = run, live_sum = 0u;
-            LfEventRow pl = cur;
+            // A run: plain events (refraction at a curved interface), possibly led by a curved
+            // mirror (the fork of a sub-tree or of one pair); straight-line bodies.  The last row of
+            // a run may complete a path.  Events are tallied per RUN, not per row: a run of n rows
+            // entered by m live rays completes n * m events minus, for every ray that ends at a row
+            // with k rows of the run left (that row included), k -- so the common row costs no
+            // scalar tally work at all; the rare death branch does the arithmetic.
+            unsigned k = run, lost = 0u;
+            const unsigned live0 = live_count();
             if (fl & LF_EV_REFLECT) {
-              // the run starts with a (curved) mirror: the fork of a sub-tree or of one pair
-              if (fl & LF_EV_SAVE0) { park(s_state[wave][0], lane, r); alive0 = alive; }
-              if (fl & LF_EV_SAVE1) { park(s_state[wave][1], lane, r); alive1 = alive; }
-              lanemask geom_ok;
-              const lanemask ok = surface_event<false>(r, cur.zv, cur.curv, cur.radius, cur.h2, cur.eta,
-                                                       cur.eta2, true, false, cur.sgn, geom_ok);
-              if ((alive & ~ok) != 0ull) {
-                vign32 += mult * (unsigned)__popcll(alive & ~geom_ok);
-                alive &= ok;
+              if (fl & LF_EV_SAVE0) park_all(0, alive0);
+              if (fl & LF_EV_SAVE1) park_all(1, alive1);
+              lanemask okv[K], died = 0ull;
+#pragma unroll
+              for (int j = 0; j < K; j++) {
+                if (K > 1 && alive[j] == 0ull) { okv[j] = 0ull; continue; }
+                lanemask geom_ok;
+                okv[j] = surface_event<false>(r[j], cur.zv, cur.curv, cur.radius, cur.h2, cur.eta[j],
+                                              cur.eta2[j], true, false, cur.sgn, geom_ok);
+                died |= alive[j] & ~okv[j];
               }
-              live_sum += (unsigned)__popcll(alive);
+              if (died != 0ull) {
+#pragma unroll
+                for (int j = 0; j < K; j++) {
+                  const unsigned nd = (unsigned)__popcll(alive[j] & ~okv[j]);
+                  vign32 += mult * nd;
+                  lost += nd * k;
+                  alive[j] &= okv[j];
+                }
+                if (none_alive()) { dead = true; k = 1u; sk = cur.skip; }
+              }
+              endfl = fl;
               ++e; --k;
-              if (alive == 0ull) k = 0u;
+              cur = load_prow(e);
             }
-            auto plain = [&](const LfEventRow& row) {
-              lanemask geom_ok;
-              const lanemask ok = surface_event<false>(r, row.zv, row.curv, row.radius, row.h2, row.eta,
-                                                       row.eta2, false, false, row.sgn, geom_ok);
-              if ((alive & ~ok) != 0ull) {  // some ray ends here, in `mult` logical paths
-                vign32 += mult * (unsigned)__popcll(alive & ~geom_ok);
-                tir32 += mult * (unsigned)__popcll(alive & geom_ok & ~ok);
-                alive &= ok;
+            while (k != 0u) {
+              lanemask okv[K], gv[K], died = 0ull;
+#pragma unroll
+              for (int j = 0; j < K; j++) {
+                // a wavelength whose rays are all gone is not computed (one scalar branch; without
+                // it its lanes would keep marching garbage through every row the others still visit)
+                if (K > 1 && alive[j] == 0ull) { okv[j] = 0ull; gv[j] = 0ull; continue; }
+                okv[j] = surface_event<false>(r[j], cur.zv, cur.curv, cur.radius, cur.h2, cur.eta[j],
+                                              cur.eta2[j], false, false, cur.sgn, gv[j]);
+                died |= alive[j] & ~okv[j];
               }
-              live_sum += (unsigned)__popcll(alive);
-            };
-            while (k >= 2u) {
-              const LfEventRow ra = load_row(e), rb = load_row(e + 1);
-              plain(ra);
-              pl = ra; ++e; --k;
-              if (alive == 0ull) break;
-              plain(rb);
-              pl = rb; ++e; --k;
-              if (alive == 0ull) break;
+              endfl = (unsigned)cur.flags;
+              if (died != 0ull) {  // some ray ends here, in `mult` logical paths
+#pragma unroll
+                for (int j = 0; j < K; j++) {
+                  vign32 += mult * (unsigned)__popcll(alive[j] & ~gv[j]);
+                  tir32 += mult * (unsigned)__popcll(alive[j] & gv[j] & ~okv[j]);
+                  lost += (unsigned)__popcll(alive[j] & ~okv[j]) * k;
+                  alive[j] &= okv[j];
+                }
+                if (none_alive()) { dead = true; k = 1u; sk = cur.skip; }
+              }
+              ++e; --k;
+              cur = load_prow(e);   // (the table ends with a spare row)
             }
-            if (k == 1u && alive != 0ull) {
-              pl = load_row(e);
-              plain(pl);
-              ++e;
-            }
+            const unsigned live_sum = run * live0 - lost;
             ev32 += mult * live_sum;   // logical events: one per path that shares these rows
             exec32 += live_sum;        // computed events
-            endfl = (unsigned)pl.flags;
           } else if (fl & LF_EV_STOP) {
-            const lanemask ok = stop_event<false>(r, cur.zv, cur.h2, inv_stop_h, mask, a.mw, a.mh);
-            if ((alive & ~ok) != 0ull) {
-              clip32 += mult * (unsigned)__popcll(alive & ~ok);
-              alive &= ok;
+            lanemask okv[K], died = 0ull;
+#pragma unroll
+            for (int j = 0; j < K; j++) {
+              if (K > 1 && alive[j] == 0ull) { okv[j] = 0ull; continue; }
+              okv[j] = stop_event<false>(r[j], cur.zv, cur.h2, inv_stop_h, mask, a.mw, a.mh);
+              died |= alive[j] & ~okv[j];
             }
-            const unsigned live = (unsigned)__popcll(alive);
+            if (died != 0ull) {
+#pragma unroll
+              for (int j = 0; j < K; j++) {
+                clip32 += mult * (unsigned)__popcll(alive[j] & ~okv[j]);
+                alive[j] &= okv[j];
+              }
+              dead = none_alive();
+            }
+            const unsigned live = live_count();
             ev32 += mult * live;
             exec32 += live;
-            ++e;
             endfl = fl;
+            sk = cur.skip;
+            ++e;
+            cur = load_prow(e);
           } else {
-            // a mirror event (the fork of a sub-tree or of one pair) or flat glass
-            if (fl & LF_EV_SAVE0) { park(s_state[wave][0], lane, r); alive0 = alive; }
-            if (fl & LF_EV_SAVE1) { park(s_state[wave][1], lane, r); alive1 = alive; }
-            lanemask geom_ok;
-            const lanemask ok = surface_event<false>(r, cur.zv, cur.curv, cur.radius, cur.h2,
-                                                     cur.eta, cur.eta2, (fl & LF_EV_REFLECT) != 0,
-                                                     (fl & LF_EV_FLAT) != 0, cur.sgn, geom_ok);
-            if ((alive & ~ok) != 0ull) {
-              vign32 += mult * (unsigned)__popcll(alive & ~geom_ok);
-              tir32 += mult * (unsigned)__popcll(alive & geom_ok & ~ok);
-              alive &= ok;
+            // a single mirror event (a fork that ends its leg at once) or flat glass
+            if (fl & LF_EV_SAVE0) park_all(0, alive0);
+            if (fl & LF_EV_SAVE1) park_all(1, alive1);
+            lanemask okv[K], gv[K], died = 0ull;
+#pragma unroll
+            for (int j = 0; j < K; j++) {
+              if (K > 1 && alive[j] == 0ull) { okv[j] = 0ull; gv[j] = 0ull; continue; }
+              okv[j] = surface_event<false>(r[j], cur.zv, cur.curv, cur.radius, cur.h2, cur.eta[j],
+                                            cur.eta2[j], (fl & LF_EV_REFLECT) != 0,
+                                            (fl & LF_EV_FLAT) != 0, cur.sgn, gv[j]);
+              died |= alive[j] & ~okv[j];
             }
-            const unsigned live = (unsigned)__popcll(alive);
+            if (died != 0ull) {
+#pragma unroll
+              for (int j = 0; j < K; j++) {
+                vign32 += mult * (unsigned)__popcll(alive[j] & ~gv[j]);
+                tir32 += mult * (unsigned)__popcll(alive[j] & gv[j] & ~okv[j]);
+                alive[j] &= okv[j];
+              }
+              dead = none_alive();
+            }
+            const unsigned live = live_count();
             ev32 += mult * live;
             exec32 += live;
-            ++e;
             endfl = fl;
+            sk = cur.skip;
+            ++e;
+            cur = load_prow(e);
           }
-          if (alive == 0ull) {
-            // the whole wave is dead: jump over everything only these rays would still visit
-            const int sk = skip_tab[(e - 1) - prog];
+          if (dead) {
+            // every ray of the wave is dead: jump over everything only these rays would still visit
+            // (the jump-table entry travels in the row itself: no dependent load in front of the next row)
             e = (e - 1) + (sk >> 2);
-            if ((sk & 3) == 1) { unpark(s_state[wave][1], lane, r); alive = alive1; }
-            else if ((sk & 3) == 2) { unpark(s_state[wave][0], lane, r); alive = alive0; }
+            cur = load_prow(e);
+            if ((sk & 3) == 1) unpark_all(1, alive1);
+            else if ((sk & 3) == 2) unpark_all(0, alive0);
           } else if (endfl & LF_EV_END) {
             // ---- a path is complete ---------------------------------------------------------
-            scene32 += (unsigned)__popcll(alive);
-            // inside the sun's lobe?
-            // (cheap pre-test: 1 - d.s cancels -- its absolute error of ~1e-7 is ~1e-4 of a 0.05 rad
-            // lobe -- so it only selects, with a 1/16 margin; the lobe factor itself is evaluated
-            // without cancellation after the weight re-march, see lobe_q)
-            const float cg = fmaf(r.dx, sx, fmaf(r.dy, sy, r.dz * sz));
-            const lanemask lit = alive & __ballot((1.0f - cg) * inv_1mc < 1.0625f);
-            if (lit != 0ull) {
-              // rare (about 1 % of the wave-paths): march this path again, alone and with the
-              // weight, along its own row sequence
-              const int q = (int)(endfl >> 24);
-              const LfEventRow* __restrict__ w = ev_table + (size_t)l * (size_t)total_events +
-                                                 pairs->ev_off[q];
-              Ray rw{X, Y, z_sensor, d0x, d0y, d0z, w0, 1.0f};
-              for (int left = pairs->ev_cnt[q]; left > 0; --left, ++w) {
-                const LfEventRow wr = load_row(w);
-                if (wr.flags & LF_EV_STOP) {
-                  (void)stop_event<true>(rw, wr.zv, wr.h2, inv_stop_h, mask, a.mw, a.mh);
-                } else {
-                  lanemask geom_ok;
-                  (void)surface_event<true>(rw, wr.zv, wr.curv, wr.radius, wr.h2, wr.eta, wr.eta2,
-                                            (wr.flags & LF_EV_REFLECT) != 0,
-                                            (wr.flags & LF_EV_FLAT) != 0, wr.sgn, geom_ok);
-                }
-              }
-              // (selects, not branches: with no divergent branch anywhere in the walk the compiler
-              // keeps its control flow as plain scalar branches)
-              // (the re-march reproduces the first pass bit for bit: rw's direction is r's)
-              const float qq = lobe_q(rw.dx, rw.dy, rw.dz, sx, sy, sz, sun_ss, inv_1mc);
-              const float om = 1.0f - qq;
-              float contrib = __fdiv_rn(rw.wn, rw.wd) * (om * om);
-              contrib = (((lit >> lane) & 1ull) != 0ull && qq < 1.0f && contrib > 0.0f) ? contrib : 0.0f;
-              n_light += contrib > 0.0f ? 1u : 0u;
+            scene32 += live_count();
+            // inside the sun's lobe?  (cheap pre-test: 1 - d.s cancels -- its absolute error of ~1e-7
+            // is ~1e-4 of a 0.05 rad lobe -- so it only selects, with a 1/16 margin; the lobe factor
+            // itself is evaluated without cancellation after the weight re-march, see lobe_q)
+            lanemask lit[K], lit_any = 0ull;
 #pragma unroll
-              for (int c = 0; c < 3; c++) {
-                const float v = contrib * (lens->sun_radiance[c] * lens->lambda_rgb[l][c]);
-                acc[c] += (unsigned long long)(v * kFixScale);
+            for (int j = 0; j < K; j++) {
+              const float cg = fmaf(r[j].dx, sx, fmaf(r[j].dy, sy, r[j].dz * sz));
+              lit[j] = alive[j] & __ballot((1.0f - cg) * inv_1mc < 1.0625f);
+              lit_any |= lit[j];
+            }
+            if (lit_any != 0ull) {
+              // rare (about 1 % of the wave-paths): march this path again, alone and with the
+              // weight, along its own row sequence -- once per wavelength that has a lit lane
+              const int q = (int)(endfl >> 24);
+              for (int j = 0; j < K; j++) {   // not unrolled: one copy of the weighted march
+                lanemask lj = lit[0];
+#pragma unroll
+                for (int jj = 1; jj < K; jj++) lj = (j == jj) ? lit[jj] : lj;
+                if (lj == 0ull) continue;
+                const int l = g * K + j;
+                const LfEventRow* __restrict__ w = ev_table + (size_t)l * (size_t)total_events +
+                                                   pairs->ev_off[q];
+                Ray rw{s_start[wave][0][lane], s_start[wave][1][lane], z_sensor, s_start[wave][2][lane],
+                       s_start[wave][3][lane], s_start[wave][4][lane], s_start[wave][5][lane], 1.0f};
+                for (int left = pairs->ev_cnt[q]; left > 0; --left, ++w) {
+                  const LfEventRow wr = load_row(w);
+                  if (wr.flags & LF_EV_STOP) {
+                    (void)stop_event<true>(rw, wr.zv, wr.h2, inv_stop_h, mask, a.mw, a.mh);
+                  } else {
+                    lanemask geom_ok;
+                    (void)surface_event<true>(rw, wr.zv, wr.curv, wr.radius, wr.h2, wr.eta, wr.eta2,
+                                              (wr.flags & LF_EV_REFLECT) != 0,
+                                              (wr.flags & LF_EV_FLAT) != 0, wr.sgn, geom_ok);
+                  }
+                }
+                // (selects, not branches: with no divergent branch anywhere in the walk the compiler
+                // keeps its control flow as plain scalar branches)
+                // (the re-march reproduces the first pass bit for bit: rw's direction is r[j]'s)
+                const float qq = lobe_q(rw.dx, rw.dy, rw.dz, sx, sy, sz, sun_ss, inv_1mc);
+                const float om = 1.0f - qq;
+                float contrib = __fdiv_rn(rw.wn, rw.wd) * (om * om);
+                contrib = (((lj >> lane) & 1ull) != 0ull && qq < 1.0f && contrib > 0.0f) ? contrib : 0.0f;
+                n_light += contrib > 0.0f ? 1u : 0u;
+#pragma unroll
+                for (int c = 0; c < 3; c++) {
+                  // straight into the tile's LDS sums (integers: any order gives the same bits);
+                  // lit lanes are ~0.4 % of the rays, six registers of per-lane sums are not worth it
+                  const float v = contrib * (lens->sun_radiance[c] * lens->lambda_rgb[l][c]);
+                  const unsigned long long fx = (unsigned long long)(v * kFixScale);
+                  if (fx) atomicAdd(&s_acc[lane * 3 + c], fx);
+                }
               }
             }
             // back to the fork this path left from (neither flag: that was the primary path)
-            if (endfl & LF_EV_REST1) { unpark(s_state[wave][1], lane, r); alive = alive1; }
-            else if (endfl & LF_EV_REST0) { unpark(s_state[wave][0], lane, r); alive = alive0; }
+            if (endfl & LF_EV_REST1) unpark_all(1, alive1);
+            else if (endfl & LF_EV_REST0) unpark_all(0, alive0);
           }
         }
       }
       n_exec += exec32; events += ev32; n_clip += clip32; n_vign += vign32; n_tir += tir32; n_scene += scene32;
     }
-    if (active) {
-#pragma unroll
-      for (int c = 0; c < 3; c++)
-        if (acc[c]) atomicAdd(&s_acc[lane * 3 + c], acc[c]);
-    }
   }
 
   // ---- counters: wave reduce, one LDS add per wave, one global add per workgroup ------------
   {
-    unsigned long long v0 = n_launched, v6 = n_light;
+    unsigned long long v0 = active ? (unsigned long long)n_samples * (unsigned)(n_lambda * n_pairs) : 0ull;
+    unsigned long long v6 = n_light;
     for (int off = 32; off > 0; off >>= 1) { v0 += __shfl_down(v0, off); v6 += __shfl_down(v6, off); }
     const unsigned long long vals[8] = {v0, events, n_clip, n_vign, n_tir, n_scene, v6, n_exec};
     if (lane == 0) {
@@ -809,31 +930,66 @@ lf_status lf_build_march_tables(lf_ctx* ctx, std::vector<LfEventRow>& rows, std:
   return LF_OK;
 }
 
+// rays per lane for n wavelengths: groups of at most 4, as even as possible (3 -> 3; 8 -> 4 + 4;
+// 5 -> 3 + 2; 7 -> 4 + 3)
+static int rays_per_lane(int n_lambda) {
+  int k = (n_lambda + ((n_lambda + 3) / 4) - 1) / ((n_lambda + 3) / 4);
+  if (const char* kv = std::getenv("LF_MARCH_K")) {  // experiments only
+    int v = std::atoi(kv);
+    if (v >= 1 && v <= 4) k = v;
+  }
+  return k;
+}
+
+// host: merge the per-wavelength programs (identical but for the index ratios) into rows that
+// serve K wavelengths at once
+static void pack_program(const lf_ctx* ctx, const std::vector<LfEventRow>& rows,
+                         const std::vector<int>& skip, int K, std::vector<LfProgRow>& out) {
+  const LfPairsDev& P = ctx->pairs;
+  const int n_lambda = ctx->lens.n_lambda, n_groups = (n_lambda + K - 1) / K;
+  out.assign((size_t)n_groups * P.prog_rows + 1, LfProgRow{});   // + one spare row
+  for (int g = 0; g < n_groups; g++)
+    for (int i = 0; i < P.prog_rows; i++) {
+      LfProgRow& o = out[(size_t)g * P.prog_rows + i];
+      for (int j = 0; j < 4; j++) {
+        const int l = std::min(g * K + (j < K ? j : K - 1), n_lambda - 1);
+        const LfEventRow& r = rows[(size_t)P.prog_off + (size_t)l * P.prog_rows + i];
+        if (j == 0) {
+          o.zv = r.zv; o.curv = r.curv; o.h2 = r.h2; o.radius = r.radius; o.sgn = r.sgn; o.flags = r.flags;
+          o.skip = skip[(size_t)i];
+        }
+        o.eta[j] = r.eta; o.eta2[j] = r.eta2;
+      }
+    }
+}
+
 static lf_status build_event_table(lf_ctx* ctx) {
   std::vector<LfEventRow> rows;
   std::vector<int> skip;
   lf_status st = lf_build_march_tables(ctx, rows, skip);
   if (st != LF_OK) return st;
+  ctx->march_k = rays_per_lane(ctx->lens.n_lambda);
+  std::vector<LfProgRow> prog;
+  pack_program(ctx, rows, skip, ctx->march_k, prog);
+  rows.resize((size_t)ctx->pairs.prog_off);   // the device keeps the flat sequences in this format
+  rows.push_back(LfEventRow{});               // spare
   // The context's stream is non-blocking, so the null-stream copies below are NOT ordered behind a
   // k_march that is still walking the previous program: a program / jump-table pair that changes
   // under a live kernel can send a wave past the program's end.  Drain the stream first.
   LF_HIP(ctx, hipStreamSynchronize(ctx->stream));
-  if (skip.size() > ctx->skip_cap) {
-    if (ctx->skip_dev) { (void)hipFree(ctx->skip_dev); }
-    ctx->skip_dev = nullptr;
-    LF_HIP(ctx, hipMalloc((void**)&ctx->skip_dev, skip.size() * sizeof(int)));
-    ctx->skip_cap = skip.size();
-  }
-  if (!skip.empty())
-    LF_HIP(ctx, hipMemcpy(ctx->skip_dev, skip.data(), skip.size() * sizeof(int), hipMemcpyHostToDevice));
-  if (rows.size() > ctx->events_cap) {
-    if (ctx->events_dev) { (void)hipFree(ctx->events_dev); }
-    ctx->events_dev = nullptr;
-    LF_HIP(ctx, hipMalloc((void**)&ctx->events_dev, rows.size() * sizeof(LfEventRow)));
-    ctx->events_cap = rows.size();
-  }
-  LF_HIP(ctx, hipMemcpy(ctx->events_dev, rows.data(), rows.size() * sizeof(LfEventRow),
-                        hipMemcpyHostToDevice));
+  auto upload = [&](void** dev, size_t* cap, const void* src, size_t bytes) -> hipError_t {
+    if (bytes > *cap) {
+      if (*dev) (void)hipFree(*dev);
+      *dev = nullptr; *cap = 0;
+      hipError_t e = hipMalloc(dev, bytes);
+      if (e != hipSuccess) return e;
+      *cap = bytes;
+    }
+    return bytes ? hipMemcpy(*dev, src, bytes, hipMemcpyHostToDevice) : hipSuccess;
+  };
+  LF_HIP(ctx, upload((void**)&ctx->skip_dev, &ctx->skip_cap, skip.data(), skip.size() * sizeof(int)));
+  LF_HIP(ctx, upload((void**)&ctx->events_dev, &ctx->events_cap, rows.data(), rows.size() * sizeof(LfEventRow)));
+  LF_HIP(ctx, upload((void**)&ctx->prog_dev, &ctx->prog_cap, prog.data(), prog.size() * sizeof(LfProgRow)));
   ctx->events_dirty = false;
   return LF_OK;
 }
@@ -871,10 +1027,8 @@ lf_status lfk_march(lf_ctx* ctx, int spp, uint64_t key) {
   // A launch that covers only part of the frame (one GPU's share) keeps >= 24k workgroups in flight
   // by splitting each tile's samples over `sgroups` workgroups (power of two), so that its tail
   // stays short -- but a workgroup needs >= 64 samples to amortise its set-up and its 192 global
-  // atomics.  Measured with profiles/share_timing.py on the bench frame (ms for 1, 1/2, 1/4, 1/8 of
-  // the tile rows): sgroups 1: 155.7 80.3 41.9 22.6 | 2: 154.3 78.6 40.1 20.9 |
-  // 4: 157.2 79.5 40.0 20.3 | 8: 169.4 85.5 42.8 21.6.  The whole frame on one GPU stays unsplit:
-  // the split costs 5x the HBM write traffic (atomics) for 1 % of time.
+  // atomics.  The whole frame on one GPU stays unsplit: the split costs 5x the HBM write traffic
+  // (atomics) for 1 % of time.
   a.sgroups = 1;
   while (tiles * a.sgroups < 24000 && a.sgroups * 2 * 64 <= spp) a.sgroups *= 2;
   if (const char* sgv = std::getenv("LF_MARCH_SGROUPS")) {  // experiments only
@@ -891,9 +1045,17 @@ lf_status lfk_march(lf_ctx* ctx, int spp, uint64_t key) {
                                ctx->stream));
   }
   hipEvent_t ev = lf_timing_begin(ctx, LFK_MARCH);
-  hipLaunchKernelGGL(k_march, dim3((unsigned)blocks), dim3(256), 0, ctx->stream, ctx->lens_dev,
-                     ctx->pairs_dev, ctx->events_dev, ctx->skip_dev, m.texels, a, ctx->ghost, ctx->accum,
-                     ctx->counters_dev);
+#define LF_LAUNCH_MARCH(KK)                                                                        \
+  hipLaunchKernelGGL(k_march<KK>, dim3((unsigned)blocks), dim3(256), 0, ctx->stream, ctx->lens_dev, \
+                     ctx->pairs_dev, ctx->events_dev, ctx->prog_dev, ctx->skip_dev, m.texels, a,    \
+                     ctx->ghost, ctx->accum, ctx->counters_dev)
+  switch (ctx->march_k) {
+    case 1: LF_LAUNCH_MARCH(1); break;
+    case 2: LF_LAUNCH_MARCH(2); break;
+    case 3: LF_LAUNCH_MARCH(3); break;
+    default: LF_LAUNCH_MARCH(4); break;
+  }
+#undef LF_LAUNCH_MARCH
   lf_timing_end(ctx, LFK_MARCH, ev);
   LF_HIP(ctx, hipGetLastError());
   if (a.sgroups > 1) {

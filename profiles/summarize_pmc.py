@@ -13,7 +13,8 @@ kern = sys.argv[2] if len(sys.argv) > 2 else "k_march"
 sums, disp = defaultdict(float), defaultdict(set)
 for f in glob.glob(out_dir + "/*/*/*counter_collection.csv"):
     for row in csv.DictReader(open(f)):
-        if kern + "(" not in row["Kernel_Name"]:   # k_march, not k_march_finish
+        name = row["Kernel_Name"]
+        if kern + "(" not in name and kern + "<" not in name:   # k_march / k_march<K>, not k_march_finish
             continue
         c = row["Counter_Name"]
         sums[c] += float(row["Counter_Value"])
