@@ -1,22 +1,29 @@
 #!/usr/bin/env python3
 """bench.py -- headline benchmark of the lens-flare hot path on MI355X.
 
-    python bench.py [--gpus N --steps K --warmup W]          (N=1)
+    python bench.py [--gpus N --steps K --warmup W] [--config c2|c3|c4_1gpu|c5_1gpu]
     python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N --steps K --warmup W
 
-Workload (BASELINE.json configs[2], the one its metric is quoted on): Double-Gauss 11-interface
-prescription (lens-flare_amd/data/dgauss11.lens), primary path + all 45 ghost pairs, 3 wavelengths,
-pentagon aperture mask (final_apertures/pentbig500_14.png), 1920x1080, 256 sensor samples/pixel,
-one synthetic sun at normalised screen position (0.521445, 0.517156).
+Default workload = BASELINE.json configs[2], the one its metric is quoted on ("c3"): Double-Gauss
+11-interface prescription (lens-flare_amd/data/dgauss11.lens), primary path + all 45 ghost pairs,
+3 wavelengths, pentagon aperture mask (final_apertures/pentbig500_14.png), 1920x1080, 256 sensor
+samples per pixel, one synthetic sun at normalised screen position (0.521445, 0.517156).  The other
+single-GPU configurations of BASELINE.json are selectable with --config (see CONFIGS).
 
-One step = one full frame of the hot path: find_sun_pos -> geometric ghost march (the dominant
-kernel) -> starburst/falloff/compose flare layer; with N > 1 the 8-row sensor tile rows are dealt
-round-robin to the ranks (strong scaling: the frame is fixed) and the finished tile rows are
-exchanged with in-place RCCL all-gathers over xGMI.  `value` = executed ray-surface events of the whole
-job per second (device counters, not an upper bound).  Inputs are resident in HBM before the timed
-region starts.
+One step = one full frame of the hot path: find_sun_pos -> [scene term] -> geometric ghost march
+(the dominant kernel) -> starburst / falloff / compose flare layer; with N > 1 the 8-row sensor
+tile rows are dealt round-robin to the ranks (strong scaling: the frame is fixed) and the finished
+tile rows are exchanged with ONE all-gather per frame (RCCL over xGMI).
+
+`value` = ray-surface intersections the device EXECUTED per second, whole job (device counter
+lf_get_executed_events; the reference's own metric also counts rays actually traced,
+raytraced_renderer.cpp:706-709).  The paths of one sensor sample share legs, which the march
+computes once; counting every path on its own (what a per-path tracer such as the CPU baseline
+does) gives `value_logical`, 3.9x larger on c3 -- an algorithmic saving, reported as such, never as
+throughput.  Inputs are resident in HBM before the timed region starts.
 """
 import argparse
+import hashlib
 import json
 import math
 import os
@@ -27,26 +34,62 @@ import numpy as np
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
-sys.path.insert(0, os.path.join(ROOT, "tests"))
 
-HBM_PEAK_GBS = 8000.0            # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
-VALU_PEAK_LANEOPS = 256 * 4 * 32 * 2.4e9   # 1024 SIMD-32 x 2.4 GHz (one wave64 VALU op / 2 clk)
+HBM_PEAK_GBS = 8000.0                     # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
+CLOCK_HZ = 2.4e9
+VALU_PEAK = 256 * 4 * CLOCK_HZ / 2.0      # wave64 instructions / s: 1024 SIMD-32, 2 clk each
+VALU_PRACTICAL = 1.05e12                  # profiles/microbench/valu_issue.hip (independent v_fma_f32)
+SCALAR_PEAK = 256 * CLOCK_HZ              # one scalar unit per CU, one instruction per clock
 SUN_NS = (0.521445, 0.517156)
 TILE_ROWS = 8   # the march kernel's sensor tile is 8x8 pixels
+PMC_FILE = os.path.join(ROOT, "profiles", "r02_march_pmc.json")
+
+# BASELINE.json configs[1..4]; configs[3] / [4] are 8-GPU jobs there, here one GPU's whole frame
+CONFIGS = {
+    "c2": dict(W=1920, H=1080, spp=64, pairs="reference", n_lambda=3, scene=None, spectral=False,
+               text="BASELINE.json configs[1]: double-Gauss 11 interfaces, pentagon mask, 1080p 64 spp, "
+                    "primary + the reference's pair enumeration (both mirrors on one side of the stop, "
+                    "pathtracer.cpp:735-762: 20 pairs) x 3 wavelengths"),
+    "c3": dict(W=1920, H=1080, spp=256, pairs="all", n_lambda=3, scene=None, spectral=False,
+               text="BASELINE.json configs[2]: double-Gauss 11 interfaces (dgauss11.lens), primary + 45 "
+                    "ghost pairs x 3 wavelengths, pentagon mask pentbig500_14, 1920x1080, 256 spp, one sun"),
+    "c4_1gpu": dict(W=3840, H=2160, spp=256, pairs="all", n_lambda=3, scene="pyramid.dae", spectral=False,
+                    text="BASELINE.json configs[3] on ONE GPU: 4K 256 spp, the sun is the scene's "
+                         "DirectionalLight (dae/dragon.dae is absent from the reference checkout: "
+                         "dae/pyramid.dae, the project's own sun scene), scene term on the device, "
+                         "sun handed to the march by lf_set_sun_from_flares"),
+    "c5_1gpu": dict(W=3840, H=2160, spp=1024, pairs="all", n_lambda=8, scene=None, spectral=True,
+                    text="BASELINE.json configs[4] on ONE GPU: 8 wavelengths (indices interpolated between "
+                         "the lens file's C, d, F columns) + spectral starburst, 4K 1024 spp"),
+}
 
 
-def load_mask():
-    from goldenlib import load_texels
-    return load_texels("pentbig500_14.png")
+def sun_direction(lens, efl, W, H):
+    """Lens-space direction towards a sun that a lens of focal length efl images at normalised
+    screen position SUN_NS (what lf_set_sun_from_flares computes from a flare)."""
+    sw = lens["sensor_width_mm"]
+    return [(SUN_NS[0] - 0.5) * sw / efl, (SUN_NS[1] - 0.5) * sw * H / W / efl, -1.0]
 
 
-def sun_direction(lens, W, H):
-    """Lens-space direction towards a sun that a pinhole of the lens' focal length images at
-    normalised screen position SUN_NS (same convention as Camera::analyze_world_coord)."""
-    efl = 50.358
-    ex = 0.5 * lens["sensor_width_mm"] / efl
-    ey = ex * H / W
-    return [(2 * SUN_NS[0] - 1) * ex, (2 * SUN_NS[1] - 1) * ey, -1.0]
+def lens_8_lambda(lens3):
+    t = np.linspace(0.0, 2.0, 8)
+    ior8 = np.stack([np.array([np.interp(tt, [0, 1, 2], lens3["ior"][:, k]) for k in range(lens3["n"])])
+                     for tt in t]).astype(np.float32)
+    w8 = np.zeros((8, 3), np.float32)
+    for l, tt in enumerate(t):   # tent weights onto R, G, B
+        for c in range(3):
+            w8[l, c] = max(0.0, 1.0 - abs(tt - c)) / 2.6666667
+    # starburst: the pattern scales with wavelength; 656 .. 486 nm relative to the d line (588 nm)
+    lam = np.interp(t, [0, 1, 2], [656.0, 588.0, 486.0])
+    return dict(lens3, ior=ior8), w8, (588.0 / lam)
+
+
+def pair_list(lens, kind):
+    if kind == "all":
+        return None
+    stop = lens["stop"]
+    return [(i, j) for i in range(stop) for j in range(i + 1, stop)] + \
+           [(i, j) for i in range(stop + 1, lens["n"]) for j in range(i + 1, lens["n"])]
 
 
 class DevView:
@@ -57,83 +100,129 @@ class DevView:
                                          "data": (ptr, False), "version": 2}
 
 
-def cpu_baseline(lens, mask, sun, W, H, target_s):
-    """The CPU oracle (kind 'port': oracle/lf_geo_oracle.c) timed on this host's cores on a bounded
-    sample of the same workload: a band of rows of the same frame at reduced spp."""
+def source_sha():
+    """Identity of the shipped march kernel: the PMC-derived figures are only quoted as this
+    binary's when the profile in profiles/ was taken from the same sources."""
+    h = hashlib.sha256()
+    for f in ("lens-flare_amd/csrc/lf_march.hip", "lens-flare_amd/csrc/lf_internal.h", "lens-flare_amd/Makefile"):
+        h.update(open(os.path.join(ROOT, f), "rb").read())
+    return h.hexdigest()[:16]
+
+
+def cpu_baseline(lens, mask, sun, W, H, pairs, lambda_rgb, target_s):
+    """The CPU oracle (kind 'port': oracle/lf_geo_oracle.c, one path at a time like any per-path
+    tracer) timed on this host's cores on a bounded sample of the same workload: a band of rows
+    of the same frame at reduced spp."""
     from oracle import lfo
     cores = min(os.cpu_count() or 1, 64)
     rows = (H // 2 - 32, H // 2 + 32)
     t0 = time.time()
-    _, c = lfo.geo_trace(lens, W, H, rows[0], rows[0] + 4, 1, 1, None, True, mask, sun,
-                         [1.0, 0.9, 0.5], 0.05, n_threads=cores)
+    _, c = lfo.geo_trace(lens, W, H, rows[0], rows[0] + 4, 1, 1, pairs, True, mask, sun,
+                         [1.0, 0.9, 0.5], 0.05, n_threads=cores, lambda_rgb=lambda_rgb)
     dt = max(time.time() - t0, 1e-3)
     rate = c["surface_events"] / dt
     per_sample = c["surface_events"] / (4 * W)
     spp = int(max(1, min(64, target_s * rate / (per_sample * (rows[1] - rows[0]) * W))))
     t0 = time.time()
-    _, c = lfo.geo_trace(lens, W, H, rows[0], rows[1], spp, 1, None, True, mask, sun,
-                         [1.0, 0.9, 0.5], 0.05, n_threads=cores)
+    _, c = lfo.geo_trace(lens, W, H, rows[0], rows[1], spp, 1, pairs, True, mask, sun,
+                         [1.0, 0.9, 0.5], 0.05, n_threads=cores, lambda_rgb=lambda_rgb)
     dt = time.time() - t0
     return {"value": c["surface_events"] / dt / 1e6, "unit": "Mray-surface-intersections/s",
             "cores": cores, "kind": "port",
-            "sample": f"rows {rows[0]}..{rows[1]} of the {W}x{H} frame, {spp} of the spp, "
-                      f"46 paths x 3 wavelengths, {c['surface_events']} events in {dt:.1f} s "
-                      f"(oracle/lf_geo_oracle.c, OpenMP)"}
+            "sample": f"rows {rows[0]}..{rows[1]} of the {W}x{H} frame, {spp} of the spp, every path "
+                      f"marched on its own: {c['surface_events']} intersections in {dt:.1f} s "
+                      f"(oracle/lf_geo_oracle.c, OpenMP); the reference has no geometric lens to time"}
 
 
-def reference_flare_path(pkg):
-    """Side datum (never `value`): the REAL reference's own CPU renderer (oracle/_ref/ref_dump, the
-    reference hot path compiled from its own sources, 1 thread) on the golden 64x48 frame, next to
-    the same frame through the C ABI on the GPU.  None when the prebuilt binary is absent."""
+def reference_flare_path(pkg, budget_s):
+    """Side data (never `value`): the REAL reference's own CPU renderer (oracle/_ref/ref_dump, the
+    reference hot path compiled from its own sources) per BASELINE.md section 3 -- the 1080p frame with
+    final_apertures/pentbig500_14.png (340x350 bbox: a crop, the whole frame is ~4 core-hours) and
+    with apertures/pentbiglines.png (80x78 bbox), on 1 thread and on all host cores (the reference's
+    tile workers = independent pixel lists) -- next to the same frame through the C ABI on the GPU.
+    None when the prebuilt binary is absent."""
     import subprocess
     import tempfile
-    from goldenlib import GOLD, Case, load_texels
     dump = os.path.join(ROOT, "oracle", "_ref", "ref_dump")
     if not os.path.exists(dump):
         return None
+    out = {"kind": "reference", "binary": "oracle/_ref/ref_dump (reference TUs, g++ -O3 -mavx2)"}
     try:
-        case = Case("f64x48_pentbiglines")
-        m = case.meta
+        W, H = 1920, 1080
         tmp = tempfile.mkdtemp(prefix="lfref")
+        hf, vf = 50.0, 2 * math.degrees(math.atan(math.tan(math.radians(25.0)) * H / W))
+        ex, ey = math.tan(math.radians(hf) / 2), math.tan(math.radians(vf) / 2)
+        light = [(2 * SUN_NS[0] - 1) * ex * 10, (2 * SUN_NS[1] - 1) * ey * 10, -10.0, 1.0, 0.9, 0.5]
         cam = os.path.join(tmp, "cam.txt")
-        sd = case.H / (2 * math.tan(math.radians(m["vFov"]) / 2))
-        with open(cam, "w") as f:
-            f.write(f"{m['hFov']!r} {m['vFov']!r} {case.W / case.H!r} 0.01 100\n")
-            f.write(" ".join(repr(float(v)) for v in m["cam_pos"]) + " 0 0 0\n1.5 0.7 5 0.5 100\n")
-            f.write(" ".join(repr(float(v)) for v in m["c2w"]) + f"\n{case.W} {case.H} {sd!r}\n4.7 0\n")
-        spec = ";".join(",".join(repr(float(v)) for v in l) for l in m["lights"])
-        ap_png = os.path.join(GOLD, "apertures", m["aperture"])
-        gh_png = os.path.join(GOLD, "apertures", m["ghost_aperture"])
-        t0 = time.time()
-        subprocess.run([dump, "frame", cam, str(case.W), str(case.H), str(m["ns_aa"]),
-                        repr(float(m["flare_radius"])), repr(float(m["flare_intensity"])), ap_png,
-                        gh_png, spec, "tiles", os.path.join(tmp, "o")], check=True,
-                       stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
-        t_ref = time.time() - t0
-        got = np.fromfile(os.path.join(tmp, "o.sample.f64")).reshape(case.H, case.W, 3)
+        sd = H / (2 * math.tan(math.radians(vf) / 2))
+        with open(cam, "w") as f:   # Camera::load_settings (camera.cpp:228-242)
+            f.write(f"{hf!r} {vf!r} {W / H!r} 0.01 100\n0 0 0 0 0 -1\n1.5 0.7 5 0.5 100\n")
+            f.write("1 0 0 0 1 0 0 0 1\n" + f"{W} {H} {sd!r}\n4.7 0\n")
+        spec = ",".join(repr(float(v)) for v in light)
+        gh_png = os.path.join(pkg.DATA, "octagonbokeh.png")
+        cores = min(os.cpu_count() or 1, 64)
+        cx, cy = int(SUN_NS[0] * W), int(SUN_NS[1] * H)
+
+        def run(ap_name, crop, threads):
+            """crop x crop pixels around the sun, dealt to `threads` processes; -> seconds, pixels."""
+            ap_png = os.path.join(pkg.DATA, ap_name)
+            x0, y0 = max(0, cx - crop // 2), max(0, cy - crop // 2)
+            pix = [(x, y) for y in range(y0, min(H, y0 + crop)) for x in range(x0, min(W, x0 + crop))]
+            procs = []
+            t0 = time.time()
+            for t in range(threads):
+                lst = os.path.join(tmp, f"list{t}.txt")
+                with open(lst, "w") as f:
+                    f.write("\n".join(f"{x} {y}" for x, y in pix[t::threads]))
+                procs.append(subprocess.Popen(
+                    [dump, "frame", cam, str(W), str(H), "1", "25.0", "1.0", ap_png, gh_png, spec,
+                     "list:" + lst, os.path.join(tmp, f"o{t}")], stdout=subprocess.DEVNULL,
+                    stderr=subprocess.DEVNULL))
+            for p in procs:
+                if p.wait() != 0:
+                    raise RuntimeError("ref_dump failed")
+            return time.time() - t0, len(pix)
+
+        # size the crops to the budget from the reference's measured ~1.7e7 DFT terms / s / core
+        # (BASELINE.md section 2)
+        cases = []
+        for ap_name, bbox in (("pentbig500_14.png", 340 * 350), ("pentbiglines.png", 80 * 78)):
+            per_px = bbox / 1.7e7
+            c1 = int(max(8, min(256, math.sqrt(budget_s / 4 / per_px))))
+            cn = int(max(8, min(1024, math.sqrt(budget_s / 4 * cores / per_px))))
+            t1, n1 = run(ap_name, c1, 1)
+            tn, nn = run(ap_name, cn, cores)
+            cases.append({"aperture": ap_name, "dft_terms_per_pixel": bbox,
+                          "t1": {"threads": 1, "pixels": n1, "seconds": t1, "terms_per_s": n1 * bbox / t1,
+                                 "whole_1080p_frame_s_extrapolated": t1 * W * H / n1},
+                          "tN": {"threads": cores, "pixels": nn, "seconds": tn, "terms_per_s": nn * bbox / tn,
+                                 "whole_1080p_frame_s_extrapolated": tn * W * H / nn}})
+        out["frames"] = cases
+        # the same 1080p frame (paraxial ghosts + starburst + falloff + compose) through the C ABI
         lf = pkg.LensFlare(0)
-        lf.set_frame(case.W, case.H)
-        lf.set_params(m["ns_aa"], m["flare_radius"], m["flare_intensity"])
-        lf.set_aperture(pkg.APERTURE_STARBURST, load_texels(m["aperture"]))
-        lf.set_aperture(pkg.APERTURE_GHOST, load_texels(m["ghost_aperture"]))
-        lf.set_camera(m["c2w"], m["cam_pos"], m["hFov"], m["vFov"])
-        lf.set_jitter_mt19937(5489, None)
-        lf.synchronize()
-        t0 = time.perf_counter()
-        lf.find_sun_pos(m["lights"])
-        lf.generate_ghost_buffer()
-        lf.render_flare_layer()
-        lf.synchronize()
-        t_gpu = time.perf_counter() - t0
-        dev = lf.read_buffer(pkg.SAMPLE_BUFFER)
+        lf.set_frame(W, H)
+        lf.set_params(1, 25.0, 1.0)
+        lf.set_aperture(pkg.APERTURE_STARBURST, pkg.load_aperture_png("pentbig500_14.png"))
+        lf.set_aperture(pkg.APERTURE_GHOST, pkg.load_aperture_png("octagonbokeh.png"))
+        lf.set_camera(np.eye(3), [0, 0, 0], hf, vf)
+        lf.set_jitter_counter(0x1e45f1a4e)
+        for _ in range(2):
+            lf.synchronize()
+            t0 = time.perf_counter()
+            lf.find_sun_pos([light])
+            lf.generate_ghost_buffer()
+            lf.render_flare_layer()
+            lf.synchronize()
+            t_gpu = time.perf_counter() - t0
         lf.close()
-        return {"frame": "64x48, apertures/pentbiglines.png (80x78 bbox), 1 sun, ns_aa 1",
-                "reference_cpu_s": t_ref, "cores": 1, "kind": "reference",
-                "gpu_s": t_gpu, "max_rel_diff": float((np.abs(dev - got) / np.abs(got)).max()),
-                "note": "reference time includes its PNG decode; its cost is the per-pixel direct "
-                        "DFT (pathtracer.cpp:947-974), the device path gathers from one DFT of the aperture"}
+        out["gpu_whole_1080p_frame_s"] = t_gpu
+        out["note"] = ("the reference re-sums the aperture DFT for every pixel (pathtracer.cpp:947-974); "
+                       "the device gathers from one DFT of the aperture (DESIGN.md section 4); parity of the "
+                       "two is pinned by tests/test_gpu_flare_parity.py")
+        return out
     except Exception as e:  # noqa: BLE001
-        return {"error": str(e)}
+        out["error"] = str(e)
+        return out
 
 
 def main():
@@ -141,12 +230,16 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--width", type=int, default=1920)
-    ap.add_argument("--height", type=int, default=1080)
-    ap.add_argument("--spp", type=int, default=256)
+    ap.add_argument("--config", choices=sorted(CONFIGS), default="c3")
+    ap.add_argument("--width", type=int, default=0)
+    ap.add_argument("--height", type=int, default=0)
+    ap.add_argument("--spp", type=int, default=0)
     ap.add_argument("--cpu-seconds", type=float, default=15.0)
+    ap.add_argument("--ref-seconds", type=float, default=12.0)
     ap.add_argument("--no-cpu", action="store_true")
     args = ap.parse_args()
+    cfg = dict(CONFIGS[args.config])
+    W, H, spp = args.width or cfg["W"], args.height or cfg["H"], args.spp or cfg["spp"]
 
     import torch
     import torch.distributed as dist
@@ -172,15 +265,19 @@ def main():
         else:
             dist.init_process_group(backend)
 
-    W, H, spp = args.width, args.height, args.spp
     lens = pkg.load_lens_file(os.environ.get("LF_BENCH_LENS", "dgauss11.lens"))  # env: experiments only
-    mask = load_mask()
-    sun = sun_direction(lens, W, H)
+    mask = pkg.load_aperture_png("pentbig500_14.png")
+    lambda_rgb, star_scale = None, None
+    if cfg["n_lambda"] == 8:
+        lens, lambda_rgb, star_scale = lens_8_lambda(lens)
+    efl = pkg.paraxial_efl(lens)
+    sun = sun_direction(lens, efl, W, H)
+    pairs = pair_list(lens, cfg["pairs"])
 
     cpu, ref_path = None, None
     if rank == 0 and world == 1 and not args.no_cpu:
-        cpu = cpu_baseline(lens, mask, sun, W, H, args.cpu_seconds)
-        ref_path = reference_flare_path(pkg)
+        cpu = cpu_baseline(lens, mask, sun, W, H, pairs, lambda_rgb, args.cpu_seconds)
+        ref_path = reference_flare_path(pkg, args.ref_seconds)
 
     lf = pkg.LensFlare(local)
     lf.set_frame(W, H)
@@ -188,15 +285,28 @@ def main():
     lf.set_aperture(pkg.APERTURE_STARBURST, mask)       # stop mask + starburst spectrum (set-up)
     lf.set_aperture(pkg.APERTURE_GHOST, mask)
     lf.set_lens(lens)
-    lf.set_sun(sun, [1.0, 0.9, 0.5], 0.05)
-    lf.set_ghost_pairs(None, True)
+    if lambda_rgb is not None:
+        lf.set_lambda_rgb(lambda_rgb)
+    lf.set_ghost_pairs(pairs, True)
     lf.set_jitter_counter(0x1e45f1a4e)
-    # camera looking down -z from the origin; the sun where analyze_world_coord puts SUN_NS
-    hf = 2 * math.degrees(math.atan(0.5 * lens["sensor_width_mm"] / 50.358))
+    if cfg["spectral"]:
+        lf.set_starburst_spectrum(star_scale, lambda_rgb)
+    # the camera has the lens' own field of view, so that the pinhole projection of find_sun_pos and
+    # the lens agree about where a direction lands on the sensor
+    hf = 2 * math.degrees(math.atan(0.5 * lens["sensor_width_mm"] / efl))
     vf = 2 * math.degrees(math.atan(math.tan(math.radians(hf) / 2) * H / W))
-    lf.set_camera(np.eye(3), [0, 0, 0], hf, vf)
-    ex, ey = math.tan(math.radians(hf) / 2), math.tan(math.radians(vf) / 2)
-    lights = [[(2 * SUN_NS[0] - 1) * ex * 10, (2 * SUN_NS[1] - 1) * ey * 10, -10.0, 1.0, 0.9, 0.5]]
+    if cfg["scene"]:
+        # C4: the scene file's own sun; camera looking at it so that it projects to SUN_NS
+        camera, suns = lf.load_collada(os.path.join(pkg.DATA, cfg["scene"]))
+        lights = suns[:1]
+        pos = np.array(camera["pos"], float) if camera else np.zeros(3)
+        c2w = pkg.aim_camera(pos, lights[0][:3], SUN_NS, hf, vf)
+        lf.set_camera(c2w, pos, hf, vf)
+        lf.set_params(1, 25.0, 1.0)
+    else:
+        lf.set_camera(np.eye(3), [0, 0, 0], hf, vf)
+        ex, ey = math.tan(math.radians(hf) / 2), math.tan(math.radians(vf) / 2)
+        lights = [[(2 * SUN_NS[0] - 1) * ex * 10, (2 * SUN_NS[1] - 1) * ey * 10, -10.0, 1.0, 0.9, 0.5]]
 
     # sensor tile rows (8 rows each) are dealt round-robin: tile row t belongs to rank t % world.
     # One march launch per frame covers all of this rank's tile rows.
@@ -211,12 +321,15 @@ def main():
 
     def one_frame():
         lf.find_sun_pos(lights)
+        lf.set_sun_from_flares(0, efl, 0.05)   # the sun hand-over: the in-frame light feeds the march
+        if cfg["scene"]:
+            lf.render_scene_term()
         lf.trace_ghosts(spp, 0x1e45f1a4e)
         lf.render_flare_layer()
         if world > 1:
             # the real exchange step: every rank ends up with the whole frame -- ONE all-gather per
             # frame (lens_flare_amd/sharding.py: pack this rank's tile rows, gather, unpack); the
-            # buffer is padded to 64 rows so the last group of tile rows never runs past the end.
+            # buffer is padded so that the last group of tile rows never runs past the end.
             lf.synchronize()
             if backend == "nccl":
                 sharding.gather_frame(frame_t, W, H, rank, world, dist, scratch=scratch)
@@ -257,72 +370,80 @@ def main():
         dist.all_reduce(tot[:3], op=dist.ReduceOp.SUM)
         mx = ev[3:].clone()
         dist.all_reduce(mx, op=dist.ReduceOp.MAX)
-        events, rays, executed, dt = float(tot[0]), float(tot[1]), float(tot[2]), float(mx[0])
+        logical, rays, executed, dt = float(tot[0]), float(tot[1]), float(tot[2]), float(mx[0])
     else:
-        events, rays, executed = float(ev[0]), float(ev[1]), float(ev[2])
+        logical, rays, executed = float(ev[0]), float(ev[1]), float(ev[2])
 
     if rank == 0:
-        # roofline of the dominant kernel (the march): algorithmic HBM bytes per launch =
-        # framebuffer rows it writes (f64 RGB) + the aperture mask + the lens/pair tables it reads
+        # ---- roofline of the dominant kernel (k_march) -------------------------------------------
+        # algorithmic HBM bytes per launch = framebuffer rows it writes (f64 RGB) + the aperture
+        # mask + the lens / program tables it reads
         rows_per_launch = min(my_trows * TILE_ROWS, H)
-        alg_bytes = rows_per_launch * W * 24 + mask.size * 4 + 4096
+        alg_bytes = rows_per_launch * W * 24 + mask.size * 4 + 64 * 1024
         avg_ms = march_ms / max(n_launch, 1)
-        achieved = alg_bytes / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0
-        traffic, slots = None, None
-        tf = os.path.join(ROOT, "profiles", "r01_march_pmc.json")
-        if os.path.exists(tf):
-            try:
-                pmc = json.load(open(tf))
-                slots = pmc.get("valu_lane_slots_per_event")
-                # PMC traffic is per launch of the profiled 1-GPU run (whole frame per launch)
-                traffic = pmc.get("hbm_bytes_per_launch") if world == 1 else None
-            except Exception:
-                traffic = None
-        # the VALU accounting is on the events the device computes (shared legs once), not on the
-        # per-path count that `value` reports
+        hbm_achieved = alg_bytes / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0
         ev_per_launch = executed / max(1, n_launch * world)
         ev_rate_gpu = ev_per_launch / (avg_ms * 1e-3) if avg_ms > 0 else 0.0
-        valu = {"bound": "valu", "unit": "wave-instr/s", "peak": VALU_PEAK_LANEOPS / 64.0,
-                "practical_peak": 1.05e12, "executed_events_per_s_per_gpu": ev_rate_gpu,
-                "note": "peak = 1024 SIMD-32 x 2.4 GHz / 2 clk per wave64 op; practical_peak = "
-                        "profiles/microbench/valu_issue.hip (8 waves/SIMD, independent v_fma_f32); "
-                        "instructions per event from the rocprofv3 PMC pass in profiles/"}
-        if slots:
-            valu["lane_slots_per_event"] = slots
-            valu["achieved"] = ev_rate_gpu * slots / 64.0
-            valu["frac"] = valu["achieved"] / valu["peak"]
-            valu["frac_of_practical"] = valu["achieved"] / valu["practical_peak"]
+        # per-event instruction counts come from the rocprofv3 --pmc passes committed under
+        # profiles/ (counters cannot be read inside this process); they are quoted as THIS binary's
+        # only if the profile was taken from the same sources
+        pmc, pmc_note = None, "no PMC summary for this config under profiles/"
+        if os.path.exists(PMC_FILE):
+            try:
+                allp = json.load(open(PMC_FILE))
+                pmc = allp.get(args.config) or allp.get("c3")
+                if pmc is not None:
+                    pmc_note = (f"profiles/{os.path.basename(PMC_FILE)}[{args.config if args.config in allp else 'c3'}], "
+                                f"rocprofv3 --pmc, separate passes")
+            except Exception as e:  # noqa: BLE001
+                pmc_note = f"unreadable PMC summary: {e}"
+        roof = {"bound": "valu", "unit": "wave-instr/s", "peak": VALU_PEAK, "achieved": None, "frac": None,
+                "traffic": None, "kernel": "k_march", "launches": n_launch, "avg_launch_ms": avg_ms,
+                "executed_events_per_s_per_gpu": ev_rate_gpu, "practical_peak": VALU_PRACTICAL,
+                "pmc_source": pmc_note,
+                "note": "register-resident march: compulsory HBM traffic is O(frame), the binding resource "
+                        "is vector issue (then the CU's single scalar unit); peak = 1024 SIMD-32 x 2.4 GHz / "
+                        "2 clk per wave64 instruction, practical_peak = independent v_fma_f32 at 8 waves/SIMD "
+                        "(profiles/microbench/valu_issue.hip)",
+                "hbm": {"achieved": hbm_achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                        "frac": hbm_achieved / HBM_PEAK_GBS, "algorithmic_bytes_per_launch": alg_bytes,
+                        "traffic_bytes_per_launch": None}}
+        if pmc:
+            same = pmc.get("source_sha") == source_sha()
+            roof["pmc_matches_shipped_sources"] = same
+            vi = pmc["valu_wave_instr_per_executed_event"]
+            si = pmc["scalar_instr_per_executed_event"]
+            roof["achieved"] = ev_rate_gpu * vi
+            roof["frac"] = roof["achieved"] / VALU_PEAK
+            roof["frac_of_practical"] = roof["achieved"] / VALU_PRACTICAL
+            roof["valu_wave_instr_per_executed_event"] = vi
+            roof["scalar"] = {"achieved": ev_rate_gpu * si, "peak": SCALAR_PEAK, "unit": "instr/s",
+                              "frac": ev_rate_gpu * si / SCALAR_PEAK,
+                              "note": "SALU + branch + scalar-memory instructions on the one scalar unit per CU"}
+            if world == 1 and args.config in (pmc.get("config"), "c3"):
+                roof["traffic"] = pmc.get("hbm_bytes_per_launch")
+                roof["hbm"]["traffic_bytes_per_launch"] = pmc.get("hbm_bytes_per_launch")
         out = {
             "metric": "Mray-surface-intersections/s + frame time, 1080p 256spp double-Gauss",
-            "value": events / dt / 1e6,
+            "value": executed / dt / 1e6,
             "unit": "Mray-surface-intersections/s",
-            # the same frames counted by the intersections the device actually computes (legs
-            # shared by the paths of one sample are computed once), see config.note
-            "value_computed_only": executed / dt / 1e6,
+            # every path's intersections counted on their own (what a per-path tracer executes):
+            # the march computes the legs shared by the paths of one sample once
+            "value_logical": logical / dt / 1e6,
+            "shared_leg_saving": logical / executed if executed else None,
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": dt / args.steps * 1e3,
             "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
             "dtype": "f32", "data": "synthetic",
-            "config": {"workload": f"double-Gauss 11 interfaces (dgauss11.lens), primary + 45 ghost "
-                                   f"pairs x 3 wavelengths, pentagon mask pentbig500_14, {W}x{H}, "
-                                   f"{spp} spp, one sun (BASELINE.json configs[2])",
+            "config": {"workload": f"{args.config}: {cfg['text']}" +
+                                   (f" [overridden: {W}x{H}, {spp} spp]" if (args.width or args.height or args.spp) else ""),
                        "parallelism": f"{world} GPU(s), 8-row sensor tile rows dealt round-robin"
-                                      + (", one RCCL all_gather per frame"
-                                         if world > 1 else ""),
+                                      + (", one RCCL all_gather per frame" if world > 1 else ""),
                        "rays_per_frame": rays / args.steps,
-                       "events_per_frame": events / args.steps,
                        "events_executed_per_frame": executed / args.steps,
-                       "note": "value counts every path's ray-surface intersections on their own "
-                               "(what the per-path CPU oracle counts and does); the device computes "
-                               "the legs that the paths of one sample share once "
-                               "(events_executed_per_frame)"},
-            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-                         "kernel": "k_march", "launches": n_launch, "avg_launch_ms": avg_ms,
-                         "algorithmic_bytes_per_launch": alg_bytes,
-                         "note": "register-resident march: compulsory traffic is O(frame); the "
-                                 "binding resource is FP32 VALU issue, see valu"},
-            "valu": valu,
+                       "events_logical_per_frame": logical / args.steps,
+                       "focal_length_mm": efl},
+            "roofline": roof,
             "cpu_baseline": cpu,
             "reference_flare_path": ref_path,
         }

@@ -137,6 +137,24 @@ def paraxial_efl(lens, lam=None):
     return out.value
 
 
+def aim_camera(pos, world_point, ns, hfov_deg, vfov_deg):
+    """Row-major c2w of a camera at `pos` under which `world_point` projects to the normalised screen
+    position `ns` (Camera::analyze_world_coord, camera.cpp:245-273): any rotation that maps the
+    camera-space direction of that screen point onto the direction towards the point."""
+    import math
+    ex, ey = math.tan(math.radians(hfov_deg) / 2), math.tan(math.radians(vfov_deg) / 2)
+    d_cam = np.array([(2 * ns[0] - 1) * ex, (2 * ns[1] - 1) * ey, -1.0])
+    d_cam /= np.linalg.norm(d_cam)
+    fwd = np.asarray(world_point, float) - np.asarray(pos, float)
+    fwd /= np.linalg.norm(fwd)
+
+    def frame(z):
+        h = np.array([0.0, 1.0, 0.0]) if abs(z[1]) < 0.9 else np.array([1.0, 0.0, 0.0])
+        x = np.cross(h, z); x /= np.linalg.norm(x)
+        return np.column_stack([x, np.cross(z, x), z])
+    return frame(fwd) @ frame(d_cam).T
+
+
 class LensFlare:
     """One context = one GPU.  Thin, checked wrappers; names follow include/lensflare.h."""
 
