@@ -237,6 +237,9 @@ struct MarchArgs {
   int trow0, tperiod;  // tile rows handled: trow0 + j * tperiod, j = 0 ..
   int sgroups;         // the samples of a tile are split over this many workgroups (power of two)
   uint2 key;
+  float inv_stop_h;    // 1 / stop_h (correctly rounded)
+  float half_w, half_h;  // 0.5 * W, 0.5 * H
+  float vz;            // pupil_z - z_sensor
 };
 
 // One program row for a GROUP of up to 4 wavelengths: the geometry of the interface once, the
@@ -262,9 +265,9 @@ __device__ __forceinline__ LfProgRow load_prow(const LfProgRow* __restrict__ e) 
 // instructions on four SIMDs (53 %); profiles/r02_*.  Each ray keeps its own liveness mask, tallies
 // are per ray, so pixels and counters are exactly those of K separate walks.
 // (second launch bound = waves per SIMD the register allocation must leave room for; the LDS
-// footprint allows exactly as many: 8 / 6 / 6 / 4 workgroups of 4 waves per CU for K = 1 .. 4)
+// footprint allows at least as many workgroups of 4 waves per CU: 8 / 6 / 6 / 5 for K = 1 .. 4)
 template <int K>
-__global__ __launch_bounds__(256, (K == 1 ? 8 : K <= 3 ? 6 : 4))
+__global__ __launch_bounds__(256, (K == 1 ? 8 : K <= 3 ? 6 : 5))
 void k_march(const LfLensDev* __restrict__ lens, const LfPairsDev* __restrict__ pairs,
              const LfEventRow* __restrict__ ev_table, const LfProgRow* __restrict__ prog_table,
              const int* __restrict__ skip_tab, const float* __restrict__ mask, MarchArgs a,
@@ -283,7 +286,7 @@ void k_march(const LfLensDev* __restrict__ lens, const LfPairsDev* __restrict__ 
   // the rare weight re-march reads it back, so it need not occupy six registers during the walk
   // (volatile: otherwise the compiler forwards the stores to the loads and keeps the registers)
   __shared__ volatile float s_start[4][6][64];
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int tid = threadIdx.x;
   if (tid < 64 * 3) s_acc[tid] = 0ull;
   if (tid < 8) s_cnt[tid] = 0ull;
   if (tid == 0) s_next = 0;
@@ -292,22 +295,36 @@ void k_march(const LfLensDev* __restrict__ lens, const LfPairsDev* __restrict__ 
   const int tiles_x = (a.W + 7) >> 3;
   const int sg = blockIdx.x % a.sgroups, tile_lin = blockIdx.x / a.sgroups;
   const int tx = tile_lin % tiles_x, tj = tile_lin / tiles_x;
-  const int x = tx * 8 + (lane & 7);
-  const int y = (a.trow0 + tj * a.tperiod) * 8 + (lane >> 3);
-  const bool active = x < a.W && y >= a.y0 && y < a.y1;
-  const unsigned p = (unsigned)y * (unsigned)a.W + (unsigned)x;
   const unsigned tile_id = (unsigned)((a.trow0 + tj * a.tperiod) * tiles_x + tx);  // frame-absolute
+  // Everything that depends on the lane (pixel coordinates, LDS addresses) is re-derived from the
+  // thread id where it is used: held across the walk it costs ~10 registers, which at 6 waves per
+  // SIMD the allocator can only find in scratch memory (430 MB of spill traffic per bench frame).
+  // The volatile asm keeps the compiler from hoisting the derivation back out of the loop.
+  // (the lane id comes from mbcnt, the wave id sits in an SGPR: not even the thread id is held)
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  auto lane_id = [&]() {
+    int t = (int)__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
+    asm volatile("" : "+v"(t));
+    return t;
+  };
+  lanemask active_mask;
+  {
+    const int lane = tid & 63;
+    const int x = tx * 8 + (lane & 7), y = (a.trow0 + tj * a.tperiod) * 8 + (lane >> 3);
+    active_mask = __ballot(x < a.W && y >= a.y0 && y < a.y1);
+  }
 
   const int n_lambda = lens->n_lambda, n_pairs = pairs->n, total_events = pairs->total_events;
   const int prog_rows = pairs->prog_rows;
   const int n_groups = (n_lambda + K - 1) / K;
   const float z_sensor = lens->z_sensor, pitch = lens->pitch, pupil_h = lens->pupil_h;
-  const float pupil_z = lens->pupil_z, geom_norm = lens->geom_norm;
-  const float inv_stop_h = __fdiv_rn(1.0f, lens->stop_h);
+  const float geom_norm = lens->geom_norm;
+  // (wave-uniform floats the device would have to compute on the vector unit -- and then hold in, or
+  // spill from, vector registers -- arrive as kernel arguments: IEEE operations, the same on the host)
+  const float inv_stop_h = a.inv_stop_h, half_w = a.half_w, half_h = a.half_h, vz_u = a.vz;
   const float sx = lens->sun_dir[0], sy = lens->sun_dir[1], sz = lens->sun_dir[2];
   const float inv_1mc = lens->sun_inv_one_minus_cos, sun_ss = lens->sun_ss;
   const int GG = a.G * a.G;
-  const lanemask active_mask = __ballot(active);
 
   unsigned n_light = 0;     // per lane
   unsigned n_samples = 0;   // per wave
@@ -321,10 +338,13 @@ void k_march(const LfLensDev* __restrict__ lens, const LfPairsDev* __restrict__ 
     // (Which wave marches which sample does not matter: the sums are integers.)
     for (;;) {
       int k = 0;
-      if (lane == 0) k = atomicAdd(&s_next, 1);
+      if (lane_id() == 0) k = atomicAdd(&s_next, 1);
       k = __builtin_amdgcn_readfirstlane(k);
       const int s = sg + k * a.sgroups;  // wave-uniform
       if (s >= a.spp) break;
+      const int lane = lane_id();
+      const int x = tx * 8 + (lane & 7), y = (a.trow0 + tj * a.tperiod) * 8 + (lane >> 3);
+      const unsigned p = (unsigned)y * (unsigned)a.W + (unsigned)x;
       // ---- sensor sample -> initial ray --------------------------------------------------
       const uint4 rnd = philox4x32_10(make_uint4(p, (unsigned)s, kDomainMarch, 0u), a.key);
       const float jx = u01(rnd.x), jy = u01(rnd.y);
@@ -342,8 +362,8 @@ void k_march(const LfLensDev* __restrict__ lens, const LfPairsDev* __restrict__ 
         ub = ((float)cy + ((float)syi + ub) * a.inv_sub) * a.inv_G;
       }
       const float pa = fmaf(2.0f, ua, -1.0f), pb = fmaf(2.0f, ub, -1.0f);
-      const float X = -(((float)x + jx) - 0.5f * (float)a.W) * pitch;
-      const float Y = -(((float)y + jy) - 0.5f * (float)a.H) * pitch;
+      const float X = -(((float)x + jx) - half_w) * pitch;
+      const float Y = -(((float)y + jy) - half_h) * pitch;
       // concentric square -> disc map; sin/cos of (pi/4)*t by fixed polynomials (fmaf only)
       float qx = 0.0f, qy = 0.0f;
       if (pa != 0.0f || pb != 0.0f) {
@@ -358,7 +378,7 @@ void k_march(const LfLensDev* __restrict__ lens, const LfPairsDev* __restrict__ 
         qx = wide ? rr * cs : rr * sn;
         qy = wide ? rr * sn : rr * cs;
       }
-      const float vx = fmaf(pupil_h, qx, -X), vy = fmaf(pupil_h, qy, -Y), vz = pupil_z - z_sensor;
+      const float vx = fmaf(pupil_h, qx, -X), vy = fmaf(pupil_h, qy, -Y), vz = vz_u;
       const float len = lf_sqrt(fmaf(vx, vx, fmaf(vy, vy, vz * vz)));
       const float rl = __fdiv_rn(1.0f, len);
       const float d0x = vx * rl, d0y = vy * rl, d0z = vz * rl;
@@ -611,6 +631,10 @@ void k_march(const LfLensDev* __restrict__ lens, const LfPairsDev* __restrict__ 
   }
 
   // ---- counters: wave reduce, one LDS add per wave, one global add per workgroup ------------
+  const int lane = lane_id();
+  const int x = tx * 8 + (lane & 7), y = (a.trow0 + tj * a.tperiod) * 8 + (lane >> 3);
+  const bool active = x < a.W && y >= a.y0 && y < a.y1;
+  const unsigned p = (unsigned)y * (unsigned)a.W + (unsigned)x;
   {
     unsigned long long v0 = active ? (unsigned long long)n_samples * (unsigned)(n_lambda * n_pairs) : 0ull;
     unsigned long long v6 = n_light;
@@ -623,7 +647,7 @@ void k_march(const LfLensDev* __restrict__ lens, const LfPairsDev* __restrict__ 
     }
   }
   __syncthreads();
-  if (tid < 8 && s_cnt[tid]) atomicAdd(&counters[tid], s_cnt[tid]);
+  if (wave == 0 && lane < 8 && s_cnt[lane]) atomicAdd(&counters[lane], s_cnt[lane]);
 
   // ---- the tile's pixels: 8 rows of 8 x 24 contiguous bytes -----------------------------------
   if (wave == 0 && active) {
@@ -1015,7 +1039,10 @@ lf_status lfk_march(lf_ctx* ctx, int spp, uint64_t key) {
   a.inv_G = 1.0f / (float)a.G;
   a.sub_bits = ctx->march_sub_bits;
   a.inv_sub = 1.0f / (float)(1 << a.sub_bits);
-  a.key =make_uint2((unsigned)key, (unsigned)(key >> 32));
+  a.key = make_uint2((unsigned)key, (unsigned)(key >> 32));
+  a.inv_stop_h = 1.0f / ctx->lens.stop_h;
+  a.half_w = 0.5f * (float)ctx->W; a.half_h = 0.5f * (float)ctx->H;
+  a.vz = ctx->lens.pupil_z - ctx->lens.z_sensor;
   // tile rows (8 sensor rows each) of the band that belong to this context's interleave phase
   const int t_lo = ctx->y0 / 8, t_hi = (ctx->y1 + 7) / 8;  // [t_lo, t_hi)
   const int period = ctx->row_period, phase = ctx->row_phase;
