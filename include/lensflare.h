@@ -133,7 +133,9 @@ lf_status lf_set_scene_term(lf_ctx* ctx, const double* rgb);
  * :271-288) and DirectionalLight / PointLight (scene/light.h:16-29, :47-58).
  *   spheres        n x {cx, cy, cz, r}
  *   tri_positions  n x 9 (p1 p2 p3), tri_normals n x 9 (vertex normals n1 n2 n3)
- *   materials      n x {kind, r, g, b}: kind 0 = diffuse reflectance, 1 = emitted radiance
+ *   materials      n x {kind, r, g, b}: kind 0 = diffuse reflectance, 1 = emitted radiance,
+ *                  2 = diffuse given as the BSDF value f = reflectance / pi (what DiffuseBSDF::f
+ *                  returns, bsdf.cpp:52-60: for hosts that can call f() but not read `reflectance`)
  *   lights         n x {type, x, y, z, r, g, b}: type 0 = directional (xyz = dirToLight, unit),
  *                  1 = point (xyz = position); rgb = radiance.  Order = order in scene->lights.
  * Other light and BSDF types are refused (LF_ERR_INVALID): see lf_scene.hip. */

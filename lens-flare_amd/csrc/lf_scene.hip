@@ -188,7 +188,9 @@ __device__ V3 radiance(const LfSceneDev& sc, DRay r, int* __restrict__ stack) {
       const double cos_theta = unit(wo).z;
       // DiffuseBSDF::f = Vector3D(1/PI) * reflectance (bsdf.cpp:52-60); EmissionBSDF::f = 0
       const double ipi = 1.0 / 3.14159265358979323;
-      const V3 f = m.kind == 0 ? mulv(v3(ipi, ipi, ipi), v3(m.rgb[0], m.rgb[1], m.rgb[2])) : v3(0, 0, 0);
+      // (kind 2: the value of f itself, as a host that can only call BSDF::f hands it over)
+      const V3 f = m.kind == 0 ? mulv(v3(ipi, ipi, ipi), v3(m.rgb[0], m.rgb[1], m.rgb[2]))
+                 : m.kind == 2 ? v3(m.rgb[0], m.rgb[1], m.rgb[2]) : v3(0, 0, 0);
       L = L + divs(mulv(f, emit) * cos_theta, 1.0);  // / pdf, pdf = 1 for delta lights
     }
   }
@@ -358,8 +360,8 @@ lf_status lf_set_scene(lf_ctx* ctx, int n_spheres, const double* spheres, const 
   std::vector<LfMaterial> mats(n_materials);
   for (int i = 0; i < n_materials; i++) {
     mats[i].kind = (int)materials[4 * i];
-    if (mats[i].kind != 0 && mats[i].kind != 1)
-      return lf_fail(ctx, LF_ERR_INVALID, "scene: only diffuse (0) and emission (1) materials are supported");
+    if (mats[i].kind < 0 || mats[i].kind > 2)
+      return lf_fail(ctx, LF_ERR_INVALID, "scene: only diffuse (0 / 2) and emission (1) materials are supported");
     for (int c = 0; c < 3; c++) mats[i].rgb[c] = materials[4 * i + 1 + c];
   }
   std::vector<LfLight> lts(n_lights);

@@ -28,8 +28,11 @@
 
 // the dump reads private members of the reference's BSDF classes (reflectance, radiance); the
 // reference's sources are left untouched, only this test tool sees them as public
+// (likewise Mesh::indices, so that a hand-made one-triangle Mesh answers get_primitives() the way
+// RaytracedRenderer::build_accel asks for it, raytraced_renderer.cpp:377-401)
 #define private public
 #include "pathtracer/bsdf.h"
+#include "scene/object.h"
 #undef private
 #include "pathtracer/pathtracer.h"
 #include "pathtracer/camera.h"
@@ -188,6 +191,8 @@ static int cmd_frame(int argc, char** argv) {
           m->positions[k] = Vector3D(v[3 * k], v[3 * k + 1], v[3 * k + 2]);
           m->normals[k] = Vector3D(v[9 + 3 * k], v[10 + 3 * k], v[11 + 3 * k]);
         }
+        m->indices = {0, 1, 2};   // get_primitives() -> this one triangle (what a host that walks
+                                  // scene->objects sees; the BVH below is built from `prims` as before)
         objs.push_back(m);
         prims.push_back(new Triangle(m, 0, 1, 2));
       } else if (kind == "point") {
