@@ -205,6 +205,42 @@ lf_status lf_save_image_rgba(lf_ctx* ctx, uint32_t* dst);
  * tile-row groups never run past the end. */
 lf_status lf_device_buffer(lf_ctx* ctx, int which, void** dptr, size_t* bytes);
 
+/* ---------------------------------------------------------------- multi-GPU -------------- */
+/* Replaces the reference's scale-out, which lives in the host: a mutex-guarded queue of 32x32 tiles
+ * drained by std::threads (src/pathtracer/raytraced_renderer.cpp:314-328, :352-354, :681-715;
+ * src/util/work_queue.h:11-51).  The 8-row sensor tile rows are dealt round-robin to the GPUs
+ * (lf_set_row_interleave), every GPU renders its tile rows, and ONE RCCL all-gather per frame (over
+ * xGMI) completes the frame on every GPU; there is no other data-path collective.  RCCL is loaded at
+ * first use (dlopen): LF_ERR_STATE if it is not installed.
+ *
+ * One process per GPU: rank 0 calls lf_comm_get_unique_id, the host shares the id (MPI,
+ * torch.distributed, a file ...), every rank calls lf_comm_init_rank after lf_set_frame -- it also
+ * sets the row interleave (rank, nranks).  lf_comm_gather(which) after rendering: buffer `which`
+ * (as lf_read_tile) then holds the whole frame on every rank; it is enqueued on the context's stream. */
+#define LF_COMM_ID_BYTES 128
+lf_status lf_comm_get_unique_id(unsigned char id[LF_COMM_ID_BYTES]);
+lf_status lf_comm_init_rank(lf_ctx* ctx, int nranks, int rank, const unsigned char id[LF_COMM_ID_BYTES]);
+lf_status lf_comm_gather(lf_ctx* ctx, int which);
+lf_status lf_comm_destroy(lf_ctx* ctx);
+/* One process, n devices (a C++ host such as the CGL application): one context + stream per device
+ * and one communicator over them (ncclCommInitAll).  Set-up calls go to every context
+ * (lf_group_ctx); lf_group_set_frame = lf_set_frame + the round-robin deal on every context;
+ * lf_group_for_each runs fn(ctx, rank, user) on one host thread per device, concurrently -- the
+ * per-frame sequence (lf_find_sun_pos, lf_trace_ghosts, lf_render_flare_layer ...) goes there, like
+ * the reference's worker threads; lf_group_gather exchanges the finished tile rows and returns when
+ * every device holds the whole frame.  A device listed twice (a rehearsal on a one-GPU box) cannot
+ * join an RCCL communicator: such a group exchanges with peer copies instead. */
+typedef struct lf_group lf_group;
+typedef lf_status (*lf_group_fn)(lf_ctx* ctx, int rank, void* user);
+lf_status lf_group_create(lf_group** out, int n, const int* devices);
+lf_status lf_group_destroy(lf_group* g);
+int lf_group_size(const lf_group* g);
+lf_ctx* lf_group_ctx(lf_group* g, int rank);
+const char* lf_group_last_error(const lf_group* g);
+lf_status lf_group_set_frame(lf_group* g, int width, int height);
+lf_status lf_group_for_each(lf_group* g, lf_group_fn fn, void* user);
+lf_status lf_group_gather(lf_group* g, int which);
+
 /* ---------------------------------------------------------------- geometric lens --------- */
 /* The north-star path: real ray march through spherical interfaces.  The reference has no
  * counterpart (its lens is paraxial, pathtracer.cpp:511-689; Camera::generate_ray_for_thin_lens

@@ -34,6 +34,9 @@ ABI_SYMBOLS = [
     "lf_write_to_framebuffer", "lf_save_image_rgba", "lf_device_buffer", "lf_set_lens", "lf_set_lambda_rgb", "lf_set_sun",
     "lf_set_sun_from_flares", "lf_paraxial_efl", "lf_set_ghost_pairs", "lf_set_pupil_subcells", "lf_trace_ghosts", "lf_generate_lens_rays", "lf_get_counters", "lf_reset_counters", "lf_get_executed_events", "lf_native_sqrt", "lf_set_starburst_spectrum", "lf_load_collada", "lf_march_tables",
     "lf_timing_enable", "lf_timing_reset", "lf_timing_get",
+    "lf_comm_get_unique_id", "lf_comm_init_rank", "lf_comm_gather", "lf_comm_destroy",
+    "lf_group_create", "lf_group_destroy", "lf_group_size", "lf_group_ctx", "lf_group_last_error",
+    "lf_group_set_frame", "lf_group_for_each", "lf_group_gather",
 ]
 
 
@@ -155,22 +158,50 @@ def aim_camera(pos, world_point, ns, hfov_deg, vfov_deg):
     return frame(fwd) @ frame(d_cam).T
 
 
+COMM_ID_BYTES = 128
+
+
+def comm_unique_id():
+    """lf_comm_get_unique_id: the RCCL id rank 0 makes and the host shares (bytes)."""
+    buf = (C.c_ubyte * COMM_ID_BYTES)()
+    st = load_library().lf_comm_get_unique_id(buf)
+    if st != 0:
+        raise LensFlareError(st, "lf_comm_get_unique_id (is librccl.so.1 installed?)")
+    return bytes(buf)
+
+
 class LensFlare:
     """One context = one GPU.  Thin, checked wrappers; names follow include/lensflare.h."""
 
-    def __init__(self, device=0):
+    def __init__(self, device=0, _borrowed=None):
         self.lib = load_library()
+        self.lib.lf_group_ctx.restype = C.c_void_p
+        self.W = self.H = 0
+        self._owned = _borrowed is None
+        if _borrowed is not None:
+            self.ctx = C.c_void_p(_borrowed)
+            return
         self.ctx = C.c_void_p()
         st = self.lib.lf_create(C.byref(self.ctx), int(device))
         if st != 0:
             self.ctx = C.c_void_p()
             raise LensFlareError(st, "lf_create failed (no gfx950 device visible?)")
-        self.W = self.H = 0
 
     def close(self):
-        if self.ctx:
+        if self.ctx and self._owned:
             self.lib.lf_destroy(self.ctx)
-            self.ctx = C.c_void_p()
+        self.ctx = C.c_void_p()
+
+    # ---- multi-GPU, one process per GPU
+    def comm_init_rank(self, nranks, rank, unique_id):
+        buf = (C.c_ubyte * COMM_ID_BYTES).from_buffer_copy(unique_id)
+        self._ck(self.lib.lf_comm_init_rank(self.ctx, int(nranks), int(rank), buf))
+
+    def comm_gather(self, which):
+        self._ck(self.lib.lf_comm_gather(self.ctx, int(which)))
+
+    def comm_destroy(self):
+        self._ck(self.lib.lf_comm_destroy(self.ctx))
 
     def __del__(self):
         try:
@@ -443,3 +474,67 @@ class LensFlare:
         ms = C.c_double()
         self._ck(self.lib.lf_timing_get(self.ctx, kernel.encode(), C.byref(n), C.byref(ms)))
         return n.value, ms.value
+
+
+GROUP_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_int, C.c_void_p)
+
+
+class LensFlareGroup:
+    """lf_group_*: one process, n devices (one context + stream per device, one RCCL communicator)."""
+
+    def __init__(self, devices):
+        self.lib = load_library()
+        self.lib.lf_group_ctx.restype = C.c_void_p
+        self.lib.lf_group_last_error.restype = C.c_char_p
+        self.g = C.c_void_p()
+        dv = (C.c_int * len(devices))(*devices)
+        st = self.lib.lf_group_create(C.byref(self.g), len(devices), dv)
+        if st != 0:
+            self.g = C.c_void_p()
+            raise LensFlareError(st, "lf_group_create failed")
+        self.ranks = [LensFlare(_borrowed=self.lib.lf_group_ctx(self.g, r)) for r in range(len(devices))]
+
+    def _ck(self, st):
+        if st != 0:
+            raise LensFlareError(st, self.lib.lf_group_last_error(self.g).decode())
+
+    def set_frame(self, W, H):
+        self._ck(self.lib.lf_group_set_frame(self.g, int(W), int(H)))
+        for r in self.ranks:
+            r.W, r.H = int(W), int(H)
+
+    def for_each(self, fn):
+        """fn(LensFlare, rank) on one host thread per device, concurrently."""
+        errors = []
+
+        def tramp(ctx, rank, _user):
+            try:
+                fn(self.ranks[rank], rank)
+                return 0
+            except LensFlareError as e:
+                errors.append(e)
+                return e.status
+            except Exception as e:  # noqa: BLE001
+                errors.append(e)
+                return 1
+        cb = GROUP_FN(tramp)
+        st = self.lib.lf_group_for_each(self.g, cb, None)
+        if errors:
+            raise errors[0]
+        self._ck(st)
+
+    def gather(self, which):
+        self._ck(self.lib.lf_group_gather(self.g, int(which)))
+
+    def close(self):
+        if self.g:
+            for r in self.ranks:
+                r.ctx = C.c_void_p()
+            self.lib.lf_group_destroy(self.g)
+            self.g = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass

@@ -203,6 +203,8 @@ lf_status lf_destroy(lf_ctx* ctx) {
   if (!ctx) return LF_ERR_INVALID;
   (void)hipSetDevice(ctx->device);
   (void)hipDeviceSynchronize();
+  (void)lf_comm_destroy(ctx);
+  if (ctx->comm_stage) (void)hipFree(ctx->comm_stage);
   free_frame_buffers(ctx);
   for (auto& t : ctx->timed) { (void)hipEventDestroy(t.start); (void)hipEventDestroy(t.stop); }
   for (hipEvent_t e : ctx->event_pool) (void)hipEventDestroy(e);

@@ -1,0 +1,327 @@
+// lf_group.hip -- multi-GPU inside the C ABI (SURVEY.md section 8 row e; north star: "sensor tiles
+// shard naturally across the 8 GPUs of one node with a final RCCL gather over xGMI").
+//
+// The reference scales a frame over std::threads that pull 32x32 tiles from a mutex-guarded queue
+// (src/pathtracer/raytraced_renderer.cpp:314-328, :352-354, :681-715; src/util/work_queue.h:11-51).
+// Here the unit is the march's 8-row sensor tile row, dealt round-robin: tile row t belongs to rank
+// t % n (lf_set_row_interleave), every rank renders its tile rows into its own full-frame buffer, and
+// the ONLY data-path collective is the exchange of finished tile rows: the frame viewed as
+// [groups][n][tile row] is completed everywhere by ONE ncclAllGather per frame (pack this rank's
+// slots, gather, unpack -- two device copies of 1/n and 1 frame).  xGMI is point to point (7 links
+// x ~153 GB/s per GPU), the ring all-gather of a 49.8 MB f64 1080p frame moves 43.6 MB into every
+// GPU: well under a millisecond of wire time against an 18 ms share of the march at n = 8.
+//
+// Two shapes, one exchange:
+//   lf_comm_*   one process per GPU (the driver's torchrun launch): rank 0 makes the id, the host
+//               shares it by whatever it has (MPI, torch.distributed, a file), every rank attaches.
+//   lf_group_*  one process, n devices (a C++ host application such as the CGL app): one context +
+//               stream per device, ncclCommInitAll, work issued from one host thread per device.
+// RCCL is resolved with dlopen at first use: the library has no link-time dependency on it, and a
+// single-GPU host never loads it.  Devices listed twice in a group (a rehearsal on a one-GPU box)
+// cannot form an RCCL communicator; the group then exchanges with peer copies on the streams.
+#include <dlfcn.h>
+
+#include <cstring>
+#include <thread>
+#include <vector>
+
+#include <rccl/rccl.h>   // types and prototypes only: the entry points are resolved at run time
+
+#include "lf_internal.h"
+
+namespace {
+
+struct Rccl {
+  void* handle = nullptr;
+  ncclResult_t (*GetUniqueId)(ncclUniqueId*) = nullptr;
+  ncclResult_t (*CommInitRank)(ncclComm_t*, int, ncclUniqueId, int) = nullptr;
+  ncclResult_t (*CommInitAll)(ncclComm_t*, int, const int*) = nullptr;
+  ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
+  ncclResult_t (*AllGather)(const void*, void*, size_t, ncclDataType_t, ncclComm_t, hipStream_t) = nullptr;
+  ncclResult_t (*GroupStart)() = nullptr;
+  ncclResult_t (*GroupEnd)() = nullptr;
+  const char* (*GetErrorString)(ncclResult_t) = nullptr;
+  std::string error;
+};
+
+Rccl* rccl() {
+  static Rccl r;
+  static bool tried = false;
+  if (tried) return r.handle ? &r : nullptr;
+  tried = true;
+  const char* names[] = {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
+  for (const char* n : names) {
+    r.handle = dlopen(n, RTLD_NOW | RTLD_LOCAL);
+    if (r.handle) break;
+  }
+  if (!r.handle) { r.error = "librccl.so.1 not found"; return nullptr; }
+  bool ok = true;
+  auto sym = [&](const char* name) { void* p = dlsym(r.handle, name); if (!p) ok = false; return p; };
+  r.GetUniqueId = (decltype(r.GetUniqueId))sym("ncclGetUniqueId");
+  r.CommInitRank = (decltype(r.CommInitRank))sym("ncclCommInitRank");
+  r.CommInitAll = (decltype(r.CommInitAll))sym("ncclCommInitAll");
+  r.CommDestroy = (decltype(r.CommDestroy))sym("ncclCommDestroy");
+  r.AllGather = (decltype(r.AllGather))sym("ncclAllGather");
+  r.GroupStart = (decltype(r.GroupStart))sym("ncclGroupStart");
+  r.GroupEnd = (decltype(r.GroupEnd))sym("ncclGroupEnd");
+  r.GetErrorString = (decltype(r.GetErrorString))sym("ncclGetErrorString");
+  if (!ok) { dlclose(r.handle); r.handle = nullptr; r.error = "librccl lacks an entry point"; return nullptr; }
+  return &r;
+}
+
+// frame viewed as [groups][world][e doubles]: slot (g, rank) -> send[g]
+__global__ void k_pack_rows(const double* __restrict__ frame, double* __restrict__ send, int rank, int world,
+                            size_t groups, size_t e) {
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= groups * e) return;
+  const size_t g = i / e, k = i - g * e;
+  send[i] = frame[(g * world + rank) * e + k];
+}
+// recv = [world][groups][e] -> frame[g][r]; the rank's own slots are already in place
+__global__ void k_unpack_rows(const double* __restrict__ recv, double* __restrict__ frame, int rank, int world,
+                              size_t groups, size_t e) {
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= (size_t)world * groups * e) return;
+  const size_t r = i / (groups * e), rem = i - r * groups * e, g = rem / e, k = rem - g * e;
+  if ((int)r == rank) return;
+  frame[(g * world + r) * e + k] = recv[i];
+}
+
+double* frame_buffer(lf_ctx* ctx, int which) { return which == 0 ? ctx->sample : which == 1 ? ctx->ghost : ctx->star; }
+
+struct Shape { size_t groups, e; };
+Shape shape(const lf_ctx* ctx, int world) {
+  const size_t ntrows = (size_t)(ctx->H + 7) / 8;
+  return Shape{(ntrows + world - 1) / world, (size_t)8 * ctx->W * 3};
+}
+
+lf_status ensure_staging(lf_ctx* ctx, int world) {
+  const Shape s = shape(ctx, world);
+  const size_t need = (size_t)(world + 1) * s.groups * s.e;   // send [groups][e] + recv [world][groups][e]
+  if (need <= ctx->comm_stage_cap) return LF_OK;
+  LF_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  if (ctx->comm_stage) (void)hipFree(ctx->comm_stage);
+  ctx->comm_stage = nullptr; ctx->comm_stage_cap = 0;
+  LF_HIP(ctx, hipMalloc((void**)&ctx->comm_stage, need * sizeof(double)));
+  ctx->comm_stage_cap = need;
+  return LF_OK;
+}
+
+lf_status launch_pack(lf_ctx* ctx, int which, int rank, int world) {
+  const Shape s = shape(ctx, world);
+  const size_t n = s.groups * s.e;
+  hipLaunchKernelGGL(k_pack_rows, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream,
+                     frame_buffer(ctx, which), ctx->comm_stage, rank, world, s.groups, s.e);
+  LF_HIP(ctx, hipGetLastError());
+  return LF_OK;
+}
+
+lf_status launch_unpack(lf_ctx* ctx, int which, int rank, int world) {
+  const Shape s = shape(ctx, world);
+  const size_t n = (size_t)world * s.groups * s.e;
+  hipLaunchKernelGGL(k_unpack_rows, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream,
+                     ctx->comm_stage + s.groups * s.e, frame_buffer(ctx, which), rank, world, s.groups, s.e);
+  LF_HIP(ctx, hipGetLastError());
+  return LF_OK;
+}
+
+lf_status check_gather_args(lf_ctx* ctx, int which, int world) {
+  if (!ctx || which < 0 || which > 2) return LF_ERR_INVALID;
+  if (ctx->W == 0) return lf_fail(ctx, LF_ERR_STATE, "gather before lf_set_frame");
+  if (ctx->row_period != world)
+    return lf_fail(ctx, LF_ERR_STATE, "gather: the row interleave does not match the communicator (frame resized?)");
+  const Shape s = shape(ctx, world);
+  if ((size_t)ctx->H_alloc * ctx->W * 3 < s.groups * world * s.e)
+    return lf_fail(ctx, LF_ERR_STATE, "gather: frame buffers are not padded for this world size");
+  return LF_OK;
+}
+
+}  // namespace
+
+struct lf_group {
+  std::vector<lf_ctx*> ctx;
+  std::vector<int> devices;
+  bool rccl = false;   // false: duplicate devices (rehearsal) -> peer copies instead of a communicator
+  std::string err;
+};
+
+extern "C" {
+
+// ---------------------------------------------------------------- one process per GPU -----------
+lf_status lf_comm_get_unique_id(unsigned char id[LF_COMM_ID_BYTES]) {
+  if (!id) return LF_ERR_INVALID;
+  Rccl* r = rccl();
+  if (!r) return LF_ERR_STATE;
+  static_assert(LF_COMM_ID_BYTES == NCCL_UNIQUE_ID_BYTES, "id size");
+  ncclUniqueId u;
+  if (r->GetUniqueId(&u) != ncclSuccess) return LF_ERR_HIP;
+  std::memcpy(id, u.internal, LF_COMM_ID_BYTES);
+  return LF_OK;
+}
+
+lf_status lf_comm_init_rank(lf_ctx* ctx, int nranks, int rank, const unsigned char id[LF_COMM_ID_BYTES]) {
+  if (!ctx || !id || nranks < 1 || rank < 0 || rank >= nranks) return LF_ERR_INVALID;
+  if (ctx->W == 0) return lf_fail(ctx, LF_ERR_STATE, "lf_comm_init_rank before lf_set_frame");
+  Rccl* r = rccl();
+  if (!r) return lf_fail(ctx, LF_ERR_STATE, "RCCL is not available: librccl.so.1 could not be loaded");
+  if (ctx->comm) return lf_fail(ctx, LF_ERR_STATE, "this context already has a communicator");
+  LF_HIP(ctx, hipSetDevice(ctx->device));
+  ncclUniqueId u;
+  std::memcpy(u.internal, id, LF_COMM_ID_BYTES);
+  ncclComm_t c = nullptr;
+  const ncclResult_t rc = r->CommInitRank(&c, nranks, u, rank);
+  if (rc != ncclSuccess) return lf_fail(ctx, LF_ERR_HIP, std::string("ncclCommInitRank: ") + r->GetErrorString(rc));
+  ctx->comm = c; ctx->comm_nranks = nranks; ctx->comm_rank = rank;
+  return lf_set_row_interleave(ctx, rank, nranks);   // the deal: tile row t belongs to rank t % nranks
+}
+
+lf_status lf_comm_gather(lf_ctx* ctx, int which) {
+  if (!ctx) return LF_ERR_INVALID;
+  if (!ctx->comm) return lf_fail(ctx, LF_ERR_STATE, "lf_comm_gather before lf_comm_init_rank");
+  const int world = ctx->comm_nranks, rank = ctx->comm_rank;
+  lf_status st = check_gather_args(ctx, which, world);
+  if (st != LF_OK) return st;
+  if (world == 1) return LF_OK;
+  Rccl* r = rccl();
+  LF_HIP(ctx, hipSetDevice(ctx->device));
+  if ((st = ensure_staging(ctx, world)) != LF_OK) return st;
+  if ((st = launch_pack(ctx, which, rank, world)) != LF_OK) return st;
+  const Shape s = shape(ctx, world);
+  const ncclResult_t rc = r->AllGather(ctx->comm_stage, ctx->comm_stage + s.groups * s.e, s.groups * s.e,
+                                       ncclDouble, (ncclComm_t)ctx->comm, ctx->stream);
+  if (rc != ncclSuccess) return lf_fail(ctx, LF_ERR_HIP, std::string("ncclAllGather: ") + r->GetErrorString(rc));
+  return launch_unpack(ctx, which, rank, world);
+}
+
+lf_status lf_comm_destroy(lf_ctx* ctx) {
+  if (!ctx) return LF_ERR_INVALID;
+  if (ctx->comm) {
+    (void)hipSetDevice(ctx->device);
+    (void)hipStreamSynchronize(ctx->stream);
+    Rccl* r = rccl();
+    if (r) (void)r->CommDestroy((ncclComm_t)ctx->comm);
+    ctx->comm = nullptr; ctx->comm_nranks = 1; ctx->comm_rank = 0;
+  }
+  return LF_OK;
+}
+
+// ---------------------------------------------------------------- one process, n devices --------
+lf_status lf_group_create(lf_group** out, int n, const int* devices) {
+  if (!out || n < 1 || n > 64 || !devices) return LF_ERR_INVALID;
+  *out = nullptr;
+  lf_group* g = new lf_group();
+  bool distinct = true;
+  for (int i = 0; i < n; i++)
+    for (int j = 0; j < i; j++) if (devices[i] == devices[j]) distinct = false;
+  for (int i = 0; i < n; i++) {
+    lf_ctx* c = nullptr;
+    const lf_status st = lf_create(&c, devices[i]);
+    if (st != LF_OK) { lf_group_destroy(g); return st; }
+    g->ctx.push_back(c);
+    g->devices.push_back(devices[i]);
+  }
+  if (n > 1 && distinct) {
+    Rccl* r = rccl();
+    if (!r) { lf_group_destroy(g); return LF_ERR_STATE; }
+    std::vector<ncclComm_t> comms(n);
+    if (r->CommInitAll(comms.data(), n, devices) != ncclSuccess) { lf_group_destroy(g); return LF_ERR_HIP; }
+    for (int i = 0; i < n; i++) { g->ctx[i]->comm = comms[i]; g->ctx[i]->comm_nranks = n; g->ctx[i]->comm_rank = i; }
+    g->rccl = true;
+  } else {
+    for (int i = 0; i < n; i++) { g->ctx[i]->comm_nranks = n; g->ctx[i]->comm_rank = i; }
+  }
+  *out = g;
+  return LF_OK;
+}
+
+lf_status lf_group_destroy(lf_group* g) {
+  if (!g) return LF_ERR_INVALID;
+  for (lf_ctx* c : g->ctx) { (void)lf_comm_destroy(c); (void)lf_destroy(c); }
+  delete g;
+  return LF_OK;
+}
+
+int lf_group_size(const lf_group* g) { return g ? (int)g->ctx.size() : 0; }
+
+lf_ctx* lf_group_ctx(lf_group* g, int rank) {
+  return (g && rank >= 0 && rank < (int)g->ctx.size()) ? g->ctx[rank] : nullptr;
+}
+
+const char* lf_group_last_error(const lf_group* g) { return g ? g->err.c_str() : "null group"; }
+
+lf_status lf_group_set_frame(lf_group* g, int width, int height) {
+  if (!g) return LF_ERR_INVALID;
+  const int n = (int)g->ctx.size();
+  for (int r = 0; r < n; r++) {
+    lf_status st = lf_set_frame(g->ctx[r], width, height);
+    if (st == LF_OK) st = lf_set_row_interleave(g->ctx[r], r, n);
+    if (st != LF_OK) { g->err = lf_last_error(g->ctx[r]); return st; }
+  }
+  return LF_OK;
+}
+
+lf_status lf_group_for_each(lf_group* g, lf_group_fn fn, void* user) {
+  if (!g || !fn) return LF_ERR_INVALID;
+  const int n = (int)g->ctx.size();
+  std::vector<lf_status> st(n, LF_OK);
+  std::vector<std::thread> th;
+  // one host thread per device, like the reference's worker threads (raytraced_renderer.cpp:352-354)
+  for (int r = 1; r < n; r++) th.emplace_back([&, r]() { st[r] = fn(g->ctx[r], r, user); });
+  st[0] = fn(g->ctx[0], 0, user);
+  for (auto& t : th) t.join();
+  for (int r = 0; r < n; r++)
+    if (st[r] != LF_OK) { g->err = "rank " + std::to_string(r) + ": " + lf_last_error(g->ctx[r]); return st[r]; }
+  return LF_OK;
+}
+
+lf_status lf_group_gather(lf_group* g, int which) {
+  if (!g) return LF_ERR_INVALID;
+  const int n = (int)g->ctx.size();
+  if (n == 1) return LF_OK;
+  for (int r = 0; r < n; r++) {
+    lf_ctx* c = g->ctx[r];
+    lf_status st = check_gather_args(c, which, n);
+    if (st == LF_OK) { (void)hipSetDevice(c->device); st = ensure_staging(c, n); }
+    if (st == LF_OK) st = launch_pack(c, which, r, n);
+    if (st != LF_OK) { g->err = lf_last_error(c); return st; }
+  }
+  const Shape s = shape(g->ctx[0], n);
+  const size_t cnt = s.groups * s.e;
+  if (g->rccl) {
+    Rccl* rc = rccl();
+    (void)rc->GroupStart();
+    for (int r = 0; r < n; r++) {
+      lf_ctx* c = g->ctx[r];
+      (void)hipSetDevice(c->device);
+      const ncclResult_t e = rc->AllGather(c->comm_stage, c->comm_stage + cnt, cnt, ncclDouble,
+                                           (ncclComm_t)c->comm, c->stream);
+      if (e != ncclSuccess) { (void)rc->GroupEnd(); g->err = std::string("ncclAllGather: ") + rc->GetErrorString(e); return LF_ERR_HIP; }
+    }
+    const ncclResult_t e = rc->GroupEnd();
+    if (e != ncclSuccess) { g->err = std::string("ncclGroupEnd: ") + rc->GetErrorString(e); return LF_ERR_HIP; }
+  } else {
+    // rehearsal (devices listed twice): every context pulls the other contexts' packed rows with
+    // peer copies on its own stream, after they have been packed
+    for (int r = 0; r < n; r++) { (void)hipSetDevice(g->ctx[r]->device); (void)hipStreamSynchronize(g->ctx[r]->stream); }
+    for (int r = 0; r < n; r++) {
+      lf_ctx* c = g->ctx[r];
+      (void)hipSetDevice(c->device);
+      for (int q = 0; q < n; q++) {
+        const hipError_t e = hipMemcpyPeerAsync(c->comm_stage + cnt + (size_t)q * cnt, c->device,
+                                                g->ctx[q]->comm_stage, g->ctx[q]->device, cnt * sizeof(double),
+                                                c->stream);
+        if (e != hipSuccess) { g->err = std::string("hipMemcpyPeerAsync: ") + hipGetErrorString(e); return LF_ERR_HIP; }
+      }
+    }
+  }
+  for (int r = 0; r < n; r++) {
+    (void)hipSetDevice(g->ctx[r]->device);
+    const lf_status st = launch_unpack(g->ctx[r], which, r, n);
+    if (st != LF_OK) { g->err = lf_last_error(g->ctx[r]); return st; }
+  }
+  // the staging buffers are reused by the next gather: order the streams against each other
+  for (int r = 0; r < n; r++) { (void)hipSetDevice(g->ctx[r]->device); (void)hipStreamSynchronize(g->ctx[r]->stream); }
+  return LF_OK;
+}
+
+}  // extern "C"

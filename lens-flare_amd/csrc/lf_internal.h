@@ -242,6 +242,12 @@ struct lf_ctx {
   int march_k = 1;                             // wavelengths (rays per lane) that walk together
   bool events_dirty = true;
 
+  // multi-GPU (lf_group.hip): the communicator this context belongs to, staging for the exchange
+  void* comm = nullptr;          // ncclComm_t, or null (single GPU / rehearsal group)
+  int comm_nranks = 1, comm_rank = 0;
+  double* comm_stage = nullptr;  // send [groups][e] followed by recv [world][groups][e]
+  size_t comm_stage_cap = 0;     // doubles
+
   bool timing = false;
   std::vector<LfTimedLaunch> timed;       // launches not folded yet (bounded, see lf_api.hip)
   std::vector<hipEvent_t> event_pool;     // recycled events

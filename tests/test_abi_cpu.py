@@ -16,7 +16,7 @@ def test_header_symbols_exported():
     pkg = _pkg()
     header = open(os.path.join(ROOT, "include", "lensflare.h")).read()
     declared = set(re.findall(r"\b(lf_[a-z0-9_]+)\s*\(", header))
-    declared -= {"lf_ctx"}
+    declared -= {"lf_ctx", "lf_status"}   # (lf_status appears in the function-pointer typedef lf_group_fn)
     assert declared == set(pkg.ABI_SYMBOLS), declared ^ set(pkg.ABI_SYMBOLS)
     lib = pkg.load_library()
     for sym in sorted(declared):
@@ -40,6 +40,9 @@ def test_no_device_fails_loudly():
         raise AssertionError("LensFlare() must raise without a device")
     except pkg.LensFlareError as e:
         assert e.status == 2
+    # ... and so must the multi-GPU group
+    g = C.c_void_p()
+    assert lib.lf_group_create(C.byref(g), 2, (C.c_int * 2)(0, 1)) == 2 and not g.value
 
 
 def test_product_never_references_oracle():

@@ -1,0 +1,95 @@
+"""Multi-GPU inside the C ABI (lens-flare_amd/csrc/lf_group.hip): tile rows dealt round-robin, ONE
+all-gather of finished tile rows per frame.  The GPU box has one device, so what runs here is
+  * the RCCL plumbing itself with a 1-rank communicator (dlopen, unique id, ncclCommInitRank, gather);
+  * the whole sharded frame with 2 and 3 contexts on device 0 (a device listed twice cannot join an
+    RCCL communicator: the group then exchanges with peer copies -- same packing, same result):
+    every context must end up with the frame a single context renders, bit for bit.
+The n-GPU RCCL path proper is exercised by the driver's scaling run (bench.py --gpus N)."""
+import numpy as np
+import pytest
+
+from goldenlib import load_texels
+
+pytestmark = pytest.mark.gpu
+SUN = dict(direction=[0.03, 0.02, -1.0], radiance=[1.0, 0.9, 0.5], angular_radius=0.05)
+
+
+@pytest.fixture(scope="module")
+def pkg():
+    import __graft_entry__ as g
+    return g.load_package()
+
+
+def _setup(pkg, lf, lens, mask):
+    lf.set_params(1, 25.0, 1.0)
+    lf.set_aperture(pkg.APERTURE_STARBURST, mask)
+    lf.set_aperture(pkg.APERTURE_GHOST, mask)
+    lf.set_lens(lens)
+    lf.set_sun(SUN["direction"], SUN["radiance"], SUN["angular_radius"])
+    lf.set_ghost_pairs(None, True)
+    lf.set_jitter_counter(42)
+    lf.set_camera(np.eye(3), [0, 0, 0], 40.0, 30.0)
+
+
+def _frame(lf, spp, key):
+    lf.find_sun_pos([[0.4, 0.3, -10.0, 1.0, 0.9, 0.5]])
+    lf.trace_ghosts(spp, key)
+    lf.render_flare_layer()
+
+
+def test_single_rank_communicator(pkg):
+    """ncclGetUniqueId / ncclCommInitRank / the gather entry point on a communicator of one."""
+    lens = pkg.load_lens_file("dgauss11.lens")
+    mask = load_texels("pentbig500_14.png")
+    lf = pkg.LensFlare(0)
+    lf.set_frame(72, 40)
+    _setup(pkg, lf, lens, mask)
+    uid = pkg.comm_unique_id()
+    assert len(uid) == 128 and any(uid)
+    lf.comm_init_rank(1, 0, uid)
+    _frame(lf, 8, 5)
+    before = lf.read_buffer(pkg.SAMPLE_BUFFER)
+    lf.comm_gather(pkg.SAMPLE_BUFFER)
+    assert np.array_equal(lf.read_buffer(pkg.SAMPLE_BUFFER), before) and before.max() > 0
+    with pytest.raises(pkg.LensFlareError):
+        lf.comm_init_rank(1, 0, uid)          # one communicator per context
+    lf.comm_destroy()
+    lf.close()
+
+
+@pytest.mark.parametrize("n,W,H", [(2, 72, 40), (3, 100, 52), (2, 64, 8)])
+def test_group_renders_the_single_gpu_frame(pkg, n, W, H):
+    """n contexts (rehearsal group on device 0): round-robin tile rows + gather == one context."""
+    lens = pkg.load_lens_file("dgauss11.lens")
+    mask = load_texels("pentbig500_14.png")
+    one = pkg.LensFlare(0)
+    one.set_frame(W, H)
+    _setup(pkg, one, lens, mask)
+    one.reset_counters()
+    _frame(one, 16, 9)
+    want_sample, want_ghost = one.read_buffer(pkg.SAMPLE_BUFFER), one.read_buffer(pkg.GHOST_BUFFER)
+    want_cnt = one.counters()
+    one.close()
+    assert want_ghost.max() > 0
+
+    grp = pkg.LensFlareGroup([0] * n)
+    grp.set_frame(W, H)
+    for r in grp.ranks:
+        _setup(pkg, r, lens, mask)
+        r.reset_counters()
+    grp.for_each(lambda lf, rank: _frame(lf, 16, 9))      # one host thread per context
+    # before the exchange a rank holds only its own tile rows
+    part = grp.ranks[1].read_buffer(pkg.GHOST_BUFFER)
+    own = (np.arange(H) // 8) % n == 1
+    assert np.array_equal(part[own], want_ghost[own])
+    grp.gather(pkg.SAMPLE_BUFFER)
+    grp.gather(pkg.GHOST_BUFFER)
+    for r in grp.ranks:
+        assert np.array_equal(r.read_buffer(pkg.SAMPLE_BUFFER), want_sample)
+        assert np.array_equal(r.read_buffer(pkg.GHOST_BUFFER), want_ghost)
+    total = {}
+    for r in grp.ranks:
+        for k, v in r.counters().items():
+            total[k] = total.get(k, 0) + v
+    assert total == want_cnt                              # the shares add up to the single-GPU frame
+    grp.close()
