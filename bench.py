@@ -253,17 +253,23 @@ def main():
         raise SystemExit(f"--gpus {args.gpus} needs WORLD_SIZE={args.gpus} (launch with torch.distributed.run)")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the hot path has no CPU fallback")
-    # LF_BENCH_BACKEND=gloo is a REHEARSAL mode for a 1-GPU box (several ranks share GPU 0 and the
-    # tile-row exchange is staged through host memory); the real run uses nccl (= RCCL over xGMI).
-    backend = os.environ.get("LF_BENCH_BACKEND", "nccl")
-    local = local % torch.cuda.device_count() if backend == "gloo" else local
+    # Control plane (rendezvous, the RCCL id, barriers, the final sums): torch.distributed over gloo.
+    # Data plane: the C ABI's own RCCL communicator (lf_comm_*, one all-gather of finished tile rows
+    # per frame over xGMI).  LF_BENCH_GATHER=torch selects the round-1 exchange (torch.distributed
+    # nccl all_gather_into_tensor on the library's buffers) instead; it is also the fallback, on every
+    # rank together, should the C ABI's communicator fail to initialise.
+    # LF_BENCH_REHEARSAL=1: several ranks share GPU 0 on a one-GPU box (no RCCL communicator is
+    # possible there: the exchange is staged through host memory over gloo).
+    rehearsal = os.environ.get("LF_BENCH_REHEARSAL") == "1"
+    gather_mode = "none" if world == 1 else ("host" if rehearsal else os.environ.get("LF_BENCH_GATHER", "cabi"))
+    local = local % max(1, torch.cuda.device_count()) if rehearsal else local
     torch.cuda.set_device(local)
+    nccl_group = None
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        if backend == "nccl":
-            dist.init_process_group("nccl", device_id=torch.device("cuda", local))
-        else:
-            dist.init_process_group(backend)
+        dist.init_process_group("gloo")
+        if gather_mode == "torch":
+            nccl_group = dist.new_group(backend="nccl")
 
     lens = pkg.load_lens_file(os.environ.get("LF_BENCH_LENS", "dgauss11.lens"))  # env: experiments only
     mask = pkg.load_aperture_png("pentbig500_14.png")
@@ -314,10 +320,36 @@ def main():
     my_trows = len(sharding.my_tile_rows(H, rank, world))
     lf.set_band(0, H)
     lf.set_row_interleave(rank, world)
-    frame_t, scratch = None, {}
-    if world > 1:
+    frame_t, scratch, gather_note = None, {}, None
+    if gather_mode == "cabi":
+        # rank 0 makes the RCCL id, gloo carries it, every rank attaches its context
+        ok, why = 1, ""
+        try:
+            box = [pkg.comm_unique_id() if rank == 0 else None]
+        except Exception as e:  # noqa: BLE001
+            box, ok, why = [None], 0, str(e)
+        dist.broadcast_object_list(box, src=0)
+        if box[0] is None:
+            ok = 0
+        if ok:
+            try:
+                lf.comm_init_rank(world, rank, box[0])
+            except Exception as e:  # noqa: BLE001
+                ok, why = 0, str(e)
+        flag = torch.tensor([ok], dtype=torch.int32)
+        dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+        if int(flag[0]) == 0:   # every rank takes the same decision
+            gather_mode = "torch"
+            gather_note = f"C-ABI RCCL communicator unavailable ({why or 'another rank failed'}): torch.distributed nccl exchange"
+            nccl_group = dist.new_group(backend="nccl")
+    if gather_mode in ("torch", "host"):
         ptr, nbytes = lf.device_buffer(pkg.SAMPLE_BUFFER)
         frame_t = torch.as_tensor(DevView(ptr, nbytes // 8), device=f"cuda:{local}")
+
+    class GroupDist:   # sharding.gather_frame only needs all_gather_into_tensor
+        @staticmethod
+        def all_gather_into_tensor(out, inp):
+            dist.all_gather_into_tensor(out, inp, group=nccl_group)
 
     def one_frame():
         lf.find_sun_pos(lights)
@@ -326,18 +358,19 @@ def main():
             lf.render_scene_term()
         lf.trace_ghosts(spp, 0x1e45f1a4e)
         lf.render_flare_layer()
-        if world > 1:
-            # the real exchange step: every rank ends up with the whole frame -- ONE all-gather per
-            # frame (lens_flare_amd/sharding.py: pack this rank's tile rows, gather, unpack); the
-            # buffer is padded so that the last group of tile rows never runs past the end.
+        # the exchange step: every rank ends up with the whole frame -- ONE all-gather per frame
+        if gather_mode == "cabi":
+            lf.comm_gather(pkg.SAMPLE_BUFFER)          # enqueued on the context's stream
+        elif gather_mode == "torch":
             lf.synchronize()
-            if backend == "nccl":
-                sharding.gather_frame(frame_t, W, H, rank, world, dist, scratch=scratch)
-            else:
-                host = frame_t.cpu()
-                sharding.gather_frame(host, W, H, rank, world, dist)
-                frame_t.copy_(host)
+            sharding.gather_frame(frame_t, W, H, rank, world, GroupDist, scratch=scratch)
             torch.cuda.synchronize()   # the next frame rewrites these rows on the library's stream
+        elif gather_mode == "host":
+            lf.synchronize()
+            host = frame_t.cpu()
+            sharding.gather_frame(host, W, H, rank, world, dist)
+            frame_t.copy_(host)
+            torch.cuda.synchronize()
 
     def barrier():
         lf.synchronize()
@@ -363,8 +396,7 @@ def main():
     cnt = lf.counters()
     n_launch, march_ms = lf.timing_get("march")
     ev = torch.tensor([float(cnt["surface_events"]), float(cnt["rays_launched"]),
-                       float(lf.executed_events()), dt],
-                      dtype=torch.float64, device=f"cuda:{local}" if backend == "nccl" else "cpu")
+                       float(lf.executed_events()), dt], dtype=torch.float64)
     if world > 1:
         tot = ev.clone()
         dist.all_reduce(tot[:3], op=dist.ReduceOp.SUM)
@@ -438,7 +470,11 @@ def main():
             "config": {"workload": f"{args.config}: {cfg['text']}" +
                                    (f" [overridden: {W}x{H}, {spp} spp]" if (args.width or args.height or args.spp) else ""),
                        "parallelism": f"{world} GPU(s), 8-row sensor tile rows dealt round-robin"
-                                      + (", one RCCL all_gather per frame" if world > 1 else ""),
+                                      + ({"cabi": ", one ncclAllGather per frame inside the C ABI (lf_comm_gather)",
+                                          "torch": ", one torch.distributed nccl all_gather per frame",
+                                          "host": ", REHEARSAL: ranks share one GPU, exchange staged through host memory",
+                                          "none": ""}[gather_mode]),
+                       "gather_note": gather_note,
                        "rays_per_frame": rays / args.steps,
                        "events_executed_per_frame": executed / args.steps,
                        "events_logical_per_frame": logical / args.steps,

@@ -143,19 +143,38 @@ lf_status lf_set_scene(lf_ctx* ctx, int n_spheres, const double* spheres, const 
                        int n_triangles, const double* tri_positions, const double* tri_normals,
                        const int* tri_material, int n_materials, const double* materials,
                        int n_lights, const double* lights);
+/* The lights of the current scene in their general form (replaces the lights lf_set_scene took; the
+ * order is the order of scene->lights): n x 16 doubles
+ *   {type, r, g, b,  v0 xyz,  v1 xyz,  v2 xyz,  v3 xyz}
+ *   type 0 DirectionalLight          v0 = dirToLight                       (scene/light.h:16-29)
+ *        1 PointLight                v0 = position                         (:47-58)
+ *        2 InfiniteHemisphereLight   (no vectors)                          (:31-44, light.cpp:26-48)
+ *        3 AreaLight                 v0 = position, v1 = direction, v2 = dim_x, v3 = dim_y  (:78-97, light.cpp:74-101)
+ * Types 2 and 3 are SAMPLED lights: lf_set_light_samples(ns_area_light) samples each per hit
+ * (PathTracer::ns_area_light, pathtracer.h:108; estimate_direct_lighting_importance,
+ * pathtracer.cpp:143-213), drawn from the counter RNG -- they need lf_set_jitter_counter (the
+ * reference's shared MT19937 is consumed in hit order, which no parallel schedule reproduces) and are
+ * validated statistically against reference frames, not bit for bit. */
+lf_status lf_set_scene_lights(lf_ctx* ctx, int n_lights, const double* rows);
+lf_status lf_set_light_samples(lf_ctx* ctx, int ns_area_light);
 /* Row f3: a COLLADA file -> the static scene, in one call.  Replaces
  * Collada::ColladaParser::load (src/scene/collada/collada.cpp:131-218) + Application::load
  * (src/application/application.cpp:232-365) + the GLScene -> SceneObjects conversion behind them
  * (gl_scene/mesh.cpp, util/halfEdgeMesh.cpp, scene/object.cpp, gl_scene/ *_light.h): parses the file
  * on the host (lens-flare_amd/host/lf_collada.cpp; triangles, vertex normals, lights and camera come
  * out bit-identical to the reference's, tests/test_collada_loader.py) and hands the result to
- * lf_set_scene.  Lights are uploaded in node order, directional and point lights only.
+ * lf_set_scene / lf_set_scene_lights.  Lights are uploaded in node order: directional, point, area
+ * and ambient (= infinite hemisphere) lights.
  *   camera          (may be NULL) what Application::load derives from the file's camera node(s)
  *   sun_lights      (may be NULL) for lf_find_sun_pos: 6 doubles per DirectionalLight, posLight
  *                   xyz + radiance rgb; at most max_sun_lights are written, *n_sun_lights = found
- * LF_ERR_INVALID with a message if the file has what the device scene term refuses (area, spot or
- * hemisphere lights, mirror / glass / microfacet / refraction BSDFs) or what the reference itself
- * cannot load (it exits or reads uninitialised memory there). */
+ * Mirror / glass / refraction / microfacet BSDFs are unfilled stubs in the reference (f() = 0, no
+ * emission, advanced_bsdf.cpp:17-133) under a direct-lighting-only integrator (pathtracer.cpp:
+ * 282-302): such surfaces are black occluders there and are uploaded as exactly that.
+ * LF_ERR_INVALID with a message if the file has a spot light (a stub in the reference whose
+ * sample_L leaves its outputs uninitialised, light.cpp:64-72) or what the reference itself cannot
+ * load (it exits or reads uninitialised memory there).  lf_collada_check answers the
+ * same question for a file without a device (0 = renderable; msg receives the reason otherwise). */
 typedef struct {
   int present;
   double hfov, vfov, nclip, fclip;
@@ -163,6 +182,7 @@ typedef struct {
 } lf_collada_camera;
 lf_status lf_load_collada(lf_ctx* ctx, const char* path, lf_collada_camera* camera,
                           double* sun_lights, int max_sun_lights, int* n_sun_lights);
+lf_status lf_collada_check(const char* path, char* msg, size_t msg_cap);
 /* replaces the public fields samplesPerBatch / maxTolerance (pathtracer.h:112-113) and
  * Camera::nClip / fClip (camera.h:188) */
 lf_status lf_set_sampling(lf_ctx* ctx, int samples_per_batch, double max_tolerance, double n_clip,

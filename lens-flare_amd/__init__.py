@@ -29,7 +29,7 @@ ABI_SYMBOLS = [
     "lf_set_frame", "lf_set_band", "lf_set_row_interleave", "lf_set_params", "lf_set_aperture", "lf_get_aperture_stats",
     "lf_set_paraxial_lens", "lf_set_camera", "lf_find_sun_pos", "lf_set_flares", "lf_get_flares",
     "lf_set_jitter_mt19937", "lf_set_jitter_counter", "lf_set_scene_term", "lf_set_scene",
-    "lf_set_sampling", "lf_render_scene_term",
+    "lf_set_sampling", "lf_set_scene_lights", "lf_set_light_samples", "lf_collada_check", "lf_render_scene_term",
     "lf_generate_ghost_buffer", "lf_render_flare_layer", "lf_read_tile", "lf_read_pixel",
     "lf_write_to_framebuffer", "lf_save_image_rgba", "lf_device_buffer", "lf_set_lens", "lf_set_lambda_rgb", "lf_set_sun",
     "lf_set_sun_from_flares", "lf_paraxial_efl", "lf_set_ghost_pairs", "lf_set_pupil_subcells", "lf_trace_ghosts", "lf_generate_lens_rays", "lf_get_counters", "lf_reset_counters", "lf_get_executed_events", "lf_native_sqrt", "lf_set_starburst_spectrum", "lf_load_collada", "lf_march_tables",
@@ -138,6 +138,13 @@ def paraxial_efl(lens, lam=None):
     if st != 0:
         raise LensFlareError(st, "lf_paraxial_efl")
     return out.value
+
+
+def collada_check(path):
+    """lf_collada_check: None if the device scene term can render the file, else the reason (no device needed)."""
+    msg = C.create_string_buffer(512)
+    st = load_library().lf_collada_check(os.fsencode(path), msg, C.c_size_t(512))
+    return None if st == 0 else msg.value.decode()
 
 
 def aim_camera(pos, world_point, ns, hfov_deg, vfov_deg):
@@ -309,7 +316,9 @@ class LensFlare:
         mats, sp, spm, tp, tn, tm = [], [], [], [], [], []
 
         def mat(kind, a, b, c):
-            mats.append([1.0 if kind == "e" else 0.0, a, b, c])
+            # 'd' diffuse reflectance, 'e' emitted radiance, 'm' one of the reference's stub BSDFs
+            # (mirror / glass / ...: f() = 0, a black occluder under its integrator)
+            mats.append([1.0, a, b, c] if kind == "e" else [0.0, 0.0, 0.0, 0.0] if kind == "m" else [0.0, a, b, c])
             return len(mats) - 1
 
         for s in spheres:
@@ -324,6 +333,14 @@ class LensFlare:
                                        len(tp), _fp(tpa, C.c_double), _fp(tna, C.c_double),
                                        _fp(tma, C.c_int), len(mats), _fp(ma, C.c_double),
                                        len(lights), _fp(la, C.c_double)))
+
+    def set_scene_lights(self, rows):
+        """rows: n x 16 {type, rgb, v0, v1, v2, v3} (include/lensflare.h, lf_set_scene_lights)."""
+        r = np.ascontiguousarray(rows, np.float64).reshape(-1, 16)
+        self._ck(self.lib.lf_set_scene_lights(self.ctx, len(r), _fp(r, C.c_double)))
+
+    def set_light_samples(self, ns_area_light):
+        self._ck(self.lib.lf_set_light_samples(self.ctx, int(ns_area_light)))
 
     def load_collada(self, path, max_suns=8):
         """Row f3: parse a .dae, upload its static scene; returns (camera dict or None, sun lights

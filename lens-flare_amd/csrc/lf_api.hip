@@ -846,47 +846,80 @@ lf_status lf_march_tables(int n_surfaces, int stop_index, int n_lambda, const fl
   return LF_OK;
 }
 
+namespace {
+// what Application::load hands the renderer, flattened for lf_set_scene / lf_set_scene_lights;
+// returns an empty string, or why the device scene term cannot render the file
+std::string flatten_collada(const lfamd::ColladaScene& sc, std::vector<double>& sph, std::vector<int>& sph_m,
+                            std::vector<double>& tp, std::vector<double>& tn, std::vector<int>& tri_m,
+                            std::vector<double>& mats, std::vector<double>& lights, std::vector<double>& suns) {
+  // DiffuseBSDF and EmissionBSDF as they are.  Mirror / Refraction / Glass / Microfacet are unfilled
+  // stubs in the reference: their f() returns 0 and they emit nothing (advanced_bsdf.cpp:17-133,
+  // bsdf.h:183-254), and the reference's integrator is zero_bounce + one_bounce only
+  // (pathtracer.cpp:282-302) -- such a surface IS a black occluder there, so that is what it is here:
+  // diffuse with reflectance 0.
+  for (const auto& m : sc.materials) {
+    const bool lit = m.kind == lfamd::BSDF_DIFFUSE || m.kind == lfamd::BSDF_EMISSION;
+    mats.push_back(m.kind == lfamd::BSDF_EMISSION ? 1.0 : 0.0);
+    mats.push_back(lit ? m.rgb.x : 0.0); mats.push_back(lit ? m.rgb.y : 0.0); mats.push_back(lit ? m.rgb.z : 0.0);
+  }
+  for (const auto& s : sc.spheres) {
+    sph.insert(sph.end(), {s.o.x, s.o.y, s.o.z, s.r});
+    sph_m.push_back(s.material);
+  }
+  for (const auto& t : sc.triangles) {
+    for (int k = 0; k < 3; k++) { tp.push_back(t.p[k].x); tp.push_back(t.p[k].y); tp.push_back(t.p[k].z); }
+    for (int k = 0; k < 3; k++) { tn.push_back(t.n[k].x); tn.push_back(t.n[k].y); tn.push_back(t.n[k].z); }
+    tri_m.push_back(t.material);
+  }
+  for (const auto& l : sc.lights) {
+    double row[16] = {0};
+    row[1] = l.radiance.x; row[2] = l.radiance.y; row[3] = l.radiance.z;
+    auto put = [&](int at, const lfamd::ColladaVec3& v) { row[at] = v.x; row[at + 1] = v.y; row[at + 2] = v.z; };
+    if (l.type == lfamd::LIGHT_DIRECTIONAL) {
+      row[0] = 0; put(4, l.direction);
+      suns.insert(suns.end(), {l.position.x, l.position.y, l.position.z, l.radiance.x, l.radiance.y, l.radiance.z});
+    } else if (l.type == lfamd::LIGHT_POINT) {
+      row[0] = 1; put(4, l.position);
+    } else if (l.type == lfamd::LIGHT_HEMISPHERE) {
+      row[0] = 2;
+    } else if (l.type == lfamd::LIGHT_AREA) {
+      row[0] = 3; put(4, l.position); put(7, l.direction); put(10, l.dim_x); put(13, l.dim_y);
+    } else {
+      return "spot lights are a stub in the reference (light.cpp:64-72) and are not rendered";
+    }
+    lights.insert(lights.end(), row, row + 16);
+  }
+  return "";
+}
+}  // namespace
+
+lf_status lf_collada_check(const char* path, char* msg, size_t msg_cap) {
+  if (!path) return LF_ERR_INVALID;
+  lfamd::ColladaScene sc;
+  std::string err;
+  if (!lfamd::load_collada(path, sc, err)) err = "lf_load_collada: " + err;
+  else {
+    std::vector<double> a, c, d, e, f, g;
+    std::vector<int> b, h;
+    err = flatten_collada(sc, a, b, c, d, h, e, f, g);
+  }
+  if (msg && msg_cap) { std::strncpy(msg, err.c_str(), msg_cap - 1); msg[msg_cap - 1] = 0; }
+  return err.empty() ? LF_OK : LF_ERR_INVALID;
+}
+
 lf_status lf_load_collada(lf_ctx* ctx, const char* path, lf_collada_camera* camera, double* sun_lights,
                           int max_sun_lights, int* n_sun_lights) {
   if (!ctx || !path) return LF_ERR_INVALID;
   lfamd::ColladaScene sc;
   std::string err;
   if (!lfamd::load_collada(path, sc, err)) return lf_fail(ctx, LF_ERR_INVALID, "lf_load_collada: " + err);
-  std::vector<double> sph, tp, tn, mats, lights;
+  std::vector<double> sph, tp, tn, mats, lights, suns;
   std::vector<int> sph_m, tri_m;
-  for (const auto& m : sc.materials) {
-    // only the materials some primitive uses have to be shadeable
-    mats.push_back(m.kind == lfamd::BSDF_EMISSION ? 1.0 : 0.0);
-    mats.push_back(m.rgb.x); mats.push_back(m.rgb.y); mats.push_back(m.rgb.z);
-  }
-  auto check_mat = [&](int m) { return sc.materials[m].kind == lfamd::BSDF_DIFFUSE || sc.materials[m].kind == lfamd::BSDF_EMISSION; };
-  for (const auto& s : sc.spheres) {
-    if (!check_mat(s.material)) return lf_fail(ctx, LF_ERR_INVALID, "lf_load_collada: a sphere uses a mirror/glass/refraction/microfacet BSDF (stubs in the reference, refused here)");
-    sph.insert(sph.end(), {s.o.x, s.o.y, s.o.z, s.r});
-    sph_m.push_back(s.material);
-  }
-  for (const auto& t : sc.triangles) {
-    if (!check_mat(t.material)) return lf_fail(ctx, LF_ERR_INVALID, "lf_load_collada: a mesh uses a mirror/glass/refraction/microfacet BSDF (stubs in the reference, refused here)");
-    for (int k = 0; k < 3; k++) { tp.push_back(t.p[k].x); tp.push_back(t.p[k].y); tp.push_back(t.p[k].z); }
-    for (int k = 0; k < 3; k++) { tn.push_back(t.n[k].x); tn.push_back(t.n[k].y); tn.push_back(t.n[k].z); }
-    tri_m.push_back(t.material);
-  }
-  int n_sun = 0;
-  for (const auto& l : sc.lights) {
-    if (l.type == lfamd::LIGHT_DIRECTIONAL) {
-      lights.insert(lights.end(), {0.0, l.direction.x, l.direction.y, l.direction.z, l.radiance.x, l.radiance.y, l.radiance.z});
-      if (sun_lights && n_sun < max_sun_lights) {
-        double* o = sun_lights + 6 * n_sun;
-        o[0] = l.position.x; o[1] = l.position.y; o[2] = l.position.z;
-        o[3] = l.radiance.x; o[4] = l.radiance.y; o[5] = l.radiance.z;
-      }
-      n_sun++;
-    } else if (l.type == lfamd::LIGHT_POINT) {
-      lights.insert(lights.end(), {1.0, l.position.x, l.position.y, l.position.z, l.radiance.x, l.radiance.y, l.radiance.z});
-    } else {
-      return lf_fail(ctx, LF_ERR_INVALID, "lf_load_collada: area / spot / hemisphere lights are not supported by the device scene term");
-    }
-  }
+  err = flatten_collada(sc, sph, sph_m, tp, tn, tri_m, mats, lights, suns);
+  if (!err.empty()) return lf_fail(ctx, LF_ERR_INVALID, "lf_load_collada: " + err);
+  const int n_sun = (int)(suns.size() / 6);
+  for (int k = 0; k < n_sun && sun_lights && k < max_sun_lights; k++)
+    std::memcpy(sun_lights + 6 * k, suns.data() + 6 * k, 6 * sizeof(double));
   if (n_sun_lights) *n_sun_lights = n_sun;
   if (camera) {
     std::memset(camera, 0, sizeof(*camera));
@@ -897,8 +930,10 @@ lf_status lf_load_collada(lf_ctx* ctx, const char* path, lf_collada_camera* came
     camera->dir[0] = c.dir.x; camera->dir[1] = c.dir.y; camera->dir[2] = c.dir.z;
     camera->up[0] = c.up.x; camera->up[1] = c.up.y; camera->up[2] = c.up.z;
   }
-  return lf_set_scene(ctx, (int)sph_m.size(), sph.data(), sph_m.data(), (int)tri_m.size(), tp.data(), tn.data(),
-                      tri_m.data(), (int)sc.materials.size(), mats.data(), (int)(lights.size() / 7), lights.data());
+  lf_status st = lf_set_scene(ctx, (int)sph_m.size(), sph.data(), sph_m.data(), (int)tri_m.size(), tp.data(),
+                              tn.data(), tri_m.data(), (int)sc.materials.size(), mats.data(), 0, nullptr);
+  if (st != LF_OK) return st;
+  return lf_set_scene_lights(ctx, (int)(lights.size() / 16), lights.data());
 }
 
 lf_status lf_set_starburst_spectrum(lf_ctx* ctx, int n, const double* scale, const double* rgb_weights) {

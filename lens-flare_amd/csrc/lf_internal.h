@@ -62,10 +62,13 @@ struct LfCamera {
 struct LfBvhNode { double bmin[3], bmax[3]; int left, right, first, count; };  // leaf: count > 0
 struct LfPrim { int type, material; double d[18]; };  // sphere: c(3) r r^2; triangle: 3 pos + 3 normals
 struct LfMaterial { int kind, pad; double rgb[3]; };   // 0 diffuse (reflectance), 1 emission (radiance)
-struct LfLight { int type, pad; double v[3], rgb[3]; }; // 0 directional (v = dirToLight), 1 point (v = position)
+// 0 directional (v = dirToLight), 1 point (v = position), 2 infinite hemisphere, 3 area (v = position,
+// dir, dim_x, dim_y, area = |dim_x| |dim_y|: scene/light.h:80-97)
+struct LfLight { int type, pad; double v[3], rgb[3], dir[3], dim_x[3], dim_y[3], area; };
 struct LfSceneDev {
   LfBvhNode* nodes; LfPrim* prims; LfMaterial* materials; LfLight* lights;
   int n_nodes, n_prims, n_materials, n_lights;
+  int n_soft_lights;   // lights that are sampled (hemisphere, area): they need the counter RNG
 };
 
 // per-wavelength starburst (row f4): n = 0 is the reference's monochrome starburst
@@ -217,6 +220,7 @@ struct lf_ctx {
   // scene term
   LfSceneDev scene_dev{};
   bool scene_valid = false;
+  int ns_area_light = 1;          // PathTracer::ns_area_light (pathtracer.h:108; the -l flag)
   int samples_per_batch = 32;     // PathTracer::samplesPerBatch default (raytraced_renderer.h:67-81)
   double max_tolerance = 0.05;    // PathTracer::maxTolerance
 

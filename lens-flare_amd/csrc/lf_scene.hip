@@ -10,10 +10,16 @@
 // inside the 1e-4 bar.  The BVH is our own (median split on the host, stack traversal on the
 // device): the closest hit does not depend on the tree, only the amount of work does.
 //
-// Not covered (the call fails loudly rather than approximating): area / hemisphere / environment
-// lights and hemisphere sampling (they draw from the shared MT19937 only when a camera ray hits
-// something, which makes every later pixel's jitter depend on every earlier pixel's hits), and the
-// Mirror/Glass/Microfacet BSDFs, which are unfilled stubs in the reference (advanced_bsdf.cpp).
+// Sampled lights -- AreaLight and InfiniteHemisphereLight (scene/light.cpp:35-48, :82-101) with
+// ns_area_light samples each, exactly the estimator of estimate_direct_lighting_importance
+// (pathtracer.cpp:143-213) -- draw from the order-free Philox counter RNG: the reference draws them
+// from its shared MT19937 only when a camera ray hits something, which makes every later pixel's
+// jitter depend on every earlier pixel's hits, so no device schedule can reproduce its stream.
+// They are therefore validated statistically against frames the reference rendered
+// (tests/test_gpu_area_lights.py) and refused in MT19937 parity mode.
+// Not covered (the call fails loudly rather than approximating): environment maps, uniform
+// hemisphere sampling of emitters (-H), spot lights (a stub in the reference, light.cpp:64-72) and
+// the Mirror/Glass/Microfacet BSDFs, which are unfilled stubs in the reference (advanced_bsdf.cpp).
 #include <algorithm>
 #include <cmath>
 #include <cstring>
@@ -155,7 +161,11 @@ __device__ inline void make_coord_space(V3 n, V3& X, V3& Y, V3& Z) {
 
 // est_radiance_global_illumination (pathtracer.cpp:282-302) = zero_bounce + one_bounce with
 // estimate_direct_lighting_importance (:142-213)
-__device__ V3 radiance(const LfSceneDev& sc, DRay r, int* __restrict__ stack) {
+__device__ inline uint4 philox4x32_10(uint4 ctr, uint2 key);
+__device__ inline double random_uniform_from_raw(unsigned raw);
+
+__device__ V3 radiance(const LfSceneDev& sc, DRay r, int* __restrict__ stack, int ns_area_light,
+                       uint4 rng_ctr, uint2 rng_key) {
   Hit isect;
   if (!closest_hit(sc.nodes, sc.prims, r, &isect, stack)) return v3(0, 0, 0);  // no envLight
   const LfMaterial& m = sc.materials[isect.material];
@@ -165,36 +175,62 @@ __device__ V3 radiance(const LfSceneDev& sc, DRay r, int* __restrict__ stack) {
   const V3 hit_p = r.o + r.d * isect.t;
   V3 L = v3(0, 0, 0);
   const double kEpsF = (double)0.00001f;  // EPS_F (misc.h:13)
+  int total_samples = 0;
+  const double ipi = 1.0 / 3.14159265358979323;
+  // DiffuseBSDF::f = Vector3D(1/PI) * reflectance (bsdf.cpp:52-60); EmissionBSDF::f = 0
+  // (kind 2: the value of f itself, as a host that can only call BSDF::f hands it over)
+  const V3 f = m.kind == 0 ? mulv(v3(ipi, ipi, ipi), v3(m.rgb[0], m.rgb[1], m.rgb[2]))
+             : m.kind == 2 ? v3(m.rgb[0], m.rgb[1], m.rgb[2]) : v3(0, 0, 0);
   for (int l = 0; l < sc.n_lights; l++) {
     const LfLight& lt = sc.lights[l];
-    V3 wi;
-    double dist;
-    const V3 emit = v3(lt.rgb[0], lt.rgb[1], lt.rgb[2]);
-    if (lt.type == 0) {  // DirectionalLight::sample_L (light.cpp:18-24)
-      wi = v3(lt.v[0], lt.v[1], lt.v[2]);
-      dist = INFINITY;
-    } else {             // PointLight::sample_L (light.cpp:52-60)
-      const V3 d = v3(lt.v[0], lt.v[1], lt.v[2]) - hit_p;
-      wi = unit(d);
-      dist = norm(d);
-    }
-    // w2o * wi: rows of w2o are the columns of o2w; Matrix3x3 * Vector3D sums column-wise:
-    // wi.x*col0 + wi.y*col1 + wi.z*col2 of w2o, i.e. component k = (wi.x*R0[k] + wi.y*R1[k]) + wi.z*R2[k]
-    const V3 wo = v3((wi.x * X.x + wi.y * X.y) + wi.z * X.z, (wi.x * Y.x + wi.y * Y.y) + wi.z * Y.z,
-                     (wi.x * Z.x + wi.y * Z.y) + wi.z * Z.z);
-    if (wo.z < 0) continue;
-    DRay sh{hit_p, wi, kEpsF, dist - kEpsF};
-    if (!closest_hit(sc.nodes, sc.prims, sh, nullptr, stack)) {
-      const double cos_theta = unit(wo).z;
-      // DiffuseBSDF::f = Vector3D(1/PI) * reflectance (bsdf.cpp:52-60); EmissionBSDF::f = 0
-      const double ipi = 1.0 / 3.14159265358979323;
-      // (kind 2: the value of f itself, as a host that can only call BSDF::f hands it over)
-      const V3 f = m.kind == 0 ? mulv(v3(ipi, ipi, ipi), v3(m.rgb[0], m.rgb[1], m.rgb[2]))
-                 : m.kind == 2 ? v3(m.rgb[0], m.rgb[1], m.rgb[2]) : v3(0, 0, 0);
-      L = L + divs(mulv(f, emit) * cos_theta, 1.0);  // / pdf, pdf = 1 for delta lights
+    const int num_samples = lt.type >= 2 ? ns_area_light : 1;   // is_delta_light() ? 1 : ns_area_light
+    total_samples += num_samples;
+    for (int k = 0; k < num_samples; k++) {
+      V3 wi;
+      double dist, pdf = 1.0;
+      V3 emit = v3(lt.rgb[0], lt.rgb[1], lt.rgb[2]);
+      if (lt.type == 0) {  // DirectionalLight::sample_L (light.cpp:18-24)
+        wi = v3(lt.v[0], lt.v[1], lt.v[2]);
+        dist = INFINITY;
+      } else if (lt.type == 1) {  // PointLight::sample_L (light.cpp:52-60)
+        const V3 d = v3(lt.v[0], lt.v[1], lt.v[2]) - hit_p;
+        wi = unit(d);
+        dist = norm(d);
+      } else {
+        const uint4 rr = philox4x32_10(make_uint4(rng_ctr.x, rng_ctr.y, 0x11640000u + (unsigned)l, (unsigned)k),
+                                       rng_key);
+        const double xi1 = random_uniform_from_raw(rr.x), xi2 = random_uniform_from_raw(rr.y);
+        if (lt.type == 2) {  // InfiniteHemisphereLight::sample_L (light.cpp:35-48)
+          const double theta = acos(xi1), phi = 2.0 * 3.14159265358979323 * xi2;
+          const double xs = sin(theta) * cos(phi), ys = sin(theta) * sin(phi), zs = cos(theta);
+          wi = v3(xs, zs, -ys);   // sampleToWorld: columns (1,0,0), (0,0,-1), (0,1,0)
+          dist = INFINITY;
+          pdf = 1.0 / (2.0 * 3.14159265358979323);
+        } else {             // AreaLight::sample_L (light.cpp:82-101)
+          const double sx = xi1 - (double)0.5f, sy = xi2 - (double)0.5f;
+          const V3 d = ((v3(lt.v[0], lt.v[1], lt.v[2]) + sx * v3(lt.dim_x[0], lt.dim_x[1], lt.dim_x[2])) +
+                        sy * v3(lt.dim_y[0], lt.dim_y[1], lt.dim_y[2])) - hit_p;
+          const double cos_l = dot(d, v3(lt.dir[0], lt.dir[1], lt.dir[2]));
+          const double sq = dot(d, d);
+          dist = sqrt(sq);
+          wi = divs(d, dist);
+          pdf = sq / (lt.area * fabs(cos_l));
+          if (!(cos_l < 0)) emit = v3(0, 0, 0);   // the light shines to one side only
+        }
+      }
+      // w2o * wi: rows of w2o are the columns of o2w; Matrix3x3 * Vector3D sums column-wise:
+      // wi.x*col0 + wi.y*col1 + wi.z*col2 of w2o, i.e. component k = (wi.x*R0[k] + wi.y*R1[k]) + wi.z*R2[k]
+      const V3 wo = v3((wi.x * X.x + wi.y * X.y) + wi.z * X.z, (wi.x * Y.x + wi.y * Y.y) + wi.z * Y.z,
+                       (wi.x * Z.x + wi.y * Z.y) + wi.z * Z.z);
+      if (wo.z < 0) continue;
+      DRay sh{hit_p, wi, kEpsF, dist - kEpsF};
+      if (!closest_hit(sc.nodes, sc.prims, sh, nullptr, stack)) {
+        const double cos_theta = unit(wo).z;
+        L = L + divs(mulv(f, emit) * cos_theta, pdf);  // / pdf (1 for delta lights)
+      }
     }
   }
-  if (sc.n_lights > 0) L = divs(L, (double)sc.n_lights);  // L_out / total_samples (:211)
+  if (total_samples > 0) L = divs(L, (double)total_samples);  // L_out / total_samples (:211)
   return emission + L;
 }
 
@@ -219,8 +255,8 @@ __device__ inline double random_uniform_from_raw(unsigned raw) {  // util/random
 
 // the sample loop of raytrace_pixel (pathtracer.cpp:831-875)
 __global__ __launch_bounds__(256) void k_scene_term(LfSceneDev sc, LfCamera cam, int W, int H, int y0,
-                                                    int y1, int ns_aa, int samples_per_batch,
-                                                    double max_tolerance,
+                                                    int y1, int ns_aa, int ns_area_light,
+                                                    int samples_per_batch, double max_tolerance,
                                                     const uint32_t* __restrict__ aa_raw, int jitter_mode,
                                                     uint64_t key, double* __restrict__ scene) {
   // traversal stacks of the 256 threads: the median-split tree of n primitives is ceil(log2(n / 4))
@@ -258,7 +294,8 @@ __global__ __launch_bounds__(256) void k_scene_term(LfSceneDev sc, LfCamera cam,
              (dir.x * cam.c2w[3] + dir.y * cam.c2w[4]) + dir.z * cam.c2w[5],
              (dir.x * cam.c2w[6] + dir.y * cam.c2w[7]) + dir.z * cam.c2w[8]);
     r.min_t = cam.n_clip; r.max_t = cam.f_clip;
-    const V3 L = radiance(sc, r, stack);
+    const V3 L = radiance(sc, r, stack, ns_area_light, make_uint4((unsigned)p, (unsigned)sample, 0u, 0u),
+                          make_uint2((unsigned)key, (unsigned)(key >> 32)));
     // Vector3D::illum (vector3D.h:231-233): float coefficients, double arithmetic, float result
     const float illum = (float)((0.2126f * L.x + 0.7152f * L.y) + 0.0722f * L.z);
     s1 += illum;
@@ -366,9 +403,11 @@ lf_status lf_set_scene(lf_ctx* ctx, int n_spheres, const double* spheres, const 
   }
   std::vector<LfLight> lts(n_lights);
   for (int i = 0; i < n_lights; i++) {
+    std::memset(&lts[i], 0, sizeof(LfLight));
     lts[i].type = (int)lights[7 * i];
     if (lts[i].type != 0 && lts[i].type != 1)
-      return lf_fail(ctx, LF_ERR_INVALID, "scene: only directional (0) and point (1) lights are supported");
+      return lf_fail(ctx, LF_ERR_INVALID, "scene: lf_set_scene takes directional (0) and point (1) lights; "
+                                          "hemisphere and area lights go through lf_set_scene_lights");
     for (int c = 0; c < 3; c++) { lts[i].v[c] = lights[7 * i + 1 + c]; lts[i].rgb[c] = lights[7 * i + 4 + c]; }
   }
   std::vector<LfBvhNode> nodes;
@@ -395,9 +434,50 @@ lf_status lf_set_scene(lf_ctx* ctx, int n_spheres, const double* spheres, const 
   LF_HIP(ctx, up((void**)&S.materials, mats.data(), mats.size() * sizeof(LfMaterial)));
   LF_HIP(ctx, up((void**)&S.lights, lts.data(), lts.size() * sizeof(LfLight)));
   S.n_nodes = (int)nodes.size(); S.n_prims = (int)prims.size();
-  S.n_materials = n_materials; S.n_lights = n_lights;
+  S.n_materials = n_materials; S.n_lights = n_lights; S.n_soft_lights = 0;
   if (prims.empty()) S.n_nodes = 1;
   ctx->scene_valid = true;
+  return LF_OK;
+}
+
+lf_status lf_set_scene_lights(lf_ctx* ctx, int n_lights, const double* rows) {
+  if (!ctx || n_lights < 0 || (n_lights && !rows)) return LF_ERR_INVALID;
+  if (!ctx->scene_valid) return lf_fail(ctx, LF_ERR_STATE, "lf_set_scene_lights before lf_set_scene");
+  std::vector<LfLight> lts(n_lights);
+  int soft = 0;
+  for (int i = 0; i < n_lights; i++) {
+    const double* r = rows + 16 * (size_t)i;
+    LfLight& l = lts[i];
+    std::memset(&l, 0, sizeof(l));
+    l.type = (int)r[0];
+    if (l.type < 0 || l.type > 3) return lf_fail(ctx, LF_ERR_INVALID, "scene light type must be 0 .. 3");
+    for (int c = 0; c < 3; c++) {
+      l.rgb[c] = r[1 + c]; l.v[c] = r[4 + c]; l.dir[c] = r[7 + c]; l.dim_x[c] = r[10 + c]; l.dim_y[c] = r[13 + c];
+    }
+    if (l.type >= 2) soft++;
+    if (l.type == 3) {
+      // AreaLight's constructor: area = dim_x.norm() * dim_y.norm() (light.cpp:76-80)
+      const double nx = std::sqrt((l.dim_x[0] * l.dim_x[0] + l.dim_x[1] * l.dim_x[1]) + l.dim_x[2] * l.dim_x[2]);
+      const double ny = std::sqrt((l.dim_y[0] * l.dim_y[0] + l.dim_y[1] * l.dim_y[1]) + l.dim_y[2] * l.dim_y[2]);
+      l.area = nx * ny;
+      if (!(l.area > 0)) return lf_fail(ctx, LF_ERR_INVALID, "area light with zero area");
+    }
+  }
+  LF_HIP(ctx, hipSetDevice(ctx->device));
+  LF_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  LfSceneDev& S = ctx->scene_dev;
+  if (S.lights) (void)hipFree(S.lights);
+  S.lights = nullptr;
+  LF_HIP(ctx, hipMalloc((void**)&S.lights, std::max<size_t>(lts.size() * sizeof(LfLight), 16)));
+  if (n_lights) LF_HIP(ctx, hipMemcpy(S.lights, lts.data(), lts.size() * sizeof(LfLight), hipMemcpyHostToDevice));
+  S.n_lights = n_lights;
+  S.n_soft_lights = soft;
+  return LF_OK;
+}
+
+lf_status lf_set_light_samples(lf_ctx* ctx, int ns_area_light) {
+  if (!ctx || ns_area_light < 1) return LF_ERR_INVALID;
+  ctx->ns_area_light = ns_area_light;
   return LF_OK;
 }
 
@@ -416,6 +496,10 @@ lf_status lf_render_scene_term(lf_ctx* ctx) {
   if (ctx->W == 0) return lf_fail(ctx, LF_ERR_STATE, "lf_render_scene_term before lf_set_frame");
   if (!ctx->scene_valid) return lf_fail(ctx, LF_ERR_STATE, "lf_render_scene_term before lf_set_scene");
   if (!ctx->cam_valid) return lf_fail(ctx, LF_ERR_STATE, "lf_render_scene_term before lf_set_camera");
+  if (ctx->jitter_mode == 0 && ctx->scene_dev.n_soft_lights > 0)
+    return lf_fail(ctx, LF_ERR_INVALID,
+                   "MT19937 parity mode cannot serve area / hemisphere lights: the reference samples them from "
+                   "its shared generator in hit order (use lf_set_jitter_counter)");
   if (ctx->jitter_mode == 0) {
     if (!ctx->jitter_table_valid || !ctx->jitter_aa_raw || ctx->jitter_aa_ns != ctx->ns_aa)
       return lf_fail(ctx, LF_ERR_STATE, "MT19937 jitter: call lf_set_jitter_mt19937 after lf_set_params");
@@ -434,7 +518,7 @@ lf_status lf_render_scene_term(lf_ctx* ctx) {
   if (px == 0) return LF_OK;
   hipLaunchKernelGGL(k_scene_term, dim3((unsigned)((px + 255) / 256)), dim3(256), 0, ctx->stream,
                      ctx->scene_dev, ctx->cam, ctx->W, ctx->H, ctx->y0, ctx->y1, ctx->ns_aa,
-                     ctx->samples_per_batch, ctx->max_tolerance, ctx->jitter_aa_raw, ctx->jitter_mode,
+                     ctx->ns_area_light, ctx->samples_per_batch, ctx->max_tolerance, ctx->jitter_aa_raw, ctx->jitter_mode,
                      ctx->jitter_key, ctx->scene);
   LF_HIP(ctx, hipGetLastError());
   return LF_OK;

@@ -18,6 +18,7 @@
 // The integrator methods that are not on the flare path (estimate_direct_lighting_*, *_bounce_radiance,
 // autofocus) are not defined here: in the reference tree they stay where they are, in this build
 // nothing calls them.  No CPU fallback: without a device the constructor ends the program.
+#include <algorithm>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -90,13 +91,12 @@ void upload_scene(DeviceState& s, PathTracer* pt) {
     if (dynamic_cast<EmissionBSDF*>(b)) {
       Vector3D e = b->get_emission();
       kind = 1; rgb[0] = e.x; rgb[1] = e.y; rgb[2] = e.z;
-    } else if (dynamic_cast<DiffuseBSDF*>(b)) {
-      Vector3D f = b->f(Vector3D(0, 0, 1), Vector3D(0, 0, 1));   // = reflectance / pi, any directions
-      kind = 2; rgb[0] = f.x; rgb[1] = f.y; rgb[2] = f.z;
     } else {
-      fprintf(stderr, "[PathTracer/MI355X] a surface uses a mirror / glass / microfacet BSDF "
-                      "(unfilled stubs in the reference, advanced_bsdf.cpp): not rendered\n");
-      exit(1);
+      // every other BSDF through its public f(): the diffuse one returns reflectance / pi whatever the
+      // directions (bsdf.cpp:52-60); the Mirror / Refraction / Glass / Microfacet stubs return 0
+      // (advanced_bsdf.cpp:17-133), i.e. under this integrator they are black occluders
+      Vector3D f = b->f(Vector3D(0, 0, 1), Vector3D(0, 0, 1));
+      kind = 2; rgb[0] = f.x; rgb[1] = f.y; rgb[2] = f.z;
     }
     const int id = (int)(mats.size() / 4);
     mats.insert(mats.end(), {kind, rgb[0], rgb[1], rgb[2]});
@@ -115,21 +115,25 @@ void upload_scene(DeviceState& s, PathTracer* pt) {
         tri_m.push_back(material(t->get_bsdf()));
       }
     }
+  // scene->lights in order, in the general row form of lf_set_scene_lights
   for (SceneLight* l : pt->scene->lights) {
-    if (DirectionalLight* d = dynamic_cast<DirectionalLight*>(l))
-      lights.insert(lights.end(), {0.0, d->dirToLight.x, d->dirToLight.y, d->dirToLight.z, d->radiance.x,
-                                   d->radiance.y, d->radiance.z});
-    else if (PointLight* p = dynamic_cast<PointLight*>(l))
-      lights.insert(lights.end(), {1.0, p->position.x, p->position.y, p->position.z, p->radiance.x,
-                                   p->radiance.y, p->radiance.z});
-    else {
-      fprintf(stderr, "[PathTracer/MI355X] light type not supported by the device scene term\n");
+    double row[16] = {0};
+    auto put = [&](int at, const Vector3D& v) { row[at] = v.x; row[at + 1] = v.y; row[at + 2] = v.z; };
+    if (DirectionalLight* d = dynamic_cast<DirectionalLight*>(l)) { row[0] = 0; put(1, d->radiance); put(4, d->dirToLight); }
+    else if (PointLight* p = dynamic_cast<PointLight*>(l)) { row[0] = 1; put(1, p->radiance); put(4, p->position); }
+    else if (InfiniteHemisphereLight* h = dynamic_cast<InfiniteHemisphereLight*>(l)) { row[0] = 2; put(1, h->radiance); }
+    else if (AreaLight* a = dynamic_cast<AreaLight*>(l)) {
+      row[0] = 3; put(1, a->radiance); put(4, a->position); put(7, a->direction); put(10, a->dim_x); put(13, a->dim_y);
+    } else {
+      fprintf(stderr, "[PathTracer/MI355X] spot / sphere / mesh lights are stubs in the reference (light.cpp): not rendered\n");
       exit(1);
     }
+    lights.insert(lights.end(), row, row + 16);
   }
   check(s, lf_set_scene(s.ctx, (int)sph_m.size(), sph.data(), sph_m.data(), (int)tri_m.size(), tp.data(),
-                        tn.data(), tri_m.data(), (int)(mats.size() / 4), mats.data(),
-                        (int)(lights.size() / 7), lights.data()), "lf_set_scene");
+                        tn.data(), tri_m.data(), (int)(mats.size() / 4), mats.data(), 0, nullptr), "lf_set_scene");
+  check(s, lf_set_scene_lights(s.ctx, (int)(lights.size() / 16), lights.data()), "lf_set_scene_lights");
+  check(s, lf_set_light_samples(s.ctx, (int)std::max<size_t>(1, pt->ns_area_light)), "lf_set_light_samples");
   s.scene_of = pt->scene;
 }
 

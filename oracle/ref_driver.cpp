@@ -162,6 +162,7 @@ static int cmd_frame(int argc, char** argv) {
   //   sphere cx cy cz r  d|e  a b c          (diffuse reflectance or emitted radiance)
   //   tri  9 x vertex coords  9 x vertex normals  d|e  a b c
   //   point px py pz  Lr Lg Lb
+  //   area  pos(3) dir(3) dim_x(3) dim_y(3)  Lr Lg Lb ;  hemi Lr Lg Lb   (sampled lights, REF_NS_AREA_LIGHT each)
   std::string scenefile = argc > a ? argv[a++] : "";
   if (!scenefile.empty()) {
     std::ifstream sf(scenefile);
@@ -171,6 +172,7 @@ static int cmd_frame(int argc, char** argv) {
         double cx, cy, cz, rr, c0, c1, c2; std::string mk;
         sf >> cx >> cy >> cz >> rr >> mk >> c0 >> c1 >> c2;
         BSDF* b = mk == "e" ? (BSDF*)new EmissionBSDF(Vector3D(c0, c1, c2))
+                : mk == "m" ? (BSDF*)new MirrorBSDF(Vector3D(c0, c1, c2))   // one of the stub BSDFs
                             : (BSDF*)new DiffuseBSDF(Vector3D(c0, c1, c2));
         SphereObject* so = new SphereObject(Vector3D(cx, cy, cz), rr, b);
         objs.push_back(so);
@@ -199,6 +201,16 @@ static int cmd_frame(int argc, char** argv) {
         double px, py, pz, l0, l1, l2;
         sf >> px >> py >> pz >> l0 >> l1 >> l2;
         lights.push_back(new PointLight(Vector3D(l0, l1, l2), Vector3D(px, py, pz)));
+      } else if (kind == "area") {   // area  pos(3) dir(3) dim_x(3) dim_y(3)  radiance(3)
+        double v[15];
+        for (int k = 0; k < 15; k++) sf >> v[k];
+        lights.push_back(new AreaLight(Vector3D(v[12], v[13], v[14]), Vector3D(v[0], v[1], v[2]),
+                                       Vector3D(v[3], v[4], v[5]), Vector3D(v[6], v[7], v[8]),
+                                       Vector3D(v[9], v[10], v[11])));
+      } else if (kind == "hemi") {   // hemi  radiance(3)
+        double l0, l1, l2;
+        sf >> l0 >> l1 >> l2;
+        lights.push_back(new InfiniteHemisphereLight(Vector3D(l0, l1, l2)));
       }
     }
   }
@@ -208,7 +220,7 @@ static int cmd_frame(int argc, char** argv) {
   PathTracer pt;
   pt.ns_aa = ns_aa;
   pt.max_ray_depth = 1;
-  pt.ns_area_light = 1;
+  pt.ns_area_light = getenv("REF_NS_AREA_LIGHT") ? strtoul(getenv("REF_NS_AREA_LIGHT"), 0, 10) : 1;   // the -l flag
   pt.ns_diff = pt.ns_glsy = pt.ns_refr = 1;
   pt.samplesPerBatch = 32;
   pt.maxTolerance = 0.05;

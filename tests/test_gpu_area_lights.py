@@ -1,0 +1,163 @@
+"""Sampled lights of the scene term on the device: AreaLight and
+InfiniteHemisphereLight through estimate_direct_lighting_importance with ns_area_light samples
+(pathtracer.cpp:143-213, light.cpp:35-48, :82-101).  The reference samples them from its shared
+std::mt19937 in hit order, which no parallel schedule reproduces, so parity here is STATISTICAL: the
+REAL reference rendered each frame twice (ns_aa 256 and 255: all draws differ), which gives its own
+Monte-Carlo spread per pixel (oracle/make_golden_area.py); the device frame -- counter RNG, same
+estimator -- must sit inside that spread, pixel by pixel, with no systematic offset."""
+import json
+import os
+
+import numpy as np
+import pytest
+
+from goldenlib import GOLD, load_texels
+
+CASES = ["a48x36_cbspheres_area", "h48x36_cbspheres_hemisphere"]
+
+
+@pytest.fixture(scope="module")
+def pkg():
+    import __graft_entry__ as g
+    return g.load_package()
+
+
+def _box(a, k=2):
+    """(2k+1)^2 box mean with edge replication."""
+    p = np.pad(a, ((k, k), (k, k), (0, 0)), mode="edge")
+    out = np.zeros_like(a)
+    for dy in range(2 * k + 1):
+        for dx in range(2 * k + 1):
+            out += p[dy:dy + a.shape[0], dx:dx + a.shape[1]]
+    return out / (2 * k + 1) ** 2
+
+
+def _light_rows(m):
+    rows = []
+    for l in m["lights"]:                       # the sun: DirectionalLight, dirToLight = unit(posLight)
+        p = np.array(l[:3])
+        d = p / np.sqrt((p[0] * p[0] + p[1] * p[1]) + p[2] * p[2])
+        rows.append([0.0] + list(l[3:6]) + d.tolist() + [0.0] * 9)
+    for a in m["scene"]["area"]:                # pos dir dim_x dim_y radiance
+        rows.append([3.0] + list(a[12:15]) + list(a[0:12]))
+    for h in m["scene"]["hemi"]:
+        rows.append([2.0] + list(h) + [0.0] * 12)
+    return rows
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", CASES)
+def test_sampled_lights_within_the_references_own_spread(pkg, name):
+    z = np.load(os.path.join(GOLD, name + ".npz"))
+    m = json.loads(bytes(z["meta"]).decode())
+    a, b = z["sample_a"], z["sample_b"]
+    W, H = m["W"], m["H"]
+    lf = pkg.LensFlare(0)
+    lf.set_frame(W, H)
+    lf.set_params(m["ns_aa_a"], m["flare_radius"], m["flare_intensity"])
+    lf.set_sampling(32, 0.05, 0.01, 100.0)   # the reference's adaptive early-out, the same rule on both sides
+    lf.set_paraxial_lens()
+    lf.set_aperture(pkg.APERTURE_STARBURST, load_texels(m["aperture"]))
+    lf.set_aperture(pkg.APERTURE_GHOST, load_texels(m["ghost_aperture"]))
+    lf.set_flares(np.zeros((0, 2)), np.zeros((0, 3)), (0.0, 0.0), 0.0)
+    lf.set_camera(m["c2w"], m["cam_pos"], m["hFov"], m["vFov"])
+    lf.find_sun_pos(m["lights"])
+    sc = m["scene"]
+    spheres = [(1e4, 1e4, 1e4, 1.0, "d", 0.5, 0.5, 0.5)] + [tuple(s) for s in sc["spheres"]]
+    lf.set_scene(spheres, [tuple(t) for t in sc["tris"]], [])
+    lf.set_scene_lights(_light_rows(m))
+    lf.set_light_samples(m["ns_area_light"])
+    # the reference's stream cannot be reproduced for sampled lights: parity mode must refuse them
+    lf.set_jitter_mt19937(5489, None)
+    with pytest.raises(pkg.LensFlareError):
+        lf.render_scene_term()
+    lf.set_jitter_counter(2024)
+    lf.render_scene_term()
+    lf.generate_ghost_buffer()
+    lf.render_flare_layer()
+    got = lf.read_buffer(pkg.SAMPLE_BUFFER)
+    assert np.array_equal(lf.read_buffer(pkg.GHOST_BUFFER), z["ghost"])   # the flare part stays exact
+    lf.close()
+    _inside_reference_spread(got, a, b)
+
+
+def _inside_reference_spread(got, a, b):
+    # (both sides stop a pixel once its confidence interval is inside maxTolerance, pathtracer.cpp:862-868:
+    # most pixels take 32 or 64 of the 256 samples, which is the noise level the spread measures)
+    ref = 0.5 * (a + b)
+    var = _box((a - b) ** 2 / 2.0)                      # per-pixel variance of ONE reference frame, pooled 5x5
+    sigma = np.sqrt(var * 0.5 + var * 1.0) + 1e-4 * ref + 1e-9   # (mean of two frames) vs (one device frame)
+    zed = (got - ref) / sigma
+    lit = ref > 0.05 * np.median(ref)      # (the starburst peak next to the sun dwarfs everything: not max)
+    assert lit.mean() > 0.5
+    inside = np.abs(zed[lit]) < 3.5
+    assert inside.mean() > 0.985, inside.mean()
+    assert abs(np.median(zed[lit])) < 0.25, np.median(zed[lit])   # no systematic offset
+    # total light: the frame sum is dominated by a few bright, noisy pixels (the emitter's jittered
+    # edges), so its tolerance comes from the reference's own run-to-run difference as well:
+    # Var(sum(got) - sum(ref)) = 1.5 * sum of per-pixel variances, estimated by sum((a - b)^2) / 2
+    tot_sigma = np.sqrt(1.5 * ((a.sum(axis=2) - b.sum(axis=2)) ** 2).sum() / 2.0)
+    assert abs(got.sum() - ref.sum()) < 4.0 * tot_sigma, (got.sum() - ref.sum(), tot_sigma)
+    # the spread test has teeth: leaving out the sampled light moves the frame far outside it
+    assert np.abs(a - b)[lit].mean() / ref[lit].mean() < 0.03
+
+
+@pytest.mark.gpu
+def test_drop_in_binary_renders_the_area_light_scene(pkg, tmp_path):
+    """The reference's own objects with pathtracer.o replaced (oracle/_ref/ref_dump_amd, see
+    test_gpu_dropin.py) on the Cornell box with its AreaLight: scene->lights walked by the drop-in,
+    ns_area_light from the PathTracer field, counter RNG -- inside the reference's own spread."""
+    import math
+    import subprocess
+    binary = os.path.join(os.path.dirname(GOLD), "..", "oracle", "_ref", "ref_dump_amd")
+    assert os.path.exists(binary), "oracle/_ref/ref_dump_amd is missing: make -C oracle dropin (build container)"
+    name = CASES[0]
+    z = np.load(os.path.join(GOLD, name + ".npz"))
+    m = json.loads(bytes(z["meta"]).decode())
+    W, H = m["W"], m["H"]
+    cam = tmp_path / "cam.txt"
+    sd = H / (2 * math.tan(math.radians(m["vFov"]) / 2))
+    with open(cam, "w") as f:
+        f.write(f"{m['hFov']!r} {m['vFov']!r} {W / H!r} 0.01 100\n")
+        f.write(" ".join(repr(float(v)) for v in m["cam_pos"]) + " 0 0 0\n1.5 0.7 5 0.5 100\n")
+        f.write(" ".join(repr(float(v)) for v in m["c2w"]) + f"\n{W} {H} {sd!r}\n4.7 0\n")
+    num = lambda v: v if isinstance(v, str) else repr(float(v))  # noqa: E731
+    with open(tmp_path / "scene.txt", "w") as f:
+        for s in m["scene"]["spheres"]:
+            f.write("sphere " + " ".join(num(v) for v in s) + "\n")
+        for t in m["scene"]["tris"]:
+            f.write("tri " + " ".join(num(v) for v in t) + "\n")
+        for a in m["scene"]["area"]:
+            f.write("area " + " ".join(num(v) for v in a) + "\n")
+    spec = ";".join(",".join(repr(float(v)) for v in l) for l in m["lights"])
+    env = dict(os.environ, LF_COUNTER_JITTER="1", REF_NS_AREA_LIGHT=str(m["ns_area_light"]))
+    r = subprocess.run([binary, "frame", str(cam), str(W), str(H), str(m["ns_aa_a"]), "25.0", "1.0",
+                        os.path.join(GOLD, "apertures", m["aperture"]), os.path.join(GOLD, "apertures", m["ghost_aperture"]),
+                        spec, "tiles", str(tmp_path / "o"), str(tmp_path / "scene.txt")], env=env,
+                       capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr[-2000:]
+    got = np.fromfile(str(tmp_path / "o") + ".sample.f64").reshape(H, W, 3)
+    ghost = np.fromfile(str(tmp_path / "o") + ".ghost.f64").reshape(H, W, 3)
+    assert np.array_equal(ghost, z["ghost"])
+    _inside_reference_spread(got, z["sample_a"], z["sample_b"])
+
+
+def test_collada_scenes_with_area_and_ambient_lights_are_accepted(pkg):
+    """lf_collada_check (no device): every scene file the reference ships is renderable -- the Cornell
+    boxes and the keenan models with their area lights, the ambient-lit scenes, and the scenes whose
+    mirror / glass / microfacet BSDFs are unfilled stubs in the reference (f() = 0: black occluders
+    under its direct-lighting integrator, uploaded as exactly that)."""
+    gold = os.path.join(GOLD, "collada")
+    for f in ("CBspheres_lambertian.dae", "CBempty.dae", "pyramid.dae", "CBgems.dae"):
+        assert pkg.collada_check(os.path.join(gold, f)) is None, f
+    assert pkg.collada_check(os.path.join(gold, "no_such_file.dae")) is not None
+    ref = "/root/reference/dae"
+    if not os.path.isdir(ref):
+        return          # the GPU box has no reference checkout: the committed files above are the check
+    n = 0
+    for root, _, files in os.walk(ref):
+        for f in sorted(files):
+            if f.endswith(".dae"):
+                assert pkg.collada_check(os.path.join(root, f)) is None, f
+                n += 1
+    assert n == 21      # every scene file the reference ships

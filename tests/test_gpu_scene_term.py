@@ -109,8 +109,9 @@ def test_collada_file_end_to_end(pkg, lf):
     scene = case.sample - case.ghost - lf.read_buffer(pkg.STARBURST_BUFFER)
     assert (scene.max(axis=-1) > 0.02).mean() > 0.25     # the pyramids fill a good part of the frame
     assert np.array_equal(lf.write_to_framebuffer(0, 0, case.W, case.H), case.rgba)
-    with pytest.raises(pkg.LensFlareError):              # glass BSDFs: refused, not approximated
-        lf.load_collada(os.path.join(os.path.dirname(dae), "CBgems.dae"))
+    # glass BSDFs are unfilled stubs in the reference (f() = 0): black occluders, loaded as such
+    cam2, _ = lf.load_collada(os.path.join(os.path.dirname(dae), "CBgems.dae"))
+    assert cam2 is not None
 
 
 def test_counter_jitter_converges_to_the_same_image(pkg, lf):
