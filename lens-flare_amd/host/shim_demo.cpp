@@ -7,6 +7,8 @@
 // case.txt: W H ns_aa flare_radius flare_intensity hFov vFov  pos(3)  c2w(9)  aw ah gw gh
 //           n_lights  then n_lights x (posLight xyz, radiance rgb)
 #include <cstdio>
+#include <cstdlib>
+#include <string>
 #include <fstream>
 #include <thread>
 #include <vector>
@@ -30,7 +32,75 @@ static void dump(const std::string& path, const T* p, size_t n) {
   fclose(f);
 }
 
+// shim_demo geo <lens.txt> <mask.f32> <mw> <mh> <W> <H> <spp> <sun x y z> <angular radius> <outprefix>
+// lens.txt: n stop n_lambda sensor_w, then n rows {radius thickness semi_aperture ior[0..n_lambda)}
+// The north star's plug-in surface through the C++ mirror: PathTracer::use_geometric_ghosts +
+// generate_ghost_buffer (the geometric march fills ghost_buffer) and LensCamera::generate_rays
+// (camera rays that really went through the prescription).
+static int geo_main(int argc, char** argv) {
+  if (argc < 14) return 1;
+  std::ifstream in(argv[2]);
+  int n, stop, nl;
+  float sensor_w;
+  in >> n >> stop >> nl >> sensor_w;
+  std::vector<float> radius(n), thick(n), semi(n), ior((size_t)n * nl);
+  for (int k = 0; k < n; k++) {
+    in >> radius[k] >> thick[k] >> semi[k];
+    for (int l = 0; l < nl; l++) in >> ior[(size_t)l * n + k];
+  }
+  const size_t mw = atoi(argv[4]), mh = atoi(argv[5]), W = atoi(argv[6]), H = atoi(argv[7]);
+  const int spp = atoi(argv[8]);
+  const float sun[3] = {(float)atof(argv[9]), (float)atof(argv[10]), (float)atof(argv[11])};
+  const float alpha = (float)atof(argv[12]);
+  const std::string out = argv[13];
+  try {
+    PathTracer pt(0);
+    Camera cam;
+    CameraApertureTexture ap;
+    ap.init_from_texels(read_f32(argv[3], mw * mh).data(), mw, mh);
+    cam.aperture_texture = &ap;
+    cam.ghost_aperture_texture = &ap;
+    pt.clear();
+    pt.set_frame_size(W, H);
+    pt.camera = &cam;
+    pt.counter_jitter = true;
+    pt.flare_radiance.emplace_back(1.0, 0.9, 0.5);       // the radiance the march takes for the sun
+    pt.flare_origins.emplace_back(0.5, 0.5);
+    pt.axis_ray = Vector2D(0.5, 0.5);
+    pt.use_geometric_ghosts(n, stop, nl, radius.data(), thick.data(), ior.data(), semi.data(), sensor_w, sun,
+                            alpha, spp);
+    pt.generate_ghost_buffer();
+    dump(out + ".ghost.f64", &pt.ghost_buffer.data[0].x, W * H * 3);
+    // LensCamera: a grid of sensor positions x pupil samples
+    LensCamera lc(&pt, sensor_w, sensor_w * (float)H / (float)W);
+    std::vector<double> q;
+    for (int i = 0; i < 16; i++)
+      for (int j = 0; j < 16; j++) {
+        q.push_back(0.1 + 0.8 * i / 15.0); q.push_back(0.1 + 0.8 * j / 15.0);
+        q.push_back(0.05 + 0.9 * ((i * 7 + j * 3) % 16) / 15.0); q.push_back(0.05 + 0.9 * ((i * 5 + j * 11) % 16) / 15.0);
+      }
+    std::vector<Ray> rays;
+    std::vector<double> w;
+    lc.generate_rays(q.size() / 4, q.data(), &rays, &w, nl / 2);
+    std::vector<double> flat;
+    for (size_t i = 0; i < rays.size(); i++)
+      flat.insert(flat.end(), {rays[i].o.x, rays[i].o.y, rays[i].o.z, rays[i].d.x, rays[i].d.y, rays[i].d.z, w[i],
+                               (double)rays[i].depth});
+    dump(out + ".rays.f64", flat.data(), flat.size());
+    dump(out + ".query.f64", q.data(), q.size());
+    Ray one;
+    double w1 = 0;
+    const bool alive = lc.generate_ray(0.5, 0.5, 0.5, 0.5, &one, &w1, nl / 2);   // the chief ray
+    printf("chief ray alive=%d d=(%g, %g, %g) w=%g\n", (int)alive, one.d.x, one.d.y, one.d.z, w1);
+  } catch (const std::exception& e) {
+    fprintf(stderr, "shim_demo geo: %s\n", e.what());
+    return 3;
+  }
+  return 0;
+}
+
 int main(int argc, char** argv) {
+  if (argc > 1 && std::string(argv[1]) == "geo") return geo_main(argc, argv);
   if (argc < 5) return 1;
   std::ifstream in(argv[1]);
   size_t W, H, ns_aa, aw, ah, gw, gh, n_lights;

@@ -1,0 +1,155 @@
+"""BASELINE.json's configurations as whole frames through the C ABI ("configs only
+exercised in pieces"): C5 = 8-wavelength march + spectral starburst composed in ONE frame (small
+size against the oracles, 4K x 1 spp by properties); C3 at its full 1080p x 256 spp (properties + a
+row crop bit for bit against the oracle)."""
+import math
+
+import numpy as np
+import pytest
+
+from goldenlib import load_red, load_texels
+from oracle import lfo
+
+pytestmark = pytest.mark.gpu
+SUN_NS = (0.521445, 0.517156)
+
+
+@pytest.fixture(scope="module")
+def pkg():
+    import __graft_entry__ as g
+    return g.load_package()
+
+
+@pytest.fixture(scope="module")
+def lf(pkg):
+    ctx = pkg.LensFlare(0)
+    lfo.geo_set_sqrt_table(lfo.sqrt_deviation_table(ctx.native_sqrt))
+    yield ctx
+    lfo.geo_set_sqrt_table(None)
+    ctx.close()
+
+
+def _lens8(pkg):
+    lens3 = pkg.load_lens_file("dgauss11.lens")
+    t = np.linspace(0.0, 2.0, 8)
+    ior8 = np.stack([np.array([np.interp(tt, [0, 1, 2], lens3["ior"][:, k]) for k in range(lens3["n"])])
+                     for tt in t]).astype(np.float32)
+    w8 = np.zeros((8, 3), np.float32)
+    for l, tt in enumerate(t):
+        for c in range(3):
+            w8[l, c] = max(0.0, 1.0 - abs(tt - c)) / 2.6666667
+    scale = 588.0 / np.interp(t, [0, 1, 2], [656.0, 588.0, 486.0])
+    return dict(lens3, ior=ior8), w8, scale
+
+
+def _c5_setup(pkg, lf, W, H, mask_name="pentbig500_14.png"):
+    lens8, w8, scale = _lens8(pkg)
+    efl = pkg.paraxial_efl(lens8)
+    hf = 2 * math.degrees(math.atan(0.5 * lens8["sensor_width_mm"] / efl))
+    vf = 2 * math.degrees(math.atan(math.tan(math.radians(hf) / 2) * H / W))
+    lf.set_frame(W, H)
+    lf.set_params(1, 25.0, 1.0)
+    mask = load_texels(mask_name)
+    lf.set_aperture(pkg.APERTURE_STARBURST, mask)
+    lf.set_aperture(pkg.APERTURE_GHOST, mask)
+    lf.set_lens(lens8)
+    lf.set_lambda_rgb(w8)
+    lf.set_ghost_pairs(None, True)
+    lf.set_starburst_spectrum(scale, w8)
+    lf.set_scene_term(None)
+    lf.set_jitter_counter(0x1e45f1a4e)
+    lf.set_camera(np.eye(3), [0, 0, 0], hf, vf)
+    ex, ey = math.tan(math.radians(hf) / 2), math.tan(math.radians(vf) / 2)
+    light = [(2 * SUN_NS[0] - 1) * ex * 10, (2 * SUN_NS[1] - 1) * ey * 10, -10.0, 1.0, 0.9, 0.5]
+    return lens8, w8, scale, mask, efl, hf, vf, light
+
+
+def test_c5_one_frame_small(pkg, lf):
+    """C5 at 96x54, 16 spp: ghost buffer = the 8-wavelength march, bit for bit against the oracle;
+    starburst = the per-wavelength pattern against the oracle's restatement; sensor = their sum."""
+    W, H, spp, key = 96, 54, 16, 0xC5
+    lens8, w8, scale, mask, efl, hf, vf, light = _c5_setup(pkg, lf, W, H)
+    lf.find_sun_pos([light])
+    lf.set_sun_from_flares(0, efl, 0.05)
+    lf.reset_counters()
+    lf.trace_ghosts(spp, key)
+    lf.render_flare_layer()
+    ghost, star, sample = (lf.read_buffer(b) for b in (pkg.GHOST_BUFFER, pkg.STARBURST_BUFFER, pkg.SAMPLE_BUFFER))
+    cnt = lf.counters()
+    sun = [(SUN_NS[0] - 0.5) * lens8["sensor_width_mm"] / efl, (SUN_NS[1] - 0.5) * lens8["sensor_width_mm"] * H / W / efl, -1.0]
+    og, ocnt = lfo.geo_trace(lens8, W, H, 0, H, spp, key, None, True, mask, sun, [1.0, 0.9, 0.5], 0.05, lambda_rgb=w8)
+    assert cnt == ocnt and cnt["rays_launched"] == W * H * spp * 8 * 46
+    assert np.array_equal(ghost, og) and og.max() > 0
+    assert np.array_equal(sample, ghost + star)         # (scene + ghost) + starburst, no scene term
+    # the spectral starburst against the oracle (falloff included in both: compare the spectral part)
+    f = lfo.make_frame(W, H, ns_aa=1, flare_radius=25.0, flare_intensity=1.0)
+    lfo.find_sun_pos(np.eye(3), [0, 0, 0], hf, vf, [light], f)
+    tex, st = lfo.aperture_from_red(load_red("pentbig500_14.png"))
+    lf.set_starburst_spectrum(None)
+    lf.render_flare_layer()
+    mono = lf.read_buffer(pkg.STARBURST_BUFFER)
+    rng = np.random.default_rng(5)
+    for x, y in zip(rng.integers(0, W, 60), rng.integers(0, H, 60)):
+        o_mono, _ = lfo.starburst_pixel(f, tex, st, int(x), int(y))
+        o_spec = lfo.starburst_pixel_spectral(f, tex, st, int(x), int(y), scale, w8)
+        tol = 1e-9 * np.maximum(np.abs(o_spec), np.abs(o_mono)) + 1e-13 * np.abs(mono[y, x])
+        assert np.all(np.abs((star[y, x] - mono[y, x]) - (o_spec - o_mono)) <= tol), (x, y)
+
+
+def test_c5_whole_4k_frame_properties(pkg, lf):
+    """C5's frame size with 8 wavelengths + spectral starburst, 1 spp: exact ray budget, every ray
+    accounted for, sensor = ghost + starburst on a window, identical when rendered twice, and the
+    first 16 rows bit for bit against the oracle."""
+    W, H, spp, key = 3840, 2160, 1, 0x5C
+    lens8, w8, scale, mask, efl, hf, vf, light = _c5_setup(pkg, lf, W, H)
+    lf.find_sun_pos([light])
+    lf.set_sun_from_flares(0, efl, 0.05)
+    lf.reset_counters()
+    lf.trace_ghosts(spp, key)
+    lf.render_flare_layer()
+    cnt = lf.counters()
+    assert cnt["rays_launched"] == W * H * spp * 8 * 46
+    assert cnt["rays_launched"] == cnt["rays_clipped_stop"] + cnt["rays_vignetted"] + cnt["rays_tir"] + cnt["rays_reached_scene"]
+    assert cnt["rays_hit_light"] > 0
+    x0, y0 = int(SUN_NS[0] * W) - 256, int(SUN_NS[1] * H) - 128
+    g1, s1, a1 = (lf.read_tile(b, x0, y0, x0 + 512, y0 + 256) for b in (pkg.GHOST_BUFFER, pkg.STARBURST_BUFFER, pkg.SAMPLE_BUFFER))
+    assert np.array_equal(a1, g1 + s1) and g1.max() > 0 and s1.max() > 0
+    top = lf.read_tile(pkg.GHOST_BUFFER, 0, 0, W, 16)
+    lf.trace_ghosts(spp, key)
+    lf.render_flare_layer()
+    assert np.array_equal(lf.read_tile(pkg.SAMPLE_BUFFER, x0, y0, x0 + 512, y0 + 256), a1)
+    sun = [(SUN_NS[0] - 0.5) * lens8["sensor_width_mm"] / efl, (SUN_NS[1] - 0.5) * lens8["sensor_width_mm"] * H / W / efl, -1.0]
+    og, _ = lfo.geo_trace(lens8, W, H, 0, 16, spp, key, None, True, mask, sun, [1.0, 0.9, 0.5], 0.05,
+                          n_threads=16, lambda_rgb=w8)
+    assert np.array_equal(top, og[:16])
+
+
+def test_c3_full_spp_frame(pkg, lf):
+    """The benchmark frame itself (1080p, 256 spp, primary + 45 pairs x 3 wavelengths): exact ray
+    budget, every ray accounted for, the executed-event counter below the per-path one by the
+    shared-leg factor, identical when rendered twice, and an 8-row tile row around the sun bit for bit
+    against the oracle (5e8 rays on the host's cores)."""
+    W, H, spp, key = 1920, 1080, 256, 0x1e45f1a4e
+    lens = pkg.load_lens_file("dgauss11.lens")
+    mask = load_texels("pentbig500_14.png")
+    efl = pkg.paraxial_efl(lens)
+    sun = [(SUN_NS[0] - 0.5) * lens["sensor_width_mm"] / efl, (SUN_NS[1] - 0.5) * lens["sensor_width_mm"] * H / W / efl, -1.0]
+    lf.set_frame(W, H)
+    lf.set_aperture(pkg.APERTURE_STARBURST, mask)
+    lf.set_lens(lens)
+    lf.set_sun(sun, [1.0, 0.9, 0.5], 0.05)
+    lf.set_ghost_pairs(None, True)
+    lf.reset_counters()
+    lf.trace_ghosts(spp, key)
+    cnt = lf.counters()
+    executed = lf.executed_events()
+    assert cnt["rays_launched"] == W * H * spp * 3 * 46
+    assert cnt["rays_launched"] == cnt["rays_clipped_stop"] + cnt["rays_vignetted"] + cnt["rays_tir"] + cnt["rays_reached_scene"]
+    assert 3.0 < cnt["surface_events"] / executed < 5.0      # the path tree computes shared legs once
+    y0 = (int(SUN_NS[1] * H) // 8) * 8
+    band = lf.read_tile(pkg.GHOST_BUFFER, 0, y0, W, y0 + 8)
+    lf.trace_ghosts(spp, key)
+    assert np.array_equal(lf.read_tile(pkg.GHOST_BUFFER, 0, y0, W, y0 + 8), band)
+    og, _ = lfo.geo_trace(lens, W, H, y0, y0 + 8, spp, key, None, True, mask, sun, [1.0, 0.9, 0.5], 0.05,
+                          n_threads=16)
+    assert np.array_equal(band, og[y0:y0 + 8]) and band.max() > 0

@@ -48,3 +48,73 @@ def test_cpp_shim_matches_reference(name, tmp_path):
     assert err.max() <= 1e-9
     rgba = np.fromfile(out + ".rgba.u32", np.uint32).reshape(case.H, case.W)
     assert np.array_equal(rgba, case.rgba)
+
+
+def test_cpp_shim_geometric_ghosts_and_lens_camera(tmp_path):
+    """The north star's plug-in surface through the C++ mirror (lens-flare_amd/host): PathTracer::
+    use_geometric_ghosts + generate_ghost_buffer must fill ghost_buffer with exactly what the C ABI's
+    march produces (and therefore what the oracle computes, bit for bit), and LensCamera::generate_rays
+    must return the rays of lf_generate_lens_rays rotated into the camera's frame (identity here),
+    checked against the oracle's single-ray trace."""
+    import __graft_entry__ as g
+    from oracle import lfo
+    pkg = g.load_package()
+    assert os.path.exists(DEMO), "run __graft_entry__.build() first"
+    lens = pkg.load_lens_file("dgauss11.lens")
+    mask = load_texels("pentbig500_14.png")
+    mask.tofile(tmp_path / "mask.f32")
+    n, nl = lens["n"], lens["ior"].shape[0]
+    with open(tmp_path / "lens.txt", "w") as f:
+        f.write(f"{n} {lens['stop']} {nl} {lens['sensor_width_mm']!r}\n")
+        for k in range(n):
+            row = [lens["radius"][k], lens["thickness"][k], lens["semi_aperture"][k]] + [lens["ior"][l, k] for l in range(nl)]
+            f.write(" ".join(repr(float(v)) for v in row) + "\n")
+    W, H, spp = 48, 32, 16
+    sun = [0.03, 0.02, -1.0]
+    out = str(tmp_path / "g")
+    r = subprocess.run([DEMO, "geo", str(tmp_path / "lens.txt"), str(tmp_path / "mask.f32"), str(mask.shape[1]),
+                        str(mask.shape[0]), str(W), str(H), str(spp)] + [repr(v) for v in sun] + ["0.05", out],
+                       capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    assert "chief ray alive=1" in r.stdout
+    ghost = np.fromfile(out + ".ghost.f64", np.float64).reshape(H, W, 3)
+    lf = pkg.LensFlare(0)
+    lfo.geo_set_sqrt_table(lfo.sqrt_deviation_table(lf.native_sqrt))
+    try:
+        og, _ = lfo.geo_trace(lens, W, H, 0, H, spp, 0x1e45f1a4e, None, True, mask, sun, [1.0, 0.9, 0.5], 0.05)
+        assert np.array_equal(ghost, og) and og.max() > 0
+        # LensCamera::generate_rays
+        q = np.fromfile(out + ".query.f64", np.float64).reshape(-1, 4)
+        rays = np.fromfile(out + ".rays.f64", np.float64).reshape(-1, 8)
+        sw, sh = lens["sensor_width_mm"], lens["sensor_width_mm"] * H / W
+        lf.set_frame(W, H)
+        lf.set_aperture(pkg.APERTURE_STARBURST, mask)
+        lf.set_lens(lens)
+        xy = np.stack([-(q[:, 0] - 0.5) * sw, -(q[:, 1] - 0.5) * sh], 1).astype(np.float32)
+        uv = (2.0 * q[:, 2:4] - 1.0).astype(np.float32)
+        want = lf.generate_lens_rays(nl // 2, xy, uv)
+        assert np.array_equal(rays[:, 7] != 0, want[:, 7] != 0) and (want[:, 7] != 0).sum() > 40
+        alive = want[:, 7] != 0
+        assert np.allclose(rays[alive, :6], want[alive, :6].astype(np.float64), atol=1e-12)
+        assert np.allclose(rays[alive, 6], want[alive, 6].astype(np.float64), atol=1e-12)
+        # ... and each alive ray leaves the front element along the oracle's ray for the same start
+        zs = lfo.geo_z_sensor(lens)
+        pupil_h, pupil_z = float(lens["semi_aperture"][-1]), zs - float(lens["thickness"][-1])
+        checked = 0
+        for i in np.flatnonzero(alive)[:40]:
+            a, b = float(uv[i, 0]), float(uv[i, 1])
+            if abs(a) > abs(b):
+                th = (np.pi / 4) * (b / a); qx, qy = a * np.cos(th), a * np.sin(th)
+            else:
+                th = (np.pi / 4) * (a / b); qx, qy = b * np.sin(th), b * np.cos(th)
+            d = np.array([pupil_h * qx - xy[i, 0], pupil_h * qy - xy[i, 1], pupil_z - zs])
+            d /= np.linalg.norm(d)
+            st, p, dd, w, ne = lfo.geo_trace_ray(lens, nl // 2, -1, -1, [float(xy[i, 0]), float(xy[i, 1]), zs], d, mask=mask)
+            if st != 0:
+                continue
+            checked += 1
+            assert np.allclose(rays[i, 3:6], dd, atol=2e-5) and np.allclose(rays[i, 0:3], p, atol=2e-4)
+        assert checked > 10
+    finally:
+        lfo.geo_set_sqrt_table(None)
+        lf.close()
