@@ -321,7 +321,8 @@ lf_status lf_generate_lens_rays(lf_ctx* ctx, int lambda, size_t n, const float* 
  *   info   int[8 + 4 (LF_MAX_PAIRS + 1)]: {n_paths, flat rows per wavelength, first program row,
  *          program rows per wavelength, total rows, jump-table entries, 0, 0} then per path
  *          {i, j, first flat row, flat rows}
- *   rows   8 x 4 bytes per row: zv, curv, h2, eta, sgn (floats), flags (int), radius, eta^2 (floats);
+ *   rows   8 x 4 bytes per row: dzv (vertex z of the interface the ray comes from, or of the sensor,
+ *          minus this interface's), curv, h2, eta, sgn (floats), flags (int), radius, eta^2 (floats);
  *          n_lambda x flat sequences, then n_lambda x the path-tree program, then one spare row
  *   skip   one int per program row: (rows to jump << 2) | state to restore, for a wave that is dead
  * flags: 1 mirror, 2 stop, 4 flat, 8 restore slot 1 after END, 0x10 / 0x20 park in slot 0 / 1

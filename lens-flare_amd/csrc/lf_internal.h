@@ -133,7 +133,8 @@ struct LfPairsDev {
 // Two tables use it: the flat per-(wavelength, pair) sequences (n_lambda x total_events rows, read
 // only by the rare weight re-march) and the per-wavelength path-tree program (see LF_EV_SAVE0).
 struct alignas(32) LfEventRow {
-  float zv, curv, h2, eta;
+  float dzv;       // vertex z of the interface the ray comes from (or the sensor) minus this one's
+  float curv, h2, eta;
   float sgn;       // +1: the ray travels +z (towards the sensor), -1: -z
   int flags;       // bit 0: mirror reflection, bit 1: the stop, bit 2: flat (curv == 0)
   float radius;    // 1 / curv as given in the prescription (0 for flats)
@@ -143,7 +144,7 @@ enum { LF_EV_REFLECT = 1, LF_EV_STOP = 2, LF_EV_FLAT = 4 };
 // A program row as the device walks it: the interface once, the index ratios of the up to four
 // wavelengths that march it together (lf_march.hip, k_march<K>); one 64-byte scalar load.
 struct alignas(64) LfProgRow {
-  float zv, curv, h2, radius;
+  float dzv, curv, h2, radius;
   float sgn;
   int flags;        // as LfEventRow::flags of the per-wavelength program rows
   int skip;         // jump-table entry of this row: (rows to jump << 2) | state to restore

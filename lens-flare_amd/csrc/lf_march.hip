@@ -71,8 +71,14 @@ __device__ __forceinline__ float u01(unsigned r) { return (float)(r >> 8) * 5.96
 // The transmitted weight is carried as a fraction wn / wd: every Fresnel factor is a ratio of
 // two cheap products, so the march multiplies numerators and denominators separately and divides
 // ONCE, and only for the ~0.4 % of rays that end inside the sun's lobe.
+// Position: (px, py) and hz = z RELATIVE to the vertex of the interface the ray sits on (0 on the
+// sensor / the stop plane), plus r2 = px^2 + py^2 of that point, which the previous event's aperture
+// test has already computed and the next event's |o|^2 reuses.  A row carries dzv = (vertex z of the
+// interface the ray comes from) - (vertex z of this one): one add gives the origin's z in this
+// interface's frame, absolute z never exists (3 vector instructions per event less than tracking it,
+// and less cancellation).
 struct Ray {
-  float px, py, pz, dx, dy, dz, wn, wd;
+  float px, py, hz, r2, dx, dy, dz, wn, wd;
 };
 
 // One glass-surface event, straight-line (no divergent branches): a lane that misses the surface,
@@ -91,12 +97,12 @@ typedef unsigned long long lanemask;
 // 0.4 % of the rays.  Both instantiations do the same arithmetic on the ray itself, so the
 // repeated march reproduces the first one bit for bit.
 template <bool W>
-__device__ __forceinline__ lanemask surface_event(Ray& r, float zv, float c, float rad, float h2,
+__device__ __forceinline__ lanemask surface_event(Ray& r, float dzv, float c, float rad, float h2,
                                                   float eta, float eta2, bool reflect, bool flat,
                                                   float sgn, lanemask& geom_ok) {
-  const float oz = r.pz - zv;
+  const float oz = r.hz + dzv;
   const float od = fmaf(r.px, r.dx, fmaf(r.py, r.dy, oz * r.dz));
-  const float oo = fmaf(r.px, r.px, fmaf(r.py, r.py, oz * oz));
+  const float oo = fmaf(oz, oz, r.r2);
   const float F = fmaf(c, oo, -2.0f * oz);
   const float G = fmaf(-c, od, r.dz);
   const float cF = c * F;
@@ -161,15 +167,15 @@ __device__ __forceinline__ lanemask surface_event(Ray& r, float zv, float c, flo
     r.dy = fmaf(eta, r.dy, -(gc * hy));
     r.dz = fmaf(eta, r.dz, fmaf(-gc, hz, g));
   }
-  r.px = hx; r.py = hy; r.pz = zv + hz;
+  r.px = hx; r.py = hy; r.hz = hz; r.r2 = r2;
   return ok;
 }
 
 // the stop: flat pass-through, clipped by its housing and by the aperture mask
 template <bool W>
-__device__ __forceinline__ lanemask stop_event(Ray& r, float zv, float h2, float inv_h,
+__device__ __forceinline__ lanemask stop_event(Ray& r, float dzv, float h2, float inv_h,
                                                const float* __restrict__ mask, int mw, int mh) {
-  const float t = __fdiv_rn(zv - r.pz, r.dz);
+  const float t = __fdiv_rn(-(r.hz + dzv), r.dz);
   const float hx = fmaf(t, r.dx, r.px), hy = fmaf(t, r.dy, r.py);
   const float r2 = fmaf(hx, hx, hy * hy);
   const float fu = fmaf(hx, inv_h, 1.0f) * (0.5f * (float)mw);
@@ -179,7 +185,7 @@ __device__ __forceinline__ lanemask stop_event(Ray& r, float zv, float h2, float
   iy = min(max(iy, 0), mh - 1);
   const float a = mask[iy * mw + ix];
   if (W) r.wn *= a;
-  r.px = hx; r.py = hy; r.pz = zv;
+  r.px = hx; r.py = hy; r.hz = 0.0f; r.r2 = r2;
   return __ballot(r2 <= h2) & __ballot(a > 0.0f);
 }
 
@@ -192,7 +198,7 @@ typedef const lf_i8 __attribute__((address_space(4))) * lf_const_row_ptr;
 __device__ __forceinline__ LfEventRow load_row(const LfEventRow* __restrict__ e) {
   const lf_i8 v = *(lf_const_row_ptr)(e);
   LfEventRow r;
-  r.zv = __int_as_float(v[0]); r.curv = __int_as_float(v[1]); r.h2 = __int_as_float(v[2]);
+  r.dzv = __int_as_float(v[0]); r.curv = __int_as_float(v[1]); r.h2 = __int_as_float(v[2]);
   r.eta = __int_as_float(v[3]); r.sgn = __int_as_float(v[4]); r.flags = v[5];
   r.radius = __int_as_float(v[6]); r.eta2 = __int_as_float(v[7]);
   return r;
@@ -202,12 +208,13 @@ __device__ __forceinline__ LfEventRow load_row(const LfEventRow* __restrict__ e)
 // wave of every SIMD
 __device__ __forceinline__ void park(float2* __restrict__ slot, int lane, const Ray& r) {
   slot[lane] = make_float2(r.px, r.py);          // [pair][lane]: 8-byte lane stride, conflict-free
-  slot[64 + lane] = make_float2(r.pz, r.dx);
+  slot[64 + lane] = make_float2(r.hz, r.dx);
   slot[128 + lane] = make_float2(r.dy, r.dz);
 }
 __device__ __forceinline__ void unpark(const float2* __restrict__ slot, int lane, Ray& r) {
   const float2 a = slot[lane], b = slot[64 + lane], c = slot[128 + lane];
-  r.px = a.x; r.py = a.y; r.pz = b.x; r.dx = b.y; r.dy = c.x; r.dz = c.y;
+  r.px = a.x; r.py = a.y; r.hz = b.x; r.dx = b.y; r.dy = c.x; r.dz = c.y;
+  r.r2 = fmaf(r.px, r.px, r.py * r.py);   // the same expression that produced it: the same bits
 }
 
 // The sun's lobe: q = (1 - cos theta) / (1 - cos alpha), theta between the ray and the sun.
@@ -249,7 +256,7 @@ typedef const lf_i16 __attribute__((address_space(4))) * lf_const_prow_ptr;
 __device__ __forceinline__ LfProgRow load_prow(const LfProgRow* __restrict__ e) {
   const lf_i16 v = *(lf_const_prow_ptr)(e);
   LfProgRow r;
-  r.zv = __int_as_float(v[0]); r.curv = __int_as_float(v[1]); r.h2 = __int_as_float(v[2]);
+  r.dzv = __int_as_float(v[0]); r.curv = __int_as_float(v[1]); r.h2 = __int_as_float(v[2]);
   r.radius = __int_as_float(v[3]); r.sgn = __int_as_float(v[4]); r.flags = v[5];
   r.skip = v[6]; r.pad1 = 0;
 #pragma unroll
@@ -284,8 +291,11 @@ void k_march(const LfLensDev* __restrict__ lens, const LfPairsDev* __restrict__ 
   __shared__ float2 s_state[4][K][3 * 64];
   // the start of the current sample's rays per lane (sensor point, direction, start weight): only
   // the rare weight re-march reads it back, so it need not occupy six registers during the walk
-  // (volatile: otherwise the compiler forwards the stores to the loads and keeps the registers)
-  __shared__ volatile float s_start[4][6][64];
+  // (read back through a lane index the compiler cannot see through -- launder() -- or it forwards the
+  // stores to the loads and keeps the registers; `volatile` would do too, but turns the accesses into
+  // serialised FLAT instructions)
+  __shared__ float s_start[4][6][64];
+  auto launder = [](int v) { asm volatile("" : "+v"(v)); return v; };
   const int tid = threadIdx.x;
   if (tid < 64 * 3) s_acc[tid] = 0ull;
   if (tid < 8) s_cnt[tid] = 0ull;
@@ -399,38 +409,46 @@ void k_march(const LfLensDev* __restrict__ lens, const LfPairsDev* __restrict__ 
         lanemask alive[K], alive0[K], alive1[K];
 #pragma unroll
         for (int j = 0; j < K; j++) {
-          r[j] = Ray{X, Y, z_sensor, d0x, d0y, d0z, 0.0f, 0.0f};
+          // (read back from LDS rather than kept in registers across the groups of the sample)
+          const int lo = launder(lane);
+          r[j] = Ray{s_start[wave][0][lo], s_start[wave][1][lo], 0.0f, 0.0f, s_start[wave][2][lo],
+                     s_start[wave][3][lo], s_start[wave][4][lo], 0.0f, 0.0f};
+          r[j].r2 = fmaf(r[j].px, r[j].px, r[j].py * r[j].py);
           alive[j] = (g * K + j < n_lambda) ? active_mask : 0ull;  // a short last group: dead rays
           alive0[j] = 0ull; alive1[j] = 0ull;
         }
-        auto live_count = [&]() {
-          unsigned n = 0;
+        // live rays of the group (sum of the K masks' populations), kept up to date where rays end and
+        // where fork states come back, so that no row has to count its masks
+        unsigned nlive = 0u, nlive0 = 0u, nlive1 = 0u;
 #pragma unroll
-          for (int j = 0; j < K; j++) n += (unsigned)__popcll(alive[j]);
-          return n;
-        };
-        auto none_alive = [&]() {
-          lanemask m = alive[0];
-#pragma unroll
-          for (int j = 1; j < K; j++) m |= alive[j];
-          return m == 0ull;
-        };
-        Ray r0[K];   // fork slot 0
+        for (int j = 0; j < K; j++) nlive += (unsigned)__popcll(alive[j]);
+        float r0[K][6];   // fork slot 0: px py hz dx dy dz (r2 is re-derived, like after an LDS restore)
         auto park_all = [&](int slot, lanemask* keep) {
 #pragma unroll
           for (int j = 0; j < K; j++) {
-            if (slot == 0) r0[j] = r[j];
-            else park(s_state[wave][j], lane, r[j]);
+            if (slot == 0) {
+              r0[j][0] = r[j].px; r0[j][1] = r[j].py; r0[j][2] = r[j].hz;
+              r0[j][3] = r[j].dx; r0[j][4] = r[j].dy; r0[j][5] = r[j].dz;
+            } else {
+              park(s_state[wave][j], lane, r[j]);
+            }
             keep[j] = alive[j];
           }
+          if (slot == 0) nlive0 = nlive; else nlive1 = nlive;
         };
         auto unpark_all = [&](int slot, const lanemask* keep) {
 #pragma unroll
           for (int j = 0; j < K; j++) {
-            if (slot == 0) r[j] = r0[j];
-            else unpark(s_state[wave][j], lane, r[j]);
+            if (slot == 0) {
+              r[j].px = r0[j][0]; r[j].py = r0[j][1]; r[j].hz = r0[j][2];
+              r[j].dx = r0[j][3]; r[j].dy = r0[j][4]; r[j].dz = r0[j][5];
+              r[j].r2 = fmaf(r[j].px, r[j].px, r[j].py * r[j].py);
+            } else {
+              unpark(s_state[wave][j], lane, r[j]);
+            }
             alive[j] = keep[j];
           }
+          nlive = slot == 0 ? nlive0 : nlive1;
         };
         // `cur` always holds the row at e: whoever moves e loads the row it lands on, so a run's
         // last iteration has already fetched the row the dispatch below looks at next
@@ -449,7 +467,7 @@ void k_march(const LfLensDev* __restrict__ lens, const LfPairsDev* __restrict__ 
             // with k rows of the run left (that row included), k -- so the common row costs no
             // scalar tally work at all; the rare death branch does the arithmetic.
             unsigned k = run, lost = 0u;
-            const unsigned live0 = live_count();
+            const unsigned live0 = nlive;
             if (fl & LF_EV_REFLECT) {
               if (fl & LF_EV_SAVE0) park_all(0, alive0);
               if (fl & LF_EV_SAVE1) park_all(1, alive1);
@@ -458,7 +476,7 @@ void k_march(const LfLensDev* __restrict__ lens, const LfPairsDev* __restrict__ 
               for (int j = 0; j < K; j++) {
                 if (K > 1 && alive[j] == 0ull) { okv[j] = 0ull; continue; }
                 lanemask geom_ok;
-                okv[j] = surface_event<false>(r[j], cur.zv, cur.curv, cur.radius, cur.h2, cur.eta[j],
+                okv[j] = surface_event<false>(r[j], cur.dzv, cur.curv, cur.radius, cur.h2, cur.eta[j],
                                               cur.eta2[j], true, false, cur.sgn, geom_ok);
                 died |= alive[j] & ~okv[j];
               }
@@ -468,9 +486,10 @@ void k_march(const LfLensDev* __restrict__ lens, const LfPairsDev* __restrict__ 
                   const unsigned nd = (unsigned)__popcll(alive[j] & ~okv[j]);
                   vign32 += mult * nd;
                   lost += nd * k;
+                  nlive -= nd;
                   alive[j] &= okv[j];
                 }
-                if (none_alive()) { dead = true; k = 1u; sk = cur.skip; }
+                if (nlive == 0u) { dead = true; k = 1u; sk = cur.skip; }
               }
               endfl = fl;
               ++e; --k;
@@ -483,7 +502,7 @@ void k_march(const LfLensDev* __restrict__ lens, const LfPairsDev* __restrict__ 
                 // a wavelength whose rays are all gone is not computed (one scalar branch; without
                 // it its lanes would keep marching garbage through every row the others still visit)
                 if (K > 1 && alive[j] == 0ull) { okv[j] = 0ull; gv[j] = 0ull; continue; }
-                okv[j] = surface_event<false>(r[j], cur.zv, cur.curv, cur.radius, cur.h2, cur.eta[j],
+                okv[j] = surface_event<false>(r[j], cur.dzv, cur.curv, cur.radius, cur.h2, cur.eta[j],
                                               cur.eta2[j], false, false, cur.sgn, gv[j]);
                 died |= alive[j] & ~okv[j];
               }
@@ -493,10 +512,12 @@ void k_march(const LfLensDev* __restrict__ lens, const LfPairsDev* __restrict__ 
                 for (int j = 0; j < K; j++) {
                   vign32 += mult * (unsigned)__popcll(alive[j] & ~gv[j]);
                   tir32 += mult * (unsigned)__popcll(alive[j] & gv[j] & ~okv[j]);
-                  lost += (unsigned)__popcll(alive[j] & ~okv[j]) * k;
+                  const unsigned nd = (unsigned)__popcll(alive[j] & ~okv[j]);
+                  lost += nd * k;
+                  nlive -= nd;
                   alive[j] &= okv[j];
                 }
-                if (none_alive()) { dead = true; k = 1u; sk = cur.skip; }
+                if (nlive == 0u) { dead = true; k = 1u; sk = cur.skip; }
               }
               ++e; --k;
               cur = load_prow(e);   // (the table ends with a spare row)
@@ -509,18 +530,20 @@ void k_march(const LfLensDev* __restrict__ lens, const LfPairsDev* __restrict__ 
 #pragma unroll
             for (int j = 0; j < K; j++) {
               if (K > 1 && alive[j] == 0ull) { okv[j] = 0ull; continue; }
-              okv[j] = stop_event<false>(r[j], cur.zv, cur.h2, inv_stop_h, mask, a.mw, a.mh);
+              okv[j] = stop_event<false>(r[j], cur.dzv, cur.h2, inv_stop_h, mask, a.mw, a.mh);
               died |= alive[j] & ~okv[j];
             }
             if (died != 0ull) {
 #pragma unroll
               for (int j = 0; j < K; j++) {
-                clip32 += mult * (unsigned)__popcll(alive[j] & ~okv[j]);
+                const unsigned nd = (unsigned)__popcll(alive[j] & ~okv[j]);
+                clip32 += mult * nd;
+                nlive -= nd;
                 alive[j] &= okv[j];
               }
-              dead = none_alive();
+              dead = nlive == 0u;
             }
-            const unsigned live = live_count();
+            const unsigned live = nlive;
             ev32 += mult * live;
             exec32 += live;
             endfl = fl;
@@ -535,7 +558,7 @@ void k_march(const LfLensDev* __restrict__ lens, const LfPairsDev* __restrict__ 
 #pragma unroll
             for (int j = 0; j < K; j++) {
               if (K > 1 && alive[j] == 0ull) { okv[j] = 0ull; gv[j] = 0ull; continue; }
-              okv[j] = surface_event<false>(r[j], cur.zv, cur.curv, cur.radius, cur.h2, cur.eta[j],
+              okv[j] = surface_event<false>(r[j], cur.dzv, cur.curv, cur.radius, cur.h2, cur.eta[j],
                                             cur.eta2[j], (fl & LF_EV_REFLECT) != 0,
                                             (fl & LF_EV_FLAT) != 0, cur.sgn, gv[j]);
               died |= alive[j] & ~okv[j];
@@ -545,11 +568,12 @@ void k_march(const LfLensDev* __restrict__ lens, const LfPairsDev* __restrict__ 
               for (int j = 0; j < K; j++) {
                 vign32 += mult * (unsigned)__popcll(alive[j] & ~gv[j]);
                 tir32 += mult * (unsigned)__popcll(alive[j] & gv[j] & ~okv[j]);
+                nlive -= (unsigned)__popcll(alive[j] & ~okv[j]);
                 alive[j] &= okv[j];
               }
-              dead = none_alive();
+              dead = nlive == 0u;
             }
-            const unsigned live = live_count();
+            const unsigned live = nlive;
             ev32 += mult * live;
             exec32 += live;
             endfl = fl;
@@ -566,7 +590,7 @@ void k_march(const LfLensDev* __restrict__ lens, const LfPairsDev* __restrict__ 
             else if ((sk & 3) == 2) unpark_all(0, alive0);
           } else if (endfl & LF_EV_END) {
             // ---- a path is complete ---------------------------------------------------------
-            scene32 += live_count();
+            scene32 += nlive;
             // inside the sun's lobe?  (cheap pre-test: 1 - d.s cancels -- its absolute error of ~1e-7
             // is ~1e-4 of a 0.05 rad lobe -- so it only selects, with a 1/16 margin; the lobe factor
             // itself is evaluated without cancellation after the weight re-march, see lobe_q)
@@ -589,15 +613,17 @@ void k_march(const LfLensDev* __restrict__ lens, const LfPairsDev* __restrict__ 
                 const int l = g * K + j;
                 const LfEventRow* __restrict__ w = ev_table + (size_t)l * (size_t)total_events +
                                                    pairs->ev_off[q];
-                Ray rw{s_start[wave][0][lane], s_start[wave][1][lane], z_sensor, s_start[wave][2][lane],
-                       s_start[wave][3][lane], s_start[wave][4][lane], s_start[wave][5][lane], 1.0f};
+                const int lo = launder(lane);
+                Ray rw{s_start[wave][0][lo], s_start[wave][1][lo], 0.0f, 0.0f, s_start[wave][2][lo],
+                       s_start[wave][3][lo], s_start[wave][4][lo], s_start[wave][5][lo], 1.0f};
+                rw.r2 = fmaf(rw.px, rw.px, rw.py * rw.py);
                 for (int left = pairs->ev_cnt[q]; left > 0; --left, ++w) {
                   const LfEventRow wr = load_row(w);
                   if (wr.flags & LF_EV_STOP) {
-                    (void)stop_event<true>(rw, wr.zv, wr.h2, inv_stop_h, mask, a.mw, a.mh);
+                    (void)stop_event<true>(rw, wr.dzv, wr.h2, inv_stop_h, mask, a.mw, a.mh);
                   } else {
                     lanemask geom_ok;
-                    (void)surface_event<true>(rw, wr.zv, wr.curv, wr.radius, wr.h2, wr.eta, wr.eta2,
+                    (void)surface_event<true>(rw, wr.dzv, wr.curv, wr.radius, wr.h2, wr.eta, wr.eta2,
                                               (wr.flags & LF_EV_REFLECT) != 0,
                                               (wr.flags & LF_EV_FLAT) != 0, wr.sgn, geom_ok);
                   }
@@ -698,16 +724,17 @@ __global__ __launch_bounds__(256) void k_lens_rays(const LfLensDev* __restrict__
   const float vx = fmaf(lens->pupil_h, qx, -X), vy = fmaf(lens->pupil_h, qy, -Y), vz = lens->pupil_z - z_sensor;
   const float len = lf_sqrt(fmaf(vx, vx, fmaf(vy, vy, vz * vz)));
   const float rl = __fdiv_rn(1.0f, len);
-  Ray r{X, Y, z_sensor, vx * rl, vy * rl, vz * rl, 1.0f, 1.0f};
+  Ray r{X, Y, 0.0f, fmaf(X, X, Y * Y), vx * rl, vy * rl, vz * rl, 1.0f, 1.0f};
   const float c2 = r.dz * r.dz;
   r.wn = lens->geom_norm * (c2 * c2);
   const float inv_stop_h = __fdiv_rn(1.0f, lens->stop_h);
   lanemask alive = __ballot(active);
   for (int k = lens->n_surf - 1; k >= 0; k--) {  // wave-uniform
     const LfSurfaceDev& sf = lens->surf[k];
+    const float dzv = (k == lens->n_surf - 1 ? z_sensor : lens->surf[k + 1].zv) - sf.zv;
     lanemask ok, geom_ok;
-    if (sf.is_stop != 0.0f) ok = stop_event<true>(r, sf.zv, sf.h2, inv_stop_h, mask, mw, mh);
-    else ok = surface_event<true>(r, sf.zv, sf.curv, sf.radius, sf.h2, sf.eta_bwd[lambda],
+    if (sf.is_stop != 0.0f) ok = stop_event<true>(r, dzv, sf.h2, inv_stop_h, mask, mw, mh);
+    else ok = surface_event<true>(r, dzv, sf.curv, sf.radius, sf.h2, sf.eta_bwd[lambda],
                             sf.eta_bwd[lambda] * sf.eta_bwd[lambda], false,
                             sf.curv == 0.0f, -1.0f, geom_ok);
     alive &= ok;
@@ -715,7 +742,7 @@ __global__ __launch_bounds__(256) void k_lens_rays(const LfLensDev* __restrict__
   if (active) {
     const bool a = (alive >> lane) & 1ull;
     float* o = out + 8 * (size_t)i;
-    o[0] = r.px; o[1] = r.py; o[2] = r.pz; o[3] = r.dx; o[4] = r.dy; o[5] = r.dz;
+    o[0] = r.px; o[1] = r.py; o[2] = lens->surf[0].zv + r.hz; o[3] = r.dx; o[4] = r.dy; o[5] = r.dz;
     o[6] = a ? __fdiv_rn(r.wn, r.wd) : 0.0f;
     o[7] = a ? 1.0f : 0.0f;
   }
@@ -793,14 +820,22 @@ void lf_derive_lens(lf_ctx* ctx, int n, int stop, int n_lambda, const float* rad
 //     refract backward through k
 // skip[r] = (rows to jump << 2) | restore, used when the whole wave is dead after row r: nothing of
 // what only these rays would still visit is executed (restore: 0 = program end, 1 = slot 1, 2 = slot 0)
+// vertex z of the interface the ray comes from (N = the sensor plane) minus that of interface k:
+// what one add turns the ray's z (relative to where it sits) into z relative to k's vertex
+static float lf_vertex_step(const LfLensDev& L, int from, int k) {
+  return (from >= L.n_surf ? L.z_sensor : L.surf[from].zv) - L.surf[k].zv;
+}
+
 static void build_program(const LfLensDev& L, const LfPairsDev& P, int l, std::vector<LfEventRow>& prog,
                           std::vector<int>& skip) {
   prog.clear();
   std::vector<int> target, restore;  // per row: absolute row to jump to when dead, restore kind
-  auto put = [&](int k, bool reflect, bool fwd, int extra_flags, int mult) {
+  // `from`: the interface the ray comes from (N = the sensor) -- every row of the tree has exactly
+  // one predecessor along its paths, so the vertex distance it needs is a property of the row
+  auto put = [&](int k, int from, bool reflect, bool fwd, int extra_flags, int mult) {
     const LfSurfaceDev& s = L.surf[k];
     LfEventRow r;
-    r.zv = s.zv; r.curv = s.curv; r.h2 = s.h2;
+    r.dzv = lf_vertex_step(L, from, k); r.curv = s.curv; r.h2 = s.h2;
     r.eta = fwd ? s.eta_fwd[l] : s.eta_bwd[l];
     r.sgn = fwd ? 1.0f : -1.0f;
     r.flags = (reflect ? LF_EV_REFLECT : 0) | (s.is_stop != 0.0f ? LF_EV_STOP : 0) |
@@ -832,7 +867,7 @@ static void build_program(const LfLensDev& L, const LfPairsDev& P, int l, std::v
     if (!js.empty()) {
       const int sub_first = (int)prog.size();
       std::vector<int> fwd_rows;
-      put(k, true, false, LF_EV_SAVE0, (int)js.size());
+      put(k, k + 1, true, false, LF_EV_SAVE0, (int)js.size());
       fwd_rows.push_back(sub_first);
       const int maxj = js.back().first;
       size_t p = 0;
@@ -840,9 +875,9 @@ static void build_program(const LfLensDev& L, const LfPairsDev& P, int l, std::v
         while (p < js.size() && js[p].first == m) {
           const bool last = p + 1 == js.size();
           const int leg_first = (int)prog.size();
-          put(m, true, true, last ? 0 : LF_EV_SAVE1, 1);
+          put(m, m == k + 1 ? k : m - 1, true, true, last ? 0 : LF_EV_SAVE1, 1);
           for (int t = m - 1; t >= 0; t--)
-            put(t, false, false,
+            put(t, t + 1, false, false,
                 t == 0 ? (LF_EV_END | (last ? LF_EV_REST0 : LF_EV_REST1) | (int)((unsigned)js[p].second << 24)) : 0, 1);
           for (int r = leg_first; r < (int)prog.size(); r++) {
             target[r] = (int)prog.size();
@@ -852,7 +887,7 @@ static void build_program(const LfLensDev& L, const LfPairsDev& P, int l, std::v
         }
         if (m < maxj) {
           fwd_rows.push_back((int)prog.size());
-          put(m, false, true, 0, (int)(js.size() - p));
+          put(m, m == k + 1 ? k : m - 1, false, true, 0, (int)(js.size() - p));
         }
       }
       for (int r : fwd_rows) { target[r] = (int)prog.size(); restore[r] = 2; }
@@ -860,7 +895,7 @@ static void build_program(const LfLensDev& L, const LfPairsDev& P, int l, std::v
     const int mult = (primary >= 0 ? 1 : 0) + below[k];
     if (mult > 0) {
       prefix_rows.push_back((int)prog.size());
-      put(k, false, false, (k == 0 && primary >= 0) ? (LF_EV_END | (int)((unsigned)primary << 24)) : 0, mult);
+      put(k, k + 1, false, false, (k == 0 && primary >= 0) ? (LF_EV_END | (int)((unsigned)primary << 24)) : 0, mult);
     }
   }
   for (int r : prefix_rows) { target[r] = (int)prog.size(); restore[r] = 0; }
@@ -910,10 +945,10 @@ lf_status lf_build_march_tables(lf_ctx* ctx, std::vector<LfEventRow>& rows, std:
       LfEventRow* out = rows.data() + (size_t)l * total + P.ev_off[q];
       const int i = P.ij[q][0], j = P.ij[q][1];
       int n = 0;
-      auto put = [&](int k, bool reflect, bool fwd) {
+      auto put = [&](int k, int from, bool reflect, bool fwd) {
         const LfSurfaceDev& s = L.surf[k];
         LfEventRow r;
-        r.zv = s.zv; r.curv = s.curv; r.h2 = s.h2;
+        r.dzv = lf_vertex_step(L, from, k); r.curv = s.curv; r.h2 = s.h2;
         r.eta = fwd ? s.eta_fwd[l] : s.eta_bwd[l];
         r.sgn = fwd ? 1.0f : -1.0f;
         r.flags = (reflect ? LF_EV_REFLECT : 0) | (s.is_stop != 0.0f ? LF_EV_STOP : 0) |
@@ -923,13 +958,13 @@ lf_status lf_build_march_tables(lf_ctx* ctx, std::vector<LfEventRow>& rows, std:
         out[n++] = r;
       };
       if (i < 0) {
-        for (int k = L.n_surf - 1; k >= 0; k--) put(k, false, false);
+        for (int k = L.n_surf - 1; k >= 0; k--) put(k, k + 1, false, false);
       } else {
-        for (int k = L.n_surf - 1; k > i; k--) put(k, false, false);
-        put(i, true, false);
-        for (int k = i + 1; k < j; k++) put(k, false, true);
-        put(j, true, true);
-        for (int k = j - 1; k >= 0; k--) put(k, false, false);
+        for (int k = L.n_surf - 1; k > i; k--) put(k, k + 1, false, false);
+        put(i, i + 1, true, false);
+        for (int k = i + 1; k < j; k++) put(k, k == i + 1 ? i : k - 1, false, true);
+        put(j, j == i + 1 ? i : j - 1, true, true);
+        for (int k = j - 1; k >= 0; k--) put(k, k + 1, false, false);
       }
       if (n != P.ev_cnt[q]) return lf_fail(ctx, LF_ERR_STATE, "event table: sequence length mismatch");
       // bits 8.. : length of the run of plain rows (no flag set) that starts at this row
@@ -979,7 +1014,7 @@ static void pack_program(const lf_ctx* ctx, const std::vector<LfEventRow>& rows,
         const int l = std::min(g * K + (j < K ? j : K - 1), n_lambda - 1);
         const LfEventRow& r = rows[(size_t)P.prog_off + (size_t)l * P.prog_rows + i];
         if (j == 0) {
-          o.zv = r.zv; o.curv = r.curv; o.h2 = r.h2; o.radius = r.radius; o.sgn = r.sgn; o.flags = r.flags;
+          o.dzv = r.dzv; o.curv = r.curv; o.h2 = r.h2; o.radius = r.radius; o.sgn = r.sgn; o.flags = r.flags;
           o.skip = skip[(size_t)i];
         }
         o.eta[j] = r.eta; o.eta2[j] = r.eta2;

@@ -117,16 +117,19 @@ static void derive(const geo_lens* L, int W, geo_derived* D) {
 
 /* ---- one ray ---------------------------------------------------------------------------- */
 /* the weight is carried as the fraction wn / wd (one division at the very end) */
-typedef struct { float p[3], d[3], wn, wd; } geo_ray;
+/* p[0], p[1]: x, y; p[2]: z RELATIVE to the vertex of the interface the ray sits on (0 on the sensor
+ * and on the stop plane); r2 = x^2 + y^2 of that point as the previous event computed it */
+typedef struct { float p[3], d[3], wn, wd, r2; } geo_ray;
 enum { OK_ = 0, CLIPPED = 1, VIGNETTED = 2, TIR = 3 };
 
 /* DESIGN.md "march arithmetic", glass interface.  reflect: 0 = Snell refraction, 1 = mirror.
  * forward: the ray travels +z (scene -> sensor). */
-static int glass_event(geo_ray* r, float zv, float c, float rad, float h2, float eta, int reflect,
+static int glass_event(geo_ray* r, float dzv, float c, float rad, float h2, float eta, int reflect,
                        int forward) {
-  float oz = r->p[2] - zv;
+  /* dzv: vertex z of the interface the ray comes from (or of the sensor) minus this one's */
+  float oz = r->p[2] + dzv;
   float od = fmaf(r->p[0], r->d[0], fmaf(r->p[1], r->d[1], oz * r->d[2]));
-  float oo = fmaf(r->p[0], r->p[0], fmaf(r->p[1], r->p[1], oz * oz));
+  float oo = fmaf(oz, oz, r->r2);
   float F = fmaf(c, oo, -2.0f * oz);
   float G = fmaf(-c, od, r->d[2]);
   float disc = fmaf(G, G, -(c * F));
@@ -137,7 +140,8 @@ static int glass_event(geo_ray* r, float zv, float c, float rad, float h2, float
   float sgn = forward ? 1.0f : -1.0f;
   float t = (c == 0.0f) ? F / fmaf(sgn, root, G) : fmaf(-sgn, root, G) * rad;
   float hx = fmaf(t, r->d[0], r->p[0]), hy = fmaf(t, r->d[1], r->p[1]), hz = fmaf(t, r->d[2], oz);
-  if (!(fmaf(hx, hx, hy * hy) <= h2)) return VIGNETTED;
+  float r2 = fmaf(hx, hx, hy * hy);
+  if (!(r2 <= h2)) return VIGNETTED;
   /* cosine of incidence against the unit normal n = (-c hx, -c hy, 1 - c hz), for |d| = 1:
    * mu = d.n = G - c t.  The normal itself is never formed (DESIGN.md "march arithmetic"). */
   float mu = fmaf(-c, t, G);
@@ -167,14 +171,15 @@ static int glass_event(geo_ray* r, float zv, float c, float rad, float h2, float
     float nd[3] = {fmaf(m, hx, r->d[0]), fmaf(m, hy, r->d[1]), fmaf(m, hz, fmaf(-2.0f, mu, r->d[2]))};
     memcpy(r->d, nd, sizeof(nd));
   }
-  r->p[0] = hx; r->p[1] = hy; r->p[2] = zv + hz;
+  r->p[0] = hx; r->p[1] = hy; r->p[2] = hz; r->r2 = r2;
   return OK_;
 }
 
-static int stop_event(geo_ray* r, float zv, float h2, float inv_h, const float* mask, int mw, int mh) {
-  float t = (zv - r->p[2]) / r->d[2];
+static int stop_event(geo_ray* r, float dzv, float h2, float inv_h, const float* mask, int mw, int mh) {
+  float t = -(r->p[2] + dzv) / r->d[2];
   float hx = fmaf(t, r->d[0], r->p[0]), hy = fmaf(t, r->d[1], r->p[1]);
-  if (!(fmaf(hx, hx, hy * hy) <= h2)) return CLIPPED;
+  float r2 = fmaf(hx, hx, hy * hy);
+  if (!(r2 <= h2)) return CLIPPED;
   float fu = fmaf(hx, inv_h, 1.0f) * (0.5f * (float)mw);
   float fv = fmaf(hy, inv_h, 1.0f) * (0.5f * (float)mh);
   int ix = (int)fu, iy = (int)fv;
@@ -183,16 +188,18 @@ static int stop_event(geo_ray* r, float zv, float h2, float inv_h, const float* 
   float a = mask[iy * mw + ix];
   if (!(a > 0.0f)) return CLIPPED;
   r->wn *= a;
-  r->p[0] = hx; r->p[1] = hy; r->p[2] = zv;
+  r->p[0] = hx; r->p[1] = hy; r->p[2] = 0.0f; r->r2 = r2;
   return OK_;
 }
 
 /* exported for the known-answer tests: one event on a caller-supplied ray */
 int geo_glass_event(float p[3], float d[3], float* w, float zv, float c, float h2, float eta,
                     int reflect, int forward) {
-  geo_ray r = {{p[0], p[1], p[2]}, {d[0], d[1], d[2]}, *w, 1.0f};
-  int st = glass_event(&r, zv, c, c == 0.0f ? 0.0f : 1.0f / c, h2, eta, reflect, forward);
-  memcpy(p, r.p, sizeof(r.p)); memcpy(d, r.d, sizeof(r.d)); *w = r.wn / r.wd;
+  /* absolute coordinates in and out: the ray "comes from" a vertex at z = 0 */
+  geo_ray r = {{p[0], p[1], p[2]}, {d[0], d[1], d[2]}, *w, 1.0f, fmaf(p[0], p[0], p[1] * p[1])};
+  int st = glass_event(&r, 0.0f - zv, c, c == 0.0f ? 0.0f : 1.0f / c, h2, eta, reflect, forward);
+  p[0] = r.p[0]; p[1] = r.p[1]; p[2] = zv + r.p[2];
+  memcpy(d, r.d, sizeof(r.d)); *w = r.wn / r.wd;
   return st;
 }
 
@@ -260,7 +267,8 @@ static float start_ray(const geo_derived* D, int W, int H, int x, int y, int s, 
   float vx = fmaf(D->pupil_h, qx, -X), vy = fmaf(D->pupil_h, qy, -Y), vz = D->pupil_z - D->z_sensor;
   float len = geo_sqrt(fmaf(vx, vx, fmaf(vy, vy, vz * vz)));
   float rl = 1.0f / len;
-  r->p[0] = X; r->p[1] = Y; r->p[2] = D->z_sensor;
+  r->p[0] = X; r->p[1] = Y; r->p[2] = 0.0f;   /* on the sensor plane, relative to it */
+  r->r2 = fmaf(X, X, Y * Y);
   r->d[0] = vx * rl; r->d[1] = vy * rl; r->d[2] = vz * rl;
   float c2 = r->d[2] * r->d[2];
   r->wn = D->geom_norm * (c2 * c2);
@@ -297,16 +305,19 @@ void geo_trace(const geo_lens* L, int W, int H, int y0, int y1, int spp, const u
             int n = build_sequence(L->n_surf, pairs[2 * q], pairs[2 * q + 1], seq);
             geo_ray r = r0;
             int st = OK_;
+            float z_from = D.z_sensor;   /* vertex z of where the ray sits: the sensor, then each interface */
             c.rays_launched++;
             for (int e = 0; e < n; e++) {
               int k = seq[e].k;
+              float dzv = z_from - D.zv[k];
               if (k == L->stop)
-                st = stop_event(&r, D.zv[k], D.h2[k], D.inv_stop_h, mask, mw, mh);
+                st = stop_event(&r, dzv, D.h2[k], D.inv_stop_h, mask, mw, mh);
               else
-                st = glass_event(&r, D.zv[k], D.curv[k], L->radius[k], D.h2[k],
+                st = glass_event(&r, dzv, D.curv[k], L->radius[k], D.h2[k],
                                  seq[e].forward ? D.eta_fwd[l][k] : D.eta_bwd[l][k], seq[e].reflect,
                                  seq[e].forward);
               if (st != OK_) break;
+              z_from = D.zv[k];
               c.surface_events++;
             }
             if (st == CLIPPED) { c.rays_clipped_stop++; continue; }
@@ -364,18 +375,23 @@ int geo_trace_ray(const geo_lens* L, int lambda, int i, int j, float p[3], float
   derive(L, 64, &D);
   geo_step seq[3 * GEO_MAX_SURF];
   int n = build_sequence(L->n_surf, i, j, seq);
-  geo_ray r = {{p[0], p[1], p[2]}, {d[0], d[1], d[2]}, *w, 1.0f};
+  /* absolute coordinates in and out; inside, z is relative to the sensor plane, then to each vertex */
+  geo_ray r = {{p[0], p[1], p[2] - D.z_sensor}, {d[0], d[1], d[2]}, *w, 1.0f, fmaf(p[0], p[0], p[1] * p[1])};
   int st = OK_, ev = 0;
+  float z_from = D.z_sensor;
   for (int e = 0; e < n; e++) {
     int k = seq[e].k;
-    if (k == L->stop) st = stop_event(&r, D.zv[k], D.h2[k], D.inv_stop_h, mask, mw, mh);
-    else st = glass_event(&r, D.zv[k], D.curv[k], L->radius[k], D.h2[k],
+    float dzv = z_from - D.zv[k];
+    if (k == L->stop) st = stop_event(&r, dzv, D.h2[k], D.inv_stop_h, mask, mw, mh);
+    else st = glass_event(&r, dzv, D.curv[k], L->radius[k], D.h2[k],
                           seq[e].forward ? D.eta_fwd[lambda][k] : D.eta_bwd[lambda][k],
                           seq[e].reflect, seq[e].forward);
     if (st != OK_) break;
+    z_from = D.zv[k];
     ev++;
   }
-  memcpy(p, r.p, sizeof(r.p)); memcpy(d, r.d, sizeof(r.d)); *w = r.wn / r.wd;
+  p[0] = r.p[0]; p[1] = r.p[1]; p[2] = z_from + r.p[2];
+  memcpy(d, r.d, sizeof(r.d)); *w = r.wn / r.wd;
   if (n_events) *n_events = ev;
   return st;
 }
@@ -399,14 +415,17 @@ void geo_survival(const geo_lens* L, int W, int H, int y0, int y1, int spp, cons
       for (int q = 0; q < n_pairs; q++) {
         int n = build_sequence(L->n_surf, pairs[2 * q], pairs[2 * q + 1], seq);
         geo_ray r = r0;
+        float z_from = D.z_sensor;
         alive[q * 33]++;
         for (int e = 0; e < n; e++) {
           int k = seq[e].k, st;
-          if (k == L->stop) st = stop_event(&r, D.zv[k], D.h2[k], D.inv_stop_h, mask, mw, mh);
-          else st = glass_event(&r, D.zv[k], D.curv[k], L->radius[k], D.h2[k],
+          float dzv = z_from - D.zv[k];
+          if (k == L->stop) st = stop_event(&r, dzv, D.h2[k], D.inv_stop_h, mask, mw, mh);
+          else st = glass_event(&r, dzv, D.curv[k], L->radius[k], D.h2[k],
                                 seq[e].forward ? D.eta_fwd[l][k] : D.eta_bwd[l][k], seq[e].reflect,
                                 seq[e].forward);
           if (st != OK_) break;
+          z_from = D.zv[k];
           alive[q * 33 + e + 1]++;
         }
       }
