@@ -96,6 +96,11 @@ typedef unsigned long long lanemask;
 // the wave-sequences): the weight is 15 of the 71 VALU instructions of an event and is read by
 // 0.4 % of the rays.  Both instantiations do the same arithmetic on the ray itself, so the
 // repeated march reproduces the first one bit for bit.
+// d = fma(s, d, a): one VOP3 instruction that overwrites d (s wave-uniform, in an SGPR)
+__device__ __forceinline__ void fma_in_place(float& d, float s, float a) {
+  asm("v_fma_f32 %0, %1, %0, %2" : "+v"(d) : "s"(s), "v"(a));
+}
+
 template <bool W>
 __device__ __forceinline__ lanemask surface_event(Ray& r, float dzv, float c, float rad, float h2,
                                                   float eta, float eta2, bool reflect, bool flat,
@@ -163,9 +168,12 @@ __device__ __forceinline__ lanemask surface_event(Ray& r, float dzv, float c, fl
     }
     const float g = fmaf(-eta, mu, copysignf(ct, mu));
     const float gc = g * c;
-    r.dx = fmaf(eta, r.dx, -(gc * hx));
-    r.dy = fmaf(eta, r.dy, -(gc * hy));
-    r.dz = fmaf(eta, r.dz, fmaf(-gc, hz, g));
+    // d = fma(eta, d, -(gc h)) IN PLACE (v_fma_f32 with the destination as a source): left to itself
+    // the compiler picks the two-address v_fmac that accumulates into the product's register and
+    // then moves the result back, three v_mov per event
+    fma_in_place(r.dx, eta, -(gc * hx));
+    fma_in_place(r.dy, eta, -(gc * hy));
+    fma_in_place(r.dz, eta, fmaf(-gc, hz, g));
   }
   r.px = hx; r.py = hy; r.hz = hz; r.r2 = r2;
   return ok;
