@@ -997,10 +997,11 @@ lf_status lf_build_march_tables(lf_ctx* ctx, std::vector<LfEventRow>& rows, std:
   return LF_OK;
 }
 
-// rays per lane for n wavelengths: groups of at most 4, as even as possible (3 -> 3; 8 -> 4 + 4;
-// 5 -> 3 + 2; 7 -> 4 + 3)
+// rays per lane for n wavelengths.  Measured on the 8-wavelength frame (4K, 64 spp): K = 1: 456 ms,
+// 2: 361, 3 (groups 3 + 3 + 2): 355, 4 (4 + 4, only 5 waves per SIMD): 384 -- three is the sweet
+// spot between sharing the scalar walk and keeping 6 waves per SIMD; four wavelengths go as 2 + 2.
 static int rays_per_lane(int n_lambda) {
-  int k = (n_lambda + ((n_lambda + 3) / 4) - 1) / ((n_lambda + 3) / 4);
+  int k = n_lambda == 4 ? 2 : std::min(n_lambda, 3);
   if (const char* kv = std::getenv("LF_MARCH_K")) {  // experiments only
     int v = std::atoi(kv);
     if (v >= 1 && v <= 4) k = v;
