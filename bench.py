@@ -102,10 +102,12 @@ class DevView:
 
 def source_sha():
     """Identity of the shipped march kernel: the PMC-derived figures are only quoted as this
-    binary's when the profile in profiles/ was taken from the same sources."""
+    binary's when the profile in profiles/ was taken from the same sources and compile flags."""
     h = hashlib.sha256()
-    for f in ("lens-flare_amd/csrc/lf_march.hip", "lens-flare_amd/csrc/lf_internal.h", "lens-flare_amd/Makefile"):
+    for f in ("lens-flare_amd/csrc/lf_march.hip", "lens-flare_amd/csrc/lf_internal.h"):
         h.update(open(os.path.join(ROOT, f), "rb").read())
+    mk = open(os.path.join(ROOT, "lens-flare_amd", "Makefile")).read()
+    h.update(mk[mk.index("FLAGS  :="):mk.index("SRCS   :=")].encode())
     return h.hexdigest()[:16]
 
 

@@ -93,3 +93,27 @@ def test_group_renders_the_single_gpu_frame(pkg, n, W, H):
             total[k] = total.get(k, 0) + v
     assert total == want_cnt                              # the shares add up to the single-GPU frame
     grp.close()
+
+
+def test_cpp_host_drives_a_group(pkg, tmp_path):
+    """lens-flare_amd/host/group_demo.cpp: a plain C++ host (no Python in the loop) renders a frame on a
+    group of contexts through lf_group_create / _set_frame / _for_each / _gather and verifies it against
+    a single context itself; here with device 0 listed three times."""
+    import os
+    import subprocess
+    demo = os.path.join(os.path.dirname(pkg.__file__), "host", "group_demo")
+    assert os.path.exists(demo), "run __graft_entry__.build() first"
+    lens = pkg.load_lens_file("dgauss11.lens")
+    mask = load_texels("pentbig500_14.png")
+    mask.tofile(tmp_path / "mask.f32")
+    n, nl = lens["n"], lens["ior"].shape[0]
+    with open(tmp_path / "lens.txt", "w") as f:
+        f.write(f"{n} {lens['stop']} {nl} {lens['sensor_width_mm']!r}\n")
+        for k in range(n):
+            row = [lens["radius"][k], lens["thickness"][k], lens["semi_aperture"][k]] + [lens["ior"][l, k] for l in range(nl)]
+            f.write(" ".join(repr(float(v)) for v in row) + "\n")
+    r = subprocess.run([demo, str(tmp_path / "lens.txt"), str(tmp_path / "mask.f32"), str(mask.shape[1]),
+                        str(mask.shape[0]), "120", "68", "16", "0", "0", "0"], capture_output=True, text=True,
+                       timeout=300)
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert "3 devices" in r.stdout
