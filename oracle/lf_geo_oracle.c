@@ -143,15 +143,15 @@ static int glass_event(geo_ray* r, float dzv, float c, float rad, float h2, floa
   float r2 = fmaf(hx, hx, hy * hy);
   if (!(r2 <= h2)) return VIGNETTED;
   /* cosine of incidence against the unit normal n = (-c hx, -c hy, 1 - c hz), for |d| = 1:
-   * mu = d.n = G - c t.  The normal itself is never formed (DESIGN.md "march arithmetic"). */
-  float mu = fmaf(-c, t, G);
-  float s2 = fmaf(-mu, mu, 1.0f);
+   * mu = d.n = G - c t, which with t = (G - sgn root) / c is sgn * root exactly: |mu| = root,
+   * sin^2 = 1 - disc, the sign is the direction of travel (DESIGN.md "march arithmetic"). */
+  float s2 = 1.0f - disc;
   float k2 = fmaf(-(eta * eta), s2, 1.0f);
   if (k2 < 0.0f && !reflect) return TIR;
   float ct = k2 >= 0.0f ? geo_sqrt(k2) : 0.0f;
   /* unpolarised Fresnel: R = Rn / D, Rn = a^2 (A^2 + B^2), D = (b (A + B))^2 with
    * a, b = eta ci/2 -+ ct/2, A = ci ct, B = eta sin^2(theta_i) */
-  float ci = fabsf(mu);
+  float ci = root;
   float ch = 0.5f * ci, th = 0.5f * ct;
   float a = fmaf(eta, ch, -th), b = fmaf(eta, ch, th);
   float A = ci * ct, B = eta * s2;
@@ -161,12 +161,13 @@ static int glass_event(geo_ray* r, float dzv, float c, float rad, float h2, floa
   if (!reflect) {
     r->wn *= D - Rn;
     r->wd *= D;
-    float g = fmaf(-eta, mu, copysignf(ct, mu)), gc = g * c;
+    float g = sgn * fmaf(-eta, root, ct), gc = g * c;
     float nd[3] = {fmaf(eta, r->d[0], -(gc * hx)), fmaf(eta, r->d[1], -(gc * hy)),
                    fmaf(eta, r->d[2], fmaf(-gc, hz, g))};
     memcpy(r->d, nd, sizeof(nd));
   } else {
     if (k2 >= 0.0f) { r->wn *= Rn; r->wd *= D; } /* else total reflection: R = 1 */
+    float mu = sgn * root;
     float m = 2.0f * (mu * c);
     float nd[3] = {fmaf(m, hx, r->d[0]), fmaf(m, hy, r->d[1]), fmaf(m, hz, fmaf(-2.0f, mu, r->d[2]))};
     memcpy(r->d, nd, sizeof(nd));
