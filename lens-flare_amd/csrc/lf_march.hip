@@ -262,8 +262,11 @@ struct MarchArgs {
 // index ratios of each wavelength of the group.  64 bytes = ONE s_load_dwordx16.
 typedef int lf_i16 __attribute__((ext_vector_type(16)));
 typedef const lf_i16 __attribute__((address_space(4))) * lf_const_prow_ptr;
-__device__ __forceinline__ LfProgRow load_prow(const LfProgRow* __restrict__ e) {
-  const lf_i16 v = *(lf_const_prow_ptr)(e);
+__device__ __forceinline__ LfProgRow load_prow(const LfProgRow* __restrict__ base, unsigned off) {
+  // (base + 32-bit byte offset: the row pointer of the walk is ONE scalar register to advance, and the
+  // load takes it as its SGPR offset)
+  typedef const char __attribute__((address_space(4))) * cptr;
+  const lf_i16 v = *(lf_const_prow_ptr)((cptr)(base) + off);
   LfProgRow r;
   r.dzv = __int_as_float(v[0]); r.curv = __int_as_float(v[1]); r.h2 = __int_as_float(v[2]);
   r.radius = __int_as_float(v[3]); r.sgn = __int_as_float(v[4]); r.flags = v[5];
@@ -412,8 +415,8 @@ void k_march(const LfLensDev* __restrict__ lens, const LfPairsDev* __restrict__ 
       for (int g = 0; g < n_groups; g++) {
         // ---- walk the group's program (the tree of all paths, depth first) ---------------------
         const LfProgRow* const prog = prog_table + (size_t)g * (size_t)prog_rows;
-        const LfProgRow* const prog_end = prog + prog_rows;
-        const LfProgRow* __restrict__ e = prog;
+        const unsigned prog_end = (unsigned)prog_rows * (unsigned)sizeof(LfProgRow);
+        unsigned e = 0u;   // byte offset of the current row
         Ray r[K];
         lanemask alive[K], alive0[K], alive1[K];
 #pragma unroll
@@ -461,7 +464,7 @@ void k_march(const LfLensDev* __restrict__ lens, const LfPairsDev* __restrict__ 
         };
         // `cur` always holds the row at e: whoever moves e loads the row it lands on, so a run's
         // last iteration has already fetched the row the dispatch below looks at next
-        LfProgRow cur = load_prow(e);
+        LfProgRow cur = load_prow(prog, e);
         while (e != prog_end) {
           const unsigned fl = (unsigned)cur.flags;
           const unsigned run = (fl >> 8) & 0xffu, mult = (fl >> 16) & 0xffu;
@@ -475,6 +478,9 @@ void k_march(const LfLensDev* __restrict__ lens, const LfPairsDev* __restrict__ 
             // entered by m live rays completes n * m events minus, for every ray that ends at a row
             // with k rows of the run left (that row included), k -- so the common row costs no
             // scalar tally work at all; the rare death branch does the arithmetic.
+            // (the __builtin_expect hints keep the rare blocks -- a ray ends, a wavelength is gone -- out
+            // of the straight-line path of the walk; measured together with the 32-bit row offset:
+            // 119.4 -> 117.75 ms per bench frame, profiles/r02_march_variants.txt)
             unsigned k = run, lost = 0u;
             const unsigned live0 = nlive;
             if (fl & LF_EV_REFLECT) {
@@ -483,13 +489,13 @@ void k_march(const LfLensDev* __restrict__ lens, const LfPairsDev* __restrict__ 
               lanemask okv[K], died = 0ull;
 #pragma unroll
               for (int j = 0; j < K; j++) {
-                if (K > 1 && alive[j] == 0ull) { okv[j] = 0ull; continue; }
+                if (K > 1 && __builtin_expect(alive[j] == 0ull, 0)) { okv[j] = 0ull; continue; }
                 lanemask geom_ok;
                 okv[j] = surface_event<false>(r[j], cur.dzv, cur.curv, cur.radius, cur.h2, cur.eta[j],
                                               cur.eta2[j], true, false, cur.sgn, geom_ok);
                 died |= alive[j] & ~okv[j];
               }
-              if (died != 0ull) {
+              if (__builtin_expect(died != 0ull, 0)) {
 #pragma unroll
                 for (int j = 0; j < K; j++) {
                   const unsigned nd = (unsigned)__popcll(alive[j] & ~okv[j]);
@@ -501,8 +507,8 @@ void k_march(const LfLensDev* __restrict__ lens, const LfPairsDev* __restrict__ 
                 if (nlive == 0u) { dead = true; k = 1u; sk = cur.skip; }
               }
               endfl = fl;
-              ++e; --k;
-              cur = load_prow(e);
+              e += (unsigned)sizeof(LfProgRow); --k;
+              cur = load_prow(prog, e);
             }
             while (k != 0u) {
               lanemask okv[K], gv[K], died = 0ull;
@@ -514,14 +520,14 @@ void k_march(const LfLensDev* __restrict__ lens, const LfPairsDev* __restrict__ 
                 for (int j = 0; j < K; j++) {
                   // a wavelength whose rays are all gone is not computed (one scalar branch; without
                   // it its lanes would keep marching garbage through every row the others still visit)
-                  if (K > 1 && alive[j] == 0ull) { okv[j] = 0ull; gv[j] = 0ull; continue; }
+                  if (K > 1 && __builtin_expect(alive[j] == 0ull, 0)) { okv[j] = 0ull; gv[j] = 0ull; continue; }
                   okv[j] = surface_event<false>(r[j], cur.dzv, cur.curv, cur.radius, cur.h2, cur.eta[j],
                                                 cur.eta2[j], false, false, cur.sgn, gv[j]);
                   died |= alive[j] & ~okv[j];
                 }
               }
               endfl = (unsigned)cur.flags;
-              if (died != 0ull) {  // some ray ends here, in `mult` logical paths
+              if (__builtin_expect(died != 0ull, 0)) {  // some ray ends here, in `mult` logical paths
 #pragma unroll
                 for (int j = 0; j < K; j++) {
                   vign32 += mult * (unsigned)__popcll(alive[j] & ~gv[j]);
@@ -533,8 +539,8 @@ void k_march(const LfLensDev* __restrict__ lens, const LfPairsDev* __restrict__ 
                 }
                 if (nlive == 0u) { dead = true; k = 1u; sk = cur.skip; }
               }
-              ++e; --k;
-              cur = load_prow(e);   // (the table ends with a spare row)
+              e += (unsigned)sizeof(LfProgRow); --k;
+              cur = load_prow(prog, e);   // (the table ends with a spare row)
             }
             const unsigned live_sum = run * live0 - lost;
             ev32 += mult * live_sum;   // logical events: one per path that shares these rows
@@ -543,11 +549,11 @@ void k_march(const LfLensDev* __restrict__ lens, const LfPairsDev* __restrict__ 
             lanemask okv[K], died = 0ull;
 #pragma unroll
             for (int j = 0; j < K; j++) {
-              if (K > 1 && alive[j] == 0ull) { okv[j] = 0ull; continue; }
+              if (K > 1 && __builtin_expect(alive[j] == 0ull, 0)) { okv[j] = 0ull; continue; }
               okv[j] = stop_event<false>(r[j], cur.dzv, cur.h2, inv_stop_h, mask, a.mw, a.mh);
               died |= alive[j] & ~okv[j];
             }
-            if (died != 0ull) {
+            if (__builtin_expect(died != 0ull, 0)) {
 #pragma unroll
               for (int j = 0; j < K; j++) {
                 const unsigned nd = (unsigned)__popcll(alive[j] & ~okv[j]);
@@ -562,8 +568,8 @@ void k_march(const LfLensDev* __restrict__ lens, const LfPairsDev* __restrict__ 
             exec32 += live;
             endfl = fl;
             sk = cur.skip;
-            ++e;
-            cur = load_prow(e);
+            e += (unsigned)sizeof(LfProgRow);
+            cur = load_prow(prog, e);
           } else {
             // a single mirror event (a fork that ends its leg at once) or flat glass
             if (fl & LF_EV_SAVE0) park_all(0, alive0);
@@ -571,13 +577,13 @@ void k_march(const LfLensDev* __restrict__ lens, const LfPairsDev* __restrict__ 
             lanemask okv[K], gv[K], died = 0ull;
 #pragma unroll
             for (int j = 0; j < K; j++) {
-              if (K > 1 && alive[j] == 0ull) { okv[j] = 0ull; gv[j] = 0ull; continue; }
+              if (K > 1 && __builtin_expect(alive[j] == 0ull, 0)) { okv[j] = 0ull; gv[j] = 0ull; continue; }
               okv[j] = surface_event<false>(r[j], cur.dzv, cur.curv, cur.radius, cur.h2, cur.eta[j],
                                             cur.eta2[j], (fl & LF_EV_REFLECT) != 0,
                                             (fl & LF_EV_FLAT) != 0, cur.sgn, gv[j]);
               died |= alive[j] & ~okv[j];
             }
-            if (died != 0ull) {
+            if (__builtin_expect(died != 0ull, 0)) {
 #pragma unroll
               for (int j = 0; j < K; j++) {
                 vign32 += mult * (unsigned)__popcll(alive[j] & ~gv[j]);
@@ -592,14 +598,14 @@ void k_march(const LfLensDev* __restrict__ lens, const LfPairsDev* __restrict__ 
             exec32 += live;
             endfl = fl;
             sk = cur.skip;
-            ++e;
-            cur = load_prow(e);
+            e += (unsigned)sizeof(LfProgRow);
+            cur = load_prow(prog, e);
           }
           if (dead) {
             // every ray of the wave is dead: jump over everything only these rays would still visit
             // (the jump-table entry travels in the row itself: no dependent load in front of the next row)
-            e = (e - 1) + (sk >> 2);
-            cur = load_prow(e);
+            e = e - (unsigned)sizeof(LfProgRow) + (((unsigned)sk & ~3u) << 4);  // (sk >> 2) rows of 64 bytes
+            cur = load_prow(prog, e);
             if ((sk & 3) == 1) unpark_all(1, alive1);
             else if ((sk & 3) == 2) unpark_all(0, alive0);
           } else if (endfl & LF_EV_END) {
