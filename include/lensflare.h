@@ -150,13 +150,31 @@ lf_status lf_set_scene(lf_ctx* ctx, int n_spheres, const double* spheres, const 
  *        1 PointLight                v0 = position                         (:47-58)
  *        2 InfiniteHemisphereLight   (no vectors)                          (:31-44, light.cpp:26-48)
  *        3 AreaLight                 v0 = position, v1 = direction, v2 = dim_x, v3 = dim_y  (:78-97, light.cpp:74-101)
- * Types 2 and 3 are SAMPLED lights: lf_set_light_samples(ns_area_light) samples each per hit
+ *        4 EnvironmentLight          (no vectors, rgb unused: the map of lf_set_environment_map;
+ *                                    scene/environment_light.cpp:140-171 -- the renderer appends
+ *                                    it to scene->lights, raytraced_renderer.cpp:127-128)
+ * Types 2, 3 and 4 are SAMPLED lights: lf_set_light_samples(ns_area_light) samples each per hit
  * (PathTracer::ns_area_light, pathtracer.h:108; estimate_direct_lighting_importance,
  * pathtracer.cpp:143-213), drawn from the counter RNG -- they need lf_set_jitter_counter (the
  * reference's shared MT19937 is consumed in hit order, which no parallel schedule reproduces) and are
  * validated statistically against reference frames, not bit for bit. */
 lf_status lf_set_scene_lights(lf_ctx* ctx, int n_lights, const double* rows);
 lf_status lf_set_light_samples(lf_ctx* ctx, int ns_area_light);
+/* PathTracer::envLight (pathtracer.h:119; `new EnvironmentLight(envmap)`, raytraced_renderer.cpp:
+ * 80-84): the environment map.  rgb = HDRImageBuffer::data, w*h texels of 3 doubles, row-major (the
+ * .exr decoder stays with the host).  A camera ray that hits nothing returns
+ * EnvironmentLight::sample_dir (pathtracer.cpp:291-292; environment_light.cpp:173-182, bilinear
+ * in (theta, phi) with its edge rules) -- deterministic, so it is also served in MT19937 parity mode;
+ * listed as a light of type 4 it is importance-sampled through the tables of
+ * EnvironmentLight::init (:19-59), built here in the reference's order of operations (the
+ * probability_debug.png the reference writes as a side effect is not written).  w = h = 0 removes
+ * the map.  Maps smaller than 2 x 2 or without any light are refused. */
+lf_status lf_set_environment_map(lf_ctx* ctx, int w, int h, const double* rgb);
+/* PathTracer::direct_hemisphere_sample (pathtracer.h:114, the -H flag): one_bounce_radiance
+ * (pathtracer.cpp:222-232) uses estimate_direct_lighting_hemisphere (:86-138) -- uniform directions
+ * over the hemisphere, lights.size() * ns_area_light per hit, collecting the emission of the
+ * surfaces they reach -- instead of sampling the lights.  Counter RNG only, statistical parity. */
+lf_status lf_set_direct_hemisphere_sample(lf_ctx* ctx, int on);
 /* Row f3: a COLLADA file -> the static scene, in one call.  Replaces
  * Collada::ColladaParser::load (src/scene/collada/collada.cpp:131-218) + Application::load
  * (src/application/application.cpp:232-365) + the GLScene -> SceneObjects conversion behind them

@@ -29,7 +29,8 @@ ABI_SYMBOLS = [
     "lf_set_frame", "lf_set_band", "lf_set_row_interleave", "lf_set_params", "lf_set_aperture", "lf_get_aperture_stats",
     "lf_set_paraxial_lens", "lf_set_camera", "lf_find_sun_pos", "lf_set_flares", "lf_get_flares",
     "lf_set_jitter_mt19937", "lf_set_jitter_counter", "lf_set_scene_term", "lf_set_scene",
-    "lf_set_sampling", "lf_set_scene_lights", "lf_set_light_samples", "lf_collada_check", "lf_render_scene_term",
+    "lf_set_sampling", "lf_set_scene_lights", "lf_set_light_samples", "lf_set_environment_map",
+    "lf_set_direct_hemisphere_sample", "lf_collada_check", "lf_render_scene_term",
     "lf_generate_ghost_buffer", "lf_render_flare_layer", "lf_read_tile", "lf_read_pixel",
     "lf_write_to_framebuffer", "lf_save_image_rgba", "lf_device_buffer", "lf_set_lens", "lf_set_lambda_rgb", "lf_set_sun",
     "lf_set_sun_from_flares", "lf_paraxial_efl", "lf_set_ghost_pairs", "lf_set_pupil_subcells", "lf_trace_ghosts", "lf_generate_lens_rays", "lf_get_counters", "lf_reset_counters", "lf_get_executed_events", "lf_native_sqrt", "lf_set_starburst_spectrum", "lf_load_collada", "lf_march_tables",
@@ -341,6 +342,18 @@ class LensFlare:
 
     def set_light_samples(self, ns_area_light):
         self._ck(self.lib.lf_set_light_samples(self.ctx, int(ns_area_light)))
+
+    def set_environment_map(self, rgb):
+        """PathTracer::envLight: rgb = (h, w, 3) doubles (HDRImageBuffer::data), or None to remove it."""
+        if rgb is None:
+            self._ck(self.lib.lf_set_environment_map(self.ctx, 0, 0, None))
+            return
+        a = np.ascontiguousarray(rgb, np.float64)
+        assert a.ndim == 3 and a.shape[2] == 3
+        self._ck(self.lib.lf_set_environment_map(self.ctx, a.shape[1], a.shape[0], _fp(a, C.c_double)))
+
+    def set_direct_hemisphere_sample(self, on):
+        self._ck(self.lib.lf_set_direct_hemisphere_sample(self.ctx, 1 if on else 0))
 
     def load_collada(self, path, max_suns=8):
         """Row f3: parse a .dae, upload its static scene; returns (camera dict or None, sun lights

@@ -68,7 +68,15 @@ struct LfLight { int type, pad; double v[3], rgb[3], dir[3], dim_x[3], dim_y[3],
 struct LfSceneDev {
   LfBvhNode* nodes; LfPrim* prims; LfMaterial* materials; LfLight* lights;
   int n_nodes, n_prims, n_materials, n_lights;
-  int n_soft_lights;   // lights that are sampled (hemisphere, area): they need the counter RNG
+  int n_soft_lights;   // lights that are sampled (hemisphere, area, environment): they need the counter RNG
+  int n_env_lights;    // lights of type 4 (they need lf_set_environment_map)
+};
+// EnvironmentLight (scene/environment_light.cpp): the map (HDRImageBuffer::data, w*h RGB doubles)
+// and the tables its init() derives (:19-59), built on the host in the reference's order of
+// operations; w = 0: no environment
+struct LfEnvDev {
+  const double* data; const double* pdf; const double* conds; const double* marginal;
+  int w, h;
 };
 
 // per-wavelength starburst (row f4): n = 0 is the reference's monochrome starburst
@@ -222,6 +230,9 @@ struct lf_ctx {
   LfSceneDev scene_dev{};
   bool scene_valid = false;
   int ns_area_light = 1;          // PathTracer::ns_area_light (pathtracer.h:108; the -l flag)
+  LfEnvDev env_dev{};             // PathTracer::envLight (pathtracer.h:119)
+  double* env_block = nullptr;    // one allocation behind env_dev's four tables
+  bool hemisphere_sample = false; // PathTracer::direct_hemisphere_sample (pathtracer.h:114; the -H flag)
   int samples_per_batch = 32;     // PathTracer::samplesPerBatch default (raytraced_renderer.h:67-81)
   double max_tolerance = 0.05;    // PathTracer::maxTolerance
 

@@ -339,7 +339,7 @@ void k_march(const LfLensDev* __restrict__ lens, const LfPairsDev* __restrict__ 
   const int n_lambda = lens->n_lambda, n_pairs = pairs->n, total_events = pairs->total_events;
   const int prog_rows = pairs->prog_rows;
   const int n_groups = (n_lambda + K - 1) / K;
-  const float z_sensor = lens->z_sensor, pitch = lens->pitch, pupil_h = lens->pupil_h;
+  const float pitch = lens->pitch, pupil_h = lens->pupil_h;
   const float geom_norm = lens->geom_norm;
   // (wave-uniform floats the device would have to compute on the vector unit -- and then hold in, or
   // spill from, vector registers -- arrive as kernel arguments: IEEE operations, the same on the host)

@@ -164,10 +164,37 @@ __device__ inline void make_coord_space(V3 n, V3& X, V3& Y, V3& Z) {
 __device__ inline uint4 philox4x32_10(uint4 ctr, uint2 key);
 __device__ inline double random_uniform_from_raw(unsigned raw);
 
-__device__ V3 radiance(const LfSceneDev& sc, DRay r, int* __restrict__ stack, int ns_area_light,
-                       uint4 rng_ctr, uint2 rng_key) {
+// EnvironmentLight::sample_dir (environment_light.cpp:173-182) = bilerp(theta_phi_to_xy(
+// dir_to_theta_phi(r.d))) (:86-91, :102-107, :121-138)
+__device__ V3 env_sample_dir(const LfEnvDev& ev, V3 d) {
+  const double PI_ = 3.14159265358979323;
+  const V3 u = unit(d);
+  const double theta = acos(u.y), phi = atan2(-u.z, u.x) + PI_;
+  const double x = phi / 2. / PI_ * (double)ev.w, y = theta / PI_ * (double)ev.h;
+  long right = lround(x), left, v = lround(y);
+  const double u1 = (double)right - x + .5;
+  double v1;
+  if (right == 0 || right == ev.w) { left = ev.w - 1; right = 0; } else left = right - 1;
+  if (v == 0) { v = 1; v1 = 1.0; } else if (v == ev.h) { v = ev.h - 1; v1 = 0.0; } else v1 = (double)v - y + .5;
+  const long bottom = (long)ev.w * v, top = bottom - ev.w;
+  const double u0 = 1 - u1;
+  auto px = [&](long i) { return v3(ev.data[3 * i], ev.data[3 * i + 1], ev.data[3 * i + 2]); };
+  return (px(top + left) * u1 + px(top + right) * u0) * v1 +
+         (px(bottom + left) * u1 + px(bottom + right) * u0) * (1 - v1);
+}
+
+// std::upper_bound on a non-decreasing table: the first index whose entry is > x (n if none)
+__device__ inline int upper_bound_d(const double* __restrict__ a, int n, double x) {
+  int lo = 0, hi = n;
+  while (lo < hi) { const int mid = (lo + hi) >> 1; if (x < a[mid]) hi = mid; else lo = mid + 1; }
+  return lo;
+}
+
+__device__ V3 radiance(const LfSceneDev& sc, const LfEnvDev& ev, bool hemisphere, DRay r,
+                       int* __restrict__ stack, int ns_area_light, uint4 rng_ctr, uint2 rng_key) {
   Hit isect;
-  if (!closest_hit(sc.nodes, sc.prims, r, &isect, stack)) return v3(0, 0, 0);  // no envLight
+  if (!closest_hit(sc.nodes, sc.prims, r, &isect, stack))   // pathtracer.cpp:291-292
+    return ev.w ? env_sample_dir(ev, r.d) : v3(0, 0, 0);
   const LfMaterial& m = sc.materials[isect.material];
   const V3 emission = m.kind == 1 ? v3(m.rgb[0], m.rgb[1], m.rgb[2]) : v3(0, 0, 0);
   V3 X, Y, Z;
@@ -181,6 +208,33 @@ __device__ V3 radiance(const LfSceneDev& sc, DRay r, int* __restrict__ stack, in
   // (kind 2: the value of f itself, as a host that can only call BSDF::f hands it over)
   const V3 f = m.kind == 0 ? mulv(v3(ipi, ipi, ipi), v3(m.rgb[0], m.rgb[1], m.rgb[2]))
              : m.kind == 2 ? v3(m.rgb[0], m.rgb[1], m.rgb[2]) : v3(0, 0, 0);
+  if (hemisphere) {
+    // estimate_direct_lighting_hemisphere (pathtracer.cpp:86-138): uniform directions over the
+    // hemisphere of the hit point, lights.size() * ns_area_light of them; what they find is the
+    // EMISSION of whatever surface they hit (lights as such are not sampled, the environment not seen)
+    const int num_samples = sc.n_lights * ns_area_light;
+    const double p_w = 1.0 / (2.0 * 3.14159265358979323);
+    for (int k = 0; k < num_samples; k++) {
+      const uint4 rr = philox4x32_10(make_uint4(rng_ctr.x, rng_ctr.y, 0x11650000u, (unsigned)k), rng_key);
+      const double xi1 = random_uniform_from_raw(rr.x), xi2 = random_uniform_from_raw(rr.y);
+      // UniformHemisphereSampler3D::get_sample (sampler.cpp:30-44): sinf / cosf of the double angles
+      const double theta = acos(xi1), phi = 2.0 * 3.14159265358979323 * xi2;
+      const V3 wi = v3((double)(sinf((float)theta) * cosf((float)phi)),
+                       (double)(sinf((float)theta) * sinf((float)phi)), (double)cosf((float)theta));
+      // o2w * wi: the columns of o2w are X, Y, Z
+      const V3 ww = v3((wi.x * X.x + wi.y * Y.x) + wi.z * Z.x, (wi.x * X.y + wi.y * Y.y) + wi.z * Z.y,
+                       (wi.x * X.z + wi.y * Y.z) + wi.z * Z.z);
+      DRay out{hit_p, ww, kEpsF, INFINITY};
+      Hit h2;
+      if (closest_hit(sc.nodes, sc.prims, out, &h2, stack)) {
+        const LfMaterial& m2 = sc.materials[h2.material];
+        const V3 em2 = m2.kind == 1 ? v3(m2.rgb[0], m2.rgb[1], m2.rgb[2]) : v3(0, 0, 0);
+        const double cos_theta = unit(wi).z;
+        L = L + divs(mulv(f, em2) * cos_theta, p_w);
+      }
+    }
+    return emission + divs(L, (double)num_samples);   // (0 / 0 = NaN without lights, as in the reference)
+  }
   for (int l = 0; l < sc.n_lights; l++) {
     const LfLight& lt = sc.lights[l];
     const int num_samples = lt.type >= 2 ? ns_area_light : 1;   // is_delta_light() ? 1 : ns_area_light
@@ -206,6 +260,20 @@ __device__ V3 radiance(const LfSceneDev& sc, DRay r, int* __restrict__ stack, in
           wi = v3(xs, zs, -ys);   // sampleToWorld: columns (1,0,0), (0,0,-1), (0,1,0)
           dist = INFINITY;
           pdf = 1.0 / (2.0 * 3.14159265358979323);
+        } else if (lt.type == 4) {  // EnvironmentLight::sample_L, importance sampled (:159-171)
+          // (upper_bound can return one past the end when the draw exceeds the table's last entry,
+          // ~1 - 1e-16 against draws clamped to 0.99999999: out of bounds in the reference, clamped here)
+          int yy = upper_bound_d(ev.marginal, ev.h, xi2);
+          yy = yy < ev.h ? yy : ev.h - 1;
+          int xx = upper_bound_d(ev.conds + (size_t)ev.w * yy, ev.w, xi1);
+          xx = xx < ev.w ? xx : ev.w - 1;
+          const double PI_ = 3.14159265358979323;
+          const double phi = (double)xx / (double)ev.w * 2.0 * PI_, theta = (double)yy / (double)ev.h * PI_;
+          wi = v3(cos(phi - PI_) * sin(theta), cos(theta), -sin(phi - PI_) * sin(theta));
+          dist = INFINITY;
+          const size_t t = (size_t)ev.w * yy + xx;
+          pdf = ev.pdf[t] * (double)ev.w * (double)ev.h / 2. / PI_ / PI_ / sin(theta);
+          emit = v3(ev.data[3 * t], ev.data[3 * t + 1], ev.data[3 * t + 2]);
         } else {             // AreaLight::sample_L (light.cpp:82-101)
           const double sx = xi1 - (double)0.5f, sy = xi2 - (double)0.5f;
           const V3 d = ((v3(lt.v[0], lt.v[1], lt.v[2]) + sx * v3(lt.dim_x[0], lt.dim_x[1], lt.dim_x[2])) +
@@ -254,7 +322,8 @@ __device__ inline double random_uniform_from_raw(unsigned raw) {  // util/random
 }
 
 // the sample loop of raytrace_pixel (pathtracer.cpp:831-875)
-__global__ __launch_bounds__(256) void k_scene_term(LfSceneDev sc, LfCamera cam, int W, int H, int y0,
+__global__ __launch_bounds__(256) void k_scene_term(LfSceneDev sc, LfEnvDev ev, int hemisphere,
+                                                    LfCamera cam, int W, int H, int y0,
                                                     int y1, int ns_aa, int ns_area_light,
                                                     int samples_per_batch, double max_tolerance,
                                                     const uint32_t* __restrict__ aa_raw, int jitter_mode,
@@ -294,7 +363,7 @@ __global__ __launch_bounds__(256) void k_scene_term(LfSceneDev sc, LfCamera cam,
              (dir.x * cam.c2w[3] + dir.y * cam.c2w[4]) + dir.z * cam.c2w[5],
              (dir.x * cam.c2w[6] + dir.y * cam.c2w[7]) + dir.z * cam.c2w[8]);
     r.min_t = cam.n_clip; r.max_t = cam.f_clip;
-    const V3 L = radiance(sc, r, stack, ns_area_light, make_uint4((unsigned)p, (unsigned)sample, 0u, 0u),
+    const V3 L = radiance(sc, ev, hemisphere != 0, r, stack, ns_area_light, make_uint4((unsigned)p, (unsigned)sample, 0u, 0u),
                           make_uint2((unsigned)key, (unsigned)(key >> 32)));
     // Vector3D::illum (vector3D.h:231-233): float coefficients, double arithmetic, float result
     const float illum = (float)((0.2126f * L.x + 0.7152f * L.y) + 0.0722f * L.z);
@@ -444,13 +513,14 @@ lf_status lf_set_scene_lights(lf_ctx* ctx, int n_lights, const double* rows) {
   if (!ctx || n_lights < 0 || (n_lights && !rows)) return LF_ERR_INVALID;
   if (!ctx->scene_valid) return lf_fail(ctx, LF_ERR_STATE, "lf_set_scene_lights before lf_set_scene");
   std::vector<LfLight> lts(n_lights);
-  int soft = 0;
+  int soft = 0, envs = 0;
   for (int i = 0; i < n_lights; i++) {
     const double* r = rows + 16 * (size_t)i;
     LfLight& l = lts[i];
     std::memset(&l, 0, sizeof(l));
     l.type = (int)r[0];
-    if (l.type < 0 || l.type > 3) return lf_fail(ctx, LF_ERR_INVALID, "scene light type must be 0 .. 3");
+    if (l.type < 0 || l.type > 4) return lf_fail(ctx, LF_ERR_INVALID, "scene light type must be 0 .. 4");
+    if (l.type == 4) envs++;
     for (int c = 0; c < 3; c++) {
       l.rgb[c] = r[1 + c]; l.v[c] = r[4 + c]; l.dir[c] = r[7 + c]; l.dim_x[c] = r[10 + c]; l.dim_y[c] = r[13 + c];
     }
@@ -472,6 +542,55 @@ lf_status lf_set_scene_lights(lf_ctx* ctx, int n_lights, const double* rows) {
   if (n_lights) LF_HIP(ctx, hipMemcpy(S.lights, lts.data(), lts.size() * sizeof(LfLight), hipMemcpyHostToDevice));
   S.n_lights = n_lights;
   S.n_soft_lights = soft;
+  S.n_env_lights = envs;
+  return LF_OK;
+}
+
+// EnvironmentLight::EnvironmentLight -> init() (environment_light.cpp:7-59): the sampling tables in
+// the reference's order of operations (doubles; illum() is a float, vector3D.h:231-233)
+lf_status lf_set_environment_map(lf_ctx* ctx, int w, int h, const double* rgb) {
+  if (!ctx || w < 0 || h < 0 || ((w == 0) != (h == 0)) || (w && !rgb)) return LF_ERR_INVALID;
+  if (w && (w < 2 || h < 2)) return lf_fail(ctx, LF_ERR_INVALID, "environment map smaller than 2 x 2 (bilerp reads two rows and columns)");
+  LF_HIP(ctx, hipSetDevice(ctx->device));
+  LF_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  if (ctx->env_block) { (void)hipFree(ctx->env_block); ctx->env_block = nullptr; }
+  ctx->env_dev = LfEnvDev{};
+  if (w == 0) return LF_OK;
+  const size_t n = (size_t)w * h;
+  std::vector<double> blk(3 * n + n + n + (size_t)h);
+  double* data = blk.data(); double* pdf = data + 3 * n; double* conds = pdf + n; double* marg = conds + n;
+  std::memcpy(data, rgb, 3 * n * sizeof(double));
+  const double PI_ = 3.14159265358979323846;   // PI (CGL/misc.h)
+  double sum = 0;
+  for (int j = 0; j < h; ++j)
+    for (int i = 0; i < w; ++i) {
+      const double* t = rgb + 3 * ((size_t)w * j + i);
+      const float illum = (float)((0.2126f * t[0] + 0.7152f * t[1]) + 0.0722f * t[2]);
+      pdf[(size_t)w * j + i] = illum * std::sin(PI_ * (j + .5) / h);
+      sum += pdf[(size_t)w * j + i];
+    }
+  if (!(sum > 0) || !std::isfinite(sum)) return lf_fail(ctx, LF_ERR_INVALID, "environment map without light (the reference divides by its total)");
+  for (size_t k = 0; k < n; k++) pdf[k] /= sum;
+  for (int j = 0; j < h; ++j) {
+    marg[j] = (j == 0 ? 0 : marg[j - 1]);
+    for (int i = 0; i < w; ++i) marg[j] += pdf[(size_t)w * j + i];
+  }
+  for (int j = 0; j < h; ++j) {
+    const double marginal_density = marg[j] - (j == 0 ? 0 : marg[j - 1]);
+    for (int i = 0; i < w; ++i)
+      conds[(size_t)w * j + i] = (i == 0 ? 0 : conds[(size_t)w * j + i - 1]) + pdf[(size_t)w * j + i] / marginal_density;
+  }
+  LF_HIP(ctx, hipMalloc((void**)&ctx->env_block, blk.size() * sizeof(double)));
+  LF_HIP(ctx, hipMemcpy(ctx->env_block, blk.data(), blk.size() * sizeof(double), hipMemcpyHostToDevice));
+  ctx->env_dev.data = ctx->env_block; ctx->env_dev.pdf = ctx->env_block + 3 * n;
+  ctx->env_dev.conds = ctx->env_block + 4 * n; ctx->env_dev.marginal = ctx->env_block + 5 * n;
+  ctx->env_dev.w = w; ctx->env_dev.h = h;
+  return LF_OK;
+}
+
+lf_status lf_set_direct_hemisphere_sample(lf_ctx* ctx, int on) {
+  if (!ctx) return LF_ERR_INVALID;
+  ctx->hemisphere_sample = on != 0;
   return LF_OK;
 }
 
@@ -500,6 +619,12 @@ lf_status lf_render_scene_term(lf_ctx* ctx) {
     return lf_fail(ctx, LF_ERR_INVALID,
                    "MT19937 parity mode cannot serve area / hemisphere lights: the reference samples them from "
                    "its shared generator in hit order (use lf_set_jitter_counter)");
+  if (ctx->scene_dev.n_env_lights > 0 && ctx->env_dev.w == 0)
+    return lf_fail(ctx, LF_ERR_STATE, "an environment light (type 4) is listed but no map is set (lf_set_environment_map)");
+  if (ctx->jitter_mode == 0 && ctx->hemisphere_sample && ctx->scene_dev.n_lights > 0)
+    return lf_fail(ctx, LF_ERR_INVALID,
+                   "MT19937 parity mode cannot serve hemisphere sampling: the reference draws its directions from "
+                   "the shared generator in hit order (use lf_set_jitter_counter)");
   if (ctx->jitter_mode == 0) {
     if (!ctx->jitter_table_valid || !ctx->jitter_aa_raw || ctx->jitter_aa_ns != ctx->ns_aa)
       return lf_fail(ctx, LF_ERR_STATE, "MT19937 jitter: call lf_set_jitter_mt19937 after lf_set_params");
@@ -517,7 +642,8 @@ lf_status lf_render_scene_term(lf_ctx* ctx) {
   const size_t px = (size_t)(ctx->y1 - ctx->y0) * ctx->W;
   if (px == 0) return LF_OK;
   hipLaunchKernelGGL(k_scene_term, dim3((unsigned)((px + 255) / 256)), dim3(256), 0, ctx->stream,
-                     ctx->scene_dev, ctx->cam, ctx->W, ctx->H, ctx->y0, ctx->y1, ctx->ns_aa,
+                     ctx->scene_dev, ctx->env_dev, ctx->hemisphere_sample ? 1 : 0, ctx->cam, ctx->W, ctx->H,
+                     ctx->y0, ctx->y1, ctx->ns_aa,
                      ctx->ns_area_light, ctx->samples_per_batch, ctx->max_tolerance, ctx->jitter_aa_raw, ctx->jitter_mode,
                      ctx->jitter_key, ctx->scene);
   LF_HIP(ctx, hipGetLastError());

@@ -30,6 +30,7 @@
 
 #include "pathtracer/bsdf.h"
 #include "pathtracer/camera.h"
+#include "scene/environment_light.h"
 #include "scene/light.h"
 #include "scene/object.h"
 #include "scene/sphere.h"
@@ -55,6 +56,12 @@ struct CameraHFov {
   friend type get(CameraHFov);
 };
 template struct PrivateMember<CameraHFov, &Camera::hFov>;
+// ... and EnvironmentLight keeps its map private (environment_light.h:33)
+struct EnvLightMap {
+  typedef const HDRImageBuffer* EnvironmentLight::*type;
+  friend type get(EnvLightMap);
+};
+template struct PrivateMember<EnvLightMap, &EnvironmentLight::envMap>;
 
 struct DeviceState {
   lf_ctx* ctx = nullptr;
@@ -62,6 +69,7 @@ struct DeviceState {
   std::vector<double> star;     // ... of raytrace_starburst(x, y)
   const void* textures_of = nullptr;   // camera whose aperture textures are on the device
   const void* scene_of = nullptr;      // scene that is on the device
+  const void* env_of = nullptr;        // EnvironmentLight whose map is on the device
   bool frame_ready = false;
 };
 
@@ -124,6 +132,8 @@ void upload_scene(DeviceState& s, PathTracer* pt) {
     else if (InfiniteHemisphereLight* h = dynamic_cast<InfiniteHemisphereLight*>(l)) { row[0] = 2; put(1, h->radiance); }
     else if (AreaLight* a = dynamic_cast<AreaLight*>(l)) {
       row[0] = 3; put(1, a->radiance); put(4, a->position); put(7, a->direction); put(10, a->dim_x); put(13, a->dim_y);
+    } else if (dynamic_cast<EnvironmentLight*>(l)) {
+      row[0] = 4;   // the map itself: upload_environment
     } else {
       fprintf(stderr, "[PathTracer/MI355X] spot / sphere / mesh lights are stubs in the reference (light.cpp): not rendered\n");
       exit(1);
@@ -135,6 +145,22 @@ void upload_scene(DeviceState& s, PathTracer* pt) {
   check(s, lf_set_scene_lights(s.ctx, (int)(lights.size() / 16), lights.data()), "lf_set_scene_lights");
   check(s, lf_set_light_samples(s.ctx, (int)std::max<size_t>(1, pt->ns_area_light)), "lf_set_light_samples");
   s.scene_of = pt->scene;
+}
+
+// PathTracer::envLight (pathtracer.h:119): the map behind it, texel by texel (Vector3D is 24 or 32
+// bytes wide); the sampling tables are rebuilt on the other side of the ABI
+void upload_environment(DeviceState& s, PathTracer* pt) {
+  if (s.env_of == pt->envLight) return;
+  if (!pt->envLight) {
+    check(s, lf_set_environment_map(s.ctx, 0, 0, nullptr), "lf_set_environment_map");
+  } else {
+    const HDRImageBuffer* m = (*pt->envLight).*get(EnvLightMap());
+    std::vector<double> rgb;
+    rgb.reserve(3 * m->w * m->h);
+    for (size_t i = 0; i < m->w * m->h; i++) rgb.insert(rgb.end(), {m->data[i].x, m->data[i].y, m->data[i].z});
+    check(s, lf_set_environment_map(s.ctx, (int)m->w, (int)m->h, rgb.data()), "lf_set_environment_map");
+  }
+  s.env_of = pt->envLight;
 }
 
 }  // namespace
@@ -253,6 +279,8 @@ void PathTracer::generate_ghost_buffer() {                         // pathtracer
   if (getenv("LF_COUNTER_JITTER")) check(s, lf_set_jitter_counter(s.ctx, 0x1e45f1a4eULL), "lf_set_jitter_counter");
   else check(s, lf_set_jitter_mt19937(s.ctx, 5489, nullptr, 0), "lf_set_jitter_mt19937");
   if (s.scene_of != scene) upload_scene(s, this);
+  upload_environment(s, this);
+  check(s, lf_set_direct_hemisphere_sample(s.ctx, direct_hemisphere_sample ? 1 : 0), "lf_set_direct_hemisphere_sample");
   check(s, lf_render_scene_term(s.ctx), "lf_render_scene_term");
   check(s, lf_generate_ghost_buffer(s.ctx), "lf_generate_ghost_buffer");
   check(s, lf_render_flare_layer(s.ctx), "lf_render_flare_layer");

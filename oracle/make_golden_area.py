@@ -5,8 +5,9 @@ pathtracer.cpp:143-213, light.cpp:35-48, :82-101).
 
 The reference draws these samples from its shared std::mt19937 in hit order, so no device schedule
 can reproduce its stream: parity is statistical.  For each scene the REAL reference (oracle/_ref/
-ref_dump) renders the frame TWICE with different sample counts (ns_aa 256 and 255: every draw of the
-second run differs from the first), which gives the reference's own Monte-Carlo spread per pixel;
+ref_dump) renders the frame TWICE (ns_aa 256 and 255, the second run after 100003 discarded draws:
+the adaptive early-out otherwise stops both runs at the same sample count pixel after pixel and their
+streams never part), which gives the reference's own Monte-Carlo spread per pixel;
 tests/test_gpu_area_lights.py requires the device frame to sit inside that spread.
 
 Scene: the reference's own Cornell box dae/sky/CBspheres_lambertian.dae as its loader flattens it
@@ -40,7 +41,7 @@ def parse_soft_lights(text):
     return area, hemi
 
 
-def render(name, W, H, ns_aa, ns_area, cam, lights, scene, area, hemi, tmp):
+def render(name, W, H, ns_aa, ns_area, cam, lights, scene, area, hemi, tmp, burn=0):
     hf, vf = mg.fit_fov(50.0, 35.0, W, H)
     yaw, pitch, pos = cam
     c2w = mg.rot(yaw, pitch)
@@ -61,6 +62,8 @@ def render(name, W, H, ns_aa, ns_area, cam, lights, scene, area, hemi, tmp):
             f.write("hemi " + " ".join(num(v) for v in h) + "\n")
     out = os.path.join(tmp, name + f"_{ns_aa}")
     env = dict(os.environ, REF_NS_AREA_LIGHT=str(ns_area))
+    if burn:
+        env["REF_MT_BURN"] = str(burn)   # oracle/ref_driver.cpp: discard that many draws first
     subprocess.run([mg.DUMP, "frame", camf, str(W), str(H), str(ns_aa), "25.0", "1.0",
                     os.path.join(mg.REF, "apertures/pentsmall.png"), os.path.join(mg.REF, "bokeh/octagonbokeh.png"),
                     spec, "tiles", out, sfile], check=True, env=env, stdout=subprocess.DEVNULL,
@@ -87,7 +90,7 @@ def main():
     for name, a, h in (("a48x36_cbspheres_area", area, []),
                        ("h48x36_cbspheres_hemisphere", [], [[0.6, 0.7, 0.9]])):
         sa, ghost, meta = render(name, W, H, 256, ns_area, cam, sun, scene, a, h, tmp)
-        sb, _, _ = render(name, W, H, 255, ns_area, cam, sun, scene, a, h, tmp)
+        sb, _, _ = render(name, W, H, 255, ns_area, cam, sun, scene, a, h, tmp, burn=100003)
         meta.update(name=name, ns_aa_a=256, ns_aa_b=255, ns_area_light=ns_area, flare_radius=25.0, flare_intensity=1.0,
                     aperture="pentsmall.png", ghost_aperture="octagonbokeh.png",
                     scene=dict(spheres=[list(s) for s in spheres], tris=[list(t) for t in tris], area=a, hemi=h))

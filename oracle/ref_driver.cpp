@@ -45,6 +45,7 @@
 #include "scene/gl_scene/directional_light.h"
 #include "scene/gl_scene/point_light.h"
 #include "scene/gl_scene/spot_light.h"
+#include "scene/environment_light.h"
 #include "scene/light.h"
 #include "scene/object.h"
 #include "scene/sphere.h"
@@ -164,6 +165,7 @@ static int cmd_frame(int argc, char** argv) {
   //   point px py pz  Lr Lg Lb
   //   area  pos(3) dir(3) dim_x(3) dim_y(3)  Lr Lg Lb ;  hemi Lr Lg Lb   (sampled lights, REF_NS_AREA_LIGHT each)
   std::string scenefile = argc > a ? argv[a++] : "";
+  EnvironmentLight* env_light = NULL;
   if (!scenefile.empty()) {
     std::ifstream sf(scenefile);
     std::string kind;
@@ -207,6 +209,20 @@ static int cmd_frame(int argc, char** argv) {
         lights.push_back(new AreaLight(Vector3D(v[12], v[13], v[14]), Vector3D(v[0], v[1], v[2]),
                                        Vector3D(v[3], v[4], v[5]), Vector3D(v[6], v[7], v[8]),
                                        Vector3D(v[9], v[10], v[11])));
+      } else if (kind == "env") {    // env  w h file.f64 [light]   (EnvironmentLight over w*h*3 raw doubles;
+                                     //  "light": also appended to scene->lights, as
+                                     //  RaytracedRenderer::set_scene does, raytraced_renderer.cpp:127-128)
+        size_t ew, eh; std::string ef, as_light;
+        sf >> ew >> eh >> ef >> as_light;
+        HDRImageBuffer* eb = new HDRImageBuffer();
+        eb->resize(ew, eh);
+        std::vector<double> raw(ew * eh * 3);
+        FILE* fe = fopen(ef.c_str(), "rb");
+        if (!fe || fread(raw.data(), 8, raw.size(), fe) != raw.size()) return 4;
+        fclose(fe);
+        for (size_t i = 0; i < ew * eh; i++) eb->data[i] = Vector3D(raw[3 * i], raw[3 * i + 1], raw[3 * i + 2]);
+        env_light = new EnvironmentLight(eb);   // (init() also writes probability_debug.png into the cwd)
+        if (as_light == "light") lights.push_back(env_light);
       } else if (kind == "hemi") {   // hemi  radiance(3)
         double l0, l1, l2;
         sf >> l0 >> l1 >> l2;
@@ -224,12 +240,20 @@ static int cmd_frame(int argc, char** argv) {
   pt.ns_diff = pt.ns_glsy = pt.ns_refr = 1;
   pt.samplesPerBatch = 32;
   pt.maxTolerance = 0.05;
-  pt.direct_hemisphere_sample = false;
-  pt.envLight = NULL;
+  pt.direct_hemisphere_sample = getenv("REF_HEMISPHERE") != NULL;   // the -H flag
+  pt.envLight = env_light;
   pt.flare_radius = flare_radius;
   pt.flare_intensity = flare_intensity;
   pt.axis_ray = Vector2D(0, 0);
   pt.angle_to_sun = 0;
+
+  // REF_MT_BURN=n: n draws of the pixel / light samplers' generator are thrown away first, so that two
+  // runs of one scene share no random number (adaptive sampling otherwise stops both at the same
+  // sample count pixel after pixel, and their streams never part)
+  if (getenv("REF_MT_BURN")) {
+    UniformGridSampler2D burner;
+    for (size_t k = strtoul(getenv("REF_MT_BURN"), 0, 10); k > 0; k--) (void)burner.get_sample();
+  }
 
   // start_raytracing order (raytraced_renderer.cpp:300-311)
   pt.clear();
