@@ -22,6 +22,7 @@
 #include <dlfcn.h>
 
 #include <cstring>
+#include <mutex>
 #include <thread>
 #include <vector>
 
@@ -46,27 +47,27 @@ struct Rccl {
 
 Rccl* rccl() {
   static Rccl r;
-  static bool tried = false;
-  if (tried) return r.handle ? &r : nullptr;
-  tried = true;
-  const char* names[] = {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
-  for (const char* n : names) {
-    r.handle = dlopen(n, RTLD_NOW | RTLD_LOCAL);
-    if (r.handle) break;
-  }
-  if (!r.handle) { r.error = "librccl.so.1 not found"; return nullptr; }
-  bool ok = true;
-  auto sym = [&](const char* name) { void* p = dlsym(r.handle, name); if (!p) ok = false; return p; };
-  r.GetUniqueId = (decltype(r.GetUniqueId))sym("ncclGetUniqueId");
-  r.CommInitRank = (decltype(r.CommInitRank))sym("ncclCommInitRank");
-  r.CommInitAll = (decltype(r.CommInitAll))sym("ncclCommInitAll");
-  r.CommDestroy = (decltype(r.CommDestroy))sym("ncclCommDestroy");
-  r.AllGather = (decltype(r.AllGather))sym("ncclAllGather");
-  r.GroupStart = (decltype(r.GroupStart))sym("ncclGroupStart");
-  r.GroupEnd = (decltype(r.GroupEnd))sym("ncclGroupEnd");
-  r.GetErrorString = (decltype(r.GetErrorString))sym("ncclGetErrorString");
-  if (!ok) { dlclose(r.handle); r.handle = nullptr; r.error = "librccl lacks an entry point"; return nullptr; }
-  return &r;
+  static std::once_flag once;   // (group work runs on one host thread per device)
+  std::call_once(once, []() {
+    const char* names[] = {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
+    for (const char* n : names) {
+      r.handle = dlopen(n, RTLD_NOW | RTLD_LOCAL);
+      if (r.handle) break;
+    }
+    if (!r.handle) { r.error = "librccl.so.1 not found"; return; }
+    bool ok = true;
+    auto sym = [&](const char* name) { void* p = dlsym(r.handle, name); if (!p) ok = false; return p; };
+    r.GetUniqueId = (decltype(r.GetUniqueId))sym("ncclGetUniqueId");
+    r.CommInitRank = (decltype(r.CommInitRank))sym("ncclCommInitRank");
+    r.CommInitAll = (decltype(r.CommInitAll))sym("ncclCommInitAll");
+    r.CommDestroy = (decltype(r.CommDestroy))sym("ncclCommDestroy");
+    r.AllGather = (decltype(r.AllGather))sym("ncclAllGather");
+    r.GroupStart = (decltype(r.GroupStart))sym("ncclGroupStart");
+    r.GroupEnd = (decltype(r.GroupEnd))sym("ncclGroupEnd");
+    r.GetErrorString = (decltype(r.GetErrorString))sym("ncclGetErrorString");
+    if (!ok) { dlclose(r.handle); r.handle = nullptr; r.error = "librccl lacks an entry point"; }
+  });
+  return r.handle ? &r : nullptr;
 }
 
 // frame viewed as [groups][world][e doubles]: slot (g, rank) -> send[g]
