@@ -149,7 +149,7 @@ struct alignas(32) LfEventRow {
   float eta2;      // eta * eta (float product)
 };
 enum { LF_EV_REFLECT = 1, LF_EV_STOP = 2, LF_EV_FLAT = 4 };
-// A program row as the device walks it: the interface once, the index ratios of the up to four
+// A program row as the device walks it: the interface once, the index ratios of the up to three
 // wavelengths that march it together (lf_march.hip, k_march<K>); one 64-byte scalar load.
 struct alignas(64) LfProgRow {
   float dzv, curv, h2, radius;
@@ -157,8 +157,10 @@ struct alignas(64) LfProgRow {
   int flags;        // as LfEventRow::flags of the per-wavelength program rows
   int skip;         // jump-table entry of this row: (rows to jump << 2) | state to restore
   int pad1;
-  float eta[4];     // wavelength g*K + j of group g (repeated past the group's / the lens' last one)
-  float eta2[4];
+  float eta[3];     // wavelength g*K + j of group g (repeated past the group's / the lens' last one)
+  float ch;         // curv / 2
+  float eta2[3];
+  float c2;         // 2 curv (both exact: lf_march.hip, surface_event)
 };
 // The march does not walk the per-pair sequences one by one: every path of a (sample, wavelength)
 // starts with the same backward leg from the sensor, and all pairs (i, .) share the forward leg that

@@ -101,16 +101,19 @@ __device__ __forceinline__ void fma_in_place(float& d, float s, float a) {
   asm("v_fma_f32 %0, %1, %0, %2" : "+v"(d) : "s"(s), "v"(a));
 }
 
+// ch = c / 2 and c2 = 2 c travel with the row (exact scalings): F = c |o|^2 - 2 o_z is formed as its
+// half Fh = fma(ch, |o|^2, -o_z) -- the same bits, shifted by one exponent -- and c F as c2 * Fh, so
+// the doubling of o_z is never an instruction of its own.
 template <bool W>
-__device__ __forceinline__ lanemask surface_event(Ray& r, float dzv, float c, float rad, float h2,
-                                                  float eta, float eta2, bool reflect, bool flat,
+__device__ __forceinline__ lanemask surface_event(Ray& r, float dzv, float c, float ch, float c2, float rad,
+                                                  float h2, float eta, float eta2, bool reflect, bool flat,
                                                   float sgn, lanemask& geom_ok) {
   const float oz = r.hz + dzv;
   const float od = fmaf(r.px, r.dx, fmaf(r.py, r.dy, oz * r.dz));
   const float oo = fmaf(oz, oz, r.r2);
-  const float F = fmaf(c, oo, -2.0f * oz);
+  const float Fh = fmaf(ch, oo, -oz);            // F / 2, F = c |o|^2 - 2 o_z
   const float G = fmaf(-c, od, r.dz);
-  const float cF = c * F;
+  const float cF = c2 * Fh;                      // = c F, bit for bit
   const float disc = fmaf(G, G, -cF);
   const float sq = lf_sqrt(disc);
   // the root next to the vertex, t = F / (G + sgn sqrt(disc)).  For a curved interface the same
@@ -119,7 +122,7 @@ __device__ __forceinline__ lanemask surface_event(Ray& r, float dzv, float c, fl
   // log2(2 G^2 / (c F)) bits (<= 8 for this lens: <= 3e-5 mm on the hit point), which both the
   // kernel and the oracle do identically.  Flat glass (c = 0) keeps the quotient.
   float t;
-  if (flat) t = __fdiv_rn(F, fmaf(sgn, sq, G));   // wave-uniform branch
+  if (flat) t = __fdiv_rn(Fh + Fh, fmaf(sgn, sq, G));   // wave-uniform branch
   else t = fmaf(-sgn, sq, G) * rad;
   const float hx = fmaf(t, r.dx, r.px), hy = fmaf(t, r.dy, r.py), hz = fmaf(t, r.dz, oz);
   const float r2 = fmaf(hx, hx, hy * hy);
@@ -258,7 +261,7 @@ struct MarchArgs {
   float vz;            // pupil_z - z_sensor
 };
 
-// One program row for a GROUP of up to 4 wavelengths: the geometry of the interface once, the
+// One program row for a GROUP of up to 3 wavelengths: the geometry of the interface once, the
 // index ratios of each wavelength of the group.  64 bytes = ONE s_load_dwordx16.
 typedef int lf_i16 __attribute__((ext_vector_type(16)));
 typedef const lf_i16 __attribute__((address_space(4))) * lf_const_prow_ptr;
@@ -272,7 +275,8 @@ __device__ __forceinline__ LfProgRow load_prow(const LfProgRow* __restrict__ bas
   r.radius = __int_as_float(v[3]); r.sgn = __int_as_float(v[4]); r.flags = v[5];
   r.skip = v[6]; r.pad1 = 0;
 #pragma unroll
-  for (int j = 0; j < 4; j++) { r.eta[j] = __int_as_float(v[8 + j]); r.eta2[j] = __int_as_float(v[12 + j]); }
+  for (int j = 0; j < 3; j++) { r.eta[j] = __int_as_float(v[8 + j]); r.eta2[j] = __int_as_float(v[12 + j]); }
+  r.ch = __int_as_float(v[11]); r.c2 = __int_as_float(v[15]);
   return r;
 }
 
@@ -284,9 +288,9 @@ __device__ __forceinline__ LfProgRow load_prow(const LfProgRow* __restrict__ bas
 // instructions on four SIMDs (53 %); profiles/r02_*.  Each ray keeps its own liveness mask, tallies
 // are per ray, so pixels and counters are exactly those of K separate walks.
 // (second launch bound = waves per SIMD the register allocation must leave room for; the LDS
-// footprint allows at least as many workgroups of 4 waves per CU: 8 / 6 / 6 / 5 for K = 1 .. 4)
+// footprint allows at least as many workgroups of 4 waves per CU: 8 / 6 / 6 for K = 1 .. 3)
 template <int K>
-__global__ __launch_bounds__(256, (K == 1 ? 8 : K <= 3 ? 6 : 5))
+__global__ __launch_bounds__(256, (K == 1 ? 8 : 6))
 void k_march(const LfLensDev* __restrict__ lens, const LfPairsDev* __restrict__ pairs,
              const LfEventRow* __restrict__ ev_table, const LfProgRow* __restrict__ prog_table,
              const int* __restrict__ skip_tab, const float* __restrict__ mask, MarchArgs a,
@@ -491,7 +495,7 @@ void k_march(const LfLensDev* __restrict__ lens, const LfPairsDev* __restrict__ 
               for (int j = 0; j < K; j++) {
                 if (K > 1 && __builtin_expect(alive[j] == 0ull, 0)) { okv[j] = 0ull; continue; }
                 lanemask geom_ok;
-                okv[j] = surface_event<false>(r[j], cur.dzv, cur.curv, cur.radius, cur.h2, cur.eta[j],
+                okv[j] = surface_event<false>(r[j], cur.dzv, cur.curv, cur.ch, cur.c2, cur.radius, cur.h2, cur.eta[j],
                                               cur.eta2[j], true, false, cur.sgn, geom_ok);
                 died |= alive[j] & ~okv[j];
               }
@@ -521,7 +525,7 @@ void k_march(const LfLensDev* __restrict__ lens, const LfPairsDev* __restrict__ 
                   // a wavelength whose rays are all gone is not computed (one scalar branch; without
                   // it its lanes would keep marching garbage through every row the others still visit)
                   if (K > 1 && __builtin_expect(alive[j] == 0ull, 0)) { okv[j] = 0ull; gv[j] = 0ull; continue; }
-                  okv[j] = surface_event<false>(r[j], cur.dzv, cur.curv, cur.radius, cur.h2, cur.eta[j],
+                  okv[j] = surface_event<false>(r[j], cur.dzv, cur.curv, cur.ch, cur.c2, cur.radius, cur.h2, cur.eta[j],
                                                 cur.eta2[j], false, false, cur.sgn, gv[j]);
                   died |= alive[j] & ~okv[j];
                 }
@@ -578,7 +582,7 @@ void k_march(const LfLensDev* __restrict__ lens, const LfPairsDev* __restrict__ 
 #pragma unroll
             for (int j = 0; j < K; j++) {
               if (K > 1 && __builtin_expect(alive[j] == 0ull, 0)) { okv[j] = 0ull; gv[j] = 0ull; continue; }
-              okv[j] = surface_event<false>(r[j], cur.dzv, cur.curv, cur.radius, cur.h2, cur.eta[j],
+              okv[j] = surface_event<false>(r[j], cur.dzv, cur.curv, cur.ch, cur.c2, cur.radius, cur.h2, cur.eta[j],
                                             cur.eta2[j], (fl & LF_EV_REFLECT) != 0,
                                             (fl & LF_EV_FLAT) != 0, cur.sgn, gv[j]);
               died |= alive[j] & ~okv[j];
@@ -643,7 +647,8 @@ void k_march(const LfLensDev* __restrict__ lens, const LfPairsDev* __restrict__ 
                     (void)stop_event<true>(rw, wr.dzv, wr.h2, inv_stop_h, mask, a.mw, a.mh);
                   } else {
                     lanemask geom_ok;
-                    (void)surface_event<true>(rw, wr.dzv, wr.curv, wr.radius, wr.h2, wr.eta, wr.eta2,
+                    (void)surface_event<true>(rw, wr.dzv, wr.curv, 0.5f * wr.curv, 2.0f * wr.curv, wr.radius,
+                                              wr.h2, wr.eta, wr.eta2,
                                               (wr.flags & LF_EV_REFLECT) != 0,
                                               (wr.flags & LF_EV_FLAT) != 0, wr.sgn, geom_ok);
                   }
@@ -754,7 +759,8 @@ __global__ __launch_bounds__(256) void k_lens_rays(const LfLensDev* __restrict__
     const float dzv = (k == lens->n_surf - 1 ? z_sensor : lens->surf[k + 1].zv) - sf.zv;
     lanemask ok, geom_ok;
     if (sf.is_stop != 0.0f) ok = stop_event<true>(r, dzv, sf.h2, inv_stop_h, mask, mw, mh);
-    else ok = surface_event<true>(r, dzv, sf.curv, sf.radius, sf.h2, sf.eta_bwd[lambda],
+    else ok = surface_event<true>(r, dzv, sf.curv, 0.5f * sf.curv, 2.0f * sf.curv, sf.radius, sf.h2,
+                            sf.eta_bwd[lambda],
                             sf.eta_bwd[lambda] * sf.eta_bwd[lambda], false,
                             sf.curv == 0.0f, -1.0f, geom_ok);
     alive &= ok;
@@ -1016,7 +1022,7 @@ static int rays_per_lane(int n_lambda) {
   int k = n_lambda == 4 ? 2 : std::min(n_lambda, 3);
   if (const char* kv = std::getenv("LF_MARCH_K")) {  // experiments only
     int v = std::atoi(kv);
-    if (v >= 1 && v <= 4) k = v;
+    if (v >= 1 && v <= 3) k = v;
   }
   return k;
 }
@@ -1031,11 +1037,12 @@ static void pack_program(const lf_ctx* ctx, const std::vector<LfEventRow>& rows,
   for (int g = 0; g < n_groups; g++)
     for (int i = 0; i < P.prog_rows; i++) {
       LfProgRow& o = out[(size_t)g * P.prog_rows + i];
-      for (int j = 0; j < 4; j++) {
+      for (int j = 0; j < 3; j++) {
         const int l = std::min(g * K + (j < K ? j : K - 1), n_lambda - 1);
         const LfEventRow& r = rows[(size_t)P.prog_off + (size_t)l * P.prog_rows + i];
         if (j == 0) {
           o.dzv = r.dzv; o.curv = r.curv; o.h2 = r.h2; o.radius = r.radius; o.sgn = r.sgn; o.flags = r.flags;
+          o.ch = 0.5f * r.curv; o.c2 = 2.0f * r.curv;   // exact
           o.skip = skip[(size_t)i];
         }
         o.eta[j] = r.eta; o.eta2[j] = r.eta2;
@@ -1135,8 +1142,7 @@ lf_status lfk_march(lf_ctx* ctx, int spp, uint64_t key) {
   switch (ctx->march_k) {
     case 1: LF_LAUNCH_MARCH(1); break;
     case 2: LF_LAUNCH_MARCH(2); break;
-    case 3: LF_LAUNCH_MARCH(3); break;
-    default: LF_LAUNCH_MARCH(4); break;
+    default: LF_LAUNCH_MARCH(3); break;
   }
 #undef LF_LAUNCH_MARCH
   lf_timing_end(ctx, LFK_MARCH, ev);
