@@ -159,11 +159,12 @@ __device__ __forceinline__ lanemask surface_event(Ray& r, float dzv, float c, fl
       r.wn *= no_tir ? Rn : 1.0f;  // total reflection: R = 1
       r.wd *= no_tir ? D : 1.0f;
     }
-    const float mu = sgn * sq;
-    const float m = 2.0f * (mu * c);
+    // with mu = sgn sqrt(disc): m = 2 mu c and the -2 mu of the z component as ONE product / fma
+    // each with the wave-uniform factors 2 sgn c and -2 sgn (exact scalings: the same bits)
+    const float m = sq * (c2 * sgn);
     r.dx = fmaf(m, hx, r.dx);
     r.dy = fmaf(m, hy, r.dy);
-    r.dz = fmaf(m, hz, fmaf(-2.0f, mu, r.dz));
+    r.dz = fmaf(m, hz, fmaf(-2.0f * sgn, sq, r.dz));
   } else {        // d' = eta d + g n,  g = sgn(mu) ct - eta mu = sgn (ct - eta sqrt(disc))
     ok &= __ballot(no_tir);
     if (W) {
@@ -259,6 +260,7 @@ struct MarchArgs {
   float inv_stop_h;    // 1 / stop_h (correctly rounded)
   float half_w, half_h;  // 0.5 * W, 0.5 * H
   float vz;            // pupil_z - z_sensor
+  float lobe_thr;      // d.s above this may lie inside the sun's lobe (conservative, see lfk_march)
 };
 
 // One program row for a GROUP of up to 3 wavelengths: the geometry of the interface once, the
@@ -350,6 +352,7 @@ void k_march(const LfLensDev* __restrict__ lens, const LfPairsDev* __restrict__ 
   const float inv_stop_h = a.inv_stop_h, half_w = a.half_w, half_h = a.half_h, vz_u = a.vz;
   const float sx = lens->sun_dir[0], sy = lens->sun_dir[1], sz = lens->sun_dir[2];
   const float inv_1mc = lens->sun_inv_one_minus_cos, sun_ss = lens->sun_ss;
+  const float lobe_thr = a.lobe_thr;
   const int GG = a.G * a.G;
 
   unsigned n_light = 0;     // per lane
@@ -615,14 +618,15 @@ void k_march(const LfLensDev* __restrict__ lens, const LfPairsDev* __restrict__ 
           } else if (endfl & LF_EV_END) {
             // ---- a path is complete ---------------------------------------------------------
             scene32 += nlive;
-            // inside the sun's lobe?  (cheap pre-test: 1 - d.s cancels -- its absolute error of ~1e-7
-            // is ~1e-4 of a 0.05 rad lobe -- so it only selects, with a 1/16 margin; the lobe factor
-            // itself is evaluated without cancellation after the weight re-march, see lobe_q)
+            // inside the sun's lobe?  (cheap pre-test on d.s alone: 1 - d.s cancels -- its absolute
+            // error of ~1e-7 is ~1e-4 of a 0.05 rad lobe -- so it only SELECTS, against a threshold
+            // with a 1/16 margin computed once on the host; the lobe factor itself is evaluated
+            // without cancellation after the weight re-march, see lobe_q, and decides)
             lanemask lit[K], lit_any = 0ull;
 #pragma unroll
             for (int j = 0; j < K; j++) {
               const float cg = fmaf(r[j].dx, sx, fmaf(r[j].dy, sy, r[j].dz * sz));
-              lit[j] = alive[j] & __ballot((1.0f - cg) * inv_1mc < 1.0625f);
+              lit[j] = alive[j] & __ballot(cg > lobe_thr);
               lit_any |= lit[j];
             }
             if (lit_any != 0ull) {
@@ -1106,6 +1110,15 @@ lf_status lfk_march(lf_ctx* ctx, int spp, uint64_t key) {
   a.inv_stop_h = 1.0f / ctx->lens.stop_h;
   a.half_w = 0.5f * (float)ctx->W; a.half_h = 0.5f * (float)ctx->H;
   a.vz = ctx->lens.pupil_z - ctx->lens.z_sensor;
+  {
+    // every direction the float test (1 - d.s) * inv < 1.0625 accepts (the oracle's selection, a
+    // superset of the lobe itself) has d.s above this: 1 - d.s is exact for d.s >= 1/2, the product
+    // rounds by <= 2^-24 relative; the absolute 4e-7 covers lobes down to a few 1e-4 rad
+    const double thr = 1.0 - (1.0625 / (double)ctx->lens.sun_inv_one_minus_cos) * (1.0 + 1e-6) - 4e-7;
+    float t = (float)thr;
+    if ((double)t > thr) t = std::nextafterf(t, -2.0f);
+    a.lobe_thr = t;
+  }
   // tile rows (8 sensor rows each) of the band that belong to this context's interleave phase
   const int t_lo = ctx->y0 / 8, t_hi = (ctx->y1 + 7) / 8;  // [t_lo, t_hi)
   const int period = ctx->row_period, phase = ctx->row_phase;
