@@ -129,7 +129,11 @@ __device__ bool closest_hit(const LfBvhNode* __restrict__ nodes, const LfPrim* _
     const double tz1 = (nd.bmin[2] - r.o.z) * iz, tz2 = (nd.bmax[2] - r.o.z) * iz;
     const double tmin = fmax(fmax(fmin(tx1, tx2), fmin(ty1, ty2)), fmin(tz1, tz2));
     const double tmax = fmin(fmin(fmax(tx1, tx2), fmax(ty1, ty2)), fmax(tz1, tz2));
-    const double slack = 4.5e-16 * fmax(fabs(tmin), fabs(tmax));
+    // (an infinite bound -- a ray parallel to a slab and outside it has tmin = +inf -- must not turn
+    // the slack into inf: inf - inf compares false with everything and the box would never be culled;
+    // such rays, e.g. the texel-grid directions of an environment light, then walk the whole tree)
+    const double tm = fmax(fabs(tmin), fabs(tmax));
+    const double slack = tm < 1e300 ? 4.5e-16 * tm : 0.0;
     if (tmin - slack > tmax + slack || tmax + slack < r.min_t || tmin - slack > r.max_t) continue;
     if (nd.count > 0) {
       for (int i = 0; i < nd.count; i++) {
@@ -190,11 +194,15 @@ __device__ inline int upper_bound_d(const double* __restrict__ a, int n, double 
   return lo;
 }
 
+// SOFT = false is the kernel of scenes with delta lights only (no sampled light, no environment, no
+// hemisphere sampling): the sampled-light code costs ~100 vector registers, i.e. one of the three
+// waves a SIMD otherwise holds (25 -> 35 ms on the 1080p timing frame), so it is compiled out there.
+template <bool SOFT>
 __device__ V3 radiance(const LfSceneDev& sc, const LfEnvDev& ev, bool hemisphere, DRay r,
                        int* __restrict__ stack, int ns_area_light, uint4 rng_ctr, uint2 rng_key) {
   Hit isect;
   if (!closest_hit(sc.nodes, sc.prims, r, &isect, stack))   // pathtracer.cpp:291-292
-    return ev.w ? env_sample_dir(ev, r.d) : v3(0, 0, 0);
+    return (SOFT && ev.w) ? env_sample_dir(ev, r.d) : v3(0, 0, 0);
   const LfMaterial& m = sc.materials[isect.material];
   const V3 emission = m.kind == 1 ? v3(m.rgb[0], m.rgb[1], m.rgb[2]) : v3(0, 0, 0);
   V3 X, Y, Z;
@@ -208,7 +216,7 @@ __device__ V3 radiance(const LfSceneDev& sc, const LfEnvDev& ev, bool hemisphere
   // (kind 2: the value of f itself, as a host that can only call BSDF::f hands it over)
   const V3 f = m.kind == 0 ? mulv(v3(ipi, ipi, ipi), v3(m.rgb[0], m.rgb[1], m.rgb[2]))
              : m.kind == 2 ? v3(m.rgb[0], m.rgb[1], m.rgb[2]) : v3(0, 0, 0);
-  if (hemisphere) {
+  if (SOFT && hemisphere) {
     // estimate_direct_lighting_hemisphere (pathtracer.cpp:86-138): uniform directions over the
     // hemisphere of the hit point, lights.size() * ns_area_light of them; what they find is the
     // EMISSION of whatever surface they hit (lights as such are not sampled, the environment not seen)
@@ -237,6 +245,7 @@ __device__ V3 radiance(const LfSceneDev& sc, const LfEnvDev& ev, bool hemisphere
   }
   for (int l = 0; l < sc.n_lights; l++) {
     const LfLight& lt = sc.lights[l];
+    if (!SOFT && lt.type >= 2) continue;   // (never listed when this instantiation is launched)
     const int num_samples = lt.type >= 2 ? ns_area_light : 1;   // is_delta_light() ? 1 : ns_area_light
     total_samples += num_samples;
     for (int k = 0; k < num_samples; k++) {
@@ -250,7 +259,7 @@ __device__ V3 radiance(const LfSceneDev& sc, const LfEnvDev& ev, bool hemisphere
         const V3 d = v3(lt.v[0], lt.v[1], lt.v[2]) - hit_p;
         wi = unit(d);
         dist = norm(d);
-      } else {
+      } else if (SOFT) {
         const uint4 rr = philox4x32_10(make_uint4(rng_ctr.x, rng_ctr.y, 0x11640000u + (unsigned)l, (unsigned)k),
                                        rng_key);
         const double xi1 = random_uniform_from_raw(rr.x), xi2 = random_uniform_from_raw(rr.y);
@@ -322,7 +331,12 @@ __device__ inline double random_uniform_from_raw(unsigned raw) {  // util/random
 }
 
 // the sample loop of raytrace_pixel (pathtracer.cpp:831-875)
-__global__ __launch_bounds__(256) void k_scene_term(LfSceneDev sc, LfEnvDev ev, int hemisphere,
+// (second bound: 4 waves per SIMD = 128 registers.  Left alone the sampled-light instantiation takes
+// 246 and runs 2 waves; bounded it spills ~120 registers to scratch in its cold paths and is still
+// 30 % faster -- timing frame: 155 -> 110 ms with an area light and the environment, 25.4 -> 22.5 ms
+// with delta lights only; profiles/r02_scene_term_timing.json)
+template <bool SOFT>
+__global__ __launch_bounds__(256, 4) void k_scene_term(LfSceneDev sc, LfEnvDev ev, int hemisphere,
                                                     LfCamera cam, int W, int H, int y0,
                                                     int y1, int ns_aa, int ns_area_light,
                                                     int samples_per_batch, double max_tolerance,
@@ -363,7 +377,7 @@ __global__ __launch_bounds__(256) void k_scene_term(LfSceneDev sc, LfEnvDev ev, 
              (dir.x * cam.c2w[3] + dir.y * cam.c2w[4]) + dir.z * cam.c2w[5],
              (dir.x * cam.c2w[6] + dir.y * cam.c2w[7]) + dir.z * cam.c2w[8]);
     r.min_t = cam.n_clip; r.max_t = cam.f_clip;
-    const V3 L = radiance(sc, ev, hemisphere != 0, r, stack, ns_area_light, make_uint4((unsigned)p, (unsigned)sample, 0u, 0u),
+    const V3 L = radiance<SOFT>(sc, ev, hemisphere != 0, r, stack, ns_area_light, make_uint4((unsigned)p, (unsigned)sample, 0u, 0u),
                           make_uint2((unsigned)key, (unsigned)(key >> 32)));
     // Vector3D::illum (vector3D.h:231-233): float coefficients, double arithmetic, float result
     const float illum = (float)((0.2126f * L.x + 0.7152f * L.y) + 0.0722f * L.z);
@@ -641,11 +655,14 @@ lf_status lf_render_scene_term(lf_ctx* ctx) {
   }
   const size_t px = (size_t)(ctx->y1 - ctx->y0) * ctx->W;
   if (px == 0) return LF_OK;
-  hipLaunchKernelGGL(k_scene_term, dim3((unsigned)((px + 255) / 256)), dim3(256), 0, ctx->stream,
-                     ctx->scene_dev, ctx->env_dev, ctx->hemisphere_sample ? 1 : 0, ctx->cam, ctx->W, ctx->H,
-                     ctx->y0, ctx->y1, ctx->ns_aa,
-                     ctx->ns_area_light, ctx->samples_per_batch, ctx->max_tolerance, ctx->jitter_aa_raw, ctx->jitter_mode,
-                     ctx->jitter_key, ctx->scene);
+  const bool soft = ctx->scene_dev.n_soft_lights > 0 || ctx->env_dev.w > 0 || ctx->hemisphere_sample;
+#define LF_LAUNCH_SCENE(SOFT)                                                                            \
+  hipLaunchKernelGGL(k_scene_term<SOFT>, dim3((unsigned)((px + 255) / 256)), dim3(256), 0, ctx->stream,  \
+                     ctx->scene_dev, ctx->env_dev, ctx->hemisphere_sample ? 1 : 0, ctx->cam, ctx->W,    \
+                     ctx->H, ctx->y0, ctx->y1, ctx->ns_aa, ctx->ns_area_light, ctx->samples_per_batch,  \
+                     ctx->max_tolerance, ctx->jitter_aa_raw, ctx->jitter_mode, ctx->jitter_key, ctx->scene)
+  if (soft) LF_LAUNCH_SCENE(true); else LF_LAUNCH_SCENE(false);
+#undef LF_LAUNCH_SCENE
   LF_HIP(ctx, hipGetLastError());
   return LF_OK;
 }

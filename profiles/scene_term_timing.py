@@ -2,8 +2,9 @@
 """Measurement for SURVEY section 8 row f2 (the scene-radiance term, lf_scene.hip): one 1080p frame
 of a synthetic scene -- a 96x96 height-field of diffuse triangles (18 432), 64 diffuse spheres, one
 emissive sphere, a sun and a point light -- at ns_aa = 16 camera rays per pixel, counter jitter.
-Prints the device time per frame and camera rays / s, and the time of the CPU oracle
-(oracle/lf_scene_oracle.c, single thread, MT19937 order) on a 240x135 frame of the same scene.
+Prints the device time per frame and camera rays / s -- with the two delta lights, and with an
+area light + the environment listed as sampled lights on top (ns_area_light = 4: 8 more shadow rays
+per hit).  (The CPU side of this comparison is the checker's business: tests/ and bench.py.)
 Usage (GPU box, repo root): python3 profiles/scene_term_timing.py"""
 import json
 import math
@@ -17,7 +18,6 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 import __graft_entry__ as g  # noqa: E402
-from oracle import lfo  # noqa: E402
 
 pkg = g.load_package()
 rng = np.random.default_rng(3)
@@ -68,11 +68,24 @@ for _ in range(3):
     lf.render_scene_term()
 lf.synchronize()
 gpu_ms = (time.perf_counter() - t0) / 3 * 1e3
-w, h = 240, 135
+out = {"frame": f"{W}x{H}, ns_aa {ns}", "primitives": len(tris) + len(spheres),
+       "gpu_ms_per_frame": gpu_ms, "gpu_camera_rays_per_s": W * H * ns / (gpu_ms * 1e-3)}
+# the same frame with sampled lights: an area light above the field and a small environment map
+rows = [[0.0, 1.0, 0.95, 0.8, *sun] + [0.0] * 9,
+        [1.0, 8.0, 8.0, 10.0, 2.0, 2.5, -5.0] + [0.0] * 9,
+        [3.0, 6.0, 6.0, 6.0, 0.0, 4.0, -8.0, 0.0, -1.0, 0.0, 2.0, 0.0, 0.0, 0.0, 0.0, 2.0],
+        [4.0] + [0.0] * 15]
+env = np.ones((16, 32, 3)) * 0.3
+env[3:5, 20:23] = 25.0
+lf.set_scene_lights(rows)
+lf.set_light_samples(4)
+lf.set_environment_map(env)
+lf.render_scene_term(); lf.synchronize()
 t0 = time.perf_counter()
-lfo.scene_term(w, h, ns, c2w, pos, hf, vfov(w, h), spheres, tris, lights, np.arange(w * h, dtype=np.uint32))
-cpu_s = time.perf_counter() - t0
-print(json.dumps({"frame": f"{W}x{H}, ns_aa {ns}", "primitives": len(tris) + len(spheres),
-                  "gpu_ms_per_frame": gpu_ms, "gpu_camera_rays_per_s": W * H * ns / (gpu_ms * 1e-3),
-                  "cpu_oracle_s_240x135": cpu_s, "cpu_camera_rays_per_s_1_thread": w * h * ns / cpu_s}))
+for _ in range(3):
+    lf.render_scene_term()
+lf.synchronize()
+soft_ms = (time.perf_counter() - t0) / 3 * 1e3
+out.update(gpu_ms_per_frame_sampled_lights=soft_ms, sampled_lights="area + environment, ns_area_light 4")
+print(json.dumps(out))
 lf.close()
