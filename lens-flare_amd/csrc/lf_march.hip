@@ -1111,9 +1111,11 @@ lf_status lfk_march(lf_ctx* ctx, int spp, uint64_t key) {
   a.half_w = 0.5f * (float)ctx->W; a.half_h = 0.5f * (float)ctx->H;
   a.vz = ctx->lens.pupil_z - ctx->lens.z_sensor;
   {
-    // every direction the float test (1 - d.s) * inv < 1.0625 accepts (the oracle's selection, a
-    // superset of the lobe itself) has d.s above this: 1 - d.s is exact for d.s >= 1/2, the product
-    // rounds by <= 2^-24 relative; the absolute 4e-7 covers lobes down to a few 1e-4 rad
+    // candidate selection (the contract, the same expression in oracle/lf_geo_oracle.c): d.s above
+    // 1 - 1.0625 (1 - cos alpha) - 4e-7 MAY lie inside the lobe.  The 1/16 margin is relative, the
+    // 4e-7 absolute: the float dot product of two unit vectors is only good to ~2e-7, so a relative
+    // margin alone (the round-1 float test (1 - d.s) * inv < 1.0625) loses part of a sub-milliradian
+    // sun's lobe (1 - cos(0.8 mrad) = 3.2e-7).  Rounded down: float(thr) never exceeds thr.
     const double thr = 1.0 - (1.0625 / (double)ctx->lens.sun_inv_one_minus_cos) * (1.0 + 1e-6) - 4e-7;
     float t = (float)thr;
     if ((double)t > thr) t = std::nextafterf(t, -2.0f);

@@ -82,7 +82,7 @@ static float unit24(uint32_t r) { return (float)(r >> 8) * 5.9604644775390625e-8
 typedef struct {
   float zv[GEO_MAX_SURF], curv[GEO_MAX_SURF], h2[GEO_MAX_SURF];
   float eta_fwd[GEO_MAX_LAMBDA][GEO_MAX_SURF], eta_bwd[GEO_MAX_LAMBDA][GEO_MAX_SURF];
-  float z_sensor, pitch, pupil_h, pupil_z, geom_norm, inv_stop_h, inv_1mc, sun_ss;
+  float z_sensor, pitch, pupil_h, pupil_z, geom_norm, inv_stop_h, inv_1mc, sun_ss, lobe_thr;
 } geo_derived;
 
 static void derive(const geo_lens* L, int W, geo_derived* D) {
@@ -110,6 +110,16 @@ static void derive(const geo_lens* L, int W, geo_derived* D) {
   D->geom_norm = (float)((3.14159265358979323846 * (double)D->pupil_h * (double)D->pupil_h) / (dist * dist));
   D->inv_stop_h = 1.0f / (L->stop >= 0 ? L->semi_ap[L->stop] : 1.0f);
   D->inv_1mc = (float)(1.0 / (1.0 - cos((double)L->sun_angular_radius)));
+  {
+    /* candidate selection: d.s above this MAY lie inside the lobe (the contract's threshold: a 1/16
+       margin on 1 - cos plus 4e-7 absolute, which covers the rounding of the float dot product for
+       any lobe size -- a float test on (1 - d.s) * inv loses sub-milliradian suns); the lobe factor
+       itself (cancellation-free, below) decides */
+    const double thr = 1.0 - (1.0625 / (double)D->inv_1mc) * (1.0 + 1e-6) - 4e-7;
+    float t = (float)thr;
+    if ((double)t > thr) t = nextafterf(t, -2.0f);
+    D->lobe_thr = t;
+  }
   /* |s|^2 of the float unit vector as stored (exact in double, then narrowed) */
   D->sun_ss = (float)((double)L->sun_dir[0] * L->sun_dir[0] + (double)L->sun_dir[1] * L->sun_dir[1] +
                       (double)L->sun_dir[2] * L->sun_dir[2]);
@@ -325,14 +335,14 @@ void geo_trace(const geo_lens* L, int W, int H, int y0, int y1, int spp, const u
             if (st == VIGNETTED) { c.rays_vignetted++; continue; }
             if (st == TIR) { c.rays_tir++; continue; }
             c.rays_reached_scene++;
-            /* the sun's lobe, DESIGN.md "march arithmetic": a cheap pre-test on 1 - d.s (which
-             * cancels: its absolute error ~1e-7 is ~1e-4 of a 0.05 rad lobe) with a 1/16 margin,
+            /* the sun's lobe, DESIGN.md "march arithmetic": candidates are selected on d.s alone
+             * against the conservative threshold of geo_derive (1 - d.s cancels: it cannot decide),
              * then 1 - cos(theta) = |d x s|^2 / (|d|^2 |s|^2 + sqrt(|d|^2 |s|^2) d.s), which has no
              * cancellation and does not assume |d| = |s| = 1 */
             float sx = L->sun_dir[0], sy = L->sun_dir[1], sz = L->sun_dir[2];
             float cg = fmaf(r.d[0], sx, fmaf(r.d[1], sy, r.d[2] * sz));
             float qq = 2.0f;
-            if ((1.0f - cg) * D.inv_1mc < 1.0625f) {
+            if (cg > D.lobe_thr) {
               float cx = fmaf(r.d[1], sz, -(r.d[2] * sy)), cy = fmaf(r.d[2], sx, -(r.d[0] * sz));
               float cz = fmaf(r.d[0], sy, -(r.d[1] * sx));
               float c2 = fmaf(cx, cx, fmaf(cy, cy, cz * cz));

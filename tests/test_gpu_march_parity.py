@@ -86,6 +86,21 @@ def test_dgauss_all_pairs_bit_exact(pkg, lf, W, H, spp):
     assert cnt["rays_hit_light"] > 0 and og.max() > 0  # the test is not vacuous
 
 
+@pytest.mark.parametrize("radius", [0.0008, 0.004, 0.3, 1.4])
+def test_sun_lobes_from_sub_milliradian_to_wide(pkg, lf, radius):
+    """The walk selects candidate rays with a host-side threshold on d.s (conservative against the
+    float test the oracle applies, lf_march.hip lfk_march); the lobe factor itself decides.  Pixels and
+    counters must stay those of the oracle from a 0.8 mrad sun to one of 1.4 rad."""
+    lens = pkg.load_lens_file("dgauss11.lens")
+    mask = load_texels("pentbig500_14.png")
+    sun = dict(direction=[0.01, -0.015, -1.0], radiance=[1.0, 0.9, 0.5], angular_radius=radius)
+    W, H, spp = (96, 64, 64) if radius < 0.01 else (40, 24, 16)
+    g, cnt, og, ocnt = _run(pkg, lf, lens, W, H, spp, 0xBEEF, mask, sun=sun)
+    assert cnt == ocnt
+    assert np.array_equal(g, og)
+    assert cnt["rays_hit_light"] > 0 and og.max() > 0
+
+
 def test_thin_lens_config_c1(pkg, lf):
     """BASELINE.json configs[0]: single thin lens (2 spherical surfaces), 256x256, 1 spp, one
     light; no stop, one ghost pair (0,1) + primary.  GPU == CPU oracle bit for bit; plus 4 spp."""
