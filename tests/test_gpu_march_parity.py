@@ -145,6 +145,90 @@ def test_eight_wavelengths_config_c5_subset(pkg, lf):
     assert np.array_equal(g, og) and og.max() > 0
 
 
+@pytest.mark.parametrize("n_lambda", [1, 2, 4, 5, 6, 7])
+def test_every_wavelength_count_groups_correctly(pkg, lf, n_lambda):
+    """The wavelengths walk the path tree in groups of up to three per lane (1, 2, 3, 2+2, 3+2, 3+3,
+    3+3+1, 3+3+2): every count, short last group included, bit for bit against the oracle -- which
+    marches each wavelength of each path on its own."""
+    lens3 = pkg.load_lens_file("dgauss11.lens")
+    t = np.linspace(0.0, 2.0, n_lambda) if n_lambda > 1 else np.array([1.0])
+    ior = np.stack([np.array([np.interp(tt, [0, 1, 2], lens3["ior"][:, k]) for k in range(lens3["n"])])
+                    for tt in t]).astype(np.float32)
+    lens = dict(lens3, ior=ior)
+    w = np.zeros((n_lambda, 3), np.float32)
+    for l, tt in enumerate(t):
+        for c in range(3):
+            w[l, c] = max(0.0, 1.0 - abs(tt - c)) * 3.0 / n_lambda
+    mask = load_texels("pentbig500_14.png")
+    W, H, spp = 24, 16, 9
+    lf.set_frame(W, H)
+    lf.set_aperture(pkg.APERTURE_STARBURST, mask)
+    lf.set_lens(lens)
+    lf.set_lambda_rgb(w)
+    lf.set_sun(SUN["direction"], SUN["radiance"], SUN["angular_radius"])
+    lf.set_ghost_pairs(None, True)
+    lf.reset_counters()
+    lf.trace_ghosts(spp, 1000 + n_lambda)
+    g = lf.read_buffer(pkg.GHOST_BUFFER)
+    og, ocnt = lfo.geo_trace(lens, W, H, 0, H, spp, 1000 + n_lambda, None, True, mask, SUN["direction"],
+                             SUN["radiance"], SUN["angular_radius"], lambda_rgb=w)
+    assert lf.counters() == ocnt and ocnt["rays_launched"] == W * H * spp * n_lambda * 46
+    assert np.array_equal(g, og) and og.max() > 0
+
+
+def _random_lens(rng):
+    """A random stack of singlets / cemented groups with a stop somewhere (or none): nothing that
+    focuses, everything the event arithmetic and the path-tree builder can meet -- flats, weak and
+    steep curvatures of both signs, total reflection, rays that miss the sphere, a stop next to the
+    sensor or in front of everything."""
+    n_glass = int(rng.integers(1, 4))
+    rows = []   # radius, thickness, [ior x3], semi_aperture
+    for _ in range(n_glass):
+        m = int(rng.integers(2, 4))          # surfaces of this group (2 = singlet, 3 = cemented pair)
+        for k in range(m):
+            kind = rng.random()
+            rad = 0.0 if kind < 0.15 else float(rng.choice([-1, 1]) * (12.0 if kind < 0.3 else 1.0) *
+                                                 rng.uniform(14.0, 120.0) ** (1.6 if kind > 0.85 else 1.0))
+            nd = float(rng.uniform(1.45, 1.85)) if k < m - 1 else 1.0
+            disp = (nd - 1.0) / float(rng.uniform(25.0, 65.0))
+            rows.append([rad, float(rng.uniform(0.4, 7.0)), nd - 0.3 * disp, nd, nd + 0.7 * disp,
+                         float(rng.uniform(6.0, 14.0))])
+    stop = int(rng.integers(-1, len(rows) + 1))
+    stop = -1 if stop < 0 else stop
+    if stop >= 0:
+        # (the stop sits in air: insert it in front of a group's first surface, or behind the last)
+        firsts = [0] + [i + 1 for i, r in enumerate(rows) if r[3] == 1.0]
+        at = firsts[stop % len(firsts)]
+        rows.insert(at, [0.0, float(rng.uniform(0.5, 5.0)), 1.0, 1.0, 1.0, float(rng.uniform(4.0, 9.0))])
+        stop = at
+    rows[-1][1] = float(rng.uniform(25.0, 60.0))
+    a = np.array(rows, np.float64)
+    return dict(n=len(rows), stop=stop, radius=a[:, 0].astype(np.float32), thickness=a[:, 1].astype(np.float32),
+                ior=a[:, 2:5].T.astype(np.float32).copy(), semi_aperture=a[:, 5].astype(np.float32),
+                sensor_width_mm=36.0)
+
+
+@pytest.mark.parametrize("seed", list(range(12)))
+def test_random_prescriptions_bit_exact(pkg, lf, seed):
+    rng = np.random.default_rng(4242 + seed)
+    lens = _random_lens(rng)
+    mask = load_texels("pentbiglines.png") if seed % 2 else np.ones((8, 8), np.float32)
+    sun = dict(direction=[float(rng.uniform(-0.1, 0.1)), float(rng.uniform(-0.1, 0.1)), -1.0],
+               radiance=[1.0, 0.8, 0.6], angular_radius=0.2)
+    W, H, spp = 24, 16, 16
+    try:
+        g, cnt, og, ocnt = _run(pkg, lf, lens, W, H, spp, 31 + seed, mask, sun=sun)
+    except pkg.LensFlareError as e:
+        # a prescription the library refuses is refused with a message, not marched wrongly
+        assert str(e)
+        return
+    n_pairs = sum(1 for i in range(lens["n"]) for j in range(i + 1, lens["n"])
+                  if i != lens["stop"] and j != lens["stop"])
+    assert cnt["rays_launched"] == W * H * spp * 3 * (n_pairs + 1)
+    assert cnt == ocnt
+    assert np.array_equal(g, og)
+
+
 def test_reference_pair_subset_and_no_primary(pkg, lf):
     """The reference's own enumeration (pathtracer.cpp:735-762): pairs on one side of the stop."""
     lens = pkg.load_lens_file("dgauss11.lens")
