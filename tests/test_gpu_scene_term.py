@@ -10,7 +10,10 @@ import pytest
 from goldenlib import Case, load_texels
 
 pytestmark = pytest.mark.gpu
-SCENE_CASES = ["s96x64_spheres", "s80x60_tris_rotcam"]
+# (z*: random scenes -- spheres inside each other and behind the camera, sliver triangles, arbitrary vertex
+# normals, two suns, point lights, turned cameras -- rendered by the real reference, oracle/make_golden_fuzz.py)
+SCENE_CASES = ["s96x64_spheres", "s80x60_tris_rotcam", "z40x30_fuzz0", "z40x30_fuzz1", "z36x28_fuzz2",
+               "z44x26_fuzz3"]
 
 
 @pytest.fixture(scope="module")
@@ -74,7 +77,7 @@ def test_scene_term_matches_reference(pkg, lf, name):
     # the scene term alone is a substantial part of these frames (the test is not vacuous)
     star = lf.read_buffer(pkg.STARBURST_BUFFER)
     scene = case.sample - case.ghost - star
-    assert (scene.max(axis=-1) > 0.05).mean() > 0.3
+    assert (scene.max(axis=-1) > 0.05).mean() > (0.3 if name[0] == "s" else 0.1)
     assert np.array_equal(lf.write_to_framebuffer(0, 0, case.W, case.H), case.rgba)
 
 

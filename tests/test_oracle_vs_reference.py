@@ -116,7 +116,8 @@ def test_spectral_starburst_reduces_to_the_reference_formula():
     assert np.allclose(ab, a + b, rtol=1e-13, atol=0)
 
 
-@pytest.mark.parametrize("name", ["s96x64_spheres", "s80x60_tris_rotcam"])
+@pytest.mark.parametrize("name", ["s96x64_spheres", "s80x60_tris_rotcam", "z40x30_fuzz0", "z40x30_fuzz1",
+                                  "z36x28_fuzz2", "z44x26_fuzz3"])
 def test_scene_term_oracle_matches_reference(name):
     """Row f2: the sample loop of raytrace_pixel with real geometry (oracle/lf_scene_oracle.c):
     spheres, triangles with interpolated normals, emission, sun + point light, shadow rays --
@@ -134,7 +135,7 @@ def test_scene_term_oracle_matches_reference(name):
     spheres = [(1e4, 1e4, 1e4, 1.0, "d", 0.5, 0.5, 0.5)] + [tuple(s) for s in m["scene"]["spheres"]]
     scene = lfo.scene_term(case.W, case.H, m["ns_aa"], m["c2w"], m["cam_pos"], m["hFov"], m["vFov"],
                            spheres, [tuple(t) for t in m["scene"]["tris"]], lights, order)
-    assert (scene.max(axis=-1) > 0.05).mean() > 0.3
+    assert (scene.max(axis=-1) > 0.05).mean() > (0.3 if name[0] == "s" else 0.1)   # not vacuous
     lfo.set_scene_term(scene)
     try:
         got = lfo.render_pixels(f, tex, st, case.ghost, order, n_threads=8)
