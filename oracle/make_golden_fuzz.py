@@ -17,6 +17,22 @@ sys.path.insert(0, HERE)
 import make_golden as mg  # noqa: E402
 
 NAMES = ["z40x30_fuzz0", "z40x30_fuzz1", "z36x28_fuzz2", "z44x26_fuzz3"]
+# flare-only frames (rows a1-a7): every branch of raytrace_starburst's shaping -- exponent 3 -
+# flare_intensity incl. <= 0 (-> 2), = 3 (-> 0) and > 3 (negative), flare radii from half a pixel to
+# beyond the frame, suns on the frame's edge and outside it, odd sizes, every aperture family
+FLARE = [("q47x31_fuzz0", 47, 31, 2, 0.5, -1.0, "final_apertures/pent2_8.png", "bokeh/octagonbokeh.png",
+          [((0.0, 0.5), (1.0, 0.5, 0.2), 10.0)]),
+         ("q38x52_fuzz1", 38, 52, 1, 200.0, 0.0, "apertures/pentsmalllottalines.png", "final_apertures/pent_11.png",
+          [((0.5, 1.0), (0.3, 0.6, 1.0), 20.0), ((0.25, 0.25), (2.0, 2.0, 2.0), 15.0)]),
+         ("q61x33_fuzz2", 61, 33, 3, 8.0, 3.0, "final_apertures/pent3_18.png", "final_apertures/pent4_13.png",
+          [((0.9, 0.1), (1.0, 1.0, 1.0), 12.0), ((1.2, 0.4), (5.0, 5.0, 5.0), 12.0)]),
+         ("q33x33_fuzz3", 33, 33, 1, 3.0, 5.0, "final_apertures/pent4_15.png", "bokeh/octagonbokeh.png",
+          [((0.49, 0.51), (0.7, 0.8, 0.9), 30.0)]),
+         ("q52x40_fuzz4", 52, 40, 2, 60.0, 2.999, "final_apertures/pentbig2_500_9.png", "final_apertures/pent2_18.png",
+          [((0.13, 0.87), (1.2, 1.1, 1.0), 18.0), ((0.8, 0.2), (0.2, 0.3, 0.4), 18.0),
+           ((0.5, 0.5), (0.05, 0.05, 0.05), 18.0)]),
+         ("q45x29_fuzz5", 45, 29, 1, 25.0, 0.3, "final_apertures/pentbig4_500_17.png", "final_apertures/pent4_17.png",
+          [((0.998, 0.004), (1.0, 0.9, 0.5), 10.0)])]
 
 
 def scene_for(rng, c2w, pos):
@@ -73,6 +89,11 @@ def main():
                  raw_lights=[far + rng.uniform(0.2, 0.9, 3).tolist()],
                  cam=cam, visit="tiles", scene=scene_for(rng, c2w, cam[2]))
         mg.run_case(c, tmp)
+    for k, (name, W, H, ns_aa, radius, intensity, ap, gh, lights) in enumerate(FLARE):
+        rng = np.random.default_rng(9200 + k)
+        cam = (float(rng.uniform(-1.0, 1.0)), float(rng.uniform(-0.4, 0.4)), tuple(rng.uniform(-3, 3, 3).tolist()))
+        mg.run_case(dict(name=name, W=W, H=H, ns_aa=ns_aa, radius=radius, intensity=intensity, ap=ap, gh=gh,
+                         lights=lights, cam=cam, visit="tiles"), tmp)
 
 
 if __name__ == "__main__":

@@ -8,7 +8,9 @@ import numpy as np
 GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
 
 FRAME_CASES = ["f64x48_pentbiglines", "f97x65_odd_rotcam", "f96x64_naive_rgba", "f80x50_two_suns",
-               "f256_pentbiglines", "f1080p_pentbig500_14_scatter", "f4k_pentbiglines_scatter"]
+               "f256_pentbiglines", "f1080p_pentbig500_14_scatter", "f4k_pentbiglines_scatter",
+               # random flare-only frames (oracle/make_golden_fuzz.py): every branch of the starburst shaping
+               "q47x31_fuzz0", "q38x52_fuzz1", "q61x33_fuzz2", "q33x33_fuzz3", "q52x40_fuzz4", "q45x29_fuzz5"]
 
 
 def load_red(name):

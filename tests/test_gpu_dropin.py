@@ -22,7 +22,8 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 BIN = os.path.join(ROOT, "oracle", "_ref", "ref_dump_amd")
 
 CASES = ["f64x48_pentbiglines", "f97x65_odd_rotcam", "f80x50_two_suns", "f96x64_naive_rgba",
-         "s96x64_spheres", "s80x60_tris_rotcam", "c96x72_pyramid_dae", "z40x30_fuzz1", "z44x26_fuzz3"]
+         "s96x64_spheres", "s80x60_tris_rotcam", "c96x72_pyramid_dae", "z40x30_fuzz1", "z44x26_fuzz3",
+         "q47x31_fuzz0", "q38x52_fuzz1", "q52x40_fuzz4"]
 
 
 def _write_inputs(case, tmp):
