@@ -367,7 +367,12 @@ def main():
         lf.render_flare_layer()
         # the exchange step: every rank ends up with the whole frame -- ONE all-gather per frame
         if gather_mode == "cabi":
-            lf.comm_gather(pkg.SAMPLE_BUFFER)          # enqueued on the context's stream
+            # on the context's second stream: the next frame's march overlaps this frame's exchange
+            # (the barrier's lf.synchronize() joins the streams); LF_BENCH_GATHER_SYNC=1: in-stream
+            if os.environ.get("LF_BENCH_GATHER_SYNC") == "1":
+                lf.comm_gather(pkg.SAMPLE_BUFFER)
+            else:
+                lf.comm_gather_async(pkg.SAMPLE_BUFFER)
         elif gather_mode == "torch":
             lf.synchronize()
             sharding.gather_frame(frame_t, W, H, rank, world, GroupDist, scratch=scratch)
@@ -477,7 +482,7 @@ def main():
             "config": {"workload": f"{args.config}: {cfg['text']}" +
                                    (f" [overridden: {W}x{H}, {spp} spp]" if (args.width or args.height or args.spp) else ""),
                        "parallelism": f"{world} GPU(s), 8-row sensor tile rows dealt round-robin"
-                                      + ({"cabi": ", one ncclAllGather per frame inside the C ABI (lf_comm_gather)",
+                                      + ({"cabi": ", one ncclAllGather per frame inside the C ABI (lf_comm_gather_async: overlapped with the next frame's march)",
                                           "torch": ", one torch.distributed nccl all_gather per frame",
                                           "host": ", REHEARSAL: ranks share one GPU, exchange staged through host memory",
                                           "none": ""}[gather_mode]),

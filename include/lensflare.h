@@ -259,6 +259,15 @@ lf_status lf_device_buffer(lf_ctx* ctx, int which, void** dptr, size_t* bytes);
 lf_status lf_comm_get_unique_id(unsigned char id[LF_COMM_ID_BYTES]);
 lf_status lf_comm_init_rank(lf_ctx* ctx, int nranks, int rank, const unsigned char id[LF_COMM_ID_BYTES]);
 lf_status lf_comm_gather(lf_ctx* ctx, int which);
+/* The same exchange on the context's second stream, so that it overlaps what the host queues next
+ * (a sequence of frames: frame k + 1 is marched while frame k is exchanged).  The main stream waits
+ * only until this rank's rows have been copied out; the rows the exchange fills in belong to other
+ * ranks.  lf_comm_wait makes the main stream wait for the exchange; lf_synchronize and the read
+ * functions (lf_read_tile / _pixel, lf_write_to_framebuffer, lf_save_image_rgba) do so themselves.
+ * Until then the buffer's rows of the OTHER ranks are undefined; do not change the frame size, band or
+ * interleave while an exchange is pending (those calls drain it first). */
+lf_status lf_comm_gather_async(lf_ctx* ctx, int which);
+lf_status lf_comm_wait(lf_ctx* ctx);
 lf_status lf_comm_destroy(lf_ctx* ctx);
 /* One process, n devices (a C++ host such as the CGL application): one context + stream per device
  * and one communicator over them (ncclCommInitAll).  Set-up calls go to every context

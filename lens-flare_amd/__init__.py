@@ -35,7 +35,8 @@ ABI_SYMBOLS = [
     "lf_write_to_framebuffer", "lf_save_image_rgba", "lf_device_buffer", "lf_set_lens", "lf_set_lambda_rgb", "lf_set_sun",
     "lf_set_sun_from_flares", "lf_paraxial_efl", "lf_set_ghost_pairs", "lf_set_pupil_subcells", "lf_trace_ghosts", "lf_generate_lens_rays", "lf_get_counters", "lf_reset_counters", "lf_get_executed_events", "lf_native_sqrt", "lf_set_starburst_spectrum", "lf_load_collada", "lf_march_tables",
     "lf_timing_enable", "lf_timing_reset", "lf_timing_get",
-    "lf_comm_get_unique_id", "lf_comm_init_rank", "lf_comm_gather", "lf_comm_destroy",
+    "lf_comm_get_unique_id", "lf_comm_init_rank", "lf_comm_gather", "lf_comm_gather_async", "lf_comm_wait",
+    "lf_comm_destroy",
     "lf_group_create", "lf_group_destroy", "lf_group_size", "lf_group_ctx", "lf_group_last_error",
     "lf_group_set_frame", "lf_group_for_each", "lf_group_gather",
 ]
@@ -207,6 +208,13 @@ class LensFlare:
 
     def comm_gather(self, which):
         self._ck(self.lib.lf_comm_gather(self.ctx, int(which)))
+
+    def comm_gather_async(self, which):
+        """The exchange on the context's second stream: overlaps whatever is queued next."""
+        self._ck(self.lib.lf_comm_gather_async(self.ctx, int(which)))
+
+    def comm_wait(self):
+        self._ck(self.lib.lf_comm_wait(self.ctx))
 
     def comm_destroy(self):
         self._ck(self.lib.lf_comm_destroy(self.ctx))

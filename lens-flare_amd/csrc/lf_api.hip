@@ -234,6 +234,8 @@ lf_status lf_set_stream(lf_ctx* ctx, void* hip_stream) {
 
 lf_status lf_synchronize(lf_ctx* ctx) {
   if (!ctx) return LF_ERR_INVALID;
+  lf_status js = lf_comm_join(ctx);   // an exchange still running on the second stream
+  if (js != LF_OK) return js;
   LF_HIP(ctx, hipStreamSynchronize(ctx->stream));
   return LF_OK;
 }
@@ -241,6 +243,7 @@ lf_status lf_synchronize(lf_ctx* ctx) {
 // (re)allocate the frame-sized buffers for `rows` rows; content is lost
 static lf_status alloc_frame_buffers(lf_ctx* ctx, int rows) {
   LF_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  if (ctx->comm_stream) { LF_HIP(ctx, hipStreamSynchronize(ctx->comm_stream)); ctx->comm_pending = false; }
   free_frame_buffers(ctx);
   ctx->H_alloc = rows;
   size_t n = (size_t)ctx->W * ctx->H_alloc;
@@ -555,6 +558,7 @@ lf_status lf_read_tile(lf_ctx* ctx, int which, int x0, int y0, int x1, int y1, d
     return lf_fail(ctx, LF_ERR_INVALID, "tile out of range");
   if (x0 == x1 || y0 == y1) return LF_OK;
   const double* src = which == 0 ? ctx->sample : which == 1 ? ctx->ghost : ctx->star;
+  { const lf_status js = lf_comm_join(ctx); if (js != LF_OK) return js; }
   LF_HIP(ctx, hipStreamSynchronize(ctx->stream));
   const size_t tw = (size_t)(x1 - x0);
   if (pixel_stride == 3) {
@@ -585,6 +589,7 @@ lf_status lf_write_to_framebuffer(lf_ctx* ctx, int x0, int y0, int x1, int y1, u
   if (row_stride < (size_t)(x1 - x0)) return lf_fail(ctx, LF_ERR_INVALID, "row_stride < tile width");
   if (x0 == x1 || y0 == y1) return LF_OK;
   LF_HIP(ctx, hipSetDevice(ctx->device));
+  { const lf_status js = lf_comm_join(ctx); if (js != LF_OK) return js; }
   if (y0 < ctx->rgba_y0 || y1 > ctx->rgba_y1) {
     // tonemap the current band and whatever else the tile needs (the reference tonemaps exactly
     // the tile, image.h:208-223; whole rows keep the launch simple), remember the rows done
@@ -606,6 +611,7 @@ lf_status lf_save_image_rgba(lf_ctx* ctx, uint32_t* dst) {
   if (ctx->W == 0) return lf_fail(ctx, LF_ERR_STATE, "lf_save_image_rgba before lf_set_frame");
   if (!ctx->sample_valid) return lf_fail(ctx, LF_ERR_STATE, "lf_save_image_rgba before lf_render_flare_layer");
   LF_HIP(ctx, hipSetDevice(ctx->device));
+  { const lf_status js = lf_comm_join(ctx); if (js != LF_OK) return js; }
   lf_status st = lfk_tonemap(ctx, 0, ctx->H);   // the saved image is always the whole frame
   if (st != LF_OK) return st;
   ctx->rgba_y0 = 0; ctx->rgba_y1 = ctx->H;

@@ -21,6 +21,7 @@
 // cannot form an RCCL communicator; the group then exchanges with peer copies on the streams.
 #include <dlfcn.h>
 
+#include <cstdlib>
 #include <cstring>
 #include <mutex>
 #include <thread>
@@ -101,6 +102,7 @@ lf_status ensure_staging(lf_ctx* ctx, int world) {
   const size_t need = (size_t)(world + 1) * s.groups * s.e;   // send [groups][e] + recv [world][groups][e]
   if (need <= ctx->comm_stage_cap) return LF_OK;
   LF_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  if (ctx->comm_stream) LF_HIP(ctx, hipStreamSynchronize(ctx->comm_stream));
   if (ctx->comm_stage) (void)hipFree(ctx->comm_stage);
   ctx->comm_stage = nullptr; ctx->comm_stage_cap = 0;
   LF_HIP(ctx, hipMalloc((void**)&ctx->comm_stage, need * sizeof(double)));
@@ -108,19 +110,19 @@ lf_status ensure_staging(lf_ctx* ctx, int world) {
   return LF_OK;
 }
 
-lf_status launch_pack(lf_ctx* ctx, int which, int rank, int world) {
+lf_status launch_pack(lf_ctx* ctx, int which, int rank, int world, hipStream_t stream = nullptr) {
   const Shape s = shape(ctx, world);
   const size_t n = s.groups * s.e;
-  hipLaunchKernelGGL(k_pack_rows, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream,
+  hipLaunchKernelGGL(k_pack_rows, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream ? stream : ctx->stream,
                      frame_buffer(ctx, which), ctx->comm_stage, rank, world, s.groups, s.e);
   LF_HIP(ctx, hipGetLastError());
   return LF_OK;
 }
 
-lf_status launch_unpack(lf_ctx* ctx, int which, int rank, int world) {
+lf_status launch_unpack(lf_ctx* ctx, int which, int rank, int world, hipStream_t stream = nullptr) {
   const Shape s = shape(ctx, world);
   const size_t n = (size_t)world * s.groups * s.e;
-  hipLaunchKernelGGL(k_unpack_rows, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream,
+  hipLaunchKernelGGL(k_unpack_rows, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream ? stream : ctx->stream,
                      ctx->comm_stage + s.groups * s.e, frame_buffer(ctx, which), rank, world, s.groups, s.e);
   LF_HIP(ctx, hipGetLastError());
   return LF_OK;
@@ -137,6 +139,9 @@ lf_status check_gather_args(lf_ctx* ctx, int which, int world) {
   return LF_OK;
 }
 
+// tests only: run the whole exchange (pack, all-gather, unpack) even with a single rank
+bool force_exchange() { return std::getenv("LF_COMM_FORCE_EXCHANGE") != nullptr; }
+
 }  // namespace
 
 struct lf_group {
@@ -145,6 +150,14 @@ struct lf_group {
   bool rccl = false;   // false: duplicate devices (rehearsal) -> peer copies instead of a communicator
   std::string err;
 };
+
+lf_status lf_comm_join(lf_ctx* ctx) {
+  if (ctx && ctx->comm_pending) {
+    LF_HIP(ctx, hipStreamWaitEvent(ctx->stream, ctx->comm_ev_done, 0));
+    ctx->comm_pending = false;
+  }
+  return LF_OK;
+}
 
 extern "C" {
 
@@ -182,9 +195,10 @@ lf_status lf_comm_gather(lf_ctx* ctx, int which) {
   const int world = ctx->comm_nranks, rank = ctx->comm_rank;
   lf_status st = check_gather_args(ctx, which, world);
   if (st != LF_OK) return st;
-  if (world == 1) return LF_OK;
+  if (world == 1 && !force_exchange()) return LF_OK;
   Rccl* r = rccl();
   LF_HIP(ctx, hipSetDevice(ctx->device));
+  if ((st = lf_comm_join(ctx)) != LF_OK) return st;     // an asynchronous exchange uses the same staging
   if ((st = ensure_staging(ctx, world)) != LF_OK) return st;
   if ((st = launch_pack(ctx, which, rank, world)) != LF_OK) return st;
   const Shape s = shape(ctx, world);
@@ -194,8 +208,59 @@ lf_status lf_comm_gather(lf_ctx* ctx, int which) {
   return launch_unpack(ctx, which, rank, world);
 }
 
+// The exchange of the frame just rendered, on the context's SECOND stream: pack (after everything the
+// main stream has queued so far), all-gather, unpack.  The main stream only waits for the pack -- the
+// rows it is about to overwrite with the next frame have been copied out by then -- so the next
+// frame's march overlaps this frame's exchange.  The rows the unpack writes belong to other ranks:
+// nothing this rank renders touches them.  lf_comm_wait / lf_synchronize / the read functions join
+// the two streams again.
+lf_status lf_comm_gather_async(lf_ctx* ctx, int which) {
+  if (!ctx) return LF_ERR_INVALID;
+  if (!ctx->comm) return lf_fail(ctx, LF_ERR_STATE, "lf_comm_gather_async before lf_comm_init_rank");
+  const int world = ctx->comm_nranks, rank = ctx->comm_rank;
+  lf_status st = check_gather_args(ctx, which, world);
+  if (st != LF_OK) return st;
+  if (world == 1 && !force_exchange()) return LF_OK;
+  Rccl* r = rccl();
+  LF_HIP(ctx, hipSetDevice(ctx->device));
+  if (!ctx->comm_stream) {
+    LF_HIP(ctx, hipStreamCreateWithFlags(&ctx->comm_stream, hipStreamNonBlocking));
+    LF_HIP(ctx, hipEventCreateWithFlags(&ctx->comm_ev_main, hipEventDisableTiming));
+    LF_HIP(ctx, hipEventCreateWithFlags(&ctx->comm_ev_pack, hipEventDisableTiming));
+    LF_HIP(ctx, hipEventCreateWithFlags(&ctx->comm_ev_done, hipEventDisableTiming));
+  }
+  if ((st = ensure_staging(ctx, world)) != LF_OK) return st;
+  const Shape s = shape(ctx, world);
+  LF_HIP(ctx, hipEventRecord(ctx->comm_ev_main, ctx->stream));
+  LF_HIP(ctx, hipStreamWaitEvent(ctx->comm_stream, ctx->comm_ev_main, 0));
+  if ((st = launch_pack(ctx, which, rank, world, ctx->comm_stream)) != LF_OK) return st;
+  LF_HIP(ctx, hipEventRecord(ctx->comm_ev_pack, ctx->comm_stream));
+  LF_HIP(ctx, hipStreamWaitEvent(ctx->stream, ctx->comm_ev_pack, 0));
+  const ncclResult_t rc = r->AllGather(ctx->comm_stage, ctx->comm_stage + s.groups * s.e, s.groups * s.e,
+                                       ncclDouble, (ncclComm_t)ctx->comm, ctx->comm_stream);
+  if (rc != ncclSuccess) return lf_fail(ctx, LF_ERR_HIP, std::string("ncclAllGather: ") + r->GetErrorString(rc));
+  if ((st = launch_unpack(ctx, which, rank, world, ctx->comm_stream)) != LF_OK) return st;
+  LF_HIP(ctx, hipEventRecord(ctx->comm_ev_done, ctx->comm_stream));
+  ctx->comm_pending = true;
+  return LF_OK;
+}
+
+lf_status lf_comm_wait(lf_ctx* ctx) {
+  if (!ctx) return LF_ERR_INVALID;
+  return lf_comm_join(ctx);
+}
+
 lf_status lf_comm_destroy(lf_ctx* ctx) {
   if (!ctx) return LF_ERR_INVALID;
+  if (ctx->comm_stream) {
+    (void)hipSetDevice(ctx->device);
+    (void)hipStreamSynchronize(ctx->comm_stream);
+    (void)hipEventDestroy(ctx->comm_ev_main); (void)hipEventDestroy(ctx->comm_ev_pack);
+    (void)hipEventDestroy(ctx->comm_ev_done);
+    (void)hipStreamDestroy(ctx->comm_stream);
+    ctx->comm_stream = nullptr; ctx->comm_ev_main = ctx->comm_ev_pack = ctx->comm_ev_done = nullptr;
+    ctx->comm_pending = false;
+  }
   if (ctx->comm) {
     (void)hipSetDevice(ctx->device);
     (void)hipStreamSynchronize(ctx->stream);

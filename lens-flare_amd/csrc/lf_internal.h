@@ -182,6 +182,9 @@ enum LfKernelId { LFK_MARCH = 0, LFK_FLARE_LAYER, LFK_GHOST_RASTER, LFK_DFT, LFK
 struct LfTimedLaunch { int kernel; hipEvent_t start, stop; };
 
 // ---- the context ----------------------------------------------------------------------------
+// makes ctx->stream wait for an exchange still running on ctx->comm_stream (lf_group.hip)
+lf_status lf_comm_join(struct lf_ctx* ctx);
+
 struct lf_ctx {
   int device = 0;
   hipStream_t stream = nullptr;
@@ -265,6 +268,10 @@ struct lf_ctx {
   int comm_nranks = 1, comm_rank = 0;
   double* comm_stage = nullptr;  // send [groups][e] followed by recv [world][groups][e]
   size_t comm_stage_cap = 0;     // doubles
+  // lf_comm_gather_async: the exchange of frame k runs on its own stream while frame k + 1 is marched
+  hipStream_t comm_stream = nullptr;
+  hipEvent_t comm_ev_main = nullptr, comm_ev_pack = nullptr, comm_ev_done = nullptr;
+  bool comm_pending = false;     // an exchange on comm_stream the main stream has not yet waited for
 
   bool timing = false;
   std::vector<LfTimedLaunch> timed;       // launches not folded yet (bounded, see lf_api.hip)

@@ -57,6 +57,53 @@ def test_single_rank_communicator(pkg):
     lf.close()
 
 
+def test_async_exchange_pipeline_of_frames(pkg, monkeypatch):
+    """lf_comm_gather_async: pack / ncclAllGather / unpack on the second stream while the next frame
+    is rendered on the first.  With LF_COMM_FORCE_EXCHANGE the whole path runs on a communicator of
+    one (RCCL copies the rank's slots to itself, the unpack skips them): a sequence of DIFFERENT
+    frames queued back to back, each exchanged asynchronously, must leave exactly the last frame --
+    and every read in between must see the frame that was current, whole."""
+    monkeypatch.setenv("LF_COMM_FORCE_EXCHANGE", "1")
+    lens = pkg.load_lens_file("dgauss11.lens")
+    mask = load_texels("pentbig500_14.png")
+    W, H = 96, 56
+    ref = pkg.LensFlare(0)
+    ref.set_frame(W, H)
+    _setup(pkg, ref, lens, mask)
+    want = []
+    for k in range(4):
+        ref.set_sun([0.03 - 0.02 * k, 0.02, -1.0], SUN["radiance"], SUN["angular_radius"])
+        _frame(ref, 8, 100 + k)
+        want.append(ref.read_buffer(pkg.SAMPLE_BUFFER))
+    ref.close()
+    assert not np.array_equal(want[0], want[3])
+
+    lf = pkg.LensFlare(0)
+    lf.set_frame(W, H)
+    _setup(pkg, lf, lens, mask)
+    lf.comm_init_rank(1, 0, pkg.comm_unique_id())
+    for k in range(4):                       # nothing waits for anything in here
+        lf.set_sun([0.03 - 0.02 * k, 0.02, -1.0], SUN["radiance"], SUN["angular_radius"])
+        _frame(lf, 8, 100 + k)
+        lf.comm_gather_async(pkg.SAMPLE_BUFFER)
+    assert np.array_equal(lf.read_buffer(pkg.SAMPLE_BUFFER), want[3])     # the read joins the streams
+    # ... interleaved with reads, synchronous gathers and an explicit wait
+    for k in (1, 0, 2):
+        lf.set_sun([0.03 - 0.02 * k, 0.02, -1.0], SUN["radiance"], SUN["angular_radius"])
+        _frame(lf, 8, 100 + k)
+        lf.comm_gather_async(pkg.SAMPLE_BUFFER)
+        if k == 0:
+            lf.comm_gather(pkg.SAMPLE_BUFFER)
+        if k == 2:
+            lf.comm_wait()
+        assert np.array_equal(lf.read_buffer(pkg.SAMPLE_BUFFER), want[k])
+    lf.comm_gather_async(pkg.GHOST_BUFFER)
+    lf.synchronize()
+    lf.set_frame(40, 24)                      # a resize drains a pending exchange before it frees the buffers
+    lf.comm_destroy()
+    lf.close()
+
+
 @pytest.mark.parametrize("n,W,H", [(2, 72, 40), (3, 100, 52), (2, 64, 8)])
 def test_group_renders_the_single_gpu_frame(pkg, n, W, H):
     """n contexts (rehearsal group on device 0): round-robin tile rows + gather == one context."""
