@@ -135,6 +135,7 @@ struct LfPairsDev {
   int ev_cnt[LF_MAX_PAIRS + 1];  // N + 2(j - i) rows
   int prog_off;                  // first row of the shared-prefix program (wavelength 0)
   int prog_rows;                 // rows of the program per wavelength
+  int prog_recs;                 // distinct interface records of a wavelength group's program
 };
 
 // One pre-expanded surface event: everything the march needs for it in ONE 32-byte scalar load.
@@ -151,12 +152,22 @@ struct alignas(32) LfEventRow {
 enum { LF_EV_REFLECT = 1, LF_EV_STOP = 2, LF_EV_FLAT = 4 };
 // A program row as the device walks it: the interface once, the index ratios of the up to three
 // wavelengths that march it together (lf_march.hip, k_march<K>); one 64-byte scalar load.
+// (The program is stored in two levels: a 16-byte header per row -- what is particular to the row --
+// and one 64-byte record per distinct (interface, direction of travel) -- the constants of the
+// event, shared by all the rows that cross that interface that way.  As one table of 64-byte rows
+// the double-Gauss program is 27 KB per wavelength group and misses the CU's 16 KB scalar cache on
+// 35 % of its loads (SQC_DCACHE_MISSES, profiles/r02_frontend_counters.json); as 6.8 KB of headers
+// + 1.4 KB of records it stays resident.)
+struct alignas(16) LfProgHdr {
+  int flags;        // as LfEventRow::flags of the per-wavelength program rows
+  int skip;         // jump-table entry of this row: (rows to jump << 2) | state to restore
+  int rec;          // byte offset of this row's record in the group's record table
+  int rec_next;     // ... of the NEXT row's: both loads of the next row can then be issued together
+};
 struct alignas(64) LfProgRow {
   float dzv, curv, h2, radius;
   float sgn;
-  int flags;        // as LfEventRow::flags of the per-wavelength program rows
-  int skip;         // jump-table entry of this row: (rows to jump << 2) | state to restore
-  int pad1;
+  int pad0, pad1, pad2;
   float eta[3];     // wavelength g*K + j of group g (repeated past the group's / the lens' last one)
   float ch;         // curv / 2
   float eta2[3];
@@ -258,8 +269,8 @@ struct lf_ctx {
   size_t events_cap = 0;
   int* skip_dev = nullptr;                     // prog_rows entries: where a dead wave jumps to
   size_t skip_cap = 0;                         // capacities in BYTES
-  LfProgRow* prog_dev = nullptr;               // n_groups x prog_rows packed program rows (+ spare)
-  size_t prog_cap = 0;
+  unsigned char* prog_dev = nullptr;           // the packed program: headers, then records (lf_march.hip pack_program)
+  size_t prog_cap = 0, prog_rec_off = 0;       // bytes; offset of the records
   int march_k = 1;                             // wavelengths (rays per lane) that walk together
   bool events_dirty = true;
 

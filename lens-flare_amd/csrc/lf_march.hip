@@ -263,23 +263,33 @@ struct MarchArgs {
   float lobe_thr;      // d.s above this may lie inside the sun's lobe (conservative, see lfk_march)
 };
 
-// One program row for a GROUP of up to 3 wavelengths: the geometry of the interface once, the
-// index ratios of each wavelength of the group.  64 bytes = ONE s_load_dwordx16.
+// The program of a GROUP of up to 3 wavelengths, in two levels (LfProgHdr / LfProgRow in
+// lf_internal.h): per row a 16-byte header (ONE s_load_dwordx4), per distinct (interface, direction)
+// a 64-byte record (ONE s_load_dwordx16: the geometry once, the index ratios of each wavelength of
+// the group).  A header names its own record and the NEXT row's, so stepping to the next row issues
+// both loads at once; only a jump (a wave that died as a whole) loads header, then record.
 typedef int lf_i16 __attribute__((ext_vector_type(16)));
+typedef int lf_i4 __attribute__((ext_vector_type(4)));
 typedef const lf_i16 __attribute__((address_space(4))) * lf_const_prow_ptr;
-__device__ __forceinline__ LfProgRow load_prow(const LfProgRow* __restrict__ base, unsigned off) {
-  // (base + 32-bit byte offset: the row pointer of the walk is ONE scalar register to advance, and the
-  // load takes it as its SGPR offset)
+typedef const lf_i4 __attribute__((address_space(4))) * lf_const_phdr_ptr;
+__device__ __forceinline__ LfProgRow load_prec(const LfProgRow* __restrict__ base, unsigned off) {
+  // (base + 32-bit byte offset: the load takes it as its SGPR offset)
   typedef const char __attribute__((address_space(4))) * cptr;
   const lf_i16 v = *(lf_const_prow_ptr)((cptr)(base) + off);
   LfProgRow r;
   r.dzv = __int_as_float(v[0]); r.curv = __int_as_float(v[1]); r.h2 = __int_as_float(v[2]);
-  r.radius = __int_as_float(v[3]); r.sgn = __int_as_float(v[4]); r.flags = v[5];
-  r.skip = v[6]; r.pad1 = 0;
+  r.radius = __int_as_float(v[3]); r.sgn = __int_as_float(v[4]); r.pad0 = r.pad1 = r.pad2 = 0;
 #pragma unroll
   for (int j = 0; j < 3; j++) { r.eta[j] = __int_as_float(v[8 + j]); r.eta2[j] = __int_as_float(v[12 + j]); }
   r.ch = __int_as_float(v[11]); r.c2 = __int_as_float(v[15]);
   return r;
+}
+__device__ __forceinline__ LfProgHdr load_phdr(const LfProgHdr* __restrict__ base, unsigned off) {
+  typedef const char __attribute__((address_space(4))) * cptr;
+  const lf_i4 v = *(lf_const_phdr_ptr)((cptr)(base) + off);
+  LfProgHdr h;
+  h.flags = v[0]; h.skip = v[1]; h.rec = v[2]; h.rec_next = v[3];
+  return h;
 }
 
 // K = rays per lane: the K wavelengths of a group walk the program TOGETHER.  They start as the same
@@ -294,8 +304,8 @@ __device__ __forceinline__ LfProgRow load_prow(const LfProgRow* __restrict__ bas
 template <int K>
 __global__ __launch_bounds__(256, (K == 1 ? 8 : 6))
 void k_march(const LfLensDev* __restrict__ lens, const LfPairsDev* __restrict__ pairs,
-             const LfEventRow* __restrict__ ev_table, const LfProgRow* __restrict__ prog_table,
-             const int* __restrict__ skip_tab, const float* __restrict__ mask, MarchArgs a,
+             const LfEventRow* __restrict__ ev_table, const LfProgHdr* __restrict__ hdr_table,
+             const LfProgRow* __restrict__ rec_table, const float* __restrict__ mask, MarchArgs a,
              double* __restrict__ ghost, unsigned long long* __restrict__ accum,
              unsigned long long* __restrict__ counters) {
   __shared__ unsigned long long s_acc[64 * 3];
@@ -343,7 +353,7 @@ void k_march(const LfLensDev* __restrict__ lens, const LfPairsDev* __restrict__ 
   }
 
   const int n_lambda = lens->n_lambda, n_pairs = pairs->n, total_events = pairs->total_events;
-  const int prog_rows = pairs->prog_rows;
+  const int prog_rows = pairs->prog_rows, prog_recs = pairs->prog_recs;
   const int n_groups = (n_lambda + K - 1) / K;
   const float pitch = lens->pitch, pupil_h = lens->pupil_h;
   const float geom_norm = lens->geom_norm;
@@ -421,9 +431,11 @@ void k_march(const LfLensDev* __restrict__ lens, const LfPairsDev* __restrict__ 
 
       for (int g = 0; g < n_groups; g++) {
         // ---- walk the group's program (the tree of all paths, depth first) ---------------------
-        const LfProgRow* const prog = prog_table + (size_t)g * (size_t)prog_rows;
-        const unsigned prog_end = (unsigned)prog_rows * (unsigned)sizeof(LfProgRow);
-        unsigned e = 0u;   // byte offset of the current row
+        const LfProgHdr* const prog = hdr_table + (size_t)g * (size_t)(prog_rows + 1);   // (+ a spare header)
+        const LfProgRow* const recs = rec_table + (size_t)g * (size_t)prog_recs;
+        constexpr unsigned kHdr = (unsigned)sizeof(LfProgHdr);
+        const unsigned prog_end = (unsigned)prog_rows * kHdr;
+        unsigned e = 0u;   // byte offset of the current row's header
         Ray r[K];
         lanemask alive[K], alive0[K], alive1[K];
 #pragma unroll
@@ -471,9 +483,17 @@ void k_march(const LfLensDev* __restrict__ lens, const LfPairsDev* __restrict__ 
         };
         // `cur` always holds the row at e: whoever moves e loads the row it lands on, so a run's
         // last iteration has already fetched the row the dispatch below looks at next
-        LfProgRow cur = load_prow(prog, e);
+        LfProgHdr hdr = load_phdr(prog, e);
+        LfProgRow cur = load_prec(recs, (unsigned)hdr.rec);
+        // the next row: its header and -- named by the current header -- its record, issued together
+        auto step = [&]() {
+          const unsigned rn = (unsigned)hdr.rec_next;
+          e += kHdr;
+          hdr = load_phdr(prog, e);
+          cur = load_prec(recs, rn);
+        };
         while (e != prog_end) {
-          const unsigned fl = (unsigned)cur.flags;
+          const unsigned fl = (unsigned)hdr.flags;
           const unsigned run = (fl >> 8) & 0xffu, mult = (fl >> 16) & 0xffu;
           unsigned endfl = 0u;  // flags of the row just executed if it completes a path
           bool dead = false;    // no ray of the group is alive any more
@@ -511,11 +531,11 @@ void k_march(const LfLensDev* __restrict__ lens, const LfPairsDev* __restrict__ 
                   nlive -= nd;
                   alive[j] &= okv[j];
                 }
-                if (nlive == 0u) { dead = true; k = 1u; sk = cur.skip; }
+                if (nlive == 0u) { dead = true; k = 1u; sk = hdr.skip; }
               }
               endfl = fl;
-              e += (unsigned)sizeof(LfProgRow); --k;
-              cur = load_prow(prog, e);
+              --k;
+              step();
             }
             while (k != 0u) {
               lanemask okv[K], gv[K], died = 0ull;
@@ -533,7 +553,7 @@ void k_march(const LfLensDev* __restrict__ lens, const LfPairsDev* __restrict__ 
                   died |= alive[j] & ~okv[j];
                 }
               }
-              endfl = (unsigned)cur.flags;
+              endfl = (unsigned)hdr.flags;
               if (__builtin_expect(died != 0ull, 0)) {  // some ray ends here, in `mult` logical paths
 #pragma unroll
                 for (int j = 0; j < K; j++) {
@@ -544,10 +564,10 @@ void k_march(const LfLensDev* __restrict__ lens, const LfPairsDev* __restrict__ 
                   nlive -= nd;
                   alive[j] &= okv[j];
                 }
-                if (nlive == 0u) { dead = true; k = 1u; sk = cur.skip; }
+                if (nlive == 0u) { dead = true; k = 1u; sk = hdr.skip; }
               }
-              e += (unsigned)sizeof(LfProgRow); --k;
-              cur = load_prow(prog, e);   // (the table ends with a spare row)
+              --k;
+              step();   // (the table ends with a spare row)
             }
             const unsigned live_sum = run * live0 - lost;
             ev32 += mult * live_sum;   // logical events: one per path that shares these rows
@@ -574,9 +594,8 @@ void k_march(const LfLensDev* __restrict__ lens, const LfPairsDev* __restrict__ 
             ev32 += mult * live;
             exec32 += live;
             endfl = fl;
-            sk = cur.skip;
-            e += (unsigned)sizeof(LfProgRow);
-            cur = load_prow(prog, e);
+            sk = hdr.skip;
+            step();
           } else {
             // a single mirror event (a fork that ends its leg at once) or flat glass
             if (fl & LF_EV_SAVE0) park_all(0, alive0);
@@ -604,15 +623,15 @@ void k_march(const LfLensDev* __restrict__ lens, const LfPairsDev* __restrict__ 
             ev32 += mult * live;
             exec32 += live;
             endfl = fl;
-            sk = cur.skip;
-            e += (unsigned)sizeof(LfProgRow);
-            cur = load_prow(prog, e);
+            sk = hdr.skip;
+            step();
           }
           if (dead) {
             // every ray of the wave is dead: jump over everything only these rays would still visit
             // (the jump-table entry travels in the row itself: no dependent load in front of the next row)
-            e = e - (unsigned)sizeof(LfProgRow) + (((unsigned)sk & ~3u) << 4);  // (sk >> 2) rows of 64 bytes
-            cur = load_prow(prog, e);
+            e = e - kHdr + (((unsigned)sk & ~3u) << 2);  // (sk >> 2) rows of 16 bytes
+            hdr = load_phdr(prog, e);
+            cur = load_prec(recs, (unsigned)hdr.rec);
             if ((sk & 3) == 1) unpark_all(1, alive1);
             else if ((sk & 3) == 2) unpark_all(0, alive0);
           } else if (endfl & LF_EV_END) {
@@ -1031,27 +1050,60 @@ static int rays_per_lane(int n_lambda) {
   return k;
 }
 
-// host: merge the per-wavelength programs (identical but for the index ratios) into rows that
-// serve K wavelengths at once
-static void pack_program(const lf_ctx* ctx, const std::vector<LfEventRow>& rows,
-                         const std::vector<int>& skip, int K, std::vector<LfProgRow>& out) {
-  const LfPairsDev& P = ctx->pairs;
+// host: merge the per-wavelength programs (identical but for the index ratios) into one program that
+// serves K wavelengths at once, in two levels: a header per row, a record per distinct (interface,
+// direction of travel) -- found by content: rows whose constants agree share a record.
+// out = [n_groups x (prog_rows + 1) headers][padding to 64 bytes][n_groups x n_recs records]
+static void pack_program(lf_ctx* ctx, const std::vector<LfEventRow>& rows, const std::vector<int>& skip, int K,
+                         std::vector<unsigned char>& out, size_t* rec_off) {
+  LfPairsDev& P = ctx->pairs;
   const int n_lambda = ctx->lens.n_lambda, n_groups = (n_lambda + K - 1) / K;
-  out.assign((size_t)n_groups * P.prog_rows + 1, LfProgRow{});   // + one spare row
-  for (int g = 0; g < n_groups; g++)
+  auto row_at = [&](int l, int i) -> const LfEventRow& {
+    return rows[(size_t)P.prog_off + (size_t)l * P.prog_rows + i];
+  };
+  // record ids from the first wavelength's rows (geometry + its index ratio identify the pair
+  // (interface, direction); the other wavelengths of the same interface follow it)
+  std::vector<int> rec_of(P.prog_rows);
+  std::vector<int> first_row;   // a row that uses record r
+  for (int i = 0; i < P.prog_rows; i++) {
+    const LfEventRow& r = row_at(0, i);
+    int id = -1;
+    for (size_t k = 0; k < first_row.size() && id < 0; k++) {
+      const LfEventRow& q = row_at(0, first_row[k]);
+      if (std::memcmp(&q.dzv, &r.dzv, sizeof(float)) == 0 && q.curv == r.curv && q.h2 == r.h2 &&
+          q.radius == r.radius && q.sgn == r.sgn && q.eta == r.eta) id = (int)k;
+    }
+    if (id < 0) { id = (int)first_row.size(); first_row.push_back(i); }
+    rec_of[i] = id;
+  }
+  const int n_recs = (int)first_row.size();
+  P.prog_recs = n_recs;
+  const size_t hdr_bytes = (size_t)n_groups * (P.prog_rows + 1) * sizeof(LfProgHdr);
+  *rec_off = (hdr_bytes + 63) & ~(size_t)63;
+  out.assign(*rec_off + (size_t)n_groups * n_recs * sizeof(LfProgRow), 0);
+  LfProgHdr* hdrs = reinterpret_cast<LfProgHdr*>(out.data());
+  LfProgRow* recs = reinterpret_cast<LfProgRow*>(out.data() + *rec_off);
+  for (int g = 0; g < n_groups; g++) {
     for (int i = 0; i < P.prog_rows; i++) {
-      LfProgRow& o = out[(size_t)g * P.prog_rows + i];
+      LfProgHdr& h = hdrs[(size_t)g * (P.prog_rows + 1) + i];
+      h.flags = row_at(0, i).flags;
+      h.skip = skip[(size_t)i];
+      h.rec = rec_of[i] * (int)sizeof(LfProgRow);
+      h.rec_next = (i + 1 < P.prog_rows ? rec_of[i + 1] : 0) * (int)sizeof(LfProgRow);
+    }
+    for (int k = 0; k < n_recs; k++) {
+      LfProgRow& o = recs[(size_t)g * n_recs + k];
       for (int j = 0; j < 3; j++) {
         const int l = std::min(g * K + (j < K ? j : K - 1), n_lambda - 1);
-        const LfEventRow& r = rows[(size_t)P.prog_off + (size_t)l * P.prog_rows + i];
+        const LfEventRow& r = row_at(l, first_row[k]);
         if (j == 0) {
-          o.dzv = r.dzv; o.curv = r.curv; o.h2 = r.h2; o.radius = r.radius; o.sgn = r.sgn; o.flags = r.flags;
+          o.dzv = r.dzv; o.curv = r.curv; o.h2 = r.h2; o.radius = r.radius; o.sgn = r.sgn;
           o.ch = 0.5f * r.curv; o.c2 = 2.0f * r.curv;   // exact
-          o.skip = skip[(size_t)i];
         }
         o.eta[j] = r.eta; o.eta2[j] = r.eta2;
       }
     }
+  }
 }
 
 static lf_status build_event_table(lf_ctx* ctx) {
@@ -1060,8 +1112,9 @@ static lf_status build_event_table(lf_ctx* ctx) {
   lf_status st = lf_build_march_tables(ctx, rows, skip);
   if (st != LF_OK) return st;
   ctx->march_k = rays_per_lane(ctx->lens.n_lambda);
-  std::vector<LfProgRow> prog;
-  pack_program(ctx, rows, skip, ctx->march_k, prog);
+  std::vector<unsigned char> prog;
+  size_t rec_off = 0;
+  pack_program(ctx, rows, skip, ctx->march_k, prog, &rec_off);
   rows.resize((size_t)ctx->pairs.prog_off);   // the device keeps the flat sequences in this format
   rows.push_back(LfEventRow{});               // spare
   // The context's stream is non-blocking, so the null-stream copies below are NOT ordered behind a
@@ -1080,7 +1133,8 @@ static lf_status build_event_table(lf_ctx* ctx) {
   };
   LF_HIP(ctx, upload((void**)&ctx->skip_dev, &ctx->skip_cap, skip.data(), skip.size() * sizeof(int)));
   LF_HIP(ctx, upload((void**)&ctx->events_dev, &ctx->events_cap, rows.data(), rows.size() * sizeof(LfEventRow)));
-  LF_HIP(ctx, upload((void**)&ctx->prog_dev, &ctx->prog_cap, prog.data(), prog.size() * sizeof(LfProgRow)));
+  LF_HIP(ctx, upload((void**)&ctx->prog_dev, &ctx->prog_cap, prog.data(), prog.size()));
+  ctx->prog_rec_off = rec_off;
   ctx->events_dirty = false;
   return LF_OK;
 }
@@ -1152,7 +1206,8 @@ lf_status lfk_march(lf_ctx* ctx, int spp, uint64_t key) {
   hipEvent_t ev = lf_timing_begin(ctx, LFK_MARCH);
 #define LF_LAUNCH_MARCH(KK)                                                                        \
   hipLaunchKernelGGL(k_march<KK>, dim3((unsigned)blocks), dim3(256), 0, ctx->stream, ctx->lens_dev, \
-                     ctx->pairs_dev, ctx->events_dev, ctx->prog_dev, ctx->skip_dev, m.texels, a,    \
+                     ctx->pairs_dev, ctx->events_dev, (const LfProgHdr*)ctx->prog_dev,              \
+                     (const LfProgRow*)(ctx->prog_dev + ctx->prog_rec_off), m.texels, a,            \
                      ctx->ghost, ctx->accum, ctx->counters_dev)
   switch (ctx->march_k) {
     case 1: LF_LAUNCH_MARCH(1); break;
