@@ -265,12 +265,8 @@ struct lf_ctx {
   LfPairsDev* pairs_dev = nullptr;
   unsigned long long* counters_dev = nullptr;  // 8 x u64
   unsigned long long* accum = nullptr;         // W*H_alloc*3 fixed-point partial sums (split launches)
-  LfEventRow* events_dev = nullptr;            // n_lambda x total_events flat rows (weight re-march)
-  size_t events_cap = 0;
-  int* skip_dev = nullptr;                     // prog_rows entries: where a dead wave jumps to
-  size_t skip_cap = 0;                         // capacities in BYTES
   unsigned char* prog_dev = nullptr;           // the packed program: headers, then records (lf_march.hip pack_program)
-  size_t prog_cap = 0, prog_rec_off = 0;       // bytes; offset of the records
+  size_t prog_cap = 0, prog_rec_off = 0, prog_seq_off = 0;   // bytes; offsets of the records / the pair sequences
   int march_k = 1;                             // wavelengths (rays per lane) that walk together
   bool events_dirty = true;
 

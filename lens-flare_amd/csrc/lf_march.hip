@@ -202,20 +202,10 @@ __device__ __forceinline__ lanemask stop_event(Ray& r, float dzv, float h2, floa
   return __ballot(r2 <= h2) & __ballot(a > 0.0f);
 }
 
-// One event row as ONE 32-byte scalar load (left to itself the compiler sinks the eight field loads
-// into the branches that use them: 4-5 dependent scalar-cache round trips per event).
-// (read through the CONSTANT address space: such a load can never be clobbered by the kernel's own
-// stores, so it always qualifies for the scalar unit and may be scheduled freely)
-typedef int lf_i8 __attribute__((ext_vector_type(8)));
-typedef const lf_i8 __attribute__((address_space(4))) * lf_const_row_ptr;
-__device__ __forceinline__ LfEventRow load_row(const LfEventRow* __restrict__ e) {
-  const lf_i8 v = *(lf_const_row_ptr)(e);
-  LfEventRow r;
-  r.dzv = __int_as_float(v[0]); r.curv = __int_as_float(v[1]); r.h2 = __int_as_float(v[2]);
-  r.eta = __int_as_float(v[3]); r.sgn = __int_as_float(v[4]); r.flags = v[5];
-  r.radius = __int_as_float(v[6]); r.eta2 = __int_as_float(v[7]);
-  return r;
-}
+// Table rows are read with ONE wide scalar load each (left to itself the compiler sinks the field
+// loads into the branches that use them: 4-5 dependent scalar-cache round trips per event), through
+// the CONSTANT address space: such a load can never be clobbered by the kernel's own stores, so it
+// always qualifies for the scalar unit and may be scheduled freely (load_phdr / load_prec below).
 
 // parked ray state (a fork of the path tree) in LDS: the two slots would cost 12 VGPRs and the 8th
 // wave of every SIMD
@@ -304,7 +294,7 @@ __device__ __forceinline__ LfProgHdr load_phdr(const LfProgHdr* __restrict__ bas
 template <int K>
 __global__ __launch_bounds__(256, (K == 1 ? 8 : 6))
 void k_march(const LfLensDev* __restrict__ lens, const LfPairsDev* __restrict__ pairs,
-             const LfEventRow* __restrict__ ev_table, const LfProgHdr* __restrict__ hdr_table,
+             const int* __restrict__ seq_table, const LfProgHdr* __restrict__ hdr_table,
              const LfProgRow* __restrict__ rec_table, const float* __restrict__ mask, MarchArgs a,
              double* __restrict__ ghost, unsigned long long* __restrict__ accum,
              unsigned long long* __restrict__ counters) {
@@ -352,7 +342,7 @@ void k_march(const LfLensDev* __restrict__ lens, const LfPairsDev* __restrict__ 
     active_mask = __ballot(x < a.W && y >= a.y0 && y < a.y1);
   }
 
-  const int n_lambda = lens->n_lambda, n_pairs = pairs->n, total_events = pairs->total_events;
+  const int n_lambda = lens->n_lambda, n_pairs = pairs->n;
   const int prog_rows = pairs->prog_rows, prog_recs = pairs->prog_recs;
   const int n_groups = (n_lambda + K - 1) / K;
   const float pitch = lens->pitch, pupil_h = lens->pupil_h;
@@ -658,22 +648,25 @@ void k_march(const LfLensDev* __restrict__ lens, const LfPairsDev* __restrict__ 
                 for (int jj = 1; jj < K; jj++) lj = (j == jj) ? lit[jj] : lj;
                 if (lj == 0ull) continue;
                 const int l = g * K + j;
-                const LfEventRow* __restrict__ w = ev_table + (size_t)l * (size_t)total_events +
-                                                   pairs->ev_off[q];
+                // the path's own sequence: one dword per event (record | kind << 16), the constants come
+                // from the same resident records the walk uses
+                const int* __restrict__ w = seq_table + pairs->ev_off[q];
                 const int lo = launder(lane);
                 Ray rw{s_start[wave][0][lo], s_start[wave][1][lo], 0.0f, 0.0f, s_start[wave][2][lo],
                        s_start[wave][3][lo], s_start[wave][4][lo], s_start[wave][5][lo], 1.0f};
                 rw.r2 = fmaf(rw.px, rw.px, rw.py * rw.py);
                 for (int left = pairs->ev_cnt[q]; left > 0; --left, ++w) {
-                  const LfEventRow wr = load_row(w);
-                  if (wr.flags & LF_EV_STOP) {
+                  const unsigned se = (unsigned)*(const int __attribute__((address_space(4)))*)(w);
+                  const LfProgRow wr = load_prec(recs, se & 0xffffu);
+                  const unsigned wfl = se >> 16;
+                  const float w_eta = j == 0 ? wr.eta[0] : j == 1 ? wr.eta[1] : wr.eta[2];
+                  const float w_eta2 = j == 0 ? wr.eta2[0] : j == 1 ? wr.eta2[1] : wr.eta2[2];
+                  if (wfl & LF_EV_STOP) {
                     (void)stop_event<true>(rw, wr.dzv, wr.h2, inv_stop_h, mask, a.mw, a.mh);
                   } else {
                     lanemask geom_ok;
-                    (void)surface_event<true>(rw, wr.dzv, wr.curv, 0.5f * wr.curv, 2.0f * wr.curv, wr.radius,
-                                              wr.h2, wr.eta, wr.eta2,
-                                              (wr.flags & LF_EV_REFLECT) != 0,
-                                              (wr.flags & LF_EV_FLAT) != 0, wr.sgn, geom_ok);
+                    (void)surface_event<true>(rw, wr.dzv, wr.curv, wr.ch, wr.c2, wr.radius, wr.h2, w_eta, w_eta2,
+                                              (wfl & LF_EV_REFLECT) != 0, (wfl & LF_EV_FLAT) != 0, wr.sgn, geom_ok);
                   }
                 }
                 // (selects, not branches: with no divergent branch anywhere in the walk the compiler
@@ -1054,8 +1047,9 @@ static int rays_per_lane(int n_lambda) {
 // serves K wavelengths at once, in two levels: a header per row, a record per distinct (interface,
 // direction of travel) -- found by content: rows whose constants agree share a record.
 // out = [n_groups x (prog_rows + 1) headers][padding to 64 bytes][n_groups x n_recs records]
+//       [total_events sequence dwords]
 static void pack_program(lf_ctx* ctx, const std::vector<LfEventRow>& rows, const std::vector<int>& skip, int K,
-                         std::vector<unsigned char>& out, size_t* rec_off) {
+                         std::vector<unsigned char>& out, size_t* rec_off, size_t* seq_off, bool* ok) {
   LfPairsDev& P = ctx->pairs;
   const int n_lambda = ctx->lens.n_lambda, n_groups = (n_lambda + K - 1) / K;
   auto row_at = [&](int l, int i) -> const LfEventRow& {
@@ -1080,7 +1074,24 @@ static void pack_program(lf_ctx* ctx, const std::vector<LfEventRow>& rows, const
   P.prog_recs = n_recs;
   const size_t hdr_bytes = (size_t)n_groups * (P.prog_rows + 1) * sizeof(LfProgHdr);
   *rec_off = (hdr_bytes + 63) & ~(size_t)63;
-  out.assign(*rec_off + (size_t)n_groups * n_recs * sizeof(LfProgRow), 0);
+  *seq_off = *rec_off + (size_t)n_groups * n_recs * sizeof(LfProgRow);
+  out.assign(*seq_off + ((size_t)P.total_events + 1) * sizeof(int), 0);
+  // the per-pair sequences (read by the weight re-march): one dword per event, record | kind << 16;
+  // every (interface, direction) a pair crosses is in the program, so its record exists
+  {
+    int* seq = reinterpret_cast<int*>(out.data() + *seq_off);
+    for (int e = 0; e < P.total_events; e++) {
+      const LfEventRow& r = rows[(size_t)e];   // wavelength 0
+      int id = -1;
+      for (int k = 0; k < n_recs && id < 0; k++) {
+        const LfEventRow& q = row_at(0, first_row[k]);
+        if (std::memcmp(&q.dzv, &r.dzv, sizeof(float)) == 0 && q.curv == r.curv && q.h2 == r.h2 &&
+            q.radius == r.radius && q.sgn == r.sgn && q.eta == r.eta) id = k;
+      }
+      if (id < 0) { *ok = false; return; }
+      seq[e] = id * (int)sizeof(LfProgRow) | ((r.flags & (LF_EV_REFLECT | LF_EV_STOP | LF_EV_FLAT)) << 16);
+    }
+  }
   LfProgHdr* hdrs = reinterpret_cast<LfProgHdr*>(out.data());
   LfProgRow* recs = reinterpret_cast<LfProgRow*>(out.data() + *rec_off);
   for (int g = 0; g < n_groups; g++) {
@@ -1113,10 +1124,13 @@ static lf_status build_event_table(lf_ctx* ctx) {
   if (st != LF_OK) return st;
   ctx->march_k = rays_per_lane(ctx->lens.n_lambda);
   std::vector<unsigned char> prog;
-  size_t rec_off = 0;
-  pack_program(ctx, rows, skip, ctx->march_k, prog, &rec_off);
-  rows.resize((size_t)ctx->pairs.prog_off);   // the device keeps the flat sequences in this format
-  rows.push_back(LfEventRow{});               // spare
+  size_t rec_off = 0, seq_off = 0;
+  bool packed = true;
+  pack_program(ctx, rows, skip, ctx->march_k, prog, &rec_off, &seq_off, &packed);
+  if (!packed || (size_t)ctx->pairs.prog_recs * sizeof(LfProgRow) > 0xffffu)
+    return lf_fail(ctx, LF_ERR_STATE, "march program: a pair crosses an interface the program has no record for");
+  // (the flat per-pair rows and the jump table stay on the host: the device walks headers, records and
+  // sequence dwords only)
   // The context's stream is non-blocking, so the null-stream copies below are NOT ordered behind a
   // k_march that is still walking the previous program: a program / jump-table pair that changes
   // under a live kernel can send a wave past the program's end.  Drain the stream first.
@@ -1131,10 +1145,9 @@ static lf_status build_event_table(lf_ctx* ctx) {
     }
     return bytes ? hipMemcpy(*dev, src, bytes, hipMemcpyHostToDevice) : hipSuccess;
   };
-  LF_HIP(ctx, upload((void**)&ctx->skip_dev, &ctx->skip_cap, skip.data(), skip.size() * sizeof(int)));
-  LF_HIP(ctx, upload((void**)&ctx->events_dev, &ctx->events_cap, rows.data(), rows.size() * sizeof(LfEventRow)));
   LF_HIP(ctx, upload((void**)&ctx->prog_dev, &ctx->prog_cap, prog.data(), prog.size()));
   ctx->prog_rec_off = rec_off;
+  ctx->prog_seq_off = seq_off;
   ctx->events_dirty = false;
   return LF_OK;
 }
@@ -1206,7 +1219,8 @@ lf_status lfk_march(lf_ctx* ctx, int spp, uint64_t key) {
   hipEvent_t ev = lf_timing_begin(ctx, LFK_MARCH);
 #define LF_LAUNCH_MARCH(KK)                                                                        \
   hipLaunchKernelGGL(k_march<KK>, dim3((unsigned)blocks), dim3(256), 0, ctx->stream, ctx->lens_dev, \
-                     ctx->pairs_dev, ctx->events_dev, (const LfProgHdr*)ctx->prog_dev,              \
+                     ctx->pairs_dev, (const int*)(ctx->prog_dev + ctx->prog_seq_off),                \
+                     (const LfProgHdr*)ctx->prog_dev,                                               \
                      (const LfProgRow*)(ctx->prog_dev + ctx->prog_rec_off), m.texels, a,            \
                      ctx->ghost, ctx->accum, ctx->counters_dev)
   switch (ctx->march_k) {
