@@ -855,7 +855,7 @@ lf_status lf_march_tables(int n_surfaces, int stop_index, int n_lambda, const fl
 namespace {
 // what Application::load hands the renderer, flattened for lf_set_scene / lf_set_scene_lights;
 // returns an empty string, or why the device scene term cannot render the file
-std::string flatten_collada(const lfamd::ColladaScene& sc, std::vector<double>& sph, std::vector<int>& sph_m,
+extern "C++" std::string flatten_collada(const lfamd::ColladaScene& sc, std::vector<double>& sph, std::vector<int>& sph_m,
                             std::vector<double>& tp, std::vector<double>& tn, std::vector<int>& tri_m,
                             std::vector<double>& mats, std::vector<double>& lights, std::vector<double>& suns) {
   // DiffuseBSDF and EmissionBSDF as they are.  Mirror / Refraction / Glass / Microfacet are unfilled
