@@ -346,9 +346,20 @@ def main():
             nccl_group = dist.new_group(backend="nccl")
     if gather_mode == "cabi":
         # first use of a communicator sets up its channels (tens to hundreds of ms): part of set-up,
-        # like the aperture spectrum, not of a frame -- whatever --warmup says
-        lf.comm_gather(pkg.SAMPLE_BUFFER)
-        lf.synchronize()
+        # like the aperture spectrum, not of a frame -- whatever --warmup says.  Should it fail on
+        # any rank, every rank falls back to the torch.distributed exchange together.
+        ok, why = 1, ""
+        try:
+            lf.comm_gather(pkg.SAMPLE_BUFFER)
+            lf.synchronize()
+        except Exception as e:  # noqa: BLE001
+            ok, why = 0, str(e)
+        flag = torch.tensor([ok], dtype=torch.int32)
+        dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+        if int(flag[0]) == 0:
+            gather_mode = "torch"
+            gather_note = f"C-ABI exchange failed at its first use ({why or 'on another rank'}): torch.distributed nccl exchange"
+            nccl_group = dist.new_group(backend="nccl")
     if gather_mode in ("torch", "host"):
         ptr, nbytes = lf.device_buffer(pkg.SAMPLE_BUFFER)
         frame_t = torch.as_tensor(DevView(ptr, nbytes // 8), device=f"cuda:{local}")
