@@ -219,6 +219,47 @@ lf_status lf_generate_ghost_buffer(lf_ctx* ctx);
  * sample = scene + ghost_buffer + raytrace_starburst (incl. calculate_irradiance_falloff) */
 lf_status lf_render_flare_layer(lf_ctx* ctx);
 
+/* ---------------------------------------------------------------- helper members ---------- */
+/* The reference declares the steps of generate_ghost_buffer / raytrace_starburst as public members
+ * ("Testing functions", pathtracer.h:42-57, :95-101).  A replacement of pathtracer.cpp defines every
+ * one of them; these are their device forms (one small launch each; the frame-level calls above do
+ * not go through them).  The ghost helpers ADD to the device ghost buffer, triangle by triangle like
+ * HDRImageBuffer::update_pixel_additive (util/image.h:145); bbox (may be NULL) receives the pixel
+ * rectangle [x0, x1) x [y0, y1) the call can have touched, for a partial read-back.
+ *
+ * replaces: ghost_buffer.clear() (generate_ghost_buffer, pathtracer.cpp:719; util/image.h:233) */
+lf_status lf_clear_ghost_buffer(lf_ctx* ctx);
+/* replaces: PathTracer::draw_ghost(string color, float r1, float r2) (pathtracer.cpp:433-508):
+ * channel 0 / 1 / 2 = "red" / "green" / any other string; uses axis_ray of the flare state */
+lf_status lf_draw_ghost(lf_ctx* ctx, int channel, float r1, float r2, int bbox[4]);
+/* replaces: PathTracer::rasterize_textured_triangle (pathtracer.cpp:346-410);
+ * v = {x0, y0, u0, v0,  x1, y1, u1, v1,  x2, y2, u2, v2}, colour = ghost_color */
+lf_status lf_rasterize_textured_triangle(lf_ctx* ctx, const float v[12], const double colour[3], int bbox[4]);
+/* replaces: PathTracer::fill_textured_pixel (pathtracer.cpp:305-343): vertices as given (already
+ * y-sorted and shifted by the caller), pixel (x, y) inside the frame */
+lf_status lf_fill_textured_pixel(lf_ctx* ctx, const float v[12], int x, int y, const double colour[3]);
+/* replaces: PathTracer::shift_vertex (pathtracer.cpp:412-430) */
+lf_status lf_shift_vertex(lf_ctx* ctx, float x, float y, float scale, float shift_amount, double out_xy[2]);
+/* replaces: PathTracer::compute_phase (pathtracer.cpp:917-931) with complex_exp (:901-915);
+ * screen_pos (may be NULL) = the flare origin in pixels the member returns through its reference */
+lf_status lf_compute_phase(lf_ctx* ctx, int flare, double u, double v, double out_re_im[2], double screen_pos[2]);
+/* replaces: PathTracer::calculate_irradiance_falloff(x, y, radius) (pathtracer.cpp:1043-1063); the
+ * 32 jitter draws are pixel (x, y)'s own (lf_set_jitter_*) */
+lf_status lf_irradiance_falloff(lf_ctx* ctx, int x, int y, double radius, double rgb[3]);
+/* Single-ray forms of the integrator members (pathtracer.h:66-77) on the device scene of
+ * lf_set_scene.  ray = {origin xyz, direction xyz, min_t, max_t}.  Sampled lights draw from the
+ * counter RNG, stream `seq` (any number; distinct calls should pass distinct values).
+ * replaces: PathTracer::est_radiance_global_illumination (pathtracer.cpp:282-302) and the closest-hit
+ * query of PathTracer::autofocus (:1065-1072): out = {hit (1/0), t, normal xyz, radiance rgb};
+ * without a hit the radiance is the environment's (or 0). */
+lf_status lf_scene_trace_ray(lf_ctx* ctx, const double ray[8], uint64_t seq, double out[8]);
+/* replaces, for an intersection (t, n, material) the host found itself: what = 0
+ * PathTracer::zero_bounce_radiance (:215-220), 1 one_bounce_radiance (:222-232, by
+ * lf_set_direct_hemisphere_sample), 2 estimate_direct_lighting_hemisphere (:86-138),
+ * 3 estimate_direct_lighting_importance (:142-213).  material = {kind, r, g, b} as lf_set_scene. */
+lf_status lf_scene_shade(lf_ctx* ctx, int what, const double ray[8], double t, const double n[3],
+                         const double material[4], uint64_t seq, double rgb[3]);
+
 /* ---------------------------------------------------------------- read back -------------- */
 /* replaces reads of PathTracer::sampleBuffer / ghost_buffer (util/image.h:139-151).
  * which: 0 = sampleBuffer, 1 = ghost_buffer, 2 = the value of raytrace_starburst(x,y)
@@ -269,6 +310,23 @@ lf_status lf_comm_gather(lf_ctx* ctx, int which);
 lf_status lf_comm_gather_async(lf_ctx* ctx, int which);
 lf_status lf_comm_wait(lf_ctx* ctx);
 lf_status lf_comm_destroy(lf_ctx* ctx);
+/* LF_OK if RCCL can be loaded here (dlopen + every entry point): what every rank checks, and agrees
+ * on over its control plane, BEFORE the first blocking RCCL call */
+lf_status lf_comm_available(void);
+/* what RCCL reports for the communicator the context is attached to (ncclCommCount,
+ * ncclCommUserRank); nranks = 0, rank = -1 without one */
+lf_status lf_comm_info(lf_ctx* ctx, int* nranks, int* rank);
+/* non-blocking: has the last exchange (lf_comm_gather or _async) finished on the device?  Lets a host
+ * wait for the first collective of a new communicator with a deadline instead of blocking in
+ * lf_synchronize behind a peer that never joined */
+lf_status lf_comm_test(lf_ctx* ctx, int* done);
+/* ncclCommAbort: ends the collectives in flight on this rank and drops the communicator, so that the
+ * context's streams drain; the recovery from a failed first exchange (every rank calls it) */
+lf_status lf_comm_abort(lf_ctx* ctx);
+/* bits = 64 (default): tile rows travel as the doubles they are (every rank holds the same bits);
+ * 32: as floats -- half the bytes on the wire (SURVEY 8e budgets f32: 12.4 MB per rank at 4K), the
+ * rows a rank receives are rounded to float, its own stay as rendered.  Same value on every rank. */
+lf_status lf_comm_set_exchange_precision(lf_ctx* ctx, int bits);
 /* One process, n devices (a C++ host such as the CGL application): one context + stream per device
  * and one communicator over them (ncclCommInitAll).  Set-up calls go to every context
  * (lf_group_ctx); lf_group_set_frame = lf_set_frame + the round-robin deal on every context;
@@ -300,6 +358,15 @@ lf_status lf_group_gather(lf_group* g, int which);
 lf_status lf_set_lens(lf_ctx* ctx, int n_surfaces, int stop_index, int n_lambda,
                       const float* radius, const float* thickness, const float* ior,
                       const float* semi_aperture, float sensor_width_mm);
+/* The same from a prescription file (lens-flare_amd/data/ *.lens: `sensor_width_mm w`, then one row
+ * per interface `radius thickness n_1 .. n_L semi_aperture`, '#' comments; radius 0 with index 0 is
+ * the stop).  Replaces the hard-coded table of pathtracer.cpp:541-556 as an INPUT, which is what
+ * lets a host that cannot change the reference's header select a lens (LF_LENS_FILE). */
+lf_status lf_load_lens_file(lf_ctx* ctx, const char* path);
+/* what lf_set_lens / lf_load_lens_file installed (any pointer may be NULL); efl_mm = lf_paraxial_efl at
+ * the middle wavelength (0 for an afocal prescription) */
+lf_status lf_get_lens_info(lf_ctx* ctx, int* n_surfaces, int* stop_index, int* n_lambda, float* sensor_width_mm,
+                           double* efl_mm);
 /* RGB weight of each wavelength (n_lambda x 3); default: identity for n_lambda == 3 */
 lf_status lf_set_lambda_rgb(lf_ctx* ctx, const float* weights);
 /* the light: unit direction from the lens towards the sun in lens space (z < 0), radiance,
@@ -381,7 +448,8 @@ lf_status lf_get_executed_events(lf_ctx* ctx, uint64_t* out);
 
 /* ---------------------------------------------------------------- measurement ------------ */
 /* HIP-event timing of the kernels launched since the last reset, on the context's stream.
- * kernel: "march", "flare_layer", "ghost_raster", "dft", "frame_setup", "tonemap". */
+ * kernel: "march", "flare_layer", "ghost_raster", "dft", "frame_setup", "tonemap", "scene_term",
+ * "exchange" (pack -> all-gather -> unpack of lf_comm_gather / _async, on the stream it runs on). */
 lf_status lf_timing_enable(lf_ctx* ctx, int on);
 lf_status lf_timing_reset(lf_ctx* ctx);
 lf_status lf_timing_get(lf_ctx* ctx, const char* kernel, int* launches, double* total_ms);

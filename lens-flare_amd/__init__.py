@@ -35,8 +35,12 @@ ABI_SYMBOLS = [
     "lf_write_to_framebuffer", "lf_save_image_rgba", "lf_device_buffer", "lf_set_lens", "lf_set_lambda_rgb", "lf_set_sun",
     "lf_set_sun_from_flares", "lf_paraxial_efl", "lf_set_ghost_pairs", "lf_set_pupil_subcells", "lf_trace_ghosts", "lf_generate_lens_rays", "lf_get_counters", "lf_reset_counters", "lf_get_executed_events", "lf_native_sqrt", "lf_set_starburst_spectrum", "lf_load_collada", "lf_march_tables",
     "lf_timing_enable", "lf_timing_reset", "lf_timing_get",
+    "lf_clear_ghost_buffer", "lf_draw_ghost", "lf_rasterize_textured_triangle", "lf_fill_textured_pixel",
+    "lf_shift_vertex", "lf_compute_phase", "lf_irradiance_falloff", "lf_scene_trace_ray", "lf_scene_shade",
+    "lf_load_lens_file", "lf_get_lens_info",
     "lf_comm_get_unique_id", "lf_comm_init_rank", "lf_comm_gather", "lf_comm_gather_async", "lf_comm_wait",
-    "lf_comm_destroy",
+    "lf_comm_destroy", "lf_comm_available", "lf_comm_info", "lf_comm_test", "lf_comm_abort",
+    "lf_comm_set_exchange_precision",
     "lf_group_create", "lf_group_destroy", "lf_group_size", "lf_group_ctx", "lf_group_last_error",
     "lf_group_set_frame", "lf_group_for_each", "lf_group_gather",
 ]
@@ -170,6 +174,11 @@ def aim_camera(pos, world_point, ns, hfov_deg, vfov_deg):
 COMM_ID_BYTES = 128
 
 
+def comm_available():
+    """lf_comm_available: can RCCL be loaded in this process? (no blocking call, no device)"""
+    return load_library().lf_comm_available() == 0
+
+
 def comm_unique_id():
     """lf_comm_get_unique_id: the RCCL id rank 0 makes and the host shares (bytes)."""
     buf = (C.c_ubyte * COMM_ID_BYTES)()
@@ -215,6 +224,23 @@ class LensFlare:
 
     def comm_wait(self):
         self._ck(self.lib.lf_comm_wait(self.ctx))
+
+    def comm_info(self):
+        """(nranks, rank) as RCCL reports them; (0, -1) without a communicator."""
+        n, r = C.c_int(), C.c_int()
+        self._ck(self.lib.lf_comm_info(self.ctx, C.byref(n), C.byref(r)))
+        return n.value, r.value
+
+    def comm_test(self):
+        d = C.c_int()
+        self._ck(self.lib.lf_comm_test(self.ctx, C.byref(d)))
+        return bool(d.value)
+
+    def comm_abort(self):
+        self._ck(self.lib.lf_comm_abort(self.ctx))
+
+    def comm_set_exchange_precision(self, bits):
+        self._ck(self.lib.lf_comm_set_exchange_precision(self.ctx, int(bits)))
 
     def comm_destroy(self):
         self._ck(self.lib.lf_comm_destroy(self.ctx))
@@ -484,6 +510,65 @@ class LensFlare:
         w = np.ascontiguousarray(rgb_weights, np.float64).reshape(len(sc), 3)
         self._ck(self.lib.lf_set_starburst_spectrum(self.ctx, len(sc), _fp(sc, C.c_double),
                                                     _fp(w, C.c_double)))
+
+    # ---- the reference's public helper members, single-shot on the device
+    def clear_ghost_buffer(self):
+        self._ck(self.lib.lf_clear_ghost_buffer(self.ctx))
+
+    def draw_ghost(self, channel, r1, r2):
+        bbox = (C.c_int * 4)()
+        self._ck(self.lib.lf_draw_ghost(self.ctx, int(channel), C.c_float(r1), C.c_float(r2), bbox))
+        return tuple(bbox)
+
+    def rasterize_textured_triangle(self, verts12, colour):
+        v = np.ascontiguousarray(verts12, np.float32).reshape(12)
+        c = np.ascontiguousarray(colour, np.float64).reshape(3)
+        bbox = (C.c_int * 4)()
+        self._ck(self.lib.lf_rasterize_textured_triangle(self.ctx, _fp(v, C.c_float), _fp(c, C.c_double), bbox))
+        return tuple(bbox)
+
+    def fill_textured_pixel(self, verts12, x, y, colour):
+        v = np.ascontiguousarray(verts12, np.float32).reshape(12)
+        c = np.ascontiguousarray(colour, np.float64).reshape(3)
+        self._ck(self.lib.lf_fill_textured_pixel(self.ctx, _fp(v, C.c_float), int(x), int(y), _fp(c, C.c_double)))
+
+    def shift_vertex(self, x, y, scale, shift_amount):
+        out = (C.c_double * 2)()
+        self._ck(self.lib.lf_shift_vertex(self.ctx, C.c_float(x), C.c_float(y), C.c_float(scale),
+                                          C.c_float(shift_amount), out))
+        return out[0], out[1]
+
+    def compute_phase(self, flare, u, v):
+        out, pos = (C.c_double * 2)(), (C.c_double * 2)()
+        self._ck(self.lib.lf_compute_phase(self.ctx, int(flare), C.c_double(u), C.c_double(v), out, pos))
+        return complex(out[0], out[1]), (pos[0], pos[1])
+
+    def irradiance_falloff(self, x, y, radius):
+        out = (C.c_double * 3)()
+        self._ck(self.lib.lf_irradiance_falloff(self.ctx, int(x), int(y), C.c_double(radius), out))
+        return np.array(out[:], np.float64)
+
+    def scene_trace_ray(self, origin, direction, min_t=0.0, max_t=float("inf"), seq=0):
+        ray = (C.c_double * 8)(*origin, *direction, min_t, max_t)
+        out = (C.c_double * 8)()
+        self._ck(self.lib.lf_scene_trace_ray(self.ctx, ray, C.c_uint64(seq), out))
+        return dict(hit=bool(out[0]), t=out[1], n=np.array(out[2:5]), radiance=np.array(out[5:8]))
+
+    def scene_shade(self, what, origin, direction, t, n, material, min_t=0.0, max_t=float("inf"), seq=0):
+        ray = (C.c_double * 8)(*origin, *direction, min_t, max_t)
+        nn, mm, out = (C.c_double * 3)(*n), (C.c_double * 4)(*material), (C.c_double * 3)()
+        self._ck(self.lib.lf_scene_shade(self.ctx, int(what), ray, C.c_double(t), nn, mm, C.c_uint64(seq), out))
+        return np.array(out[:], np.float64)
+
+    def load_lens_file(self, path):
+        if not os.path.isabs(path) and not os.path.exists(path):
+            path = os.path.join(DATA, path)
+        self._ck(self.lib.lf_load_lens_file(self.ctx, path.encode()))
+
+    def lens_info(self):
+        n, stop, nl, sw, efl = C.c_int(), C.c_int(), C.c_int(), C.c_float(), C.c_double()
+        self._ck(self.lib.lf_get_lens_info(self.ctx, C.byref(n), C.byref(stop), C.byref(nl), C.byref(sw), C.byref(efl)))
+        return dict(n=n.value, stop=stop.value, n_lambda=nl.value, sensor_width_mm=sw.value, efl_mm=efl.value)
 
     def native_sqrt(self, x):
         x = np.ascontiguousarray(x, np.float32)

@@ -4,6 +4,8 @@
 // lf_march.hip; there is no CPU fallback -- without a device lf_create fails.
 #include <algorithm>
 #include <cmath>
+#include <cstdio>
+#include <cstdlib>
 #include <cstring>
 
 #include "lf_internal.h"
@@ -49,28 +51,28 @@ static void timing_fold(lf_ctx* ctx, bool wait) {
   ctx->timed.resize(keep);
 }
 
-hipEvent_t lf_timing_begin(lf_ctx* ctx, int kernel) {
+hipEvent_t lf_timing_begin(lf_ctx* ctx, int kernel, hipStream_t stream) {
   if (!ctx->timing) return nullptr;
   (void)kernel;
   if (ctx->timed.size() >= kTimedCap) timing_fold(ctx, false);
   if (ctx->timed.size() >= kTimedCap) timing_fold(ctx, true);
   hipEvent_t e = timing_event(ctx);
-  if (e) (void)hipEventRecord(e, ctx->stream);
+  if (e) (void)hipEventRecord(e, stream ? stream : ctx->stream);
   return e;
 }
 
-void lf_timing_end(lf_ctx* ctx, int kernel, hipEvent_t start) {
+void lf_timing_end(lf_ctx* ctx, int kernel, hipEvent_t start, hipStream_t stream) {
   if (!ctx->timing || !start) return;
   hipEvent_t e = timing_event(ctx);
   if (!e) { ctx->event_pool.push_back(start); return; }
-  (void)hipEventRecord(e, ctx->stream);
+  (void)hipEventRecord(e, stream ? stream : ctx->stream);
   ctx->timed.push_back(LfTimedLaunch{kernel, start, e});
 }
 
 namespace {
 
 const char* kKernelNames[LFK_COUNT] = {"march", "flare_layer", "ghost_raster", "dft",
-                                       "frame_setup", "tonemap"};
+                                       "frame_setup", "tonemap", "exchange", "scene_term"};
 
 // the reference's hard-coded prescription (pathtracer.cpp:541-556); literals narrowed to float
 // where the reference narrows them
@@ -169,6 +171,13 @@ lf_status lf_create(lf_ctx** out, int device) {
   if (hipGetDeviceCount(&n) != hipSuccess || n <= 0) return LF_ERR_NO_DEVICE;
   if (device < 0 || device >= n) return LF_ERR_NO_DEVICE;
   if (hipSetDevice(device) != hipSuccess) return LF_ERR_NO_DEVICE;
+  {
+    // the library carries gfx950 code objects only: any other architecture would fail at the first
+    // launch with an opaque HIP error (LF_ALLOW_ANY_ARCH=1: for experiments with a fat binary)
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, device) != hipSuccess) return LF_ERR_NO_DEVICE;
+    if (std::strncmp(prop.gcnArchName, "gfx950", 6) != 0 && !std::getenv("LF_ALLOW_ANY_ARCH")) return LF_ERR_NO_DEVICE;
+  }
   lf_ctx* ctx = new lf_ctx();
   ctx->device = device;
   if (hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking) != hipSuccess) {
@@ -957,6 +966,143 @@ lf_status lf_set_starburst_spectrum(lf_ctx* ctx, int n, const double* scale, con
   return LF_OK;
 }
 
+// ---------------------------------------------------------------- helper members ---------------
+// The reference declares its ghost / starburst helpers as public members (pathtracer.h:45-57,
+// :95-101); a drop-in defines every one of them, on the device like the frame-level calls.
+static lf_status ghost_helper_ready(lf_ctx* ctx, const char* who) {
+  if (ctx->W == 0) return lf_fail(ctx, LF_ERR_STATE, std::string(who) + " before lf_set_frame");
+  if (!ctx->ap[LF_APERTURE_GHOST].valid) return lf_fail(ctx, LF_ERR_STATE, std::string(who) + ": ghost aperture not set");
+  { const lf_status js = lf_comm_join(ctx); if (js != LF_OK) return js; }
+  LF_HIP(ctx, hipSetDevice(ctx->device));
+  return LF_OK;
+}
+
+lf_status lf_clear_ghost_buffer(lf_ctx* ctx) {
+  if (!ctx) return LF_ERR_INVALID;
+  if (ctx->W == 0) return lf_fail(ctx, LF_ERR_STATE, "lf_clear_ghost_buffer before lf_set_frame");
+  LF_HIP(ctx, hipSetDevice(ctx->device));
+  LF_HIP(ctx, hipMemsetAsync(ctx->ghost, 0, (size_t)ctx->W * ctx->H_alloc * 3 * sizeof(double), ctx->stream));
+  ctx->ghost_valid = true;
+  return LF_OK;
+}
+
+lf_status lf_draw_ghost(lf_ctx* ctx, int channel, float r1, float r2, int bbox[4]) {
+  if (!ctx || channel < 0 || channel > 2) return LF_ERR_INVALID;
+  lf_status st = ghost_helper_ready(ctx, "lf_draw_ghost");
+  if (st != LF_OK) return st;
+  if (!ctx->flares_valid) return lf_fail(ctx, LF_ERR_STATE, "lf_draw_ghost: no flare state (axis_ray)");
+  return lfk_draw_ghost(ctx, channel, r1, r2, bbox);
+}
+
+lf_status lf_rasterize_textured_triangle(lf_ctx* ctx, const float v[12], const double colour[3], int bbox[4]) {
+  if (!ctx || !v || !colour) return LF_ERR_INVALID;
+  lf_status st = ghost_helper_ready(ctx, "lf_rasterize_textured_triangle");
+  if (st != LF_OK) return st;
+  return lfk_raster_triangle(ctx, v, colour, bbox);
+}
+
+lf_status lf_fill_textured_pixel(lf_ctx* ctx, const float v[12], int x, int y, const double colour[3]) {
+  if (!ctx || !v || !colour) return LF_ERR_INVALID;
+  lf_status st = ghost_helper_ready(ctx, "lf_fill_textured_pixel");
+  if (st != LF_OK) return st;
+  // "assumes in bounds" (pathtracer.cpp:307): the reference would write past its buffer
+  if (x < 0 || y < 0 || x >= ctx->W || y >= ctx->H) return lf_fail(ctx, LF_ERR_INVALID, "lf_fill_textured_pixel: pixel outside the frame");
+  return lfk_fill_pixel(ctx, v, x, y, colour);
+}
+
+lf_status lf_shift_vertex(lf_ctx* ctx, float x, float y, float scale, float shift_amount, double out_xy[2]) {
+  if (!ctx || !out_xy) return LF_ERR_INVALID;
+  if (!ctx->flares_valid) return lf_fail(ctx, LF_ERR_STATE, "lf_shift_vertex: no flare state (axis_ray)");
+  LF_HIP(ctx, hipSetDevice(ctx->device));
+  return lfk_shift_vertex(ctx, x, y, scale, shift_amount, out_xy);
+}
+
+lf_status lf_compute_phase(lf_ctx* ctx, int flare, double u, double v, double out_re_im[2], double screen_pos[2]) {
+  if (!ctx || !out_re_im || flare < 0 || flare >= LF_MAX_FLARES) return LF_ERR_INVALID;
+  if (ctx->W == 0) return lf_fail(ctx, LF_ERR_STATE, "lf_compute_phase before lf_set_frame");
+  if (!ctx->flares_valid) return lf_fail(ctx, LF_ERR_STATE, "lf_compute_phase: no flare state");
+  LF_HIP(ctx, hipSetDevice(ctx->device));
+  double o[4];
+  lf_status st = lfk_compute_phase(ctx, flare, u, v, o);
+  if (st != LF_OK) return st;
+  out_re_im[0] = o[0]; out_re_im[1] = o[1];
+  if (screen_pos) { screen_pos[0] = o[2]; screen_pos[1] = o[3]; }
+  return LF_OK;
+}
+
+lf_status lf_irradiance_falloff(lf_ctx* ctx, int x, int y, double radius, double rgb[3]) {
+  if (!ctx || !rgb) return LF_ERR_INVALID;
+  if (ctx->W == 0) return lf_fail(ctx, LF_ERR_STATE, "lf_irradiance_falloff before lf_set_frame");
+  if (x < 0 || y < 0 || x >= ctx->W || y >= ctx->H) return lf_fail(ctx, LF_ERR_INVALID, "lf_irradiance_falloff: pixel outside the frame");
+  if (!ctx->flares_valid) return lf_fail(ctx, LF_ERR_STATE, "lf_irradiance_falloff: no flare state");
+  if (ctx->jitter_mode == 0 && !ctx->jitter_table_valid)
+    return lf_fail(ctx, LF_ERR_STATE, "MT19937 jitter selected but no table (frame was resized?)");
+  LF_HIP(ctx, hipSetDevice(ctx->device));
+  return lfk_irradiance_falloff(ctx, x, y, radius, rgb);
+}
+
+// ---------------------------------------------------------------- lens file ---------------------
+lf_status lf_load_lens_file(lf_ctx* ctx, const char* path) {
+  if (!ctx || !path) return LF_ERR_INVALID;
+  FILE* f = std::fopen(path, "r");
+  if (!f) return lf_fail(ctx, LF_ERR_INVALID, std::string("lf_load_lens_file: cannot open ") + path);
+  // rows: radius thickness n_1 ... n_L semi_aperture; '#' starts a comment; radius 0 with index 0 = the stop
+  std::vector<std::vector<double>> rows;
+  double sensor_w = 36.0;
+  char line[1024];
+  bool bad = false;
+  while (std::fgets(line, sizeof(line), f)) {
+    if (char* h = std::strchr(line, '#')) *h = 0;
+    std::vector<double> v;
+    char* p = line;
+    bool keyword = false;
+    while (*p) {
+      while (*p == ' ' || *p == '\t' || *p == '\r' || *p == '\n') p++;
+      if (!*p) break;
+      if (v.empty() && !keyword && std::strncmp(p, "sensor_width_mm", 15) == 0) { keyword = true; p += 15; continue; }
+      char* e = nullptr;
+      const double d = std::strtod(p, &e);
+      if (e == p) { bad = true; break; }
+      v.push_back(d);
+      p = e;
+    }
+    if (bad) break;
+    if (keyword) { if (v.size() != 1) { bad = true; break; } sensor_w = v[0]; continue; }
+    if (!v.empty()) rows.push_back(v);
+  }
+  std::fclose(f);
+  const int n = (int)rows.size();
+  if (bad || n < 1 || n > LF_MAX_SURFACES) return lf_fail(ctx, LF_ERR_INVALID, "lf_load_lens_file: malformed prescription");
+  const int nl = (int)rows[0].size() - 3;
+  if (nl < 1 || nl > LF_MAX_LAMBDA) return lf_fail(ctx, LF_ERR_INVALID, "lf_load_lens_file: a row is radius thickness n_1..n_L semi_aperture");
+  float radius[LF_MAX_SURFACES], thick[LF_MAX_SURFACES], semi[LF_MAX_SURFACES], ior[LF_MAX_LAMBDA * LF_MAX_SURFACES];
+  int stop = -1;
+  for (int k = 0; k < n; k++) {
+    if ((int)rows[k].size() != nl + 3) return lf_fail(ctx, LF_ERR_INVALID, "lf_load_lens_file: rows of different length");
+    radius[k] = (float)rows[k][0]; thick[k] = (float)rows[k][1]; semi[k] = (float)rows[k][nl + 2];
+    const bool is_stop = rows[k][0] == 0 && rows[k][2] == 0;
+    if (is_stop && stop < 0) stop = k;
+    for (int l = 0; l < nl; l++) ior[l * n + k] = (is_stop && stop == k) ? 1.0f : (float)rows[k][2 + l];
+  }
+  return lf_set_lens(ctx, n, stop, nl, radius, thick, ior, semi, (float)sensor_w);
+}
+
+lf_status lf_get_lens_info(lf_ctx* ctx, int* n_surfaces, int* stop_index, int* n_lambda, float* sensor_width_mm,
+                           double* efl_mm) {
+  if (!ctx) return LF_ERR_INVALID;
+  if (!ctx->lens_valid) return lf_fail(ctx, LF_ERR_STATE, "lf_get_lens_info before lf_set_lens");
+  if (n_surfaces) *n_surfaces = ctx->raw_n;
+  if (stop_index) *stop_index = ctx->raw_stop;
+  if (n_lambda) *n_lambda = ctx->lens.n_lambda;
+  if (sensor_width_mm) *sensor_width_mm = ctx->sensor_w_mm;
+  if (efl_mm) {
+    *efl_mm = 0.0;   // (an afocal prescription has none)
+    (void)lf_paraxial_efl(ctx->raw_n, ctx->raw_stop, ctx->raw_radius, ctx->raw_thickness,
+                          ctx->raw_ior + (size_t)(ctx->lens.n_lambda / 2) * ctx->raw_n, efl_mm);
+  }
+  return LF_OK;
+}
+
 lf_status lf_native_sqrt(lf_ctx* ctx, const float* x, float* y, size_t n) {
   if (!ctx || (n && (!x || !y))) return LF_ERR_INVALID;
   if (n == 0) return LF_OK;
@@ -1024,6 +1170,7 @@ lf_status lf_timing_get(lf_ctx* ctx, const char* kernel, int* launches, double* 
   for (int k = 0; k < LFK_COUNT; k++) if (std::strcmp(kernel, kKernelNames[k]) == 0) id = k;
   if (id < 0) return lf_fail(ctx, LF_ERR_INVALID, "unknown kernel name");
   LF_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  if (ctx->comm_stream) LF_HIP(ctx, hipStreamSynchronize(ctx->comm_stream));   // "exchange" runs there
   timing_fold(ctx, true);
   *launches = ctx->timed_n[id];
   *total_ms = ctx->timed_ms[id];

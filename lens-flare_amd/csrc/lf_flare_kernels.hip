@@ -207,7 +207,7 @@ __device__ inline void shift_vertex(double sc, double cs, double nsn, double sn,
 
 __device__ void make_tri(LfGhostTri& t, float x0, float y0, float u0, float v0, float x1, float y1,
                          float u1, float v1, float x2, float y2, float u2, float v2, int W, int H,
-                         int channel, double colour) {
+                         const double colour[3]) {
   // rasterize_textured_triangle :350-394
 #define LF_SWAP(a, b) { float tmp_ = a; a = b; b = tmp_; }
   if (y1 < y0) { LF_SWAP(x0, x1) LF_SWAP(y0, y1) LF_SWAP(u0, u1) LF_SWAP(v0, v1) }
@@ -222,9 +222,35 @@ __device__ void make_tri(LfGhostTri& t, float x0, float y0, float u0, float v0, 
   t.bx1 = min(W - 1, (int)ceilf(fmaxf(fmaxf(x0, x1), x2)));
   t.by0 = max(0, (int)floorf(y0));
   t.by1 = min(H - 1, (int)ceilf(y2));
-  t.channel = channel;
-  t.pad = 0;
-  t.colour = colour;
+  t.colour[0] = colour[0]; t.colour[1] = colour[1]; t.colour[2] = colour[2];
+}
+
+// draw_ghost :433-508: the textured quad (two triangles) of one ghost from the sensor heights r1, r2
+// of its two marginal rays; channel 0, 1, 2 = "red", "green", anything else ("blue", :482-488)
+__device__ void make_ghost_quad(LfGhostTri* two, float r1, float r2, int channel, double ax, double ay,
+                                int W, int H, int tex_w, int tex_h) {
+  float shift_amt = (float)((double)(-(r1 + r2) / 2) * 0.4);
+  float scale_amt = (float)((double)fabsf(r2 - r1) * 0.2);
+  double mid_w = ceil(ax * (double)W), mid_h = ceil(ay * (double)H);
+  float ang = (float)atan((ay - 0.5) / (ax - 0.5));
+  float cs = (float)cos((double)ang), sn = (float)sin((double)ang);  // cosf / sinf
+  float shx = shift_amt * cs, shy = shift_amt * sn;
+  double ulx, uly, llx, lly, urx, ury, lrx, lry;
+  shift_vertex(scale_amt, cs, -sn, sn, shx, shy, -1, 1, ulx, uly);
+  shift_vertex(scale_amt, cs, -sn, sn, shx, shy, -1, -1, llx, lly);
+  shift_vertex(scale_amt, cs, -sn, sn, shx, shy, 1, 1, urx, ury);
+  shift_vertex(scale_amt, cs, -sn, sn, shx, shy, 1, -1, lrx, lry);
+  float intensity_scalar = 10;
+  float size_scalar = __fdiv_rn(1.0f, scale_amt * scale_amt);
+  double colour[3] = {0.0, 0.0, 0.0};   // Vector3D(1,0,0) *= float: the zeros stay zeros
+  colour[channel] = (double)(intensity_scalar * size_scalar);
+  float th = (float)tex_h, tw = (float)tex_w;
+  make_tri(two[0], (float)(mid_w + ulx), (float)(mid_h + uly), 0, 0,
+           (float)(mid_w + llx), (float)(mid_h + lly), 0, th, (float)(mid_w + urx),
+           (float)(mid_h + ury), tw, 0, W, H, colour);
+  make_tri(two[1], (float)(mid_w + lrx), (float)(mid_h + lry), 0, 0,
+           (float)(mid_w + llx), (float)(mid_h + lly), 0, th, (float)(mid_w + urx),
+           (float)(mid_h + ury), tw, 0, W, H, colour);
 }
 
 __global__ void k_frame_setup(const LfParaxialLens* __restrict__ plp, LfCamera cam,
@@ -291,28 +317,7 @@ __global__ void k_frame_setup(const LfParaxialLens* __restrict__ plp, LfCamera c
     build_tables(pl, colour, tb);
     float r1 = (float)trace_pair(pl, tb, pl.marginal, theta, pi, pj, after);
     float r2 = (float)trace_pair(pl, tb, -pl.marginal, theta, pi, pj, after);
-    // draw_ghost :452-498
-    float shift_amt = (float)((double)(-(r1 + r2) / 2) * 0.4);
-    float scale_amt = (float)((double)fabsf(r2 - r1) * 0.2);
-    double mid_w = ceil(ax * (double)W), mid_h = ceil(ay * (double)H);
-    float ang = (float)atan((ay - 0.5) / (ax - 0.5));
-    float cs = (float)cos((double)ang), sn = (float)sin((double)ang);  // cosf / sinf
-    float shx = shift_amt * cs, shy = shift_amt * sn;
-    double ulx, uly, llx, lly, urx, ury, lrx, lry;
-    shift_vertex(scale_amt, cs, -sn, sn, shx, shy, -1, 1, ulx, uly);
-    shift_vertex(scale_amt, cs, -sn, sn, shx, shy, -1, -1, llx, lly);
-    shift_vertex(scale_amt, cs, -sn, sn, shx, shy, 1, 1, urx, ury);
-    shift_vertex(scale_amt, cs, -sn, sn, shx, shy, 1, -1, lrx, lry);
-    float intensity_scalar = 10;
-    float size_scalar = __fdiv_rn(1.0f, scale_amt * scale_amt);
-    double colour_k = (double)(intensity_scalar * size_scalar);
-    float th = (float)tex_h, tw = (float)tex_w;
-    make_tri(gl->tri[2 * g], (float)(mid_w + ulx), (float)(mid_h + uly), 0, 0,
-             (float)(mid_w + llx), (float)(mid_h + lly), 0, th, (float)(mid_w + urx),
-             (float)(mid_h + ury), tw, 0, W, H, colour, colour_k);
-    make_tri(gl->tri[2 * g + 1], (float)(mid_w + lrx), (float)(mid_h + lry), 0, 0,
-             (float)(mid_w + llx), (float)(mid_h + lly), 0, th, (float)(mid_w + urx),
-             (float)(mid_h + ury), tw, 0, W, H, colour, colour_k);
+    make_ghost_quad(&gl->tri[2 * g], r1, r2, colour, ax, ay, W, H, tex_w, tex_h);
   }
 }
 
@@ -322,9 +327,37 @@ __global__ void k_frame_setup(const LfParaxialLens* __restrict__ plp, LfCamera c
 // =============================================================================================
 constexpr int kTileW = 64, kTileH = 4;
 
+// fill_textured_pixel :305-343, all float, unfused: acc += texel * ghost_color when (x, y) is inside
+__device__ inline void fill_textured_pixel(const LfGhostTri& tr, int x, int y,
+                                           const float* __restrict__ tex, int tex_w, int tex_h,
+                                           double acc[3]) {
+  const float x0 = tr.x0, y0f = tr.y0, x1 = tr.x1, y1f = tr.y1, x2 = tr.x2, y2f = tr.y2;
+  float xy_to_01 = -(y1f - y0f) * (x - x0) + (x1 - x0) * (y - y0f);
+  float two_to_01 = -(y1f - y0f) * (x2 - x0) + (x1 - x0) * (y2f - y0f);
+  float alpha = __fdiv_rn(xy_to_01, two_to_01);
+  float xy_to_12 = -(y2f - y1f) * (x - x1) + (x2 - x1) * (y - y1f);
+  float zero_to_12 = -(y2f - y1f) * (x0 - x1) + (x2 - x1) * (y0f - y1f);
+  float beta = __fdiv_rn(xy_to_12, zero_to_12);
+  float gamma = 1 - alpha - beta;
+  if (gamma >= 0 && alpha >= 0 && beta >= 0) {
+    float u = tr.u2 * alpha + tr.u0 * beta + tr.u1 * gamma;
+    float v = tr.v2 * alpha + tr.v0 * beta + tr.v1 * gamma;
+    int idx = (int)(floor((double)v) * (double)tex_w + (double)u);  // :338
+    // the reference reads its vector unchecked; an index past the end is defined as 0 here
+    float s = (idx >= 0 && idx < tex_w * tex_h) ? tex[idx] : 0.0f;
+    // sample * ghost_color, then update_pixel_additive (image.h:145): a zero component adds +0.0
+    acc[0] += (double)s * tr.colour[0];
+    acc[1] += (double)s * tr.colour[1];
+    acc[2] += (double)s * tr.colour[2];
+  }
+}
+
+// accumulate = 0: the pixel is REPLACED by the sum over the list (generate_ghost_buffer: the buffer
+// was cleared, :719); 1: the list is added on top of what the pixel holds, triangle by triangle like
+// update_pixel_additive (the single-ghost / single-triangle entry points)
 __global__ __launch_bounds__(256) void k_ghost_raster(const LfGhostList* __restrict__ gl,
                                                       const float* __restrict__ tex, int tex_w,
-                                                      int tex_h, int W, int y0, int y1,
+                                                      int tex_h, int W, int y0, int y1, int accumulate,
                                                       double* __restrict__ ghost) {
   __shared__ unsigned char s_hit[kMaxGhostTris];
   const int n_tris = gl->n_tris;
@@ -337,31 +370,70 @@ __global__ __launch_bounds__(256) void k_ghost_raster(const LfGhostList* __restr
   __syncthreads();
   const int x = tx0 + (threadIdx.x & (kTileW - 1)), y = ty0 + (threadIdx.x / kTileW);
   if (x >= W || y >= y1) return;
+  double* px = ghost + 3 * ((size_t)x + (size_t)y * W);
   double acc[3] = {0.0, 0.0, 0.0};
+  if (accumulate) { acc[0] = px[0]; acc[1] = px[1]; acc[2] = px[2]; }
   for (int t = 0; t < n_tris; t++) {
     if (!s_hit[t]) continue;           // workgroup-uniform
     const LfGhostTri& tr = gl->tri[t]; // uniform address -> scalar loads
     if (x < tr.bx0 || x >= tr.bx1 || y < tr.by0 || y >= tr.by1) continue;
-    // fill_textured_pixel :309-340, all float, unfused
-    const float x0 = tr.x0, y0f = tr.y0, x1 = tr.x1, y1f = tr.y1, x2 = tr.x2, y2f = tr.y2;
-    float xy_to_01 = -(y1f - y0f) * (x - x0) + (x1 - x0) * (y - y0f);
-    float two_to_01 = -(y1f - y0f) * (x2 - x0) + (x1 - x0) * (y2f - y0f);
-    float alpha = __fdiv_rn(xy_to_01, two_to_01);
-    float xy_to_12 = -(y2f - y1f) * (x - x1) + (x2 - x1) * (y - y1f);
-    float zero_to_12 = -(y2f - y1f) * (x0 - x1) + (x2 - x1) * (y0f - y1f);
-    float beta = __fdiv_rn(xy_to_12, zero_to_12);
-    float gamma = 1 - alpha - beta;
-    if (gamma >= 0 && alpha >= 0 && beta >= 0) {
-      float u = tr.u2 * alpha + tr.u0 * beta + tr.u1 * gamma;
-      float v = tr.v2 * alpha + tr.v0 * beta + tr.v1 * gamma;
-      int idx = (int)(floor((double)v) * (double)tex_w + (double)u);  // :338
-      // the reference reads its vector unchecked; an index past the end is defined as 0 here
-      float s = (idx >= 0 && idx < tex_w * tex_h) ? tex[idx] : 0.0f;
-      acc[tr.channel] += (double)s * tr.colour;
-    }
+    fill_textured_pixel(tr, x, y, tex, tex_w, tex_h, acc);
   }
-  double* px = ghost + 3 * ((size_t)x + (size_t)y * W);
   px[0] = acc[0]; px[1] = acc[1]; px[2] = acc[2];
+}
+
+// ---- the single-shot forms of the reference's public helper members (one wave each) ----------
+// PathTracer::draw_ghost(color, r1, r2): the quad of one ghost into the list
+__global__ void k_one_ghost(const LfFlares* __restrict__ fl, float r1, float r2, int channel, int W,
+                            int H, int tex_w, int tex_h, LfGhostList* __restrict__ gl) {
+  if (threadIdx.x != 0) return;
+  gl->n_tris = 2;
+  make_ghost_quad(gl->tri, r1, r2, channel, fl->axis_ray[0], fl->axis_ray[1], W, H, tex_w, tex_h);
+}
+
+struct LfTriArgs { float v[12]; double colour[3]; };
+// PathTracer::rasterize_textured_triangle(x0, y0, u0, v0, ..., ghost_color): one triangle into the list
+__global__ void k_one_triangle(LfTriArgs a, int W, int H, LfGhostList* __restrict__ gl) {
+  if (threadIdx.x != 0) return;
+  gl->n_tris = 1;
+  make_tri(gl->tri[0], a.v[0], a.v[1], a.v[2], a.v[3], a.v[4], a.v[5], a.v[6], a.v[7], a.v[8], a.v[9],
+           a.v[10], a.v[11], W, H, a.colour);
+}
+// PathTracer::fill_textured_pixel(x0, ..., v2, x, y, ghost_color): vertices as given (the caller has
+// sorted and shifted them), one pixel
+__global__ void k_one_pixel(LfTriArgs a, int x, int y, const float* __restrict__ tex, int tex_w,
+                            int tex_h, int W, double* __restrict__ ghost) {
+  if (threadIdx.x != 0) return;
+  LfGhostTri tr;
+  tr.x0 = a.v[0]; tr.y0 = a.v[1]; tr.u0 = a.v[2]; tr.v0 = a.v[3];
+  tr.x1 = a.v[4]; tr.y1 = a.v[5]; tr.u1 = a.v[6]; tr.v1 = a.v[7];
+  tr.x2 = a.v[8]; tr.y2 = a.v[9]; tr.u2 = a.v[10]; tr.v2 = a.v[11];
+  tr.colour[0] = a.colour[0]; tr.colour[1] = a.colour[1]; tr.colour[2] = a.colour[2];
+  double* px = ghost + 3 * ((size_t)x + (size_t)y * W);
+  double acc[3] = {px[0], px[1], px[2]};
+  fill_textured_pixel(tr, x, y, tex, tex_w, tex_h, acc);
+  px[0] = acc[0]; px[1] = acc[1]; px[2] = acc[2];
+}
+// PathTracer::shift_vertex(x, y, scale, shift_amount) :412-430 with the members' axis_ray
+__global__ void k_shift_vertex(const LfFlares* __restrict__ fl, float x, float y, float scale,
+                               float shift_amount, double* __restrict__ out) {
+  if (threadIdx.x != 0) return;
+  const double ax = fl->axis_ray[0], ay = fl->axis_ray[1];
+  float ang = (float)atan((ay - 0.5) / (ax - 0.5));
+  float cs = (float)cos((double)ang), sn = (float)sin((double)ang);
+  shift_vertex(scale, cs, -sn, sn, shift_amount * cs, shift_amount * sn, x, y, out[0], out[1]);
+}
+// PathTracer::compute_phase(flare, u, v, screen_pos) :917-931 with complex_exp(., false) :901-915
+__global__ void k_compute_phase(const LfFlares* __restrict__ fl, int flare, double u, double v, int W,
+                                int H, double* __restrict__ out) {
+  if (threadIdx.x != 0) return;
+  double lr = ceil(fl->origin[flare][0] * (double)W), ud = ceil(fl->origin[flare][1] * (double)H);
+  out[2] = lr; out[3] = ud;
+  lr -= (double)W / 2.0;
+  ud = -ud + (double)H / 2.0;
+  const double e = u * lr + v * ud;
+  out[0] = cos(2.0 * 3.14159265358979323846 * e);
+  out[1] = sin(2.0 * 3.14159265358979323846 * e);
 }
 
 // =============================================================================================
@@ -397,6 +469,55 @@ __device__ inline double convert_coordinate(int p, int length, bool y) {
   double c = y ? (-((double)(float)p) + ((double)(float)length / 2.0))
                : (((double)(float)p) - ((double)(float)length / 2.0));
   return c >= 0 ? c : (double)length + c;
+}
+
+// calculate_irradiance_falloff(x, y, radius) :1043-1063; the 32 draws of pixel p come from the MT19937
+// table in the reference's visit order (jitter_mode 0) or from the counter RNG
+__device__ inline void irradiance_falloff(const LfFlares* __restrict__ fl, int n_flares, int x, int y,
+                                          size_t p, double radius, double dW, double dH,
+                                          const uint32_t* __restrict__ jitter_raw, int jitter_mode,
+                                          uint64_t key, double out[3]) {
+  double t[3] = {0.0, 0.0, 0.0};
+  uint4 raw4 = make_uint4(0, 0, 0, 0);
+  for (int s = 0; s < 16; s++) {
+    unsigned ra, rb;
+    if (jitter_mode == 0) {
+      const uint32_t* jr = jitter_raw + p * 32;
+      ra = jr[2 * s]; rb = jr[2 * s + 1];
+    } else {
+      if ((s & 1) == 0)
+        raw4 = philox4x32_10(make_uint4((unsigned)p, (unsigned)(p >> 32), (unsigned)(s >> 1),
+                                        0x0fa110ffu),
+                             make_uint2((unsigned)key, (unsigned)(key >> 32)));
+      ra = (s & 1) ? raw4.z : raw4.x;
+      rb = (s & 1) ? raw4.w : raw4.y;
+    }
+    // Vector2D(random_uniform(), random_uniform()) (sampler.cpp:8-12): g++ evaluates the
+    // second argument first, so the first draw is the y jitter
+    double sy = (double)y + random_uniform_from_raw(ra);
+    double sx = (double)x + random_uniform_from_raw(rb);
+    for (int l = 0; l < n_flares; l++) {
+      double fx = fl->origin[l][0] * dW, fy = fl->origin[l][1] * dH;
+      double ex = fx - sx, ey = fy - sy;
+      double nrm = sqrt(ex * ex + ey * ey) - radius;
+      double r = 1 + (0.0 < nrm ? nrm : 0.0);
+      double rc = 1.0 / pow(r, 1.5);
+      t[0] += rc * fl->radiance[l][0];
+      t[1] += rc * fl->radiance[l][1];
+      t[2] += rc * fl->radiance[l][2];
+    }
+  }
+  const double rc16 = 1.0 / 16.0;   // total / (double)num_samples: Vector3D::operator/ multiplies
+  out[0] = rc16 * t[0]; out[1] = rc16 * t[1]; out[2] = rc16 * t[2];
+}
+
+// PathTracer::calculate_irradiance_falloff(x, y, radius) on its own
+__global__ void k_one_falloff(const LfFlares* __restrict__ fl, int x, int y, double radius, int W, int H,
+                              const uint32_t* __restrict__ jitter_raw, int jitter_mode, uint64_t key,
+                              double* __restrict__ out) {
+  if (threadIdx.x != 0) return;
+  irradiance_falloff(fl, fl->n_flares, x, y, (size_t)x + (size_t)y * W, radius, (double)W, (double)H,
+                     jitter_raw, jitter_mode, key, out);
 }
 
 __global__ __launch_bounds__(256) void k_flare_layer(
@@ -468,40 +589,10 @@ __global__ __launch_bounds__(256) void k_flare_layer(
           for (int c = 0; c < 3; c++) star[c] += (pw * fl->radiance[l][c]) * spec.rgb[w][c];
       }
     }
-    // ---- calculate_irradiance_falloff(x, y, 5.0) :1043-1063 ------------------------------
-    double t[3] = {0.0, 0.0, 0.0};
-    const double radius = 5.0;
-    uint4 raw4 = make_uint4(0, 0, 0, 0);
-    for (int s = 0; s < 16; s++) {
-      unsigned ra, rb;
-      if (jitter_mode == 0) {
-        const uint32_t* jr = jitter_raw + p * 32;
-        ra = jr[2 * s]; rb = jr[2 * s + 1];
-      } else {
-        if ((s & 1) == 0)
-          raw4 = philox4x32_10(make_uint4((unsigned)p, (unsigned)(p >> 32), (unsigned)(s >> 1),
-                                          0x0fa110ffu),
-                               make_uint2((unsigned)key, (unsigned)(key >> 32)));
-        ra = (s & 1) ? raw4.z : raw4.x;
-        rb = (s & 1) ? raw4.w : raw4.y;
-      }
-      // Vector2D(random_uniform(), random_uniform()) (sampler.cpp:8-12): g++ evaluates the
-      // second argument first, so the first draw is the y jitter
-      double sy = (double)y + random_uniform_from_raw(ra);
-      double sx = (double)x + random_uniform_from_raw(rb);
-      for (int l = 0; l < n_flares; l++) {
-        double fx = fl->origin[l][0] * dW, fy = fl->origin[l][1] * dH;
-        double ex = fx - sx, ey = fy - sy;
-        double nrm = sqrt(ex * ex + ey * ey) - radius;
-        double r = 1 + (0.0 < nrm ? nrm : 0.0);
-        double rc = 1.0 / pow(r, 1.5);
-        t[0] += rc * fl->radiance[l][0];
-        t[1] += rc * fl->radiance[l][1];
-        t[2] += rc * fl->radiance[l][2];
-      }
-    }
-    const double rc16 = 1.0 / 16.0;
-    star[0] += rc16 * t[0]; star[1] += rc16 * t[1]; star[2] += rc16 * t[2];  // :1004
+    // ---- calculate_irradiance_falloff(x, y, 5.0) :1002 -------------------------------------
+    double t[3];
+    irradiance_falloff(fl, n_flares, x, y, p, 5.0, dW, dH, jitter_raw, jitter_mode, key, t);
+    star[0] += t[0]; star[1] += t[1]; star[2] += t[2];  // :1004
   }
   // ---- raytrace_pixel :875-891 ---------------------------------------------------------------
   // scene holds the already averaged radiance (sum / (ns_aa+1), :875); absent = nothing was hit
@@ -610,10 +701,96 @@ lf_status lfk_ghost_raster(lf_ctx* ctx) {
   dim3 grid((ctx->W + kTileW - 1) / kTileW, (ctx->y1 - ctx->y0 + kTileH - 1) / kTileH);
   hipEvent_t ev = lf_timing_begin(ctx, LFK_GHOST_RASTER);
   hipLaunchKernelGGL(k_ghost_raster, grid, dim3(256), 0, ctx->stream, ctx->ghosts, g.texels, g.w,
-                     g.h, ctx->W, ctx->y0, ctx->y1, ctx->ghost);
+                     g.h, ctx->W, ctx->y0, ctx->y1, 0, ctx->ghost);
   lf_timing_end(ctx, LFK_GHOST_RASTER, ev);
   LF_HIP(ctx, hipGetLastError());
   return LF_OK;
+}
+
+// the one or two triangles a single-shot set-up kernel left in ctx->ghosts, added on top of the
+// ghost buffer; bbox (may be null) receives the pixel rectangle [x0, x1) x [y0, y1) they can touch
+static lf_status raster_list_additive(lf_ctx* ctx, int bbox[4]) {
+  struct { int n_tris, pad; LfGhostTri tri[2]; } head;
+  LF_HIP(ctx, hipMemcpyAsync(&head, ctx->ghosts, sizeof(head), hipMemcpyDeviceToHost, ctx->stream));
+  LF_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  int x0 = ctx->W, y0 = ctx->H, x1 = 0, y1 = 0;
+  for (int t = 0; t < head.n_tris && t < 2; t++) {
+    x0 = std::min(x0, head.tri[t].bx0); x1 = std::max(x1, head.tri[t].bx1);
+    y0 = std::min(y0, head.tri[t].by0); y1 = std::max(y1, head.tri[t].by1);
+  }
+  if (x1 <= x0 || y1 <= y0) { x0 = x1 = y0 = y1 = 0; }
+  if (bbox) { bbox[0] = x0; bbox[1] = y0; bbox[2] = x1; bbox[3] = y1; }
+  if (y1 > y0) {
+    const LfApertureDev& g = ctx->ap[LF_APERTURE_GHOST];
+    dim3 grid((ctx->W + kTileW - 1) / kTileW, (y1 - y0 + kTileH - 1) / kTileH);
+    hipLaunchKernelGGL(k_ghost_raster, grid, dim3(256), 0, ctx->stream, ctx->ghosts, g.texels, g.w, g.h,
+                       ctx->W, y0, y1, 1, ctx->ghost);
+    LF_HIP(ctx, hipGetLastError());
+  }
+  return LF_OK;
+}
+
+lf_status lfk_draw_ghost(lf_ctx* ctx, int channel, float r1, float r2, int bbox[4]) {
+  const LfApertureDev& g = ctx->ap[LF_APERTURE_GHOST];
+  hipLaunchKernelGGL(k_one_ghost, dim3(1), dim3(64), 0, ctx->stream, ctx->flares, r1, r2, channel, ctx->W,
+                     ctx->H, g.w, g.h, ctx->ghosts);
+  LF_HIP(ctx, hipGetLastError());
+  return raster_list_additive(ctx, bbox);
+}
+
+lf_status lfk_raster_triangle(lf_ctx* ctx, const float v[12], const double colour[3], int bbox[4]) {
+  LfTriArgs a;
+  std::memcpy(a.v, v, sizeof(a.v));
+  std::memcpy(a.colour, colour, sizeof(a.colour));
+  hipLaunchKernelGGL(k_one_triangle, dim3(1), dim3(64), 0, ctx->stream, a, ctx->W, ctx->H, ctx->ghosts);
+  LF_HIP(ctx, hipGetLastError());
+  return raster_list_additive(ctx, bbox);
+}
+
+lf_status lfk_fill_pixel(lf_ctx* ctx, const float v[12], int x, int y, const double colour[3]) {
+  LfTriArgs a;
+  std::memcpy(a.v, v, sizeof(a.v));
+  std::memcpy(a.colour, colour, sizeof(a.colour));
+  const LfApertureDev& g = ctx->ap[LF_APERTURE_GHOST];
+  hipLaunchKernelGGL(k_one_pixel, dim3(1), dim3(64), 0, ctx->stream, a, x, y, g.texels, g.w, g.h, ctx->W,
+                     ctx->ghost);
+  LF_HIP(ctx, hipGetLastError());
+  return LF_OK;
+}
+
+// the scalar-valued helper members: one wave writes `n_out` doubles, which come straight back
+template <typename Launch>
+static lf_status probe_doubles(lf_ctx* ctx, int n_out, double* out, Launch launch) {
+  double* d = nullptr;
+  LF_HIP(ctx, hipMalloc((void**)&d, sizeof(double) * (size_t)n_out));
+  launch(d);
+  hipError_t e = hipGetLastError();
+  if (e == hipSuccess) e = hipMemcpyAsync(out, d, sizeof(double) * (size_t)n_out, hipMemcpyDeviceToHost, ctx->stream);
+  if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+  (void)hipFree(d);
+  LF_HIP(ctx, e);
+  return LF_OK;
+}
+
+lf_status lfk_shift_vertex(lf_ctx* ctx, float x, float y, float scale, float shift_amount, double out[2]) {
+  return probe_doubles(ctx, 2, out, [&](double* d) {
+    hipLaunchKernelGGL(k_shift_vertex, dim3(1), dim3(64), 0, ctx->stream, ctx->flares, x, y, scale,
+                       shift_amount, d);
+  });
+}
+
+lf_status lfk_compute_phase(lf_ctx* ctx, int flare, double u, double v, double out[4]) {
+  return probe_doubles(ctx, 4, out, [&](double* d) {
+    hipLaunchKernelGGL(k_compute_phase, dim3(1), dim3(64), 0, ctx->stream, ctx->flares, flare, u, v, ctx->W,
+                       ctx->H, d);
+  });
+}
+
+lf_status lfk_irradiance_falloff(lf_ctx* ctx, int x, int y, double radius, double out[3]) {
+  return probe_doubles(ctx, 3, out, [&](double* d) {
+    hipLaunchKernelGGL(k_one_falloff, dim3(1), dim3(64), 0, ctx->stream, ctx->flares, x, y, radius, ctx->W,
+                       ctx->H, ctx->jitter_raw, ctx->jitter_mode, ctx->jitter_key, d);
+  });
 }
 
 lf_status lfk_flare_layer(lf_ctx* ctx) {

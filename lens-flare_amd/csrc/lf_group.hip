@@ -42,6 +42,9 @@ struct Rccl {
   ncclResult_t (*AllGather)(const void*, void*, size_t, ncclDataType_t, ncclComm_t, hipStream_t) = nullptr;
   ncclResult_t (*GroupStart)() = nullptr;
   ncclResult_t (*GroupEnd)() = nullptr;
+  ncclResult_t (*CommCount)(const ncclComm_t, int*) = nullptr;
+  ncclResult_t (*CommUserRank)(const ncclComm_t, int*) = nullptr;
+  ncclResult_t (*CommAbort)(ncclComm_t) = nullptr;
   const char* (*GetErrorString)(ncclResult_t) = nullptr;
   std::string error;
 };
@@ -65,28 +68,35 @@ Rccl* rccl() {
     r.AllGather = (decltype(r.AllGather))sym("ncclAllGather");
     r.GroupStart = (decltype(r.GroupStart))sym("ncclGroupStart");
     r.GroupEnd = (decltype(r.GroupEnd))sym("ncclGroupEnd");
+    r.CommCount = (decltype(r.CommCount))sym("ncclCommCount");
+    r.CommUserRank = (decltype(r.CommUserRank))sym("ncclCommUserRank");
+    r.CommAbort = (decltype(r.CommAbort))sym("ncclCommAbort");
     r.GetErrorString = (decltype(r.GetErrorString))sym("ncclGetErrorString");
     if (!ok) { dlclose(r.handle); r.handle = nullptr; r.error = "librccl lacks an entry point"; }
   });
   return r.handle ? &r : nullptr;
 }
 
-// frame viewed as [groups][world][e doubles]: slot (g, rank) -> send[g]
-__global__ void k_pack_rows(const double* __restrict__ frame, double* __restrict__ send, int rank, int world,
+// frame viewed as [groups][world][e doubles]: slot (g, rank) -> send[g].  T = double: the exchange
+// moves the sensor values as they are; T = float (lf_comm_set_exchange_precision(32)): half the bytes
+// on the wire, the rows a rank RECEIVES are rounded to float (its own rows stay as rendered)
+template <typename T>
+__global__ void k_pack_rows(const double* __restrict__ frame, T* __restrict__ send, int rank, int world,
                             size_t groups, size_t e) {
   const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= groups * e) return;
   const size_t g = i / e, k = i - g * e;
-  send[i] = frame[(g * world + rank) * e + k];
+  send[i] = (T)frame[(g * world + rank) * e + k];
 }
 // recv = [world][groups][e] -> frame[g][r]; the rank's own slots are already in place
-__global__ void k_unpack_rows(const double* __restrict__ recv, double* __restrict__ frame, int rank, int world,
+template <typename T>
+__global__ void k_unpack_rows(const T* __restrict__ recv, double* __restrict__ frame, int rank, int world,
                               size_t groups, size_t e) {
   const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= (size_t)world * groups * e) return;
   const size_t r = i / (groups * e), rem = i - r * groups * e, g = rem / e, k = rem - g * e;
   if ((int)r == rank) return;
-  frame[(g * world + r) * e + k] = recv[i];
+  frame[(g * world + r) * e + k] = (double)recv[i];
 }
 
 double* frame_buffer(lf_ctx* ctx, int which) { return which == 0 ? ctx->sample : which == 1 ? ctx->ghost : ctx->star; }
@@ -110,11 +120,23 @@ lf_status ensure_staging(lf_ctx* ctx, int world) {
   return LF_OK;
 }
 
+// staging layout in elements of the exchange type: send [groups][e], then recv [world][groups][e]
+// (sized for doubles, so the float exchange fits as well)
+void* stage_recv(lf_ctx* ctx, size_t cnt) {
+  return ctx->comm_f32 ? (void*)((float*)ctx->comm_stage + cnt) : (void*)(ctx->comm_stage + cnt);
+}
+
 lf_status launch_pack(lf_ctx* ctx, int which, int rank, int world, hipStream_t stream = nullptr) {
   const Shape s = shape(ctx, world);
   const size_t n = s.groups * s.e;
-  hipLaunchKernelGGL(k_pack_rows, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream ? stream : ctx->stream,
-                     frame_buffer(ctx, which), ctx->comm_stage, rank, world, s.groups, s.e);
+  const dim3 grid((unsigned)((n + 255) / 256));
+  hipStream_t q = stream ? stream : ctx->stream;
+  if (ctx->comm_f32)
+    hipLaunchKernelGGL(k_pack_rows<float>, grid, dim3(256), 0, q, frame_buffer(ctx, which), (float*)ctx->comm_stage,
+                       rank, world, s.groups, s.e);
+  else
+    hipLaunchKernelGGL(k_pack_rows<double>, grid, dim3(256), 0, q, frame_buffer(ctx, which), ctx->comm_stage, rank,
+                       world, s.groups, s.e);
   LF_HIP(ctx, hipGetLastError());
   return LF_OK;
 }
@@ -122,10 +144,21 @@ lf_status launch_pack(lf_ctx* ctx, int which, int rank, int world, hipStream_t s
 lf_status launch_unpack(lf_ctx* ctx, int which, int rank, int world, hipStream_t stream = nullptr) {
   const Shape s = shape(ctx, world);
   const size_t n = (size_t)world * s.groups * s.e;
-  hipLaunchKernelGGL(k_unpack_rows, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream ? stream : ctx->stream,
-                     ctx->comm_stage + s.groups * s.e, frame_buffer(ctx, which), rank, world, s.groups, s.e);
+  const dim3 grid((unsigned)((n + 255) / 256));
+  hipStream_t q = stream ? stream : ctx->stream;
+  if (ctx->comm_f32)
+    hipLaunchKernelGGL(k_unpack_rows<float>, grid, dim3(256), 0, q, (const float*)stage_recv(ctx, s.groups * s.e),
+                       frame_buffer(ctx, which), rank, world, s.groups, s.e);
+  else
+    hipLaunchKernelGGL(k_unpack_rows<double>, grid, dim3(256), 0, q, (const double*)stage_recv(ctx, s.groups * s.e),
+                       frame_buffer(ctx, which), rank, world, s.groups, s.e);
   LF_HIP(ctx, hipGetLastError());
   return LF_OK;
+}
+
+// the exchange changes rows of a frame buffer: a tonemapped copy of the sensor buffer is stale then
+void invalidate_tonemap(lf_ctx* ctx, int which) {
+  if (which == 0) ctx->rgba_y0 = ctx->rgba_y1 = 0;
 }
 
 lf_status check_gather_args(lf_ctx* ctx, int which, int world) {
@@ -200,12 +233,16 @@ lf_status lf_comm_gather(lf_ctx* ctx, int which) {
   LF_HIP(ctx, hipSetDevice(ctx->device));
   if ((st = lf_comm_join(ctx)) != LF_OK) return st;     // an asynchronous exchange uses the same staging
   if ((st = ensure_staging(ctx, world)) != LF_OK) return st;
+  invalidate_tonemap(ctx, which);
+  hipEvent_t ev = lf_timing_begin(ctx, LFK_EXCHANGE);
   if ((st = launch_pack(ctx, which, rank, world)) != LF_OK) return st;
   const Shape s = shape(ctx, world);
-  const ncclResult_t rc = r->AllGather(ctx->comm_stage, ctx->comm_stage + s.groups * s.e, s.groups * s.e,
-                                       ncclDouble, (ncclComm_t)ctx->comm, ctx->stream);
+  const ncclResult_t rc = r->AllGather(ctx->comm_stage, stage_recv(ctx, s.groups * s.e), s.groups * s.e,
+                                       ctx->comm_f32 ? ncclFloat : ncclDouble, (ncclComm_t)ctx->comm, ctx->stream);
   if (rc != ncclSuccess) return lf_fail(ctx, LF_ERR_HIP, std::string("ncclAllGather: ") + r->GetErrorString(rc));
-  return launch_unpack(ctx, which, rank, world);
+  st = launch_unpack(ctx, which, rank, world);
+  lf_timing_end(ctx, LFK_EXCHANGE, ev);
+  return st;
 }
 
 // The exchange of the frame just rendered, on the context's SECOND stream: pack (after everything the
@@ -230,16 +267,19 @@ lf_status lf_comm_gather_async(lf_ctx* ctx, int which) {
     LF_HIP(ctx, hipEventCreateWithFlags(&ctx->comm_ev_done, hipEventDisableTiming));
   }
   if ((st = ensure_staging(ctx, world)) != LF_OK) return st;
+  invalidate_tonemap(ctx, which);
   const Shape s = shape(ctx, world);
   LF_HIP(ctx, hipEventRecord(ctx->comm_ev_main, ctx->stream));
   LF_HIP(ctx, hipStreamWaitEvent(ctx->comm_stream, ctx->comm_ev_main, 0));
+  hipEvent_t ev = lf_timing_begin(ctx, LFK_EXCHANGE, ctx->comm_stream);   // pack -> unpack, on the exchange's own stream
   if ((st = launch_pack(ctx, which, rank, world, ctx->comm_stream)) != LF_OK) return st;
   LF_HIP(ctx, hipEventRecord(ctx->comm_ev_pack, ctx->comm_stream));
   LF_HIP(ctx, hipStreamWaitEvent(ctx->stream, ctx->comm_ev_pack, 0));
-  const ncclResult_t rc = r->AllGather(ctx->comm_stage, ctx->comm_stage + s.groups * s.e, s.groups * s.e,
-                                       ncclDouble, (ncclComm_t)ctx->comm, ctx->comm_stream);
+  const ncclResult_t rc = r->AllGather(ctx->comm_stage, stage_recv(ctx, s.groups * s.e), s.groups * s.e,
+                                       ctx->comm_f32 ? ncclFloat : ncclDouble, (ncclComm_t)ctx->comm, ctx->comm_stream);
   if (rc != ncclSuccess) return lf_fail(ctx, LF_ERR_HIP, std::string("ncclAllGather: ") + r->GetErrorString(rc));
   if ((st = launch_unpack(ctx, which, rank, world, ctx->comm_stream)) != LF_OK) return st;
+  lf_timing_end(ctx, LFK_EXCHANGE, ev, ctx->comm_stream);
   LF_HIP(ctx, hipEventRecord(ctx->comm_ev_done, ctx->comm_stream));
   ctx->comm_pending = true;
   return LF_OK;
@@ -248,6 +288,57 @@ lf_status lf_comm_gather_async(lf_ctx* ctx, int which) {
 lf_status lf_comm_wait(lf_ctx* ctx) {
   if (!ctx) return LF_ERR_INVALID;
   return lf_comm_join(ctx);
+}
+
+lf_status lf_comm_available(void) { return rccl() ? LF_OK : LF_ERR_STATE; }
+
+lf_status lf_comm_info(lf_ctx* ctx, int* nranks, int* rank) {
+  if (!ctx) return LF_ERR_INVALID;
+  int n = ctx->comm_nranks, k = ctx->comm_rank;
+  if (ctx->comm) {   // what RCCL itself says about the communicator this context is attached to
+    Rccl* r = rccl();
+    ncclResult_t rc = r->CommCount((ncclComm_t)ctx->comm, &n);
+    if (rc == ncclSuccess) rc = r->CommUserRank((ncclComm_t)ctx->comm, &k);
+    if (rc != ncclSuccess) return lf_fail(ctx, LF_ERR_HIP, std::string("ncclCommCount: ") + r->GetErrorString(rc));
+  } else {
+    n = 0; k = -1;   // no RCCL communicator (single GPU, or a rehearsal group exchanging with peer copies)
+  }
+  if (nranks) *nranks = n;
+  if (rank) *rank = k;
+  return LF_OK;
+}
+
+lf_status lf_comm_test(lf_ctx* ctx, int* done) {
+  if (!ctx || !done) return LF_ERR_INVALID;
+  LF_HIP(ctx, hipSetDevice(ctx->device));
+  hipError_t e = ctx->comm_pending ? hipEventQuery(ctx->comm_ev_done) : hipStreamQuery(ctx->stream);
+  if (e == hipErrorNotReady) { *done = 0; return LF_OK; }
+  LF_HIP(ctx, e);
+  *done = 1;
+  return LF_OK;
+}
+
+lf_status lf_comm_abort(lf_ctx* ctx) {
+  if (!ctx) return LF_ERR_INVALID;
+  if (!ctx->comm) return LF_OK;
+  Rccl* r = rccl();
+  (void)hipSetDevice(ctx->device);
+  const ncclResult_t rc = r->CommAbort((ncclComm_t)ctx->comm);   // ends the collectives in flight on this rank
+  ctx->comm = nullptr; ctx->comm_nranks = 1; ctx->comm_rank = 0;
+  ctx->comm_pending = false;
+  if (ctx->comm_stream) (void)hipStreamSynchronize(ctx->comm_stream);
+  (void)hipStreamSynchronize(ctx->stream);
+  if (rc != ncclSuccess) return lf_fail(ctx, LF_ERR_HIP, std::string("ncclCommAbort: ") + r->GetErrorString(rc));
+  return LF_OK;
+}
+
+lf_status lf_comm_set_exchange_precision(lf_ctx* ctx, int bits) {
+  if (!ctx || (bits != 32 && bits != 64)) return LF_ERR_INVALID;
+  lf_status st = lf_comm_join(ctx);   // an exchange in flight keeps the layout it started with
+  if (st != LF_OK) return st;
+  LF_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  ctx->comm_f32 = bits == 32;
+  return LF_OK;
 }
 
 lf_status lf_comm_destroy(lf_ctx* ctx) {
@@ -344,49 +435,63 @@ lf_status lf_group_gather(lf_group* g, int which) {
   if (!g) return LF_ERR_INVALID;
   const int n = (int)g->ctx.size();
   if (n == 1) return LF_OK;
+  auto hip_fail = [&](int r, const char* what, hipError_t e) {
+    g->err = "rank " + std::to_string(r) + ": " + what + ": " + hipGetErrorString(e);
+    return LF_ERR_HIP;
+  };
+#define LF_GROUP_HIP(r, expr) do { const hipError_t e_ = (expr); if (e_ != hipSuccess) return hip_fail(r, #expr, e_); } while (0)
+  for (int r = 1; r < n; r++)
+    if (g->ctx[r]->comm_f32 != g->ctx[0]->comm_f32) { g->err = "the contexts of a group must exchange at one precision"; return LF_ERR_STATE; }
   for (int r = 0; r < n; r++) {
     lf_ctx* c = g->ctx[r];
     lf_status st = check_gather_args(c, which, n);
-    if (st == LF_OK) { (void)hipSetDevice(c->device); st = ensure_staging(c, n); }
-    if (st == LF_OK) st = launch_pack(c, which, r, n);
+    if (st == LF_OK) { LF_GROUP_HIP(r, hipSetDevice(c->device)); st = ensure_staging(c, n); }
+    if (st == LF_OK) { invalidate_tonemap(c, which); st = launch_pack(c, which, r, n); }
     if (st != LF_OK) { g->err = lf_last_error(c); return st; }
   }
   const Shape s = shape(g->ctx[0], n);
   const size_t cnt = s.groups * s.e;
+  const size_t esz = g->ctx[0]->comm_f32 ? sizeof(float) : sizeof(double);
   if (g->rccl) {
     Rccl* rc = rccl();
-    (void)rc->GroupStart();
+    ncclResult_t e = rc->GroupStart();
+    if (e != ncclSuccess) { g->err = std::string("ncclGroupStart: ") + rc->GetErrorString(e); return LF_ERR_HIP; }
     for (int r = 0; r < n; r++) {
       lf_ctx* c = g->ctx[r];
-      (void)hipSetDevice(c->device);
-      const ncclResult_t e = rc->AllGather(c->comm_stage, c->comm_stage + cnt, cnt, ncclDouble,
-                                           (ncclComm_t)c->comm, c->stream);
+      const hipError_t he = hipSetDevice(c->device);
+      if (he != hipSuccess) { (void)rc->GroupEnd(); return hip_fail(r, "hipSetDevice", he); }
+      e = rc->AllGather(c->comm_stage, stage_recv(c, cnt), cnt, c->comm_f32 ? ncclFloat : ncclDouble,
+                        (ncclComm_t)c->comm, c->stream);
       if (e != ncclSuccess) { (void)rc->GroupEnd(); g->err = std::string("ncclAllGather: ") + rc->GetErrorString(e); return LF_ERR_HIP; }
     }
-    const ncclResult_t e = rc->GroupEnd();
+    e = rc->GroupEnd();
     if (e != ncclSuccess) { g->err = std::string("ncclGroupEnd: ") + rc->GetErrorString(e); return LF_ERR_HIP; }
   } else {
     // rehearsal (devices listed twice): every context pulls the other contexts' packed rows with
     // peer copies on its own stream, after they have been packed
-    for (int r = 0; r < n; r++) { (void)hipSetDevice(g->ctx[r]->device); (void)hipStreamSynchronize(g->ctx[r]->stream); }
+    for (int r = 0; r < n; r++) {
+      LF_GROUP_HIP(r, hipSetDevice(g->ctx[r]->device));
+      LF_GROUP_HIP(r, hipStreamSynchronize(g->ctx[r]->stream));
+    }
     for (int r = 0; r < n; r++) {
       lf_ctx* c = g->ctx[r];
-      (void)hipSetDevice(c->device);
-      for (int q = 0; q < n; q++) {
-        const hipError_t e = hipMemcpyPeerAsync(c->comm_stage + cnt + (size_t)q * cnt, c->device,
-                                                g->ctx[q]->comm_stage, g->ctx[q]->device, cnt * sizeof(double),
-                                                c->stream);
-        if (e != hipSuccess) { g->err = std::string("hipMemcpyPeerAsync: ") + hipGetErrorString(e); return LF_ERR_HIP; }
-      }
+      LF_GROUP_HIP(r, hipSetDevice(c->device));
+      for (int q = 0; q < n; q++)
+        LF_GROUP_HIP(r, hipMemcpyPeerAsync((char*)stage_recv(c, cnt) + (size_t)q * cnt * esz, c->device,
+                                           g->ctx[q]->comm_stage, g->ctx[q]->device, cnt * esz, c->stream));
     }
   }
   for (int r = 0; r < n; r++) {
-    (void)hipSetDevice(g->ctx[r]->device);
+    LF_GROUP_HIP(r, hipSetDevice(g->ctx[r]->device));
     const lf_status st = launch_unpack(g->ctx[r], which, r, n);
     if (st != LF_OK) { g->err = lf_last_error(g->ctx[r]); return st; }
   }
   // the staging buffers are reused by the next gather: order the streams against each other
-  for (int r = 0; r < n; r++) { (void)hipSetDevice(g->ctx[r]->device); (void)hipStreamSynchronize(g->ctx[r]->stream); }
+  for (int r = 0; r < n; r++) {
+    LF_GROUP_HIP(r, hipSetDevice(g->ctx[r]->device));
+    LF_GROUP_HIP(r, hipStreamSynchronize(g->ctx[r]->stream));
+  }
+#undef LF_GROUP_HIP
   return LF_OK;
 }
 

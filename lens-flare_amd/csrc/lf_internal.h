@@ -30,9 +30,7 @@ struct LfFlares {
 struct LfGhostTri {
   float x0, y0, u0, v0, x1, y1, u1, v1, x2, y2, u2, v2;
   int bx0, bx1, by0, by1;  // loops run x in [bx0,bx1), y in [by0,by1)  (:402-403)
-  int channel;             // 0,1,2 = red, green, blue
-  int pad;
-  double colour;           // 10 / scale_amt^2 widened (:492-494)
+  double colour[3];        // ghost_color: unit R, G or B times 10 / scale_amt^2 widened (:482-494)
 };
 
 struct LfGhostList {
@@ -188,7 +186,7 @@ enum { LF_EV_REST1 = 8, LF_EV_SAVE0 = 0x10, LF_EV_SAVE1 = 0x20, LF_EV_END = 0x40
 
 // ---- timing ---------------------------------------------------------------------------------
 enum LfKernelId { LFK_MARCH = 0, LFK_FLARE_LAYER, LFK_GHOST_RASTER, LFK_DFT, LFK_FRAME_SETUP,
-                  LFK_TONEMAP, LFK_COUNT };
+                  LFK_TONEMAP, LFK_EXCHANGE, LFK_SCENE, LFK_COUNT };
 
 struct LfTimedLaunch { int kernel; hipEvent_t start, stop; };
 
@@ -279,6 +277,7 @@ struct lf_ctx {
   hipStream_t comm_stream = nullptr;
   hipEvent_t comm_ev_main = nullptr, comm_ev_pack = nullptr, comm_ev_done = nullptr;
   bool comm_pending = false;     // an exchange on comm_stream the main stream has not yet waited for
+  bool comm_f32 = false;         // lf_comm_set_exchange_precision(32): the tile rows travel as floats
 
   bool timing = false;
   std::vector<LfTimedLaunch> timed;       // launches not folded yet (bounded, see lf_api.hip)
@@ -289,8 +288,9 @@ struct lf_ctx {
 
 // implemented in lf_api.hip
 lf_status lf_fail(const lf_ctx* ctx, lf_status st, const std::string& msg);
-hipEvent_t lf_timing_begin(lf_ctx* ctx, int kernel);
-void lf_timing_end(lf_ctx* ctx, int kernel, hipEvent_t start);
+// (stream: where the timed work runs; null = the context's main stream)
+hipEvent_t lf_timing_begin(lf_ctx* ctx, int kernel, hipStream_t stream = nullptr);
+void lf_timing_end(lf_ctx* ctx, int kernel, hipEvent_t start, hipStream_t stream = nullptr);
 
 #define LF_HIP(ctx, expr)                                                                     \
   do {                                                                                        \
@@ -305,6 +305,13 @@ lf_status lfk_build_spectrum(lf_ctx* ctx);
 lf_status lfk_frame_setup(lf_ctx* ctx, const LfSunLightArgs* lights_arg, const double* lights_dev,
                           int n_lights, bool project);
 lf_status lfk_ghost_raster(lf_ctx* ctx);
+// single-shot forms of the reference's public helper members (lf_draw_ghost ... lf_irradiance_falloff)
+lf_status lfk_draw_ghost(lf_ctx* ctx, int channel, float r1, float r2, int bbox[4]);
+lf_status lfk_raster_triangle(lf_ctx* ctx, const float v[12], const double colour[3], int bbox[4]);
+lf_status lfk_fill_pixel(lf_ctx* ctx, const float v[12], int x, int y, const double colour[3]);
+lf_status lfk_shift_vertex(lf_ctx* ctx, float x, float y, float scale, float shift_amount, double out[2]);
+lf_status lfk_compute_phase(lf_ctx* ctx, int flare, double u, double v, double out[4]);
+lf_status lfk_irradiance_falloff(lf_ctx* ctx, int x, int y, double radius, double out[3]);
 lf_status lfk_flare_layer(lf_ctx* ctx);
 lf_status lfk_tonemap(lf_ctx* ctx, int ya, int yb);
 lf_status lfk_flip_rows(lf_ctx* ctx, uint32_t* out_dev);

@@ -143,7 +143,8 @@ __device__ bool closest_hit(const LfBvhNode* __restrict__ nodes, const LfPrim* _
       }
       if (any && !h) return true;
     } else {
-      if (sp < kStackDepth - 1) { stack[256 * sp++] = nd.right; stack[256 * sp++] = nd.left; }
+      // (left < 0: the childless node of an empty scene, should a ray ever pass its degenerate box)
+      if (nd.left >= 0 && sp < kStackDepth - 1) { stack[256 * sp++] = nd.right; stack[256 * sp++] = nd.left; }
     }
   }
   return any;
@@ -197,17 +198,18 @@ __device__ inline int upper_bound_d(const double* __restrict__ a, int n, double 
 // SOFT = false is the kernel of scenes with delta lights only (no sampled light, no environment, no
 // hemisphere sampling): the sampled-light code costs ~100 vector registers, i.e. one of the three
 // waves a SIMD otherwise holds (25 -> 35 ms on the 1080p timing frame), so it is compiled out there.
+// what: bit 0 = zero_bounce_radiance (:215-220, the hit surface's emission), bit 1 =
+// one_bounce_radiance (:222-232: the hemisphere or the importance estimator)
+enum { kShadeZero = 1, kShadeOne = 2 };
 template <bool SOFT>
-__device__ V3 radiance(const LfSceneDev& sc, const LfEnvDev& ev, bool hemisphere, DRay r,
-                       int* __restrict__ stack, int ns_area_light, uint4 rng_ctr, uint2 rng_key) {
-  Hit isect;
-  if (!closest_hit(sc.nodes, sc.prims, r, &isect, stack))   // pathtracer.cpp:291-292
-    return (SOFT && ev.w) ? env_sample_dir(ev, r.d) : v3(0, 0, 0);
-  const LfMaterial& m = sc.materials[isect.material];
-  const V3 emission = m.kind == 1 ? v3(m.rgb[0], m.rgb[1], m.rgb[2]) : v3(0, 0, 0);
+__device__ V3 shade_hit(const LfSceneDev& sc, const LfEnvDev& ev, bool hemisphere, const DRay& r,
+                        double isect_t, V3 isect_n, const LfMaterial& m, int what,
+                        int* __restrict__ stack, int ns_area_light, uint4 rng_ctr, uint2 rng_key) {
+  const V3 emission = (m.kind == 1 && (what & kShadeZero)) ? v3(m.rgb[0], m.rgb[1], m.rgb[2]) : v3(0, 0, 0);
+  if (!(what & kShadeOne)) return emission;
   V3 X, Y, Z;
-  make_coord_space(isect.n, X, Y, Z);
-  const V3 hit_p = r.o + r.d * isect.t;
+  make_coord_space(isect_n, X, Y, Z);
+  const V3 hit_p = r.o + r.d * isect_t;
   V3 L = v3(0, 0, 0);
   const double kEpsF = (double)0.00001f;  // EPS_F (misc.h:13)
   int total_samples = 0;
@@ -311,6 +313,16 @@ __device__ V3 radiance(const LfSceneDev& sc, const LfEnvDev& ev, bool hemisphere
   return emission + L;
 }
 
+template <bool SOFT>
+__device__ V3 radiance(const LfSceneDev& sc, const LfEnvDev& ev, bool hemisphere, DRay r,
+                       int* __restrict__ stack, int ns_area_light, uint4 rng_ctr, uint2 rng_key) {
+  Hit isect;
+  if (!closest_hit(sc.nodes, sc.prims, r, &isect, stack))   // pathtracer.cpp:291-292
+    return (SOFT && ev.w) ? env_sample_dir(ev, r.d) : v3(0, 0, 0);
+  return shade_hit<SOFT>(sc, ev, hemisphere, r, isect.t, isect.n, sc.materials[isect.material],
+                         kShadeZero | kShadeOne, stack, ns_area_light, rng_ctr, rng_key);
+}
+
 __device__ inline uint4 philox4x32_10(uint4 ctr, uint2 key) {
 #pragma unroll
   for (int r = 0; r < 10; r++) {
@@ -338,7 +350,8 @@ __device__ inline double random_uniform_from_raw(unsigned raw) {  // util/random
 template <bool SOFT>
 __global__ __launch_bounds__(256, 4) void k_scene_term(LfSceneDev sc, LfEnvDev ev, int hemisphere,
                                                     LfCamera cam, int W, int H, int y0,
-                                                    int y1, int ns_aa, int ns_area_light,
+                                                    int y1, int row_phase, int row_period,
+                                                    int ns_aa, int ns_area_light,
                                                     int samples_per_batch, double max_tolerance,
                                                     const uint32_t* __restrict__ aa_raw, int jitter_mode,
                                                     uint64_t key, double* __restrict__ scene) {
@@ -349,6 +362,9 @@ __global__ __launch_bounds__(256, 4) void k_scene_term(LfSceneDev sc, LfEnvDev e
   const size_t p = (size_t)y0 * W + (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (p >= (size_t)y1 * W) return;
   const int x = (int)(p % W), y = (int)(p / W);
+  // multi-GPU: only the 8-row tile rows this context owns, like k_flare_layer, which is the only
+  // reader of this buffer (whole waves leave: 64 consecutive pixels share a tile row unless W < 64)
+  if (row_period > 1 && (y >> 3) % row_period != row_phase) return;
   const double PI_ = 3.14159265358979323;
   const double edge_x = tan(0.5 * (cam.hfov_deg * (PI_ / 180.0)));
   const double edge_y = tan(0.5 * (cam.vfov_deg * (PI_ / 180.0)));
@@ -394,6 +410,43 @@ __global__ __launch_bounds__(256, 4) void k_scene_term(LfSceneDev sc, LfEnvDev e
   scene[3 * p] = total.x * rc;
   scene[3 * p + 1] = total.y * rc;
   scene[3 * p + 2] = total.z * rc;
+}
+
+// ---- single-ray forms of the integrator's public members (pathtracer.h:66-77) ----------------
+struct LfProbeRay { double o[3], d[3], min_t, max_t; };
+// est_radiance_global_illumination(r) (:282-302) and the closest hit behind autofocus (:1065-1072):
+// out = {hit, t, n xyz, radiance rgb}
+__global__ void k_scene_trace_ray(LfSceneDev sc, LfEnvDev ev, int hemisphere, LfProbeRay pr,
+                                  int ns_area_light, uint64_t seq, uint64_t key, double* __restrict__ out) {
+  __shared__ int s_stack[kStackDepth * 256];
+  if (threadIdx.x != 0) return;
+  DRay r{v3(pr.o[0], pr.o[1], pr.o[2]), v3(pr.d[0], pr.d[1], pr.d[2]), pr.min_t, pr.max_t};
+  const uint4 ctr = make_uint4((unsigned)seq, (unsigned)(seq >> 32) | 0x80000000u, 0u, 0u);
+  const uint2 k2 = make_uint2((unsigned)key, (unsigned)(key >> 32));
+  Hit h;
+  V3 L;
+  if (closest_hit(sc.nodes, sc.prims, r, &h, s_stack)) {
+    out[0] = 1.0; out[1] = h.t; out[2] = h.n.x; out[3] = h.n.y; out[4] = h.n.z;
+    L = shade_hit<true>(sc, ev, hemisphere != 0, r, h.t, h.n, sc.materials[h.material], kShadeZero | kShadeOne,
+                        s_stack, ns_area_light, ctr, k2);
+  } else {
+    out[0] = 0.0; out[1] = out[2] = out[3] = out[4] = 0.0;
+    L = ev.w ? env_sample_dir(ev, r.d) : v3(0, 0, 0);
+  }
+  out[5] = L.x; out[6] = L.y; out[7] = L.z;
+}
+// zero_bounce_radiance / one_bounce_radiance / estimate_direct_lighting_{hemisphere, importance}
+// (r, isect) for an intersection the host found itself
+__global__ void k_scene_shade(LfSceneDev sc, LfEnvDev ev, int hemisphere, LfProbeRay pr, double t,
+                              double nx, double ny, double nz, LfMaterial m, int what,
+                              int ns_area_light, uint64_t seq, uint64_t key, double* __restrict__ out) {
+  __shared__ int s_stack[kStackDepth * 256];
+  if (threadIdx.x != 0) return;
+  const DRay r{v3(pr.o[0], pr.o[1], pr.o[2]), v3(pr.d[0], pr.d[1], pr.d[2]), pr.min_t, pr.max_t};
+  const V3 L = shade_hit<true>(sc, ev, hemisphere != 0, r, t, v3(nx, ny, nz), m, what, s_stack, ns_area_light,
+                               make_uint4((unsigned)seq, (unsigned)(seq >> 32) | 0x80000000u, 0u, 0u),
+                               make_uint2((unsigned)key, (unsigned)(key >> 32)));
+  out[0] = L.x; out[1] = L.y; out[2] = L.z;
 }
 
 // ---- host: BVH over the primitives (median split of the centroids along the widest axis) -----
@@ -447,6 +500,28 @@ int build_node(std::vector<LfBvhNode>& nodes, std::vector<LfPrim>& prims, int fi
   return id;
 }
 
+// one wave writes `n_out` doubles, which come straight back
+template <typename Launch>
+static lf_status scene_probe(lf_ctx* ctx, int n_out, double* out, Launch launch) {
+  double* d = nullptr;
+  LF_HIP(ctx, hipMalloc((void**)&d, sizeof(double) * (size_t)n_out));
+  launch(d);
+  hipError_t e = hipGetLastError();
+  if (e == hipSuccess) e = hipMemcpyAsync(out, d, sizeof(double) * (size_t)n_out, hipMemcpyDeviceToHost, ctx->stream);
+  if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+  (void)hipFree(d);
+  LF_HIP(ctx, e);
+  return LF_OK;
+}
+
+static lf_status scene_probe_ready(lf_ctx* ctx, const char* who) {
+  if (!ctx->scene_valid) return lf_fail(ctx, LF_ERR_STATE, std::string(who) + " before lf_set_scene");
+  if (ctx->scene_dev.n_env_lights > 0 && ctx->env_dev.w == 0)
+    return lf_fail(ctx, LF_ERR_STATE, "an environment light (type 4) is listed but no map is set (lf_set_environment_map)");
+  LF_HIP(ctx, hipSetDevice(ctx->device));
+  return LF_OK;
+}
+
 }  // namespace
 
 extern "C" {
@@ -495,13 +570,16 @@ lf_status lf_set_scene(lf_ctx* ctx, int n_spheres, const double* spheres, const 
   }
   std::vector<LfBvhNode> nodes;
   int depth = 0;
-  if (!prims.empty()) build_node(nodes, prims, 0, (int)prims.size(), &depth);
+  if (!prims.empty()) {
+    build_node(nodes, prims, 0, (int)prims.size(), &depth);
+  } else {   // an empty scene: one node whose inverted box no ray enters
+    LfBvhNode e; std::memset(&e, 0, sizeof(e)); e.bmin[0] = 1; e.bmax[0] = -1; e.count = 0; e.left = e.right = -1; nodes.push_back(e);
+  }
   // the device traversal keeps at most depth + 1 node ids on its LDS stack and would otherwise
   // have to drop children (= lose geometry silently); the median split is ceil(log2(n / 4)) + 1
   // deep, so this only triggers beyond ~2^32 primitives -- but it must fail, not drop
   if (depth + 1 > kStackDepth - 1)
     return lf_fail(ctx, LF_ERR_INVALID, "scene: BVH deeper than the device traversal stack");
-  else { LfBvhNode e; std::memset(&e, 0, sizeof(e)); e.bmin[0] = 1; e.bmax[0] = -1; e.count = 0; e.left = e.right = 0; nodes.push_back(e); }
   LfSceneDev& S = ctx->scene_dev;
   LF_HIP(ctx, hipStreamSynchronize(ctx->stream));
   void* old[] = {S.nodes, S.prims, S.materials, S.lights};
@@ -518,7 +596,6 @@ lf_status lf_set_scene(lf_ctx* ctx, int n_spheres, const double* spheres, const 
   LF_HIP(ctx, up((void**)&S.lights, lts.data(), lts.size() * sizeof(LfLight)));
   S.n_nodes = (int)nodes.size(); S.n_prims = (int)prims.size();
   S.n_materials = n_materials; S.n_lights = n_lights; S.n_soft_lights = 0;
-  if (prims.empty()) S.n_nodes = 1;
   ctx->scene_valid = true;
   return LF_OK;
 }
@@ -624,6 +701,39 @@ lf_status lf_set_sampling(lf_ctx* ctx, int samples_per_batch, double max_toleran
   return LF_OK;
 }
 
+lf_status lf_scene_trace_ray(lf_ctx* ctx, const double ray[8], uint64_t seq, double out[8]) {
+  if (!ctx || !ray || !out) return LF_ERR_INVALID;
+  lf_status st = scene_probe_ready(ctx, "lf_scene_trace_ray");
+  if (st != LF_OK) return st;
+  LfProbeRay pr;
+  std::memcpy(&pr, ray, sizeof(pr));
+  return scene_probe(ctx, 8, out, [&](double* d) {
+    hipLaunchKernelGGL(k_scene_trace_ray, dim3(1), dim3(64), 0, ctx->stream, ctx->scene_dev, ctx->env_dev,
+                       ctx->hemisphere_sample ? 1 : 0, pr, ctx->ns_area_light, seq, ctx->jitter_key, d);
+  });
+}
+
+lf_status lf_scene_shade(lf_ctx* ctx, int what, const double ray[8], double t, const double n[3],
+                         const double material[4], uint64_t seq, double rgb[3]) {
+  if (!ctx || !ray || !n || !material || !rgb || what < 0 || what > 3) return LF_ERR_INVALID;
+  lf_status st = scene_probe_ready(ctx, "lf_scene_shade");
+  if (st != LF_OK) return st;
+  LfMaterial m;
+  std::memset(&m, 0, sizeof(m));
+  m.kind = (int)material[0];
+  if (m.kind < 0 || m.kind > 2) return lf_fail(ctx, LF_ERR_INVALID, "lf_scene_shade: material kind must be 0, 1 or 2");
+  for (int c = 0; c < 3; c++) m.rgb[c] = material[1 + c];
+  LfProbeRay pr;
+  std::memcpy(&pr, ray, sizeof(pr));
+  // 0 zero_bounce, 1 one_bounce (by the direct_hemisphere_sample flag), 2 / 3 the two estimators by name
+  const int bits = what == 0 ? kShadeZero : kShadeOne;
+  const int hemi = what == 2 ? 1 : what == 3 ? 0 : (ctx->hemisphere_sample ? 1 : 0);
+  return scene_probe(ctx, 3, rgb, [&](double* d) {
+    hipLaunchKernelGGL(k_scene_shade, dim3(1), dim3(64), 0, ctx->stream, ctx->scene_dev, ctx->env_dev, hemi, pr,
+                       t, n[0], n[1], n[2], m, bits, ctx->ns_area_light, seq, ctx->jitter_key, d);
+  });
+}
+
 lf_status lf_render_scene_term(lf_ctx* ctx) {
   if (!ctx) return LF_ERR_INVALID;
   if (ctx->W == 0) return lf_fail(ctx, LF_ERR_STATE, "lf_render_scene_term before lf_set_frame");
@@ -640,7 +750,7 @@ lf_status lf_render_scene_term(lf_ctx* ctx) {
                    "MT19937 parity mode cannot serve hemisphere sampling: the reference draws its directions from "
                    "the shared generator in hit order (use lf_set_jitter_counter)");
   if (ctx->jitter_mode == 0) {
-    if (!ctx->jitter_table_valid || !ctx->jitter_aa_raw || ctx->jitter_aa_ns != ctx->ns_aa)
+    if (!ctx->jitter_table_valid || (ctx->ns_aa > 0 && !ctx->jitter_aa_raw) || ctx->jitter_aa_ns != ctx->ns_aa)
       return lf_fail(ctx, LF_ERR_STATE, "MT19937 jitter: call lf_set_jitter_mt19937 after lf_set_params");
     if (ctx->ns_aa >= ctx->samples_per_batch)
       return lf_fail(ctx, LF_ERR_INVALID,
@@ -659,9 +769,12 @@ lf_status lf_render_scene_term(lf_ctx* ctx) {
 #define LF_LAUNCH_SCENE(SOFT)                                                                            \
   hipLaunchKernelGGL(k_scene_term<SOFT>, dim3((unsigned)((px + 255) / 256)), dim3(256), 0, ctx->stream,  \
                      ctx->scene_dev, ctx->env_dev, ctx->hemisphere_sample ? 1 : 0, ctx->cam, ctx->W,    \
-                     ctx->H, ctx->y0, ctx->y1, ctx->ns_aa, ctx->ns_area_light, ctx->samples_per_batch,  \
+                     ctx->H, ctx->y0, ctx->y1, ctx->row_phase, ctx->row_period, ctx->ns_aa,              \
+                     ctx->ns_area_light, ctx->samples_per_batch,                                         \
                      ctx->max_tolerance, ctx->jitter_aa_raw, ctx->jitter_mode, ctx->jitter_key, ctx->scene)
+  hipEvent_t ev = lf_timing_begin(ctx, LFK_SCENE);
   if (soft) LF_LAUNCH_SCENE(true); else LF_LAUNCH_SCENE(false);
+  lf_timing_end(ctx, LFK_SCENE, ev);
 #undef LF_LAUNCH_SCENE
   LF_HIP(ctx, hipGetLastError());
   return LF_OK;

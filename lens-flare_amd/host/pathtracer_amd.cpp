@@ -1,29 +1,44 @@
 // pathtracer_amd.cpp -- the drop-in: the reference's OWN `class CGL::PathTracer`
-// (src/pathtracer/pathtracer.h:25-143, compiled against that header UNCHANGED) with the lens-flare
-// members implemented on the MI355X through the C ABI of include/lensflare.h.  This translation
-// unit takes the place of src/pathtracer/pathtracer.cpp in libpt31 (CMakeLists.txt:20-33); nothing
-// else in the reference tree changes: RaytracedRenderer::start_raytracing / raytrace_tile
-// (raytraced_renderer.cpp:287-355, :622-647) keep calling
-//     clear(); set_frame_size(); find_sun_pos(); generate_ghost_buffer();        (main thread)
-//     raytrace_pixel(x, y) ...; write_to_framebuffer(tile);                      (worker threads)
+// (src/pathtracer/pathtracer.h:25-143, compiled against that header UNCHANGED) with every member on
+// the MI355X through the C ABI of include/lensflare.h.  This translation unit takes the place of
+// src/pathtracer/pathtracer.cpp in libpt31 (CMakeLists.txt:20-33) -- the whole file, it is removed,
+// not split: every out-of-line member the header declares is defined here.  Nothing else in the
+// reference tree changes: RaytracedRenderer (raytraced_renderer.cpp:58, :287-355, :622-647, :678)
+// keeps calling
+//     new PathTracer; set_frame_size(); clear(); find_sun_pos(); generate_ghost_buffer();   (main thread)
+//     raytrace_pixel(x, y) ...; write_to_framebuffer(tile);                               (worker threads)
+//     autofocus(loc);                                                                       (UI thread)
 //
-// What runs where: find_sun_pos, the paraxial ghost trace + quad rasteriser, the starburst, the
-// irradiance falloff, the sample loop of raytrace_pixel (camera rays, closest hit, direct lighting)
-// and the tonemap all run on the device; raytrace_pixel itself is the per-pixel hand-over of the
-// composed value.  The device context hangs off the PathTracer in a side table keyed by `this`
-// (the class has no spare member and its header must not change).
+// What runs where: find_sun_pos, the ghosts (paraxial trace + quad rasteriser, or the geometric
+// march), the starburst, the irradiance falloff, the sample loop of raytrace_pixel (camera rays,
+// closest hit, direct lighting) and the tonemap all run on the device, once per frame, inside
+// generate_ghost_buffer -- the place the reference already reserves for its per-frame pre-pass;
+// raytrace_pixel / write_to_framebuffer are the per-pixel / per-tile hand-over of the finished
+// values (plain host copies: callable concurrently, like the reference's).  The helper members the
+// header also publishes (draw_ghost, rasterize_textured_triangle, ..., the single-ray integrator
+// queries, autofocus) are single launches of the same device code.  The device context hangs off the
+// PathTracer in a side table keyed by `this` (the class has no spare member and its header must not
+// change).  No CPU fallback: without a gfx950 device the constructor ends the program.
 //
-// Built and exercised as test infrastructure by oracle/Makefile (target `dropin`: the reference's
-// other objects linked unmodified, pathtracer.o replaced by this file) and tests/test_gpu_dropin.py.
-// The integrator methods that are not on the flare path (estimate_direct_lighting_*, *_bounce_radiance,
-// autofocus) are not defined here: in the reference tree they stay where they are, in this build
-// nothing calls them.  No CPU fallback: without a device the constructor ends the program.
+// The geometric lens march (the north star's kernel) is selected WITHOUT touching the header:
+//   * the camera handed to the renderer is a CGL::LensCamera (lens_camera_amd.h), or
+//   * LF_LENS_FILE=<prescription.lens> is set in the environment of the unchanged host application;
+//     LF_GEOMETRIC_SPP (default 64), LF_SUN_ANGULAR_RADIUS (radians, default 0.05) and
+//     LF_GEOMETRIC_KEY (counter-RNG key) tune it.
+// generate_ghost_buffer then fills ghost_buffer with lf_trace_ghosts (sun = the in-frame
+// DirectionalLight find_sun_pos found, lf_set_sun_from_flares) instead of the paraxial quads.
+//
+// Built and exercised as test infrastructure by oracle/Makefile (targets `dropin`, `app`: the
+// reference's other objects -- raytraced_renderer.o included -- linked unmodified, pathtracer.o
+// replaced by this file) and tests/test_gpu_dropin.py, tests/test_dropin_symbols.py.
 #include <algorithm>
+#include <atomic>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
 #include <map>
 #include <mutex>
+#include <string>
 #include <vector>
 
 #include "pathtracer/pathtracer.h"   // the reference's header, as it is
@@ -35,7 +50,9 @@
 #include "scene/object.h"
 #include "scene/sphere.h"
 #include "scene/triangle.h"
+#include "util/random_util.h"
 
+#include "lens_camera_amd.h"
 #include "lensflare.h"
 
 using namespace CGL::SceneObjects;
@@ -65,12 +82,24 @@ template struct PrivateMember<EnvLightMap, &EnvironmentLight::envMap>;
 
 struct DeviceState {
   lf_ctx* ctx = nullptr;
-  std::vector<double> sample;   // host mirror of the composed sensor buffer
-  std::vector<double> star;     // ... of raytrace_starburst(x, y)
+  std::vector<double> sample;      // host mirror of the composed sensor buffer (what raytrace_pixel hands over)
+  std::vector<uint32_t> rgba;      // ... of the tonemapped frame (what write_to_framebuffer hands over)
+  std::vector<double> star;        // ... of raytrace_starburst(x, y): fetched when first asked for
+  bool star_ready = false;
+  std::mutex star_mu;
   const void* textures_of = nullptr;   // camera whose aperture textures are on the device
   const void* scene_of = nullptr;      // scene that is on the device
   const void* env_of = nullptr;        // EnvironmentLight whose map is on the device
   bool frame_ready = false;
+  // the geometric march: prescription file, samples per pixel, lobe of the sun, RNG key
+  std::string lens_file;
+  int geo_spp = 64;
+  float sun_radius = 0.05f;
+  uint64_t geo_key = 0x1e45f1a4eULL;
+  std::string lens_loaded;             // file that is on the device ...
+  size_t lens_w = 0, lens_h = 0;       // ... for this frame size (the pixel pitch depends on it)
+  bool mirror_ghost = false;           // LF_MIRROR_GHOST_BUFFER: fill the public ghost_buffer field every frame
+  std::atomic<uint64_t> probe_seq{0};  // counter-RNG stream of the single-ray integrator members
 };
 
 std::mutex g_mu;
@@ -87,6 +116,20 @@ void check(const DeviceState& s, lf_status st, const char* what) {
   exit(1);
 }
 
+// a BSDF as the device's material record {kind, r, g, b} (include/lensflare.h, lf_set_scene)
+void material_of(BSDF* b, double m[4]) {
+  if (dynamic_cast<EmissionBSDF*>(b)) {
+    Vector3D e = b->get_emission();
+    m[0] = 1; m[1] = e.x; m[2] = e.y; m[3] = e.z;
+  } else {
+    // every other BSDF through its public f(): the diffuse one returns reflectance / pi whatever the
+    // directions (bsdf.cpp:52-60); the Mirror / Refraction / Glass / Microfacet stubs return 0
+    // (advanced_bsdf.cpp:17-133), i.e. under this integrator they are black occluders
+    Vector3D f = b->f(Vector3D(0, 0, 1), Vector3D(0, 0, 1));
+    m[0] = 2; m[1] = f.x; m[2] = f.y; m[3] = f.z;
+  }
+}
+
 // the static scene, flattened the way lf_set_scene takes it (include/lensflare.h)
 void upload_scene(DeviceState& s, PathTracer* pt) {
   std::vector<double> sph, tp, tn, mats, lights;
@@ -95,19 +138,10 @@ void upload_scene(DeviceState& s, PathTracer* pt) {
   auto material = [&](BSDF* b) -> int {
     auto it = mat_of.find(b);
     if (it != mat_of.end()) return it->second;
-    double kind, rgb[3];
-    if (dynamic_cast<EmissionBSDF*>(b)) {
-      Vector3D e = b->get_emission();
-      kind = 1; rgb[0] = e.x; rgb[1] = e.y; rgb[2] = e.z;
-    } else {
-      // every other BSDF through its public f(): the diffuse one returns reflectance / pi whatever the
-      // directions (bsdf.cpp:52-60); the Mirror / Refraction / Glass / Microfacet stubs return 0
-      // (advanced_bsdf.cpp:17-133), i.e. under this integrator they are black occluders
-      Vector3D f = b->f(Vector3D(0, 0, 1), Vector3D(0, 0, 1));
-      kind = 2; rgb[0] = f.x; rgb[1] = f.y; rgb[2] = f.z;
-    }
+    double m[4];
+    material_of(b, m);
     const int id = (int)(mats.size() / 4);
-    mats.insert(mats.end(), {kind, rgb[0], rgb[1], rgb[2]});
+    mats.insert(mats.end(), m, m + 4);
     mat_of[b] = id;
     return id;
   };
@@ -143,7 +177,6 @@ void upload_scene(DeviceState& s, PathTracer* pt) {
   check(s, lf_set_scene(s.ctx, (int)sph_m.size(), sph.data(), sph_m.data(), (int)tri_m.size(), tp.data(),
                         tn.data(), tri_m.data(), (int)(mats.size() / 4), mats.data(), 0, nullptr), "lf_set_scene");
   check(s, lf_set_scene_lights(s.ctx, (int)(lights.size() / 16), lights.data()), "lf_set_scene_lights");
-  check(s, lf_set_light_samples(s.ctx, (int)std::max<size_t>(1, pt->ns_area_light)), "lf_set_light_samples");
   s.scene_of = pt->scene;
 }
 
@@ -163,7 +196,78 @@ void upload_environment(DeviceState& s, PathTracer* pt) {
   s.env_of = pt->envLight;
 }
 
+// what the scene kernels need besides the geometry: the public sampling fields as they are now
+void sync_scene(DeviceState& s, PathTracer* pt) {
+  if (s.scene_of != pt->scene) upload_scene(s, pt);
+  upload_environment(s, pt);
+  check(s, lf_set_light_samples(s.ctx, (int)std::max<size_t>(1, pt->ns_area_light)), "lf_set_light_samples");
+  check(s, lf_set_direct_hemisphere_sample(s.ctx, pt->direct_hemisphere_sample ? 1 : 0),
+        "lf_set_direct_hemisphere_sample");
+}
+
+void sync_textures(DeviceState& s, PathTracer* pt) {
+  if (s.textures_of == pt->camera) return;   // CameraApertureTexture::init already decoded the PNGs (camera.h:26-83)
+  CameraApertureTexture* t[2] = {pt->camera->aperture_texture, pt->camera->ghost_aperture_texture};
+  for (int k = 0; k < 2; k++)
+    check(s, lf_set_aperture(s.ctx, (lf_aperture_slot)k, t[k]->aperture.data(), (int)t[k]->width,
+                             (int)t[k]->height), "lf_set_aperture");
+  s.textures_of = pt->camera;
+}
+
+// flare_origins, flare_radiance, axis_ray, angle_to_sun as they are now (the host may have edited them)
+void sync_flares(DeviceState& s, PathTracer* pt) {
+  std::vector<double> o, r;
+  for (auto& f : pt->flare_origins) { o.push_back(f.x); o.push_back(f.y); }
+  for (auto& f : pt->flare_radiance) { r.push_back(f.x); r.push_back(f.y); r.push_back(f.z); }
+  double ax[2] = {pt->axis_ray.x, pt->axis_ray.y};
+  check(s, lf_set_flares(s.ctx, (int)pt->flare_origins.size(), o.data(), r.data(), ax, pt->angle_to_sun),
+        "lf_set_flares");
+}
+
+// rows [y0, y1) x columns [x0, x1) of the device ghost buffer into the public field
+// (Vector3D is 24 bytes, or 32 in the AVX build: CGL/include/CGL/vector3D.h:31-43)
+void fetch_ghost_rect(DeviceState& s, PathTracer* pt, int x0, int y0, int x1, int y1) {
+  const size_t W = pt->sampleBuffer.w, H = pt->sampleBuffer.h;
+  if (pt->ghost_buffer.w != W || pt->ghost_buffer.h != H) {
+    pt->ghost_buffer.resize(W, H);
+    x0 = y0 = 0; x1 = (int)W; y1 = (int)H;   // the field held another frame: take all of this one
+  }
+  if (x1 <= x0 || y1 <= y0) return;
+  const size_t stride = sizeof(Vector3D) / sizeof(double), tw = (size_t)(x1 - x0);
+  std::vector<double> tile(tw * (size_t)(y1 - y0) * stride);
+  check(s, lf_read_tile(s.ctx, 1, x0, y0, x1, y1, tile.data(), stride), "lf_read_tile(ghost)");
+  for (int y = y0; y < y1; y++)
+    std::copy(tile.begin() + (size_t)(y - y0) * tw * stride, tile.begin() + (size_t)(y - y0 + 1) * tw * stride,
+              (double*)&pt->ghost_buffer.data[(size_t)x0 + (size_t)y * W]);
+}
+
+// the helper members work on the ghost buffer outside a frame too: make sure the device has the
+// frame size, the textures and the flare state they read
+void helper_ready(DeviceState& s, PathTracer* pt, const char* who) {
+  if (!pt->camera || pt->sampleBuffer.w == 0) {
+    fprintf(stderr, "[PathTracer/MI355X] %s needs a camera and a frame size\n", who);
+    exit(1);
+  }
+  sync_textures(s, pt);
+  sync_flares(s, pt);
+}
+
+std::atomic<size_t> g_host_glue_calls{0};
+
 }  // namespace
+
+// how often the only member that is host glue around the reference's own BSDF / BVH objects
+// (at_least_one_bounce_radiance) ran: the frame path never calls it (tests assert 0)
+extern "C" size_t lf_dropin_host_glue_calls(void) { return g_host_glue_calls.load(); }
+
+// fill the public field PathTracer::ghost_buffer from the device now (a host that reads the field;
+// the reference's own host application never does, so the frame path does not pay for the copy
+// unless LF_MIRROR_GHOST_BUFFER=1)
+extern "C" void lf_dropin_fetch_ghost_buffer(PathTracer* pt) {
+  DeviceState& s = state(pt);
+  pt->ghost_buffer.resize(0, 0);   // forces the whole frame
+  fetch_ghost_rect(s, pt, 0, 0, (int)pt->sampleBuffer.w, (int)pt->sampleBuffer.h);
+}
 
 PathTracer::PathTracer() {
   gridSampler = new UniformGridSampler2D();          // pathtracer.cpp:14-24: the host still owns these
@@ -180,6 +284,11 @@ PathTracer::PathTracer() {
     fprintf(stderr, "[PathTracer/MI355X] no gfx950 device: this build has no CPU path\n");
     exit(1);
   }
+  if (const char* f = getenv("LF_LENS_FILE")) s.lens_file = f;
+  if (const char* v = getenv("LF_GEOMETRIC_SPP")) s.geo_spp = std::max(1, atoi(v));
+  if (const char* v = getenv("LF_SUN_ANGULAR_RADIUS")) s.sun_radius = (float)atof(v);
+  if (const char* v = getenv("LF_GEOMETRIC_KEY")) s.geo_key = strtoull(v, nullptr, 0);
+  s.mirror_ghost = getenv("LF_MIRROR_GHOST_BUFFER") != nullptr;
 }
 
 PathTracer::~PathTracer() {
@@ -214,12 +323,13 @@ void PathTracer::clear() {                                         // pathtracer
 
 void PathTracer::write_to_framebuffer(ImageBuffer& framebuffer, size_t x0, size_t y0, size_t x1,
                                       size_t y1) {                 // pathtracer.cpp:81-84 -> image.h:208-223
+  // the frame was tonemapped on the device (k_tonemap = HDRImageBuffer::toColor) when it was
+  // rendered; a tile is a plain copy, callable from every worker at once
   DeviceState& s = state(this);
-  static std::mutex mu;   // lf_write_to_framebuffer launches the tonemap once: one caller at a time
-  std::lock_guard<std::mutex> lock(mu);
-  check(s, lf_write_to_framebuffer(s.ctx, (int)x0, (int)y0, (int)x1, (int)y1,
-                                   &framebuffer.data[x0 + y0 * framebuffer.w], framebuffer.w),
-        "lf_write_to_framebuffer");
+  if (!s.frame_ready) { fprintf(stderr, "[PathTracer/MI355X] write_to_framebuffer before generate_ghost_buffer\n"); exit(1); }
+  const size_t W = sampleBuffer.w;
+  for (size_t y = y0; y < y1; y++)
+    std::copy(s.rgba.begin() + x0 + y * W, s.rgba.begin() + x1 + y * W, &framebuffer.data[x0 + y * framebuffer.w]);
 }
 
 void PathTracer::find_sun_pos() {                                  // pathtracer.cpp:32-64
@@ -236,11 +346,7 @@ void PathTracer::find_sun_pos() {                                  // pathtracer
                            camera->far_clip()), "lf_set_sampling");
   // the members keep what they held (axis_ray / angle_to_sun survive a frame without a sun, the
   // vectors are appended to: emplace_back at :42-43)
-  std::vector<double> o, r;
-  for (auto& f : flare_origins) { o.push_back(f.x); o.push_back(f.y); }
-  for (auto& f : flare_radiance) { r.push_back(f.x); r.push_back(f.y); r.push_back(f.z); }
-  double ax[2] = {axis_ray.x, axis_ray.y};
-  check(s, lf_set_flares(s.ctx, (int)flare_origins.size(), o.data(), r.data(), ax, angle_to_sun), "lf_set_flares");
+  sync_flares(s, this);
   check(s, lf_find_sun_pos(s.ctx, L.data(), (int)(L.size() / 6)), "lf_find_sun_pos");
   int n = 0;
   double oo[2 * LF_MAX_FLARES], rr[3 * LF_MAX_FLARES], a2[2];
@@ -260,46 +366,68 @@ void PathTracer::generate_ghost_buffer() {                         // pathtracer
   // evaluates scene radiance + starburst later, pixel by pixel, inside raytrace_pixel.  The device
   // renders all of it now; raytrace_pixel hands the composed pixels over.
   DeviceState& s = state(this);
-  if (s.textures_of != camera) {   // CameraApertureTexture::init already decoded the PNGs (camera.h:26-83)
-    CameraApertureTexture* t[2] = {camera->aperture_texture, camera->ghost_aperture_texture};
-    for (int k = 0; k < 2; k++)
-      check(s, lf_set_aperture(s.ctx, (lf_aperture_slot)k, t[k]->aperture.data(), (int)t[k]->width,
-                               (int)t[k]->height), "lf_set_aperture");
-    s.textures_of = camera;
-  }
-  // the public fields as they are now (the host may have edited them after find_sun_pos)
-  std::vector<double> o, r;
-  for (auto& f : flare_origins) { o.push_back(f.x); o.push_back(f.y); }
-  for (auto& f : flare_radiance) { r.push_back(f.x); r.push_back(f.y); r.push_back(f.z); }
-  double ax[2] = {axis_ray.x, axis_ray.y};
-  check(s, lf_set_flares(s.ctx, (int)flare_origins.size(), o.data(), r.data(), ax, angle_to_sun), "lf_set_flares");
+  sync_textures(s, this);
+  sync_flares(s, this);
   check(s, lf_set_params(s.ctx, (int)ns_aa, flare_radius, flare_intensity), "lf_set_params");
   // the reference's shared std::mt19937 in its visit order (32x32 tiles, one worker); a host that
   // runs several workers has no reproducible order anyway and may switch to lf_set_jitter_counter
   if (getenv("LF_COUNTER_JITTER")) check(s, lf_set_jitter_counter(s.ctx, 0x1e45f1a4eULL), "lf_set_jitter_counter");
   else check(s, lf_set_jitter_mt19937(s.ctx, 5489, nullptr, 0), "lf_set_jitter_mt19937");
-  if (s.scene_of != scene) upload_scene(s, this);
-  upload_environment(s, this);
-  check(s, lf_set_direct_hemisphere_sample(s.ctx, direct_hemisphere_sample ? 1 : 0), "lf_set_direct_hemisphere_sample");
+  sync_scene(s, this);
   check(s, lf_render_scene_term(s.ctx), "lf_render_scene_term");
-  check(s, lf_generate_ghost_buffer(s.ctx), "lf_generate_ghost_buffer");
-  check(s, lf_render_flare_layer(s.ctx), "lf_render_flare_layer");
+
   const size_t W = sampleBuffer.w, H = sampleBuffer.h;
-  ghost_buffer.resize(W, H);
-  // Vector3D is 24 bytes, or 32 in the AVX build (CGL/include/CGL/vector3D.h:31-43)
-  check(s, lf_read_tile(s.ctx, 1, 0, 0, (int)W, (int)H, (double*)&ghost_buffer.data[0],
-                        sizeof(Vector3D) / sizeof(double)), "lf_read_tile(ghost)");
+  // which ghosts: a LensCamera brings its prescription, LF_LENS_FILE selects one for any camera
+  const LensCamera* lens_cam = dynamic_cast<const LensCamera*>(camera);
+  const std::string lens_file = lens_cam && !lens_cam->lens_file().empty() ? lens_cam->lens_file() : s.lens_file;
+  if (!lens_file.empty()) {
+    // the geometric march: every ghost pair of the prescription + the primary path, per sensor sample
+    if (s.lens_loaded != lens_file || s.lens_w != W || s.lens_h != H) {
+      check(s, lf_load_lens_file(s.ctx, lens_file.c_str()), "lf_load_lens_file");
+      s.lens_loaded = lens_file; s.lens_w = W; s.lens_h = H;
+    }
+    if (flare_origins.empty()) {   // no sun in the frame: nothing to march towards (:724-726)
+      check(s, lf_clear_ghost_buffer(s.ctx), "lf_clear_ghost_buffer");
+    } else {
+      check(s, lf_set_sun_from_flares(s.ctx, 0, 0.0, lens_cam ? lens_cam->sun_angular_radius() : s.sun_radius),
+            "lf_set_sun_from_flares");
+      check(s, lf_trace_ghosts(s.ctx, lens_cam ? lens_cam->samples_per_pixel() : s.geo_spp, s.geo_key),
+            "lf_trace_ghosts");
+    }
+  } else {
+    check(s, lf_generate_ghost_buffer(s.ctx), "lf_generate_ghost_buffer");   // the reference's paraxial quads
+  }
+  check(s, lf_render_flare_layer(s.ctx), "lf_render_flare_layer");
+  // read back what the host's per-pixel / per-tile calls hand over: the composed sensor values and
+  // their tonemapped form.  ghost_buffer (a public field no caller of the reference reads) and the
+  // starburst alone (raytrace_starburst) come on demand.
   s.sample.resize(W * H * 3);
-  s.star.resize(W * H * 3);
   check(s, lf_read_tile(s.ctx, 0, 0, 0, (int)W, (int)H, s.sample.data(), 3), "lf_read_tile(sample)");
-  check(s, lf_read_tile(s.ctx, 2, 0, 0, (int)W, (int)H, s.star.data(), 3), "lf_read_tile(starburst)");
+  s.rgba.resize(W * H);
+  check(s, lf_write_to_framebuffer(s.ctx, 0, 0, (int)W, (int)H, s.rgba.data(), W), "lf_write_to_framebuffer");
+  s.star_ready = false;
+  if (s.mirror_ghost) {
+    ghost_buffer.resize(0, 0);
+    fetch_ghost_rect(s, this, 0, 0, (int)W, (int)H);
+  } else {
+    ghost_buffer.resize(W, H);   // :720 (its content lives on the device: lf_dropin_fetch_ghost_buffer)
+  }
   s.frame_ready = true;
 }
 
 Vector3D PathTracer::raytrace_starburst(size_t x, size_t y) {     // pathtracer.cpp:947-1004
   DeviceState& s = state(this);
   if (!s.frame_ready) { fprintf(stderr, "[PathTracer/MI355X] raytrace_starburst before generate_ghost_buffer\n"); exit(1); }
-  const double* v = &s.star[3 * (x + y * sampleBuffer.w)];
+  const size_t W = sampleBuffer.w, H = sampleBuffer.h;
+  {
+    std::lock_guard<std::mutex> lock(s.star_mu);
+    if (!s.star_ready) {
+      s.star.resize(W * H * 3);
+      check(s, lf_read_tile(s.ctx, 2, 0, 0, (int)W, (int)H, s.star.data(), 3), "lf_read_tile(starburst)");
+      s.star_ready = true;
+    }
+  }
+  const double* v = &s.star[3 * (x + y * W)];
   return Vector3D(v[0], v[1], v[2]);
 }
 
@@ -309,6 +437,158 @@ void PathTracer::raytrace_pixel(size_t x, size_t y) {             // pathtracer.
   if (!s.frame_ready) { fprintf(stderr, "[PathTracer/MI355X] raytrace_pixel before generate_ghost_buffer\n"); exit(1); }
   const double* v = &s.sample[3 * (x + y * sampleBuffer.w)];
   sampleBuffer.update_pixel(Vector3D(v[0], v[1], v[2]), x, y);
+}
+
+// ---- the ghost / starburst helper members (pathtracer.h:42-57, :95-101): one device launch each ----
+
+void PathTracer::fill_textured_pixel(float x0, float y0, float u0, float v0, float x1, float y1, float u1,
+                                     float v1, float x2, float y2, float u2, float v2, int x, int y,
+                                     Vector3D ghost_color) {       // pathtracer.cpp:305-343
+  DeviceState& s = state(this);
+  helper_ready(s, this, "fill_textured_pixel");
+  const float v[12] = {x0, y0, u0, v0, x1, y1, u1, v1, x2, y2, u2, v2};
+  const double c[3] = {ghost_color.x, ghost_color.y, ghost_color.z};
+  check(s, lf_fill_textured_pixel(s.ctx, v, x, y, c), "lf_fill_textured_pixel");
+  fetch_ghost_rect(s, this, x, y, x + 1, y + 1);
+}
+
+void PathTracer::rasterize_textured_triangle(float x0, float y0, float u0, float v0, float x1, float y1,
+                                             float u1, float v1, float x2, float y2, float u2, float v2,
+                                             Vector3D ghost_color) {   // pathtracer.cpp:346-410
+  DeviceState& s = state(this);
+  helper_ready(s, this, "rasterize_textured_triangle");
+  const float v[12] = {x0, y0, u0, v0, x1, y1, u1, v1, x2, y2, u2, v2};
+  const double c[3] = {ghost_color.x, ghost_color.y, ghost_color.z};
+  int bb[4];
+  check(s, lf_rasterize_textured_triangle(s.ctx, v, c, bb), "lf_rasterize_textured_triangle");
+  fetch_ghost_rect(s, this, bb[0], bb[1], bb[2], bb[3]);
+}
+
+Vector2D PathTracer::shift_vertex(float x, float y, float scale, float shift_amount) {   // pathtracer.cpp:412-430
+  DeviceState& s = state(this);
+  sync_flares(s, this);   // reads axis_ray
+  double out[2];
+  check(s, lf_shift_vertex(s.ctx, x, y, scale, shift_amount, out), "lf_shift_vertex");
+  return Vector2D(out[0], out[1]);
+}
+
+void PathTracer::draw_ghost(string color, float r1, float r2) {   // pathtracer.cpp:433-508
+  DeviceState& s = state(this);
+  helper_ready(s, this, "draw_ghost");
+  const int channel = color == "red" ? 0 : color == "green" ? 1 : 2;   // :482-488
+  int bb[4];
+  check(s, lf_draw_ghost(s.ctx, channel, r1, r2, bb), "lf_draw_ghost");
+  fetch_ghost_rect(s, this, bb[0], bb[1], bb[2], bb[3]);
+}
+
+std::complex<double> PathTracer::compute_phase(int flare, double u, double v, Vector2D& screen_pos) {   // :917-931
+  DeviceState& s = state(this);
+  if (flare < 0 || (size_t)flare >= flare_origins.size()) {   // the reference indexes its vector unchecked
+    fprintf(stderr, "[PathTracer/MI355X] compute_phase: no flare %d in the frame\n", flare);
+    exit(1);
+  }
+  sync_flares(s, this);
+  double e[2], p[2];
+  check(s, lf_compute_phase(s.ctx, flare, u, v, e, p), "lf_compute_phase");
+  screen_pos = Vector2D(p[0], p[1]);
+  return std::complex<double>(e[0], e[1]);
+}
+
+Vector3D PathTracer::calculate_irradiance_falloff(size_t x, size_t y, double radius) {   // pathtracer.cpp:1043-1063
+  // the 32 draws are pixel (x, y)'s own: those the reference's shared generator hands that pixel when
+  // the frame is visited in tile order (lf_set_jitter_mt19937 in generate_ghost_buffer), or the
+  // counter RNG's
+  DeviceState& s = state(this);
+  sync_flares(s, this);
+  double rgb[3];
+  check(s, lf_irradiance_falloff(s.ctx, (int)x, (int)y, radius, rgb), "lf_irradiance_falloff");
+  return Vector3D(rgb[0], rgb[1], rgb[2]);
+}
+
+// ---- the integrator members (pathtracer.h:62-77): single-ray queries on the device scene ----------
+namespace {
+void pack_ray(const Ray& r, double out[8]) {
+  out[0] = r.o.x; out[1] = r.o.y; out[2] = r.o.z; out[3] = r.d.x; out[4] = r.d.y; out[5] = r.d.z;
+  out[6] = r.min_t; out[7] = r.max_t;
+}
+Vector3D shade_on_device(PathTracer* pt, int what, const Ray& r, const Intersection& isect) {
+  DeviceState& s = state(pt);
+  if (!pt->scene) { fprintf(stderr, "[PathTracer/MI355X] integrator query without a scene\n"); exit(1); }
+  sync_scene(s, pt);
+  double ray[8], m[4], rgb[3];
+  pack_ray(r, ray);
+  material_of(isect.bsdf, m);
+  const double n[3] = {isect.n.x, isect.n.y, isect.n.z};
+  check(s, lf_scene_shade(s.ctx, what, ray, isect.t, n, m, s.probe_seq++, rgb), "lf_scene_shade");
+  return Vector3D(rgb[0], rgb[1], rgb[2]);
+}
+}  // namespace
+
+Vector3D PathTracer::zero_bounce_radiance(const Ray& r, const Intersection& isect) {          // :215-220
+  return shade_on_device(this, 0, r, isect);
+}
+Vector3D PathTracer::one_bounce_radiance(const Ray& r, const Intersection& isect) {           // :222-232
+  return shade_on_device(this, 1, r, isect);
+}
+Vector3D PathTracer::estimate_direct_lighting_hemisphere(const Ray& r, const Intersection& isect) {   // :86-138
+  return shade_on_device(this, 2, r, isect);
+}
+Vector3D PathTracer::estimate_direct_lighting_importance(const Ray& r, const Intersection& isect) {   // :142-213
+  return shade_on_device(this, 3, r, isect);
+}
+
+Vector3D PathTracer::est_radiance_global_illumination(const Ray& r) {                         // :282-302
+  DeviceState& s = state(this);
+  if (!scene) { fprintf(stderr, "[PathTracer/MI355X] est_radiance_global_illumination without a scene\n"); exit(1); }
+  sync_scene(s, this);
+  double ray[8], out[8];
+  pack_ray(r, ray);
+  check(s, lf_scene_trace_ray(s.ctx, ray, s.probe_seq++, out), "lf_scene_trace_ray");
+  if (out[0] != 0.0) r.max_t = out[1];   // BVHAccel::intersect shortens the (mutable) segment to the hit
+  return Vector3D(out[5], out[6], out[7]);
+}
+
+Vector3D PathTracer::at_least_one_bounce_radiance(const Ray& r, const Intersection& isect) {  // :234-280
+  // Dead code in the reference (its only call is commented out, :299), kept callable: the direct
+  // term is the device's (one_bounce_radiance above); the recursion is the Russian-roulette walk of
+  // the reference's own objects -- BSDF::sample_f, BVHAccel::intersect, random_uniform -- which are
+  // the host's, not this library's.
+  g_host_glue_calls++;
+  Vector3D L_out(0, 0, 0);
+  if (r.depth <= 0) return L_out;
+  L_out = one_bounce_radiance(r, isect);
+  const double continue_p = 0.7;
+  if (r.depth <= 1 || random_uniform() < 1 - continue_p) return L_out;
+  Matrix3x3 o2w;
+  make_coord_space(o2w, isect.n);
+  const Matrix3x3 w2o = o2w.T();
+  const Vector3D w_out = w2o * (-r.d);
+  Vector3D w_in;
+  double pdf;
+  isect.bsdf->sample_f(w_out, &w_in, &pdf);
+  Ray next(r.o + r.d * isect.t, o2w * w_in);
+  next.depth = r.depth - 1;
+  next.min_t = EPS_F;
+  Intersection next_isect;
+  if (bvh && bvh->intersect(next, &next_isect)) {
+    const double cos_theta = dot(w_in.unit(), Vector3D(0, 0, 1));
+    const Vector3D f = isect.bsdf->f(-1 * w_in, w_out);
+    L_out += ((at_least_one_bounce_radiance(next, next_isect) * cos_theta * f) / pdf) / continue_p;
+  }
+  return L_out;
+}
+
+void PathTracer::autofocus(Vector2D loc) {                         // pathtracer.cpp:1065-1072
+  // UI thread (raytraced_renderer.cpp:677-679): the closest hit of the camera ray through the clicked
+  // pixel becomes the focal distance; a miss leaves INF_D there, like Intersection's default t
+  DeviceState& s = state(this);
+  if (!camera || !scene) { fprintf(stderr, "[PathTracer/MI355X] autofocus needs a camera and a scene\n"); return; }
+  sync_scene(s, this);
+  const Ray r = camera->generate_ray(loc.x / sampleBuffer.w, loc.y / sampleBuffer.h);
+  double ray[8], out[8];
+  pack_ray(r, ray);
+  check(s, lf_scene_trace_ray(s.ctx, ray, s.probe_seq++, out), "lf_scene_trace_ray");
+  camera->focalDistance = out[0] != 0.0 ? out[1] : INF_D;
 }
 
 }  // namespace CGL

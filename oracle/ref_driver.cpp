@@ -18,7 +18,16 @@
 //            <visit: tiles | list:<file>> <outprefix>
 //   ref_dump collada <scene.dae> <out.txt>      (row f3: the reference's ColladaParser + the
 //            GLScene -> SceneObjects conversion Application::load performs, dumped as hex floats)
+//   ref_dump members <camfile> <W> <H> <aperture.png> <ghost.png> <lights> <scenefile> <out.txt>
+//            every other public member of PathTracer (pathtracer.h:42-101), called one by one the way a
+//            host could: the ghost / starburst helpers, the single-ray integrator queries, autofocus
+// Only in the drop-in build (-DLF_DROPIN, oracle/Makefile `dropin`), for what the reference lacks:
+//   ref_dump lensrays <lens file> <camfile> <aperture.png | -> <samples.txt: x y pu pv per line> <out.txt>
+//            CGL::LensCamera::generate_rays (lens-flare_amd/host/lens_camera_amd.h)
+//   ... and `frame` with REF_LENS_CAMERA=<lens file> [REF_LENS_SPP, REF_LENS_SUN_RADIUS] hands the
+//   renderer a LensCamera instead of a Camera (the geometric march then fills ghost_buffer)
 
+#include <complex>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -52,6 +61,11 @@
 #include "scene/triangle.h"
 #include "util/halfEdgeMesh.h"
 #include "util/image.h"
+#ifdef LF_DROPIN
+#include "lens_camera_amd.h"
+extern "C" void lf_dropin_fetch_ghost_buffer(CGL::PathTracer* pt);
+extern "C" size_t lf_dropin_host_glue_calls(void);
+#endif
 
 using namespace CGL;
 using namespace CGL::SceneObjects;
@@ -131,12 +145,22 @@ static int cmd_frame(int argc, char** argv) {
   std::string visit = argv[a++];
   std::string out = argv[a++];
 
-  Camera cam;
-  cam.load_settings(camfile);
-  cam.aperture_texture = new CameraApertureTexture();
-  cam.aperture_texture->init(ap_png);
-  cam.ghost_aperture_texture = new CameraApertureTexture();
-  cam.ghost_aperture_texture->init(gh_png);
+  Camera base_cam;
+  base_cam.load_settings(camfile);
+  base_cam.aperture_texture = new CameraApertureTexture();
+  base_cam.aperture_texture->init(ap_png);
+  base_cam.ghost_aperture_texture = new CameraApertureTexture();
+  base_cam.ghost_aperture_texture->init(gh_png);
+#ifdef LF_DROPIN
+  // the camera route into the geometric march: the renderer is handed a LensCamera
+  LensCamera lens_cam(base_cam);
+  if (getenv("REF_LENS_CAMERA"))
+    lens_cam.set_lens(getenv("REF_LENS_CAMERA"), getenv("REF_LENS_SPP") ? atoi(getenv("REF_LENS_SPP")) : 64,
+                      getenv("REF_LENS_SUN_RADIUS") ? (float)atof(getenv("REF_LENS_SUN_RADIUS")) : 0.05f);
+  Camera& cam = getenv("REF_LENS_CAMERA") ? static_cast<Camera&>(lens_cam) : base_cam;
+#else
+  Camera& cam = base_cam;
+#endif
 
   // one diffuse sphere far behind the camera target so no camera ray hits it (scene term = 0)
   DiffuseBSDF* bsdf = new DiffuseBSDF(Vector3D(0.5, 0.5, 0.5));
@@ -265,6 +289,9 @@ static int cmd_frame(int argc, char** argv) {
   pt.flare_radiance.clear();
   pt.find_sun_pos();
   pt.generate_ghost_buffer();
+#ifdef LF_DROPIN
+  lf_dropin_fetch_ghost_buffer(&pt);   // the public field, which this tool dumps and no host reads
+#endif
 
   FILE* meta = fopen((out + ".meta.txt").c_str(), "w");
   fprintf(meta, "W %zu\nH %zu\nns_aa %zu\nn_flares %zu\n", W, H, ns_aa, pt.flare_origins.size());
@@ -274,6 +301,9 @@ static int cmd_frame(int argc, char** argv) {
   fprintf(meta, "axis_ray %a %a\nangle_to_sun %a\n", pt.axis_ray.x, pt.axis_ray.y,
           (double)pt.angle_to_sun);
   fprintf(meta, "sizeof_Vector3D %zu\n", sizeof(Vector3D));
+#ifdef LF_DROPIN
+  fprintf(meta, "host_glue_calls %zu\n", lf_dropin_host_glue_calls());
+#endif
   fclose(meta);
 
   {
@@ -425,6 +455,186 @@ static int cmd_collada(int argc, char** argv) {
   return 0;
 }
 
+// ---- every other public member of PathTracer, one by one ----------------------------------------
+static void put3v(FILE* o, const char* tag, const Vector3D& v) { fprintf(o, "%s %a %a %a\n", tag, v.x, v.y, v.z); }
+static void put_ghost_sum(FILE* o, const char* tag, PathTracer& pt) {
+  // position-weighted checksums of the ghost buffer + its non-zero pixels, enough to pin every texel
+  double s0 = 0, s1 = 0, s2 = 0; size_t nz = 0;
+  for (size_t i = 0; i < pt.ghost_buffer.data.size(); i++) {
+    const Vector3D& v = pt.ghost_buffer.data[i];
+    const double w = 1.0 + (double)(i % 97);
+    s0 += w * v.x; s1 += w * v.y; s2 += w * v.z;
+    if (v.x != 0 || v.y != 0 || v.z != 0) nz++;
+  }
+  fprintf(o, "%s %a %a %a %zu\n", tag, s0, s1, s2, nz);
+}
+
+static int cmd_members(int argc, char** argv) {
+  if (argc < 10) return 1;
+  int a = 2;
+  std::string camfile = argv[a++];
+  size_t W = strtoul(argv[a++], 0, 10), H = strtoul(argv[a++], 0, 10);
+  std::string ap_png = argv[a++], gh_png = argv[a++], lightspec = argv[a++], scenefile = argv[a++], outp = argv[a++];
+  Camera cam;
+  cam.load_settings(camfile);
+  cam.aperture_texture = new CameraApertureTexture();
+  cam.aperture_texture->init(ap_png);
+  cam.ghost_aperture_texture = new CameraApertureTexture();
+  cam.ghost_aperture_texture->init(gh_png);
+  std::vector<SceneObject*> objs;
+  std::vector<SceneLight*> lights;
+  std::vector<Primitive*> prims;
+  {
+    double v[6];
+    if (sscanf(lightspec.c_str(), "%lf,%lf,%lf,%lf,%lf,%lf", &v[0], &v[1], &v[2], &v[3], &v[4], &v[5]) != 6) return 3;
+    lights.push_back(new DirectionalLight(Vector3D(v[3], v[4], v[5]), Vector3D(-v[0], -v[1], -v[2]), Vector3D(-v[0], -v[1], -v[2])));
+  }
+  {
+    std::ifstream sf(scenefile);
+    std::string kind;
+    while (sf >> kind) {
+      if (kind == "sphere") {
+        double cx, cy, cz, rr, c0, c1, c2; std::string mk;
+        sf >> cx >> cy >> cz >> rr >> mk >> c0 >> c1 >> c2;
+        BSDF* b = mk == "e" ? (BSDF*)new EmissionBSDF(Vector3D(c0, c1, c2)) : (BSDF*)new DiffuseBSDF(Vector3D(c0, c1, c2));
+        SphereObject* so = new SphereObject(Vector3D(cx, cy, cz), rr, b);
+        objs.push_back(so);
+        for (Primitive* p : so->get_primitives()) prims.push_back(p);
+      } else if (kind == "point") {
+        double px, py, pz, l0, l1, l2;
+        sf >> px >> py >> pz >> l0 >> l1 >> l2;
+        lights.push_back(new PointLight(Vector3D(l0, l1, l2), Vector3D(px, py, pz)));
+      }
+    }
+  }
+  Scene scene(objs, lights);
+  BVHAccel bvh(prims, 4);
+  PathTracer pt;
+  pt.ns_aa = 0;   // no pixel-jitter draws: the shared generator then hands pixel k (tile order) draws 32k .. 32k+31
+  pt.max_ray_depth = 1;
+  pt.ns_area_light = 1;
+  pt.ns_diff = pt.ns_glsy = pt.ns_refr = 1;
+  pt.samplesPerBatch = 32;
+  pt.maxTolerance = 0.05;
+  pt.direct_hemisphere_sample = false;
+  pt.envLight = NULL;
+  pt.flare_radius = 25;
+  pt.flare_intensity = 1;
+  pt.axis_ray = Vector2D(0, 0);
+  pt.angle_to_sun = 0;
+  pt.clear();
+  pt.set_frame_size(W, H);
+  pt.bvh = &bvh;
+  pt.camera = &cam;
+  pt.scene = &scene;
+  pt.find_sun_pos();
+  pt.generate_ghost_buffer();
+  FILE* o = fopen(outp.c_str(), "w");
+  if (!o) return 2;
+  fprintf(o, "n_flares %zu\n", pt.flare_origins.size());
+  // calculate_irradiance_falloff, pixels in the order the tile queue would visit them
+  for (size_t x = 0; x < 3; x++) put3v(o, "falloff", pt.calculate_irradiance_falloff(x, 0, x == 1 ? 3.0 : 5.0));
+  put3v(o, "starburst", pt.raytrace_starburst(3, 0));   // the fourth pixel: starburst + its falloff draws
+  // shift_vertex / compute_phase
+  const float sv[3][4] = {{-1, 1, 7.5f, -3.25f}, {1, -1, 0.4f, 12.f}, {0.3f, 0.2f, 55.f, 0.f}};
+  for (int k = 0; k < 3; k++) {
+    Vector2D v = pt.shift_vertex(sv[k][0], sv[k][1], sv[k][2], sv[k][3]);
+    fprintf(o, "shift_vertex %a %a\n", v.x, v.y);
+  }
+  const double uv[3][2] = {{0.0, 0.0}, {0.123, -0.37}, {-0.5, 0.498}};
+  for (int k = 0; k < 3; k++) {
+    Vector2D sp;
+    std::complex<double> e = pt.compute_phase(0, uv[k][0], uv[k][1], sp);
+    fprintf(o, "compute_phase %a %a %a %a\n", e.real(), e.imag(), sp.x, sp.y);
+  }
+  // the ghost helpers, on top of the frame's ghost buffer
+#ifdef LF_DROPIN
+  lf_dropin_fetch_ghost_buffer(&pt);
+#endif
+  put_ghost_sum(o, "ghost_frame", pt);
+  pt.draw_ghost("red", 14.25f, -37.5f);
+  put_ghost_sum(o, "ghost_after_draw_red", pt);
+  pt.draw_ghost("blue", -3.0f, 9.0f);
+  put_ghost_sum(o, "ghost_after_draw_blue", pt);
+  pt.rasterize_textured_triangle(10.25f, 40.5f, 0.f, 0.f, 30.75f, 5.5f, 0.f, 300.f, 52.f, 33.25f, 420.f, 17.f, Vector3D(0.25, 2.0, 0.5));
+  put_ghost_sum(o, "ghost_after_triangle", pt);
+  pt.fill_textured_pixel(2.5f, 1.5f, 10.f, 20.f, 30.5f, 4.5f, 400.f, 40.f, 12.5f, 28.5f, 100.f, 450.f, 14, 10, Vector3D(3.0, 0.0, 1.5));
+  pt.fill_textured_pixel(2.5f, 1.5f, 10.f, 20.f, 30.5f, 4.5f, 400.f, 40.f, 12.5f, 28.5f, 100.f, 450.f, 60, 3, Vector3D(3.0, 0.0, 1.5));   // outside: no change
+  put_ghost_sum(o, "ghost_after_pixels", pt);
+  put3v(o, "ghost_px_14_10", pt.ghost_buffer.get_pixel_value(14, 10));
+  // the integrator members: camera rays through a few pixels, shaded through each entry point
+  const double pxs[9][2] = {{0.5, 0.5}, {0.31, 0.62}, {0.7, 0.35}, {0.05, 0.95}, {0.52, 0.41},
+                            {0.25, 0.75}, {0.4, 0.8}, {0.6, 0.2}, {0.45, 0.55}};
+  for (int k = 0; k < 9; k++) {
+    Ray r = cam.generate_ray(pxs[k][0], pxs[k][1]);
+    put3v(o, "est_radiance", pt.est_radiance_global_illumination(r));
+    Ray r2 = cam.generate_ray(pxs[k][0], pxs[k][1]);
+    Intersection isect;
+    if (bvh.intersect(r2, &isect)) {
+      fprintf(o, "hit %a\n", isect.t);
+      put3v(o, "zero_bounce", pt.zero_bounce_radiance(r2, isect));
+      put3v(o, "one_bounce", pt.one_bounce_radiance(r2, isect));
+      put3v(o, "importance", pt.estimate_direct_lighting_importance(r2, isect));
+      Ray r3 = r2; r3.depth = 1;
+      put3v(o, "at_least_one", pt.at_least_one_bounce_radiance(r3, isect));
+    } else {
+      fprintf(o, "miss\n");
+    }
+  }
+  // autofocus, like RaytracedRenderer::autofocus from the UI thread
+  const double locs[3][2] = {{W * 0.5, H * 0.5}, {W * 0.31, H * 0.62}, {W * 0.05, H * 0.95}};
+  for (int k = 0; k < 3; k++) {
+    cam.focalDistance = -1;
+    pt.autofocus(Vector2D(locs[k][0], locs[k][1]));
+    fprintf(o, "autofocus %a\n", cam.focalDistance);
+  }
+#ifdef LF_DROPIN
+  fprintf(o, "host_glue_calls %zu\n", lf_dropin_host_glue_calls());
+#endif
+  fclose(o);
+  return 0;
+}
+
+#ifdef LF_DROPIN
+static int cmd_lensrays(int argc, char** argv) {
+  if (argc < 7) return 1;
+  Camera base;
+  base.load_settings(argv[3]);
+  base.aperture_texture = NULL;
+  base.ghost_aperture_texture = NULL;
+  if (std::string(argv[4]) != "-") {
+    base.aperture_texture = new CameraApertureTexture();
+    base.aperture_texture->init(argv[4]);
+  }
+  LensCamera cam(base);
+  cam.set_lens(argv[2]);
+  std::vector<double> in;
+  {
+    std::ifstream f(argv[5]);
+    double v;
+    while (f >> v) in.push_back(v);
+  }
+  const size_t n = in.size() / 4;
+  std::vector<Ray> rays;
+  std::vector<double> w;
+  cam.generate_rays(n, in.data(), &rays, &w, getenv("REF_LENS_LAMBDA") ? atoi(getenv("REF_LENS_LAMBDA")) : -1);
+  FILE* o = fopen(argv[6], "w");
+  if (!o) return 2;
+  for (size_t i = 0; i < n; i++)
+    fprintf(o, "%a %a %a %a %a %a %a %zu %a %a\n", rays[i].o.x, rays[i].o.y, rays[i].o.z, rays[i].d.x, rays[i].d.y,
+            rays[i].d.z, w[i], rays[i].depth, rays[i].min_t, rays[i].max_t);
+  // the single-ray forms agree with the batch
+  bool alive = false;
+  double wt = 0;
+  Ray r1 = cam.generate_ray(in[0], in[1], in[2], in[3], &alive, &wt);
+  fprintf(o, "single %a %a %a %a %a %a %a %d\n", r1.o.x, r1.o.y, r1.o.z, r1.d.x, r1.d.y, r1.d.z, wt, alive ? 1 : 0);
+  Ray r2 = cam.generate_ray(0.5, 0.5);   // pupil point drawn from random_uniform()
+  fprintf(o, "drawn %a %a %a %a %a %a %zu\n", r2.o.x, r2.o.y, r2.o.z, r2.d.x, r2.d.y, r2.d.z, r2.depth);
+  fclose(o);
+  return 0;
+}
+#endif
+
 int main(int argc, char** argv) {
   if (argc < 2) return 1;
   std::string c = argv[1];
@@ -433,5 +643,9 @@ int main(int argc, char** argv) {
   if (c == "convert") return cmd_convert(argc, argv);
   if (c == "frame") return cmd_frame(argc, argv);
   if (c == "collada") return cmd_collada(argc, argv);
+  if (c == "members") return cmd_members(argc, argv);
+#ifdef LF_DROPIN
+  if (c == "lensrays") return cmd_lensrays(argc, argv);
+#endif
   return 1;
 }

@@ -6,11 +6,25 @@ src/pathtracer/pathtracer.h:25-143) on the MI355X through the C ABI.  The same d
 (raytraced_renderer.cpp:300-311, :622-647) on it, and the buffers it dumps must equal the golden
 frames the all-reference build of the very same driver produced (tests/golden/, oracle/make_golden.py).
 
-The binary is built in the build container only (oracle/Makefile `dropin`; it needs the reference
-checkout) and travels to the GPU box with the snapshot."""
+Round 3 completes the replacement: pathtracer_amd.cpp defines EVERY member the header declares
+(tests/test_dropin_symbols.py checks the link), so this file also runs
+  * oracle/_ref/ref_app_amd -- the reference's own render controller, RaytracedRenderer compiled from
+    raytraced_renderer.cpp as it is (tile queue, worker threads, save_image, autofocus), on the
+    replaced PathTracer -- against the PNG the all-reference ref_app wrote (tests/golden/app_*.json);
+  * every other public member one by one (`ref_dump members`, tests/golden/members_*.json);
+  * the geometric march -- the kernel bench.py measures -- THROUGH the reference's surface, selected
+    by LF_LENS_FILE in the environment of the unchanged host or by handing the renderer a
+    CGL::LensCamera, bit for bit against the float32 oracle;
+  * CGL::LensCamera::generate_ray(s) against lf_generate_lens_rays.
+
+The binaries are built in the build container only (oracle/Makefile `dropin`, `app`; they need the
+reference checkout) and travel to the GPU box with the snapshot."""
+import base64
+import json
 import math
 import os
 import subprocess
+import sys
 
 import numpy as np
 import pytest
@@ -20,6 +34,8 @@ from goldenlib import GOLD, Case
 pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 BIN = os.path.join(ROOT, "oracle", "_ref", "ref_dump_amd")
+APP = os.path.join(ROOT, "oracle", "_ref", "ref_app_amd")
+sys.path.insert(0, os.path.join(ROOT, "oracle"))
 
 CASES = ["f64x48_pentbiglines", "f97x65_odd_rotcam", "f80x50_two_suns", "f96x64_naive_rgba",
          "s96x64_spheres", "s80x60_tris_rotcam", "c96x72_pyramid_dae", "z40x30_fuzz1", "z44x26_fuzz3",
@@ -62,6 +78,7 @@ def test_reference_binary_with_pathtracer_replaced(name, tmp_path):
     assert r.returncode == 0, r.stderr[-2000:]
     out = str(tmp_path / "o")
     meta = dict(l.split(None, 1) for l in open(out + ".meta.txt") if not l.startswith("flare "))
+    assert int(meta["host_glue_calls"]) == 0            # nothing on the frame path is host arithmetic
     assert int(meta["n_flares"]) == case.meta["n_flares"]
     assert [float.fromhex(v) for v in meta["axis_ray"].split()] == case.meta["axis_ray"]
     assert float.fromhex(meta["angle_to_sun"].strip()) == case.meta["angle_to_sun"]
@@ -75,3 +92,196 @@ def test_reference_binary_with_pathtracer_replaced(name, tmp_path):
     from oracle import lfo
     order = np.fromfile(out + ".order.u32", np.uint32)   # the driver visited the pixels like the reference's tiles
     assert np.array_equal(order, lfo.tile_order(case.W, case.H))
+
+
+# ---- the reference's own render controller on the replaced PathTracer -------------------------------
+def _golden_json(prefix):
+    return sorted(f for f in os.listdir(GOLD) if f.startswith(prefix) and f.endswith(".json"))
+
+
+@pytest.mark.parametrize("fixture", _golden_json("app_"))
+@pytest.mark.parametrize("threads", [1, 5])
+def test_reference_render_controller_with_pathtracer_replaced(fixture, threads, tmp_path):
+    """RaytracedRenderer::render_to_file (start_raytracing -> tile queue -> N worker threads calling
+    raytrace_pixel / write_to_framebuffer -> save_image) and ::autofocus, compiled from the
+    reference's raytraced_renderer.cpp unchanged: the PNG on disk, the sampling-rate PNG and the focal
+    distance equal what the all-reference build produced.  With 5 workers too: unlike the reference
+    (shared generator), the replacement does not depend on the schedule."""
+    import make_golden_app as mga
+    assert os.path.exists(APP), "oracle/_ref/ref_app_amd is missing: make -C oracle app (build container)"
+    rec = json.load(open(os.path.join(GOLD, fixture)))
+    out = str(tmp_path / "out.png")
+    args = mga.app_args(dict(rec, threads=threads), str(tmp_path), out)
+    r = subprocess.run([APP] + args, capture_output=True, text=True, timeout=600, cwd=str(tmp_path))
+    assert r.returncode == 0, r.stderr[-2000:]
+    from PIL import Image
+    import io
+    got = np.asarray(Image.open(out).convert("RGBA"))
+    want = np.asarray(Image.open(io.BytesIO(base64.b64decode(rec["png"]))).convert("RGBA"))
+    assert got.shape == want.shape == (rec["H"], rec["W"], 4)
+    assert np.array_equal(got, want)                                      # every byte of every pixel
+    assert open(out, "rb").read() == base64.b64decode(rec["png"])         # ... and of the file
+    assert open(out[:-4] + "_rate.png", "rb").read() == base64.b64decode(rec["rate_png"])
+    focal = [float.fromhex(l.split()[1]) for l in r.stdout.splitlines() if l.startswith("FOCAL ")]
+    assert focal and focal[0] == pytest.approx(float.fromhex(rec["focal"]), rel=1e-12)
+
+
+def _numbers(line):
+    out = []
+    for t in line.split()[1:]:
+        out.append(float.fromhex(t) if ("0x" in t or t in ("inf", "-inf", "nan")) else float(t))
+    return np.array(out)
+
+
+@pytest.mark.parametrize("fixture", _golden_json("members_"))
+def test_every_other_public_member(fixture, tmp_path):
+    """calculate_irradiance_falloff, raytrace_starburst, shift_vertex, compute_phase, draw_ghost,
+    rasterize_textured_triangle, fill_textured_pixel, est_radiance_global_illumination, zero / one
+    bounce, the importance estimator, at_least_one_bounce_radiance, autofocus: called one by one on
+    the replacement, compared with what the reference's own members returned for the same calls."""
+    import make_golden_app as mga
+    rec = json.load(open(os.path.join(GOLD, fixture)))
+    out = str(tmp_path / "members.txt")
+    r = subprocess.run([BIN] + mga.member_args(rec, str(tmp_path), out), capture_output=True, text=True,
+                       timeout=600, cwd=str(tmp_path))
+    assert r.returncode == 0, r.stderr[-2000:]
+    got = open(out).read().splitlines()
+    glue = [l for l in got if l.startswith("host_glue_calls")]
+    got = [l for l in got if not l.startswith("host_glue_calls")]
+    want = rec["lines"]
+    assert [l.split()[0] for l in got] == [l.split()[0] for l in want]
+    exact = ("n_flares", "ghost_frame", "ghost_after_draw_red", "ghost_after_draw_blue", "ghost_after_triangle",
+             "ghost_after_pixels", "ghost_px_14_10", "zero_bounce", "miss")
+    seen = set()
+    for g, w in zip(got, want):
+        tag = g.split()[0]
+        seen.add(tag)
+        a, b = _numbers(g), _numbers(w)
+        if tag in exact:      # float rasteriser + double accumulation in the reference's order: bit for bit
+            assert np.array_equal(a, b), (g, w)
+        elif tag == "compute_phase":   # cos / sin of ~1e2 rad: absolute
+            assert np.allclose(a, b, rtol=0, atol=1e-12), (g, w)
+        else:
+            assert np.allclose(a, b, rtol=1e-9, atol=0), (g, w)
+    assert {"falloff", "starburst", "shift_vertex", "draw", "est_radiance", "hit", "one_bounce", "importance",
+            "at_least_one", "autofocus"} <= {t.replace("ghost_after_draw_red", "draw") for t in seen}
+    # the one member that is host glue (dead code in the reference) ran here, 5 hits x once
+    assert glue and int(glue[0].split()[1]) >= 1
+
+
+# ---- the geometric march through the reference's surface --------------------------------------------
+def _geometric_frame(tmp_path, env_extra, W=64, H=48):
+    case = Case("f64x48_pentbiglines")
+    args = _write_inputs(case, tmp_path)
+    args[6] = os.path.join(GOLD, "apertures", "pentbig500_14.png")     # the stop's mask = the -x aperture
+    env = dict(os.environ, **env_extra)
+    r = subprocess.run([BIN, "frame"] + args, capture_output=True, text=True, timeout=600, env=env)
+    assert r.returncode == 0, r.stderr[-2000:]
+    out = str(tmp_path / "o")
+    flares = [[float.fromhex(v) for v in l.split()[1:]] for l in open(out + ".meta.txt") if l.startswith("flare ")]
+    ghost = np.fromfile(out + ".ghost.f64", np.float64).reshape(H, W, 3)
+    sample = np.fromfile(out + ".sample.f64", np.float64).reshape(H, W, 3)
+    return case, flares, ghost, sample
+
+
+@pytest.mark.parametrize("route", ["LF_LENS_FILE", "LensCamera"])
+def test_geometric_march_through_the_reference_surface(route, tmp_path):
+    """The kernel the bench line measures, reached from the reference's own call sequence
+    (find_sun_pos(); generate_ghost_buffer(); raytrace_pixel ...): ghost_buffer as the host reads it
+    equals the float32 oracle's march bit for bit, and sampleBuffer = ghost + starburst."""
+    import __graft_entry__ as g
+    from goldenlib import load_texels
+    from oracle import lfo
+    pkg = g.load_package()
+    lens_path = os.path.join(ROOT, "lens-flare_amd", "data", "dgauss11.lens")
+    spp, key, radius, W, H = 16, 0x51a7, 0.04, 64, 48
+    if route == "LF_LENS_FILE":
+        env = dict(LF_LENS_FILE=lens_path, LF_GEOMETRIC_SPP=str(spp), LF_GEOMETRIC_KEY=hex(key),
+                   LF_SUN_ANGULAR_RADIUS=repr(radius))
+    else:
+        env = dict(REF_LENS_CAMERA=lens_path, REF_LENS_SPP=str(spp), REF_LENS_SUN_RADIUS=repr(radius),
+                   LF_GEOMETRIC_KEY=hex(key))
+    case, flares, ghost, sample = _geometric_frame(tmp_path, env)
+    assert len(flares) == 1
+    lens = pkg.load_lens_file("dgauss11.lens")
+    efl = pkg.paraxial_efl(lens)
+    nx, ny = flares[0][0], flares[0][1]
+    sun = [(nx - 0.5) * lens["sensor_width_mm"] / efl, (ny - 0.5) * lens["sensor_width_mm"] * H / W / efl, -1.0]
+    mask = load_texels("pentbig500_14.png")
+    lf = pkg.LensFlare(0)
+    lfo.geo_set_sqrt_table(lfo.sqrt_deviation_table(lf.native_sqrt))
+    try:
+        og, _ = lfo.geo_trace(lens, W, H, 0, H, spp, key, None, True, mask, sun, flares[0][2:5], radius)
+    finally:
+        lfo.geo_set_sqrt_table(None)
+        lf.close()
+    assert og.max() > 0
+    assert np.array_equal(ghost, og)
+    # the paraxial quads are NOT what filled the buffer
+    assert not np.array_equal(ghost, case.ghost)
+    # raytrace_pixel composed it: sample - ghost = the frame's starburst (+ scene term), which is the
+    # same whichever way the ghosts were made (the same inputs through the paraxial path)
+    (tmp_path / "p").mkdir()
+    _, _, ghost_p, sample_p = _geometric_frame(tmp_path / "p", {})
+    assert np.array_equal(ghost_p[ghost_p != 0] > 0, np.ones((ghost_p != 0).sum(), bool)) and ghost_p.max() > 0
+    assert np.allclose(sample - ghost, sample_p - ghost_p, rtol=1e-9, atol=1e-12 * np.abs(sample_p).max())
+
+
+def test_geometric_march_without_a_sun_clears_the_ghost_buffer(tmp_path):
+    """generate_ghost_buffer's early return (pathtracer.cpp:724-726): no light in the frame, no ghosts."""
+    case = Case("f64x64_no_sun")
+    args = _write_inputs(case, tmp_path)
+    env = dict(os.environ, LF_LENS_FILE=os.path.join(ROOT, "lens-flare_amd", "data", "dgauss11.lens"), LF_GEOMETRIC_SPP="4")
+    r = subprocess.run([BIN, "frame"] + args, capture_output=True, text=True, timeout=600, env=env)
+    assert r.returncode == 0, r.stderr[-2000:]
+    ghost = np.fromfile(str(tmp_path / "o") + ".ghost.f64", np.float64)
+    assert ghost.size == case.W * case.H * 3 and not ghost.any()
+
+
+def test_lens_camera_generate_rays(tmp_path):
+    """CGL::LensCamera (a Camera subclass compiled against the reference's camera.h): its rays are
+    lf_generate_lens_rays' exit rays carried into world space by the camera's c2w and position."""
+    import __graft_entry__ as g
+    from goldenlib import load_texels
+    pkg = g.load_package()
+    case = Case("f97x65_odd_rotcam")
+    args = _write_inputs(case, tmp_path)
+    cam = args[0]
+    rng = np.random.default_rng(11)
+    smp = rng.random((64, 4))
+    smp[0] = [0.5, 0.5, 0.5, 0.5]                     # the chief ray of the centre pixel
+    np.savetxt(tmp_path / "samples.txt", smp, fmt="%.17g")
+    lens_path = os.path.join(ROOT, "lens-flare_amd", "data", "dgauss11.lens")
+    mask_png = os.path.join(GOLD, "apertures", "pentbig500_14.png")
+    out = tmp_path / "rays.txt"
+    r = subprocess.run([BIN, "lensrays", lens_path, cam, mask_png, str(tmp_path / "samples.txt"), str(out)],
+                       capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = open(out).read().splitlines()
+    rows = np.array([[float.fromhex(v) if "0x" in v else float(v) for v in l.split()] for l in lines[:64]])
+    lens = pkg.load_lens_file("dgauss11.lens")
+    lf = pkg.LensFlare(0)
+    lf.set_frame(64, 64)
+    lf.set_aperture(pkg.APERTURE_STARBURST, load_texels("pentbig500_14.png"))
+    lf.set_lens(lens)
+    sw = lens["sensor_width_mm"]
+    sh = sw / (case.W / case.H)
+    xy = np.stack([-(smp[:, 0] - 0.5) * sw, -(smp[:, 1] - 0.5) * sh], 1).astype(np.float32)
+    uv = (2.0 * smp[:, 2:4] - 1.0).astype(np.float32)
+    dev = lf.generate_lens_rays(1, xy, uv)
+    lf.close()
+    c2w = np.array(case.meta["c2w"], float).reshape(3, 3)
+    pos = np.array(case.meta["cam_pos"], float)
+    alive = dev[:, 7] != 0
+    assert 8 < alive.sum() < 64                       # some samples are blocked by the pentagon / vignetted
+    assert np.array_equal(rows[:, 7] != 0, alive)
+    assert np.allclose(rows[:, 0:3], pos + dev[:, 0:3].astype(float) @ c2w.T, rtol=1e-12, atol=1e-12)
+    assert np.allclose(rows[:, 3:6], dev[:, 3:6].astype(float) @ c2w.T, rtol=1e-12, atol=1e-12)
+    assert np.array_equal(rows[:, 6], dev[:, 6].astype(float))
+    assert np.all(rows[:, 8] == 0.01) and np.all(rows[:, 9] == 100.0)     # Camera's clip range
+    # the centre pixel's chief ray leaves along the camera's -z axis
+    assert alive[0] and np.allclose(rows[0, 3:6], -c2w[:, 2], atol=1e-6)
+    single = [float.fromhex(v) if "0x" in v else float(v) for v in lines[64].split()[1:]]
+    assert np.array_equal(np.array(single[:7]), rows[0, :7]) and single[7] == 1
+    drawn = lines[65].split()
+    assert drawn[0] == "drawn" and int(drawn[7]) == 1    # a random pupil point that passes is found
