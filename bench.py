@@ -42,7 +42,7 @@ VALU_PRACTICAL = 1.05e12                  # profiles/microbench/valu_issue.hip (
 SCALAR_PEAK = 256 * CLOCK_HZ              # one scalar unit per CU, one instruction per clock
 SUN_NS = (0.521445, 0.517156)
 TILE_ROWS = 8   # the march kernel's sensor tile is 8x8 pixels
-PMC_FILE = os.path.join(ROOT, "profiles", "r02_march_pmc.json")
+PMC_FILES = [os.path.join(ROOT, "profiles", n) for n in ("r03_march_pmc.json", "r02_march_pmc.json")]   # newest first
 
 # BASELINE.json configs[1..4]; configs[3] / [4] are 8-GPU jobs there, here one GPU's whole frame
 CONFIGS = {
@@ -116,7 +116,8 @@ def cpu_baseline(lens, mask, sun, W, H, pairs, lambda_rgb, target_s):
     tracer) timed on this host's cores on a bounded sample of the same workload: a band of rows
     of the same frame at reduced spp."""
     from oracle import lfo
-    cores = min(os.cpu_count() or 1, 64)
+    host_cores = os.cpu_count() or 1
+    cores = min(host_cores, 64)   # the oracle's OpenMP team is capped at 64 threads
     rows = (H // 2 - 32, H // 2 + 32)
     t0 = time.time()
     _, c = lfo.geo_trace(lens, W, H, rows[0], rows[0] + 4, 1, 1, pairs, True, mask, sun,
@@ -130,7 +131,7 @@ def cpu_baseline(lens, mask, sun, W, H, pairs, lambda_rgb, target_s):
                          [1.0, 0.9, 0.5], 0.05, n_threads=cores, lambda_rgb=lambda_rgb)
     dt = time.time() - t0
     return {"value": c["surface_events"] / dt / 1e6, "unit": "Mray-surface-intersections/s",
-            "cores": cores, "kind": "port",
+            "cores": cores, "host_cores": host_cores, "kind": "port",
             "sample": f"rows {rows[0]}..{rows[1]} of the {W}x{H} frame, {spp} of the spp, every path "
                       f"marched on its own: {c['surface_events']} intersections in {dt:.1f} s "
                       f"(oracle/lf_geo_oracle.c, OpenMP); the reference has no geometric lens to time"}
@@ -324,42 +325,54 @@ def main():
     lf.set_row_interleave(rank, world)
     frame_t, scratch, gather_note = None, {}, None
     if gather_mode == "cabi":
-        # rank 0 makes the RCCL id, gloo carries it, every rank attaches its context
-        ok, why = 1, ""
+        # Bring-up of the C ABI's RCCL communicator such that no rank can hang behind a peer that failed
+        # alone (lens_flare_amd.sharding.agree / first_exchange; tests/test_sharding_gloo.py injects the
+        # failures): (1) every rank says over gloo whether it CAN (librccl loads, its context is ready)
+        # BEFORE any blocking RCCL call; (2) rank 0 makes the id, gloo carries it, every rank attaches;
+        # (3) the first exchange -- which also sets up the communicator's channels, tens to hundreds of
+        # ms that are set-up like the aperture spectrum, not part of a frame -- is waited for with a
+        # deadline.  Any verdict is taken by all ranks together; after a failed step every rank aborts
+        # its communicator (lf_comm_abort: the streams drain) and all fall back to the
+        # torch.distributed nccl exchange, saying so in the JSON line.
+        ok, why = True, ""
         try:
-            box = [pkg.comm_unique_id() if rank == 0 else None]
+            if not pkg.comm_available():
+                ok, why = False, "librccl.so.1 could not be loaded"
+            if os.environ.get("LF_BENCH_EXCHANGE") == "f32":
+                lf.comm_set_exchange_precision(32)
         except Exception as e:  # noqa: BLE001
-            box, ok, why = [None], 0, str(e)
-        dist.broadcast_object_list(box, src=0)
-        if box[0] is None:
-            ok = 0
-        if ok:
+            ok, why = False, str(e)
+        all_ok, bad = sharding.agree(dist, ok, why)
+        if all_ok:
+            box = [None]
+            try:
+                if rank == 0:
+                    box = [pkg.comm_unique_id()]
+            except Exception as e:  # noqa: BLE001
+                why = str(e)
+            dist.broadcast_object_list(box, src=0)
+            ok = box[0] is not None
+            all_ok, bad = sharding.agree(dist, ok, why if rank == 0 else "")
+        if all_ok:
+            ok, why = True, ""
             try:
                 lf.comm_init_rank(world, rank, box[0])
             except Exception as e:  # noqa: BLE001
-                ok, why = 0, str(e)
-        flag = torch.tensor([ok], dtype=torch.int32)
-        dist.all_reduce(flag, op=dist.ReduceOp.MIN)
-        if int(flag[0]) == 0:   # every rank takes the same decision
+                ok, why = False, str(e)
+            all_ok, bad = sharding.agree(dist, ok, why)
+        if all_ok:
+            all_ok, bad = sharding.first_exchange(
+                dist, lambda: lf.comm_gather(pkg.SAMPLE_BUFFER), lf.comm_test,
+                timeout_s=float(os.environ.get("LF_BENCH_COMM_TIMEOUT", "120")))
+        if not all_ok:
+            try:
+                lf.comm_abort()
+            except Exception:  # noqa: BLE001
+                pass
             gather_mode = "torch"
-            gather_note = f"C-ABI RCCL communicator unavailable ({why or 'another rank failed'}): torch.distributed nccl exchange"
+            gather_note = "C-ABI RCCL exchange unavailable (" + "; ".join(bad) + "): torch.distributed nccl exchange"
             nccl_group = dist.new_group(backend="nccl")
-    if gather_mode == "cabi":
-        # first use of a communicator sets up its channels (tens to hundreds of ms): part of set-up,
-        # like the aperture spectrum, not of a frame -- whatever --warmup says.  Should it fail on
-        # any rank, every rank falls back to the torch.distributed exchange together.
-        ok, why = 1, ""
-        try:
-            lf.comm_gather(pkg.SAMPLE_BUFFER)
-            lf.synchronize()
-        except Exception as e:  # noqa: BLE001
-            ok, why = 0, str(e)
-        flag = torch.tensor([ok], dtype=torch.int32)
-        dist.all_reduce(flag, op=dist.ReduceOp.MIN)
-        if int(flag[0]) == 0:
-            gather_mode = "torch"
-            gather_note = f"C-ABI exchange failed at its first use ({why or 'on another rank'}): torch.distributed nccl exchange"
-            nccl_group = dist.new_group(backend="nccl")
+            lf.set_row_interleave(rank, world)
     if gather_mode in ("torch", "host"):
         ptr, nbytes = lf.device_buffer(pkg.SAMPLE_BUFFER)
         frame_t = torch.as_tensor(DevView(ptr, nbytes // 8), device=f"cuda:{local}")
@@ -368,6 +381,8 @@ def main():
         @staticmethod
         def all_gather_into_tensor(out, inp):
             dist.all_gather_into_tensor(out, inp, group=nccl_group)
+
+    host_exchange = [0.0]   # seconds spent in the torch / host exchange (the C ABI's is timed on its stream)
 
     def one_frame():
         lf.find_sun_pos(lights)
@@ -386,14 +401,18 @@ def main():
                 lf.comm_gather_async(pkg.SAMPLE_BUFFER)
         elif gather_mode == "torch":
             lf.synchronize()
+            t_x = time.perf_counter()
             sharding.gather_frame(frame_t, W, H, rank, world, GroupDist, scratch=scratch)
             torch.cuda.synchronize()   # the next frame rewrites these rows on the library's stream
+            host_exchange[0] += time.perf_counter() - t_x
         elif gather_mode == "host":
             lf.synchronize()
+            t_x = time.perf_counter()
             host = frame_t.cpu()
             sharding.gather_frame(host, W, H, rank, world, dist)
             frame_t.copy_(host)
             torch.cuda.synchronize()
+            host_exchange[0] += time.perf_counter() - t_x
 
     def barrier():
         lf.synchronize()
@@ -408,6 +427,7 @@ def main():
     lf.reset_counters()
     lf.timing_reset()
     lf.timing_enable(True)
+    host_exchange[0] = 0.0
     barrier()
     t0 = time.perf_counter()
     for _ in range(args.steps):
@@ -417,17 +437,32 @@ def main():
     lf.timing_enable(False)
 
     cnt = lf.counters()
+    stats = lf.march_stats()
     n_launch, march_ms = lf.timing_get("march")
-    ev = torch.tensor([float(cnt["surface_events"]), float(cnt["rays_launched"]),
-                       float(lf.executed_events()), dt], dtype=torch.float64)
+    n_xchg, xchg_ms = lf.timing_get("exchange") if gather_mode == "cabi" else (args.steps, host_exchange[0] * 1e3)
+    n_scene, scene_ms = lf.timing_get("scene_term")
+    rccl_nranks, rccl_rank = lf.comm_info()
+    fate_keys = ("rays_launched", "rays_clipped_stop", "rays_vignetted", "rays_tir", "rays_reached_scene", "rays_hit_light")
+    ev = torch.tensor([float(cnt["surface_events"]), float(cnt["rays_launched"]), float(stats["executed_events"]),
+                       float(stats["remarch_lane_events"]), float(stats["remarch_rows"])] +
+                      [float(cnt[k]) for k in fate_keys] + [dt], dtype=torch.float64)
+    # what rank 0 needs to tell a bad scaling curve's cause from the record: every rank's own numbers
+    mine = {"rank": rank, "device": local, "tile_rows": my_trows, "march_ms": march_ms / max(n_launch, 1),
+            "exchange_ms": xchg_ms / max(n_xchg, 1), "scene_ms": scene_ms / max(n_scene, 1) if n_scene else 0.0,
+            "wall_ms_per_step": dt / args.steps * 1e3, "rccl_nranks": rccl_nranks, "rccl_rank": rccl_rank}
+    per_rank = [mine]
     if world > 1:
         tot = ev.clone()
-        dist.all_reduce(tot[:3], op=dist.ReduceOp.SUM)
-        mx = ev[3:].clone()
+        dist.all_reduce(tot[:-1], op=dist.ReduceOp.SUM)
+        mx = ev[-1:].clone()
         dist.all_reduce(mx, op=dist.ReduceOp.MAX)
-        logical, rays, executed, dt = float(tot[0]), float(tot[1]), float(tot[2]), float(mx[0])
+        dt = float(mx[0])
+        per_rank = [None] * world
+        dist.all_gather_object(per_rank, mine)
     else:
-        logical, rays, executed = float(ev[0]), float(ev[1]), float(ev[2])
+        tot = ev
+    logical, rays, executed, remarch_lane, remarch_rows = (float(v) for v in tot[:5])
+    fate_tot = {k: float(v) for k, v in zip(fate_keys, tot[5:11])}
 
     if rank == 0:
         # ---- roofline of the dominant kernel (k_march) -------------------------------------------
@@ -443,13 +478,18 @@ def main():
         # profiles/ (counters cannot be read inside this process); they are quoted as THIS binary's
         # only if the profile was taken from the same sources
         pmc, pmc_note = None, "no PMC summary for this config under profiles/"
-        if os.path.exists(PMC_FILE):
+        for pmc_file in PMC_FILES:   # the newest summary taken from the shipped sources, else the newest
+            if not os.path.exists(pmc_file):
+                continue
             try:
-                allp = json.load(open(PMC_FILE))
-                pmc = allp.get(args.config) or allp.get("c3")
-                if pmc is not None:
-                    pmc_note = (f"profiles/{os.path.basename(PMC_FILE)}[{args.config if args.config in allp else 'c3'}], "
+                allp = json.load(open(pmc_file))
+                cand = allp.get(args.config) or allp.get("c3")
+                if cand is not None and (pmc is None or cand.get("source_sha") == source_sha()):
+                    pmc = cand
+                    pmc_note = (f"profiles/{os.path.basename(pmc_file)}[{args.config if args.config in allp else 'c3'}], "
                                 f"rocprofv3 --pmc, separate passes")
+                    if cand.get("source_sha") == source_sha():
+                        break
             except Exception as e:  # noqa: BLE001
                 pmc_note = f"unreadable PMC summary: {e}"
         roof = {"bound": "valu", "unit": "wave-instr/s", "peak": VALU_PEAK, "achieved": None, "frac": None,
@@ -497,11 +537,37 @@ def main():
                                           "torch": ", one torch.distributed nccl all_gather per frame",
                                           "host": ", REHEARSAL: ranks share one GPU, exchange staged through host memory",
                                           "none": ""}[gather_mode]),
-                       "gather_note": gather_note,
+                       "gather_mode": gather_mode, "gather_note": gather_note,
+                       "exchange_dtype": ("f32" if os.environ.get("LF_BENCH_EXCHANGE") == "f32" else "f64") if world > 1 else None,
                        "rays_per_frame": rays / args.steps,
                        "events_executed_per_frame": executed / args.steps,
                        "events_logical_per_frame": logical / args.steps,
                        "focal_length_mm": efl},
+            # ---- what the counted events are, and what became of the rays ---------------------------
+            # A counted event = intersection + refraction / reflection, executed by the first pass.  Its
+            # Fresnel / aperture WEIGHT is computed by marching a finished path a second time, only where a
+            # lane reached the light's lobe: `remarch_events` (counted, NEVER added to `value`) is how many
+            # events that second march evaluated for the lanes that needed them, and
+            # fresnel_evaluated_fraction = that / executed.  profiles/r03_all_weights_ablation.json prices
+            # the event of SURVEY 8d (weight on every event) against this.
+            "event_accounting": {
+                "fresnel_evaluated_fraction": remarch_lane / executed if executed else None,
+                "remarch_events": remarch_lane / args.steps,
+                "remarch_rows_x64": 64.0 * remarch_rows / args.steps,
+                "remarch_rows_over_executed": 64.0 * remarch_rows / executed if executed else None,
+                "note": "remarch_rows_x64 = what the SIMDs executed for the second marches (whole waves); per frame"},
+            # ray = one (sample, wavelength, path); fractions of rays_launched, summed over ranks
+            "fates": {k[5:]: (fate_tot[k] / fate_tot["rays_launched"] if fate_tot["rays_launched"] else None)
+                      for k in fate_keys[1:]},
+            "events_per_ray": {"executed": executed / rays if rays else None, "logical": logical / rays if rays else None},
+            # ---- multi-GPU diagnostics (every rank's own numbers; ms per frame) -----------------------
+            "rccl_nranks": max(r["rccl_nranks"] for r in per_rank),
+            "march_ms": {"min": min(r["march_ms"] for r in per_rank), "max": max(r["march_ms"] for r in per_rank)},
+            "exchange_ms": {"min": min(r["exchange_ms"] for r in per_rank), "max": max(r["exchange_ms"] for r in per_rank),
+                            "timed": ("HIP events around pack -> ncclAllGather -> unpack on the stream the exchange runs on "
+                                      "(overlapped with the next frame's march)" if gather_mode == "cabi" else
+                                      "host clock around the exchange incl. its synchronisation" if world > 1 else "no exchange")},
+            "per_rank": per_rank,
             "roofline": roof,
             "cpu_baseline": cpu,
             "reference_flare_path": ref_path,

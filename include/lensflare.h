@@ -445,6 +445,14 @@ lf_status lf_reset_counters(lf_ctx* ctx);
  * sample start with the same backward leg and the pairs (i, .) share the forward leg after the
  * reflection at i, and the march computes every shared leg once (no reference counterpart). */
 lf_status lf_get_executed_events(lf_ctx* ctx, uint64_t* out);
+/* What the counted events cost in full (no reference counterpart): the march's first pass computes
+ * intersection + refraction / reflection for every event; the Fresnel / aperture WEIGHT of an event is
+ * computed by marching a finished path a second time, and only for waves in which a lane reached the
+ * light's lobe.  out = {executed events (= lf_get_executed_events), events of those second marches
+ * counted for the lanes that needed them (= events that ever had a Fresnel factor evaluated), rows of
+ * those second marches (each row is one event for all 64 lanes of a wave), 0}.  The second marches are
+ * NOT part of `executed events`. */
+lf_status lf_get_march_stats(lf_ctx* ctx, uint64_t out[4]);
 
 /* ---------------------------------------------------------------- measurement ------------ */
 /* HIP-event timing of the kernels launched since the last reset, on the context's stream.

@@ -196,13 +196,13 @@ lf_status lf_create(lf_ctx** out, int device) {
             hipMalloc((void**)&ctx->pl_dev, sizeof(LfParaxialLens)) == hipSuccess &&
             hipMalloc((void**)&ctx->lens_dev, sizeof(LfLensDev)) == hipSuccess &&
             hipMalloc((void**)&ctx->pairs_dev, sizeof(LfPairsDev)) == hipSuccess &&
-            hipMalloc((void**)&ctx->counters_dev, 8 * sizeof(unsigned long long)) == hipSuccess;
+            hipMalloc((void**)&ctx->counters_dev, kMarchCounterSlots * sizeof(unsigned long long)) == hipSuccess;
   for (int s = 0; s < 2 && ok; s++)
     ok = hipMalloc((void**)&ctx->ap[s].stats, sizeof(lf_aperture_stats)) == hipSuccess;
   if (!ok) { lf_destroy(ctx); return LF_ERR_OOM; }
   (void)hipMemset(ctx->flares, 0, sizeof(LfFlares));
   (void)hipMemset(ctx->ghosts, 0, sizeof(LfGhostList));
-  (void)hipMemset(ctx->counters_dev, 0, 8 * sizeof(unsigned long long));
+  (void)hipMemset(ctx->counters_dev, 0, kMarchCounterSlots * sizeof(unsigned long long));
   if (upload_paraxial(ctx) != LF_OK) { lf_destroy(ctx); return LF_ERR_HIP; }
   *out = ctx;
   return LF_OK;
@@ -223,7 +223,7 @@ lf_status lf_destroy(lf_ctx* ctx) {
   }
   void* ptrs[] = {ctx->spectrum, ctx->twiddle, ctx->dft_rows, ctx->flares, ctx->ghosts, ctx->pl_dev,
                   ctx->lens_dev, ctx->pairs_dev, ctx->counters_dev, ctx->accum,
-                  ctx->prog_dev, ctx->sun_lights_dev,
+                  ctx->prog_dev, ctx->sun_lights_dev, ctx->march_scratch,
                   ctx->scene_dev.nodes, ctx->scene_dev.prims, ctx->scene_dev.materials,
                   ctx->scene_dev.lights, ctx->env_block};
   for (void* p : ptrs) if (p) (void)hipFree(p);
@@ -1142,9 +1142,23 @@ lf_status lf_get_executed_events(lf_ctx* ctx, uint64_t* out) {
   return LF_OK;
 }
 
+lf_status lf_get_march_stats(lf_ctx* ctx, uint64_t out[4]) {
+  if (!ctx || !out) return LF_ERR_INVALID;
+  unsigned long long c[kMarchCounterSlots];
+  LF_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  LF_HIP(ctx, hipMemcpy(c, ctx->counters_dev, sizeof(c), hipMemcpyDeviceToHost));
+  out[0] = c[7]; out[1] = c[8]; out[2] = c[9]; out[3] = 0;
+  if (std::getenv("LF_MARCH_PRINT_HIST")) {   // instrumented builds only (LF_MARCH_LIVE_HIST): the slots stay 0 otherwise
+    std::fprintf(stderr, "LIVE_HIST");
+    for (int b = 0; b < 9; b++) std::fprintf(stderr, " %llu", c[kMarchCounters + b]);
+    std::fprintf(stderr, "\n");
+  }
+  return LF_OK;
+}
+
 lf_status lf_reset_counters(lf_ctx* ctx) {
   if (!ctx) return LF_ERR_INVALID;
-  LF_HIP(ctx, hipMemsetAsync(ctx->counters_dev, 0, 8 * sizeof(unsigned long long), ctx->stream));
+  LF_HIP(ctx, hipMemsetAsync(ctx->counters_dev, 0, kMarchCounterSlots * sizeof(unsigned long long), ctx->stream));
   return LF_OK;
 }
 

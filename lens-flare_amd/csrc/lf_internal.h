@@ -11,6 +11,9 @@
 #include "lensflare.h"
 
 // ---- limits -------------------------------------------------------------------------------
+// k_march's counters: the seven of lf_counters, executed events, re-march lane events, re-march rows
+constexpr int kMarchCounters = 10;
+constexpr int kMarchCounterSlots = 32;   // allocated (instrumented experiment builds append a histogram)
 constexpr int kMaxParaxialGhosts = 3 * 105;          // 3 colours x C(15,2) pairs
 constexpr int kMaxGhostTris = 2 * kMaxParaxialGhosts; // two triangles per quad
 
@@ -261,8 +264,10 @@ struct lf_ctx {
   LfLensDev* lens_dev = nullptr;
   LfPairsDev pairs{};
   LfPairsDev* pairs_dev = nullptr;
-  unsigned long long* counters_dev = nullptr;  // 8 x u64
+  unsigned long long* counters_dev = nullptr;  // kMarchCounterSlots x u64
   unsigned long long* accum = nullptr;         // W*H_alloc*3 fixed-point partial sums (split launches)
+  float* march_scratch = nullptr;              // per-wave slices for the samples' start states (k_march)
+  size_t march_scratch_cap = 0;                // bytes
   unsigned char* prog_dev = nullptr;           // the packed program: headers, then records (lf_march.hip pack_program)
   size_t prog_cap = 0, prog_rec_off = 0, prog_seq_off = 0;   // bytes; offsets of the records / the pair sequences
   int march_k = 1;                             // wavelengths (rays per lane) that walk together

@@ -289,34 +289,51 @@ __device__ __forceinline__ LfProgHdr load_phdr(const LfProgHdr* __restrict__ bas
 // instructions per bench frame on ONE scalar unit per CU (85 % busy) against 9.5e10 vector
 // instructions on four SIMDs (53 %); profiles/r02_*.  Each ray keeps its own liveness mask, tallies
 // are per ray, so pixels and counters are exactly those of K separate walks.
-// (second launch bound = waves per SIMD the register allocation must leave room for; the LDS
-// footprint allows at least as many workgroups of 4 waves per CU: 8 / 6 / 6 for K = 1 .. 3)
+// (second launch bound = waves per SIMD the register allocation must leave room for.  The LDS
+// footprint -- 20 KB for K = 3 -- would admit 8 workgroups of 4 waves per CU; the registers admit 6
+// waves per SIMD: 73 of them.  Capped at 72 for a 7th wave the allocator adds 4 % of vector
+// instructions and the frame takes 123 instead of 117 ms; occupancy sweep 3 .. 7 waves per SIMD:
+// 155, 133, 122, 117, 123 ms, profiles/r03_march_variants.txt)
 template <int K>
 __global__ __launch_bounds__(256, (K == 1 ? 8 : 6))
 void k_march(const LfLensDev* __restrict__ lens, const LfPairsDev* __restrict__ pairs,
              const int* __restrict__ seq_table, const LfProgHdr* __restrict__ hdr_table,
              const LfProgRow* __restrict__ rec_table, const float* __restrict__ mask, MarchArgs a,
              double* __restrict__ ghost, unsigned long long* __restrict__ accum,
-             unsigned long long* __restrict__ counters) {
+             unsigned long long* __restrict__ counters, float* __restrict__ start_scratch) {
   __shared__ unsigned long long s_acc[64 * 3];
-  __shared__ unsigned long long s_cnt[8];
+  __shared__ unsigned long long s_cnt[kMarchCounters];
   __shared__ int s_next;
+#ifdef LF_MARCH_LIVE_HIST
+  // instrumented build (profiles/r03_march_variants.txt), never shipped: executed wave-ray events by
+  // the number of live lanes, bucket = lanes / 8 (8 = all 64)
+  __shared__ unsigned long long s_hist[9];
+  if (threadIdx.x < 9) s_hist[threadIdx.x] = 0ull;
+#define LF_HIST(mask) do { if ((mask) != 0ull && lane_id() == 0) atomicAdd(&s_hist[__popcll(mask) >> 3], 1ull); } while (0)
+#else
+#define LF_HIST(mask) do { } while (0)
+#endif
   // parked ray states: [wave][slot][ray][px py|pz dx|dy dz][lane]
   // fork slot 1 (the reflection at j, parked and restored once per pair) is parked here; slot 0 (the
   // reflection at i, once per sub-tree: 3-4x rarer, so its register copies are cheap) lives in
   // registers: with both in LDS a K = 3 workgroup needs 38 KB and only 4 waves fit a SIMD
   // (measured 147 -> 137 ms per bench frame)
   __shared__ float2 s_state[4][K][3 * 64];
-  // the start of the current sample's rays per lane (sensor point, direction, start weight): only
-  // the rare weight re-march reads it back, so it need not occupy six registers during the walk
+  // The start of the current sample's rays per lane (sensor point, direction, start weight) is read
+  // back only by the head of each wavelength group and by the rare weight re-march (~2x per sample), so
+  // it must not occupy six registers during the walk.  It lives in a per-wave slice of a global scratch
+  // buffer: a slice is rewritten once per sample while its workgroup lives and stays in the XCD's L2
+  // (HBM sees each slice once, when it is evicted).  Rounds 1-2 kept it in LDS: 6 KB per workgroup more,
+  // and 1.2 % slower (profiles/r03_march_variants.txt; recomputing it instead costs two Philox draws +
+  // the pupil map ~2.4x per sample: +7 %).
+  float* const s_start_g = start_scratch + ((size_t)blockIdx.x * 4u + (size_t)(threadIdx.x >> 6)) * (6u * 64u);
+#define LF_START(k, l) s_start_g[(k) * 64 + (l)]
   // (read back through a lane index the compiler cannot see through -- launder() -- or it forwards the
-  // stores to the loads and keeps the registers; `volatile` would do too, but turns the accesses into
-  // serialised FLAT instructions)
-  __shared__ float s_start[4][6][64];
+  // stores to the loads and keeps the registers)
   auto launder = [](int v) { asm volatile("" : "+v"(v)); return v; };
   const int tid = threadIdx.x;
   if (tid < 64 * 3) s_acc[tid] = 0ull;
-  if (tid < 8) s_cnt[tid] = 0ull;
+  if (tid < kMarchCounters) s_cnt[tid] = 0ull;
   if (tid == 0) s_next = 0;
   __syncthreads();
 
@@ -359,6 +376,7 @@ void k_march(const LfLensDev* __restrict__ lens, const LfPairsDev* __restrict__ 
   unsigned n_samples = 0;   // per wave
   // wave-uniform, counted once per wave with s_bcnt1 (SALU)
   unsigned long long events = 0, n_clip = 0, n_vign = 0, n_tir = 0, n_scene = 0, n_exec = 0;
+  unsigned long long n_rm_lane = 0, n_rm_rows = 0;   // the weight re-march (diagnostics, lf_get_march_stats)
 
   {
     // The 4 waves of the workgroup pull sample indices from one LDS counter instead of owning
@@ -413,8 +431,8 @@ void k_march(const LfLensDev* __restrict__ lens, const LfPairsDev* __restrict__ 
       const float d0x = vx * rl, d0y = vy * rl, d0z = vz * rl;
       const float c2 = d0z * d0z;
       const float w0 = geom_norm * (c2 * c2);
-      s_start[wave][0][lane] = X; s_start[wave][1][lane] = Y; s_start[wave][2][lane] = d0x;
-      s_start[wave][3][lane] = d0y; s_start[wave][4][lane] = d0z; s_start[wave][5][lane] = w0;
+      LF_START(0, lane) = X; LF_START(1, lane) = Y; LF_START(2, lane) = d0x;
+      LF_START(3, lane) = d0y; LF_START(4, lane) = d0z; LF_START(5, lane) = w0;
       n_samples++;
       // wave-uniform 32-bit tallies of this sample (64 lanes x pairs x wavelengths x rows < 2^32)
       unsigned ev32 = 0, clip32 = 0, vign32 = 0, tir32 = 0, scene32 = 0, exec32 = 0;
@@ -432,8 +450,8 @@ void k_march(const LfLensDev* __restrict__ lens, const LfPairsDev* __restrict__ 
         for (int j = 0; j < K; j++) {
           // (read back from LDS rather than kept in registers across the groups of the sample)
           const int lo = launder(lane);
-          r[j] = Ray{s_start[wave][0][lo], s_start[wave][1][lo], 0.0f, 0.0f, s_start[wave][2][lo],
-                     s_start[wave][3][lo], s_start[wave][4][lo], 0.0f, 0.0f};
+          r[j] = Ray{LF_START(0, lo), LF_START(1, lo), 0.0f, 0.0f, LF_START(2, lo),
+                     LF_START(3, lo), LF_START(4, lo), 0.0f, 0.0f};
           r[j].r2 = fmaf(r[j].px, r[j].px, r[j].py * r[j].py);
           alive[j] = (g * K + j < n_lambda) ? active_mask : 0ull;  // a short last group: dead rays
           alive0[j] = 0ull; alive1[j] = 0ull;
@@ -508,6 +526,7 @@ void k_march(const LfLensDev* __restrict__ lens, const LfPairsDev* __restrict__ 
               for (int j = 0; j < K; j++) {
                 if (K > 1 && __builtin_expect(alive[j] == 0ull, 0)) { okv[j] = 0ull; continue; }
                 lanemask geom_ok;
+                LF_HIST(alive[j]);
                 okv[j] = surface_event<false>(r[j], cur.dzv, cur.curv, cur.ch, cur.c2, cur.radius, cur.h2, cur.eta[j],
                                               cur.eta2[j], true, false, cur.sgn, geom_ok);
                 died |= alive[j] & ~okv[j];
@@ -538,6 +557,7 @@ void k_march(const LfLensDev* __restrict__ lens, const LfPairsDev* __restrict__ 
                   // a wavelength whose rays are all gone is not computed (one scalar branch; without
                   // it its lanes would keep marching garbage through every row the others still visit)
                   if (K > 1 && __builtin_expect(alive[j] == 0ull, 0)) { okv[j] = 0ull; gv[j] = 0ull; continue; }
+                  LF_HIST(alive[j]);
                   okv[j] = surface_event<false>(r[j], cur.dzv, cur.curv, cur.ch, cur.c2, cur.radius, cur.h2, cur.eta[j],
                                                 cur.eta2[j], false, false, cur.sgn, gv[j]);
                   died |= alive[j] & ~okv[j];
@@ -567,6 +587,7 @@ void k_march(const LfLensDev* __restrict__ lens, const LfPairsDev* __restrict__ 
 #pragma unroll
             for (int j = 0; j < K; j++) {
               if (K > 1 && __builtin_expect(alive[j] == 0ull, 0)) { okv[j] = 0ull; continue; }
+              LF_HIST(alive[j]);
               okv[j] = stop_event<false>(r[j], cur.dzv, cur.h2, inv_stop_h, mask, a.mw, a.mh);
               died |= alive[j] & ~okv[j];
             }
@@ -594,6 +615,7 @@ void k_march(const LfLensDev* __restrict__ lens, const LfPairsDev* __restrict__ 
 #pragma unroll
             for (int j = 0; j < K; j++) {
               if (K > 1 && __builtin_expect(alive[j] == 0ull, 0)) { okv[j] = 0ull; gv[j] = 0ull; continue; }
+              LF_HIST(alive[j]);
               okv[j] = surface_event<false>(r[j], cur.dzv, cur.curv, cur.ch, cur.c2, cur.radius, cur.h2, cur.eta[j],
                                             cur.eta2[j], (fl & LF_EV_REFLECT) != 0,
                                             (fl & LF_EV_FLAT) != 0, cur.sgn, gv[j]);
@@ -652,9 +674,12 @@ void k_march(const LfLensDev* __restrict__ lens, const LfPairsDev* __restrict__ 
                 // from the same resident records the walk uses
                 const int* __restrict__ w = seq_table + pairs->ev_off[q];
                 const int lo = launder(lane);
-                Ray rw{s_start[wave][0][lo], s_start[wave][1][lo], 0.0f, 0.0f, s_start[wave][2][lo],
-                       s_start[wave][3][lo], s_start[wave][4][lo], s_start[wave][5][lo], 1.0f};
+                Ray rw{LF_START(0, lo), LF_START(1, lo), 0.0f, 0.0f, LF_START(2, lo),
+                       LF_START(3, lo), LF_START(4, lo), LF_START(5, lo), 1.0f};
                 rw.r2 = fmaf(rw.px, rw.px, rw.py * rw.py);
+                // events computed a second time, with the weight: for the lit lanes / as wave-wide rows
+                n_rm_lane += (unsigned long long)((unsigned)pairs->ev_cnt[q] * (unsigned)__popcll(lj));
+                n_rm_rows += (unsigned)pairs->ev_cnt[q];
                 for (int left = pairs->ev_cnt[q]; left > 0; --left, ++w) {
                   const unsigned se = (unsigned)*(const int __attribute__((address_space(4)))*)(w);
                   const LfProgRow wr = load_prec(recs, se & 0xffffu);
@@ -706,15 +731,19 @@ void k_march(const LfLensDev* __restrict__ lens, const LfPairsDev* __restrict__ 
     unsigned long long v0 = active ? (unsigned long long)n_samples * (unsigned)(n_lambda * n_pairs) : 0ull;
     unsigned long long v6 = n_light;
     for (int off = 32; off > 0; off >>= 1) { v0 += __shfl_down(v0, off); v6 += __shfl_down(v6, off); }
-    const unsigned long long vals[8] = {v0, events, n_clip, n_vign, n_tir, n_scene, v6, n_exec};
+    const unsigned long long vals[kMarchCounters] = {v0, events, n_clip, n_vign, n_tir, n_scene, v6, n_exec,
+                                                     n_rm_lane, n_rm_rows};
     if (lane == 0) {
 #pragma unroll
-      for (int i = 0; i < 8; i++)
+      for (int i = 0; i < kMarchCounters; i++)
         if (vals[i]) atomicAdd(&s_cnt[i], vals[i]);
     }
   }
   __syncthreads();
-  if (wave == 0 && lane < 8 && s_cnt[lane]) atomicAdd(&counters[lane], s_cnt[lane]);
+  if (wave == 0 && lane < kMarchCounters && s_cnt[lane]) atomicAdd(&counters[lane], s_cnt[lane]);
+#ifdef LF_MARCH_LIVE_HIST
+  if (wave == 0 && lane < 9 && s_hist[lane]) atomicAdd(&counters[kMarchCounters + lane], s_hist[lane]);
+#endif
 
   // ---- the tile's pixels: 8 rows of 8 x 24 contiguous bytes -----------------------------------
   if (wave == 0 && active) {
@@ -1216,13 +1245,28 @@ lf_status lfk_march(lf_ctx* ctx, int spp, uint64_t key) {
                                (size_t)(ctx->y1 - ctx->y0) * ctx->W * 3 * sizeof(unsigned long long),
                                ctx->stream));
   }
+  {
+    // per-wave slices for the samples' start states (k_march): 6 x 64 floats per wave
+    const size_t need = blocks * 4 * 6 * 64 * sizeof(float);
+    if (need > ctx->march_scratch_cap) {
+      LF_HIP(ctx, hipStreamSynchronize(ctx->stream));
+      if (ctx->march_scratch) (void)hipFree(ctx->march_scratch);
+      ctx->march_scratch = nullptr; ctx->march_scratch_cap = 0;
+      LF_HIP(ctx, hipMalloc((void**)&ctx->march_scratch, need));
+      ctx->march_scratch_cap = need;
+    }
+  }
+  // experiments only: unused dynamic LDS caps the workgroups a CU holds (occupancy sweeps,
+  // profiles/r03_march_variants.txt)
+  size_t dyn_lds = 0;
+  if (const char* dl = std::getenv("LF_MARCH_DYN_LDS")) dyn_lds = (size_t)std::max(0, std::atoi(dl));
   hipEvent_t ev = lf_timing_begin(ctx, LFK_MARCH);
 #define LF_LAUNCH_MARCH(KK)                                                                        \
-  hipLaunchKernelGGL(k_march<KK>, dim3((unsigned)blocks), dim3(256), 0, ctx->stream, ctx->lens_dev, \
+  hipLaunchKernelGGL(k_march<KK>, dim3((unsigned)blocks), dim3(256), dyn_lds, ctx->stream, ctx->lens_dev, \
                      ctx->pairs_dev, (const int*)(ctx->prog_dev + ctx->prog_seq_off),                \
                      (const LfProgHdr*)ctx->prog_dev,                                               \
                      (const LfProgRow*)(ctx->prog_dev + ctx->prog_rec_off), m.texels, a,            \
-                     ctx->ghost, ctx->accum, ctx->counters_dev)
+                     ctx->ghost, ctx->accum, ctx->counters_dev, ctx->march_scratch)
   switch (ctx->march_k) {
     case 1: LF_LAUNCH_MARCH(1); break;
     case 2: LF_LAUNCH_MARCH(2); break;

@@ -62,3 +62,43 @@ def gather_frame(frame, W, H, rank, world, dist, elems_per_pixel=3, scratch=None
     send.copy_(v[:, rank, :])
     dist.all_gather_into_tensor(recv.view(-1), send.view(-1))
     v.copy_(recv.permute(1, 0, 2))
+
+
+# ---- bringing up the data-path communicator without ever hanging --------------------------------
+# One process per GPU: a rank that fails LOCALLY (library missing, bad argument, a launch error) while
+# its peers are inside a blocking collective leaves them there for good.  Two rules avoid that:
+# (1) nothing blocking is called before every rank has said, over the control plane (gloo), that it is
+# able to; (2) the first collective on a new communicator is waited for with a deadline, and the
+# verdict is again taken together.  bench.py follows both; tests/test_sharding_gloo.py injects a
+# one-rank failure into each.
+def agree(dist, ok, why=""):
+    """Every rank passes its own verdict; returns (all ok?, reasons of the ranks that were not).
+    Control-plane collective (gloo): every rank MUST reach it -- callers catch their local errors and
+    pass ok=False instead of raising."""
+    verdicts = [None] * dist.get_world_size()
+    dist.all_gather_object(verdicts, (bool(ok), str(why)))
+    bad = [f"rank {r}: {w or 'failed'}" for r, (k, w) in enumerate(verdicts) if not k]
+    return not bad, bad
+
+
+def first_exchange(dist, enqueue, test, timeout_s=120.0, poll_s=0.01, clock=None, sleep=None):
+    """Run the first exchange of a fresh communicator so that NO rank can hang: `enqueue()` queues it
+    (non-blocking; may raise), `test()` says whether it has completed on the device (non-blocking).
+    A rank whose peers never joined sees `test()` stay False and gives up after timeout_s.  Returns
+    (all ranks completed?, reasons); on False every rank must abort its communicator (lf_comm_abort)
+    before using its streams again."""
+    import time
+    clock = clock or time.monotonic
+    sleep = sleep or time.sleep
+    ok, why = True, ""
+    try:
+        enqueue()
+        t0 = clock()
+        while not test():
+            if clock() - t0 > timeout_s:
+                ok, why = False, f"the first exchange did not complete within {timeout_s:g} s"
+                break
+            sleep(poll_s)
+    except Exception as e:  # noqa: BLE001 -- the verdict must reach agree() whatever went wrong
+        ok, why = False, f"{type(e).__name__}: {e}"
+    return agree(dist, ok, why)

@@ -1,12 +1,13 @@
 #!/usr/bin/env python3
 """Install a summary produced by profiles/run_pmc_r02.sh as the profile bench.py prices its roofline
-with:  python3 profiles/install_pmc.py gpurun_out/pmc_<tag>/summary.json [config]"""
+with:  python3 profiles/install_pmc.py gpurun_out/pmc_<tag>/summary.json [config] [round, default r03]"""
 import json
 import os
 import sys
 
 root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-dst = os.path.join(root, "profiles", "r02_march_pmc.json")
+rnd = sys.argv[3] if len(sys.argv) > 3 else "r03"
+dst = os.path.join(root, "profiles", f"{rnd}_march_pmc.json")
 s = json.load(open(sys.argv[1]))
 cfg = sys.argv[2] if len(sys.argv) > 2 else s.get("config", "c3")
 allp = json.load(open(dst)) if os.path.exists(dst) else {}

@@ -90,3 +90,60 @@ def test_sharding_helpers():
         assert sorted(sum(rows, [])) == list(range(135))
         assert max(map(len, rows)) - min(map(len, rows)) <= 1
         assert sharding.padded_rows(1080, world) <= 1088  # fits the library's 64-row padding
+
+
+# ---- a rank that fails alone must not leave its peers hanging ----------------------------------------
+def _bringup_worker(rank, world, port, out_dir, fail_rank, stage):
+    import torch.distributed as dist
+    sys.path.insert(0, ROOT)
+    import __graft_entry__ as g
+    g.load_package()
+    from lens_flare_amd import sharding
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    log = []
+    # stage "preflight": rank `fail_rank` cannot load the communication library
+    ok, bad = sharding.agree(dist, not (stage == "preflight" and rank == fail_rank), "librccl.so.1 not found")
+    log.append(("preflight", ok, bad))
+    if ok:
+        # stage "exchange": rank `fail_rank` raises when it enqueues; the others' collective can then
+        # never complete (their test() stays False) -- they must give up at the deadline, not block
+        state = {"enqueued": False}
+
+        def enqueue():
+            if stage == "exchange" and rank == fail_rank:
+                raise RuntimeError("LF_ERR_HIP: injected launch failure")
+            state["enqueued"] = True
+
+        def test():
+            return stage != "exchange"     # completes at once unless a peer is missing
+
+        ok, bad = sharding.first_exchange(dist, enqueue, test, timeout_s=0.3, poll_s=0.01)
+        log.append(("exchange", ok, bad))
+    import json
+    json.dump(log, open(os.path.join(out_dir, f"log_{rank}.json"), "w"))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("stage", ["none", "preflight", "exchange"])
+def test_one_rank_failing_alone_is_noticed_by_all(stage, tmp_path):
+    """bench.py's bring-up of the C ABI's RCCL communicator (lens_flare_amd.sharding.agree /
+    first_exchange): whatever a single rank's local failure, every rank returns, with the same verdict
+    and the failing rank's reason."""
+    import json
+    import torch.multiprocessing as mp
+    world, fail_rank = 3, 1
+    mp.spawn(_bringup_worker, args=(world, _free_port(), str(tmp_path), fail_rank, stage), nprocs=world, join=True)
+    logs = [json.load(open(tmp_path / f"log_{r}.json")) for r in range(world)]
+    assert all(l == logs[0] for l in logs)                      # one verdict
+    if stage == "none":
+        assert [x[:2] for x in logs[0]] == [["preflight", True], ["exchange", True]]
+    elif stage == "preflight":
+        assert logs[0] == [["preflight", False, ["rank 1: librccl.so.1 not found"]]]   # no exchange was attempted
+    else:
+        name, ok, bad = logs[0][1]
+        assert name == "exchange" and not ok and len(bad) == world
+        assert "rank 1: RuntimeError: LF_ERR_HIP: injected launch failure" in bad
+        assert all("did not complete within" in b for b in bad if not b.startswith("rank 1"))
