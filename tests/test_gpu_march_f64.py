@@ -160,3 +160,68 @@ def test_pupil_subcells_converge_to_the_independent_estimate(pkg, lf):
     img0, _ = _gpu_frame(pkg, lf, lens, W, H, spp, keys[0], mask, sun, rad, alpha, sub_bits=0)
     litp = ref >= FLOOR
     assert np.all(np.abs(img0 - ref)[litp] <= TOL * ref[litp] + 1.05 * frag[litp])
+
+
+# ---- the independent check at BENCH size ----------------------------------------------------------------
+SUN_NS = (0.521445, 0.517156)
+
+
+def _band_against_f64(pkg, lf, lens, W, H, y0, y1, spp, key, mask, lambda_rgb=None, min_lit=200):
+    import os
+    efl = pkg.paraxial_efl(lens)
+    sun = [(SUN_NS[0] - 0.5) * lens["sensor_width_mm"] / efl, (SUN_NS[1] - 0.5) * lens["sensor_width_mm"] * H / W / efl, -1.0]
+    rad, alpha = [1.0, 0.9, 0.5], 0.05
+    lf.set_frame(W, H)
+    lf.set_aperture(pkg.APERTURE_STARBURST, mask)
+    lf.set_lens(lens)
+    if lambda_rgb is not None:
+        lf.set_lambda_rgb(lambda_rgb)
+    lf.set_sun(sun, rad, alpha)
+    lf.set_ghost_pairs(None, True)
+    lf.set_band(y0, y1)                 # the band alone: its own ray budget and counters
+    lf.reset_counters()
+    lf.trace_ghosts(spp, key)
+    img = lf.read_tile(pkg.GHOST_BUFFER, 0, y0, W, y1)
+    cnt = lf.counters()
+    lf.set_band(0, H)
+    ref, frag, c64 = lfo.g64_trace(lens, W, H, y0, y1, spp, key, None, True, mask, sun, rad, alpha,
+                                   n_threads=min(64, os.cpu_count() or 8), lambda_rgb=lambda_rgb)
+    ref, frag = ref[y0:y1], frag[y0:y1]
+    rel = _check_against_f64(img, cnt, ref, frag, c64, min_lit=min_lit)
+    lit = ref >= FLOOR
+    needed = (np.abs(img - ref)[lit] > TOL * ref[lit]).sum()
+    return rel, needed, c64
+
+
+def test_c3_band_at_full_spp_against_the_independent_tracer(pkg, lf):
+    """The benchmark frame itself -- 1920x1080, 256 spp, primary + 45 pairs x 3 wavelengths -- on the
+    8-row tile row through the sun (5e8 rays): every pixel within 1e-4 of the float64 tracer up to the
+    fragile rays' weight, ray fates equal up to the number of fragile rays."""
+    lens = pkg.load_lens_file("dgauss11.lens")
+    mask = load_texels("pentbig500_14.png")
+    W, H, spp, key = 1920, 1080, 256, 0x1e45f1a4e
+    y0 = (int(SUN_NS[1] * H) // 8) * 8
+    rel, needed, c64 = _band_against_f64(pkg, lf, lens, W, H, y0, y0 + 8, spp, key, mask, min_lit=2000)
+    print(f"c3 band rows {y0}..{y0 + 8}: {rel.size} lit channel values, max rel {rel.max():.2e}, median "
+          f"{np.median(rel):.2e}; the fragile-ray allowance was needed by {needed} of them "
+          f"({c64['rays_fragile']} fragile rays of {c64['rays_launched']})")
+
+
+def test_c5_band_of_the_4k_frame_against_the_independent_tracer(pkg, lf):
+    """C5's frame size and its 8 wavelengths, a 16-row band through the sun at 64 of the 1024 spp
+    (both sides evaluate the same samples, so the sample count only sets the coverage: 1.4e9 rays)."""
+    lens3 = pkg.load_lens_file("dgauss11.lens")
+    t = np.linspace(0.0, 2.0, 8)
+    ior8 = np.stack([np.array([np.interp(tt, [0, 1, 2], lens3["ior"][:, k]) for k in range(lens3["n"])])
+                     for tt in t]).astype(np.float32)
+    lens8 = dict(lens3, ior=ior8)
+    w8 = np.zeros((8, 3), np.float32)
+    for l, tt in enumerate(t):
+        for c in range(3):
+            w8[l, c] = max(0.0, 1.0 - abs(tt - c)) / 2.6666667
+    mask = load_texels("pentbig500_14.png")
+    W, H, spp, key = 3840, 2160, 64, 0xC5C5
+    y0 = (int(SUN_NS[1] * H) // 8) * 8 - 8
+    rel, needed, c64 = _band_against_f64(pkg, lf, lens8, W, H, y0, y0 + 16, spp, key, mask, lambda_rgb=w8, min_lit=2000)
+    print(f"c5 band rows {y0}..{y0 + 16}: {rel.size} lit channel values, max rel {rel.max():.2e}; allowance "
+          f"needed by {needed}")
