@@ -438,6 +438,21 @@ def main():
 
     cnt = lf.counters()
     stats = lf.march_stats()
+    # opt-in sampling specifications, timed beside the default (N = 1 only, outside the timed region; what
+    # they cost in image quality is in profiles/r03_sampling_efficiency.json)
+    sampling_variants = None
+    if world == 1 and not cfg["scene"]:
+        sampling_variants = {}
+        for bits in (4, 0):
+            lf.set_pupil_subcells(bits)
+            one_frame()
+            lf.synchronize()
+            t_v = time.perf_counter()
+            for _ in range(2):
+                one_frame()
+            lf.synchronize()
+            sampling_variants[f"pupil_subcells_{1 << bits}x{1 << bits}"] = {"ms_per_step": (time.perf_counter() - t_v) / 2 * 1e3}
+        lf.set_pupil_subcells(2)
     n_launch, march_ms = lf.timing_get("march")
     n_xchg, xchg_ms = lf.timing_get("exchange") if gather_mode == "cabi" else (args.steps, host_exchange[0] * 1e3)
     n_scene, scene_ms = lf.timing_get("scene_term")
@@ -560,6 +575,11 @@ def main():
             "fates": {k[5:]: (fate_tot[k] / fate_tot["rays_launched"] if fate_tot["rays_launched"] else None)
                       for k in fate_keys[1:]},
             "events_per_ray": {"executed": executed / rays if rays else None, "logical": logical / rays if rays else None},
+            # `value` is measured with the default sampling specification (4x4 pupil sub-cells per tile and
+            # sample: pixels, counters and goldens of rounds 1-2 hold).  More coherence is faster at the
+            # same per-pixel variance but correlates the noise inside an 8x8 tile further, none is slower
+            # with independent pixels: profiles/r03_sampling_efficiency.json has the quality side.
+            "sampling_variants": sampling_variants,
             # ---- multi-GPU diagnostics (every rank's own numbers; ms per frame) -----------------------
             "rccl_nranks": max(r["rccl_nranks"] for r in per_rank),
             "march_ms": {"min": min(r["march_ms"] for r in per_rank), "max": max(r["march_ms"] for r in per_rank)},

@@ -398,6 +398,26 @@ lf_status lf_set_ghost_pairs(lf_ctx* ctx, const int* pairs, int n_pairs, int inc
  * mask).  bits = 0 draws every pixel's pupil point independently inside its stratum; every value
  * is an unbiased estimator of the same image (tests/test_gpu_march_f64.py).  Default 2; 0..8. */
 lf_status lf_set_pupil_subcells(lf_ctx* ctx, int bits);
+/* Part of the sampling specification (no reference counterpart): the disc every sensor sample aims its
+ * pupil point at -- radius and axial position z in the prescription's coordinates (z = 0 at the first
+ * vertex, growing towards the sensor).  Default (radius <= 0): the rear element's clear aperture at its
+ * vertex plane, which is valid for EVERY path but wastes the samples that miss the exit pupil.  A
+ * smaller disc is an unbiased estimator only for paths whose first crossing of the stop precedes their
+ * first reflection (the primary path and the pairs (i, j) with i in front of the stop): the start
+ * weight is the disc's solid angle, so nothing else changes.  Pairs with both mirrors behind the stop
+ * must keep the default.  lf_aim_at_exit_pupil sets the disc to the paraxial image of the stop's open
+ * part (the circle around the mask's non-zero texels) through the rear group, times `margin` (> 1
+ * leaves room for pupil aberration off the axis).  lf_paraxial_exit_pupil: that image for a
+ * prescription and one wavelength (host arithmetic with the reference's T / R operators,
+ * pathtracer.cpp:527-533): its z and its lateral magnification. */
+lf_status lf_set_pupil_target(lf_ctx* ctx, float radius_mm, float z_mm);
+lf_status lf_get_pupil_target(lf_ctx* ctx, float* radius_mm, float* z_mm, float* z_sensor_mm);
+lf_status lf_aim_at_exit_pupil(lf_ctx* ctx, float margin);
+lf_status lf_paraxial_exit_pupil(int n_surfaces, int stop_index, const float* radius, const float* thickness,
+                                 const float* ior_row, double* z_mm, double* magnification);
+/* on: lf_trace_ghosts ADDS its pixels to ghost_buffer instead of replacing them (a frame composed of
+ * launches with different pair sets / pupil targets).  Default off. */
+lf_status lf_set_ghost_accumulate(lf_ctx* ctx, int on);
 /* march `spp` sensor samples per pixel of the band through every selected pair and wavelength and
  * accumulate into ghost_buffer (replacing its content).  key seeds the counter RNG. */
 lf_status lf_trace_ghosts(lf_ctx* ctx, int spp, uint64_t key);

@@ -38,12 +38,29 @@ ABI_SYMBOLS = [
     "lf_clear_ghost_buffer", "lf_draw_ghost", "lf_rasterize_textured_triangle", "lf_fill_textured_pixel",
     "lf_shift_vertex", "lf_compute_phase", "lf_irradiance_falloff", "lf_scene_trace_ray", "lf_scene_shade",
     "lf_load_lens_file", "lf_get_lens_info",
+    "lf_set_pupil_target", "lf_get_pupil_target", "lf_aim_at_exit_pupil", "lf_paraxial_exit_pupil", "lf_set_ghost_accumulate",
     "lf_comm_get_unique_id", "lf_comm_init_rank", "lf_comm_gather", "lf_comm_gather_async", "lf_comm_wait",
     "lf_comm_destroy", "lf_comm_available", "lf_comm_info", "lf_comm_test", "lf_comm_abort",
     "lf_comm_set_exchange_precision",
     "lf_group_create", "lf_group_destroy", "lf_group_size", "lf_group_ctx", "lf_group_last_error",
     "lf_group_set_frame", "lf_group_for_each", "lf_group_gather",
 ]
+
+
+def paraxial_exit_pupil(lens, lam=None):
+    """(z_mm, magnification) of the paraxial image of the stop through the rear group (host arithmetic)."""
+    lib = load_library()
+    ior = np.ascontiguousarray(lens["ior"], np.float32)
+    lam = ior.shape[0] // 2 if lam is None else lam
+    r = np.ascontiguousarray(lens["radius"], np.float32)
+    t = np.ascontiguousarray(lens["thickness"], np.float32)
+    row = np.ascontiguousarray(ior[lam], np.float32)
+    z, m = C.c_double(), C.c_double()
+    st = lib.lf_paraxial_exit_pupil(int(lens["n"]), int(lens["stop"]), _fp(r, C.c_float), _fp(t, C.c_float),
+                                    _fp(row, C.c_float), C.byref(z), C.byref(m))
+    if st != 0:
+        raise LensFlareError(st, "lf_paraxial_exit_pupil")
+    return z.value, m.value
 
 
 class LensFlareError(RuntimeError):
@@ -564,6 +581,21 @@ class LensFlare:
         if not os.path.isabs(path) and not os.path.exists(path):
             path = os.path.join(DATA, path)
         self._ck(self.lib.lf_load_lens_file(self.ctx, path.encode()))
+
+    def set_pupil_target(self, radius_mm=0.0, z_mm=0.0):
+        self._ck(self.lib.lf_set_pupil_target(self.ctx, C.c_float(radius_mm), C.c_float(z_mm)))
+
+    def pupil_target(self):
+        r, z, zs = C.c_float(), C.c_float(), C.c_float()
+        self._ck(self.lib.lf_get_pupil_target(self.ctx, C.byref(r), C.byref(z), C.byref(zs)))
+        return dict(radius_mm=r.value, z_mm=z.value, z_sensor_mm=zs.value)
+
+    def aim_at_exit_pupil(self, margin=1.0):
+        self._ck(self.lib.lf_aim_at_exit_pupil(self.ctx, C.c_float(margin)))
+        return self.pupil_target()
+
+    def set_ghost_accumulate(self, on):
+        self._ck(self.lib.lf_set_ghost_accumulate(self.ctx, int(bool(on))))
 
     def lens_info(self):
         n, stop, nl, sw, efl = C.c_int(), C.c_int(), C.c_int(), C.c_float(), C.c_double()

@@ -335,6 +335,20 @@ lf_status lf_set_aperture(lf_ctx* ctx, lf_aperture_slot slot, const float* texel
   LF_HIP(ctx, hipMemcpyAsync(a.texels, texels, sizeof(float) * (size_t)width * height,
                              hipMemcpyHostToDevice, ctx->stream));
   if ((st = lfk_aperture_stats(ctx, slot)) != LF_OK) return st;
+  {
+    // how far from the centre the mask is open (a sampling parameter for lf_aim_at_exit_pupil, not pixel
+    // arithmetic): the far corner of the outermost texel > 0, as the march maps texels onto [-h, h]^2
+    double r2max = 0.0;
+    const double hw = 0.5 * width, hh = 0.5 * height;
+    for (int y = 0; y < height; y++)
+      for (int x = 0; x < width; x++)
+        if (texels[(size_t)y * width + x] > 0.0f) {
+          const double ex = std::max(std::fabs(x - hw), std::fabs(x + 1 - hw)) / hw;
+          const double ey = std::max(std::fabs(y - hh), std::fabs(y + 1 - hh)) / hh;
+          r2max = std::max(r2max, ex * ex + ey * ey);
+        }
+    a.open_radius = std::sqrt(r2max);
+  }
   a.valid = true;
   if (slot == LF_APERTURE_STARBURST) {
     ctx->spectrum_valid = false;
@@ -1100,6 +1114,90 @@ lf_status lf_get_lens_info(lf_ctx* ctx, int* n_surfaces, int* stop_index, int* n
     (void)lf_paraxial_efl(ctx->raw_n, ctx->raw_stop, ctx->raw_radius, ctx->raw_thickness,
                           ctx->raw_ior + (size_t)(ctx->lens.n_lambda / 2) * ctx->raw_n, efl_mm);
   }
+  return LF_OK;
+}
+
+// ---------------------------------------------------------------- pupil target -------------------
+lf_status lf_set_pupil_target(lf_ctx* ctx, float radius_mm, float z_mm) {
+  if (!ctx) return LF_ERR_INVALID;
+  if (!ctx->lens_valid) return lf_fail(ctx, LF_ERR_STATE, "lf_set_pupil_target before lf_set_lens");
+  if (radius_mm > 0.0f) {
+    if (!(z_mm < ctx->lens.z_sensor) || !std::isfinite(z_mm) || !std::isfinite(radius_mm))
+      return lf_fail(ctx, LF_ERR_INVALID, "pupil target: the disc must lie in front of the sensor plane");
+    ctx->pupil_target_h = radius_mm; ctx->pupil_target_z = z_mm;
+  } else {
+    ctx->pupil_target_h = 0.0f; ctx->pupil_target_z = 0.0f;
+  }
+  lf_apply_pupil_target(ctx);
+  return LF_OK;
+}
+
+lf_status lf_get_pupil_target(lf_ctx* ctx, float* radius_mm, float* z_mm, float* z_sensor_mm) {
+  if (!ctx) return LF_ERR_INVALID;
+  if (!ctx->lens_valid) return lf_fail(ctx, LF_ERR_STATE, "lf_get_pupil_target before lf_set_lens");
+  if (radius_mm) *radius_mm = ctx->lens.pupil_h;
+  if (z_mm) *z_mm = ctx->lens.pupil_z;
+  if (z_sensor_mm) *z_sensor_mm = ctx->lens.z_sensor;
+  return LF_OK;
+}
+
+lf_status lf_paraxial_exit_pupil(int n, int stop, const float* radius, const float* thickness, const float* ior_row,
+                                 double* z_mm, double* magnification) {
+  if (n < 1 || n > LF_MAX_SURFACES || stop < 0 || stop >= n || !radius || !thickness || !ior_row || !z_mm || !magnification)
+    return LF_ERR_INVALID;
+  // the stop's centre imaged by the interfaces behind it: ray (height y, angle u) from the stop plane,
+  // T(d) = [[1, d], [0, 1]], R(c, n1, n2) = [[1, 0], [c (n1 - n2) / n2, n1 / n2]] (pathtracer.cpp:527-533)
+  double A = 1, B = 0, Cc = 0, D = 1;   // system matrix stop plane -> rear vertex
+  double n1 = 1.0, z = 0.0, z_stop = 0.0;
+  for (int k = 0; k < n; k++) {
+    if (k == stop) z_stop = z;
+    if (k < stop) n1 = ior_row[k];      // the medium the stop sits in
+    z += thickness[k];
+  }
+  double z_rear = z - thickness[n - 1];
+  double nm = n1;
+  for (int k = stop; k < n; k++) {
+    if (k > stop) {
+      const double c = radius[k] == 0.0f ? 0.0 : 1.0 / (double)radius[k], n2 = ior_row[k];
+      if (!(n2 >= 1.0)) return LF_ERR_INVALID;
+      const double r10 = c * (nm - n2) / n2, r11 = nm / n2;
+      const double c2 = r10 * A + r11 * Cc, d2 = r10 * B + r11 * D;
+      Cc = c2; D = d2;
+      nm = n2;
+    }
+    if (k + 1 < n) {
+      const double d = thickness[k];
+      A += d * Cc; B += d * D;
+    }
+  }
+  (void)z_stop;
+  if (D == 0.0) return LF_ERR_INVALID;   // the stop is imaged at infinity (image-space telecentric)
+  const double l = -B / D;               // image distance behind the rear vertex (+z = towards the sensor)
+  *z_mm = z_rear + l;
+  *magnification = A + l * Cc;
+  return LF_OK;
+}
+
+lf_status lf_aim_at_exit_pupil(lf_ctx* ctx, float margin) {
+  if (!ctx || !(margin > 0.0f)) return LF_ERR_INVALID;
+  if (!ctx->lens_valid) return lf_fail(ctx, LF_ERR_STATE, "lf_aim_at_exit_pupil before lf_set_lens");
+  if (ctx->raw_stop < 0) return lf_fail(ctx, LF_ERR_INVALID, "lf_aim_at_exit_pupil: the prescription has no stop");
+  if (!ctx->ap[LF_APERTURE_STARBURST].valid)
+    return lf_fail(ctx, LF_ERR_STATE, "aperture mask (LF_APERTURE_STARBURST slot) not set");
+  double z = 0, m = 0;
+  lf_status st = lf_paraxial_exit_pupil(ctx->raw_n, ctx->raw_stop, ctx->raw_radius, ctx->raw_thickness,
+                                        ctx->raw_ior + (size_t)(ctx->lens.n_lambda / 2) * ctx->raw_n, &z, &m);
+  if (st != LF_OK) return lf_fail(ctx, LF_ERR_INVALID, "lf_aim_at_exit_pupil: the stop has no finite paraxial image");
+  // the part of the stop that is open: the circle around the mask's non-zero texels, never more than
+  // the housing
+  const double open = std::min(1.0, ctx->ap[LF_APERTURE_STARBURST].open_radius);
+  const double r = (double)ctx->lens.stop_h * open * std::fabs(m) * (double)margin;
+  return lf_set_pupil_target(ctx, (float)r, (float)z);
+}
+
+lf_status lf_set_ghost_accumulate(lf_ctx* ctx, int on) {
+  if (!ctx) return LF_ERR_INVALID;
+  ctx->ghost_accumulate = on != 0;
   return LF_OK;
 }
 

@@ -96,6 +96,7 @@ struct LfApertureDev {
   int w = 0, h = 0;
   lf_aperture_stats* stats = nullptr;  // device copy
   lf_aperture_stats host_stats{};
+  double open_radius = 1.0;   // radius of the circle around the texels > 0, in units of the half width (host, lf_set_aperture)
   bool valid = false;
 };
 
@@ -261,6 +262,9 @@ struct lf_ctx {
   int raw_n = 0, raw_stop = -1;   // the prescription as handed to lf_set_lens (for lf_paraxial_efl)
   float raw_radius[LF_MAX_SURFACES] = {}, raw_thickness[LF_MAX_SURFACES] = {};
   float raw_ior[LF_MAX_LAMBDA * LF_MAX_SURFACES] = {};
+  float raw_semi_ap[LF_MAX_SURFACES] = {};
+  float pupil_target_h = 0.0f, pupil_target_z = 0.0f;   // lf_set_pupil_target; h <= 0: the rear element
+  bool ghost_accumulate = false;                          // lf_set_ghost_accumulate
   LfLensDev* lens_dev = nullptr;
   LfPairsDev pairs{};
   LfPairsDev* pairs_dev = nullptr;
@@ -326,6 +330,7 @@ lf_status lfk_lens_rays(lf_ctx* ctx, int lambda, int n, const float* d_xy, const
                         float* d_out);
 lf_status lf_build_march_tables(lf_ctx* ctx, std::vector<LfEventRow>& rows, std::vector<int>& skip);
 lf_status lfk_native_sqrt(lf_ctx* ctx, const float* d_x, float* d_y, size_t n);
+void lf_apply_pupil_target(lf_ctx* ctx);
 void lf_derive_lens(lf_ctx* ctx, int n, int stop, int n_lambda, const float* radius,
                     const float* thickness, const float* ior, const float* semi_ap,
                     float sensor_w_mm);

@@ -251,6 +251,7 @@ struct MarchArgs {
   float half_w, half_h;  // 0.5 * W, 0.5 * H
   float vz;            // pupil_z - z_sensor
   float lobe_thr;      // d.s above this may lie inside the sun's lobe (conservative, see lfk_march)
+  int accumulate;      // add the launch's pixels to the ghost buffer instead of replacing them
 };
 
 // The program of a GROUP of up to 3 wavelengths, in two levels (LfProgHdr / LfProgRow in
@@ -301,6 +302,15 @@ void k_march(const LfLensDev* __restrict__ lens, const LfPairsDev* __restrict__ 
              const LfProgRow* __restrict__ rec_table, const float* __restrict__ mask, MarchArgs a,
              double* __restrict__ ghost, unsigned long long* __restrict__ accum,
              unsigned long long* __restrict__ counters, float* __restrict__ start_scratch) {
+#ifdef LF_MARCH_ALL_WEIGHTS
+  // ablation build (profiles/r03_all_weights_ablation.json), never shipped, TIMING ONLY: every event of
+  // the first pass also evaluates its Fresnel / aperture weight -- the event of SURVEY 8d -- and a path's
+  // end uses the carried weight instead of marching the path again (fork states do not carry the
+  // weight here, so pixels are wrong; events, fates and the instruction mix are the real thing)
+  constexpr bool kW1 = true;
+#else
+  constexpr bool kW1 = false;
+#endif
   __shared__ unsigned long long s_acc[64 * 3];
   __shared__ unsigned long long s_cnt[kMarchCounters];
   __shared__ int s_next;
@@ -451,7 +461,7 @@ void k_march(const LfLensDev* __restrict__ lens, const LfPairsDev* __restrict__ 
           // (read back from LDS rather than kept in registers across the groups of the sample)
           const int lo = launder(lane);
           r[j] = Ray{LF_START(0, lo), LF_START(1, lo), 0.0f, 0.0f, LF_START(2, lo),
-                     LF_START(3, lo), LF_START(4, lo), 0.0f, 0.0f};
+                     LF_START(3, lo), LF_START(4, lo), kW1 ? LF_START(5, lo) : 0.0f, kW1 ? 1.0f : 0.0f};
           r[j].r2 = fmaf(r[j].px, r[j].px, r[j].py * r[j].py);
           alive[j] = (g * K + j < n_lambda) ? active_mask : 0ull;  // a short last group: dead rays
           alive0[j] = 0ull; alive1[j] = 0ull;
@@ -527,7 +537,7 @@ void k_march(const LfLensDev* __restrict__ lens, const LfPairsDev* __restrict__ 
                 if (K > 1 && __builtin_expect(alive[j] == 0ull, 0)) { okv[j] = 0ull; continue; }
                 lanemask geom_ok;
                 LF_HIST(alive[j]);
-                okv[j] = surface_event<false>(r[j], cur.dzv, cur.curv, cur.ch, cur.c2, cur.radius, cur.h2, cur.eta[j],
+                okv[j] = surface_event<kW1>(r[j], cur.dzv, cur.curv, cur.ch, cur.c2, cur.radius, cur.h2, cur.eta[j],
                                               cur.eta2[j], true, false, cur.sgn, geom_ok);
                 died |= alive[j] & ~okv[j];
               }
@@ -558,7 +568,7 @@ void k_march(const LfLensDev* __restrict__ lens, const LfPairsDev* __restrict__ 
                   // it its lanes would keep marching garbage through every row the others still visit)
                   if (K > 1 && __builtin_expect(alive[j] == 0ull, 0)) { okv[j] = 0ull; gv[j] = 0ull; continue; }
                   LF_HIST(alive[j]);
-                  okv[j] = surface_event<false>(r[j], cur.dzv, cur.curv, cur.ch, cur.c2, cur.radius, cur.h2, cur.eta[j],
+                  okv[j] = surface_event<kW1>(r[j], cur.dzv, cur.curv, cur.ch, cur.c2, cur.radius, cur.h2, cur.eta[j],
                                                 cur.eta2[j], false, false, cur.sgn, gv[j]);
                   died |= alive[j] & ~okv[j];
                 }
@@ -588,7 +598,7 @@ void k_march(const LfLensDev* __restrict__ lens, const LfPairsDev* __restrict__ 
             for (int j = 0; j < K; j++) {
               if (K > 1 && __builtin_expect(alive[j] == 0ull, 0)) { okv[j] = 0ull; continue; }
               LF_HIST(alive[j]);
-              okv[j] = stop_event<false>(r[j], cur.dzv, cur.h2, inv_stop_h, mask, a.mw, a.mh);
+              okv[j] = stop_event<kW1>(r[j], cur.dzv, cur.h2, inv_stop_h, mask, a.mw, a.mh);
               died |= alive[j] & ~okv[j];
             }
             if (__builtin_expect(died != 0ull, 0)) {
@@ -616,7 +626,7 @@ void k_march(const LfLensDev* __restrict__ lens, const LfPairsDev* __restrict__ 
             for (int j = 0; j < K; j++) {
               if (K > 1 && __builtin_expect(alive[j] == 0ull, 0)) { okv[j] = 0ull; gv[j] = 0ull; continue; }
               LF_HIST(alive[j]);
-              okv[j] = surface_event<false>(r[j], cur.dzv, cur.curv, cur.ch, cur.c2, cur.radius, cur.h2, cur.eta[j],
+              okv[j] = surface_event<kW1>(r[j], cur.dzv, cur.curv, cur.ch, cur.c2, cur.radius, cur.h2, cur.eta[j],
                                             cur.eta2[j], (fl & LF_EV_REFLECT) != 0,
                                             (fl & LF_EV_FLAT) != 0, cur.sgn, gv[j]);
               died |= alive[j] & ~okv[j];
@@ -677,6 +687,9 @@ void k_march(const LfLensDev* __restrict__ lens, const LfPairsDev* __restrict__ 
                 Ray rw{LF_START(0, lo), LF_START(1, lo), 0.0f, 0.0f, LF_START(2, lo),
                        LF_START(3, lo), LF_START(4, lo), LF_START(5, lo), 1.0f};
                 rw.r2 = fmaf(rw.px, rw.px, rw.py * rw.py);
+                if (kW1) {   // (ablation: the weight travelled with the ray)
+                  rw = j == 0 ? r[0] : j == 1 ? r[K > 1 ? 1 : 0] : r[K > 2 ? 2 : 0];
+                } else {
                 // events computed a second time, with the weight: for the lit lanes / as wave-wide rows
                 n_rm_lane += (unsigned long long)((unsigned)pairs->ev_cnt[q] * (unsigned)__popcll(lj));
                 n_rm_rows += (unsigned)pairs->ev_cnt[q];
@@ -693,6 +706,7 @@ void k_march(const LfLensDev* __restrict__ lens, const LfPairsDev* __restrict__ 
                     (void)surface_event<true>(rw, wr.dzv, wr.curv, wr.ch, wr.c2, wr.radius, wr.h2, w_eta, w_eta2,
                                               (wfl & LF_EV_REFLECT) != 0, (wfl & LF_EV_FLAT) != 0, wr.sgn, geom_ok);
                   }
+                }
                 }
                 // (selects, not branches: with no divergent branch anywhere in the walk the compiler
                 // keeps its control flow as plain scalar branches)
@@ -749,9 +763,10 @@ void k_march(const LfLensDev* __restrict__ lens, const LfPairsDev* __restrict__ 
   if (wave == 0 && active) {
     if (a.sgroups == 1) {
 #pragma unroll
-      for (int c = 0; c < 3; c++)
-        ghost[3 * (size_t)p + c] =
-            ((double)s_acc[lane * 3 + c] * (1.0 / 68719476736.0)) / (double)a.spp;
+      for (int c = 0; c < 3; c++) {
+        const double v = ((double)s_acc[lane * 3 + c] * (1.0 / 68719476736.0)) / (double)a.spp;
+        ghost[3 * (size_t)p + c] = a.accumulate ? ghost[3 * (size_t)p + c] + v : v;
+      }
     } else {
       // several workgroups share the tile (short launches, e.g. 1/8 of a frame per GPU, would
       // otherwise leave the last wave of long-running workgroups running alone): integer partial
@@ -831,11 +846,25 @@ __global__ void k_march_finish(const unsigned long long* __restrict__ accum, Mar
   const int t = (int)(p / a.W) >> 3;
   if (t < a.trow0 || (t - a.trow0) % a.tperiod != 0) return;
 #pragma unroll
-  for (int c = 0; c < 3; c++)
-    ghost[3 * p + c] = ((double)accum[3 * p + c] * (1.0 / 68719476736.0)) / (double)a.spp;
+  for (int c = 0; c < 3; c++) {
+    const double v = ((double)accum[3 * p + c] * (1.0 / 68719476736.0)) / (double)a.spp;
+    ghost[3 * p + c] = a.accumulate ? ghost[3 * p + c] + v : v;
+  }
 }
 
 }  // namespace
+
+// host: the disc every sensor sample aims at -- by default the rear element's clear aperture at its
+// vertex plane, or what lf_set_pupil_target names (part of the sampling specification) -- and the
+// solid-angle factor of the start weight, pupil area / distance^2 (double, then float)
+void lf_apply_pupil_target(lf_ctx* ctx) {
+  LfLensDev& L = ctx->lens;
+  const int n = L.n_surf;
+  if (ctx->pupil_target_h > 0.0f) { L.pupil_h = ctx->pupil_target_h; L.pupil_z = ctx->pupil_target_z; }
+  else { L.pupil_h = ctx->raw_semi_ap[n - 1]; L.pupil_z = L.surf[n - 1].zv; }
+  const double D = (double)L.z_sensor - (double)L.pupil_z;
+  L.geom_norm = (float)((3.14159265358979323846 * (double)L.pupil_h * (double)L.pupil_h) / (D * D));
+}
 
 // host: derive the per-interface march constants from the raw prescription (float arithmetic,
 // mirrored by the oracle)
@@ -873,10 +902,8 @@ void lf_derive_lens(lf_ctx* ctx, int n, int stop, int n_lambda, const float* rad
   }
   ctx->sensor_w_mm = sensor_w_mm;
   L.pitch = sensor_w_mm / (float)ctx->W;  // refreshed at every launch: the frame may be resized
-  L.pupil_h = semi_ap[n - 1];
-  L.pupil_z = L.surf[n - 1].zv;
-  double D = (double)L.z_sensor - (double)L.pupil_z;
-  L.geom_norm = (float)((3.14159265358979323846 * (double)L.pupil_h * (double)L.pupil_h) / (D * D));
+  for (int k = 0; k < n; k++) ctx->raw_semi_ap[k] = semi_ap[k];
+  lf_apply_pupil_target(ctx);
   L.stop_h = stop >= 0 ? semi_ap[stop] : 1.0f;
   for (int l = 0; l < n_lambda; l++)
     for (int c = 0; c < 3; c++) L.lambda_rgb[l][c] = (n_lambda == 3) ? (l == c ? 1.0f : 0.0f)
@@ -1206,6 +1233,7 @@ lf_status lfk_march(lf_ctx* ctx, int spp, uint64_t key) {
   a.inv_stop_h = 1.0f / ctx->lens.stop_h;
   a.half_w = 0.5f * (float)ctx->W; a.half_h = 0.5f * (float)ctx->H;
   a.vz = ctx->lens.pupil_z - ctx->lens.z_sensor;
+  a.accumulate = ctx->ghost_accumulate ? 1 : 0;
   {
     // candidate selection (the contract, the same expression in oracle/lf_geo_oracle.c): d.s above
     // 1 - 1.0625 (1 - cos alpha) - 4e-7 MAY lie inside the lobe.  The 1/16 margin is relative, the

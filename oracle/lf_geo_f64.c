@@ -277,6 +277,11 @@ double g64_sensor_z(const g64_lens* L) {
 
 static double unit_interval(uint32_t bits) { return (double)(bits >> 8) / 16777216.0; }
 
+/* the disc the sensor samples aim at (lf_set_pupil_target, float values held in doubles):
+ * h <= 0 = the rear element's clear aperture at its vertex plane */
+static double g64_pupil_h = 0.0, g64_pupil_z = 0.0;
+void g64_set_pupil_target(double h, double z) { g64_pupil_h = h; g64_pupil_z = z; }
+
 /* The estimator's sample: sensor point and rear-pupil point of sample s of
  * pixel (x, y).  Returns the start direction and the start weight. */
 static double sample_ray(const g64_lens* L, const g64_system* S, int W, int H, int x, int y, int s, int spp,
@@ -311,7 +316,8 @@ static double sample_ray(const g64_lens* L, const g64_system* S, int W, int H, i
     else { const double th = (M_PI / 4.0) * (a / b); qx = b * sin(th); qy = b * cos(th); }
   }
   const int last = L->n_surf - 1;
-  const double pupil_h = L->semi_ap[last], pupil_z = S->vertex_z[last];
+  const double pupil_h = g64_pupil_h > 0.0 ? g64_pupil_h : L->semi_ap[last];
+  const double pupil_z = g64_pupil_h > 0.0 ? g64_pupil_z : S->vertex_z[last];
   *origin = V(X, Y, S->sensor_z);
   *dir = normalise(sub(V(pupil_h * qx, pupil_h * qy, pupil_z), *origin));
   const double dist = S->sensor_z - pupil_z;

@@ -85,6 +85,10 @@ typedef struct {
   float z_sensor, pitch, pupil_h, pupil_z, geom_norm, inv_stop_h, inv_1mc, sun_ss, lobe_thr;
 } geo_derived;
 
+/* the disc the sensor samples aim at (lf_set_pupil_target): h <= 0 = the rear element's clear aperture */
+static float g_pupil_h = 0.0f, g_pupil_z = 0.0f;
+void geo_set_pupil_target(float h, float z) { g_pupil_h = h; g_pupil_z = z; }
+
 static void derive(const geo_lens* L, int W, geo_derived* D) {
   float z = 0.0f;
   for (int k = 0; k < L->n_surf; k++) {
@@ -106,6 +110,7 @@ static void derive(const geo_lens* L, int W, geo_derived* D) {
   D->pitch = L->sensor_w_mm / (float)W;
   D->pupil_h = L->semi_ap[L->n_surf - 1];
   D->pupil_z = D->zv[L->n_surf - 1];
+  if (g_pupil_h > 0.0f) { D->pupil_h = g_pupil_h; D->pupil_z = g_pupil_z; }
   double dist = (double)D->z_sensor - (double)D->pupil_z;
   D->geom_norm = (float)((3.14159265358979323846 * (double)D->pupil_h * (double)D->pupil_h) / (dist * dist));
   D->inv_stop_h = 1.0f / (L->stop >= 0 ? L->semi_ap[L->stop] : 1.0f);

@@ -244,6 +244,13 @@ def geo_lens(lens, sun_dir=(0, 0, -1), sun_radiance=(1, 1, 1), sun_angular_radiu
     return L
 
 
+def set_pupil_target(radius_mm=0.0, z_mm=0.0):
+    """Both tracers: the disc sensor samples aim at, as the float32 values lf_get_pupil_target reports
+    (radius <= 0: the rear element's clear aperture, the default)."""
+    lib().geo_set_pupil_target(C.c_float(radius_mm), C.c_float(z_mm))
+    lib().g64_set_pupil_target(C.c_double(float(np.float32(radius_mm))), C.c_double(float(np.float32(z_mm))))
+
+
 def all_pairs(lens, include_primary=True):
     n, stop = int(lens["n"]), int(lens["stop"])
     out = [(-1, -1)] if include_primary else []
