@@ -58,6 +58,12 @@ CONFIGS = {
                          "DirectionalLight (dae/dragon.dae is absent from the reference checkout: "
                          "dae/pyramid.dae, the project's own sun scene), scene term on the device, "
                          "sun handed to the march by lf_set_sun_from_flares"),
+    "c4_maxplanck_1gpu": dict(W=3840, H=2160, spp=256, pairs="all", n_lambda=3, scene="maxplanck.dae", spectral=False,
+                              behind_mesh=True,
+                              text="configs[3]'s shape on the LARGEST scene file the reference ships that loads "
+                                   "(dae/meshedit/maxplanck.dae: 50 801 triangles, its own DirectionalLight is the sun): "
+                                   "4K 256 spp on ONE GPU, camera behind the mesh looking at the sun, scene term on "
+                                   "the device, sun handed to the march by lf_set_sun_from_flares"),
     "c5_1gpu": dict(W=3840, H=2160, spp=1024, pairs="all", n_lambda=8, scene=None, spectral=True,
                     text="BASELINE.json configs[4] on ONE GPU: 8 wavelengths (indices interpolated between "
                          "the lens file's C, d, F columns) + spectral starburst, 4K 1024 spp"),
@@ -309,6 +315,13 @@ def main():
         camera, suns = lf.load_collada(os.path.join(pkg.DATA, cfg["scene"]))
         lights = suns[:1]
         pos = np.array(camera["pos"], float) if camera else np.zeros(3)
+        if cfg.get("behind_mesh"):
+            # the mesh between the camera and the sun: it fills the middle of the frame (a scene-heavy
+            # frame), the sun's screen position does not depend on what lies in between
+            lo, hi, _ = lf.scene_bounds()
+            mid, ext = 0.5 * (lo + hi), float(np.linalg.norm(hi - lo))
+            to_sun = np.array(lights[0][:3], float) - mid
+            pos = mid - to_sun / np.linalg.norm(to_sun) * (1.5 * ext)
         c2w = pkg.aim_camera(pos, lights[0][:3], SUN_NS, hf, vf)
         lf.set_camera(c2w, pos, hf, vf)
         lf.set_params(1, 25.0, 1.0)

@@ -158,6 +158,9 @@ lf_status lf_set_scene(lf_ctx* ctx, int n_spheres, const double* spheres, const 
  * pathtracer.cpp:143-213), drawn from the counter RNG -- they need lf_set_jitter_counter (the
  * reference's shared MT19937 is consumed in hit order, which no parallel schedule reproduces) and are
  * validated statistically against reference frames, not bit for bit. */
+/* the box around the scene's primitives (what Application::load asks GLScene::Scene::get_bbox for to
+ * place its camera, application.cpp:277-300) and how many there are */
+lf_status lf_scene_bounds(lf_ctx* ctx, double bmin[3], double bmax[3], int* n_primitives);
 lf_status lf_set_scene_lights(lf_ctx* ctx, int n_lights, const double* rows);
 lf_status lf_set_light_samples(lf_ctx* ctx, int ns_area_light);
 /* PathTracer::envLight (pathtracer.h:119; `new EnvironmentLight(envmap)`, raytraced_renderer.cpp:

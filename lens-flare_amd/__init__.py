@@ -29,7 +29,7 @@ ABI_SYMBOLS = [
     "lf_set_frame", "lf_set_band", "lf_set_row_interleave", "lf_set_params", "lf_set_aperture", "lf_get_aperture_stats",
     "lf_set_paraxial_lens", "lf_set_camera", "lf_find_sun_pos", "lf_set_flares", "lf_get_flares",
     "lf_set_jitter_mt19937", "lf_set_jitter_counter", "lf_set_scene_term", "lf_set_scene",
-    "lf_set_sampling", "lf_set_scene_lights", "lf_set_light_samples", "lf_set_environment_map",
+    "lf_set_sampling", "lf_scene_bounds", "lf_set_scene_lights", "lf_set_light_samples", "lf_set_environment_map",
     "lf_set_direct_hemisphere_sample", "lf_collada_check", "lf_render_scene_term",
     "lf_generate_ghost_buffer", "lf_render_flare_layer", "lf_read_tile", "lf_read_pixel",
     "lf_write_to_framebuffer", "lf_save_image_rgba", "lf_device_buffer", "lf_set_lens", "lf_set_lambda_rgb", "lf_set_sun",
@@ -419,6 +419,11 @@ class LensFlare:
             camera = dict(hfov=cam.hfov, vfov=cam.vfov, nclip=cam.nclip, fclip=cam.fclip,
                           pos=list(cam.pos), dir=list(cam.dir), up=list(cam.up))
         return camera, suns[:min(n.value, max_suns)].tolist()
+
+    def scene_bounds(self):
+        lo, hi, n = (C.c_double * 3)(), (C.c_double * 3)(), C.c_int()
+        self._ck(self.lib.lf_scene_bounds(self.ctx, lo, hi, C.byref(n)))
+        return np.array(lo[:]), np.array(hi[:]), n.value
 
     def set_sampling(self, samples_per_batch=32, max_tolerance=0.05, n_clip=0.01, f_clip=100.0):
         self._ck(self.lib.lf_set_sampling(self.ctx, int(samples_per_batch), C.c_double(max_tolerance),

@@ -247,6 +247,7 @@ struct lf_ctx {
   // scene term
   LfSceneDev scene_dev{};
   bool scene_valid = false;
+  double scene_bmin[3] = {}, scene_bmax[3] = {};   // the BVH root's box (lf_scene_bounds)
   int ns_area_light = 1;          // PathTracer::ns_area_light (pathtracer.h:108; the -l flag)
   LfEnvDev env_dev{};             // PathTracer::envLight (pathtracer.h:119)
   double* env_block = nullptr;    // one allocation behind env_dev's four tables

@@ -594,9 +594,18 @@ lf_status lf_set_scene(lf_ctx* ctx, int n_spheres, const double* spheres, const 
   LF_HIP(ctx, up((void**)&S.prims, prims.data(), prims.size() * sizeof(LfPrim)));
   LF_HIP(ctx, up((void**)&S.materials, mats.data(), mats.size() * sizeof(LfMaterial)));
   LF_HIP(ctx, up((void**)&S.lights, lts.data(), lts.size() * sizeof(LfLight)));
+  for (int a = 0; a < 3; a++) { ctx->scene_bmin[a] = nodes[0].bmin[a]; ctx->scene_bmax[a] = nodes[0].bmax[a]; }
   S.n_nodes = (int)nodes.size(); S.n_prims = (int)prims.size();
   S.n_materials = n_materials; S.n_lights = n_lights; S.n_soft_lights = 0;
   ctx->scene_valid = true;
+  return LF_OK;
+}
+
+lf_status lf_scene_bounds(lf_ctx* ctx, double bmin[3], double bmax[3], int* n_primitives) {
+  if (!ctx || !bmin || !bmax) return LF_ERR_INVALID;
+  if (!ctx->scene_valid) return lf_fail(ctx, LF_ERR_STATE, "lf_scene_bounds before lf_set_scene");
+  for (int a = 0; a < 3; a++) { bmin[a] = ctx->scene_bmin[a]; bmax[a] = ctx->scene_bmax[a]; }
+  if (n_primitives) *n_primitives = ctx->scene_dev.n_prims;
   return LF_OK;
 }
 

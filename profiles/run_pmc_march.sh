@@ -1,11 +1,11 @@
 #!/bin/bash
-# Round-2 profile of the shipped march kernel: rocprofv3 kernel stats + PMC counters in SEPARATE
+# Profile of the shipped march kernel (rounds 2 and 3): rocprofv3 kernel stats + PMC counters in SEPARATE
 # passes (SQ / FETCH_SIZE / WRITE_SIZE / misc), as MI355X_MICROARCH.md's HBM section prescribes,
-# reduced to profiles-ready JSON.  Usage (GPU box, repo root):  bash profiles/run_pmc_r02.sh <tag> [config]
+# reduced to profiles-ready JSON.  Usage (GPU box, repo root):  bash profiles/run_pmc_march.sh <tag> [config]
 # Nothing is built here: the library must exist BEFORE the profiler starts (no exec of hipcc under it).
 set -e
 [ -f lens-flare_amd/liblensflare_hip.so ] || { echo "liblensflare_hip.so missing: run __graft_entry__.build() first" >&2; exit 1; }
-TAG=${1:-r02}
+TAG=${1:-r03}
 CFG=${2:-c3}
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
 OUT=gpurun_out/pmc_$TAG

@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Reduce the rocprofv3 --pmc CSVs of profiles/run_pmc_r02.sh to one JSON: per-launch averages for
+"""Reduce the rocprofv3 --pmc CSVs of profiles/run_pmc_march.sh to one JSON: per-launch averages for
 the march kernel with the gfx950 FETCH_SIZE x2 correction of MI355X_MICROARCH.md (HBM section), the
 per-event instruction counts bench.py prices its roofline with, and the identity of the sources the
 profiled library was built from."""

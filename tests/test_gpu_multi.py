@@ -164,3 +164,75 @@ def test_cpp_host_drives_a_group(pkg, tmp_path):
                        timeout=300)
     assert r.returncode == 0, r.stdout + r.stderr
     assert "3 devices" in r.stdout
+
+
+def test_communicator_introspection_deadline_test_and_abort(pkg, monkeypatch):
+    """What bench.py's bring-up relies on (round 3): lf_comm_available before any blocking call,
+    lf_comm_info = what RCCL itself reports (ncclCommCount / ncclCommUserRank), lf_comm_test = the
+    non-blocking completion query behind the first exchange's deadline, lf_comm_abort = the way out of
+    a failed one, and the exchange's own timing entry."""
+    import time
+    assert pkg.comm_available()
+    lens = pkg.load_lens_file("dgauss11.lens")
+    mask = load_texels("pentbig500_14.png")
+    lf = pkg.LensFlare(0)
+    lf.set_frame(64, 48)
+    _setup(pkg, lf, lens, mask)
+    assert lf.comm_info() == (0, -1)                       # no communicator yet
+    lf.comm_init_rank(1, 0, pkg.comm_unique_id())
+    assert lf.comm_info() == (1, 0)
+    _frame(lf, 8, 3)
+    want = lf.read_buffer(pkg.SAMPLE_BUFFER)
+    monkeypatch.setenv("LF_COMM_FORCE_EXCHANGE", "1")
+    lf.timing_reset()
+    lf.timing_enable(True)
+    lf.comm_gather_async(pkg.SAMPLE_BUFFER)
+    t0 = time.time()
+    while not lf.comm_test():                              # polls, never blocks
+        assert time.time() - t0 < 30
+        time.sleep(0.001)
+    lf.comm_gather(pkg.SAMPLE_BUFFER)
+    lf.synchronize()
+    assert lf.comm_test()
+    n, ms = lf.timing_get("exchange")
+    lf.timing_enable(False)
+    assert n == 2 and 0 < ms < 1000                        # both forms are timed, on the stream they run on
+    assert np.array_equal(lf.read_buffer(pkg.SAMPLE_BUFFER), want)
+    lf.comm_abort()
+    assert lf.comm_info() == (0, -1)
+    lf.set_row_interleave(0, 1)
+    _frame(lf, 8, 3)                                       # the context's streams are usable afterwards
+    assert np.array_equal(lf.read_buffer(pkg.SAMPLE_BUFFER), want)
+    lf.close()
+
+
+def test_float_exchange_rounds_only_received_rows(pkg):
+    """lf_comm_set_exchange_precision(32) (SURVEY 8e budgets an f32 exchange): a rank's own tile rows
+    stay the doubles it rendered, the rows it receives are those doubles rounded to float."""
+    lens = pkg.load_lens_file("dgauss11.lens")
+    mask = load_texels("pentbig500_14.png")
+    W, H, spp, key, n = 72, 52, 8, 21, 3
+    ref = pkg.LensFlare(0)
+    ref.set_frame(W, H)
+    _setup(pkg, ref, lens, mask)
+    _frame(ref, spp, key)
+    want = ref.read_buffer(pkg.SAMPLE_BUFFER)
+    ref.close()
+    grp = pkg.LensFlareGroup([0] * n)
+    grp.set_frame(W, H)
+    for lf in grp.ranks:
+        _setup(pkg, lf, lens, mask)
+        lf.comm_set_exchange_precision(32)
+    grp.for_each(lambda lf, r: _frame(lf, spp, key))
+    grp.gather(pkg.SAMPLE_BUFFER)
+    as_float = want.astype(np.float32).astype(np.float64)
+    for r, lf in enumerate(grp.ranks):
+        got = lf.read_buffer(pkg.SAMPLE_BUFFER)
+        own = (np.arange(H) // 8) % n == r
+        assert np.array_equal(got[own], want[own])             # rendered here: untouched
+        assert np.array_equal(got[~own], as_float[~own])       # received: the sender's value as a float
+        assert np.abs(got - want).max() <= 6e-8 * np.abs(want).max()
+    grp.ranks[0].comm_set_exchange_precision(64)
+    with pytest.raises(pkg.LensFlareError):                    # one precision per group
+        grp.gather(pkg.SAMPLE_BUFFER)
+    grp.close()
