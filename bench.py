@@ -454,7 +454,7 @@ def main():
     # opt-in sampling specifications, timed beside the default (N = 1 only, outside the timed region; what
     # they cost in image quality is in profiles/r03_sampling_efficiency.json)
     sampling_variants = None
-    if world == 1 and not cfg["scene"]:
+    if world == 1 and not cfg["scene"] and not args.no_cpu:   # (--no-cpu = the march alone: profiler passes, A/B runs)
         sampling_variants = {}
         for bits in (4, 0):
             lf.set_pupil_subcells(bits)

@@ -223,7 +223,7 @@ lf_status lf_destroy(lf_ctx* ctx) {
   }
   void* ptrs[] = {ctx->spectrum, ctx->twiddle, ctx->dft_rows, ctx->flares, ctx->ghosts, ctx->pl_dev,
                   ctx->lens_dev, ctx->pairs_dev, ctx->counters_dev, ctx->accum,
-                  ctx->prog_dev, ctx->sun_lights_dev, ctx->march_scratch,
+                  ctx->prog_dev, ctx->sun_lights_dev,
                   ctx->scene_dev.nodes, ctx->scene_dev.prims, ctx->scene_dev.materials,
                   ctx->scene_dev.lights, ctx->env_block};
   for (void* p : ptrs) if (p) (void)hipFree(p);

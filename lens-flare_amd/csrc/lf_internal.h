@@ -271,8 +271,6 @@ struct lf_ctx {
   LfPairsDev* pairs_dev = nullptr;
   unsigned long long* counters_dev = nullptr;  // kMarchCounterSlots x u64
   unsigned long long* accum = nullptr;         // W*H_alloc*3 fixed-point partial sums (split launches)
-  float* march_scratch = nullptr;              // per-wave slices for the samples' start states (k_march)
-  size_t march_scratch_cap = 0;                // bytes
   unsigned char* prog_dev = nullptr;           // the packed program: headers, then records (lf_march.hip pack_program)
   size_t prog_cap = 0, prog_rec_off = 0, prog_seq_off = 0;   // bytes; offsets of the records / the pair sequences
   int march_k = 1;                             // wavelengths (rays per lane) that walk together

@@ -290,18 +290,18 @@ __device__ __forceinline__ LfProgHdr load_phdr(const LfProgHdr* __restrict__ bas
 // instructions per bench frame on ONE scalar unit per CU (85 % busy) against 9.5e10 vector
 // instructions on four SIMDs (53 %); profiles/r02_*.  Each ray keeps its own liveness mask, tallies
 // are per ray, so pixels and counters are exactly those of K separate walks.
-// (second launch bound = waves per SIMD the register allocation must leave room for.  The LDS
-// footprint -- 20 KB for K = 3 -- would admit 8 workgroups of 4 waves per CU; the registers admit 6
-// waves per SIMD: 73 of them.  Capped at 72 for a 7th wave the allocator adds 4 % of vector
-// instructions and the frame takes 123 instead of 117 ms; occupancy sweep 3 .. 7 waves per SIMD:
-// 155, 133, 122, 117, 123 ms, profiles/r03_march_variants.txt)
+// (second launch bound = waves per SIMD the register allocation must leave room for; the LDS
+// footprint allows at least as many workgroups of 4 waves per CU: 8 / 6 / 6 for K = 1 .. 3.  A 7th
+// wave for K = 3 is not to be had: with the LDS made to fit (20 KB) the allocator, capped at 72
+// registers, adds 4 % of vector instructions and the frame takes 123 instead of 117 ms; occupancy sweep
+// 3 .. 7 waves per SIMD: 155, 133, 122, 117, 123 ms, profiles/r03_march_variants.txt)
 template <int K>
 __global__ __launch_bounds__(256, (K == 1 ? 8 : 6))
 void k_march(const LfLensDev* __restrict__ lens, const LfPairsDev* __restrict__ pairs,
              const int* __restrict__ seq_table, const LfProgHdr* __restrict__ hdr_table,
              const LfProgRow* __restrict__ rec_table, const float* __restrict__ mask, MarchArgs a,
              double* __restrict__ ghost, unsigned long long* __restrict__ accum,
-             unsigned long long* __restrict__ counters, float* __restrict__ start_scratch) {
+             unsigned long long* __restrict__ counters) {
 #ifdef LF_MARCH_ALL_WEIGHTS
   // ablation build (profiles/r03_all_weights_ablation.json), never shipped, TIMING ONLY: every event of
   // the first pass also evaluates its Fresnel / aperture weight -- the event of SURVEY 8d -- and a path's
@@ -329,15 +329,15 @@ void k_march(const LfLensDev* __restrict__ lens, const LfPairsDev* __restrict__ 
   // registers: with both in LDS a K = 3 workgroup needs 38 KB and only 4 waves fit a SIMD
   // (measured 147 -> 137 ms per bench frame)
   __shared__ float2 s_state[4][K][3 * 64];
-  // The start of the current sample's rays per lane (sensor point, direction, start weight) is read
-  // back only by the head of each wavelength group and by the rare weight re-march (~2x per sample), so
-  // it must not occupy six registers during the walk.  It lives in a per-wave slice of a global scratch
-  // buffer: a slice is rewritten once per sample while its workgroup lives and stays in the XCD's L2
-  // (HBM sees each slice once, when it is evicted).  Rounds 1-2 kept it in LDS: 6 KB per workgroup more,
-  // and 1.2 % slower (profiles/r03_march_variants.txt; recomputing it instead costs two Philox draws +
-  // the pupil map ~2.4x per sample: +7 %).
-  float* const s_start_g = start_scratch + ((size_t)blockIdx.x * 4u + (size_t)(threadIdx.x >> 6)) * (6u * 64u);
-#define LF_START(k, l) s_start_g[(k) * 64 + (l)]
+  // the start of the current sample's rays per lane (sensor point, direction, start weight): only
+  // the head of each wavelength group and the rare weight re-march (~2.4x per sample) read it back,
+  // so it must not occupy six registers during the walk.  6 KB of LDS.  Round 3 tried the two other
+  // homes (profiles/r03_march_variants.txt): RECOMPUTING it where a ray starts (two Philox draws + the
+  // pupil map, ~250 instructions, 2.4x per sample) costs 7 % of the frame; a per-wave slice of a GLOBAL
+  // scratch buffer is 1.2 % faster than LDS, but a seventh to a quarter of its stores leave the L2 for
+  // the fabric -- 1.8 to 3.2 GB of write-back per frame against 50.8 MB of algorithmic traffic.
+  __shared__ float s_start[4][6][64];
+#define LF_START(k, l) s_start[wave][k][l]
   // (read back through a lane index the compiler cannot see through -- launder() -- or it forwards the
   // stores to the loads and keeps the registers)
   auto launder = [](int v) { asm volatile("" : "+v"(v)); return v; };
@@ -1273,17 +1273,6 @@ lf_status lfk_march(lf_ctx* ctx, int spp, uint64_t key) {
                                (size_t)(ctx->y1 - ctx->y0) * ctx->W * 3 * sizeof(unsigned long long),
                                ctx->stream));
   }
-  {
-    // per-wave slices for the samples' start states (k_march): 6 x 64 floats per wave
-    const size_t need = blocks * 4 * 6 * 64 * sizeof(float);
-    if (need > ctx->march_scratch_cap) {
-      LF_HIP(ctx, hipStreamSynchronize(ctx->stream));
-      if (ctx->march_scratch) (void)hipFree(ctx->march_scratch);
-      ctx->march_scratch = nullptr; ctx->march_scratch_cap = 0;
-      LF_HIP(ctx, hipMalloc((void**)&ctx->march_scratch, need));
-      ctx->march_scratch_cap = need;
-    }
-  }
   // experiments only: unused dynamic LDS caps the workgroups a CU holds (occupancy sweeps,
   // profiles/r03_march_variants.txt)
   size_t dyn_lds = 0;
@@ -1294,7 +1283,7 @@ lf_status lfk_march(lf_ctx* ctx, int spp, uint64_t key) {
                      ctx->pairs_dev, (const int*)(ctx->prog_dev + ctx->prog_seq_off),                \
                      (const LfProgHdr*)ctx->prog_dev,                                               \
                      (const LfProgRow*)(ctx->prog_dev + ctx->prog_rec_off), m.texels, a,            \
-                     ctx->ghost, ctx->accum, ctx->counters_dev, ctx->march_scratch)
+                     ctx->ghost, ctx->accum, ctx->counters_dev)
   switch (ctx->march_k) {
     case 1: LF_LAUNCH_MARCH(1); break;
     case 2: LF_LAUNCH_MARCH(2); break;
