@@ -866,7 +866,7 @@ lf_status lf_march_tables(int n_surfaces, int stop_index, int n_lambda, const fl
   }
   if (rows) {
     if (rows_cap < r.size() * 8) return LF_ERR_INVALID;
-    std::memcpy(rows, r.data(), r.size() * sizeof(LfEventRow));
+    for (size_t i = 0; i < r.size(); i++) std::memcpy(rows + 8 * i, &r[i], 8 * sizeof(float));   // the documented fields
   }
   if (skip) {
     if (skip_cap < sk.size()) return LF_ERR_INVALID;

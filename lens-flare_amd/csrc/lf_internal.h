@@ -111,6 +111,8 @@ struct LfSurfaceDev {
   float is_stop;   // 1.0f for the stop
   float eta_fwd[LF_MAX_LAMBDA];  // n_before / n_after   (ray travelling +z refracts with this)
   float eta_bwd[LF_MAX_LAMBDA];  // n_after / n_before   (ray travelling -z)
+  float n_before[LF_MAX_LAMBDA]; // index of the medium on the scene side of the interface
+  float n_after[LF_MAX_LAMBDA];  // ... on the sensor side (the stop leaves the medium unchanged)
 };
 
 struct LfLensDev {
@@ -126,6 +128,7 @@ struct LfLensDev {
   float sun_inv_one_minus_cos;  // 1 / (1 - cos(angular radius))
   float sun_ss;                 // |sun_dir|^2 of the float vector as stored (exact in double, narrowed)
   float lambda_rgb[LF_MAX_LAMBDA][3];
+  float n_start[LF_MAX_LAMBDA];  // index of the medium between the last interface and the sensor
   LfSurfaceDev surf[LF_MAX_SURFACES];
 };
 
@@ -150,6 +153,10 @@ struct alignas(32) LfEventRow {
   int flags;       // bit 0: mirror reflection, bit 1: the stop, bit 2: flat (curv == 0)
   float radius;    // 1 / curv as given in the prescription (0 for flats)
   float eta2;      // eta * eta (float product)
+  // (host only; lf_march_tables exports the eight fields above)
+  float n_in, n_out;   // index of the medium the ray arrives in / leaves in (equal for a mirror and the stop)
+  int surf_dir;        // interface index | direction of travel << 8: what a record is keyed by
+  int pad[5];
 };
 enum { LF_EV_REFLECT = 1, LF_EV_STOP = 2, LF_EV_FLAT = 4 };
 // A program row as the device walks it: the interface once, the index ratios of the up to three
@@ -166,14 +173,32 @@ struct alignas(16) LfProgHdr {
   int rec;          // byte offset of this row's record in the group's record table
   int rec_next;     // ... of the NEXT row's: both loads of the next row can then be issued together
 };
+// The march carries the ray's direction as OPTICAL direction cosines K = n d (|K| = the index of the
+// medium the ray is in, a property of the row): Snell's law is then K' = K + (n' cos t' - n cos t) N with
+// no scaling of K by the index ratio, and cos^2 of the refraction angle is one add (round 3; rounds 1-2
+// carried the unit direction d and multiplied it by eta = n / n' at every refraction: 4 vector
+// instructions per event more).  Per wavelength the record therefore holds
+//   cn22 = 2 c n^2      (c F of the vertex-form intersection, with the ray parameter in units of 1 / n)
+//   rn2  = R / n^2      (the root (G - sgn sqrt(disc)) R / n^2 of that quadratic)
+//   delta = n'^2 - n^2  ((n' cos t')^2 = (n cos t)^2 + delta; negative: total reflection)
+// n = index the ray arrives in, n' = leaves in; all float products / quotients of the prescription's
+// indices (lf_march.hip pack_program, mirrored by the oracle).
 struct alignas(64) LfProgRow {
-  float dzv, curv, h2, radius;
+  float dzv, curv, h2, sc;   // sc = sgn * c
   float sgn;
-  int pad0, pad1, pad2;
-  float eta[3];     // wavelength g*K + j of group g (repeated past the group's / the lens' last one)
+  float delta[3];   // wavelength g*K + j of group g (repeated past the group's / the lens' last one)
+  float cn22[3];
   float ch;         // curv / 2
-  float eta2[3];
+  float rn2[3];
   float c2;         // 2 curv (both exact: lf_march.hip, surface_event)
+};
+// what only the weight re-march needs of an (interface, direction): the scale factors of the Fresnel
+// fraction (surface_event<true>): fs = 1 / (n + n'), fo = n'^2 / q, fi = n^2 / q, q = n'^2 n + n^2 n'
+struct alignas(64) LfWeightRow {
+  float fs[3], pad0;
+  float fo[3], pad1;
+  float fi[3], pad2;
+  float pad3[4];
 };
 // The march does not walk the per-pair sequences one by one: every path of a (sample, wavelength)
 // starts with the same backward leg from the sensor, and all pairs (i, .) share the forward leg that
@@ -272,7 +297,7 @@ struct lf_ctx {
   unsigned long long* counters_dev = nullptr;  // kMarchCounterSlots x u64
   unsigned long long* accum = nullptr;         // W*H_alloc*3 fixed-point partial sums (split launches)
   unsigned char* prog_dev = nullptr;           // the packed program: headers, then records (lf_march.hip pack_program)
-  size_t prog_cap = 0, prog_rec_off = 0, prog_seq_off = 0;   // bytes; offsets of the records / the pair sequences
+  size_t prog_cap = 0, prog_rec_off = 0, prog_wrec_off = 0, prog_seq_off = 0;   // bytes; offsets of the records / weight records / pair sequences
   int march_k = 1;                             // wavelengths (rays per lane) that walk together
   bool events_dirty = true;
 

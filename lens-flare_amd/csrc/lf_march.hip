@@ -96,89 +96,84 @@ typedef unsigned long long lanemask;
 // the wave-sequences): the weight is 15 of the 71 VALU instructions of an event and is read by
 // 0.4 % of the rays.  Both instantiations do the same arithmetic on the ray itself, so the
 // repeated march reproduces the first one bit for bit.
-// d = fma(s, d, a): one VOP3 instruction that overwrites d (s wave-uniform, in an SGPR)
-__device__ __forceinline__ void fma_in_place(float& d, float s, float a) {
-  asm("v_fma_f32 %0, %1, %0, %2" : "+v"(d) : "s"(s), "v"(a));
-}
-
 // ch = c / 2 and c2 = 2 c travel with the row (exact scalings): F = c |o|^2 - 2 o_z is formed as its
-// half Fh = fma(ch, |o|^2, -o_z) -- the same bits, shifted by one exponent -- and c F as c2 * Fh, so
-// the doubling of o_z is never an instruction of its own.
+// half Fh = fma(ch, |o|^2, -o_z) -- the same bits, shifted by one exponent.
+//
+// The direction is the OPTICAL direction K = n d (|K| = n, the index of the medium the ray is in: a
+// property of the row).  With the ray o + s K the vertex-form quadratic is
+//   c n^2 s^2 - 2 s G + F = 0,   G = K_z - c (o . K)
+// so disc = G^2 - (c n^2) F, the root next to the vertex is s = (G - sgn sqrt(disc)) R / n^2 for a
+// curved interface and s = F / (G + sgn sqrt(disc)) for flat glass, and with N = (-c hx, -c hy,
+// 1 - c hz) the unit normal at the hit, K . N = G - c n^2 s = sgn sqrt(disc) EXACTLY: sqrt(disc) is
+// n |cos(incidence)|.  Snell: (n' cos t')^2 = disc + (n'^2 - n^2) -- one add, negative = total
+// reflection -- and K' = K + sgn (n' cos t' - n cos t) N: no multiplication of K by an index ratio.
+// Per event that is 27 vector instructions where the unit-direction form of rounds 1-2 had 31.
+// cn22 = 2 c n^2, rn2 = R / n^2, delta = n'^2 - n^2, sc = sgn c come with the row.
+// W = true additionally takes the Fresnel scale factors fs, fo, fi of the row (LfWeightRow).
 template <bool W>
-__device__ __forceinline__ lanemask surface_event(Ray& r, float dzv, float c, float ch, float c2, float rad,
-                                                  float h2, float eta, float eta2, bool reflect, bool flat,
-                                                  float sgn, lanemask& geom_ok) {
+__device__ __forceinline__ lanemask surface_event(Ray& r, float dzv, float c, float ch, float c2, float sc,
+                                                  float cn22, float rn2, float delta, float h2, bool reflect,
+                                                  bool flat, float sgn, lanemask& geom_ok, float fs = 1.0f,
+                                                  float fo = 1.0f, float fi = 1.0f) {
   const float oz = r.hz + dzv;
   const float od = fmaf(r.px, r.dx, fmaf(r.py, r.dy, oz * r.dz));
   const float oo = fmaf(oz, oz, r.r2);
   const float Fh = fmaf(ch, oo, -oz);            // F / 2, F = c |o|^2 - 2 o_z
   const float G = fmaf(-c, od, r.dz);
-  const float cF = c2 * Fh;                      // = c F, bit for bit
+  const float cF = cn22 * Fh;                    // = c n^2 F
   const float disc = fmaf(G, G, -cF);
-  const float sq = lf_sqrt(disc);
-  // the root next to the vertex, t = F / (G + sgn sqrt(disc)).  For a curved interface the same
-  // root is (G - sgn sqrt(disc)) * R with R = 1/c from the prescription: one fma + one multiply
-  // instead of an IEEE division (12 VALU incl. v_rcp).  The subtraction cancels at most
-  // log2(2 G^2 / (c F)) bits (<= 8 for this lens: <= 3e-5 mm on the hit point), which both the
-  // kernel and the oracle do identically.  Flat glass (c = 0) keeps the quotient.
+  const float sq = lf_sqrt(disc);                // n |cos(incidence)|
   float t;
   if (flat) t = __fdiv_rn(Fh + Fh, fmaf(sgn, sq, G));   // wave-uniform branch
-  else t = fmaf(-sgn, sq, G) * rad;
+  else t = fmaf(-sgn, sq, G) * rn2;
   const float hx = fmaf(t, r.dx, r.px), hy = fmaf(t, r.dy, r.py), hz = fmaf(t, r.dz, oz);
   const float r2 = fmaf(hx, hx, hy * hy);
   // a ray that misses the sphere (disc < 0) has sq = t = r2 = NaN, and NaN <= h2 is false
   geom_ok = __ballot(r2 <= h2);
-  // The unit normal at the hit is n = (-c hx, -c hy, 1 - c hz); it is never formed.  With |d| = 1 the
-  // cosine of incidence is mu = d.n = G - c t, and t = (G - sgn sqrt(disc)) / c makes that
-  // sgn * sqrt(disc) EXACTLY: |mu| is the root already taken, sin^2 = 1 - disc, the sign is the row's.
   lanemask ok = geom_ok;
   float Rn = 0.0f, D = 1.0f, ct = 0.0f;
   bool no_tir = true;
   if (W || !reflect) {
-    const float s2 = 1.0f - disc;                  // sin^2 of the incidence angle
-    const float k2 = fmaf(-eta2, s2, 1.0f);        // cos^2 of the refraction angle (eta2 = eta^2)
+    const float k2 = disc + delta;                 // (n' cos(refraction))^2
     no_tir = k2 >= 0.0f;
     // (a totally reflected ray only survives a mirror event, and only W = true reads ct there)
     ct = lf_sqrt(reflect ? fmaxf(k2, 0.0f) : k2);
     if (W) {
-      // unpolarised Fresnel R = (rs^2 + rp^2)/2 with rp = rs (A - B)/(A + B), A = ci ct,
-      // B = si st = eta s2, rs = a/b, a = eta ci - ct, b = eta ci + ct:
-      //   R = Rn / D,   Rn = a^2 (A^2 + B^2),   D = (b (A + B))^2
-      // (a, b on half-scaled cosines so that the running denominator stays near 1)
-      const float ci = sq;
-      const float ch = 0.5f * ci, th = 0.5f * ct;
-      const float a = fmaf(eta, ch, -th), b = fmaf(eta, ch, th);
-      const float A = ci * ct, B = eta * s2;
-      Rn = (a * a) * fmaf(A, A, B * B);
-      const float bAB = b * (A + B);
-      D = bAB * bAB;
+      // unpolarised Fresnel straight from the optical cosines sq = n cos t, ct = n' cos t':
+      //   rs = (sq - ct) / (sq + ct),   rp = (n'^2 sq - n^2 ct) / (n'^2 sq + n^2 ct),   R = (rs^2 + rp^2) / 2
+      // as ONE fraction R = Rn / D, Rn = ((a B)^2 + (A b)^2) / 2, D = (b B)^2, with the numerators and
+      // denominators scaled by row constants so that b = B = 1 at normal incidence (the running
+      // denominator of a path stays near 1): fs = 1 / (n + n'), fo = n'^2 / q, fi = n^2 / q,
+      // q = n'^2 n + n^2 n'.  No true cosine, no index ratio: nothing is divided by n on the way.
+      const float a = (sq - ct) * fs, b = (sq + ct) * fs;
+      const float pc = fi * ct;
+      const float A = fmaf(fo, sq, -pc), B = fmaf(fo, sq, pc);
+      const float u = a * B, v = A * b;
+      Rn = 0.5f * fmaf(u, u, v * v);
+      const float bB = b * B;
+      D = bB * bB;
     }
   }
-  if (reflect) {  // wave-uniform: d' = d - 2 mu n
+  if (reflect) {  // wave-uniform: K' = K - 2 (K . N) N, K . N = sgn sqrt(disc)
     if (W) {
       r.wn *= no_tir ? Rn : 1.0f;  // total reflection: R = 1
       r.wd *= no_tir ? D : 1.0f;
     }
-    // with mu = sgn sqrt(disc): m = 2 mu c and the -2 mu of the z component as ONE product / fma
-    // each with the wave-uniform factors 2 sgn c and -2 sgn (exact scalings: the same bits)
     const float m = sq * (c2 * sgn);
     r.dx = fmaf(m, hx, r.dx);
     r.dy = fmaf(m, hy, r.dy);
     r.dz = fmaf(m, hz, fmaf(-2.0f * sgn, sq, r.dz));
-  } else {        // d' = eta d + g n,  g = sgn(mu) ct - eta mu = sgn (ct - eta sqrt(disc))
+  } else {        // K' = K + sgn (ct - sq) N
     ok &= __ballot(no_tir);
     if (W) {
       r.wn *= D - Rn;
       r.wd *= D;
     }
-    const float g = sgn * fmaf(-eta, sq, ct);
-    const float gc = g * c;
-    // d = fma(eta, d, -(gc h)) IN PLACE (v_fma_f32 with the destination as a source): left to itself
-    // the compiler picks the two-address v_fmac that accumulates into the product's register and
-    // then moves the result back, three v_mov per event
-    fma_in_place(r.dx, eta, -(gc * hx));
-    fma_in_place(r.dy, eta, -(gc * hy));
-    fma_in_place(r.dz, eta, fmaf(-gc, hz, g));
+    const float gs = ct - sq;
+    const float gcs = gs * sc;                     // sgn (ct - sq) c
+    r.dx = fmaf(-gcs, hx, r.dx);
+    r.dy = fmaf(-gcs, hy, r.dy);
+    r.dz = fmaf(-gcs, hz, fmaf(sgn, gs, r.dz));
   }
   r.px = hx; r.py = hy; r.hz = hz; r.r2 = r2;
   return ok;
@@ -269,10 +264,24 @@ __device__ __forceinline__ LfProgRow load_prec(const LfProgRow* __restrict__ bas
   const lf_i16 v = *(lf_const_prow_ptr)((cptr)(base) + off);
   LfProgRow r;
   r.dzv = __int_as_float(v[0]); r.curv = __int_as_float(v[1]); r.h2 = __int_as_float(v[2]);
-  r.radius = __int_as_float(v[3]); r.sgn = __int_as_float(v[4]); r.pad0 = r.pad1 = r.pad2 = 0;
+  r.sc = __int_as_float(v[3]); r.sgn = __int_as_float(v[4]);
 #pragma unroll
-  for (int j = 0; j < 3; j++) { r.eta[j] = __int_as_float(v[8 + j]); r.eta2[j] = __int_as_float(v[12 + j]); }
+  for (int j = 0; j < 3; j++) {
+    r.delta[j] = __int_as_float(v[5 + j]); r.cn22[j] = __int_as_float(v[8 + j]); r.rn2[j] = __int_as_float(v[12 + j]);
+  }
   r.ch = __int_as_float(v[11]); r.c2 = __int_as_float(v[15]);
+  return r;
+}
+__device__ __forceinline__ LfWeightRow load_wrec(const LfWeightRow* __restrict__ base, unsigned off) {
+  typedef const char __attribute__((address_space(4))) * cptr;
+  const lf_i16 v = *(lf_const_prow_ptr)((cptr)(base) + off);
+  LfWeightRow r;
+#pragma unroll
+  for (int j = 0; j < 3; j++) {
+    r.fs[j] = __int_as_float(v[j]); r.fo[j] = __int_as_float(v[4 + j]); r.fi[j] = __int_as_float(v[8 + j]);
+  }
+  r.pad0 = r.pad1 = r.pad2 = 0.0f;
+  r.pad3[0] = r.pad3[1] = r.pad3[2] = r.pad3[3] = 0.0f;
   return r;
 }
 __device__ __forceinline__ LfProgHdr load_phdr(const LfProgHdr* __restrict__ base, unsigned off) {
@@ -299,7 +308,8 @@ template <int K>
 __global__ __launch_bounds__(256, (K == 1 ? 8 : 6))
 void k_march(const LfLensDev* __restrict__ lens, const LfPairsDev* __restrict__ pairs,
              const int* __restrict__ seq_table, const LfProgHdr* __restrict__ hdr_table,
-             const LfProgRow* __restrict__ rec_table, const float* __restrict__ mask, MarchArgs a,
+             const LfProgRow* __restrict__ rec_table, const LfWeightRow* __restrict__ wrec_table,
+             const float* __restrict__ mask, MarchArgs a,
              double* __restrict__ ghost, unsigned long long* __restrict__ accum,
              unsigned long long* __restrict__ counters) {
 #ifdef LF_MARCH_ALL_WEIGHTS
@@ -451,6 +461,7 @@ void k_march(const LfLensDev* __restrict__ lens, const LfPairsDev* __restrict__ 
         // ---- walk the group's program (the tree of all paths, depth first) ---------------------
         const LfProgHdr* const prog = hdr_table + (size_t)g * (size_t)(prog_rows + 1);   // (+ a spare header)
         const LfProgRow* const recs = rec_table + (size_t)g * (size_t)prog_recs;
+        const LfWeightRow* const wrecs = wrec_table + (size_t)g * (size_t)prog_recs;
         constexpr unsigned kHdr = (unsigned)sizeof(LfProgHdr);
         const unsigned prog_end = (unsigned)prog_rows * kHdr;
         unsigned e = 0u;   // byte offset of the current row's header
@@ -463,6 +474,9 @@ void k_march(const LfLensDev* __restrict__ lens, const LfPairsDev* __restrict__ 
           r[j] = Ray{LF_START(0, lo), LF_START(1, lo), 0.0f, 0.0f, LF_START(2, lo),
                      LF_START(3, lo), LF_START(4, lo), kW1 ? LF_START(5, lo) : 0.0f, kW1 ? 1.0f : 0.0f};
           r[j].r2 = fmaf(r[j].px, r[j].px, r[j].py * r[j].py);
+          // K = n d: the index of the medium between the last interface and the sensor (air: exact)
+          const float ns = lens->n_start[min(g * K + j, n_lambda - 1)];
+          r[j].dx *= ns; r[j].dy *= ns; r[j].dz *= ns;
           alive[j] = (g * K + j < n_lambda) ? active_mask : 0ull;  // a short last group: dead rays
           alive0[j] = 0ull; alive1[j] = 0ull;
         }
@@ -537,8 +551,8 @@ void k_march(const LfLensDev* __restrict__ lens, const LfPairsDev* __restrict__ 
                 if (K > 1 && __builtin_expect(alive[j] == 0ull, 0)) { okv[j] = 0ull; continue; }
                 lanemask geom_ok;
                 LF_HIST(alive[j]);
-                okv[j] = surface_event<kW1>(r[j], cur.dzv, cur.curv, cur.ch, cur.c2, cur.radius, cur.h2, cur.eta[j],
-                                              cur.eta2[j], true, false, cur.sgn, geom_ok);
+                okv[j] = surface_event<kW1>(r[j], cur.dzv, cur.curv, cur.ch, cur.c2, cur.sc, cur.cn22[j], cur.rn2[j],
+                                            cur.delta[j], cur.h2, true, false, cur.sgn, geom_ok);
                 died |= alive[j] & ~okv[j];
               }
               if (__builtin_expect(died != 0ull, 0)) {
@@ -568,8 +582,8 @@ void k_march(const LfLensDev* __restrict__ lens, const LfPairsDev* __restrict__ 
                   // it its lanes would keep marching garbage through every row the others still visit)
                   if (K > 1 && __builtin_expect(alive[j] == 0ull, 0)) { okv[j] = 0ull; gv[j] = 0ull; continue; }
                   LF_HIST(alive[j]);
-                  okv[j] = surface_event<kW1>(r[j], cur.dzv, cur.curv, cur.ch, cur.c2, cur.radius, cur.h2, cur.eta[j],
-                                                cur.eta2[j], false, false, cur.sgn, gv[j]);
+                  okv[j] = surface_event<kW1>(r[j], cur.dzv, cur.curv, cur.ch, cur.c2, cur.sc, cur.cn22[j], cur.rn2[j],
+                                              cur.delta[j], cur.h2, false, false, cur.sgn, gv[j]);
                   died |= alive[j] & ~okv[j];
                 }
               }
@@ -626,9 +640,9 @@ void k_march(const LfLensDev* __restrict__ lens, const LfPairsDev* __restrict__ 
             for (int j = 0; j < K; j++) {
               if (K > 1 && __builtin_expect(alive[j] == 0ull, 0)) { okv[j] = 0ull; gv[j] = 0ull; continue; }
               LF_HIST(alive[j]);
-              okv[j] = surface_event<kW1>(r[j], cur.dzv, cur.curv, cur.ch, cur.c2, cur.radius, cur.h2, cur.eta[j],
-                                            cur.eta2[j], (fl & LF_EV_REFLECT) != 0,
-                                            (fl & LF_EV_FLAT) != 0, cur.sgn, gv[j]);
+              okv[j] = surface_event<kW1>(r[j], cur.dzv, cur.curv, cur.ch, cur.c2, cur.sc, cur.cn22[j], cur.rn2[j],
+                                          cur.delta[j], cur.h2, (fl & LF_EV_REFLECT) != 0,
+                                          (fl & LF_EV_FLAT) != 0, cur.sgn, gv[j]);
               died |= alive[j] & ~okv[j];
             }
             if (__builtin_expect(died != 0ull, 0)) {
@@ -687,6 +701,7 @@ void k_march(const LfLensDev* __restrict__ lens, const LfPairsDev* __restrict__ 
                 Ray rw{LF_START(0, lo), LF_START(1, lo), 0.0f, 0.0f, LF_START(2, lo),
                        LF_START(3, lo), LF_START(4, lo), LF_START(5, lo), 1.0f};
                 rw.r2 = fmaf(rw.px, rw.px, rw.py * rw.py);
+                { const float ns = lens->n_start[l]; rw.dx *= ns; rw.dy *= ns; rw.dz *= ns; }
                 if (kW1) {   // (ablation: the weight travelled with the ray)
                   rw = j == 0 ? r[0] : j == 1 ? r[K > 1 ? 1 : 0] : r[K > 2 ? 2 : 0];
                 } else {
@@ -696,15 +711,21 @@ void k_march(const LfLensDev* __restrict__ lens, const LfPairsDev* __restrict__ 
                 for (int left = pairs->ev_cnt[q]; left > 0; --left, ++w) {
                   const unsigned se = (unsigned)*(const int __attribute__((address_space(4)))*)(w);
                   const LfProgRow wr = load_prec(recs, se & 0xffffu);
+                  const LfWeightRow ww = load_wrec(wrecs, se & 0xffffu);
                   const unsigned wfl = se >> 16;
-                  const float w_eta = j == 0 ? wr.eta[0] : j == 1 ? wr.eta[1] : wr.eta[2];
-                  const float w_eta2 = j == 0 ? wr.eta2[0] : j == 1 ? wr.eta2[1] : wr.eta2[2];
+                  const float w_cn22 = j == 0 ? wr.cn22[0] : j == 1 ? wr.cn22[1] : wr.cn22[2];
+                  const float w_rn2 = j == 0 ? wr.rn2[0] : j == 1 ? wr.rn2[1] : wr.rn2[2];
+                  const float w_delta = j == 0 ? wr.delta[0] : j == 1 ? wr.delta[1] : wr.delta[2];
+                  const float w_fs = j == 0 ? ww.fs[0] : j == 1 ? ww.fs[1] : ww.fs[2];
+                  const float w_fo = j == 0 ? ww.fo[0] : j == 1 ? ww.fo[1] : ww.fo[2];
+                  const float w_fi = j == 0 ? ww.fi[0] : j == 1 ? ww.fi[1] : ww.fi[2];
                   if (wfl & LF_EV_STOP) {
                     (void)stop_event<true>(rw, wr.dzv, wr.h2, inv_stop_h, mask, a.mw, a.mh);
                   } else {
                     lanemask geom_ok;
-                    (void)surface_event<true>(rw, wr.dzv, wr.curv, wr.ch, wr.c2, wr.radius, wr.h2, w_eta, w_eta2,
-                                              (wfl & LF_EV_REFLECT) != 0, (wfl & LF_EV_FLAT) != 0, wr.sgn, geom_ok);
+                    (void)surface_event<true>(rw, wr.dzv, wr.curv, wr.ch, wr.c2, wr.sc, w_cn22, w_rn2, w_delta, wr.h2,
+                                              (wfl & LF_EV_REFLECT) != 0, (wfl & LF_EV_FLAT) != 0, wr.sgn, geom_ok,
+                                              w_fs, w_fo, w_fi);
                   }
                 }
                 }
@@ -812,17 +833,27 @@ __global__ __launch_bounds__(256) void k_lens_rays(const LfLensDev* __restrict__
   Ray r{X, Y, 0.0f, fmaf(X, X, Y * Y), vx * rl, vy * rl, vz * rl, 1.0f, 1.0f};
   const float c2 = r.dz * r.dz;
   r.wn = lens->geom_norm * (c2 * c2);
+  { const float ns = lens->n_start[lambda]; r.dx *= ns; r.dy *= ns; r.dz *= ns; }   // K = n d
   const float inv_stop_h = __fdiv_rn(1.0f, lens->stop_h);
   lanemask alive = __ballot(active);
   for (int k = lens->n_surf - 1; k >= 0; k--) {  // wave-uniform
     const LfSurfaceDev& sf = lens->surf[k];
     const float dzv = (k == lens->n_surf - 1 ? z_sensor : lens->surf[k + 1].zv) - sf.zv;
     lanemask ok, geom_ok;
-    if (sf.is_stop != 0.0f) ok = stop_event<true>(r, dzv, sf.h2, inv_stop_h, mask, mw, mh);
-    else ok = surface_event<true>(r, dzv, sf.curv, 0.5f * sf.curv, 2.0f * sf.curv, sf.radius, sf.h2,
-                            sf.eta_bwd[lambda],
-                            sf.eta_bwd[lambda] * sf.eta_bwd[lambda], false,
-                            sf.curv == 0.0f, -1.0f, geom_ok);
+    if (sf.is_stop != 0.0f) {
+      ok = stop_event<true>(r, dzv, sf.h2, inv_stop_h, mask, mw, mh);
+    } else {
+      // the record's constants (pack_program), derived here the same way: travelling -z the ray arrives
+      // in the medium behind the interface and leaves in the one in front of it
+      const float n_in = sf.n_after[lambda], n_out = sf.n_before[lambda];
+      const float n_in2 = n_in * n_in, n_out2 = n_out * n_out;
+      const float cc2 = 2.0f * sf.curv;
+      const float q = fmaf(n_out2, n_in, n_in2 * n_out);
+      ok = surface_event<true>(r, dzv, sf.curv, 0.5f * sf.curv, cc2, -sf.curv, cc2 * n_in2,
+                               sf.curv == 0.0f ? 0.0f : __fdiv_rn(sf.radius, n_in2), n_out2 - n_in2, sf.h2, false,
+                               sf.curv == 0.0f, -1.0f, geom_ok, __fdiv_rn(1.0f, n_in + n_out), __fdiv_rn(n_out2, q),
+                               __fdiv_rn(n_in2, q));
+    }
     alive &= ok;
   }
   if (active) {
@@ -897,8 +928,11 @@ void lf_derive_lens(lf_ctx* ctx, int n, int stop, int n_lambda, const float* rad
       float n_after = (k == stop) ? n_before : ior[l * n + k];
       L.surf[k].eta_fwd[l] = n_before / n_after;
       L.surf[k].eta_bwd[l] = n_after / n_before;
+      L.surf[k].n_before[l] = n_before;
+      L.surf[k].n_after[l] = n_after;
       n_before = n_after;
     }
+    L.n_start[l] = n_before;   // the medium between the last interface and the sensor
   }
   ctx->sensor_w_mm = sensor_w_mm;
   L.pitch = sensor_w_mm / (float)ctx->W;  // refreshed at every launch: the frame may be resized
@@ -940,6 +974,10 @@ static void build_program(const LfLensDev& L, const LfPairsDev& P, int l, std::v
               (s.curv == 0.0f ? LF_EV_FLAT : 0) | extra_flags | (mult << 16);
     r.radius = s.radius;
     r.eta2 = r.eta * r.eta;
+    r.n_in = fwd ? s.n_before[l] : s.n_after[l];
+    r.n_out = fwd ? s.n_after[l] : s.n_before[l];   // (a mirror's Fresnel factor needs the far side too)
+    r.surf_dir = k | ((fwd ? 1 : 0) << 8);
+    std::memset(r.pad, 0, sizeof(r.pad));
     prog.push_back(r);
     target.push_back(-1);
     restore.push_back(0);
@@ -1053,6 +1091,10 @@ lf_status lf_build_march_tables(lf_ctx* ctx, std::vector<LfEventRow>& rows, std:
                   (s.curv == 0.0f ? LF_EV_FLAT : 0);
         r.radius = s.radius;
         r.eta2 = r.eta * r.eta;
+        r.n_in = fwd ? s.n_before[l] : s.n_after[l];
+        r.n_out = fwd ? s.n_after[l] : s.n_before[l];
+        r.surf_dir = k | ((fwd ? 1 : 0) << 8);
+        std::memset(r.pad, 0, sizeof(r.pad));
         out[n++] = r;
       };
       if (i < 0) {
@@ -1105,24 +1147,26 @@ static int rays_per_lane(int n_lambda) {
 // out = [n_groups x (prog_rows + 1) headers][padding to 64 bytes][n_groups x n_recs records]
 //       [total_events sequence dwords]
 static void pack_program(lf_ctx* ctx, const std::vector<LfEventRow>& rows, const std::vector<int>& skip, int K,
-                         std::vector<unsigned char>& out, size_t* rec_off, size_t* seq_off, bool* ok) {
+                         std::vector<unsigned char>& out, size_t* rec_off, size_t* wrec_off, size_t* seq_off,
+                         bool* ok) {
   LfPairsDev& P = ctx->pairs;
   const int n_lambda = ctx->lens.n_lambda, n_groups = (n_lambda + K - 1) / K;
   auto row_at = [&](int l, int i) -> const LfEventRow& {
     return rows[(size_t)P.prog_off + (size_t)l * P.prog_rows + i];
   };
-  // record ids from the first wavelength's rows (geometry + its index ratio identify the pair
-  // (interface, direction); the other wavelengths of the same interface follow it)
+  // a record = one (interface, direction of travel, interface the ray comes from): keyed by what it IS,
+  // not by the content of one wavelength's row (two interfaces of equal geometry whose glasses agree at
+  // one wavelength and disperse differently must not share a record)
+  auto same_record = [](const LfEventRow& q, const LfEventRow& r) {
+    return q.surf_dir == r.surf_dir && std::memcmp(&q.dzv, &r.dzv, sizeof(float)) == 0;
+  };
   std::vector<int> rec_of(P.prog_rows);
   std::vector<int> first_row;   // a row that uses record r
   for (int i = 0; i < P.prog_rows; i++) {
     const LfEventRow& r = row_at(0, i);
     int id = -1;
-    for (size_t k = 0; k < first_row.size() && id < 0; k++) {
-      const LfEventRow& q = row_at(0, first_row[k]);
-      if (std::memcmp(&q.dzv, &r.dzv, sizeof(float)) == 0 && q.curv == r.curv && q.h2 == r.h2 &&
-          q.radius == r.radius && q.sgn == r.sgn && q.eta == r.eta) id = (int)k;
-    }
+    for (size_t k = 0; k < first_row.size() && id < 0; k++)
+      if (same_record(row_at(0, first_row[k]), r)) id = (int)k;
     if (id < 0) { id = (int)first_row.size(); first_row.push_back(i); }
     rec_of[i] = id;
   }
@@ -1130,7 +1174,9 @@ static void pack_program(lf_ctx* ctx, const std::vector<LfEventRow>& rows, const
   P.prog_recs = n_recs;
   const size_t hdr_bytes = (size_t)n_groups * (P.prog_rows + 1) * sizeof(LfProgHdr);
   *rec_off = (hdr_bytes + 63) & ~(size_t)63;
-  *seq_off = *rec_off + (size_t)n_groups * n_recs * sizeof(LfProgRow);
+  *wrec_off = *rec_off + (size_t)n_groups * n_recs * sizeof(LfProgRow);
+  static_assert(sizeof(LfWeightRow) == sizeof(LfProgRow), "a weight record sits at its record's offset");
+  *seq_off = *wrec_off + (size_t)n_groups * n_recs * sizeof(LfWeightRow);
   out.assign(*seq_off + ((size_t)P.total_events + 1) * sizeof(int), 0);
   // the per-pair sequences (read by the weight re-march): one dword per event, record | kind << 16;
   // every (interface, direction) a pair crosses is in the program, so its record exists
@@ -1139,17 +1185,15 @@ static void pack_program(lf_ctx* ctx, const std::vector<LfEventRow>& rows, const
     for (int e = 0; e < P.total_events; e++) {
       const LfEventRow& r = rows[(size_t)e];   // wavelength 0
       int id = -1;
-      for (int k = 0; k < n_recs && id < 0; k++) {
-        const LfEventRow& q = row_at(0, first_row[k]);
-        if (std::memcmp(&q.dzv, &r.dzv, sizeof(float)) == 0 && q.curv == r.curv && q.h2 == r.h2 &&
-            q.radius == r.radius && q.sgn == r.sgn && q.eta == r.eta) id = k;
-      }
+      for (int k = 0; k < n_recs && id < 0; k++)
+        if (same_record(row_at(0, first_row[k]), r)) id = k;
       if (id < 0) { *ok = false; return; }
       seq[e] = id * (int)sizeof(LfProgRow) | ((r.flags & (LF_EV_REFLECT | LF_EV_STOP | LF_EV_FLAT)) << 16);
     }
   }
   LfProgHdr* hdrs = reinterpret_cast<LfProgHdr*>(out.data());
   LfProgRow* recs = reinterpret_cast<LfProgRow*>(out.data() + *rec_off);
+  LfWeightRow* wrecs = reinterpret_cast<LfWeightRow*>(out.data() + *wrec_off);
   for (int g = 0; g < n_groups; g++) {
     for (int i = 0; i < P.prog_rows; i++) {
       LfProgHdr& h = hdrs[(size_t)g * (P.prog_rows + 1) + i];
@@ -1160,14 +1204,24 @@ static void pack_program(lf_ctx* ctx, const std::vector<LfEventRow>& rows, const
     }
     for (int k = 0; k < n_recs; k++) {
       LfProgRow& o = recs[(size_t)g * n_recs + k];
+      LfWeightRow& w = wrecs[(size_t)g * n_recs + k];
       for (int j = 0; j < 3; j++) {
         const int l = std::min(g * K + (j < K ? j : K - 1), n_lambda - 1);
         const LfEventRow& r = row_at(l, first_row[k]);
         if (j == 0) {
-          o.dzv = r.dzv; o.curv = r.curv; o.h2 = r.h2; o.radius = r.radius; o.sgn = r.sgn;
+          o.dzv = r.dzv; o.curv = r.curv; o.h2 = r.h2; o.sgn = r.sgn;
+          o.sc = r.sgn * r.curv;
           o.ch = 0.5f * r.curv; o.c2 = 2.0f * r.curv;   // exact
         }
-        o.eta[j] = r.eta; o.eta2[j] = r.eta2;
+        // the optical-direction constants (float arithmetic, mirrored by the oracle and k_lens_rays)
+        const float n_in2 = r.n_in * r.n_in, n_out2 = r.n_out * r.n_out;
+        o.cn22[j] = o.c2 * n_in2;
+        o.rn2[j] = r.curv == 0.0f ? 0.0f : r.radius / n_in2;
+        o.delta[j] = n_out2 - n_in2;
+        const float q = std::fmaf(n_out2, r.n_in, n_in2 * r.n_out);
+        w.fs[j] = 1.0f / (r.n_in + r.n_out);
+        w.fo[j] = n_out2 / q;
+        w.fi[j] = n_in2 / q;
       }
     }
   }
@@ -1180,9 +1234,9 @@ static lf_status build_event_table(lf_ctx* ctx) {
   if (st != LF_OK) return st;
   ctx->march_k = rays_per_lane(ctx->lens.n_lambda);
   std::vector<unsigned char> prog;
-  size_t rec_off = 0, seq_off = 0;
+  size_t rec_off = 0, wrec_off = 0, seq_off = 0;
   bool packed = true;
-  pack_program(ctx, rows, skip, ctx->march_k, prog, &rec_off, &seq_off, &packed);
+  pack_program(ctx, rows, skip, ctx->march_k, prog, &rec_off, &wrec_off, &seq_off, &packed);
   if (!packed || (size_t)ctx->pairs.prog_recs * sizeof(LfProgRow) > 0xffffu)
     return lf_fail(ctx, LF_ERR_STATE, "march program: a pair crosses an interface the program has no record for");
   // (the flat per-pair rows and the jump table stay on the host: the device walks headers, records and
@@ -1203,6 +1257,7 @@ static lf_status build_event_table(lf_ctx* ctx) {
   };
   LF_HIP(ctx, upload((void**)&ctx->prog_dev, &ctx->prog_cap, prog.data(), prog.size()));
   ctx->prog_rec_off = rec_off;
+  ctx->prog_wrec_off = wrec_off;
   ctx->prog_seq_off = seq_off;
   ctx->events_dirty = false;
   return LF_OK;
@@ -1282,7 +1337,8 @@ lf_status lfk_march(lf_ctx* ctx, int spp, uint64_t key) {
   hipLaunchKernelGGL(k_march<KK>, dim3((unsigned)blocks), dim3(256), dyn_lds, ctx->stream, ctx->lens_dev, \
                      ctx->pairs_dev, (const int*)(ctx->prog_dev + ctx->prog_seq_off),                \
                      (const LfProgHdr*)ctx->prog_dev,                                               \
-                     (const LfProgRow*)(ctx->prog_dev + ctx->prog_rec_off), m.texels, a,            \
+                     (const LfProgRow*)(ctx->prog_dev + ctx->prog_rec_off),                         \
+                     (const LfWeightRow*)(ctx->prog_dev + ctx->prog_wrec_off), m.texels, a,         \
                      ctx->ghost, ctx->accum, ctx->counters_dev)
   switch (ctx->march_k) {
     case 1: LF_LAUNCH_MARCH(1); break;

@@ -81,7 +81,9 @@ static float unit24(uint32_t r) { return (float)(r >> 8) * 5.9604644775390625e-8
 /* ---- derived per-interface constants ------------------------------------------------------ */
 typedef struct {
   float zv[GEO_MAX_SURF], curv[GEO_MAX_SURF], h2[GEO_MAX_SURF];
-  float eta_fwd[GEO_MAX_LAMBDA][GEO_MAX_SURF], eta_bwd[GEO_MAX_LAMBDA][GEO_MAX_SURF];
+  /* index of the medium on the scene side / the sensor side of interface k (the stop sits inside
+   * one medium), and of the medium between the last interface and the sensor */
+  float n_before[GEO_MAX_LAMBDA][GEO_MAX_SURF], n_after[GEO_MAX_LAMBDA][GEO_MAX_SURF], n_start[GEO_MAX_LAMBDA];
   float z_sensor, pitch, pupil_h, pupil_z, geom_norm, inv_stop_h, inv_1mc, sun_ss, lobe_thr;
 } geo_derived;
 
@@ -102,10 +104,11 @@ static void derive(const geo_lens* L, int W, geo_derived* D) {
     float nb = 1.0f;
     for (int k = 0; k < L->n_surf; k++) {
       float na = (k == L->stop) ? nb : L->ior[l][k];
-      D->eta_fwd[l][k] = nb / na;
-      D->eta_bwd[l][k] = na / nb;
+      D->n_before[l][k] = nb;
+      D->n_after[l][k] = na;
       nb = na;
     }
+    D->n_start[l] = nb;
   }
   D->pitch = L->sensor_w_mm / (float)W;
   D->pupil_h = L->semi_ap[L->n_surf - 1];
@@ -138,53 +141,62 @@ typedef struct { float p[3], d[3], wn, wd, r2; } geo_ray;
 enum { OK_ = 0, CLIPPED = 1, VIGNETTED = 2, TIR = 3 };
 
 /* DESIGN.md "march arithmetic", glass interface.  reflect: 0 = Snell refraction, 1 = mirror.
- * forward: the ray travels +z (scene -> sensor). */
-static int glass_event(geo_ray* r, float dzv, float c, float rad, float h2, float eta, int reflect,
-                       int forward) {
+ * forward: the ray travels +z (scene -> sensor).  r->d is the OPTICAL direction K = n d, |K| = n_in, the
+ * index of the medium the ray arrives in; n_out: the index on the far side of the interface (a
+ * refracted ray leaves with |K| = n_out, a reflected one keeps n_in; its Fresnel factor needs n_out
+ * all the same). */
+static int glass_event(geo_ray* r, float dzv, float c, float rad, float h2, float n_in, float n_out,
+                       int reflect, int forward) {
+  /* the row's constants, as lf_march.hip's pack_program derives them (float arithmetic) */
+  const float sgn = forward ? 1.0f : -1.0f;
+  const float n_in2 = n_in * n_in, n_out2 = n_out * n_out;
+  const float ch = 0.5f * c, c2 = 2.0f * c, sc = sgn * c;
+  const float cn22 = c2 * n_in2;                          /* 2 c n^2 */
+  const float rn2 = c == 0.0f ? 0.0f : rad / n_in2;       /* R / n^2 */
+  const float delta = n_out2 - n_in2;                     /* n'^2 - n^2 */
   /* dzv: vertex z of the interface the ray comes from (or of the sensor) minus this one's */
   float oz = r->p[2] + dzv;
   float od = fmaf(r->p[0], r->d[0], fmaf(r->p[1], r->d[1], oz * r->d[2]));
   float oo = fmaf(oz, oz, r->r2);
-  float F = fmaf(c, oo, -2.0f * oz);
+  float Fh = fmaf(ch, oo, -oz);                           /* F / 2, F = c |o|^2 - 2 o_z */
   float G = fmaf(-c, od, r->d[2]);
-  float disc = fmaf(G, G, -(c * F));
+  float disc = fmaf(G, G, -(cn22 * Fh));                  /* G^2 - c n^2 F = (n cos(incidence))^2 */
   if (disc < 0.0f) return VIGNETTED;
   float root = geo_sqrt(disc);
-  /* vertex-side root: (G -+ root) * R for a curved interface (R = 1/c as given in the
-   * prescription), the quotient F / (G +- root) for flat glass -- DESIGN.md "march arithmetic" */
-  float sgn = forward ? 1.0f : -1.0f;
-  float t = (c == 0.0f) ? F / fmaf(sgn, root, G) : fmaf(-sgn, root, G) * rad;
+  /* the root next to the vertex of c n^2 s^2 - 2 s G + F = 0 (ray o + s K): (G -+ root) R / n^2 for a
+   * curved interface, the quotient F / (G +- root) for flat glass */
+  float t = (c == 0.0f) ? (Fh + Fh) / fmaf(sgn, root, G) : fmaf(-sgn, root, G) * rn2;
   float hx = fmaf(t, r->d[0], r->p[0]), hy = fmaf(t, r->d[1], r->p[1]), hz = fmaf(t, r->d[2], oz);
   float r2 = fmaf(hx, hx, hy * hy);
   if (!(r2 <= h2)) return VIGNETTED;
-  /* cosine of incidence against the unit normal n = (-c hx, -c hy, 1 - c hz), for |d| = 1:
-   * mu = d.n = G - c t, which with t = (G - sgn root) / c is sgn * root exactly: |mu| = root,
-   * sin^2 = 1 - disc, the sign is the direction of travel (DESIGN.md "march arithmetic"). */
-  float s2 = 1.0f - disc;
-  float k2 = fmaf(-(eta * eta), s2, 1.0f);
+  /* K . N against the unit normal N = (-c hx, -c hy, 1 - c hz) is sgn * root exactly; Snell:
+   * (n' cos t')^2 = disc + (n'^2 - n^2) */
+  float k2 = disc + delta;
   if (k2 < 0.0f && !reflect) return TIR;
-  float ct = k2 >= 0.0f ? geo_sqrt(k2) : 0.0f;
-  /* unpolarised Fresnel: R = Rn / D, Rn = a^2 (A^2 + B^2), D = (b (A + B))^2 with
-   * a, b = eta ci/2 -+ ct/2, A = ci ct, B = eta sin^2(theta_i) */
-  float ci = root;
-  float ch = 0.5f * ci, th = 0.5f * ct;
-  float a = fmaf(eta, ch, -th), b = fmaf(eta, ch, th);
-  float A = ci * ct, B = eta * s2;
-  float Rn = (a * a) * fmaf(A, A, B * B);
-  float bAB = b * (A + B);
-  float D = bAB * bAB;
-  if (!reflect) {
+  float ct = geo_sqrt(k2 >= 0.0f ? k2 : 0.0f);
+  /* unpolarised Fresnel straight from the optical cosines root = n cos t, ct = n' cos t':
+   * rs = (root - ct) / (root + ct), rp = (n'^2 root - n^2 ct) / (n'^2 root + n^2 ct), R = (rs^2 + rp^2) / 2
+   * as ONE fraction Rn / D, Rn = ((a B)^2 + (A b)^2) / 2, D = (b B)^2, scaled by the row's constants
+   * fs = 1 / (n + n'), fo = n'^2 / q, fi = n^2 / q, q = n'^2 n + n^2 n' (b = B = 1 at normal incidence) */
+  const float q = fmaf(n_out2, n_in, n_in2 * n_out);
+  const float fs = 1.0f / (n_in + n_out), fo = n_out2 / q, fi = n_in2 / q;
+  float a = (root - ct) * fs, b = (root + ct) * fs;
+  float pc = fi * ct;
+  float A = fmaf(fo, root, -pc), B = fmaf(fo, root, pc);
+  float u = a * B, v = A * b;
+  float Rn = 0.5f * fmaf(u, u, v * v);
+  float bB = b * B;
+  float D = bB * bB;
+  if (!reflect) {   /* K' = K + sgn (ct - root) N */
     r->wn *= D - Rn;
     r->wd *= D;
-    float g = sgn * fmaf(-eta, root, ct), gc = g * c;
-    float nd[3] = {fmaf(eta, r->d[0], -(gc * hx)), fmaf(eta, r->d[1], -(gc * hy)),
-                   fmaf(eta, r->d[2], fmaf(-gc, hz, g))};
+    float gs = ct - root, gcs = gs * sc;
+    float nd[3] = {fmaf(-gcs, hx, r->d[0]), fmaf(-gcs, hy, r->d[1]), fmaf(-gcs, hz, fmaf(sgn, gs, r->d[2]))};
     memcpy(r->d, nd, sizeof(nd));
-  } else {
+  } else {          /* K' = K - 2 (K . N) N */
     if (k2 >= 0.0f) { r->wn *= Rn; r->wd *= D; } /* else total reflection: R = 1 */
-    float mu = sgn * root;
-    float m = 2.0f * (mu * c);
-    float nd[3] = {fmaf(m, hx, r->d[0]), fmaf(m, hy, r->d[1]), fmaf(m, hz, fmaf(-2.0f, mu, r->d[2]))};
+    float m = root * (c2 * sgn);
+    float nd[3] = {fmaf(m, hx, r->d[0]), fmaf(m, hy, r->d[1]), fmaf(m, hz, fmaf(-2.0f * sgn, root, r->d[2]))};
     memcpy(r->d, nd, sizeof(nd));
   }
   r->p[0] = hx; r->p[1] = hy; r->p[2] = hz; r->r2 = r2;
@@ -212,10 +224,13 @@ static int stop_event(geo_ray* r, float dzv, float h2, float inv_h, const float*
 int geo_glass_event(float p[3], float d[3], float* w, float zv, float c, float h2, float eta,
                     int reflect, int forward) {
   /* absolute coordinates in and out: the ray "comes from" a vertex at z = 0 */
-  geo_ray r = {{p[0], p[1], p[2]}, {d[0], d[1], d[2]}, *w, 1.0f, fmaf(p[0], p[0], p[1] * p[1])};
-  int st = glass_event(&r, 0.0f - zv, c, c == 0.0f ? 0.0f : 1.0f / c, h2, eta, reflect, forward);
+  /* the caller speaks unit directions and an index ratio: arrive in a medium of index eta, leave into 1 */
+  geo_ray r = {{p[0], p[1], p[2]}, {eta * d[0], eta * d[1], eta * d[2]}, *w, 1.0f, fmaf(p[0], p[0], p[1] * p[1])};
+  int st = glass_event(&r, 0.0f - zv, c, c == 0.0f ? 0.0f : 1.0f / c, h2, eta, 1.0f, reflect, forward);
   p[0] = r.p[0]; p[1] = r.p[1]; p[2] = zv + r.p[2];
-  memcpy(d, r.d, sizeof(r.d)); *w = r.wn / r.wd;
+  const float back = reflect ? 1.0f / eta : 1.0f;   /* a reflected ray stays in the first medium */
+  d[0] = r.d[0] * back; d[1] = r.d[1] * back; d[2] = r.d[2] * back;
+  *w = r.wn / r.wd;
   return st;
 }
 
@@ -320,6 +335,7 @@ void geo_trace(const geo_lens* L, int W, int H, int y0, int y1, int spp, const u
           for (int q = 0; q < n_pairs; q++) {
             int n = build_sequence(L->n_surf, pairs[2 * q], pairs[2 * q + 1], seq);
             geo_ray r = r0;
+            { const float ns = D.n_start[l]; r.d[0] *= ns; r.d[1] *= ns; r.d[2] *= ns; }   /* K = n d */
             int st = OK_;
             float z_from = D.z_sensor;   /* vertex z of where the ray sits: the sensor, then each interface */
             c.rays_launched++;
@@ -330,7 +346,8 @@ void geo_trace(const geo_lens* L, int W, int H, int y0, int y1, int spp, const u
                 st = stop_event(&r, dzv, D.h2[k], D.inv_stop_h, mask, mw, mh);
               else
                 st = glass_event(&r, dzv, D.curv[k], L->radius[k], D.h2[k],
-                                 seq[e].forward ? D.eta_fwd[l][k] : D.eta_bwd[l][k], seq[e].reflect,
+                                 seq[e].forward ? D.n_before[l][k] : D.n_after[l][k],
+                                 seq[e].forward ? D.n_after[l][k] : D.n_before[l][k], seq[e].reflect,
                                  seq[e].forward);
               if (st != OK_) break;
               z_from = D.zv[k];
@@ -392,7 +409,8 @@ int geo_trace_ray(const geo_lens* L, int lambda, int i, int j, float p[3], float
   geo_step seq[3 * GEO_MAX_SURF];
   int n = build_sequence(L->n_surf, i, j, seq);
   /* absolute coordinates in and out; inside, z is relative to the sensor plane, then to each vertex */
-  geo_ray r = {{p[0], p[1], p[2] - D.z_sensor}, {d[0], d[1], d[2]}, *w, 1.0f, fmaf(p[0], p[0], p[1] * p[1])};
+  const float ns = D.n_start[lambda];   /* K = n d in the medium in front of the sensor */
+  geo_ray r = {{p[0], p[1], p[2] - D.z_sensor}, {d[0] * ns, d[1] * ns, d[2] * ns}, *w, 1.0f, fmaf(p[0], p[0], p[1] * p[1])};
   int st = OK_, ev = 0;
   float z_from = D.z_sensor;
   for (int e = 0; e < n; e++) {
@@ -400,7 +418,8 @@ int geo_trace_ray(const geo_lens* L, int lambda, int i, int j, float p[3], float
     float dzv = z_from - D.zv[k];
     if (k == L->stop) st = stop_event(&r, dzv, D.h2[k], D.inv_stop_h, mask, mw, mh);
     else st = glass_event(&r, dzv, D.curv[k], L->radius[k], D.h2[k],
-                          seq[e].forward ? D.eta_fwd[lambda][k] : D.eta_bwd[lambda][k],
+                          seq[e].forward ? D.n_before[lambda][k] : D.n_after[lambda][k],
+                          seq[e].forward ? D.n_after[lambda][k] : D.n_before[lambda][k],
                           seq[e].reflect, seq[e].forward);
     if (st != OK_) break;
     z_from = D.zv[k];
@@ -431,6 +450,7 @@ void geo_survival(const geo_lens* L, int W, int H, int y0, int y1, int spp, cons
       for (int q = 0; q < n_pairs; q++) {
         int n = build_sequence(L->n_surf, pairs[2 * q], pairs[2 * q + 1], seq);
         geo_ray r = r0;
+        { const float ns = D.n_start[l]; r.d[0] *= ns; r.d[1] *= ns; r.d[2] *= ns; }
         float z_from = D.z_sensor;
         alive[q * 33]++;
         for (int e = 0; e < n; e++) {
@@ -438,7 +458,8 @@ void geo_survival(const geo_lens* L, int W, int H, int y0, int y1, int spp, cons
           float dzv = z_from - D.zv[k];
           if (k == L->stop) st = stop_event(&r, dzv, D.h2[k], D.inv_stop_h, mask, mw, mh);
           else st = glass_event(&r, dzv, D.curv[k], L->radius[k], D.h2[k],
-                                seq[e].forward ? D.eta_fwd[l][k] : D.eta_bwd[l][k], seq[e].reflect,
+                                seq[e].forward ? D.n_before[l][k] : D.n_after[l][k],
+                                seq[e].forward ? D.n_after[l][k] : D.n_before[l][k], seq[e].reflect,
                                 seq[e].forward);
           if (st != OK_) break;
           z_from = D.zv[k];
