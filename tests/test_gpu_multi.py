@@ -236,3 +236,29 @@ def test_float_exchange_rounds_only_received_rows(pkg):
     with pytest.raises(pkg.LensFlareError):                    # one precision per group
         grp.gather(pkg.SAMPLE_BUFFER)
     grp.close()
+
+
+def test_tonemapped_frame_is_refreshed_by_an_exchange(pkg):
+    """write_to_framebuffer caches the rows it has tonemapped; an exchange changes rows of the sensor
+    buffer, so the cache must not survive it (round-2 advisor finding): before the gather a rank's
+    framebuffer shows its own tile rows only, after it the whole frame -- not the stale copy."""
+    lens = pkg.load_lens_file("dgauss11.lens")
+    mask = load_texels("pentbig500_14.png")
+    W, H, n = 72, 40, 2
+    one = pkg.LensFlare(0)
+    one.set_frame(W, H)
+    _setup(pkg, one, lens, mask)
+    _frame(one, 8, 13)
+    want = one.write_to_framebuffer(0, 0, W, H)
+    one.close()
+    grp = pkg.LensFlareGroup([0] * n)
+    grp.set_frame(W, H)
+    for r in grp.ranks:
+        _setup(pkg, r, lens, mask)
+    grp.for_each(lambda lf, rank: _frame(lf, 8, 13))
+    own = (np.arange(H) // 8) % n == 0
+    before = grp.ranks[0].write_to_framebuffer(0, 0, W, H)       # fills the cache with the partial frame
+    assert np.array_equal(before[own], want[own]) and not np.array_equal(before[~own], want[~own])
+    grp.gather(pkg.SAMPLE_BUFFER)
+    assert np.array_equal(grp.ranks[0].write_to_framebuffer(0, 0, W, H), want)
+    grp.close()
