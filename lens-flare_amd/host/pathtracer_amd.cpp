@@ -106,8 +106,16 @@ std::mutex g_mu;
 std::map<const PathTracer*, DeviceState> g_state;
 
 DeviceState& state(const PathTracer* pt) {
-  std::lock_guard<std::mutex> lock(g_mu);
-  return g_state[pt];
+  // (the workers call raytrace_pixel once per pixel: each thread remembers the entry it looked up last;
+  // map nodes do not move, and an entry lives as long as its PathTracer)
+  static thread_local const PathTracer* last_pt = nullptr;
+  static thread_local DeviceState* last_state = nullptr;
+  if (pt != last_pt || !last_state) {
+    std::lock_guard<std::mutex> lock(g_mu);
+    last_state = &g_state[pt];
+    last_pt = pt;
+  }
+  return *last_state;
 }
 
 void check(const DeviceState& s, lf_status st, const char* what) {
@@ -279,6 +287,11 @@ PathTracer::PathTracer() {
   ghost_buffer = HDRImageBuffer();
   bvh = NULL; scene = NULL; camera = NULL; envLight = NULL;
   DeviceState& s = state(this);
+  // (an entry outlives its PathTracer -- see the destructor -- so one at a recycled address starts afresh)
+  s.sample.clear(); s.rgba.clear(); s.star.clear();
+  s.star_ready = s.frame_ready = false;
+  s.textures_of = s.scene_of = s.env_of = nullptr;
+  s.lens_loaded.clear(); s.lens_w = s.lens_h = 0;
   const char* dev = getenv("LF_DEVICE");
   if (lf_create(&s.ctx, dev ? atoi(dev) : 0) != LF_OK) {
     fprintf(stderr, "[PathTracer/MI355X] no gfx950 device: this build has no CPU path\n");
@@ -298,7 +311,7 @@ PathTracer::~PathTracer() {
   auto it = g_state.find(this);
   if (it != g_state.end()) {
     if (it->second.ctx) lf_destroy(it->second.ctx);
-    g_state.erase(it);
+    it->second.ctx = nullptr;   // (the entry itself stays: another thread may still hold its address)
   }
 }
 
