@@ -27,7 +27,8 @@
 //   * the 4 waves of a workgroup share the tile and pull sample indices from an LDS counter;
 //     per-pixel sums are 64-bit fixed point in registers, merged through LDS, written once.
 //
-// Arithmetic contract (DESIGN.md "march arithmetic"): float32, every multiply-add written as an
+// Arithmetic contract (DESIGN.md "march arithmetic"): the ray's direction is carried as optical
+// direction cosines K = n d (round 3); float32, every multiply-add written as an
 // explicit fmaf, IEEE-correct division (__fdiv_rn), the hardware's v_sqrt_f32 (lf_sqrt; the oracle
 // follows it through a measured deviation table), no libm.  Contributions are accumulated as 2^-36
 // fixed point in 64-bit integers, so the result does not depend on the order in which lanes
@@ -76,7 +77,7 @@ __device__ __forceinline__ float u01(unsigned r) { return (float)(r >> 8) * 5.96
 // test has already computed and the next event's |o|^2 reuses.  A row carries dzv = (vertex z of the
 // interface the ray comes from) - (vertex z of this one): one add gives the origin's z in this
 // interface's frame, absolute z never exists (3 vector instructions per event less than tracking it,
-// and less cancellation).
+// and less cancellation).  (dx, dy, dz) is the OPTICAL direction K = n d (see surface_event).
 struct Ray {
   float px, py, hz, r2, dx, dy, dz, wn, wd;
 };
@@ -93,7 +94,7 @@ typedef unsigned long long lanemask;
 // W = false is the geometry-only march (positions, directions, liveness); W = true additionally
 // carries the Fresnel / aperture weight.  The frame runs W = false for every ray and repeats the
 // sequence with W = true only for the waves in which some lane ended inside the sun's lobe (~1 % of
-// the wave-sequences): the weight is 15 of the 71 VALU instructions of an event and is read by
+// the wave-sequences): the weight is ~16 vector instructions on top of an event's 27 and is read by
 // 0.4 % of the rays.  Both instantiations do the same arithmetic on the ray itself, so the
 // repeated march reproduces the first one bit for bit.
 // ch = c / 2 and c2 = 2 c travel with the row (exact scalings): F = c |o|^2 - 2 o_z is formed as its
