@@ -268,7 +268,9 @@ lf_status lf_scene_shade(lf_ctx* ctx, int what, const double ray[8], double t, c
  * which: 0 = sampleBuffer, 1 = ghost_buffer, 2 = the value of raytrace_starburst(x,y)
  * (pathtracer.cpp:947-1004: starburst + irradiance falloff) on its own, so that a host which
  * computes its scene radiance per pixel can form (scene + ghost) + starburst exactly like
- * pathtracer.cpp:891.  dst receives (x1-x0)*(y1-y0) pixels, each
+ * pathtracer.cpp:891; 3 = the scene-radiance term itself (what lf_render_scene_term or
+ * lf_set_scene_term left: the average of est_radiance_global_illumination over the pixel's camera
+ * rays, pathtracer.cpp:841-875; LF_ERR_STATE when there is none).  dst receives (x1-x0)*(y1-y0) pixels, each
  * `pixel_stride` doubles apart (3 = packed Vector3D, 4 = the AVX build's 32-byte Vector3D). */
 lf_status lf_read_tile(lf_ctx* ctx, int which, int x0, int y0, int x1, int y1, double* dst,
                        size_t pixel_stride);

@@ -21,7 +21,7 @@ DATA = os.path.join(HERE, "data")
 STATUS = {0: "LF_OK", 1: "LF_ERR_INVALID", 2: "LF_ERR_NO_DEVICE", 3: "LF_ERR_HIP",
           4: "LF_ERR_STATE", 5: "LF_ERR_OOM"}
 APERTURE_STARBURST, APERTURE_GHOST = 0, 1
-SAMPLE_BUFFER, GHOST_BUFFER, STARBURST_BUFFER = 0, 1, 2
+SAMPLE_BUFFER, GHOST_BUFFER, STARBURST_BUFFER, SCENE_BUFFER = 0, 1, 2, 3
 
 # every symbol include/lensflare.h declares
 ABI_SYMBOLS = [

@@ -224,7 +224,7 @@ lf_status lf_destroy(lf_ctx* ctx) {
   void* ptrs[] = {ctx->spectrum, ctx->twiddle, ctx->dft_rows, ctx->flares, ctx->ghosts, ctx->pl_dev,
                   ctx->lens_dev, ctx->pairs_dev, ctx->counters_dev, ctx->accum,
                   ctx->prog_dev, ctx->sun_lights_dev,
-                  ctx->scene_dev.nodes, ctx->scene_dev.prims, ctx->scene_dev.materials,
+                  ctx->scene_dev.nodes, ctx->scene_dev.prims, ctx->scene_dev.normals, ctx->scene_dev.materials,
                   ctx->scene_dev.lights, ctx->env_block};
   for (void* p : ptrs) if (p) (void)hipFree(p);
   if (ctx->own_stream && ctx->stream) (void)hipStreamDestroy(ctx->stream);
@@ -575,12 +575,14 @@ lf_status lf_render_flare_layer(lf_ctx* ctx) {
 
 lf_status lf_read_tile(lf_ctx* ctx, int which, int x0, int y0, int x1, int y1, double* dst,
                        size_t pixel_stride) {
-  if (!ctx || !dst || which < 0 || which > 2 || pixel_stride < 3) return LF_ERR_INVALID;
+  if (!ctx || !dst || which < 0 || which > 3 || pixel_stride < 3) return LF_ERR_INVALID;
   if (ctx->W == 0) return lf_fail(ctx, LF_ERR_STATE, "lf_read_tile before lf_set_frame");
+  if (which == 3 && !ctx->scene)
+    return lf_fail(ctx, LF_ERR_STATE, "lf_read_tile(LF_SCENE_BUFFER) before lf_render_scene_term / lf_set_scene_term");
   if (x0 < 0 || y0 < 0 || x1 > ctx->W || y1 > ctx->H || x0 > x1 || y0 > y1)
     return lf_fail(ctx, LF_ERR_INVALID, "tile out of range");
   if (x0 == x1 || y0 == y1) return LF_OK;
-  const double* src = which == 0 ? ctx->sample : which == 1 ? ctx->ghost : ctx->star;
+  const double* src = which == 0 ? ctx->sample : which == 1 ? ctx->ghost : which == 2 ? ctx->star : ctx->scene;
   { const lf_status js = lf_comm_join(ctx); if (js != LF_OK) return js; }
   LF_HIP(ctx, hipStreamSynchronize(ctx->stream));
   const size_t tw = (size_t)(x1 - x0);

@@ -59,26 +59,8 @@ struct LfCamera {
   double n_clip = 0.01, f_clip = 100.0;  // Camera::nClip / fClip (camera.h:188)
 };
 
-// ---- scene term (row f2) ------------------------------------------------------------------
-struct LfBvhNode { double bmin[3], bmax[3]; int left, right, first, count; };  // leaf: count > 0
-struct LfPrim { int type, material; double d[18]; };  // sphere: c(3) r r^2; triangle: 3 pos + 3 normals
-struct LfMaterial { int kind, pad; double rgb[3]; };   // 0 diffuse (reflectance), 1 emission (radiance)
-// 0 directional (v = dirToLight), 1 point (v = position), 2 infinite hemisphere, 3 area (v = position,
-// dir, dim_x, dim_y, area = |dim_x| |dim_y|: scene/light.h:80-97)
-struct LfLight { int type, pad; double v[3], rgb[3], dir[3], dim_x[3], dim_y[3], area; };
-struct LfSceneDev {
-  LfBvhNode* nodes; LfPrim* prims; LfMaterial* materials; LfLight* lights;
-  int n_nodes, n_prims, n_materials, n_lights;
-  int n_soft_lights;   // lights that are sampled (hemisphere, area, environment): they need the counter RNG
-  int n_env_lights;    // lights of type 4 (they need lf_set_environment_map)
-};
-// EnvironmentLight (scene/environment_light.cpp): the map (HDRImageBuffer::data, w*h RGB doubles)
-// and the tables its init() derives (:19-59), built on the host in the reference's order of
-// operations; w = 0: no environment
-struct LfEnvDev {
-  const double* data; const double* pdf; const double* conds; const double* marginal;
-  int w, h;
-};
+// ---- scene term (row f2): LfSceneDev, LfEnvDev and what they point at ---------------------
+#include "lf_scene_types.h"
 
 // per-wavelength starburst (row f4): n = 0 is the reference's monochrome starburst
 struct LfStarSpectrum {

@@ -22,6 +22,7 @@
 // the Mirror/Glass/Microfacet BSDFs, which are unfilled stubs in the reference (advanced_bsdf.cpp).
 #include <algorithm>
 #include <cmath>
+#include <cstdlib>
 #include <cstring>
 
 #include "lf_internal.h"
@@ -45,12 +46,44 @@ __device__ inline double norm(V3 a) { return sqrt(dot(a, a)); }
 __device__ inline V3 unit(V3 a) { double rn = 1. / norm(a); return a * rn; }
 __device__ inline V3 divs(V3 a, double c) { const double rc = 1.0 / c; return v3(rc * a.x, rc * a.y, rc * a.z); }
 
-struct DRay { V3 o, d; double min_t, max_t; };
-struct Hit { double t; V3 n; int material; };
+// A ray as the traversal keeps it: the reference's Ray (o, d, min_t, max_t in double: every primitive
+// test uses exactly these) plus what the box tests use -- floats that BRACKET the doubles.
+struct DRay {
+  V3 o, d; double min_t, max_t;
+  float olx, oly, olz, ohx, ohy, ohz;  // o rounded down / up
+  float ix, iy, iz;                    // 1 / d; NaN when |1 / d| is no finite float: the axis then never culls
+  float tmin_c, tmax_c;                // min_t / max_t, widened by the box test's slack
+};
+// the closest hit so far: primitive + what its test produced; the normal is formed ONCE, at the end
+struct Hit { double t, b1, b2; int prim; };
+
+__device__ inline float f32_down(double x) { const float f = (float)x; return (double)f > x ? nextafterf(f, -INFINITY) : f; }
+__device__ inline float f32_up(double x) { const float f = (float)x; return (double)f < x ? nextafterf(f, INFINITY) : f; }
+__device__ inline float inv_dir(double d) {
+  const double q = 1.0 / d;           // d = 0: +-inf, which culls correctly (a ray parallel to a slab)
+  return (d != 0.0 && fabs(q) > 3.0e38) ? __int_as_float(0x7fc00000) : (float)q;
+}
+// max_t shrinks with every accepted hit: the float bound follows (2^-20 relative + 1e-30 absolute:
+// four times what the box test's own rounding can be off, see box_miss)
+__device__ inline void widen_max_t(DRay& r) {
+  const float m = f32_up(r.max_t);
+  r.tmax_c = fmaf(9.6e-7f, fabsf(m), m) + 1e-30f;
+}
+__device__ inline DRay make_ray(V3 o, V3 d, double min_t, double max_t) {
+  DRay r;
+  r.o = o; r.d = d; r.min_t = min_t; r.max_t = max_t;
+  r.olx = f32_down(o.x); r.oly = f32_down(o.y); r.olz = f32_down(o.z);
+  r.ohx = f32_up(o.x); r.ohy = f32_up(o.y); r.ohz = f32_up(o.z);
+  r.ix = inv_dir(d.x); r.iy = inv_dir(d.y); r.iz = inv_dir(d.z);
+  const float m = f32_down(min_t);
+  r.tmin_c = fmaf(-9.6e-7f, fabsf(m), m) - 1e-30f;
+  widen_max_t(r);
+  return r;
+}
 
 // ---- primitives ------------------------------------------------------------------------------
 // Sphere::test + intersect (scene/sphere.cpp:11-111)
-__device__ inline bool hit_sphere(const LfPrim& s, DRay& r, Hit* h) {
+__device__ inline bool hit_sphere(const LfPrim& s, int idx, DRay& r, Hit* h) {
   const V3 c = v3(s.d[0], s.d[1], s.d[2]);
   const V3 oc = r.o - c;
   const double a = dot(r.d, r.d);
@@ -75,16 +108,12 @@ __device__ inline bool hit_sphere(const LfPrim& s, DRay& r, Hit* h) {
     }
   }
   r.max_t = t1;
-  if (h) {
-    h->t = t1;
-    h->n = unit((r.o + t1 * r.d) - c);  // Sphere::normal (sphere.h:73-75)
-    h->material = s.material;
-  }
+  if (h) { h->t = t1; h->prim = idx; }
   return true;
 }
 
 // moller_trumbore + is_valid_intersection + Triangle::intersect (scene/triangle.cpp:25-112)
-__device__ inline bool hit_triangle(const LfPrim& t, DRay& r, Hit* h) {
+__device__ inline bool hit_triangle(const LfPrim& t, int idx, DRay& r, Hit* h) {
   const V3 p0 = v3(t.d[0], t.d[1], t.d[2]), p1 = v3(t.d[3], t.d[4], t.d[5]), p2 = v3(t.d[6], t.d[7], t.d[8]);
   const V3 e1 = p1 - p0, e2 = p2 - p0, s = r.o - p0;
   const V3 s1 = cross(r.d, e2), s2 = cross(s, e1);
@@ -95,57 +124,87 @@ __device__ inline bool hit_triangle(const LfPrim& t, DRay& r, Hit* h) {
   if (b2 < 0 || b2 > 1) return false;
   if (b1 + b2 > 1) return false;
   r.max_t = tt;
-  if (h) {
-    const double b0 = 1 - b1 - b2;
-    const V3 n1 = v3(t.d[9], t.d[10], t.d[11]), n2 = v3(t.d[12], t.d[13], t.d[14]),
-             n3 = v3(t.d[15], t.d[16], t.d[17]);
-    h->t = tt;
-    h->n = unit((b0 * n1 + b1 * n2) + b2 * n3);
-    h->material = t.material;
-  }
+  if (h) { h->t = tt; h->b1 = b1; h->b2 = b2; h->prim = idx; }
   return true;
+}
+
+// the closest hit's surface normal and material: Sphere::normal (sphere.h:73-75) at o + t d, or the
+// triangle's barycentric blend (triangle.cpp:100-105)
+__device__ inline V3 hit_normal(const LfSceneDev& sc, const DRay& r, const Hit& h, int* material) {
+  const LfPrim& p = sc.prims[h.prim];
+  *material = p.material;
+  if (p.type == 0) return unit((r.o + h.t * r.d) - v3(p.d[0], p.d[1], p.d[2]));
+  const LfPrimNormals& q = sc.normals[h.prim];
+  const double b0 = 1 - h.b1 - h.b2;
+  const V3 n1 = v3(q.n[0], q.n[1], q.n[2]), n2 = v3(q.n[3], q.n[4], q.n[5]), n3 = v3(q.n[6], q.n[7], q.n[8]);
+  return unit((b0 * n1 + h.b1 * n2) + h.b2 * n3);
+}
+
+// BBox::intersect (scene/bbox.cpp:12-49) as a conservative float test: true only when the DOUBLE ray
+// provably misses the DOUBLE box or leaves it outside [min_t, max_t].
+//   (lo - oh) <= lo - o and (hi - ol) >= hi - o exactly (box rounded outward, origin bracketed), so
+//   after the multiplication by 1 / d the smaller product bounds the entry from below and the larger
+//   one the exit from above, each off by at most 3 roundings (2^-24 each, relative) + underflow.
+// tn > tf is decided with 2^-21 (|tn| + |tf|) + 1e-30 of slack, the two ends against bounds that were
+// widened once per ray (make_ray / widen_max_t).  fminf / fmaxf drop NaNs (0 * inf on a slab plane, an
+// axis without a usable reciprocal): that only makes the test more permissive.  The sum of the
+// magnitudes is clamped so that an infinite entry (a ray parallel to a slab and outside it) still
+// compares as "misses" instead of inf > inf.
+__device__ inline bool box_miss(const DRay& r, float lx, float ly, float lz, float hx, float hy, float hz,
+                                float* entry) {
+  const float ax = (lx - r.ohx) * r.ix, bx = (hx - r.olx) * r.ix;
+  const float ay = (ly - r.ohy) * r.iy, by = (hy - r.oly) * r.iy;
+  const float az = (lz - r.ohz) * r.iz, bz = (hz - r.olz) * r.iz;
+  const float tn = fmaxf(fmaxf(fminf(ax, bx), fminf(ay, by)), fminf(az, bz));
+  const float tf = fminf(fminf(fmaxf(ax, bx), fmaxf(ay, by)), fmaxf(az, bz));
+  const float mag = fminf(fabsf(tn) + fabsf(tf), 3.0e38f);
+  *entry = tn;
+  return (tn - tf > fmaf(4.8e-7f, mag, 1e-30f)) || tf < r.tmin_c || tn > r.tmax_c;
 }
 
 // closest hit (BVHAccel::intersect, scene/bvh.cpp:201-222: the recursion shrinks r.max_t as it goes,
 // so whatever the visiting order the last accepted primitive is the closest one).  h == nullptr is
 // the shadow-ray query (has_intersection): the first accepted primitive settles it.
-// The traversal stack lives in LDS ([depth][thread]: conflict-free), not in scratch memory; the slab
-// test multiplies by the reciprocal direction (3 f64 divisions per ray instead of 6 per node) and is
-// widened by 2 ulp so that it can only be MORE permissive than the exact quotients -- the box test
-// is pure culling, every accepted leaf still runs the reference's exact primitive tests.
-constexpr int kStackDepth = 32;
-__device__ bool closest_hit(const LfBvhNode* __restrict__ nodes, const LfPrim* __restrict__ prims,
-                            DRay& r, Hit* h, int* __restrict__ stack /* [kStackDepth][256] + tid */) {
-  int sp = 0;
-  stack[256 * sp++] = 0;
+// A node visit tests the boxes of both children (LfBvhNode) and descends into the nearer one first:
+// the nearer subtree usually holds the closest hit, which then culls the farther one when it is
+// popped.  The stack of deferred children lives in LDS ([depth][thread]: conflict-free), not in
+// scratch memory; it holds one entry per level at most (the host refuses deeper trees).
+constexpr int kStackDepth = 24;
+__device__ bool closest_hit(const LfSceneDev& sc, DRay& r, Hit* h, int* __restrict__ stack /* [kStackDepth][256] + tid */) {
+  int sp = 0, cur = 0;
   bool any = false;
-  const double ix = 1.0 / r.d.x, iy = 1.0 / r.d.y, iz = 1.0 / r.d.z;
-  while (sp > 0) {
-    const LfBvhNode& nd = nodes[stack[256 * --sp]];
-    // BBox::intersect (scene/bbox.cpp:12-49); fmin/fmax drop NaNs (0 * inf on a slab plane), which
-    // only makes the test more permissive
-    const double tx1 = (nd.bmin[0] - r.o.x) * ix, tx2 = (nd.bmax[0] - r.o.x) * ix;
-    const double ty1 = (nd.bmin[1] - r.o.y) * iy, ty2 = (nd.bmax[1] - r.o.y) * iy;
-    const double tz1 = (nd.bmin[2] - r.o.z) * iz, tz2 = (nd.bmax[2] - r.o.z) * iz;
-    const double tmin = fmax(fmax(fmin(tx1, tx2), fmin(ty1, ty2)), fmin(tz1, tz2));
-    const double tmax = fmin(fmin(fmax(tx1, tx2), fmax(ty1, ty2)), fmax(tz1, tz2));
-    // (an infinite bound -- a ray parallel to a slab and outside it has tmin = +inf -- must not turn
-    // the slack into inf: inf - inf compares false with everything and the box would never be culled;
-    // such rays, e.g. the texel-grid directions of an environment light, then walk the whole tree)
-    const double tm = fmax(fabs(tmin), fabs(tmax));
-    const double slack = tm < 1e300 ? 4.5e-16 * tm : 0.0;
-    if (tmin - slack > tmax + slack || tmax + slack < r.min_t || tmin - slack > r.max_t) continue;
-    if (nd.count > 0) {
-      for (int i = 0; i < nd.count; i++) {
-        const LfPrim& p = prims[nd.first + i];
-        const bool hit = p.type == 0 ? hit_sphere(p, r, h) : hit_triangle(p, r, h);
-        any = any || hit;
+  for (;;) {
+    if (cur >= 0) {
+      const float4* __restrict__ q = reinterpret_cast<const float4*>(sc.nodes + cur);
+      const float4 q0 = q[0], q1 = q[1], q2 = q[2];
+      const int2 ch = *reinterpret_cast<const int2*>(q + 3);
+      float t0, t1;
+      const bool m0 = box_miss(r, q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, &t0) || ch.x == kLfNoChild;
+      const bool m1 = box_miss(r, q1.z, q1.w, q2.x, q2.y, q2.z, q2.w, &t1) || ch.y == kLfNoChild;
+      if (!m0 && !m1) {
+        const bool second_first = t1 < t0;
+        stack[256 * sp++] = second_first ? ch.x : ch.y;
+        cur = second_first ? ch.y : ch.x;
+        continue;
       }
-      if (any && !h) return true;
+      if (!m0) { cur = ch.x; continue; }
+      if (!m1) { cur = ch.y; continue; }
     } else {
-      // (left < 0: the childless node of an empty scene, should a ray ever pass its degenerate box)
-      if (nd.left >= 0 && sp < kStackDepth - 1) { stack[256 * sp++] = nd.right; stack[256 * sp++] = nd.left; }
+      const int code = ~cur, first = code >> 2, count = (code & 3) + 1;
+      bool hit_here = false;
+      for (int i = 0; i < count; i++) {
+        const LfPrim& p = sc.prims[first + i];
+        const bool hit = p.type == 0 ? hit_sphere(p, first + i, r, h) : hit_triangle(p, first + i, r, h);
+        hit_here = hit_here || hit;
+      }
+      if (hit_here) {
+        if (!h) return true;
+        any = true;
+        widen_max_t(r);
+      }
     }
+    if (sp == 0) break;
+    cur = stack[256 * --sp];
   }
   return any;
 }
@@ -234,10 +293,10 @@ __device__ V3 shade_hit(const LfSceneDev& sc, const LfEnvDev& ev, bool hemispher
       // o2w * wi: the columns of o2w are X, Y, Z
       const V3 ww = v3((wi.x * X.x + wi.y * Y.x) + wi.z * Z.x, (wi.x * X.y + wi.y * Y.y) + wi.z * Z.y,
                        (wi.x * X.z + wi.y * Y.z) + wi.z * Z.z);
-      DRay out{hit_p, ww, kEpsF, INFINITY};
+      DRay out = make_ray(hit_p, ww, kEpsF, INFINITY);
       Hit h2;
-      if (closest_hit(sc.nodes, sc.prims, out, &h2, stack)) {
-        const LfMaterial& m2 = sc.materials[h2.material];
+      if (closest_hit(sc, out, &h2, stack)) {
+        const LfMaterial& m2 = sc.materials[sc.prims[h2.prim].material];
         const V3 em2 = m2.kind == 1 ? v3(m2.rgb[0], m2.rgb[1], m2.rgb[2]) : v3(0, 0, 0);
         const double cos_theta = unit(wi).z;
         L = L + divs(mulv(f, em2) * cos_theta, p_w);
@@ -302,8 +361,8 @@ __device__ V3 shade_hit(const LfSceneDev& sc, const LfEnvDev& ev, bool hemispher
       const V3 wo = v3((wi.x * X.x + wi.y * X.y) + wi.z * X.z, (wi.x * Y.x + wi.y * Y.y) + wi.z * Y.z,
                        (wi.x * Z.x + wi.y * Z.y) + wi.z * Z.z);
       if (wo.z < 0) continue;
-      DRay sh{hit_p, wi, kEpsF, dist - kEpsF};
-      if (!closest_hit(sc.nodes, sc.prims, sh, nullptr, stack)) {
+      DRay sh = make_ray(hit_p, wi, kEpsF, dist - kEpsF);
+      if (!closest_hit(sc, sh, nullptr, stack)) {
         const double cos_theta = unit(wo).z;
         L = L + divs(mulv(f, emit) * cos_theta, pdf);  // / pdf (1 for delta lights)
       }
@@ -317,9 +376,11 @@ template <bool SOFT>
 __device__ V3 radiance(const LfSceneDev& sc, const LfEnvDev& ev, bool hemisphere, DRay r,
                        int* __restrict__ stack, int ns_area_light, uint4 rng_ctr, uint2 rng_key) {
   Hit isect;
-  if (!closest_hit(sc.nodes, sc.prims, r, &isect, stack))   // pathtracer.cpp:291-292
+  if (!closest_hit(sc, r, &isect, stack))   // pathtracer.cpp:291-292
     return (SOFT && ev.w) ? env_sample_dir(ev, r.d) : v3(0, 0, 0);
-  return shade_hit<SOFT>(sc, ev, hemisphere, r, isect.t, isect.n, sc.materials[isect.material],
+  int material;
+  const V3 n = hit_normal(sc, r, isect, &material);
+  return shade_hit<SOFT>(sc, ev, hemisphere, r, isect.t, n, sc.materials[material],
                          kShadeZero | kShadeOne, stack, ns_area_light, rng_ctr, rng_key);
 }
 
@@ -359,12 +420,17 @@ __global__ __launch_bounds__(256, 4) void k_scene_term(LfSceneDev sc, LfEnvDev e
   // deep (<= 29), the stack holds at most depth + 1 entries
   __shared__ int s_stack[kStackDepth * 256];
   int* const stack = s_stack + threadIdx.x;
-  const size_t p = (size_t)y0 * W + (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (p >= (size_t)y1 * W) return;
-  const int x = (int)(p % W), y = (int)(p / W);
+  // a wave = one 8 x 8 pixel tile (its 64 camera rays walk the same part of the tree: fewer divergent
+  // visits and better hit rates in the vector cache than a 64 x 1 strip), a workgroup = 4 tiles side by
+  // side; blockIdx.y counts 8-row tile rows from the one that holds y0
+  const int lane = threadIdx.x & 63;
+  const int x = ((int)blockIdx.x * 4 + ((int)threadIdx.x >> 6)) * 8 + (lane & 7);
+  const int y = ((y0 >> 3) + (int)blockIdx.y) * 8 + (lane >> 3);
+  if (x >= W || y < y0 || y >= y1) return;
   // multi-GPU: only the 8-row tile rows this context owns, like k_flare_layer, which is the only
-  // reader of this buffer (whole waves leave: 64 consecutive pixels share a tile row unless W < 64)
+  // reader of this buffer (whole workgroups leave)
   if (row_period > 1 && (y >> 3) % row_period != row_phase) return;
+  const size_t p = (size_t)y * W + x;
   const double PI_ = 3.14159265358979323;
   const double edge_x = tan(0.5 * (cam.hfov_deg * (PI_ / 180.0)));
   const double edge_y = tan(0.5 * (cam.vfov_deg * (PI_ / 180.0)));
@@ -387,12 +453,11 @@ __global__ __launch_bounds__(256, 4) void k_scene_term(LfSceneDev sc, LfEnvDev e
     const double nx = sx / (double)W, ny = sy / (double)H;
     // Camera::generate_ray (camera.cpp:278-305)
     V3 dir = unit(v3(edge_x * (2 * nx - 1), edge_y * (2 * ny - 1), -1));
-    DRay r;
-    r.o = v3(cam.pos[0], cam.pos[1], cam.pos[2]);
-    r.d = v3((dir.x * cam.c2w[0] + dir.y * cam.c2w[1]) + dir.z * cam.c2w[2],
-             (dir.x * cam.c2w[3] + dir.y * cam.c2w[4]) + dir.z * cam.c2w[5],
-             (dir.x * cam.c2w[6] + dir.y * cam.c2w[7]) + dir.z * cam.c2w[8]);
-    r.min_t = cam.n_clip; r.max_t = cam.f_clip;
+    const DRay r = make_ray(v3(cam.pos[0], cam.pos[1], cam.pos[2]),
+                            v3((dir.x * cam.c2w[0] + dir.y * cam.c2w[1]) + dir.z * cam.c2w[2],
+                               (dir.x * cam.c2w[3] + dir.y * cam.c2w[4]) + dir.z * cam.c2w[5],
+                               (dir.x * cam.c2w[6] + dir.y * cam.c2w[7]) + dir.z * cam.c2w[8]),
+                            cam.n_clip, cam.f_clip);
     const V3 L = radiance<SOFT>(sc, ev, hemisphere != 0, r, stack, ns_area_light, make_uint4((unsigned)p, (unsigned)sample, 0u, 0u),
                           make_uint2((unsigned)key, (unsigned)(key >> 32)));
     // Vector3D::illum (vector3D.h:231-233): float coefficients, double arithmetic, float result
@@ -420,14 +485,16 @@ __global__ void k_scene_trace_ray(LfSceneDev sc, LfEnvDev ev, int hemisphere, Lf
                                   int ns_area_light, uint64_t seq, uint64_t key, double* __restrict__ out) {
   __shared__ int s_stack[kStackDepth * 256];
   if (threadIdx.x != 0) return;
-  DRay r{v3(pr.o[0], pr.o[1], pr.o[2]), v3(pr.d[0], pr.d[1], pr.d[2]), pr.min_t, pr.max_t};
+  DRay r = make_ray(v3(pr.o[0], pr.o[1], pr.o[2]), v3(pr.d[0], pr.d[1], pr.d[2]), pr.min_t, pr.max_t);
   const uint4 ctr = make_uint4((unsigned)seq, (unsigned)(seq >> 32) | 0x80000000u, 0u, 0u);
   const uint2 k2 = make_uint2((unsigned)key, (unsigned)(key >> 32));
   Hit h;
   V3 L;
-  if (closest_hit(sc.nodes, sc.prims, r, &h, s_stack)) {
-    out[0] = 1.0; out[1] = h.t; out[2] = h.n.x; out[3] = h.n.y; out[4] = h.n.z;
-    L = shade_hit<true>(sc, ev, hemisphere != 0, r, h.t, h.n, sc.materials[h.material], kShadeZero | kShadeOne,
+  if (closest_hit(sc, r, &h, s_stack)) {
+    int material;
+    const V3 n = hit_normal(sc, r, h, &material);
+    out[0] = 1.0; out[1] = h.t; out[2] = n.x; out[3] = n.y; out[4] = n.z;
+    L = shade_hit<true>(sc, ev, hemisphere != 0, r, h.t, n, sc.materials[material], kShadeZero | kShadeOne,
                         s_stack, ns_area_light, ctr, k2);
   } else {
     out[0] = 0.0; out[1] = out[2] = out[3] = out[4] = 0.0;
@@ -442,62 +509,128 @@ __global__ void k_scene_shade(LfSceneDev sc, LfEnvDev ev, int hemisphere, LfProb
                               int ns_area_light, uint64_t seq, uint64_t key, double* __restrict__ out) {
   __shared__ int s_stack[kStackDepth * 256];
   if (threadIdx.x != 0) return;
-  const DRay r{v3(pr.o[0], pr.o[1], pr.o[2]), v3(pr.d[0], pr.d[1], pr.d[2]), pr.min_t, pr.max_t};
+  const DRay r = make_ray(v3(pr.o[0], pr.o[1], pr.o[2]), v3(pr.d[0], pr.d[1], pr.d[2]), pr.min_t, pr.max_t);
   const V3 L = shade_hit<true>(sc, ev, hemisphere != 0, r, t, v3(nx, ny, nz), m, what, s_stack, ns_area_light,
                                make_uint4((unsigned)seq, (unsigned)(seq >> 32) | 0x80000000u, 0u, 0u),
                                make_uint2((unsigned)key, (unsigned)(key >> 32)));
   out[0] = L.x; out[1] = L.y; out[2] = L.z;
 }
 
-// ---- host: BVH over the primitives (median split of the centroids along the widest axis) -----
+// ---- host: BVH over the primitives ------------------------------------------------------------
+// The closest hit does not depend on the tree, only the amount of work does (the
+// reference's own tree, scene/bvh.cpp:60-170, is not reproduced).  Binned surface-area heuristic over
+// the centroids (16 bins per axis), leaves of <= 4 primitives; a split that would leave one side empty
+// (coincident centroids) falls back to the median.
 struct Box { double mn[3], mx[3]; };
+struct HostPrim { int type, material; double d[18]; Box box; double cen[3]; };
+struct HostNode { Box box; int left, right, first, count; };   // leaf: left < 0
 
-Box prim_box(const LfPrim& p) {
-  Box b;
+void grow(Box& b, const Box& o) {
+  for (int a = 0; a < 3; a++) { b.mn[a] = std::min(b.mn[a], o.mn[a]); b.mx[a] = std::max(b.mx[a], o.mx[a]); }
+}
+Box empty_box() { Box b; for (int a = 0; a < 3; a++) { b.mn[a] = INFINITY; b.mx[a] = -INFINITY; } return b; }
+double half_area(const Box& b) {
+  const double x = b.mx[0] - b.mn[0], y = b.mx[1] - b.mn[1], z = b.mx[2] - b.mn[2];
+  return x * y + y * z + z * x;
+}
+
+void set_prim_box(HostPrim& p) {
   if (p.type == 0) {
-    for (int a = 0; a < 3; a++) { b.mn[a] = p.d[a] - p.d[3]; b.mx[a] = p.d[a] + p.d[3]; }
+    for (int a = 0; a < 3; a++) { p.box.mn[a] = p.d[a] - p.d[3]; p.box.mx[a] = p.d[a] + p.d[3]; }
   } else {
     for (int a = 0; a < 3; a++) {
-      b.mn[a] = std::min({p.d[a], p.d[3 + a], p.d[6 + a]});
-      b.mx[a] = std::max({p.d[a], p.d[3 + a], p.d[6 + a]});
+      p.box.mn[a] = std::min({p.d[a], p.d[3 + a], p.d[6 + a]});
+      p.box.mx[a] = std::max({p.d[a], p.d[3 + a], p.d[6 + a]});
     }
   }
-  return b;
+  for (int a = 0; a < 3; a++) p.cen[a] = 0.5 * (p.box.mn[a] + p.box.mx[a]);
 }
 
 // returns the node id; *depth = levels below (and including) this node
-int build_node(std::vector<LfBvhNode>& nodes, std::vector<LfPrim>& prims, int first, int count,
+int build_node(std::vector<HostNode>& nodes, std::vector<HostPrim>& prims, int first, int count, bool sah,
                int* depth) {
-  LfBvhNode nd;
-  for (int a = 0; a < 3; a++) { nd.bmin[a] = INFINITY; nd.bmax[a] = -INFINITY; }
+  HostNode nd;
+  nd.box = empty_box();
   double cmn[3] = {INFINITY, INFINITY, INFINITY}, cmx[3] = {-INFINITY, -INFINITY, -INFINITY};
   for (int i = first; i < first + count; i++) {
-    Box b = prim_box(prims[i]);
-    for (int a = 0; a < 3; a++) {
-      nd.bmin[a] = std::min(nd.bmin[a], b.mn[a]); nd.bmax[a] = std::max(nd.bmax[a], b.mx[a]);
-      double c = 0.5 * (b.mn[a] + b.mx[a]);
-      cmn[a] = std::min(cmn[a], c); cmx[a] = std::max(cmx[a], c);
-    }
+    grow(nd.box, prims[i].box);
+    for (int a = 0; a < 3; a++) { cmn[a] = std::min(cmn[a], prims[i].cen[a]); cmx[a] = std::max(cmx[a], prims[i].cen[a]); }
   }
   nd.left = nd.right = -1; nd.first = first; nd.count = count;
   const int id = (int)nodes.size();
   nodes.push_back(nd);
-  if (depth) *depth = 1;
+  *depth = 1;
   if (count <= 4) return id;
-  int axis = 0;
-  for (int a = 1; a < 3; a++) if (cmx[a] - cmn[a] > cmx[axis] - cmn[axis]) axis = a;
-  const int mid = first + count / 2;
-  std::nth_element(prims.begin() + first, prims.begin() + mid, prims.begin() + first + count,
-                   [axis](const LfPrim& a, const LfPrim& b) {
-                     Box ba = prim_box(a), bb = prim_box(b);
-                     return ba.mn[axis] + ba.mx[axis] < bb.mn[axis] + bb.mx[axis];
-                   });
+  int mid = -1;
+  if (sah) {
+    constexpr int kBins = 16;
+    double best = INFINITY; int best_axis = -1, best_bin = -1;
+    for (int a = 0; a < 3; a++) {
+      const double ext = cmx[a] - cmn[a];
+      if (!(ext > 0) || !std::isfinite(ext)) continue;
+      Box bb[kBins]; int bn[kBins];
+      for (int k = 0; k < kBins; k++) { bb[k] = empty_box(); bn[k] = 0; }
+      const double scale = kBins / ext;
+      for (int i = first; i < first + count; i++) {
+        const int k = std::min(kBins - 1, std::max(0, (int)((prims[i].cen[a] - cmn[a]) * scale)));
+        grow(bb[k], prims[i].box); bn[k]++;
+      }
+      double right_area[kBins]; int right_n[kBins];
+      Box acc = empty_box(); int n = 0;
+      for (int k = kBins - 1; k > 0; k--) { grow(acc, bb[k]); n += bn[k]; right_area[k] = n ? half_area(acc) : 0.0; right_n[k] = n; }
+      acc = empty_box(); n = 0;
+      for (int k = 0; k + 1 < kBins; k++) {   // split between bin k and k + 1
+        grow(acc, bb[k]); n += bn[k];
+        if (n == 0 || right_n[k + 1] == 0) continue;
+        const double cost = half_area(acc) * n + right_area[k + 1] * right_n[k + 1];
+        if (cost < best) { best = cost; best_axis = a; best_bin = k; }
+      }
+    }
+    if (best_axis >= 0) {
+      const int a = best_axis;
+      const double scale = kBins / (cmx[a] - cmn[a]), c0 = cmn[a];
+      const int kb = best_bin;
+      auto it = std::partition(prims.begin() + first, prims.begin() + first + count, [=](const HostPrim& p) {
+        return std::min(kBins - 1, std::max(0, (int)((p.cen[a] - c0) * scale))) <= kb;
+      });
+      mid = (int)(it - prims.begin());
+      if (mid == first || mid == first + count) mid = -1;
+    }
+  }
+  if (mid < 0) {   // median of the centroids along the widest axis
+    int axis = 0;
+    for (int a = 1; a < 3; a++) if (cmx[a] - cmn[a] > cmx[axis] - cmn[axis]) axis = a;
+    mid = first + count / 2;
+    std::nth_element(prims.begin() + first, prims.begin() + mid, prims.begin() + first + count,
+                     [axis](const HostPrim& a, const HostPrim& b) { return a.cen[axis] < b.cen[axis]; });
+  }
   int dl = 0, dr = 0;
-  const int l = build_node(nodes, prims, first, mid - first, &dl);
-  const int r = build_node(nodes, prims, mid, first + count - mid, &dr);
-  nodes[id].left = l; nodes[id].right = r; nodes[id].count = 0;
-  if (depth) *depth = 1 + std::max(dl, dr);
+  const int l = build_node(nodes, prims, first, mid - first, sah, &dl);
+  const int r = build_node(nodes, prims, mid, first + count - mid, sah, &dr);
+  nodes[id].left = l; nodes[id].right = r;
+  *depth = 1 + std::max(dl, dr);
   return id;
+}
+
+float round_down(double x) { const float f = (float)x; return (double)f > x ? std::nextafter(f, -INFINITY) : f; }
+float round_up(double x) { const float f = (float)x; return (double)f < x ? std::nextafter(f, INFINITY) : f; }
+
+// the device form: one LfBvhNode per inner node, holding its children's boxes (rounded outward) and
+// either their node index or their leaf range; depth-first, so a subtree is contiguous
+int flatten(const std::vector<HostNode>& h, int id, std::vector<LfBvhNode>& out) {
+  const int me = (int)out.size();
+  out.emplace_back();
+  std::memset(&out[me], 0, sizeof(LfBvhNode));
+  const int kids[2] = {h[id].left, h[id].right};
+  for (int k = 0; k < 2; k++) {
+    const HostNode& c = h[kids[k]];
+    float* lo = k == 0 ? out[me].lo0 : out[me].lo1;
+    float* hi = k == 0 ? out[me].hi0 : out[me].hi1;
+    for (int a = 0; a < 3; a++) { lo[a] = round_down(c.box.mn[a]); hi[a] = round_up(c.box.mx[a]); }
+    const int ref = c.left < 0 ? ~(c.first * 4 + (c.count - 1)) : flatten(h, kids[k], out);
+    out[me].child[k] = ref;   // (out may have been reallocated by the recursion: index, not pointer)
+  }
+  return me;
 }
 
 // one wave writes `n_out` doubles, which come straight back
@@ -536,22 +669,27 @@ lf_status lf_set_scene(lf_ctx* ctx, int n_spheres, const double* spheres, const 
       (n_materials && !materials) || (n_lights && !lights))
     return LF_ERR_INVALID;
   LF_HIP(ctx, hipSetDevice(ctx->device));
-  std::vector<LfPrim> prims;
+  if ((size_t)n_spheres + (size_t)n_triangles >= (1u << 29))
+    return lf_fail(ctx, LF_ERR_INVALID, "scene: more than 2^29 primitives");
+  std::vector<HostPrim> prims;
+  prims.reserve((size_t)n_spheres + (size_t)n_triangles);
   for (int i = 0; i < n_spheres; i++) {
-    LfPrim p; std::memset(&p, 0, sizeof(p));
+    HostPrim p; std::memset(&p, 0, sizeof(p));
     p.type = 0; p.material = sphere_material[i];
     for (int k = 0; k < 4; k++) p.d[k] = spheres[4 * i + k];
     p.d[4] = p.d[3] * p.d[3];  // Sphere::r2
     prims.push_back(p);
   }
   for (int i = 0; i < n_triangles; i++) {
-    LfPrim p; std::memset(&p, 0, sizeof(p));
+    HostPrim p; std::memset(&p, 0, sizeof(p));
     p.type = 1; p.material = tri_material[i];
     for (int k = 0; k < 9; k++) { p.d[k] = tri_positions[9 * i + k]; p.d[9 + k] = tri_normals[9 * i + k]; }
     prims.push_back(p);
   }
-  for (auto& p : prims)
+  for (auto& p : prims) {
     if (p.material < 0 || p.material >= n_materials) return lf_fail(ctx, LF_ERR_INVALID, "scene: material index out of range");
+    set_prim_box(p);
+  }
   std::vector<LfMaterial> mats(n_materials);
   for (int i = 0; i < n_materials; i++) {
     mats[i].kind = (int)materials[4 * i];
@@ -568,33 +706,63 @@ lf_status lf_set_scene(lf_ctx* ctx, int n_spheres, const double* spheres, const 
                                           "hemisphere and area lights go through lf_set_scene_lights");
     for (int c = 0; c < 3; c++) { lts[i].v[c] = lights[7 * i + 1 + c]; lts[i].rgb[c] = lights[7 * i + 4 + c]; }
   }
+  // The device traversal defers at most one child per level on its LDS stack; a deeper tree would
+  // have to drop children (= lose geometry silently).  The SAH tree of a degenerate scene can be deep:
+  // then the median split (ceil(log2(n / 4)) + 1 levels) is built instead; if even that is too deep
+  // (> 2^25 primitives) the call fails -- it must fail, not drop.
+  std::vector<HostNode> hnodes;
   std::vector<LfBvhNode> nodes;
-  int depth = 0;
+  Box root = empty_box();
   if (!prims.empty()) {
-    build_node(nodes, prims, 0, (int)prims.size(), &depth);
-  } else {   // an empty scene: one node whose inverted box no ray enters
-    LfBvhNode e; std::memset(&e, 0, sizeof(e)); e.bmin[0] = 1; e.bmax[0] = -1; e.count = 0; e.left = e.right = -1; nodes.push_back(e);
+    const char* how = std::getenv("LF_BVH_SPLIT");   // "median": the round-2 tree (A/B measurements)
+    int depth = 0;
+    bool sah = !(how && std::strcmp(how, "median") == 0);
+    build_node(hnodes, prims, 0, (int)prims.size(), sah, &depth);
+    if (sah && depth - 1 > kStackDepth) {
+      hnodes.clear();
+      build_node(hnodes, prims, 0, (int)prims.size(), false, &depth);
+    }
+    if (depth - 1 > kStackDepth)
+      return lf_fail(ctx, LF_ERR_INVALID, "scene: BVH deeper than the device traversal stack");
+    root = hnodes[0].box;
+    if (hnodes[0].left >= 0) {
+      flatten(hnodes, 0, nodes);
+    } else {   // a single leaf: a root whose first child is that leaf
+      LfBvhNode e; std::memset(&e, 0, sizeof(e));
+      for (int a = 0; a < 3; a++) { e.lo0[a] = round_down(root.mn[a]); e.hi0[a] = round_up(root.mx[a]); }
+      e.child[0] = ~(0 * 4 + (hnodes[0].count - 1)); e.child[1] = kLfNoChild;
+      nodes.push_back(e);
+    }
+  } else {   // an empty scene: a root without children
+    LfBvhNode e; std::memset(&e, 0, sizeof(e));
+    e.child[0] = e.child[1] = kLfNoChild;
+    nodes.push_back(e);
+    for (int a = 0; a < 3; a++) { root.mn[a] = 0; root.mx[a] = 0; }
+    root.mn[0] = 1; root.mx[0] = -1;   // (what lf_scene_bounds reported for it before)
   }
-  // the device traversal keeps at most depth + 1 node ids on its LDS stack and would otherwise
-  // have to drop children (= lose geometry silently); the median split is ceil(log2(n / 4)) + 1
-  // deep, so this only triggers beyond ~2^32 primitives -- but it must fail, not drop
-  if (depth + 1 > kStackDepth - 1)
-    return lf_fail(ctx, LF_ERR_INVALID, "scene: BVH deeper than the device traversal stack");
+  std::vector<LfPrim> dprims(prims.size());
+  std::vector<LfPrimNormals> dnormals(prims.size());
+  for (size_t i = 0; i < prims.size(); i++) {
+    std::memset(&dprims[i], 0, sizeof(LfPrim));
+    for (int k = 0; k < 9; k++) { dprims[i].d[k] = prims[i].d[k]; dnormals[i].n[k] = prims[i].d[9 + k]; }
+    dprims[i].type = prims[i].type; dprims[i].material = prims[i].material;
+  }
   LfSceneDev& S = ctx->scene_dev;
   LF_HIP(ctx, hipStreamSynchronize(ctx->stream));
-  void* old[] = {S.nodes, S.prims, S.materials, S.lights};
+  void* old[] = {S.nodes, S.prims, S.normals, S.materials, S.lights};
   for (void* o : old) if (o) (void)hipFree(o);
   std::memset(&S, 0, sizeof(S));
   auto up = [&](void** dst, const void* src, size_t bytes) -> hipError_t {
-    hipError_t e = hipMalloc(dst, std::max<size_t>(bytes, 16));
+    hipError_t e = hipMalloc(dst, std::max<size_t>(bytes, 64));
     if (e == hipSuccess && bytes) e = hipMemcpy(*dst, src, bytes, hipMemcpyHostToDevice);
     return e;
   };
   LF_HIP(ctx, up((void**)&S.nodes, nodes.data(), nodes.size() * sizeof(LfBvhNode)));
-  LF_HIP(ctx, up((void**)&S.prims, prims.data(), prims.size() * sizeof(LfPrim)));
+  LF_HIP(ctx, up((void**)&S.prims, dprims.data(), dprims.size() * sizeof(LfPrim)));
+  LF_HIP(ctx, up((void**)&S.normals, dnormals.data(), dnormals.size() * sizeof(LfPrimNormals)));
   LF_HIP(ctx, up((void**)&S.materials, mats.data(), mats.size() * sizeof(LfMaterial)));
   LF_HIP(ctx, up((void**)&S.lights, lts.data(), lts.size() * sizeof(LfLight)));
-  for (int a = 0; a < 3; a++) { ctx->scene_bmin[a] = nodes[0].bmin[a]; ctx->scene_bmax[a] = nodes[0].bmax[a]; }
+  for (int a = 0; a < 3; a++) { ctx->scene_bmin[a] = root.mn[a]; ctx->scene_bmax[a] = root.mx[a]; }
   S.n_nodes = (int)nodes.size(); S.n_prims = (int)prims.size();
   S.n_materials = n_materials; S.n_lights = n_lights; S.n_soft_lights = 0;
   ctx->scene_valid = true;
@@ -776,7 +944,8 @@ lf_status lf_render_scene_term(lf_ctx* ctx) {
   if (px == 0) return LF_OK;
   const bool soft = ctx->scene_dev.n_soft_lights > 0 || ctx->env_dev.w > 0 || ctx->hemisphere_sample;
 #define LF_LAUNCH_SCENE(SOFT)                                                                            \
-  hipLaunchKernelGGL(k_scene_term<SOFT>, dim3((unsigned)((px + 255) / 256)), dim3(256), 0, ctx->stream,  \
+  hipLaunchKernelGGL(k_scene_term<SOFT>, dim3((unsigned)((ctx->W + 31) / 32), (unsigned)(((ctx->y1 + 7) >> 3) - (ctx->y0 >> 3))), \
+                     dim3(256), 0, ctx->stream,                                                          \
                      ctx->scene_dev, ctx->env_dev, ctx->hemisphere_sample ? 1 : 0, ctx->cam, ctx->W,    \
                      ctx->H, ctx->y0, ctx->y1, ctx->row_phase, ctx->row_period, ctx->ns_aa,              \
                      ctx->ns_area_light, ctx->samples_per_batch,                                         \
