@@ -50,7 +50,7 @@ __device__ inline V3 divs(V3 a, double c) { const double rc = 1.0 / c; return v3
 // test uses exactly these) plus what the box tests use -- floats that BRACKET the doubles.
 struct DRay {
   V3 o, d; double min_t, max_t;
-  float olx, oly, olz, ohx, ohy, ohz;  // o rounded down / up
+  float olx, oly, olz, ohx, ohy, ohz;  // floats strictly below / above o
   float ix, iy, iz;                    // 1 / d; NaN when |1 / d| is no finite float: the axis then never culls
   float tmin_c, tmax_c;                // min_t / max_t, widened by the box test's slack
 };
@@ -59,6 +59,13 @@ struct Hit { double t, b1, b2; int prim; };
 
 __device__ inline float f32_down(double x) { const float f = (float)x; return (double)f > x ? nextafterf(f, -INFINITY) : f; }
 __device__ inline float f32_up(double x) { const float f = (float)x; return (double)f < x ? nextafterf(f, INFINITY) : f; }
+// STRICTLY below / above: the origin's bracket.  With a direction component of exactly 0 the slab
+// products are (lo - oh) * inf and (hi - ol) * inf; a difference of exactly 0 gives NaN, which the
+// min / max of box_miss resolve towards "outside".  That is only right if a zero difference MEANS
+// outside: lo == oh > o does, lo == oh == o (an origin exactly on the slab's plane, e.g. a shadow ray
+// leaving an axis-aligned face along an axis) would not.
+__device__ inline float f32_below(double x) { const float f = (float)x; return (double)f >= x ? nextafterf(f, -INFINITY) : f; }
+__device__ inline float f32_above(double x) { const float f = (float)x; return (double)f <= x ? nextafterf(f, INFINITY) : f; }
 __device__ inline float inv_dir(double d) {
   const double q = 1.0 / d;           // d = 0: +-inf, which culls correctly (a ray parallel to a slab)
   return (d != 0.0 && fabs(q) > 3.0e38) ? __int_as_float(0x7fc00000) : (float)q;
@@ -72,8 +79,8 @@ __device__ inline void widen_max_t(DRay& r) {
 __device__ inline DRay make_ray(V3 o, V3 d, double min_t, double max_t) {
   DRay r;
   r.o = o; r.d = d; r.min_t = min_t; r.max_t = max_t;
-  r.olx = f32_down(o.x); r.oly = f32_down(o.y); r.olz = f32_down(o.z);
-  r.ohx = f32_up(o.x); r.ohy = f32_up(o.y); r.ohz = f32_up(o.z);
+  r.olx = f32_below(o.x); r.oly = f32_below(o.y); r.olz = f32_below(o.z);
+  r.ohx = f32_above(o.x); r.ohy = f32_above(o.y); r.ohz = f32_above(o.z);
   r.ix = inv_dir(d.x); r.iy = inv_dir(d.y); r.iz = inv_dir(d.z);
   const float m = f32_down(min_t);
   r.tmin_c = fmaf(-9.6e-7f, fabsf(m), m) - 1e-30f;
@@ -146,8 +153,10 @@ __device__ inline V3 hit_normal(const LfSceneDev& sc, const DRay& r, const Hit& 
 //   after the multiplication by 1 / d the smaller product bounds the entry from below and the larger
 //   one the exit from above, each off by at most 3 roundings (2^-24 each, relative) + underflow.
 // tn > tf is decided with 2^-21 (|tn| + |tf|) + 1e-30 of slack, the two ends against bounds that were
-// widened once per ray (make_ray / widen_max_t).  fminf / fmaxf drop NaNs (0 * inf on a slab plane, an
-// axis without a usable reciprocal): that only makes the test more permissive.  The sum of the
+// widened once per ray (make_ray / widen_max_t).  fminf / fmaxf drop NaNs: an axis without a usable
+// reciprocal (both products NaN) simply does not cull; 0 * inf only arises for an origin strictly
+// outside the slab of an axis the ray is parallel to (f32_below / f32_above), where the surviving
+// infinite product culls, correctly.  The sum of the
 // magnitudes is clamped so that an infinite entry (a ray parallel to a slab and outside it) still
 // compares as "misses" instead of inf > inf.
 __device__ inline bool box_miss(const DRay& r, float lx, float ly, float lz, float hx, float hy, float hz,
@@ -409,7 +418,10 @@ __device__ inline double random_uniform_from_raw(unsigned raw) {  // util/random
 // 30 % faster -- timing frame: 155 -> 110 ms with an area light and the environment, 25.4 -> 22.5 ms
 // with delta lights only; profiles/r02_scene_term_timing.json)
 template <bool SOFT>
-__global__ __launch_bounds__(256, 4) void k_scene_term(LfSceneDev sc, LfEnvDev ev, int hemisphere,
+#ifndef LF_SCENE_WAVES
+#define LF_SCENE_WAVES 4
+#endif
+__global__ __launch_bounds__(256, LF_SCENE_WAVES) void k_scene_term(LfSceneDev sc, LfEnvDev ev, int hemisphere,
                                                     LfCamera cam, int W, int H, int y0,
                                                     int y1, int row_phase, int row_period,
                                                     int ns_aa, int ns_area_light,
@@ -548,7 +560,7 @@ void set_prim_box(HostPrim& p) {
 
 // returns the node id; *depth = levels below (and including) this node
 int build_node(std::vector<HostNode>& nodes, std::vector<HostPrim>& prims, int first, int count, bool sah,
-               int* depth) {
+               int leaf_max, int* depth) {
   HostNode nd;
   nd.box = empty_box();
   double cmn[3] = {INFINITY, INFINITY, INFINITY}, cmx[3] = {-INFINITY, -INFINITY, -INFINITY};
@@ -560,7 +572,7 @@ int build_node(std::vector<HostNode>& nodes, std::vector<HostPrim>& prims, int f
   const int id = (int)nodes.size();
   nodes.push_back(nd);
   *depth = 1;
-  if (count <= 4) return id;
+  if (count <= leaf_max) return id;
   int mid = -1;
   if (sah) {
     constexpr int kBins = 16;
@@ -605,8 +617,8 @@ int build_node(std::vector<HostNode>& nodes, std::vector<HostPrim>& prims, int f
                      [axis](const HostPrim& a, const HostPrim& b) { return a.cen[axis] < b.cen[axis]; });
   }
   int dl = 0, dr = 0;
-  const int l = build_node(nodes, prims, first, mid - first, sah, &dl);
-  const int r = build_node(nodes, prims, mid, first + count - mid, sah, &dr);
+  const int l = build_node(nodes, prims, first, mid - first, sah, leaf_max, &dl);
+  const int r = build_node(nodes, prims, mid, first + count - mid, sah, leaf_max, &dr);
   nodes[id].left = l; nodes[id].right = r;
   *depth = 1 + std::max(dl, dr);
   return id;
@@ -717,10 +729,12 @@ lf_status lf_set_scene(lf_ctx* ctx, int n_spheres, const double* spheres, const 
     const char* how = std::getenv("LF_BVH_SPLIT");   // "median": the round-2 tree (A/B measurements)
     int depth = 0;
     bool sah = !(how && std::strcmp(how, "median") == 0);
-    build_node(hnodes, prims, 0, (int)prims.size(), sah, &depth);
+    const char* lm = std::getenv("LF_BVH_LEAF");
+    const int leaf_max = lm ? std::min(4, std::max(1, std::atoi(lm))) : 2;
+    build_node(hnodes, prims, 0, (int)prims.size(), sah, leaf_max, &depth);
     if (sah && depth - 1 > kStackDepth) {
       hnodes.clear();
-      build_node(hnodes, prims, 0, (int)prims.size(), false, &depth);
+      build_node(hnodes, prims, 0, (int)prims.size(), false, leaf_max, &depth);
     }
     if (depth - 1 > kStackDepth)
       return lf_fail(ctx, LF_ERR_INVALID, "scene: BVH deeper than the device traversal stack");
