@@ -7,8 +7,9 @@
 //
 // Everything is double precision and follows the reference expression by expression (operator
 // order of CGL::Vector3D / Matrix3x3 included) so that pixels agree with the CPU renderer far
-// inside the 1e-4 bar.  The BVH is our own (median split on the host, stack traversal on the
-// device): the closest hit does not depend on the tree, only the amount of work does.
+// inside the 1e-4 bar.  The BVH is our own (binned SAH on the host; on the device a nearest-first walk
+// over two-child nodes with conservative FLOAT boxes, lf_scene_types.h): the closest hit does not
+// depend on the tree, only the amount of work does -- the primitive tests stay the reference's doubles.
 //
 // Sampled lights -- AreaLight and InfiniteHemisphereLight (scene/light.cpp:35-48, :82-101) with
 // ns_area_light samples each, exactly the estimator of estimate_direct_lighting_importance
@@ -414,9 +415,9 @@ __device__ inline double random_uniform_from_raw(unsigned raw) {  // util/random
 
 // the sample loop of raytrace_pixel (pathtracer.cpp:831-875)
 // (second bound: 4 waves per SIMD = 128 registers.  Left alone the sampled-light instantiation takes
-// 246 and runs 2 waves; bounded it spills ~120 registers to scratch in its cold paths and is still
-// 30 % faster -- timing frame: 155 -> 110 ms with an area light and the environment, 25.4 -> 22.5 ms
-// with delta lights only; profiles/r02_scene_term_timing.json)
+// 256 and the delta-light one 163; bounded they spill their cold paths to scratch and are still
+// faster -- timing frames at 2 / 3 / 4 / 5 waves: 32.6 / 26.0 / 24.8 / 25.0 ms with an area light and the
+// environment, 4.1 / 4.1 / 3.9 / 4.9 ms with delta lights only)
 template <bool SOFT>
 #ifndef LF_SCENE_WAVES
 #define LF_SCENE_WAVES 4
