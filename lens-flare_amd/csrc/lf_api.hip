@@ -225,7 +225,7 @@ lf_status lf_destroy(lf_ctx* ctx) {
                   ctx->lens_dev, ctx->pairs_dev, ctx->counters_dev, ctx->accum,
                   ctx->prog_dev, ctx->sun_lights_dev,
                   ctx->scene_dev.nodes, ctx->scene_dev.prims, ctx->scene_dev.normals, ctx->scene_dev.materials,
-                  ctx->scene_dev.lights, ctx->env_block};
+                  ctx->scene_dev.lights, ctx->env_block, ctx->probe_dev};
   for (void* p : ptrs) if (p) (void)hipFree(p);
   if (ctx->own_stream && ctx->stream) (void)hipStreamDestroy(ctx->stream);
   delete ctx;

@@ -258,6 +258,7 @@ struct lf_ctx {
   int ns_area_light = 1;          // PathTracer::ns_area_light (pathtracer.h:108; the -l flag)
   LfEnvDev env_dev{};             // PathTracer::envLight (pathtracer.h:119)
   double* env_block = nullptr;    // one allocation behind env_dev's four tables
+  double* probe_dev = nullptr;    // 8 doubles: where the single-ray scene probes leave their answer
   bool hemisphere_sample = false; // PathTracer::direct_hemisphere_sample (pathtracer.h:114; the -H flag)
   int samples_per_batch = 32;     // PathTracer::samplesPerBatch default (raytraced_renderer.h:67-81)
   double max_tolerance = 0.05;    // PathTracer::maxTolerance

@@ -646,17 +646,14 @@ int flatten(const std::vector<HostNode>& h, int id, std::vector<LfBvhNode>& out)
   return me;
 }
 
-// one wave writes `n_out` doubles, which come straight back
+// one wave writes `n_out` (<= 8) doubles, which come straight back
 template <typename Launch>
 static lf_status scene_probe(lf_ctx* ctx, int n_out, double* out, Launch launch) {
-  double* d = nullptr;
-  LF_HIP(ctx, hipMalloc((void**)&d, sizeof(double) * (size_t)n_out));
-  launch(d);
-  hipError_t e = hipGetLastError();
-  if (e == hipSuccess) e = hipMemcpyAsync(out, d, sizeof(double) * (size_t)n_out, hipMemcpyDeviceToHost, ctx->stream);
-  if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
-  (void)hipFree(d);
-  LF_HIP(ctx, e);
+  if (!ctx->probe_dev) LF_HIP(ctx, hipMalloc((void**)&ctx->probe_dev, sizeof(double) * 8));
+  launch(ctx->probe_dev);
+  LF_HIP(ctx, hipGetLastError());
+  LF_HIP(ctx, hipMemcpyAsync(out, ctx->probe_dev, sizeof(double) * (size_t)n_out, hipMemcpyDeviceToHost, ctx->stream));
+  LF_HIP(ctx, hipStreamSynchronize(ctx->stream));
   return LF_OK;
 }
 
