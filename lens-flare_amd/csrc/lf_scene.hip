@@ -122,8 +122,10 @@ __device__ inline bool hit_sphere(const LfPrim& s, int idx, DRay& r, Hit* h) {
 
 // moller_trumbore + is_valid_intersection + Triangle::intersect (scene/triangle.cpp:25-112)
 __device__ inline bool hit_triangle(const LfPrim& t, int idx, DRay& r, Hit* h) {
-  const V3 p0 = v3(t.d[0], t.d[1], t.d[2]), p1 = v3(t.d[3], t.d[4], t.d[5]), p2 = v3(t.d[6], t.d[7], t.d[8]);
-  const V3 e1 = p1 - p0, e2 = p2 - p0, s = r.o - p0;
+  // (e1 = p1 - p0 and e2 = p2 - p0 come with the primitive: the host's IEEE subtraction gives the bits
+  // the device's would, and the test holds 6 doubles less)
+  const V3 p0 = v3(t.d[0], t.d[1], t.d[2]), e1 = v3(t.d[3], t.d[4], t.d[5]), e2 = v3(t.d[6], t.d[7], t.d[8]);
+  const V3 s = r.o - p0;
   const V3 s1 = cross(r.d, e2), s2 = cross(s, e1);
   const double rc = 1. / dot(s1, e1);  // operator/= multiplies by the reciprocal
   const double tt = dot(s2, e2) * rc, b1 = dot(s1, s) * rc, b2 = dot(s2, r.d) * rc;
@@ -757,6 +759,11 @@ lf_status lf_set_scene(lf_ctx* ctx, int n_spheres, const double* spheres, const 
   for (size_t i = 0; i < prims.size(); i++) {
     std::memset(&dprims[i], 0, sizeof(LfPrim));
     for (int k = 0; k < 9; k++) { dprims[i].d[k] = prims[i].d[k]; dnormals[i].n[k] = prims[i].d[9 + k]; }
+    if (prims[i].type == 1)   // a triangle travels as p0, e1 = p1 - p0, e2 = p2 - p0 (triangle.cpp:29-30)
+      for (int k = 0; k < 3; k++) {
+        volatile double e1 = prims[i].d[3 + k] - prims[i].d[k], e2 = prims[i].d[6 + k] - prims[i].d[k];
+        dprims[i].d[3 + k] = e1; dprims[i].d[6 + k] = e2;
+      }
     dprims[i].type = prims[i].type; dprims[i].material = prims[i].material;
   }
   LfSceneDev& S = ctx->scene_dev;

@@ -15,7 +15,7 @@ struct alignas(64) LfBvhNode {
   int child[2];
   int pad[2];
 };
-// what the intersection tests read: a sphere's centre, r, r^2, or a triangle's three positions
+// what the intersection tests read: a sphere's centre, r, r^2, or a triangle's p0, p1 - p0, p2 - p0
 struct alignas(16) LfPrim { double d[9]; int type, material; };  // type 0 sphere, 1 triangle
 // a triangle's three vertex normals: read once per camera ray, for the closest hit only
 struct LfPrimNormals { double n[9]; };
