@@ -140,3 +140,28 @@ def test_unsupported_inputs_fail_loudly(pkg, lf):
         lf.render_scene_term()
     lf.set_jitter_counter(1)
     lf.render_scene_term()                  # fine with the counter RNG (adaptive early-out active)
+
+
+def test_scene_buffer_reads_back(pkg):
+    """lf_read_tile(which = 3): the scene term as the host left it (lf_set_scene_term) or as
+    lf_render_scene_term computed it; LF_ERR_STATE while there is none."""
+    lf = pkg.LensFlare(0)
+    try:
+        lf.set_frame(40, 24)
+        with pytest.raises(pkg.LensFlareError) as e:
+            lf.read_buffer(pkg.SCENE_BUFFER)
+        assert "LF_ERR_STATE" in str(e.value) or e.value.status != 0
+        rgb = np.random.default_rng(0).uniform(0, 2, (24, 40, 3))
+        lf.set_scene_term(rgb)
+        assert np.array_equal(lf.read_buffer(pkg.SCENE_BUFFER), rgb)
+        assert np.array_equal(lf.read_tile(pkg.SCENE_BUFFER, 3, 5, 11, 9), rgb[5:9, 3:11])
+        lf.set_params(2, 25.0, 1.0)
+        lf.set_camera(np.eye(3), [0, 0, 0], 60.0, 38.0)
+        lf.set_scene([(0, 0, -3, 1, "e", 1.0, 0.5, 0.25)], [], [])
+        lf.set_jitter_counter(1)
+        lf.render_scene_term()
+        got = lf.read_buffer(pkg.SCENE_BUFFER)
+        # (the reference divides the sum of ns_aa samples by the loop variable, ns_aa + 1: pathtracer.cpp:875)
+        assert np.allclose(got[12, 20], np.array([1.0, 0.5, 0.25]) * 2 / 3) and np.all(got[0, 0] == 0)
+    finally:
+        lf.close()
