@@ -551,7 +551,8 @@ double half_area(const Box& b) {
 
 void set_prim_box(HostPrim& p) {
   if (p.type == 0) {
-    for (int a = 0; a < 3; a++) { p.box.mn[a] = p.d[a] - p.d[3]; p.box.mx[a] = p.d[a] + p.d[3]; }
+    const double rr = std::fabs(p.d[3]);   // (the test only reads r^2: a negative radius is still a sphere)
+    for (int a = 0; a < 3; a++) { p.box.mn[a] = p.d[a] - rr; p.box.mx[a] = p.d[a] + rr; }
   } else {
     for (int a = 0; a < 3; a++) {
       p.box.mn[a] = std::min({p.d[a], p.d[3 + a], p.d[6 + a]});
@@ -700,6 +701,8 @@ lf_status lf_set_scene(lf_ctx* ctx, int n_spheres, const double* spheres, const 
   }
   for (auto& p : prims) {
     if (p.material < 0 || p.material >= n_materials) return lf_fail(ctx, LF_ERR_INVALID, "scene: material index out of range");
+    for (int k = 0; k < (p.type == 0 ? 4 : 18); k++)
+      if (!std::isfinite(p.d[k])) return lf_fail(ctx, LF_ERR_INVALID, "scene: a primitive has a non-finite coordinate");
     set_prim_box(p);
   }
   std::vector<LfMaterial> mats(n_materials);

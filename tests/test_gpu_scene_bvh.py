@@ -95,6 +95,7 @@ def make_soup(rng, n_tris, n_spheres, scale=1.0, offset=(0.0, 0.0, 0.0)):
     nrm /= np.linalg.norm(nrm, axis=-1, keepdims=True)
     sph = np.concatenate([rng.uniform(-4, 4, (n_spheres, 3)) * scale + offset,
                           rng.uniform(0.05, 0.6, (n_spheres, 1)) * scale], 1)
+    sph[::7, 3] *= -1.0     # (Sphere::test only reads r^2: a negative radius is still a sphere)
     return sph, tris, nrm.reshape(n_tris, 9)
 
 

@@ -132,6 +132,8 @@ def test_unsupported_inputs_fail_loudly(pkg, lf):
     lf.set_frame(16, 16)
     with pytest.raises(pkg.LensFlareError):
         lf.set_scene([(0, 0, -3, 1, "d", 1, 1, 1)], [], [[2.0, 0, 1, 0, 1, 1, 1]])  # area light: refused
+    with pytest.raises(pkg.LensFlareError):  # a NaN vertex has no place in a tree of boxes
+        lf.set_scene([], [(0, 0, -3, 1, 0, -3, float("nan"), 1, -3) + (0, 0, 1) * 3 + ("d", 1, 1, 1)], [])
     lf.set_scene([(0, 0, -3, 1, "d", 1, 1, 1)], [], [[1.0, 0, 3, 0, 1, 1, 1]])
     lf.set_camera(np.eye(3), [0, 0, 0], 50, 50)
     lf.set_params(40, 25.0, 1.0)           # ns_aa >= samplesPerBatch ...
