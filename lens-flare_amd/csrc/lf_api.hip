@@ -137,6 +137,8 @@ void free_frame_buffers(lf_ctx* ctx) {
   if (ctx->star) (void)hipFree(ctx->star);
   if (ctx->scene) (void)hipFree(ctx->scene);
   if (ctx->rgba) (void)hipFree(ctx->rgba);
+  if (ctx->rgba_flip) (void)hipFree(ctx->rgba_flip);
+  ctx->rgba_flip = nullptr;
   if (ctx->jitter_raw) (void)hipFree(ctx->jitter_raw);
   if (ctx->jitter_aa_raw) (void)hipFree(ctx->jitter_aa_raw);
   ctx->jitter_aa_raw = nullptr;
@@ -640,15 +642,12 @@ lf_status lf_save_image_rgba(lf_ctx* ctx, uint32_t* dst) {
   lf_status st = lfk_tonemap(ctx, 0, ctx->H);   // the saved image is always the whole frame
   if (st != LF_OK) return st;
   ctx->rgba_y0 = 0; ctx->rgba_y1 = ctx->H;
-  uint32_t* tmp = nullptr;
   const size_t n = (size_t)ctx->W * ctx->H;
-  LF_HIP(ctx, hipMalloc((void**)&tmp, n * sizeof(uint32_t)));
-  st = lfk_flip_rows(ctx, tmp);
-  hipError_t e = hipStreamSynchronize(ctx->stream);
-  if (st == LF_OK && e == hipSuccess) e = hipMemcpy(dst, tmp, n * sizeof(uint32_t), hipMemcpyDeviceToHost);
-  (void)hipFree(tmp);
+  if (!ctx->rgba_flip) LF_HIP(ctx, hipMalloc((void**)&ctx->rgba_flip, n * sizeof(uint32_t)));
+  st = lfk_flip_rows(ctx, ctx->rgba_flip);
   if (st != LF_OK) return st;
-  LF_HIP(ctx, e);
+  LF_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  LF_HIP(ctx, hipMemcpy(dst, ctx->rgba_flip, n * sizeof(uint32_t), hipMemcpyDeviceToHost));
   return LF_OK;
 }
 

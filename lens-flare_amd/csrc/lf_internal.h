@@ -240,6 +240,7 @@ struct lf_ctx {
   double* scene = nullptr;   // W*H*3 or null
   double* star = nullptr;    // W*H*3: raytrace_starburst(x,y) alone (starburst + falloff)
   uint32_t* rgba = nullptr;  // W*H
+  uint32_t* rgba_flip = nullptr;  // W*H, allocated by the first lf_save_image_rgba (rows top-down)
   bool ghost_valid = false, sample_valid = false;
   int rgba_y0 = 0, rgba_y1 = 0;  // rows [rgba_y0, rgba_y1) of rgba hold the tonemapped sample buffer
 

@@ -35,8 +35,8 @@ for name, (W, H) in {"1080p": (1920, 1080), "4k": (3840, 2160)}.items():
         ex, ey = math.tan(math.radians(hf) / 2), math.tan(math.radians(vf) / 2)
         light = [(2 * 0.62 - 1) * ex * 10, (2 * 0.58 - 1) * ey * 10, -10.0, 1.0, 0.9, 0.5]
         rgba = None
-        for rep in range(4):
-            if rep == 1:
+        for rep in range(14):
+            if rep == 4:
                 lf.timing_reset()
                 lf.synchronize()
                 t0 = time.perf_counter()
@@ -45,7 +45,7 @@ for name, (W, H) in {"1080p": (1920, 1080), "4k": (3840, 2160)}.items():
             lf.render_flare_layer()
             rgba = lf.save_image_rgba()
         lf.synchronize()
-        wall = (time.perf_counter() - t0) / 3
+        wall = (time.perf_counter() - t0) / 10
         rec = {"wall_ms_per_frame_incl_rgba_readback": wall * 1e3}
         for k in ("frame_setup", "ghost_raster", "dft", "flare_layer", "tonemap"):
             n, ms = lf.timing_get(k)
