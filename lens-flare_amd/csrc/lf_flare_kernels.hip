@@ -480,18 +480,17 @@ __device__ inline void irradiance_falloff(const LfFlares* __restrict__ fl, int n
   double t[3] = {0.0, 0.0, 0.0};
   uint4 raw4 = make_uint4(0, 0, 0, 0);
   for (int s = 0; s < 16; s++) {
-    unsigned ra, rb;
-    if (jitter_mode == 0) {
-      const uint32_t* jr = jitter_raw + p * 32;
-      ra = jr[2 * s]; rb = jr[2 * s + 1];
-    } else {
-      if ((s & 1) == 0)
+    // four draws = two samples at a time: one 16-byte load of the pixel's table row, or one Philox block
+    if ((s & 1) == 0) {
+      if (jitter_mode == 0)
+        raw4 = reinterpret_cast<const uint4*>(jitter_raw + p * 32)[s >> 1];
+      else
         raw4 = philox4x32_10(make_uint4((unsigned)p, (unsigned)(p >> 32), (unsigned)(s >> 1),
                                         0x0fa110ffu),
                              make_uint2((unsigned)key, (unsigned)(key >> 32)));
-      ra = (s & 1) ? raw4.z : raw4.x;
-      rb = (s & 1) ? raw4.w : raw4.y;
     }
+    const unsigned ra = (s & 1) ? raw4.z : raw4.x;
+    const unsigned rb = (s & 1) ? raw4.w : raw4.y;
     // Vector2D(random_uniform(), random_uniform()) (sampler.cpp:8-12): g++ evaluates the
     // second argument first, so the first draw is the y jitter
     double sy = (double)y + random_uniform_from_raw(ra);
@@ -501,11 +500,11 @@ __device__ inline void irradiance_falloff(const LfFlares* __restrict__ fl, int n
       double ex = fx - sx, ey = fy - sy;
       double nrm = sqrt(ex * ex + ey * ey) - radius;
       double r = 1 + (0.0 < nrm ? nrm : 0.0);
-      // pow(r, 1.5) as r * sqrt(r): both factors correctly rounded, so within 1 ulp of the exact power
-      // (glibc's pow, which the reference calls, is within 1 ulp as well) at a tenth of the
-      // instructions of a general double-precision pow -- 16 x n_flares of them per pixel made this
-      // kernel compute-bound (305 -> see DESIGN.md section 3)
-      double rc = 1.0 / (r * sqrt(r));
+      // 1 / pow(r, 1.5) as rsqrt(r^3): two roundings in r^3 and a reciprocal root within 2 ulp, so
+      // ~3 ulp from the exact value (glibc's pow, which the reference calls, is within 1) at a tenth of
+      // the instructions of a general double-precision pow followed by a division -- 16 x n_flares of
+      // them per pixel made this kernel compute-bound
+      double rc = rsqrt((r * r) * r);
       t[0] += rc * fl->radiance[l][0];
       t[1] += rc * fl->radiance[l][1];
       t[2] += rc * fl->radiance[l][2];
