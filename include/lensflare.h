@@ -270,7 +270,8 @@ lf_status lf_scene_shade(lf_ctx* ctx, int what, const double ray[8], double t, c
  * computes its scene radiance per pixel can form (scene + ghost) + starburst exactly like
  * pathtracer.cpp:891; 3 = the scene-radiance term itself (what lf_render_scene_term or
  * lf_set_scene_term left: the average of est_radiance_global_illumination over the pixel's camera
- * rays, pathtracer.cpp:841-875; LF_ERR_STATE when there is none).  dst receives (x1-x0)*(y1-y0) pixels, each
+ * rays, pathtracer.cpp:841-875; LF_ERR_STATE when there is none; under a row interleave only this
+ * context's tile rows are filled -- the term is consumed by the flare layer, not exchanged).  dst receives (x1-x0)*(y1-y0) pixels, each
  * `pixel_stride` doubles apart (3 = packed Vector3D, 4 = the AVX build's 32-byte Vector3D). */
 lf_status lf_read_tile(lf_ctx* ctx, int which, int x0, int y0, int x1, int y1, double* dst,
                        size_t pixel_stride);
