@@ -192,3 +192,52 @@ def test_every_tree_renders_the_same_frame(pkg):
     assert (ref.max(axis=-1) > 0).mean() > 0.15
     for k, f in frames.items():
         assert np.array_equal(f, ref), k
+
+
+def test_bands_and_row_interleave_tile_the_frame(pkg):
+    """The kernel maps a wave to an 8 x 8 pixel tile: bands whose edges cut tiles, frames whose sizes are
+    no multiples of 8 / 32, and the multi-GPU tile-row deal must each produce exactly the pixels of the
+    one-launch frame (the jitter and light samples are keyed by the pixel, not by the launch)."""
+    rng = np.random.default_rng(21)
+    sph, tris, nrm = make_soup(rng, 800, 20)
+    tris[:, 2::3] -= 9.0
+    sph[:, 2] -= 9.0
+    spheres = [tuple(s) + ("d", 0.6, 0.5, 0.4) for s in sph]
+    triangles = [tuple(t) + tuple(n) + ("d", 0.4, 0.6, 0.5) for t, n in zip(tris, nrm)]
+    lights = [[0.0, 0.3, 0.9, 0.3, 1.0, 1.0, 1.0]]
+    W, H = 77, 45
+
+    def ctx():
+        lf = pkg.LensFlare(0)
+        lf.set_frame(W, H)
+        lf.set_params(3, 25.0, 1.0)
+        lf.set_camera(np.eye(3), [0.0, 0.0, 2.0], 60.0, 38.0)
+        lf.set_scene(spheres, triangles, lights)
+        lf.set_jitter_counter(5)
+        return lf
+
+    lf = ctx()
+    lf.render_scene_term()
+    whole = lf.read_buffer(pkg.SCENE_BUFFER)
+    lf.close()
+    assert (whole.max(axis=-1) > 0).mean() > 0.1
+
+    lf = ctx()
+    for y0, y1 in ((0, 13), (13, 14), (14, 37), (37, H)):
+        lf.set_band(y0, y1)
+        lf.render_scene_term()
+    assert np.array_equal(lf.read_buffer(pkg.SCENE_BUFFER), whole)
+    lf.close()
+
+    got = np.zeros_like(whole)
+    for phase in range(3):
+        lf = ctx()
+        lf.set_row_interleave(phase, 3)
+        lf.render_scene_term()
+        part = lf.read_buffer(pkg.SCENE_BUFFER)
+        rows = [y for y in range(H) if (y >> 3) % 3 == phase]
+        got[rows] = part[rows]
+        others = [y for y in range(H) if (y >> 3) % 3 != phase]
+        assert not part[others].any()          # nobody else's tile rows are touched
+        lf.close()
+    assert np.array_equal(got, whole)
