@@ -669,11 +669,14 @@ lf_status lf_set_lens(lf_ctx* ctx, int n_surfaces, int stop_index, int n_lambda,
     return lf_fail(ctx, LF_ERR_INVALID, "lens: bad sizes");
   if (ctx->W == 0) return lf_fail(ctx, LF_ERR_STATE, "lf_set_lens before lf_set_frame");
   for (int k = 0; k < n_surfaces; k++) {
-    if (!(semi_aperture[k] > 0)) return lf_fail(ctx, LF_ERR_INVALID, "lens: semi-aperture <= 0");
+    if (!(semi_aperture[k] > 0) || !std::isfinite(semi_aperture[k]))
+      return lf_fail(ctx, LF_ERR_INVALID, "lens: semi-aperture <= 0 or not finite");
+    if (!std::isfinite(radius[k]) || !std::isfinite(thickness[k]))
+      return lf_fail(ctx, LF_ERR_INVALID, "lens: radius / thickness not finite (a flat surface is radius 0)");
     if (k == stop_index && radius[k] != 0) return lf_fail(ctx, LF_ERR_INVALID, "lens: the stop must be flat");
     for (int l = 0; l < n_lambda; l++)
-      if (!(ior[l * n_surfaces + k] >= 1.0f) && k != stop_index)
-        return lf_fail(ctx, LF_ERR_INVALID, "lens: index of refraction < 1");
+      if ((!(ior[l * n_surfaces + k] >= 1.0f) || !std::isfinite(ior[l * n_surfaces + k])) && k != stop_index)
+        return lf_fail(ctx, LF_ERR_INVALID, "lens: index of refraction < 1 or not finite");
   }
   lf_derive_lens(ctx, n_surfaces, stop_index, n_lambda, radius, thickness, ior, semi_aperture,
                  sensor_width_mm);
