@@ -63,3 +63,15 @@ def test_lens_files_parse():
     assert dg["n"] == 11 and dg["stop"] == 5 and dg["ior"].shape == (3, 11)
     tl = pkg.load_lens_file("thinlens.lens")
     assert tl["n"] == 2 and tl["stop"] == -1
+
+
+def test_null_context_is_refused_everywhere():
+    """Every entry point that takes a context (or a group) returns LF_ERR_INVALID for NULL before it
+    looks at anything else -- no device needed, nothing dereferenced."""
+    pkg = _pkg()
+    lib = pkg.load_library()
+    header = open(os.path.join(ROOT, "include", "lensflare.h")).read()
+    fns = re.findall(r"lf_status\s+(lf_[a-z0-9_]+)\s*\(\s*lf_(?:ctx|group)\s*\*\s*\w+", header)
+    assert len(fns) > 70
+    for name in fns:
+        assert getattr(lib, name)(*([C.c_void_p(0)] * 14)) == 1, name
