@@ -40,6 +40,13 @@ CLOCK_HZ = 2.4e9
 VALU_PEAK = 256 * 4 * CLOCK_HZ / 2.0      # wave64 instructions / s: 1024 SIMD-32, 2 clk each
 VALU_PRACTICAL = 1.05e12                  # profiles/microbench/valu_issue.hip (independent v_fma_f32)
 SCALAR_PEAK = 256 * CLOCK_HZ              # one scalar unit per CU, one instruction per clock
+FP32_PEAK_TFLOPS = 256 * 4 * 32 * 2 * CLOCK_HZ / 1e12   # 157.3: 32 lanes x FMA per clock and SIMD (dense vector FP32)
+# arithmetic of ONE executed event as lf_march.hip's surface_event<false> codes it (a refraction at a curved
+# interface, the common row): 15 FMA + 8 multiplies / adds (38 flop) + 2 compares + 2 square roots = the
+# kernel's 27 vector instructions; the Fresnel weight of surface_event<true> adds 20 flop (17 instructions)
+# where it is evaluated.  SURVEY 8d guessed ~80 flop + 2 sqrt + 2 rcp for an event WITH its weight.
+FLOP_PER_EVENT = 38.0
+FLOP_PER_FRESNEL = 20.0
 SUN_NS = (0.521445, 0.517156)
 TILE_ROWS = 8   # the march kernel's sensor tile is 8x8 pixels
 PMC_FILES = [os.path.join(ROOT, "profiles", n) for n in ("r03_march_pmc.json", "r02_march_pmc.json")]   # newest first
@@ -531,6 +538,15 @@ def main():
                 "hbm": {"achieved": hbm_achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                         "frac": hbm_achieved / HBM_PEAK_GBS, "algorithmic_bytes_per_launch": alg_bytes,
                         "traffic_bytes_per_launch": None}}
+        alg_flop_s = (executed * FLOP_PER_EVENT + remarch_lane * FLOP_PER_FRESNEL) / dt / world
+        roof["flops"] = {"achieved": alg_flop_s / 1e12, "peak": FP32_PEAK_TFLOPS, "unit": "TFLOP/s",
+                         "frac": alg_flop_s / 1e12 / FP32_PEAK_TFLOPS,
+                         "algorithmic_flop_per_executed_event": FLOP_PER_EVENT,
+                         "algorithmic_flop_per_fresnel_weight": FLOP_PER_FRESNEL,
+                         "note": "ALGORITHMIC flop (an FMA = 2, a square root = 0) per GPU against the dense FP32 vector peak: "
+                                 "below the issue fraction because 12 of an event's 27 vector instructions are single "
+                                 "multiplies, adds, compares and roots (an issue slot with at most one flop), and the walk "
+                                 "around the events (liveness, forks, tallies) has none"}
         if pmc:
             same = pmc.get("source_sha") == source_sha()
             roof["pmc_matches_shipped_sources"] = same
