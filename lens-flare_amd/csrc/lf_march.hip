@@ -24,7 +24,7 @@
 //     the pairs that share them; forks park the ray state in LDS;
 //   * the first pass carries geometry only; the Fresnel / aperture weight is computed by
 //     re-marching the one path, and only for waves in which a lane reaches the sun's lobe;
-//   * the 4 waves of a workgroup share the tile and pull sample indices from an LDS counter;
+//   * the 8 waves of a workgroup share the tile and pull sample indices from an LDS counter;
 //     per-pixel sums are 64-bit fixed point in registers, merged through LDS, written once.
 //
 // Arithmetic contract (DESIGN.md "march arithmetic"): the ray's direction is carried as optical
@@ -301,12 +301,18 @@ __device__ __forceinline__ LfProgHdr load_phdr(const LfProgHdr* __restrict__ bas
 // instructions on four SIMDs (53 %); profiles/r02_*.  Each ray keeps its own liveness mask, tallies
 // are per ray, so pixels and counters are exactly those of K separate walks.
 // (second launch bound = waves per SIMD the register allocation must leave room for; the LDS
-// footprint allows at least as many workgroups of 4 waves per CU: 8 / 6 / 6 for K = 1 .. 3.  A 7th
+// footprint allows at least as many waves per CU: 32 / 24 / 24 for K = 1 .. 3.  A 7th
 // wave for K = 3 is not to be had: with the LDS made to fit (20 KB) the allocator, capped at 72
 // registers, adds 4 % of vector instructions and the frame takes 123 instead of 117 ms; occupancy sweep
 // 3 .. 7 waves per SIMD: 155, 133, 122, 117, 123 ms, profiles/r03_march_variants.txt)
+// A workgroup = one 8 x 8 tile marched by kWgWaves waves that pull its samples from one LDS counter.  8
+// waves rather than 4: a tile is finished in half the time, so half as many tiles are in flight when the
+// grid runs dry and the launch's tail -- the last workgroups running on a part-empty GPU -- is half as
+// long, at the same 24 waves per CU (3 workgroups of 50.8 KB LDS); c3 frame 115.5 -> 114.9 ms, shares of
+// a frame 1-2 % (profiles/r03_march_variants.txt; 6 and 2 waves are worse, 12 no better).
+constexpr int kWgWaves = 8;
 template <int K>
-__global__ __launch_bounds__(256, (K == 1 ? 8 : 6))
+__global__ __launch_bounds__(64 * kWgWaves, (K == 1 ? 8 : 6))
 void k_march(const LfLensDev* __restrict__ lens, const LfPairsDev* __restrict__ pairs,
              const int* __restrict__ seq_table, const LfProgHdr* __restrict__ hdr_table,
              const LfProgRow* __restrict__ rec_table, const LfWeightRow* __restrict__ wrec_table,
@@ -339,7 +345,7 @@ void k_march(const LfLensDev* __restrict__ lens, const LfPairsDev* __restrict__ 
   // reflection at i, once per sub-tree: 3-4x rarer, so its register copies are cheap) lives in
   // registers: with both in LDS a K = 3 workgroup needs 38 KB and only 4 waves fit a SIMD
   // (measured 147 -> 137 ms per bench frame)
-  __shared__ float2 s_state[4][K][3 * 64];
+  __shared__ float2 s_state[kWgWaves][K][3 * 64];
   // the start of the current sample's rays per lane (sensor point, direction, start weight): only
   // the head of each wavelength group and the rare weight re-march (~2.4x per sample) read it back,
   // so it must not occupy six registers during the walk.  6 KB of LDS.  Round 3 tried the two other
@@ -347,7 +353,7 @@ void k_march(const LfLensDev* __restrict__ lens, const LfPairsDev* __restrict__ 
   // pupil map, ~250 instructions, 2.4x per sample) costs 7 % of the frame; a per-wave slice of a GLOBAL
   // scratch buffer is 1.2 % faster than LDS, but a seventh to a quarter of its stores leave the L2 for
   // the fabric -- 1.8 to 3.2 GB of write-back per frame against 50.8 MB of algorithmic traffic.
-  __shared__ float s_start[4][6][64];
+  __shared__ float s_start[kWgWaves][6][64];
 #define LF_START(k, l) s_start[wave][k][l]
   // (read back through a lane index the compiler cannot see through -- launder() -- or it forwards the
   // stores to the loads and keeps the registers)
@@ -400,8 +406,8 @@ void k_march(const LfLensDev* __restrict__ lens, const LfPairsDev* __restrict__ 
   unsigned long long n_rm_lane = 0, n_rm_rows = 0;   // the weight re-march (diagnostics, lf_get_march_stats)
 
   {
-    // The 4 waves of the workgroup pull sample indices from one LDS counter instead of owning
-    // every 4th one: a wave whose pupil cells fall outside the aperture finishes its samples in a
+    // The waves of the workgroup pull sample indices from one LDS counter instead of owning
+    // every kWgWaves-th one: a wave whose pupil cells fall outside the aperture finishes its samples in a
     // fraction of the time, and a static split leaves it idle until the slowest wave is done.
     // (Which wave marches which sample does not matter: the sums are integers.)
     for (;;) {
@@ -1309,13 +1315,15 @@ lf_status lfk_march(lf_ctx* ctx, int spp, uint64_t key) {
   const int n_trows = (t_hi - 1 - first) / period + 1;
   a.trow0 = first; a.tperiod = period;
   const size_t tiles = (size_t)n_trows * ((ctx->W + 7) / 8);
-  // A launch that covers only part of the frame (one GPU's share) keeps >= 24k workgroups in flight
-  // by splitting each tile's samples over `sgroups` workgroups (power of two), so that its tail
-  // stays short -- but a workgroup needs >= 64 samples to amortise its set-up and its 192 global
-  // atomics.  The whole frame on one GPU stays unsplit: the split costs 5x the HBM write traffic
-  // (atomics) for 1 % of time.
+  // A launch that covers only part of the frame (one GPU's share) splits each tile's samples over
+  // `sgroups` workgroups (power of two): more, shorter workgroups keep its tail short -- but a workgroup
+  // needs >= 64 samples to amortise its set-up and its 192 global atomics.  The whole frame on one GPU
+  // stays unsplit: the split is worth another 0.5 % there and costs 5x the HBM write traffic (atomics).
+  // Measured per share of the 1080p bench frame (profiles/r03_share_timing.json): 1 / 2 / 2 / 2 groups
+  // for 1, 1/2, 1/4, 1/8 of the frame.
   a.sgroups = 1;
-  while (tiles * a.sgroups < 24000 && a.sgroups * 2 * 64 <= spp) a.sgroups *= 2;
+  while (tiles * a.sgroups < 8000 && a.sgroups * 2 * 64 <= spp) a.sgroups *= 2;
+  if (a.sgroups == 1 && tiles < 20000 && 2 * 64 <= spp) a.sgroups = 2;
   if (const char* sgv = std::getenv("LF_MARCH_SGROUPS")) {  // experiments only
     int v = std::atoi(sgv);
     if (v >= 1 && v * 4 <= std::max(4, spp) && (v & (v - 1)) == 0) a.sgroups = v;
@@ -1335,7 +1343,7 @@ lf_status lfk_march(lf_ctx* ctx, int spp, uint64_t key) {
   if (const char* dl = std::getenv("LF_MARCH_DYN_LDS")) dyn_lds = (size_t)std::max(0, std::atoi(dl));
   hipEvent_t ev = lf_timing_begin(ctx, LFK_MARCH);
 #define LF_LAUNCH_MARCH(KK)                                                                        \
-  hipLaunchKernelGGL(k_march<KK>, dim3((unsigned)blocks), dim3(256), dyn_lds, ctx->stream, ctx->lens_dev, \
+  hipLaunchKernelGGL(k_march<KK>, dim3((unsigned)blocks), dim3(64 * kWgWaves), dyn_lds, ctx->stream, ctx->lens_dev, \
                      ctx->pairs_dev, (const int*)(ctx->prog_dev + ctx->prog_seq_off),                \
                      (const LfProgHdr*)ctx->prog_dev,                                               \
                      (const LfProgRow*)(ctx->prog_dev + ctx->prog_rec_off),                         \
