@@ -11,16 +11,17 @@
 // over two-child nodes with conservative FLOAT boxes, lf_scene_types.h): the closest hit does not
 // depend on the tree, only the amount of work does -- the primitive tests stay the reference's doubles.
 //
-// Sampled lights -- AreaLight and InfiniteHemisphereLight (scene/light.cpp:35-48, :82-101) with
-// ns_area_light samples each, exactly the estimator of estimate_direct_lighting_importance
-// (pathtracer.cpp:143-213) -- draw from the order-free Philox counter RNG: the reference draws them
-// from its shared MT19937 only when a camera ray hits something, which makes every later pixel's
-// jitter depend on every earlier pixel's hits, so no device schedule can reproduce its stream.
+// Sampled lights -- AreaLight, InfiniteHemisphereLight and EnvironmentLight (scene/light.cpp:35-48,
+// :82-101; scene/environment_light.cpp) with ns_area_light samples each, exactly the estimator of
+// estimate_direct_lighting_importance (pathtracer.cpp:143-213), and the uniform hemisphere sampling of
+// emitters (-H, pathtracer.cpp:86-138) -- draw from the order-free Philox counter RNG: the reference
+// draws them from its shared MT19937 only when a camera ray hits something, which makes every later
+// pixel's jitter depend on every earlier pixel's hits, so no device schedule can reproduce its stream.
 // They are therefore validated statistically against frames the reference rendered
-// (tests/test_gpu_area_lights.py) and refused in MT19937 parity mode.
-// Not covered (the call fails loudly rather than approximating): environment maps, uniform
-// hemisphere sampling of emitters (-H), spot lights (a stub in the reference, light.cpp:64-72) and
-// the Mirror/Glass/Microfacet BSDFs, which are unfilled stubs in the reference (advanced_bsdf.cpp).
+// (tests/test_gpu_area_lights.py, tests/test_gpu_env_light.py) and refused in MT19937 parity mode.
+// Not covered (the call fails loudly rather than approximating): spot lights (a stub in the reference,
+// light.cpp:64-72).  The Mirror / Glass / Microfacet BSDFs are unfilled stubs in the reference
+// (advanced_bsdf.cpp: f() = 0): a host hands them over as black diffuse occluders.
 #include <algorithm>
 #include <cmath>
 #include <cstdlib>
