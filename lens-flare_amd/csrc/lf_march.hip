@@ -25,7 +25,7 @@
 //   * the first pass carries geometry only; the Fresnel / aperture weight is computed by
 //     re-marching the one path, and only for waves in which a lane reaches the sun's lobe;
 //   * the 8 waves of a workgroup share the tile and pull sample indices from an LDS counter;
-//     per-pixel sums are 64-bit fixed point in registers, merged through LDS, written once.
+//     per-pixel sums are 64-bit fixed point, added straight into LDS by the rare lit lanes, written once.
 //
 // Arithmetic contract (DESIGN.md "march arithmetic"): the ray's direction is carried as optical
 // direction cosines K = n d (round 3); float32, every multiply-add written as an
@@ -302,7 +302,7 @@ __device__ __forceinline__ LfProgHdr load_phdr(const LfProgHdr* __restrict__ bas
 // are per ray, so pixels and counters are exactly those of K separate walks.
 // (second launch bound = waves per SIMD the register allocation must leave room for; the LDS
 // footprint allows at least as many waves per CU: 32 / 24 / 24 for K = 1 .. 3.  A 7th
-// wave for K = 3 is not to be had: with the LDS made to fit (20 KB) the allocator, capped at 72
+// wave for K = 3 is not to be had: with the LDS made to fit (5 KB per wave) the allocator, capped at 72
 // registers, adds 4 % of vector instructions and the frame takes 123 instead of 117 ms; occupancy sweep
 // 3 .. 7 waves per SIMD: 155, 133, 122, 117, 123 ms, profiles/r03_march_variants.txt)
 // A workgroup = one 8 x 8 tile marched by kWgWaves waves that pull its samples from one LDS counter.  8
@@ -343,12 +343,12 @@ void k_march(const LfLensDev* __restrict__ lens, const LfPairsDev* __restrict__ 
   // parked ray states: [wave][slot][ray][px py|pz dx|dy dz][lane]
   // fork slot 1 (the reflection at j, parked and restored once per pair) is parked here; slot 0 (the
   // reflection at i, once per sub-tree: 3-4x rarer, so its register copies are cheap) lives in
-  // registers: with both in LDS a K = 3 workgroup needs 38 KB and only 4 waves fit a SIMD
+  // registers: with both in LDS a K = 3 wave needs 9.5 KB and only 4 waves fit a SIMD
   // (measured 147 -> 137 ms per bench frame)
   __shared__ float2 s_state[kWgWaves][K][3 * 64];
   // the start of the current sample's rays per lane (sensor point, direction, start weight): only
   // the head of each wavelength group and the rare weight re-march (~2.4x per sample) read it back,
-  // so it must not occupy six registers during the walk.  6 KB of LDS.  Round 3 tried the two other
+  // so it must not occupy six registers during the walk.  1.5 KB of LDS per wave.  Round 3 tried the two other
   // homes (profiles/r03_march_variants.txt): RECOMPUTING it where a ray starts (two Philox draws + the
   // pupil map, ~250 instructions, 2.4x per sample) costs 7 % of the frame; a per-wave slice of a GLOBAL
   // scratch buffer is 1.2 % faster than LDS, but a seventh to a quarter of its stores leave the L2 for
