@@ -209,9 +209,7 @@ def test_c3_band_at_full_spp_against_the_independent_tracer(pkg, lf):
           f"({c64['rays_fragile']} fragile rays of {c64['rays_launched']})")
 
 
-def test_c5_band_of_the_4k_frame_against_the_independent_tracer(pkg, lf):
-    """C5's frame size and its 8 wavelengths, a 16-row band through the sun at 64 of the 1024 spp
-    (both sides evaluate the same samples, so the sample count only sets the coverage: 1.4e9 rays)."""
+def _c5_band(pkg, lf, spp, rows_per_call=16):
     lens3 = pkg.load_lens_file("dgauss11.lens")
     t = np.linspace(0.0, 2.0, 8)
     ior8 = np.stack([np.array([np.interp(tt, [0, 1, 2], lens3["ior"][:, k]) for k in range(lens3["n"])])
@@ -222,11 +220,28 @@ def test_c5_band_of_the_4k_frame_against_the_independent_tracer(pkg, lf):
         for c in range(3):
             w8[l, c] = max(0.0, 1.0 - abs(tt - c)) / 2.6666667
     mask = load_texels("pentbig500_14.png")
-    W, H, spp, key = 3840, 2160, 64, 0xC5C5
-    y0 = (int(SUN_NS[1] * H) // 8) * 8 - 8
-    rel, needed, c64 = _band_against_f64(pkg, lf, lens8, W, H, y0, y0 + 16, spp, key, mask, lambda_rgb=w8, min_lit=2000)
-    print(f"c5 band rows {y0}..{y0 + 16}: {rel.size} lit channel values, max rel {rel.max():.2e}; allowance "
-          f"needed by {needed}")
+    W, H, key = 3840, 2160, 0xC5C5
+    y_top = (int(SUN_NS[1] * H) // 8) * 8 - 8
+    for y0 in range(y_top, y_top + 16, rows_per_call):   # (sub-bands: a progress line every few minutes)
+        y1 = y0 + rows_per_call
+        rel, needed, c64 = _band_against_f64(pkg, lf, lens8, W, H, y0, y1, spp, key, mask, lambda_rgb=w8,
+                                             min_lit=2000 * rows_per_call // 16)
+        print(f"c5 band rows {y0}..{y1} at {spp} spp: {rel.size} lit channel values, max rel {rel.max():.2e}, median "
+              f"{np.median(rel):.2e}; allowance needed by {needed} ({c64['rays_fragile']} fragile rays of "
+              f"{c64['rays_launched']})", flush=True)
+
+
+def test_c5_band_of_the_4k_frame_against_the_independent_tracer(pkg, lf):
+    """C5's frame size and its 8 wavelengths, a 16-row band through the sun at 64 of the 1024 spp
+    (both sides evaluate the same samples, so the sample count only sets the coverage: 1.4e9 rays)."""
+    _c5_band(pkg, lf, 64)
+
+
+@pytest.mark.skipif(__import__("os").environ.get("LF_LONG_CHECKS") != "1",
+                    reason="minutes of host time on a many-core box: LF_LONG_CHECKS=1 (record: profiles/r03_f64_whole_frame.log)")
+def test_c5_band_at_full_spp_against_the_independent_tracer(pkg, lf):
+    """The same band of the C5 frame at its FULL 1024 spp (2.3e10 rays: a third of the whole c3 frame)."""
+    _c5_band(pkg, lf, 1024, rows_per_call=4)
 
 
 @pytest.mark.skipif(__import__("os").environ.get("LF_LONG_CHECKS") != "1",
