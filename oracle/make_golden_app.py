@@ -37,6 +37,17 @@ CAM_D = """40.0 40.0 1 0.01 100
 4.7 0
 """
 
+# the camera maxplanck.dae itself declares (5 units in front of the bust, looking down -z; its sun stands
+# behind that camera: a frame without a flare, all scene term -- 50 801 triangles through the
+# reference's own BVH on one side and through the device's on the other)
+CAM_MAXPLANCK = """39.5978 22.8952 1.7777777778 0.01 10000
+0.0 0.0 5.0 0.0 0.0 0.0
+0.0 0.0 5.0 0.5 100
+1.0 0.0 0.0 0.0 1.0 0.0 0.0 0.0 1.0
+{W} {H} 300.0
+4.7 0
+"""
+
 APP_CASES = [
     # a frame that is no multiple of the 32-pixel tile, 2 camera rays per pixel, one worker (the only
     # configuration in which the reference itself is reproducible: its workers share one generator)
@@ -44,6 +55,8 @@ APP_CASES = [
          ap="pentbiglines.png", gh="octagonbokeh.png", radius=25, intensity=1, autofocus=(48, 20)),
     dict(name="pyramid_130x70", dae="pyramid.dae", cam=CAM_D, W=130, H=70, ns_aa=1, threads=1,
          ap="pentsmalllines.png", gh="pent4_10.png", radius=12, intensity=2.5, autofocus=(10, 60)),
+    dict(name="maxplanck_192x108", dae="maxplanck.dae", dae_dir="data", cam=CAM_MAXPLANCK, W=192, H=108, ns_aa=1,
+         threads=1, ap="pentbiglines.png", gh="octagonbokeh.png", radius=25, intensity=1, autofocus=(96, 54)),
 ]
 
 MEMBER_CASES = [
@@ -63,7 +76,9 @@ def app_args(case, tmp, out):
     cam = os.path.join(tmp, "cam.txt")
     with open(cam, "w") as f:
         f.write(case["cam"].format(W=case["W"], H=case["H"]))
-    return [os.path.join(mg.GOLD, "collada", case["dae"]), cam, str(case["W"]), str(case["H"]), str(case["ns_aa"]),
+    dae = (os.path.join(os.path.dirname(HERE), "lens-flare_amd", "data", case["dae"]) if case.get("dae_dir") == "data"
+           else os.path.join(mg.GOLD, "collada", case["dae"]))
+    return [dae, cam, str(case["W"]), str(case["H"]), str(case["ns_aa"]),
             str(case["threads"]), png(case["ap"]), png(case["gh"]), repr(float(case["radius"])),
             repr(float(case["intensity"])), out] + [repr(float(v)) for v in case["autofocus"]]
 
