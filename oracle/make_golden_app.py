@@ -48,6 +48,13 @@ CAM_MAXPLANCK = """39.5978 22.8952 1.7777777778 0.01 10000
 4.7 0
 """
 
+def cam_meshedit(z):
+    """the default camera the meshedit scenes declare: on the z axis, looking at the origin"""
+    sgn = 1.0 if z > 0 else -1.0
+    return ("39.5978 22.8952 1.7777777778 0.01 10000\n0.0 0.0 %r 0.0 0.0 0.0\n0.0 0.0 %r 0.5 100\n"
+            "%r 0.0 0.0 0.0 1.0 0.0 0.0 0.0 %r\n{W} {H} 300.0\n4.7 0\n" % (z, abs(z), sgn, sgn))
+
+
 APP_CASES = [
     # a frame that is no multiple of the 32-pixel tile, 2 camera rays per pixel, one worker (the only
     # configuration in which the reference itself is reproducible: its workers share one generator)
@@ -57,7 +64,19 @@ APP_CASES = [
          ap="pentsmalllines.png", gh="pent4_10.png", radius=12, intensity=2.5, autofocus=(10, 60)),
     dict(name="maxplanck_192x108", dae="maxplanck.dae", dae_dir="data", cam=CAM_MAXPLANCK, W=192, H=108, ns_aa=1,
          threads=1, ap="pentbiglines.png", gh="octagonbokeh.png", radius=25, intensity=1, autofocus=(96, 54)),
-]
+    # two more of the meshes the reference ships (dae/meshedit), their own cameras and sun
+    dict(name="teapot_160x90", dae="teapot.dae", cam=cam_meshedit(5.0), W=160, H=90, ns_aa=2, threads=1,
+         ap="pentbiglines.png", gh="octagonbokeh.png", radius=25, intensity=1, autofocus=(80, 45)),
+    dict(name="cow_128x72", dae="cow.dae", cam=cam_meshedit(5.0), W=128, H=72, ns_aa=1, threads=1,
+         ap="pentsmalllines.png", gh="pent4_10.png", radius=12, intensity=2.5, autofocus=(64, 36)),
+] + ([
+    # one-off sweep (LF_GOLDEN_EXTRA=1, the .dae copied next to the others for the occasion; not committed:
+    # profiles/r03_mesh_sweep.log)
+    dict(name="beetle_160x90", dae="beetle.dae", cam=cam_meshedit(5.0), W=160, H=90, ns_aa=1, threads=1,
+         ap="pentbiglines.png", gh="octagonbokeh.png", radius=25, intensity=1, autofocus=(80, 45)),
+    dict(name="peter_160x90", dae="peter.dae", cam=cam_meshedit(-5.0), W=160, H=90, ns_aa=1, threads=1,
+         ap="pentbiglines.png", gh="octagonbokeh.png", radius=25, intensity=1, autofocus=(80, 45)),
+] if os.environ.get("LF_GOLDEN_EXTRA") == "1" else [])
 
 MEMBER_CASES = [
     dict(name="spheres_96x72", cam=CAM_D, W=96, H=72, ap="pentbiglines.png", gh="octagonbokeh.png",
