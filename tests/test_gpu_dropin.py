@@ -285,3 +285,23 @@ def test_lens_camera_generate_rays(tmp_path):
     assert np.array_equal(np.array(single[:7]), rows[0, :7]) and single[7] == 1
     drawn = lines[65].split()
     assert drawn[0] == "drawn" and int(drawn[7]) == 1    # a random pupil point that passes is found
+
+
+def test_sun_outside_the_frame_renders_the_scene_without_a_flare(tmp_path):
+    """teapot.dae from the camera the file declares (3 units away): the sun's image falls above the frame,
+    find_sun_pos keeps no flare -- and the REFERENCE then reads flare_origins[0] of an empty vector
+    (pathtracer.cpp:918, :968) and dies with SIGSEGV on this very command line (seen again
+    while making the fixtures).  The replacement must render the scene term, without a flare, and exit 0."""
+    import make_golden_app as mga
+    assert os.path.exists(APP), "oracle/_ref/ref_app_amd is missing: make -C oracle app (build container)"
+    case = dict(name="teapot_nosun", dae="teapot.dae", cam=mga.cam_meshedit(3.0), W=160, H=90, ns_aa=1, threads=3,
+                ap="pentbiglines.png", gh="octagonbokeh.png", radius=25, intensity=1, autofocus=(80, 45))
+    out = str(tmp_path / "out.png")
+    r = subprocess.run([APP] + mga.app_args(case, str(tmp_path), out), capture_output=True, text=True, timeout=600,
+                       cwd=str(tmp_path))
+    assert r.returncode == 0, r.stderr[-2000:]
+    from PIL import Image
+    img = np.asarray(Image.open(out).convert("RGB")).astype(int)
+    lit = img.max(axis=-1) > 0
+    assert 0.1 < lit.mean() < 0.9          # the teapot in front of a black background: no falloff glow, no starburst
+    assert img[0, 0].max() == 0 and img[-1, -1].max() == 0
