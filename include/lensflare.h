@@ -435,6 +435,52 @@ lf_status lf_trace_ghosts(lf_ctx* ctx, int spp, uint64_t key);
  * alive (1/0)} in lens space (optical axis = z, light travels +z, the scene lies at z < 0). */
 lf_status lf_generate_lens_rays(lf_ctx* ctx, int lambda, size_t n, const float* sensor_xy_mm,
                                 const float* pupil_uv, float* out);
+/* ---- the lens camera of the scene term (round 4) -----------------------------------------------
+ * replaces: the call `camera->generate_ray(x, y)` in the sample loop of PathTracer::raytrace_pixel
+ * (src/pathtracer/pathtracer.cpp:841-850) -- a pinhole in the reference (camera.cpp:278-305; its
+ * thin-lens variant is a stub, camera_lens.cpp:22-30, declared camera.h:168) -- by the north star's
+ * "for each sensor sample, march a ray through the lens prescription ... accumulate radiance into
+ * the sensor buffer": with mode != 0 lf_render_scene_term starts sample s of pixel (x, y) exactly as
+ * lf_trace_ghosts does (the same counter-RNG block, sensor point, pupil stratum and sub-cell; key =
+ * lf_set_jitter_counter's, strata for ns_aa samples), marches its primary path N-1 .. 0 through the
+ * prescription with the Fresnel / aperture weight (the arithmetic of lf_generate_lens_rays), carries
+ * the exit ray into the scene by the camera's pose (lens space = camera space: x right, y up, scene
+ * at -z; lens millimetres times world_per_mm; the centre of the paraxial entrance pupil sits at the
+ * camera position) and weights the radiance it finds by exposure x transmitted weight.  A sample the
+ * lens blocks contributes 0 and still counts in the mean (the division by the loop variable,
+ * pathtracer.cpp:875, is unchanged).
+ *   mode 0  off: the reference's pinhole camera (default)
+ *   mode 1  one ray per sample at the reference wavelength (index n_lambda / 2) carries R, G and B
+ *   mode 2  one ray per wavelength; channel c collects lambda_rgb[l][c] of wavelength l's radiance
+ *           (lateral and axial colour show; n_lambda closest-hit searches per sample)
+ * exposure <= 0 calibrates: 1 / (mean transmitted weight of the on-axis sensor point over a 64 x 64
+ * grid of pupil points, reference wavelength), so that a scene of uniform radiance L renders as L at
+ * the frame's centre -- what the reference's pinhole returns everywhere.  The calibration and the
+ * interface table follow later changes of the lens, the stop mask and the pupil target.
+ * Needs lf_set_lens / lf_load_lens_file, the stop mask (LF_APERTURE_STARBURST slot), lf_set_camera
+ * and the counter RNG (MT19937 parity mode is refused: its table has no pupil draws).
+ * lf_get_lens_camera: the settings in force (after calibration) and the entrance pupil's z (mm). */
+lf_status lf_set_lens_camera(lf_ctx* ctx, int mode, double world_per_mm, double exposure);
+lf_status lf_get_lens_camera(lf_ctx* ctx, int* mode, double* world_per_mm, double* exposure,
+                             double* entrance_pupil_z_mm);
+/* the paraxial image of the stop's centre through the interfaces IN FRONT of it (host arithmetic with
+ * the reference's T / R operators, pathtracer.cpp:527-533): its z in lens space (the front vertex is
+ * z = 0, the scene at z < 0; typically a few mm > 0, inside the lens) and its lateral magnification */
+lf_status lf_paraxial_entrance_pupil(int n_surfaces, int stop_index, const float* radius, const float* thickness,
+                                     const float* ior_row, double* z_mm, double* magnification);
+/* replaces: Camera::focalDistance (camera.h:174; the -d flag) for a real lens: moves the sensor -- the
+ * prescription's last thickness -- to the paraxial image (reference wavelength) of an axial object
+ * object_distance_mm in front of the first vertex; <= 0 or infinite: focus at infinity.  The pair
+ * selection, wavelength weights and a still-valid pupil target survive; march program, lens-camera
+ * table and calibration are rebuilt on next use.  sensor_distance_mm: the new last thickness. */
+lf_status lf_focus_lens(lf_ctx* ctx, double object_distance_mm, float* sensor_distance_mm);
+/* replaces: BVHAccel::total_rays / total_isects (src/scene/bvh.h:85,105,136; bvh.cpp:211), the numbers
+ * behind the reference's end-of-frame log (raytraced_renderer.cpp:706-709), as the device's scene
+ * kernel counts them since the last reset: out = {rays handed to the closest-hit / occlusion search
+ * (camera + shadow + hemisphere rays), primitive tests of closest-hit searches, lens-camera samples
+ * started (one per sample and traced wavelength), of those that left the front element} */
+lf_status lf_get_scene_counters(lf_ctx* ctx, uint64_t out[4]);
+lf_status lf_reset_scene_counters(lf_ctx* ctx);
 /* Host logic of the march, inspectable WITHOUT a device (used by the CPU tests): builds what
  * lf_trace_ghosts uploads for a prescription and a pair selection (arguments as lf_set_lens /
  * lf_set_ghost_pairs; pairs = NULL selects every glass pair).

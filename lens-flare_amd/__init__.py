@@ -39,6 +39,8 @@ ABI_SYMBOLS = [
     "lf_shift_vertex", "lf_compute_phase", "lf_irradiance_falloff", "lf_scene_trace_ray", "lf_scene_shade",
     "lf_load_lens_file", "lf_get_lens_info",
     "lf_set_pupil_target", "lf_get_pupil_target", "lf_aim_at_exit_pupil", "lf_paraxial_exit_pupil", "lf_set_ghost_accumulate",
+    "lf_set_lens_camera", "lf_get_lens_camera", "lf_paraxial_entrance_pupil", "lf_focus_lens",
+    "lf_get_scene_counters", "lf_reset_scene_counters",
     "lf_comm_get_unique_id", "lf_comm_init_rank", "lf_comm_gather", "lf_comm_gather_async", "lf_comm_wait",
     "lf_comm_destroy", "lf_comm_available", "lf_comm_info", "lf_comm_test", "lf_comm_abort",
     "lf_comm_set_exchange_precision",
@@ -60,6 +62,22 @@ def paraxial_exit_pupil(lens, lam=None):
                                     _fp(row, C.c_float), C.byref(z), C.byref(m))
     if st != 0:
         raise LensFlareError(st, "lf_paraxial_exit_pupil")
+    return z.value, m.value
+
+
+def paraxial_entrance_pupil(lens, lam=None):
+    """(z_mm, magnification) of the paraxial image of the stop through the front group (host arithmetic)."""
+    lib = load_library()
+    ior = np.ascontiguousarray(lens["ior"], np.float32)
+    lam = ior.shape[0] // 2 if lam is None else lam
+    r = np.ascontiguousarray(lens["radius"], np.float32)
+    t = np.ascontiguousarray(lens["thickness"], np.float32)
+    row = np.ascontiguousarray(ior[lam], np.float32)
+    z, m = C.c_double(), C.c_double()
+    st = lib.lf_paraxial_entrance_pupil(int(lens["n"]), int(lens["stop"]), _fp(r, C.c_float), _fp(t, C.c_float),
+                                        _fp(row, C.c_float), C.byref(z), C.byref(m))
+    if st != 0:
+        raise LensFlareError(st, "lf_paraxial_entrance_pupil")
     return z.value, m.value
 
 
@@ -598,6 +616,28 @@ class LensFlare:
     def aim_at_exit_pupil(self, margin=1.0):
         self._ck(self.lib.lf_aim_at_exit_pupil(self.ctx, C.c_float(margin)))
         return self.pupil_target()
+
+    def set_lens_camera(self, mode=1, world_per_mm=0.001, exposure=0.0):
+        """The scene term's sample loop images the scene through the prescription (0 = pinhole)."""
+        self._ck(self.lib.lf_set_lens_camera(self.ctx, int(mode), C.c_double(world_per_mm), C.c_double(exposure)))
+
+    def lens_camera(self):
+        m, w, e, z = C.c_int(), C.c_double(), C.c_double(), C.c_double()
+        self._ck(self.lib.lf_get_lens_camera(self.ctx, C.byref(m), C.byref(w), C.byref(e), C.byref(z)))
+        return dict(mode=m.value, world_per_mm=w.value, exposure=e.value, entrance_pupil_z_mm=z.value)
+
+    def focus_lens(self, object_distance_mm):
+        d = C.c_float()
+        self._ck(self.lib.lf_focus_lens(self.ctx, C.c_double(object_distance_mm), C.byref(d)))
+        return d.value
+
+    def scene_counters(self):
+        v = (C.c_uint64 * 4)()
+        self._ck(self.lib.lf_get_scene_counters(self.ctx, v))
+        return dict(rays=int(v[0]), isects=int(v[1]), lens_samples=int(v[2]), lens_left=int(v[3]))
+
+    def reset_scene_counters(self):
+        self._ck(self.lib.lf_reset_scene_counters(self.ctx))
 
     def set_ghost_accumulate(self, on):
         self._ck(self.lib.lf_set_ghost_accumulate(self.ctx, int(bool(on))))

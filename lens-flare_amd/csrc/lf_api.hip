@@ -198,13 +198,16 @@ lf_status lf_create(lf_ctx** out, int device) {
             hipMalloc((void**)&ctx->pl_dev, sizeof(LfParaxialLens)) == hipSuccess &&
             hipMalloc((void**)&ctx->lens_dev, sizeof(LfLensDev)) == hipSuccess &&
             hipMalloc((void**)&ctx->pairs_dev, sizeof(LfPairsDev)) == hipSuccess &&
-            hipMalloc((void**)&ctx->counters_dev, kMarchCounterSlots * sizeof(unsigned long long)) == hipSuccess;
+            hipMalloc((void**)&ctx->counters_dev, kMarchCounterSlots * sizeof(unsigned long long)) == hipSuccess &&
+            hipMalloc((void**)&ctx->scene_counters_dev, kSceneCounters * sizeof(unsigned long long)) == hipSuccess &&
+            hipMalloc((void**)&ctx->primary_dev, sizeof(LfPrimaryDev)) == hipSuccess;
   for (int s = 0; s < 2 && ok; s++)
     ok = hipMalloc((void**)&ctx->ap[s].stats, sizeof(lf_aperture_stats)) == hipSuccess;
   if (!ok) { lf_destroy(ctx); return LF_ERR_OOM; }
   (void)hipMemset(ctx->flares, 0, sizeof(LfFlares));
   (void)hipMemset(ctx->ghosts, 0, sizeof(LfGhostList));
   (void)hipMemset(ctx->counters_dev, 0, kMarchCounterSlots * sizeof(unsigned long long));
+  (void)hipMemset(ctx->scene_counters_dev, 0, kSceneCounters * sizeof(unsigned long long));
   if (upload_paraxial(ctx) != LF_OK) { lf_destroy(ctx); return LF_ERR_HIP; }
   *out = ctx;
   return LF_OK;
@@ -227,7 +230,8 @@ lf_status lf_destroy(lf_ctx* ctx) {
                   ctx->lens_dev, ctx->pairs_dev, ctx->counters_dev, ctx->accum,
                   ctx->prog_dev, ctx->sun_lights_dev,
                   ctx->scene_dev.nodes, ctx->scene_dev.prims, ctx->scene_dev.normals, ctx->scene_dev.materials,
-                  ctx->scene_dev.lights, ctx->env_block, ctx->probe_dev};
+                  ctx->scene_dev.lights, ctx->env_block, ctx->probe_dev, ctx->scene_counters_dev,
+                  ctx->primary_dev};
   for (void* p : ptrs) if (p) (void)hipFree(p);
   if (ctx->own_stream && ctx->stream) (void)hipStreamDestroy(ctx->stream);
   delete ctx;
@@ -354,6 +358,7 @@ lf_status lf_set_aperture(lf_ctx* ctx, lf_aperture_slot slot, const float* texel
   a.valid = true;
   if (slot == LF_APERTURE_STARBURST) {
     ctx->spectrum_valid = false;
+    ctx->lenscam_dirty = true;   // the stop mask is part of the lens camera's exposure calibration
     size_t rows = a.host_stats.max_y >= a.host_stats.min_y
                       ? (size_t)(a.host_stats.max_y - a.host_stats.min_y + 1) : 1;
     if ((st = dev_alloc(ctx, &ctx->spectrum, (size_t)width * width)) != LF_OK) return st;

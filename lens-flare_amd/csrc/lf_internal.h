@@ -195,6 +195,45 @@ struct alignas(64) LfWeightRow {
 //                  tallied per logical path, exactly as if each had been marched on its own)
 enum { LF_EV_REST1 = 8, LF_EV_SAVE0 = 0x10, LF_EV_SAVE1 = 0x20, LF_EV_END = 0x40, LF_EV_REST0 = 0x80 };
 
+// ---- lens camera (round 4): the scene imaged through the prescription --------------------------
+// The primary path N-1 .. 0 of a sensor sample (the ray travels -z, against the light), one row per
+// interface in the order the ray meets them, the constants of surface_event for EVERY wavelength
+// (lf_march.hip pack_program's float arithmetic; lf_lens_camera.hip build_primary_table).  Read by
+// k_lens_rays and by k_scene_term's lens mode through the scalar cache.
+struct LfPrimaryRow {
+  float dzv, curv, ch, c2, sc, h2;
+  int kind;        // 0 = curved glass, LF_EV_STOP, LF_EV_FLAT
+  int pad;
+  float cn22[LF_MAX_LAMBDA], rn2[LF_MAX_LAMBDA], delta[LF_MAX_LAMBDA];
+  float fs[LF_MAX_LAMBDA], fo[LF_MAX_LAMBDA], fi[LF_MAX_LAMBDA];
+};
+struct LfPrimaryDev {
+  int n, n_lambda;
+  float inv_stop_h;      // 1 / stop_h (correctly rounded)
+  float front_zv;        // vertex z of interface 0 (0 by construction; kept for clarity)
+  float n_start[LF_MAX_LAMBDA];
+  LfPrimaryRow row[LF_MAX_SURFACES];
+};
+// what k_scene_term's lens mode needs beside the table (kernel argument, by value)
+struct LfLensCamArgs {
+  int mode;              // 1 = one reference wavelength carries R, G and B; 2 = one ray per wavelength
+  int lambda_ref, n_lambda;
+  int W, G;              // sample_start's SampleSpec (the march's sampling specification)
+  float inv_G;
+  int sub_bits;
+  float inv_sub;
+  float pitch, half_w, half_h, pupil_h, vz, geom_norm;
+  int mw, mh;
+  double exposure;       // scale of the transmitted weight (lf_set_lens_camera)
+  double world_per_mm;   // lens millimetres -> scene units
+  double z_ref_mm;       // lens-space z that sits at the camera position (the entrance pupil's centre)
+  float lambda_rgb[LF_MAX_LAMBDA][3];
+};
+// k_scene_term's device counters: rays handed to the closest-hit search (camera + shadow + hemisphere
+// rays: BVHAccel::total_rays, bvh.h:85,105), primitive tests of closest-hit queries
+// (BVHAccel::total_isects, bvh.cpp:211), lens samples started / that left the front element
+constexpr int kSceneCounters = 4;
+
 // ---- timing ---------------------------------------------------------------------------------
 enum LfKernelId { LFK_MARCH = 0, LFK_FLARE_LAYER, LFK_GHOST_RASTER, LFK_DFT, LFK_FRAME_SETUP,
                   LFK_TONEMAP, LFK_EXCHANGE, LFK_SCENE, LFK_COUNT };
@@ -263,6 +302,17 @@ struct lf_ctx {
   bool hemisphere_sample = false; // PathTracer::direct_hemisphere_sample (pathtracer.h:114; the -H flag)
   int samples_per_batch = 32;     // PathTracer::samplesPerBatch default (raytraced_renderer.h:67-81)
   double max_tolerance = 0.05;    // PathTracer::maxTolerance
+  unsigned long long* scene_counters_dev = nullptr;   // kSceneCounters x u64 (lf_get_scene_counters)
+
+  // lens camera (lf_lens_camera.hip): the scene term's sample loop marches each sensor sample's primary
+  // path through the prescription instead of calling the pinhole Camera::generate_ray
+  int lenscam_mode = 0;               // 0 = off (pinhole), 1 = reference wavelength, 2 = per wavelength
+  double lenscam_world_per_mm = 0.001;
+  double lenscam_exposure_req = 0.0;  // what lf_set_lens_camera asked for; <= 0: calibrate on the axis
+  double lenscam_exposure = 1.0;      // what the kernel uses
+  double lenscam_z_ref = 0.0;         // entrance pupil z (mm, lens space)
+  bool lenscam_dirty = true;          // table / calibration older than the lens, the mask or the pupil target
+  LfPrimaryDev* primary_dev = nullptr;
 
   // geometric
   LfLensDev lens{};
@@ -336,6 +386,10 @@ lf_status lfk_flip_rows(lf_ctx* ctx, uint32_t* out_dev);
 lf_status lfk_march(lf_ctx* ctx, int spp, uint64_t key);
 lf_status lfk_lens_rays(lf_ctx* ctx, int lambda, int n, const float* d_xy, const float* d_uv,
                         float* d_out);
+// lf_lens_camera.hip
+lf_status lf_lenscam_prepare(lf_ctx* ctx);            // table + calibration up to date (no-op when clean)
+lf_status lf_upload_primary_table(lf_ctx* ctx);       // LfPrimaryDev from ctx->lens (k_lens_rays needs it too)
+void lf_fill_lenscam_args(const lf_ctx* ctx, LfLensCamArgs* a);
 lf_status lf_build_march_tables(lf_ctx* ctx, std::vector<LfEventRow>& rows, std::vector<int>& skip);
 lf_status lfk_native_sqrt(lf_ctx* ctx, const float* d_x, float* d_y, size_t n);
 void lf_apply_pupil_target(lf_ctx* ctx);

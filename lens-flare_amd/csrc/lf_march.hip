@@ -39,164 +39,12 @@
 #include <utility>
 
 #include "lf_internal.h"
+#include "lf_march_events.h"
 
 namespace {
 
-constexpr float kFixScale = 68719476736.0f;  // 2^36
-constexpr unsigned kDomainMarch = 0x6e5f1a2eu;
-constexpr unsigned kDomainSubcell = 0x51bce110u;
+using namespace lfm;
 
-__device__ __forceinline__ uint4 philox4x32_10(uint4 ctr, uint2 key) {
-#pragma unroll
-  for (int r = 0; r < 10; r++) {
-    unsigned hi0 = __umulhi(0xD2511F53u, ctr.x), lo0 = 0xD2511F53u * ctr.x;
-    unsigned hi1 = __umulhi(0xCD9E8D57u, ctr.z), lo1 = 0xCD9E8D57u * ctr.z;
-    ctr = make_uint4(hi1 ^ ctr.y ^ key.x, lo1, hi0 ^ ctr.w ^ key.y, lo0);
-    key.x += 0x9E3779B9u;
-    key.y += 0xBB67AE85u;
-  }
-  return ctr;
-}
-
-// Square roots are the hardware's v_sqrt_f32: one transcendental-rate instruction, accurate to 1 ulp.
-// A correctly rounded root costs 8 more VALU instructions (the +-1 ulp residual test), and the two
-// roots of a surface event would then be 18 of its 48 instructions.  v_sqrt_f32 is deterministic
-// and its deviation from the correctly rounded root depends only on the significand and the parity
-// of the exponent, so the CPU oracle reproduces it exactly from a table measured once through
-// lf_native_sqrt (oracle/lf_geo_oracle.c, geo_set_sqrt_table): the march stays bit-for-bit
-// comparable with the oracle.
-__device__ __forceinline__ float lf_sqrt(float x) { return __builtin_amdgcn_sqrtf(x); }
-
-__device__ __forceinline__ float u01(unsigned r) { return (float)(r >> 8) * 5.9604644775390625e-8f; }
-
-// The transmitted weight is carried as a fraction wn / wd: every Fresnel factor is a ratio of
-// two cheap products, so the march multiplies numerators and denominators separately and divides
-// ONCE, and only for the ~0.4 % of rays that end inside the sun's lobe.
-// Position: (px, py) and hz = z RELATIVE to the vertex of the interface the ray sits on (0 on the
-// sensor / the stop plane), plus r2 = px^2 + py^2 of that point, which the previous event's aperture
-// test has already computed and the next event's |o|^2 reuses.  A row carries dzv = (vertex z of the
-// interface the ray comes from) - (vertex z of this one): one add gives the origin's z in this
-// interface's frame, absolute z never exists (3 vector instructions per event less than tracking it,
-// and less cancellation).  (dx, dy, dz) is the OPTICAL direction K = n d (see surface_event).
-struct Ray {
-  float px, py, hz, r2, dx, dy, dz, wn, wd;
-};
-
-// One glass-surface event, straight-line (no divergent branches): a lane that misses the surface,
-// leaves the clear aperture or is totally reflected just gets ok = false -- its ray state turns
-// into garbage/NaN that nobody reads again.  Liveness is kept as explicit 64-bit wave masks (one
-// SGPR pair, plain s_and/s_or), not as per-lane bools: the compiler lowers loop-carried bools to
-// exec-merge triples that tripled the scalar-unit load of the loop.  geom_ok tells a vignetted ray
-// from a TIR one.
-// sgn = +1 for a ray travelling +z, -1 for -z (wave-uniform, lives in an SGPR).
-typedef unsigned long long lanemask;
-
-// W = false is the geometry-only march (positions, directions, liveness); W = true additionally
-// carries the Fresnel / aperture weight.  The frame runs W = false for every ray and repeats the
-// sequence with W = true only for the waves in which some lane ended inside the sun's lobe (~1 % of
-// the wave-sequences): the weight is ~16 vector instructions on top of an event's 27 and is read by
-// 0.4 % of the rays.  Both instantiations do the same arithmetic on the ray itself, so the
-// repeated march reproduces the first one bit for bit.
-// ch = c / 2 and c2 = 2 c travel with the row (exact scalings): F = c |o|^2 - 2 o_z is formed as its
-// half Fh = fma(ch, |o|^2, -o_z) -- the same bits, shifted by one exponent.
-//
-// The direction is the OPTICAL direction K = n d (|K| = n, the index of the medium the ray is in: a
-// property of the row).  With the ray o + s K the vertex-form quadratic is
-//   c n^2 s^2 - 2 s G + F = 0,   G = K_z - c (o . K)
-// so disc = G^2 - (c n^2) F, the root next to the vertex is s = (G - sgn sqrt(disc)) R / n^2 for a
-// curved interface and s = F / (G + sgn sqrt(disc)) for flat glass, and with N = (-c hx, -c hy,
-// 1 - c hz) the unit normal at the hit, K . N = G - c n^2 s = sgn sqrt(disc) EXACTLY: sqrt(disc) is
-// n |cos(incidence)|.  Snell: (n' cos t')^2 = disc + (n'^2 - n^2) -- one add, negative = total
-// reflection -- and K' = K + sgn (n' cos t' - n cos t) N: no multiplication of K by an index ratio.
-// Per event that is 27 vector instructions where the unit-direction form of rounds 1-2 had 31.
-// cn22 = 2 c n^2, rn2 = R / n^2, delta = n'^2 - n^2, sc = sgn c come with the row.
-// W = true additionally takes the Fresnel scale factors fs, fo, fi of the row (LfWeightRow).
-template <bool W>
-__device__ __forceinline__ lanemask surface_event(Ray& r, float dzv, float c, float ch, float c2, float sc,
-                                                  float cn22, float rn2, float delta, float h2, bool reflect,
-                                                  bool flat, float sgn, lanemask& geom_ok, float fs = 1.0f,
-                                                  float fo = 1.0f, float fi = 1.0f) {
-  const float oz = r.hz + dzv;
-  const float od = fmaf(r.px, r.dx, fmaf(r.py, r.dy, oz * r.dz));
-  const float oo = fmaf(oz, oz, r.r2);
-  const float Fh = fmaf(ch, oo, -oz);            // F / 2, F = c |o|^2 - 2 o_z
-  const float G = fmaf(-c, od, r.dz);
-  const float cF = cn22 * Fh;                    // = c n^2 F
-  const float disc = fmaf(G, G, -cF);
-  const float sq = lf_sqrt(disc);                // n |cos(incidence)|
-  float t;
-  if (flat) t = __fdiv_rn(Fh + Fh, fmaf(sgn, sq, G));   // wave-uniform branch
-  else t = fmaf(-sgn, sq, G) * rn2;
-  const float hx = fmaf(t, r.dx, r.px), hy = fmaf(t, r.dy, r.py), hz = fmaf(t, r.dz, oz);
-  const float r2 = fmaf(hx, hx, hy * hy);
-  // a ray that misses the sphere (disc < 0) has sq = t = r2 = NaN, and NaN <= h2 is false
-  geom_ok = __ballot(r2 <= h2);
-  lanemask ok = geom_ok;
-  float Rn = 0.0f, D = 1.0f, ct = 0.0f;
-  bool no_tir = true;
-  if (W || !reflect) {
-    const float k2 = disc + delta;                 // (n' cos(refraction))^2
-    no_tir = k2 >= 0.0f;
-    // (a totally reflected ray only survives a mirror event, and only W = true reads ct there)
-    ct = lf_sqrt(reflect ? fmaxf(k2, 0.0f) : k2);
-    if (W) {
-      // unpolarised Fresnel straight from the optical cosines sq = n cos t, ct = n' cos t':
-      //   rs = (sq - ct) / (sq + ct),   rp = (n'^2 sq - n^2 ct) / (n'^2 sq + n^2 ct),   R = (rs^2 + rp^2) / 2
-      // as ONE fraction R = Rn / D, Rn = ((a B)^2 + (A b)^2) / 2, D = (b B)^2, with the numerators and
-      // denominators scaled by row constants so that b = B = 1 at normal incidence (the running
-      // denominator of a path stays near 1): fs = 1 / (n + n'), fo = n'^2 / q, fi = n^2 / q,
-      // q = n'^2 n + n^2 n'.  No true cosine, no index ratio: nothing is divided by n on the way.
-      const float a = (sq - ct) * fs, b = (sq + ct) * fs;
-      const float pc = fi * ct;
-      const float A = fmaf(fo, sq, -pc), B = fmaf(fo, sq, pc);
-      const float u = a * B, v = A * b;
-      Rn = 0.5f * fmaf(u, u, v * v);
-      const float bB = b * B;
-      D = bB * bB;
-    }
-  }
-  if (reflect) {  // wave-uniform: K' = K - 2 (K . N) N, K . N = sgn sqrt(disc)
-    if (W) {
-      r.wn *= no_tir ? Rn : 1.0f;  // total reflection: R = 1
-      r.wd *= no_tir ? D : 1.0f;
-    }
-    const float m = sq * (c2 * sgn);
-    r.dx = fmaf(m, hx, r.dx);
-    r.dy = fmaf(m, hy, r.dy);
-    r.dz = fmaf(m, hz, fmaf(-2.0f * sgn, sq, r.dz));
-  } else {        // K' = K + sgn (ct - sq) N
-    ok &= __ballot(no_tir);
-    if (W) {
-      r.wn *= D - Rn;
-      r.wd *= D;
-    }
-    const float gs = ct - sq;
-    const float gcs = gs * sc;                     // sgn (ct - sq) c
-    r.dx = fmaf(-gcs, hx, r.dx);
-    r.dy = fmaf(-gcs, hy, r.dy);
-    r.dz = fmaf(-gcs, hz, fmaf(sgn, gs, r.dz));
-  }
-  r.px = hx; r.py = hy; r.hz = hz; r.r2 = r2;
-  return ok;
-}
-
-// the stop: flat pass-through, clipped by its housing and by the aperture mask
-template <bool W>
-__device__ __forceinline__ lanemask stop_event(Ray& r, float dzv, float h2, float inv_h,
-                                               const float* __restrict__ mask, int mw, int mh) {
-  const float t = __fdiv_rn(-(r.hz + dzv), r.dz);
-  const float hx = fmaf(t, r.dx, r.px), hy = fmaf(t, r.dy, r.py);
-  const float r2 = fmaf(hx, hx, hy * hy);
-  const float fu = fmaf(hx, inv_h, 1.0f) * (0.5f * (float)mw);
-  const float fv = fmaf(hy, inv_h, 1.0f) * (0.5f * (float)mh);
-  int ix = (int)fu, iy = (int)fv;  // NaN / out-of-range of a dead lane is clamped, never faults
-  ix = min(max(ix, 0), mw - 1);
-  iy = min(max(iy, 0), mh - 1);
-  const float a = mask[iy * mw + ix];
-  if (W) r.wn *= a;
-  r.px = hx; r.py = hy; r.hz = 0.0f; r.r2 = r2;
-  return __ballot(r2 <= h2) & __ballot(a > 0.0f);
-}
 
 // Table rows are read with ONE wide scalar load each (left to itself the compiler sinks the field
 // loads into the branches that use them: 4-5 dependent scalar-cache round trips per event), through
@@ -811,6 +659,7 @@ void k_march(const LfLensDev* __restrict__ lens, const LfPairsDev* __restrict__ 
 // element, unit direction xyz towards the scene, transmitted weight, alive flag} in lens space
 // (z along the axis, light travels +z, the scene is at z < 0).
 __global__ __launch_bounds__(256) void k_lens_rays(const LfLensDev* __restrict__ lens,
+                                                   const LfPrimaryDev* __restrict__ prim,
                                                    const float* __restrict__ mask, int mw, int mh,
                                                    int lambda, int n, const float* __restrict__ sensor_xy,
                                                    const float* __restrict__ pupil_uv,
@@ -820,55 +669,14 @@ __global__ __launch_bounds__(256) void k_lens_rays(const LfLensDev* __restrict__
   const bool active = i < n;
   const float X = active ? sensor_xy[2 * i] : 0.0f, Y = active ? sensor_xy[2 * i + 1] : 0.0f;
   const float pa = active ? pupil_uv[2 * i] : 0.0f, pb = active ? pupil_uv[2 * i + 1] : 0.0f;
-  float qx = 0.0f, qy = 0.0f;  // concentric map, as in k_march
-  if (pa != 0.0f || pb != 0.0f) {
-    const bool wide = fabsf(pa) > fabsf(pb);
-    const float rr = wide ? pa : pb;
-    const float th = 0.78539816339744831f * __fdiv_rn(wide ? pb : pa, rr);
-    const float t2 = th * th;
-    const float sn = th * fmaf(t2, fmaf(t2, fmaf(t2, fmaf(t2, 2.7557319e-6f, -1.9841270e-4f),
-                                                 8.3333333e-3f), -1.6666667e-1f), 1.0f);
-    const float cs = fmaf(t2, fmaf(t2, fmaf(t2, fmaf(t2, 2.4801587e-5f, -1.3888889e-3f),
-                                            4.1666667e-2f), -0.5f), 1.0f);
-    qx = wide ? rr * cs : rr * sn;
-    qy = wide ? rr * sn : rr * cs;
-  }
-  const float z_sensor = lens->z_sensor;
-  const float vx = fmaf(lens->pupil_h, qx, -X), vy = fmaf(lens->pupil_h, qy, -Y), vz = lens->pupil_z - z_sensor;
-  const float len = lf_sqrt(fmaf(vx, vx, fmaf(vy, vy, vz * vz)));
-  const float rl = __fdiv_rn(1.0f, len);
-  Ray r{X, Y, 0.0f, fmaf(X, X, Y * Y), vx * rl, vy * rl, vz * rl, 1.0f, 1.0f};
-  const float c2 = r.dz * r.dz;
-  r.wn = lens->geom_norm * (c2 * c2);
-  { const float ns = lens->n_start[lambda]; r.dx *= ns; r.dy *= ns; r.dz *= ns; }   // K = n d
-  const float inv_stop_h = __fdiv_rn(1.0f, lens->stop_h);
-  lanemask alive = __ballot(active);
-  for (int k = lens->n_surf - 1; k >= 0; k--) {  // wave-uniform
-    const LfSurfaceDev& sf = lens->surf[k];
-    const float dzv = (k == lens->n_surf - 1 ? z_sensor : lens->surf[k + 1].zv) - sf.zv;
-    lanemask ok, geom_ok;
-    if (sf.is_stop != 0.0f) {
-      ok = stop_event<true>(r, dzv, sf.h2, inv_stop_h, mask, mw, mh);
-    } else {
-      // the record's constants (pack_program), derived here the same way: travelling -z the ray arrives
-      // in the medium behind the interface and leaves in the one in front of it
-      const float n_in = sf.n_after[lambda], n_out = sf.n_before[lambda];
-      const float n_in2 = n_in * n_in, n_out2 = n_out * n_out;
-      const float cc2 = 2.0f * sf.curv;
-      const float q = fmaf(n_out2, n_in, n_in2 * n_out);
-      ok = surface_event<true>(r, dzv, sf.curv, 0.5f * sf.curv, cc2, -sf.curv, cc2 * n_in2,
-                               sf.curv == 0.0f ? 0.0f : __fdiv_rn(sf.radius, n_in2), n_out2 - n_in2, sf.h2, false,
-                               sf.curv == 0.0f, -1.0f, geom_ok, __fdiv_rn(1.0f, n_in + n_out), __fdiv_rn(n_out2, q),
-                               __fdiv_rn(n_in2, q));
-    }
-    alive &= ok;
-  }
+  const StartRay s0 = aim_at_pupil(X, Y, pa, pb, lens->pupil_h, lens->pupil_z - lens->z_sensor, lens->geom_norm);
+  Ray r{X, Y, 0.0f, fmaf(X, X, Y * Y), s0.dx, s0.dy, s0.dz, s0.w0, 1.0f};
+  const bool alive = primary_path(prim, lambda, r, mask, mw, mh, lane);
   if (active) {
-    const bool a = (alive >> lane) & 1ull;
     float* o = out + 8 * (size_t)i;
-    o[0] = r.px; o[1] = r.py; o[2] = lens->surf[0].zv + r.hz; o[3] = r.dx; o[4] = r.dy; o[5] = r.dz;
-    o[6] = a ? __fdiv_rn(r.wn, r.wd) : 0.0f;
-    o[7] = a ? 1.0f : 0.0f;
+    o[0] = r.px; o[1] = r.py; o[2] = prim->front_zv + r.hz; o[3] = r.dx; o[4] = r.dy; o[5] = r.dz;
+    o[6] = alive ? __fdiv_rn(r.wn, r.wd) : 0.0f;
+    o[7] = alive ? 1.0f : 0.0f;
   }
 }
 
@@ -902,6 +710,7 @@ void lf_apply_pupil_target(lf_ctx* ctx) {
   else { L.pupil_h = ctx->raw_semi_ap[n - 1]; L.pupil_z = L.surf[n - 1].zv; }
   const double D = (double)L.z_sensor - (double)L.pupil_z;
   L.geom_norm = (float)((3.14159265358979323846 * (double)L.pupil_h * (double)L.pupil_h) / (D * D));
+  ctx->lenscam_dirty = true;   // the lens camera's table / calibration follow the lens and its pupil disc
 }
 
 // host: derive the per-interface march constants from the raw prescription (float arithmetic,
@@ -1380,8 +1189,10 @@ lf_status lfk_lens_rays(lf_ctx* ctx, int lambda, int n, const float* d_xy, const
   ctx->lens.pitch = ctx->sensor_w_mm / (float)std::max(1, ctx->W);
   LF_HIP(ctx, hipMemcpyAsync(ctx->lens_dev, &ctx->lens, sizeof(LfLensDev), hipMemcpyHostToDevice,
                              ctx->stream));
+  lf_status st = lf_upload_primary_table(ctx);
+  if (st != LF_OK) return st;
   hipLaunchKernelGGL(k_lens_rays, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream,
-                     ctx->lens_dev, m.texels, m.w, m.h, lambda, n, d_xy, d_uv, d_out);
+                     ctx->lens_dev, ctx->primary_dev, m.texels, m.w, m.h, lambda, n, d_xy, d_uv, d_out);
   LF_HIP(ctx, hipGetLastError());
   return LF_OK;
 }

@@ -28,6 +28,7 @@
 #include <cstring>
 
 #include "lf_internal.h"
+#include "lf_march_events.h"
 
 namespace {
 
@@ -183,9 +184,16 @@ __device__ inline bool box_miss(const DRay& r, float lx, float ly, float lz, flo
 // popped.  The stack of deferred children lives in LDS ([depth][thread]: conflict-free), not in
 // scratch memory; it holds one entry per level at most (the host refuses deeper trees).
 constexpr int kStackDepth = 24;
-__device__ bool closest_hit(const LfSceneDev& sc, DRay& r, Hit* h, int* __restrict__ stack /* [kStackDepth][256] + tid */) {
+// what the reference's BVHAccel counts for its end-of-frame log (bvh.h:85,105; bvh.cpp:211;
+// raytraced_renderer.cpp:706-709): rays handed to intersect() / has_intersection(), and primitive tests of
+// the closest-hit queries (has_intersection does not count its tests) -- here per lane, summed at the
+// kernel's end (lf_get_scene_counters)
+struct SceneTally { unsigned rays, isects; };
+__device__ bool closest_hit(const LfSceneDev& sc, DRay& r, Hit* h, int* __restrict__ stack /* [kStackDepth][256] + tid */,
+                            SceneTally& tally) {
   int sp = 0, cur = 0;
   bool any = false;
+  tally.rays++;
   for (;;) {
     if (cur >= 0) {
       const float4* __restrict__ q = reinterpret_cast<const float4*>(sc.nodes + cur);
@@ -205,6 +213,7 @@ __device__ bool closest_hit(const LfSceneDev& sc, DRay& r, Hit* h, int* __restri
     } else {
       const int code = ~cur, first = code >> 2, count = (code & 3) + 1;
       bool hit_here = false;
+      if (h) tally.isects += (unsigned)count;
       for (int i = 0; i < count; i++) {
         const LfPrim& p = sc.prims[first + i];
         const bool hit = p.type == 0 ? hit_sphere(p, first + i, r, h) : hit_triangle(p, first + i, r, h);
@@ -276,7 +285,7 @@ enum { kShadeZero = 1, kShadeOne = 2 };
 template <bool SOFT>
 __device__ V3 shade_hit(const LfSceneDev& sc, const LfEnvDev& ev, bool hemisphere, const DRay& r,
                         double isect_t, V3 isect_n, const LfMaterial& m, int what,
-                        int* __restrict__ stack, int ns_area_light, uint4 rng_ctr, uint2 rng_key) {
+                        int* __restrict__ stack, int ns_area_light, uint4 rng_ctr, uint2 rng_key, SceneTally& tally) {
   const V3 emission = (m.kind == 1 && (what & kShadeZero)) ? v3(m.rgb[0], m.rgb[1], m.rgb[2]) : v3(0, 0, 0);
   if (!(what & kShadeOne)) return emission;
   V3 X, Y, Z;
@@ -308,7 +317,7 @@ __device__ V3 shade_hit(const LfSceneDev& sc, const LfEnvDev& ev, bool hemispher
                        (wi.x * X.z + wi.y * Y.z) + wi.z * Z.z);
       DRay out = make_ray(hit_p, ww, kEpsF, INFINITY);
       Hit h2;
-      if (closest_hit(sc, out, &h2, stack)) {
+      if (closest_hit(sc, out, &h2, stack, tally)) {
         const LfMaterial& m2 = sc.materials[sc.prims[h2.prim].material];
         const V3 em2 = m2.kind == 1 ? v3(m2.rgb[0], m2.rgb[1], m2.rgb[2]) : v3(0, 0, 0);
         const double cos_theta = unit(wi).z;
@@ -375,7 +384,7 @@ __device__ V3 shade_hit(const LfSceneDev& sc, const LfEnvDev& ev, bool hemispher
                        (wi.x * Z.x + wi.y * Z.y) + wi.z * Z.z);
       if (wo.z < 0) continue;
       DRay sh = make_ray(hit_p, wi, kEpsF, dist - kEpsF);
-      if (!closest_hit(sc, sh, nullptr, stack)) {
+      if (!closest_hit(sc, sh, nullptr, stack, tally)) {
         const double cos_theta = unit(wo).z;
         L = L + divs(mulv(f, emit) * cos_theta, pdf);  // / pdf (1 for delta lights)
       }
@@ -387,14 +396,14 @@ __device__ V3 shade_hit(const LfSceneDev& sc, const LfEnvDev& ev, bool hemispher
 
 template <bool SOFT>
 __device__ V3 radiance(const LfSceneDev& sc, const LfEnvDev& ev, bool hemisphere, DRay r,
-                       int* __restrict__ stack, int ns_area_light, uint4 rng_ctr, uint2 rng_key) {
+                       int* __restrict__ stack, int ns_area_light, uint4 rng_ctr, uint2 rng_key, SceneTally& tally) {
   Hit isect;
-  if (!closest_hit(sc, r, &isect, stack))   // pathtracer.cpp:291-292
+  if (!closest_hit(sc, r, &isect, stack, tally))   // pathtracer.cpp:291-292
     return (SOFT && ev.w) ? env_sample_dir(ev, r.d) : v3(0, 0, 0);
   int material;
   const V3 n = hit_normal(sc, r, isect, &material);
   return shade_hit<SOFT>(sc, ev, hemisphere, r, isect.t, n, sc.materials[material],
-                         kShadeZero | kShadeOne, stack, ns_area_light, rng_ctr, rng_key);
+                         kShadeZero | kShadeOne, stack, ns_area_light, rng_ctr, rng_key, tally);
 }
 
 __device__ inline uint4 philox4x32_10(uint4 ctr, uint2 key) {
@@ -421,31 +430,32 @@ __device__ inline double random_uniform_from_raw(unsigned raw) {  // util/random
 // 256 and the delta-light one 163; bounded they spill their cold paths to scratch and are still
 // faster -- timing frames at 2 / 3 / 4 / 5 waves: 32.6 / 26.0 / 24.8 / 25.0 ms with an area light and the
 // environment, 4.1 / 4.1 / 3.9 / 4.9 ms with delta lights only)
-template <bool SOFT>
+//
+// LENS = true (round 4; lf_set_lens_camera): the one call `camera->generate_ray(x, y)` of the loop
+// (pathtracer.cpp:848) is replaced by the primary path of the MARCH's sensor sample through the
+// prescription -- sample_start + primary_path of lf_march_events.h, float32, the arithmetic of the
+// ghost march -- and the radiance that comes back along the exit ray is weighted by the transmitted
+// fraction (Fresnel losses at every interface, the aperture mask, cos^4 and the pupil's solid angle,
+// times the exposure).  A sample the lens blocks contributes 0 and still counts: the mean is taken
+// over the loop variable exactly as before.  Lens space = camera space (x right, y up, the scene at
+// -z) scaled by world_per_mm, with the entrance pupil's centre at the camera position.
 #ifndef LF_SCENE_WAVES
 #define LF_SCENE_WAVES 4
 #endif
-__global__ __launch_bounds__(256, LF_SCENE_WAVES) void k_scene_term(LfSceneDev sc, LfEnvDev ev, int hemisphere,
-                                                    LfCamera cam, int W, int H, int y0,
-                                                    int y1, int row_phase, int row_period,
-                                                    int ns_aa, int ns_area_light,
-                                                    int samples_per_batch, double max_tolerance,
-                                                    const uint32_t* __restrict__ aa_raw, int jitter_mode,
-                                                    uint64_t key, double* __restrict__ scene) {
-  // traversal stacks of the 256 threads: the median-split tree of n primitives is ceil(log2(n / 4))
-  // deep (<= 29), the stack holds at most depth + 1 entries
-  __shared__ int s_stack[kStackDepth * 256];
-  int* const stack = s_stack + threadIdx.x;
-  // a wave = one 8 x 8 pixel tile (its 64 camera rays walk the same part of the tree: fewer divergent
-  // visits and better hit rates in the vector cache than a 64 x 1 strip), a workgroup = 4 tiles side by
-  // side; blockIdx.y counts 8-row tile rows from the one that holds y0
-  const int lane = threadIdx.x & 63;
-  const int x = ((int)blockIdx.x * 4 + ((int)threadIdx.x >> 6)) * 8 + (lane & 7);
-  const int y = ((y0 >> 3) + (int)blockIdx.y) * 8 + (lane >> 3);
-  if (x >= W || y < y0 || y >= y1) return;
-  // multi-GPU: only the 8-row tile rows this context owns, like k_flare_layer, which is the only
-  // reader of this buffer (whole workgroups leave)
-  if (row_period > 1 && (y >> 3) % row_period != row_phase) return;
+struct ScenePixelArgs {
+  int W, H, ns_aa, ns_area_light, samples_per_batch, jitter_mode, hemisphere;
+  double max_tolerance;
+  uint64_t key;
+};
+template <bool SOFT, bool LENS>
+__device__ __forceinline__ void scene_pixel(const LfSceneDev& sc, const LfEnvDev& ev, const LfCamera& cam,
+                                            const ScenePixelArgs& a, const uint32_t* __restrict__ aa_raw,
+                                            const LfLensCamArgs& lc, const LfPrimaryDev* __restrict__ prim,
+                                            const float* __restrict__ mask, int x, int y, int lane,
+                                            int* __restrict__ stack, SceneTally& tally, unsigned& lens_started,
+                                            unsigned& lens_left, double* __restrict__ scene) {
+  const int W = a.W, H = a.H, ns_aa = a.ns_aa;
+  const uint2 key2 = make_uint2((unsigned)a.key, (unsigned)(a.key >> 32));
   const size_t p = (size_t)y * W + x;
   const double PI_ = 3.14159265358979323;
   const double edge_x = tan(0.5 * (cam.hfov_deg * (PI_ / 180.0)));
@@ -454,43 +464,120 @@ __global__ __launch_bounds__(256, LF_SCENE_WAVES) void k_scene_term(LfSceneDev s
   float s1 = 0.0f, s2 = 0.0f;
   int sample;
   for (sample = 1; sample <= ns_aa; sample++) {
-    unsigned ra, rb;
-    if (jitter_mode == 0) {
-      ra = aa_raw[p * (size_t)(2 * ns_aa) + 2 * (sample - 1)];
-      rb = aa_raw[p * (size_t)(2 * ns_aa) + 2 * (sample - 1) + 1];
+    V3 L;
+    if (LENS) {
+      lfm::SampleSpec spec;
+      spec.W = W; spec.G = lc.G; spec.inv_G = lc.inv_G; spec.sub_bits = lc.sub_bits; spec.inv_sub = lc.inv_sub;
+      spec.key = key2; spec.pitch = lc.pitch; spec.half_w = lc.half_w; spec.half_h = lc.half_h;
+      spec.pupil_h = lc.pupil_h; spec.vz = lc.vz; spec.geom_norm = lc.geom_norm;
+      const lfm::StartRay st = lfm::sample_start(spec, x, y, sample - 1);
+      L = v3(0, 0, 0);
+      const int n_rays = lc.mode == 2 ? lc.n_lambda : 1;
+      for (int li = 0; li < n_rays; li++) {
+        const int l = lc.mode == 2 ? li : lc.lambda_ref;
+        lfm::Ray r{st.X, st.Y, 0.0f, fmaf(st.X, st.X, st.Y * st.Y), st.dx, st.dy, st.dz, st.w0, 1.0f};
+        const bool left = lfm::primary_path(prim, l, r, mask, lc.mw, lc.mh, lane);
+        lens_started++;
+        if (!left) continue;
+        lens_left++;
+        const double wt = (double)__fdiv_rn(r.wn, r.wd) * lc.exposure;
+        // exit state (float, lens space, mm) -> camera space -> world: doubles from here on
+        const double wpm = lc.world_per_mm;
+        const V3 oc = v3((double)r.px * wpm, (double)r.py * wpm,
+                         ((double)(prim->front_zv + r.hz) - lc.z_ref_mm) * wpm);
+        const V3 dc = unit(v3((double)r.dx, (double)r.dy, (double)r.dz));
+        const V3 ow = v3(cam.pos[0] + ((oc.x * cam.c2w[0] + oc.y * cam.c2w[1]) + oc.z * cam.c2w[2]),
+                         cam.pos[1] + ((oc.x * cam.c2w[3] + oc.y * cam.c2w[4]) + oc.z * cam.c2w[5]),
+                         cam.pos[2] + ((oc.x * cam.c2w[6] + oc.y * cam.c2w[7]) + oc.z * cam.c2w[8]));
+        const DRay ray = make_ray(ow,
+                                  v3((dc.x * cam.c2w[0] + dc.y * cam.c2w[1]) + dc.z * cam.c2w[2],
+                                     (dc.x * cam.c2w[3] + dc.y * cam.c2w[4]) + dc.z * cam.c2w[5],
+                                     (dc.x * cam.c2w[6] + dc.y * cam.c2w[7]) + dc.z * cam.c2w[8]),
+                                  cam.n_clip, cam.f_clip);
+        const V3 Ll = radiance<SOFT>(sc, ev, a.hemisphere != 0, ray, stack, a.ns_area_light,
+                                     make_uint4((unsigned)p, (unsigned)sample, 0u, 0u), key2, tally);
+        if (lc.mode == 2)
+          L = L + v3(Ll.x * (wt * (double)lc.lambda_rgb[l][0]), Ll.y * (wt * (double)lc.lambda_rgb[l][1]),
+                     Ll.z * (wt * (double)lc.lambda_rgb[l][2]));
+        else
+          L = L + Ll * wt;
+      }
     } else {
-      const uint4 r4 = philox4x32_10(make_uint4((unsigned)p, (unsigned)sample, 0x5ce4e000u, 0u),
-                                     make_uint2((unsigned)key, (unsigned)(key >> 32)));
-      ra = r4.x; rb = r4.y;
+      unsigned ra, rb;
+      if (a.jitter_mode == 0) {
+        ra = aa_raw[p * (size_t)(2 * ns_aa) + 2 * (sample - 1)];
+        rb = aa_raw[p * (size_t)(2 * ns_aa) + 2 * (sample - 1) + 1];
+      } else {
+        const uint4 r4 = philox4x32_10(make_uint4((unsigned)p, (unsigned)sample, 0x5ce4e000u, 0u), key2);
+        ra = r4.x; rb = r4.y;
+      }
+      // Vector2D(random_uniform(), random_uniform()): g++ evaluates right to left, the first draw is y
+      const double sy = (double)y + random_uniform_from_raw(ra);
+      const double sx = (double)x + random_uniform_from_raw(rb);
+      const double nx = sx / (double)W, ny = sy / (double)H;
+      // Camera::generate_ray (camera.cpp:278-305)
+      V3 dir = unit(v3(edge_x * (2 * nx - 1), edge_y * (2 * ny - 1), -1));
+      const DRay r = make_ray(v3(cam.pos[0], cam.pos[1], cam.pos[2]),
+                              v3((dir.x * cam.c2w[0] + dir.y * cam.c2w[1]) + dir.z * cam.c2w[2],
+                                 (dir.x * cam.c2w[3] + dir.y * cam.c2w[4]) + dir.z * cam.c2w[5],
+                                 (dir.x * cam.c2w[6] + dir.y * cam.c2w[7]) + dir.z * cam.c2w[8]),
+                              cam.n_clip, cam.f_clip);
+      L = radiance<SOFT>(sc, ev, a.hemisphere != 0, r, stack, a.ns_area_light,
+                         make_uint4((unsigned)p, (unsigned)sample, 0u, 0u), key2, tally);
     }
-    // Vector2D(random_uniform(), random_uniform()): g++ evaluates right to left, the first draw is y
-    const double sy = (double)y + random_uniform_from_raw(ra);
-    const double sx = (double)x + random_uniform_from_raw(rb);
-    const double nx = sx / (double)W, ny = sy / (double)H;
-    // Camera::generate_ray (camera.cpp:278-305)
-    V3 dir = unit(v3(edge_x * (2 * nx - 1), edge_y * (2 * ny - 1), -1));
-    const DRay r = make_ray(v3(cam.pos[0], cam.pos[1], cam.pos[2]),
-                            v3((dir.x * cam.c2w[0] + dir.y * cam.c2w[1]) + dir.z * cam.c2w[2],
-                               (dir.x * cam.c2w[3] + dir.y * cam.c2w[4]) + dir.z * cam.c2w[5],
-                               (dir.x * cam.c2w[6] + dir.y * cam.c2w[7]) + dir.z * cam.c2w[8]),
-                            cam.n_clip, cam.f_clip);
-    const V3 L = radiance<SOFT>(sc, ev, hemisphere != 0, r, stack, ns_area_light, make_uint4((unsigned)p, (unsigned)sample, 0u, 0u),
-                          make_uint2((unsigned)key, (unsigned)(key >> 32)));
     // Vector3D::illum (vector3D.h:231-233): float coefficients, double arithmetic, float result
     const float illum = (float)((0.2126f * L.x + 0.7152f * L.y) + 0.0722f * L.z);
     s1 += illum;
     s2 += illum * illum;
     total = total + L;
-    if (sample > 1 && sample % samples_per_batch == 0) {  // :862-868
+    if (sample > 1 && sample % a.samples_per_batch == 0) {  // :862-868
       const float sd = (float)sqrt(1.0 / (sample - 1) * (double)(s2 - s1 * s1 / (float)sample));
       const float ci = (float)(1.96 * (double)sd / sqrt((double)sample));
-      if ((double)ci <= max_tolerance * (double)s1 / (double)sample) break;
+      if ((double)ci <= a.max_tolerance * (double)s1 / (double)sample) break;
     }
   }
   const double rc = 1. / (double)sample;  // :875 -- ns_aa + 1 when the loop ran to its end
   scene[3 * p] = total.x * rc;
   scene[3 * p + 1] = total.y * rc;
   scene[3 * p + 2] = total.z * rc;
+}
+
+template <bool SOFT, bool LENS>
+__global__ __launch_bounds__(256, LF_SCENE_WAVES) void k_scene_term(LfSceneDev sc, LfEnvDev ev, LfCamera cam,
+                                                    ScenePixelArgs a, int y0, int y1, int row_phase,
+                                                    int row_period, const uint32_t* __restrict__ aa_raw,
+                                                    LfLensCamArgs lc, const LfPrimaryDev* __restrict__ prim,
+                                                    const float* __restrict__ mask,
+                                                    unsigned long long* __restrict__ counters,
+                                                    double* __restrict__ scene) {
+  // traversal stacks of the 256 threads: the median-split tree of n primitives is ceil(log2(n / 4))
+  // deep (<= 29), the stack holds at most depth + 1 entries
+  __shared__ int s_stack[kStackDepth * 256];
+  __shared__ unsigned long long s_cnt[kSceneCounters];
+  if (threadIdx.x < kSceneCounters) s_cnt[threadIdx.x] = 0ull;
+  __syncthreads();
+  int* const stack = s_stack + threadIdx.x;
+  // a wave = one 8 x 8 pixel tile (its 64 camera rays walk the same part of the tree: fewer divergent
+  // visits and better hit rates in the vector cache than a 64 x 1 strip), a workgroup = 4 tiles side by
+  // side; blockIdx.y counts 8-row tile rows from the one that holds y0
+  const int lane = threadIdx.x & 63;
+  const int x = ((int)blockIdx.x * 4 + ((int)threadIdx.x >> 6)) * 8 + (lane & 7);
+  const int y = ((y0 >> 3) + (int)blockIdx.y) * 8 + (lane >> 3);
+  // multi-GPU: only the 8-row tile rows this context owns, like k_flare_layer, which is the only
+  // reader of this buffer
+  const bool mine = x < a.W && y >= y0 && y < y1 && !(row_period > 1 && (y >> 3) % row_period != row_phase);
+  SceneTally tally{0u, 0u};
+  unsigned lens_started = 0u, lens_left = 0u;
+  if (mine)
+    scene_pixel<SOFT, LENS>(sc, ev, cam, a, aa_raw, lc, prim, mask, x, y, lane, stack, tally, lens_started,
+                            lens_left, scene);
+  // the frame's counters (every lane arrives here): LDS adds, then one global add per counter
+  if (tally.rays) atomicAdd(&s_cnt[0], (unsigned long long)tally.rays);
+  if (tally.isects) atomicAdd(&s_cnt[1], (unsigned long long)tally.isects);
+  if (LENS && lens_started) atomicAdd(&s_cnt[2], (unsigned long long)lens_started);
+  if (LENS && lens_left) atomicAdd(&s_cnt[3], (unsigned long long)lens_left);
+  __syncthreads();
+  if (threadIdx.x < kSceneCounters && s_cnt[threadIdx.x]) atomicAdd(&counters[threadIdx.x], s_cnt[threadIdx.x]);
 }
 
 // ---- single-ray forms of the integrator's public members (pathtracer.h:66-77) ----------------
@@ -506,12 +593,13 @@ __global__ void k_scene_trace_ray(LfSceneDev sc, LfEnvDev ev, int hemisphere, Lf
   const uint2 k2 = make_uint2((unsigned)key, (unsigned)(key >> 32));
   Hit h;
   V3 L;
-  if (closest_hit(sc, r, &h, s_stack)) {
+  SceneTally tally{0u, 0u};
+  if (closest_hit(sc, r, &h, s_stack, tally)) {
     int material;
     const V3 n = hit_normal(sc, r, h, &material);
     out[0] = 1.0; out[1] = h.t; out[2] = n.x; out[3] = n.y; out[4] = n.z;
     L = shade_hit<true>(sc, ev, hemisphere != 0, r, h.t, n, sc.materials[material], kShadeZero | kShadeOne,
-                        s_stack, ns_area_light, ctr, k2);
+                        s_stack, ns_area_light, ctr, k2, tally);
   } else {
     out[0] = 0.0; out[1] = out[2] = out[3] = out[4] = 0.0;
     L = ev.w ? env_sample_dir(ev, r.d) : v3(0, 0, 0);
@@ -526,9 +614,10 @@ __global__ void k_scene_shade(LfSceneDev sc, LfEnvDev ev, int hemisphere, LfProb
   __shared__ int s_stack[kStackDepth * 256];
   if (threadIdx.x != 0) return;
   const DRay r = make_ray(v3(pr.o[0], pr.o[1], pr.o[2]), v3(pr.d[0], pr.d[1], pr.d[2]), pr.min_t, pr.max_t);
+  SceneTally tally{0u, 0u};
   const V3 L = shade_hit<true>(sc, ev, hemisphere != 0, r, t, v3(nx, ny, nz), m, what, s_stack, ns_area_light,
                                make_uint4((unsigned)seq, (unsigned)(seq >> 32) | 0x80000000u, 0u, 0u),
-                               make_uint2((unsigned)key, (unsigned)(key >> 32)));
+                               make_uint2((unsigned)key, (unsigned)(key >> 32)), tally);
   out[0] = L.x; out[1] = L.y; out[2] = L.z;
 }
 
@@ -958,6 +1047,16 @@ lf_status lf_render_scene_term(lf_ctx* ctx) {
                      "every later pixel's draws depend on earlier pixels (use lf_set_jitter_counter)");
   }
   LF_HIP(ctx, hipSetDevice(ctx->device));
+  const bool lens = ctx->lenscam_mode != 0;
+  if (lens) {
+    // the lens camera's samples are the march's (a counter RNG): the MT19937 table of the parity mode
+    // holds two draws per sample, the pupil point needs two more
+    if (ctx->jitter_mode == 0)
+      return lf_fail(ctx, LF_ERR_INVALID, "the lens camera samples with the counter RNG of the march "
+                                          "(lf_set_jitter_counter); MT19937 parity mode is the pinhole's");
+    const lf_status st = lf_lenscam_prepare(ctx);
+    if (st != LF_OK) return st;
+  }
   const size_t n = (size_t)ctx->W * ctx->H * 3;
   if (!ctx->scene) {
     LF_HIP(ctx, hipMalloc((void**)&ctx->scene, n * sizeof(double)));
@@ -966,15 +1065,20 @@ lf_status lf_render_scene_term(lf_ctx* ctx) {
   const size_t px = (size_t)(ctx->y1 - ctx->y0) * ctx->W;
   if (px == 0) return LF_OK;
   const bool soft = ctx->scene_dev.n_soft_lights > 0 || ctx->env_dev.w > 0 || ctx->hemisphere_sample;
-#define LF_LAUNCH_SCENE(SOFT)                                                                            \
-  hipLaunchKernelGGL(k_scene_term<SOFT>, dim3((unsigned)((ctx->W + 31) / 32), (unsigned)(((ctx->y1 + 7) >> 3) - (ctx->y0 >> 3))), \
-                     dim3(256), 0, ctx->stream,                                                          \
-                     ctx->scene_dev, ctx->env_dev, ctx->hemisphere_sample ? 1 : 0, ctx->cam, ctx->W,    \
-                     ctx->H, ctx->y0, ctx->y1, ctx->row_phase, ctx->row_period, ctx->ns_aa,              \
-                     ctx->ns_area_light, ctx->samples_per_batch,                                         \
-                     ctx->max_tolerance, ctx->jitter_aa_raw, ctx->jitter_mode, ctx->jitter_key, ctx->scene)
+#define LF_LAUNCH_SCENE(SOFT, LENS)                                                                      \
+  hipLaunchKernelGGL((k_scene_term<SOFT, LENS>), dim3((unsigned)((ctx->W + 31) / 32), (unsigned)(((ctx->y1 + 7) >> 3) - (ctx->y0 >> 3))), \
+                     dim3(256), 0, ctx->stream, ctx->scene_dev, ctx->env_dev, ctx->cam, pa, ctx->y0, ctx->y1, \
+                     ctx->row_phase, ctx->row_period, ctx->jitter_aa_raw, lc, ctx->primary_dev,           \
+                     ctx->ap[LF_APERTURE_STARBURST].texels, ctx->scene_counters_dev, ctx->scene)
+  ScenePixelArgs pa;
+  pa.W = ctx->W; pa.H = ctx->H; pa.ns_aa = ctx->ns_aa; pa.ns_area_light = ctx->ns_area_light;
+  pa.samples_per_batch = ctx->samples_per_batch; pa.jitter_mode = ctx->jitter_mode;
+  pa.hemisphere = ctx->hemisphere_sample ? 1 : 0; pa.max_tolerance = ctx->max_tolerance; pa.key = ctx->jitter_key;
+  LfLensCamArgs lc;
+  lf_fill_lenscam_args(ctx, &lc);
   hipEvent_t ev = lf_timing_begin(ctx, LFK_SCENE);
-  if (soft) LF_LAUNCH_SCENE(true); else LF_LAUNCH_SCENE(false);
+  if (lens) { if (soft) LF_LAUNCH_SCENE(true, true); else LF_LAUNCH_SCENE(false, true); }
+  else { if (soft) LF_LAUNCH_SCENE(true, false); else LF_LAUNCH_SCENE(false, false); }
   lf_timing_end(ctx, LFK_SCENE, ev);
 #undef LF_LAUNCH_SCENE
   LF_HIP(ctx, hipGetLastError());

@@ -381,3 +381,26 @@ void g64_trace(const g64_lens* L, int W, int H, int y0, int y1, int spp, const u
   }
   if (counters) memcpy(counters, total, sizeof(total));
 }
+
+/* The lens camera of the scene term (lf_set_lens_camera): the primary path of sample s = 0 .. ns-1 of the
+ * listed pixels at wavelength `lam`, in float64 with the textbook formulations above.
+ * out: n_pix x ns x 10 doubles {origin xyz on the front element (mm, lens space), unit direction xyz,
+ * weight as float64 decides (0 when blocked), weight if every fragile decision passes, fragile, dead} */
+void g64_lens_samples(const g64_lens* L, int W, int H, int ns, const uint32_t key[2], int sub_bits, int lam,
+                      const int* pixels, int n_pix, const float* mask, int mw, int mh, double* out) {
+  g64_system S;
+  lay_out(L, &S);
+  for (int i = 0; i < n_pix; i++) {
+    const int p = pixels[i], x = p % W, y = p / W;
+    for (int s = 0; s < ns; s++) {
+      vec o, d;
+      const double w0 = sample_ray(L, &S, W, H, x, y, s, ns, sub_bits, key, &o, &d);
+      g64_ray r = {o, d, w0, w0, 0, 0};
+      follow(L, &S, lam, -1, -1, mask, mw, mh, &r);
+      double* q = out + 10 * ((size_t)i * ns + s);
+      const vec dn = normalise(r.d);
+      q[0] = r.o.x; q[1] = r.o.y; q[2] = r.o.z; q[3] = dn.x; q[4] = dn.y; q[5] = dn.z;
+      q[6] = r.dead ? 0.0 : r.w; q[7] = r.w_pot; q[8] = (double)r.fragile; q[9] = (double)r.dead;
+    }
+  }
+}

@@ -264,24 +264,9 @@ static int strata(int spp) {
 static int g_sub_bits = 2;
 void geo_set_sub_bits(int b) { g_sub_bits = b; }
 
-static float start_ray(const geo_derived* D, int W, int H, int x, int y, int s, int G,
-                       const uint32_t key[2], const uint32_t rnd[4], geo_ray* r) {
-  float jx = unit24(rnd[0]), jy = unit24(rnd[1]);
-  float ua = unit24(rnd[2]), ub = unit24(rnd[3]);
-  if (s < G * G) {
-    float inv_g = 1.0f / (float)G, inv_sub = 1.0f / (float)(1 << g_sub_bits);
-    int cy = s / G, cx = s - cy * G;
-    uint32_t tile = (uint32_t)((y >> 3) * ((W + 7) >> 3) + (x >> 3));
-    uint32_t ctr[4] = {tile, (uint32_t)s, 0x51bce110u, 0u}, r2[4];
-    philox(ctr, key, r2);
-    uint32_t sxi = g_sub_bits ? (r2[0] >> (32 - g_sub_bits)) : 0u;
-    uint32_t syi = g_sub_bits ? (r2[1] >> (32 - g_sub_bits)) : 0u;
-    ua = ((float)cx + ((float)sxi + ua) * inv_sub) * inv_g;
-    ub = ((float)cy + ((float)syi + ub) * inv_sub) * inv_g;
-  }
-  float pa = fmaf(2.0f, ua, -1.0f), pb = fmaf(2.0f, ub, -1.0f);
-  float X = -(((float)x + jx) - 0.5f * (float)W) * D->pitch;
-  float Y = -(((float)y + jy) - 0.5f * (float)H) * D->pitch;
+/* sensor point (X, Y) mm + pupil-square point (pa, pb) in [-1, 1]^2 -> start ray (unit direction, weight =
+ * the disc's solid-angle factor x cos^4): what k_march, k_lens_rays and the lens camera all start from */
+static void aim_at_pupil(const geo_derived* D, float X, float Y, float pa, float pb, geo_ray* r) {
   float qx = 0.0f, qy = 0.0f;
   if (pa != 0.0f || pb != 0.0f) {
     int wide = fabsf(pa) > fabsf(pb);
@@ -304,7 +289,87 @@ static float start_ray(const geo_derived* D, int W, int H, int x, int y, int s, 
   float c2 = r->d[2] * r->d[2];
   r->wn = D->geom_norm * (c2 * c2);
   r->wd = 1.0f;
+}
+
+static float start_ray(const geo_derived* D, int W, int H, int x, int y, int s, int G,
+                       const uint32_t key[2], const uint32_t rnd[4], geo_ray* r) {
+  float jx = unit24(rnd[0]), jy = unit24(rnd[1]);
+  float ua = unit24(rnd[2]), ub = unit24(rnd[3]);
+  if (s < G * G) {
+    float inv_g = 1.0f / (float)G, inv_sub = 1.0f / (float)(1 << g_sub_bits);
+    int cy = s / G, cx = s - cy * G;
+    uint32_t tile = (uint32_t)((y >> 3) * ((W + 7) >> 3) + (x >> 3));
+    uint32_t ctr[4] = {tile, (uint32_t)s, 0x51bce110u, 0u}, r2[4];
+    philox(ctr, key, r2);
+    uint32_t sxi = g_sub_bits ? (r2[0] >> (32 - g_sub_bits)) : 0u;
+    uint32_t syi = g_sub_bits ? (r2[1] >> (32 - g_sub_bits)) : 0u;
+    ua = ((float)cx + ((float)sxi + ua) * inv_sub) * inv_g;
+    ub = ((float)cy + ((float)syi + ub) * inv_sub) * inv_g;
+  }
+  float pa = fmaf(2.0f, ua, -1.0f), pb = fmaf(2.0f, ub, -1.0f);
+  float X = -(((float)x + jx) - 0.5f * (float)W) * D->pitch;
+  float Y = -(((float)y + jy) - 0.5f * (float)H) * D->pitch;
+  aim_at_pupil(D, X, Y, pa, pb, r);
   return r->wn;
+}
+
+/* the primary path N-1 .. 0 of a start ray at wavelength `lambda`: the exit state on the front element
+ * (p[2] relative to interface 0's vertex, d = the unit direction in air, weight wn / wd) */
+static int primary_path(const geo_lens* L, const geo_derived* D, int lambda, geo_ray* r, const float* mask,
+                        int mw, int mh) {
+  { const float ns = D->n_start[lambda]; r->d[0] *= ns; r->d[1] *= ns; r->d[2] *= ns; }   /* K = n d */
+  float z_from = D->z_sensor;
+  for (int k = L->n_surf - 1; k >= 0; k--) {
+    float dzv = z_from - D->zv[k];
+    int st = (k == L->stop) ? stop_event(r, dzv, D->h2[k], D->inv_stop_h, mask, mw, mh)
+                            : glass_event(r, dzv, D->curv[k], L->radius[k], D->h2[k], D->n_after[lambda][k],
+                                          D->n_before[lambda][k], 0, 0);
+    if (st != OK_) return st;
+    z_from = D->zv[k];
+  }
+  return OK_;
+}
+
+static void exit_state(const geo_derived* D, const geo_ray* r, int st, float* o) {
+  o[0] = r->p[0]; o[1] = r->p[1]; o[2] = D->zv[0] + r->p[2];
+  o[3] = r->d[0]; o[4] = r->d[1]; o[5] = r->d[2];
+  o[6] = st == OK_ ? r->wn / r->wd : 0.0f;
+  o[7] = st == OK_ ? 1.0f : 0.0f;
+}
+
+/* LensCamera::generate_ray, batched, as lf_generate_lens_rays / k_lens_rays computes it: n sensor points
+ * (mm) + pupil-square points -> out n x 8 {origin xyz on the front element, direction xyz, weight, alive}.
+ * (the first six values of a blocked ray are whatever the march left: compare the alive ones) */
+void geo_lens_rays(const geo_lens* L, int W, int lambda, int n, const float* xy, const float* uv,
+                   const float* mask, int mw, int mh, float* out) {
+  geo_derived D;
+  derive(L, W, &D);
+  for (int i = 0; i < n; i++) {
+    geo_ray r;
+    aim_at_pupil(&D, xy[2 * i], xy[2 * i + 1], uv[2 * i], uv[2 * i + 1], &r);
+    exit_state(&D, &r, primary_path(L, &D, lambda, &r, mask, mw, mh), out + 8 * (size_t)i);
+  }
+}
+
+/* The lens camera of the scene term (lf_set_lens_camera; lf_scene.hip k_scene_term<.., LENS>): sample s =
+ * 0 .. ns-1 of pixel p is the march's sample -- Philox(ctr = (p, s, 0x6e5f1a2e, 0), key), strata for ns
+ * samples, the sub-cell of (tile, s) -- and its primary path at wavelength `lambda`.
+ * out: n_pix x ns x 8 floats as geo_lens_rays. */
+void geo_lens_samples(const geo_lens* L, int W, int H, int ns, const uint32_t key[2], int lambda,
+                      const int* pixels, int n_pix, const float* mask, int mw, int mh, float* out) {
+  geo_derived D;
+  derive(L, W, &D);
+  const int G = strata(ns);
+  for (int i = 0; i < n_pix; i++) {
+    const int p = pixels[i], x = p % W, y = p / W;
+    for (int s = 0; s < ns; s++) {
+      uint32_t ctr[4] = {(uint32_t)p, (uint32_t)s, 0x6e5f1a2eu, 0u}, rnd[4];
+      philox(ctr, key, rnd);
+      geo_ray r;
+      start_ray(&D, W, H, x, y, s, G, key, rnd, &r);
+      exit_state(&D, &r, primary_path(L, &D, lambda, &r, mask, mw, mh), out + 8 * ((size_t)i * ns + s));
+    }
+  }
 }
 
 /* March `spp` samples of every pixel in rows [y0, y1); pairs = n x (i, j), (-1,-1) = primary.

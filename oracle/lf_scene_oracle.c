@@ -175,3 +175,19 @@ void lfo_scene_term(int W, int H, int ns_aa, int samples_per_batch, double max_t
   }
   free(raw);
 }
+
+/* est_radiance_global_illumination (pathtracer.cpp:282-302) for explicit rays: what the sample loop adds
+ * for a camera ray, whoever generated it (the lens camera's exit rays, tests/test_gpu_lens_camera.py).
+ * rays: n x 8 doubles {o xyz, d xyz, min_t, max_t}; rgb: n x 3 */
+void lfo_scene_radiance_rays(int n_spheres, const double* spheres, const int* sph_mat, int n_tris,
+                             const double* tri_pos, const double* tri_nrm, const int* tri_mat,
+                             const double* materials, int n_lights, const double* lights, size_t n_rays,
+                             const double* rays, double* rgb) {
+  scene_t S = {n_spheres, spheres, sph_mat, n_tris, tri_pos, tri_nrm, tri_mat, materials, n_lights, lights};
+  for (size_t i = 0; i < n_rays; i++) {
+    const double* q = rays + 8 * i;
+    ray r = {V(q[0], q[1], q[2]), V(q[3], q[4], q[5]), q[6], q[7]};
+    v3 L = radiance(&S, r);
+    rgb[3 * i] = L.x; rgb[3 * i + 1] = L.y; rgb[3 * i + 2] = L.z;
+  }
+}

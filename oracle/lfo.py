@@ -500,3 +500,87 @@ def g64_philox(ctr, key):
     o = (C.c_uint32 * 4)()
     lib().g64_philox(c, k, o)
     return list(o)
+
+
+# ------------------------------------------------------------------------------------------------
+# the lens camera of the scene term (lf_set_lens_camera): primary paths of sensor samples by both
+# tracers, the scene radiance along explicit rays, and the composition into pixels
+# ------------------------------------------------------------------------------------------------
+def geo_lens_rays(lens, W, lam, xy, uv, mask):
+    """lf_generate_lens_rays as the float32 oracle computes it: n x 8 {origin, direction, weight, alive}."""
+    L = geo_lens(lens)
+    xy = np.ascontiguousarray(xy, np.float32).reshape(-1, 2)
+    uv = np.ascontiguousarray(uv, np.float32).reshape(-1, 2)
+    mask = np.ascontiguousarray(mask, np.float32)
+    out = np.zeros((len(xy), 8), np.float32)
+    lib().geo_lens_rays(C.byref(L), int(W), int(lam), len(xy), _p(xy, C.c_float), _p(uv, C.c_float),
+                        _p(mask, C.c_float), mask.shape[1], mask.shape[0], _p(out, C.c_float))
+    return out
+
+
+def geo_lens_samples(lens, W, H, ns, key, lam, pixels, mask):
+    """float32 oracle: primary path of samples 0 .. ns-1 of the listed pixels -> (n_pix, ns, 8)."""
+    L = geo_lens(lens)
+    pixels = np.ascontiguousarray(pixels, np.int32)
+    mask = np.ascontiguousarray(mask, np.float32)
+    out = np.zeros((len(pixels), ns, 8), np.float32)
+    k = (C.c_uint32 * 2)(key & 0xffffffff, (key >> 32) & 0xffffffff)
+    lib().geo_lens_samples(C.byref(L), int(W), int(H), int(ns), k, int(lam), _p(pixels, C.c_int), len(pixels),
+                           _p(mask, C.c_float), mask.shape[1], mask.shape[0], _p(out, C.c_float))
+    return out
+
+
+def g64_lens_samples(lens, W, H, ns, key, lam, pixels, mask, sub_bits=2, **eps):
+    """float64 tracer: (n_pix, ns, 10) {origin, unit direction, weight, potential weight, fragile, dead}."""
+    L = g64_lens(lens, **eps)
+    pixels = np.ascontiguousarray(pixels, np.int32)
+    mask = np.ascontiguousarray(mask, np.float32)
+    out = np.zeros((len(pixels), ns, 10), np.float64)
+    k = (C.c_uint32 * 2)(key & 0xffffffff, (key >> 32) & 0xffffffff)
+    lib().g64_lens_samples(C.byref(L), int(W), int(H), int(ns), k, int(sub_bits), int(lam), _p(pixels, C.c_int),
+                           len(pixels), _p(mask, C.c_float), mask.shape[1], mask.shape[0], _p(out, C.c_double))
+    return out
+
+
+def lens_exposure(lens, W, mask, lam=None):
+    """The lens camera's calibration (lf_lens_camera.hip calibrate_exposure): 1 / mean transmitted weight of
+    the on-axis sensor point over the 64 x 64 grid of pupil-square cell centres."""
+    lam = int(np.asarray(lens["ior"]).shape[0]) // 2 if lam is None else lam
+    g = (np.float32(2.0) * (np.arange(64, dtype=np.float32) + np.float32(0.5))) / np.float32(64.0) - np.float32(1.0)
+    uv = np.stack(np.meshgrid(g, g), axis=-1).reshape(-1, 2)   # row j, column i: (g[i], g[j])
+    out = geo_lens_rays(lens, W, lam, np.zeros_like(uv), uv, mask)
+    return 4096.0 / float(np.sum(out[:, 6].astype(np.float64)))
+
+
+def scene_radiance_rays(spheres, tris, lights, rays):
+    """est_radiance_global_illumination along explicit rays (n x 8: o, d, min_t, max_t) -> n x 3.
+    Scene description as scene_term()."""
+    mats, sp, spm, tp, tn, tm = [], [], [], [], [], []
+    for s in spheres:
+        sp.append(list(s[:4])); spm.append(len(mats)); mats.append([1.0 if s[4] == "e" else 0.0] + list(s[5:8]))
+    for t in tris:
+        tp.append(list(t[:9])); tn.append(list(t[9:18])); tm.append(len(mats))
+        mats.append([1.0 if t[18] == "e" else 0.0] + list(t[19:22]))
+    f64 = lambda a: np.ascontiguousarray(np.array(a, np.float64).reshape(-1))  # noqa: E731
+    i32 = lambda a: np.ascontiguousarray(np.array(a, np.int32).reshape(-1))    # noqa: E731
+    spa, spma, tpa, tna, tma, ma, la = f64(sp), i32(spm), f64(tp), f64(tn), i32(tm), f64(mats), f64(lights)
+    rays = np.ascontiguousarray(rays, np.float64).reshape(-1, 8)
+    out = np.zeros((len(rays), 3), np.float64)
+    lib().lfo_scene_radiance_rays(len(sp), _p(spa, C.c_double), _p(spma, C.c_int), len(tp), _p(tpa, C.c_double),
+                                  _p(tna, C.c_double), _p(tma, C.c_int), _p(ma, C.c_double), len(lights),
+                                  _p(la, C.c_double), C.c_size_t(len(rays)), _p(rays, C.c_double),
+                                  _p(out, C.c_double))
+    return out
+
+
+def lens_exit_to_world(origin_mm, direction, c2w, pos, world_per_mm, z_ref_mm):
+    """The lens camera's hand-over (lf_scene.hip scene_pixel<.., LENS>): exit state in lens space (mm) ->
+    world-space ray origin / direction, the device's order of operations in float64."""
+    o = np.asarray(origin_mm, np.float64)
+    d = np.asarray(direction, np.float64)
+    c = np.asarray(c2w, np.float64).reshape(3, 3)
+    oc = np.stack([o[..., 0] * world_per_mm, o[..., 1] * world_per_mm, (o[..., 2] - z_ref_mm) * world_per_mm], -1)
+    rn = 1.0 / np.sqrt((d[..., 0] * d[..., 0] + d[..., 1] * d[..., 1]) + d[..., 2] * d[..., 2])
+    dc = d * rn[..., None]
+    rot = lambda v: np.stack([(v[..., 0] * c[k, 0] + v[..., 1] * c[k, 1]) + v[..., 2] * c[k, 2] for k in range(3)], -1)  # noqa: E731
+    return np.asarray(pos, np.float64) + rot(oc), rot(dc)
