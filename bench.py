@@ -72,8 +72,8 @@ CONFIGS = {
                                    "4K 256 spp on ONE GPU, camera behind the mesh looking at the sun, scene term on "
                                    "the device, sun handed to the march by lf_set_sun_from_flares"),
     "c5_1gpu": dict(W=3840, H=2160, spp=1024, pairs="all", n_lambda=8, scene=None, spectral=True,
-                    text="BASELINE.json configs[4] on ONE GPU: 8 wavelengths (indices interpolated between "
-                         "the lens file's C, d, F columns) + spectral starburst, 4K 1024 spp"),
+                    text="BASELINE.json configs[4] on ONE GPU: 8 wavelengths (dgauss11_8lambda.lens: 2-term Cauchy "
+                         "fit through each glass's C, d, F indices) + spectral starburst, 4K 1024 spp"),
 }
 
 
@@ -84,17 +84,13 @@ def sun_direction(lens, efl, W, H):
     return [(SUN_NS[0] - 0.5) * sw / efl, (SUN_NS[1] - 0.5) * sw * H / W / efl, -1.0]
 
 
-def lens_8_lambda(lens3):
-    t = np.linspace(0.0, 2.0, 8)
-    ior8 = np.stack([np.array([np.interp(tt, [0, 1, 2], lens3["ior"][:, k]) for k in range(lens3["n"])])
-                     for tt in t]).astype(np.float32)
-    w8 = np.zeros((8, 3), np.float32)
-    for l, tt in enumerate(t):   # tent weights onto R, G, B
-        for c in range(3):
-            w8[l, c] = max(0.0, 1.0 - abs(tt - c)) / 2.6666667
-    # starburst: the pattern scales with wavelength; 656 .. 486 nm relative to the d line (588 nm)
-    lam = np.interp(t, [0, 1, 2], [656.0, 588.0, 486.0])
-    return dict(lens3, ior=ior8), w8, (588.0 / lam)
+def lens_8_lambda(pkg):
+    """C5's prescription: the committed 8-column file (Cauchy fit through the C, d, F indices of every
+    glass; lens-flare_amd/data/make_spectral_lens.py), tent weights of the wavelengths onto R,
+    G, B and the starburst's scale lambda_d / lambda."""
+    lens = pkg.load_lens_file("dgauss11_8lambda.lens")
+    w8, scale = pkg.spectral_weights(lens["lambda_nm"])
+    return lens, w8, scale
 
 
 def pair_list(lens, kind):
@@ -291,7 +287,7 @@ def main():
     mask = pkg.load_aperture_png("pentbig500_14.png")
     lambda_rgb, star_scale = None, None
     if cfg["n_lambda"] == 8:
-        lens, lambda_rgb, star_scale = lens_8_lambda(lens)
+        lens, lambda_rgb, star_scale = lens_8_lambda(pkg)
     efl = pkg.paraxial_efl(lens)
     sun = sun_direction(lens, efl, W, H)
     pairs = pair_list(lens, cfg["pairs"])

@@ -144,7 +144,7 @@ def load_lens_file(path):
     """Parse a .lens prescription (see data/dgauss11.lens) -> dict of float32 arrays."""
     if not os.path.isabs(path) and not os.path.exists(path):
         path = os.path.join(DATA, path)
-    rows, sensor_w = [], 36.0
+    rows, sensor_w, lambda_nm = [], 36.0, None
     for line in open(path):
         line = line.split("#")[0].strip()
         if not line:
@@ -153,6 +153,9 @@ def load_lens_file(path):
         if t[0] == "sensor_width_mm":
             sensor_w = float(t[1])
             continue
+        if t[0] == "lambda_nm":      # the wavelengths of the index columns (spectral prescriptions)
+            lambda_nm = [float(v) for v in t[1:]]
+            continue
         rows.append([float(v) for v in t])
     rows = np.array(rows, np.float64)
     n = len(rows)
@@ -160,9 +163,53 @@ def load_lens_file(path):
     ior = rows[:, 2:-1].T.copy()  # n_lambda x n
     if stop:
         ior[:, stop[0]] = 1.0
-    return dict(n=n, stop=stop[0] if stop else -1, radius=rows[:, 0].astype(np.float32),
+    lens = dict(n=n, stop=stop[0] if stop else -1, radius=rows[:, 0].astype(np.float32),
                 thickness=rows[:, 1].astype(np.float32), ior=ior.astype(np.float32),
                 semi_aperture=rows[:, -1].astype(np.float32), sensor_width_mm=float(sensor_w))
+    if lambda_nm is not None:
+        if len(lambda_nm) != ior.shape[0]:
+            raise ValueError(f"{path}: lambda_nm lists {len(lambda_nm)} wavelengths for {ior.shape[0]} index columns")
+        lens["lambda_nm"] = np.array(lambda_nm, np.float64)
+    return lens
+
+
+# Fraunhofer lines of the three index columns of the shipped prescriptions (C, d, F)
+LINES_NM = (656.3, 587.6, 486.1)
+
+
+def cauchy_indices(lens3, lambda_nm):
+    """"indices by a 2-term Cauchy fit through each glass's three tabulated values"
+    (the reference tabulates three per glass, pathtracer.cpp:553-555): n(lambda) = A + B / lambda^2, A and
+    B by least squares through (C, d, F) of every interface; air and the stop stay exactly 1."""
+    lam = np.asarray(lambda_nm, np.float64)
+    basis = np.stack([np.ones(3), 1.0 / np.square(np.array(LINES_NM))], axis=1)   # 3 x 2
+    ior3 = np.asarray(lens3["ior"], np.float64)                                 # 3 x n
+    coef, *_ = np.linalg.lstsq(basis, ior3, rcond=None)                         # 2 x n
+    out = coef[0][None, :] + coef[1][None, :] / np.square(lam)[:, None]
+    out[:, np.all(ior3 == 1.0, axis=0)] = 1.0
+    return out.astype(np.float32)
+
+
+def spectral_weights(lambda_nm):
+    """RGB weight of every wavelength (tents centred on the C, d, F lines, normalised so that the
+    weights of a channel sum to 1) and the starburst's scale lambda_d / lambda (its pattern grows
+    with the wavelength)."""
+    lam = np.asarray(lambda_nm, np.float64)
+    t = np.interp(-lam, [-LINES_NM[0], -LINES_NM[1], -LINES_NM[2]], [0.0, 1.0, 2.0])
+    w = np.maximum(0.0, 1.0 - np.abs(t[:, None] - np.arange(3)[None, :]))
+    tot = w.sum(axis=0, keepdims=True)
+    w = np.where(tot > 0, w / np.where(tot > 0, tot, 1.0), 0.0)   # (a channel no wavelength reaches stays dark)
+    return w.astype(np.float32), LINES_NM[1] / lam
+
+
+def spectral_lens(lens3, n_lambda=8):
+    """The prescription with n_lambda index columns by the Cauchy fit, wavelengths equally spaced from the
+    C to the F line -> (lens, rgb weights, starburst scales).  data/dgauss11_8lambda.lens is
+    spectral_lens(dgauss11.lens, 8) written out (data/make_spectral_lens.py; tests/test_spectral_lens_cpu.py)."""
+    lam = np.linspace(LINES_NM[0], LINES_NM[2], n_lambda) if n_lambda > 1 else np.array([LINES_NM[1]])
+    lens = dict(lens3, ior=cauchy_indices(lens3, lam), lambda_nm=lam)
+    w, scale = spectral_weights(lam)
+    return lens, w, scale
 
 
 def paraxial_efl(lens, lam=None):

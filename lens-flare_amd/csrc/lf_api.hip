@@ -1078,11 +1078,13 @@ lf_status lf_load_lens_file(lf_ctx* ctx, const char* path) {
     if (char* h = std::strchr(line, '#')) *h = 0;
     std::vector<double> v;
     char* p = line;
-    bool keyword = false;
+    bool keyword = false, skip_line = false;
     while (*p) {
       while (*p == ' ' || *p == '\t' || *p == '\r' || *p == '\n') p++;
       if (!*p) break;
       if (v.empty() && !keyword && std::strncmp(p, "sensor_width_mm", 15) == 0) { keyword = true; p += 15; continue; }
+      // (the wavelengths of the index columns: documentation for the host, the march only needs the indices)
+      if (v.empty() && !keyword && std::strncmp(p, "lambda_nm", 9) == 0) { skip_line = true; break; }
       char* e = nullptr;
       const double d = std::strtod(p, &e);
       if (e == p) { bad = true; break; }
@@ -1090,6 +1092,7 @@ lf_status lf_load_lens_file(lf_ctx* ctx, const char* path) {
       p = e;
     }
     if (bad) break;
+    if (skip_line) continue;
     if (keyword) { if (v.size() != 1) { bad = true; break; } sensor_w = v[0]; continue; }
     if (!v.empty()) rows.push_back(v);
   }

@@ -16,6 +16,7 @@ struct LensCamera::Device {
   const void* mask_of = nullptr;   // aperture texture that is on the device
   float sensor_w = 36.0f;
   int n_lambda = 1;
+  double z_ep = 0.0;               // the paraxial entrance pupil's z (mm): what sits at the camera position
 };
 
 namespace {
@@ -77,6 +78,9 @@ LensCamera::Device* LensCamera::dev() const {
       must(dev_->ctx, lf_set_aperture(dev_->ctx, LF_APERTURE_STARBURST, &open, 1, 1), "lf_set_aperture");
       dev_->mask_of = dev_;
     }
+    // where the lens sits relative to the camera position: as the device's lens camera places it
+    must(dev_->ctx, lf_set_lens_camera(dev_->ctx, 1, 1.0, 1.0), "lf_set_lens_camera");
+    must(dev_->ctx, lf_get_lens_camera(dev_->ctx, nullptr, nullptr, nullptr, &dev_->z_ep), "lf_get_lens_camera");
   }
   return dev_;
 }
@@ -101,7 +105,7 @@ void LensCamera::generate_rays(size_t n, const double* xy_pupil, std::vector<Ray
   for (size_t i = 0; i < n; i++) {
     const float* o = &out[8 * i];
     // lens space = camera space: optical axis z, the scene at z < 0 (Camera looks down -z, camera.cpp:294)
-    Ray r(eye + c2w * (world_per_mm * Vector3D(o[0], o[1], o[2])), c2w * Vector3D(o[3], o[4], o[5]));
+    Ray r(eye + c2w * (world_per_mm * Vector3D(o[0], o[1], (double)o[2] - d->z_ep)), c2w * Vector3D(o[3], o[4], o[5]));
     r.min_t = near_clip();
     r.max_t = far_clip();
     r.depth = o[7] != 0.0f ? 1 : 0;

@@ -40,9 +40,16 @@ class LensCamera : public Camera {
   const std::string& lens_file() const { return lens_file_; }
   int samples_per_pixel() const { return spp_; }
   float sun_angular_radius() const { return sun_radius_; }
-  // world units per millimetre of the prescription (where the front element sits relative to the
-  // camera position); 1 by default, like the scene files of the reference, which carry no unit
-  double world_per_mm = 1.0;
+  // world units per millimetre of the prescription: the lens has a size in the scene (parallax,
+  // depth of field).  The centre of the paraxial entrance pupil sits at the camera position -- with the
+  // stop closed to a point the lens camera IS the reference's pinhole.  Default: 1 scene unit = 1 m.
+  double world_per_mm = 0.001;
+  // the renderer's sample loop images the scene THROUGH this lens (pathtracer_amd.cpp, lf_set_lens_camera:
+  // depth of field, vignetting, distortion, transmission); false: ghosts through the lens, the scene
+  // through the reference's pinhole (Camera::generate_ray, camera.cpp:278-305)
+  bool image_scene = true;
+  // one ray per wavelength instead of one at the reference wavelength (lateral / axial colour in the scene)
+  bool chromatic = false;
 
   // LensCamera::generate_ray: (x, y) normalised sensor coordinates as for Camera::generate_ray;
   // (pu, pv) in [0,1)^2 samples the rear pupil.  The primary path is marched through the prescription

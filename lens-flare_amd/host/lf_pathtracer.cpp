@@ -2,6 +2,10 @@
 // flare arithmetic happens behind the C ABI on the GPU.
 #include "lf_pathtracer.h"
 
+#include <cstring>
+
+#include "lf_frame_sequence.h"
+
 #include <cmath>
 #include <stdexcept>
 
@@ -219,7 +223,6 @@ void PathTracer::generate_ghost_buffer() {
   for (auto& f : flare_radiance) { r.push_back(f.x); r.push_back(f.y); r.push_back(f.z); }
   double ax[2] = {axis_ray.x, axis_ray.y};
   check(lf_set_flares(ctx_, (int)flare_origins.size(), o.data(), r.data(), ax, angle_to_sun), "lf_set_flares");
-  check(lf_set_params(ctx_, (int)ns_aa, flare_radius, flare_intensity), "lf_set_params");
   {
     if (starburst_scale.size() != starburst_weight.size())
       throw std::runtime_error("generate_ghost_buffer: starburst_scale / starburst_weight sizes differ");
@@ -228,16 +231,23 @@ void PathTracer::generate_ghost_buffer() {
     check(lf_set_starburst_spectrum(ctx_, (int)starburst_scale.size(), starburst_scale.data(), w.data()),
           "lf_set_starburst_spectrum");
   }
-  if (counter_jitter) check(lf_set_jitter_counter(ctx_, 0x1e45f1a4eULL), "lf_set_jitter_counter");
-  else check(lf_set_jitter_mt19937(ctx_, jitter_seed, nullptr, 0), "lf_set_jitter_mt19937");
-  if (geometric_) check(lf_trace_ghosts(ctx_, geo_spp_, 0x1e45f1a4eULL), "lf_trace_ghosts");
-  else check(lf_generate_ghost_buffer(ctx_), "lf_generate_ghost_buffer");
   const size_t W = sampleBuffer.w, H = sampleBuffer.h;
   static_assert(sizeof(Vector3D) == 3 * sizeof(double), "Vector3D must be 3 packed doubles");
-  // The scene term (est_radiance_global_illumination, still the host's CPU code -- SURVEY 8f-2)
-  // is evaluated here for the whole frame and handed to the device, so that the device composes
-  // (scene + ghost) + starburst exactly like pathtracer.cpp:891 and tonemaps the final values.
+  // the frame itself: the one definition of the call order both host mirrors share (lf_frame_sequence.h)
+  lf_frame_plan plan;
+  std::memset(&plan, 0, sizeof(plan));
+  plan.ns_aa = (int)ns_aa; plan.flare_radius = flare_radius; plan.flare_intensity = flare_intensity;
+  plan.jitter = counter_jitter ? LF_FRAME_JITTER_COUNTER : LF_FRAME_JITTER_MT19937;
+  plan.mt_seed = jitter_seed; plan.counter_key = 0x1e45f1a4eULL;
+  plan.ghosts = geometric_ ? LF_FRAME_GHOSTS_MARCH : LF_FRAME_GHOSTS_PARAXIAL;
+  plan.sun_from_flares = 0;             // use_geometric_ghosts set the sun explicitly
+  plan.geo_spp = geo_spp_; plan.geo_key = 0x1e45f1a4eULL;
+  plan.lens_camera_mode = geometric_ ? lens_camera_mode : 0;
+  plan.world_per_mm = lens_world_per_mm; plan.exposure = 0.0;
+  if (plan.lens_camera_mode) plan.jitter = LF_FRAME_JITTER_COUNTER;   // the lens camera's samples are the march's
   if (scene_radiance) {
+    // a scene term the HOST evaluates (est_radiance_global_illumination on the CPU, a callback): handed
+    // to the device, which composes (scene + ghost) + starburst exactly like pathtracer.cpp:891
     std::vector<double> scene(W * H * 3);
     for (size_t y = 0; y < H; y++)
       for (size_t x = 0; x < W; x++) {
@@ -246,13 +256,13 @@ void PathTracer::generate_ghost_buffer() {
         d[0] = t.x; d[1] = t.y; d[2] = t.z;
       }
     check(lf_set_scene_term(ctx_, scene.data()), "lf_set_scene_term");
-  } else if (device_scene_) {
-    // the sample loop of raytrace_pixel (:841-875) on the device: BVH + direct lighting
-    check(lf_render_scene_term(ctx_), "lf_render_scene_term");
+    plan.scene = LF_FRAME_SCENE_HOST;
   } else {
-    check(lf_set_scene_term(ctx_, nullptr), "lf_set_scene_term");
+    // the sample loop of raytrace_pixel (:841-875) on the device (BVH + direct lighting), or no scene
+    plan.scene = device_scene_ ? LF_FRAME_SCENE_DEVICE : LF_FRAME_SCENE_NONE;
   }
-  check(lf_render_flare_layer(ctx_), "lf_render_flare_layer");
+  const char* failed = "lf_run_frame";
+  check(lf_run_frame(ctx_, &plan, &failed), failed);
   ghost_buffer.resize(W, H);
   check(lf_read_tile(ctx_, 1, 0, 0, (int)W, (int)H, &ghost_buffer.data[0].x, 3), "lf_read_tile(ghost)");
   star_.resize(W * H * 3);

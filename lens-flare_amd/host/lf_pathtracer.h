@@ -137,6 +137,10 @@ class PathTracer {
   lf_collada_camera load_collada(const std::string& path);
   uint32_t jitter_seed = 5489;     // std::mt19937 default, reference visit order (32x32 tiles)
   bool counter_jitter = false;     // order-free Philox jitter instead
+  // with use_geometric_ghosts: the device scene term images the scene through the same prescription
+  // (lf_set_lens_camera: 0 = the reference's pinhole, 1 = reference wavelength, 2 = one ray per wavelength)
+  int lens_camera_mode = 0;
+  double lens_world_per_mm = 0.001;
   lf_ctx* context() { return ctx_; }
   std::string last_error() const;
 

@@ -54,6 +54,7 @@
 
 #include "lens_camera_amd.h"
 #include "lensflare.h"
+#include "lf_frame_sequence.h"
 
 using namespace CGL::SceneObjects;
 
@@ -99,6 +100,11 @@ struct DeviceState {
   std::string lens_loaded;             // file that is on the device ...
   size_t lens_w = 0, lens_h = 0;       // ... for this frame size (the pixel pitch depends on it)
   bool mirror_ghost = false;           // LF_MIRROR_GHOST_BUFFER: fill the public ghost_buffer field every frame
+  double world_per_mm = 0.001;         // LF_WORLD_PER_MM: scene units per lens millimetre (lens camera; 1 unit = 1 m)
+  bool log_frame = true;               // LF_QUIET unset: one stdout line per frame for the march / the lens camera
+  // what the device's scene kernel counted for the frame (BVHAccel::total_rays / total_isects, bvh.h:136)
+  uint64_t frame_rays = 0, frame_isects = 0;
+  std::atomic<bool> counters_pushed{true};
   std::atomic<uint64_t> probe_seq{0};  // counter-RNG stream of the single-ray integrator members
 };
 
@@ -302,6 +308,10 @@ PathTracer::PathTracer() {
   if (const char* v = getenv("LF_SUN_ANGULAR_RADIUS")) s.sun_radius = (float)atof(v);
   if (const char* v = getenv("LF_GEOMETRIC_KEY")) s.geo_key = strtoull(v, nullptr, 0);
   s.mirror_ghost = getenv("LF_MIRROR_GHOST_BUFFER") != nullptr;
+  if (const char* v = getenv("LF_WORLD_PER_MM")) s.world_per_mm = atof(v);
+  s.log_frame = getenv("LF_QUIET") == nullptr;
+  s.frame_rays = s.frame_isects = 0;
+  s.counters_pushed.store(true);
 }
 
 PathTracer::~PathTracer() {
@@ -381,36 +391,80 @@ void PathTracer::generate_ghost_buffer() {                         // pathtracer
   DeviceState& s = state(this);
   sync_textures(s, this);
   sync_flares(s, this);
-  check(s, lf_set_params(s.ctx, (int)ns_aa, flare_radius, flare_intensity), "lf_set_params");
-  // the reference's shared std::mt19937 in its visit order (32x32 tiles, one worker); a host that
-  // runs several workers has no reproducible order anyway and may switch to lf_set_jitter_counter
-  if (getenv("LF_COUNTER_JITTER")) check(s, lf_set_jitter_counter(s.ctx, 0x1e45f1a4eULL), "lf_set_jitter_counter");
-  else check(s, lf_set_jitter_mt19937(s.ctx, 5489, nullptr, 0), "lf_set_jitter_mt19937");
   sync_scene(s, this);
-  check(s, lf_render_scene_term(s.ctx), "lf_render_scene_term");
-
   const size_t W = sampleBuffer.w, H = sampleBuffer.h;
   // which ghosts: a LensCamera brings its prescription, LF_LENS_FILE selects one for any camera
   const LensCamera* lens_cam = dynamic_cast<const LensCamera*>(camera);
   const std::string lens_file = lens_cam && !lens_cam->lens_file().empty() ? lens_cam->lens_file() : s.lens_file;
+  lf_frame_plan plan;
+  memset(&plan, 0, sizeof(plan));
+  plan.ns_aa = (int)ns_aa; plan.flare_radius = flare_radius; plan.flare_intensity = flare_intensity;
+  // the reference's shared std::mt19937 in its visit order (32x32 tiles, one worker); a host that
+  // runs several workers has no reproducible order anyway and may switch to the counter RNG
+  // (LF_COUNTER_JITTER=<key>: that key; any other value: the default one)
+  plan.jitter = getenv("LF_COUNTER_JITTER") ? LF_FRAME_JITTER_COUNTER : LF_FRAME_JITTER_MT19937;
+  plan.mt_seed = 5489; plan.counter_key = 0x1e45f1a4eULL;
+  if (const char* v = getenv("LF_COUNTER_JITTER")) {
+    const unsigned long long k = strtoull(v, nullptr, 0);
+    if (k > 1) plan.counter_key = k;
+  }
+  plan.scene = LF_FRAME_SCENE_DEVICE;
+  plan.ghosts = LF_FRAME_GHOSTS_PARAXIAL;   // the reference's paraxial quads
   if (!lens_file.empty()) {
     // the geometric march: every ghost pair of the prescription + the primary path, per sensor sample
     if (s.lens_loaded != lens_file || s.lens_w != W || s.lens_h != H) {
       check(s, lf_load_lens_file(s.ctx, lens_file.c_str()), "lf_load_lens_file");
       s.lens_loaded = lens_file; s.lens_w = W; s.lens_h = H;
     }
-    if (flare_origins.empty()) {   // no sun in the frame: nothing to march towards (:724-726)
-      check(s, lf_clear_ghost_buffer(s.ctx), "lf_clear_ghost_buffer");
-    } else {
-      check(s, lf_set_sun_from_flares(s.ctx, 0, 0.0, lens_cam ? lens_cam->sun_angular_radius() : s.sun_radius),
-            "lf_set_sun_from_flares");
-      check(s, lf_trace_ghosts(s.ctx, lens_cam ? lens_cam->samples_per_pixel() : s.geo_spp, s.geo_key),
-            "lf_trace_ghosts");
+    // no sun in the frame: nothing to march towards (:724-726)
+    plan.ghosts = flare_origins.empty() ? LF_FRAME_GHOSTS_NONE : LF_FRAME_GHOSTS_MARCH;
+    plan.sun_from_flares = 1;
+    plan.sun_angular_radius = lens_cam ? lens_cam->sun_angular_radius() : s.sun_radius;
+    plan.geo_spp = lens_cam ? lens_cam->samples_per_pixel() : s.geo_spp;
+    plan.geo_key = s.geo_key;
+    // ... and the SCENE is imaged through the same prescription: the sample loop's camera->generate_ray
+    // (pathtracer.cpp:848) becomes the primary path of the march's sensor sample (lf_set_lens_camera).
+    // Camera::generate_ray is not virtual (camera.h:166), so the reference's loop could never reach a
+    // lens; the device's loop does.  LF_LENS_PINHOLE_SCENE / LensCamera::image_scene = false keep the
+    // reference's pinhole for the scene term (ghosts through the lens, scene through a pinhole: rounds 1-3).
+    const bool through_lens = lens_cam ? lens_cam->image_scene : getenv("LF_LENS_PINHOLE_SCENE") == nullptr;
+    if (through_lens) {
+      plan.lens_camera_mode = (lens_cam ? lens_cam->chromatic : getenv("LF_LENS_CHROMATIC") != nullptr) ? 2 : 1;
+      plan.world_per_mm = lens_cam ? lens_cam->world_per_mm : s.world_per_mm;
+      plan.exposure = 0.0;                      // calibrated on the axis
+      plan.jitter = LF_FRAME_JITTER_COUNTER;    // the lens camera's samples are the march's
+      plan.counter_key = s.geo_key;
     }
-  } else {
-    check(s, lf_generate_ghost_buffer(s.ctx), "lf_generate_ghost_buffer");   // the reference's paraxial quads
   }
-  check(s, lf_render_flare_layer(s.ctx), "lf_render_flare_layer");
+  if (s.log_frame) { check(s, lf_timing_reset(s.ctx), "lf_timing_reset"); check(s, lf_timing_enable(s.ctx, 1), "lf_timing_enable"); }
+  check(s, lf_reset_scene_counters(s.ctx), "lf_reset_scene_counters");
+  check(s, lf_reset_counters(s.ctx), "lf_reset_counters");
+  const char* failed = "lf_run_frame";
+  check(s, lf_run_frame(s.ctx, &plan, &failed), failed);
+  // the numbers behind the reference's end-of-frame log (raytraced_renderer.cpp:706-709): the renderer
+  // zeroes bvh->total_rays / total_isects AFTER this pre-pass (:349), so they are handed over by the
+  // first raytrace_pixel of the frame (push_bvh_counters)
+  {
+    uint64_t sc[4] = {0, 0, 0, 0};
+    check(s, lf_get_scene_counters(s.ctx, sc), "lf_get_scene_counters");
+    s.frame_rays = sc[0]; s.frame_isects = sc[1];
+    s.counters_pushed.store(false);
+    if (s.log_frame) {
+      // the march has no counterpart in the reference's log: one line of its own, same style
+      uint64_t ev = 0;
+      int launches = 0; double ms = 0.0;
+      check(s, lf_get_executed_events(s.ctx, &ev), "lf_get_executed_events");
+      check(s, lf_synchronize(s.ctx), "lf_synchronize");
+      (void)lf_timing_get(s.ctx, "march", &launches, &ms);
+      if (plan.ghosts == LF_FRAME_GHOSTS_MARCH && launches > 0 && ms > 0.0)
+        fprintf(stdout, "[PathTracer/MI355X] Lens march executed %llu ray-surface intersections in %.3f ms "
+                        "(%.4f million per second).\n", (unsigned long long)ev, ms, (double)ev / ms * 1e-3);
+      if (plan.lens_camera_mode)
+        fprintf(stdout, "[PathTracer/MI355X] Lens camera marched %llu sensor samples, %llu left the front element.\n",
+                (unsigned long long)sc[2], (unsigned long long)sc[3]);
+      check(s, lf_timing_enable(s.ctx, 0), "lf_timing_enable");
+    }
+  }
   // read back what the host's per-pixel / per-tile calls hand over: the composed sensor values and
   // their tonemapped form.  ghost_buffer (a public field no caller of the reference reads) and the
   // starburst alone (raytrace_starburst) come on demand.
@@ -448,6 +502,12 @@ void PathTracer::raytrace_pixel(size_t x, size_t y) {             // pathtracer.
   // sampleBuffer = total_radiance + ghost_color + starburst_radiance (:891), composed on the device
   DeviceState& s = state(this);
   if (!s.frame_ready) { fprintf(stderr, "[PathTracer/MI355X] raytrace_pixel before generate_ghost_buffer\n"); exit(1); }
+  // BVHAccel::total_rays / total_isects for the reference's end-of-frame log (raytraced_renderer.cpp:706-709):
+  // the renderer zeroes them between the pre-pass and the workers (:349), so the first pixel hands them over
+  if (!s.counters_pushed.load(std::memory_order_acquire) && !s.counters_pushed.exchange(true) && bvh) {
+    bvh->total_rays = s.frame_rays;
+    bvh->total_isects = s.frame_isects;
+  }
   const double* v = &s.sample[3 * (x + y * sampleBuffer.w)];
   sampleBuffer.update_pixel(Vector3D(v[0], v[1], v[2]), x, y);
 }

@@ -157,6 +157,12 @@ static int cmd_frame(int argc, char** argv) {
   if (getenv("REF_LENS_CAMERA"))
     lens_cam.set_lens(getenv("REF_LENS_CAMERA"), getenv("REF_LENS_SPP") ? atoi(getenv("REF_LENS_SPP")) : 64,
                       getenv("REF_LENS_SUN_RADIUS") ? (float)atof(getenv("REF_LENS_SUN_RADIUS")) : 0.05f);
+  // (the scene through the lens as well: on by default; REF_LENS_IMAGE_SCENE=0 keeps the reference's pinhole
+  // for the scene term; REF_LENS_WORLD_PER_MM = scene units per lens millimetre; REF_LENS_CHROMATIC: a ray
+  // per wavelength)
+  if (getenv("REF_LENS_IMAGE_SCENE")) lens_cam.image_scene = atoi(getenv("REF_LENS_IMAGE_SCENE")) != 0;
+  if (getenv("REF_LENS_WORLD_PER_MM")) lens_cam.world_per_mm = atof(getenv("REF_LENS_WORLD_PER_MM"));
+  if (getenv("REF_LENS_CHROMATIC")) lens_cam.chromatic = true;
   Camera& cam = getenv("REF_LENS_CAMERA") ? static_cast<Camera&>(lens_cam) : base_cam;
 #else
   Camera& cam = base_cam;

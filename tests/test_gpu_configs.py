@@ -30,16 +30,10 @@ def lf(pkg):
 
 
 def _lens8(pkg):
-    lens3 = pkg.load_lens_file("dgauss11.lens")
-    t = np.linspace(0.0, 2.0, 8)
-    ior8 = np.stack([np.array([np.interp(tt, [0, 1, 2], lens3["ior"][:, k]) for k in range(lens3["n"])])
-                     for tt in t]).astype(np.float32)
-    w8 = np.zeros((8, 3), np.float32)
-    for l, tt in enumerate(t):
-        for c in range(3):
-            w8[l, c] = max(0.0, 1.0 - abs(tt - c)) / 2.6666667
-    scale = 588.0 / np.interp(t, [0, 1, 2], [656.0, 588.0, 486.0])
-    return dict(lens3, ior=ior8), w8, scale
+    """C5's prescription: the committed 8-column file (2-term Cauchy fit)"""
+    lens8 = pkg.load_lens_file("dgauss11_8lambda.lens")
+    w8, scale = pkg.spectral_weights(lens8["lambda_nm"])
+    return lens8, w8, scale
 
 
 def _c5_setup(pkg, lf, W, H, mask_name="pentbig500_14.png"):

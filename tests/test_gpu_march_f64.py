@@ -98,15 +98,8 @@ def test_thin_lens_converged_pixels_within_1e4(pkg, lf):
 
 def test_eight_wavelengths_within_1e4(pkg, lf):
     """C5's 8 wavelengths with RGB weights, the same bar."""
-    lens3 = pkg.load_lens_file("dgauss11.lens")
-    t = np.linspace(0.0, 2.0, 8)
-    ior8 = np.stack([np.array([np.interp(tt, [0, 1, 2], lens3["ior"][:, k]) for k in range(lens3["n"])])
-                     for tt in t]).astype(np.float32)
-    lens8 = dict(lens3, ior=ior8)
-    w8 = np.zeros((8, 3), np.float32)
-    for l, tt in enumerate(t):
-        for c in range(3):
-            w8[l, c] = max(0.0, 1.0 - abs(tt - c)) / 2.6666667
+    lens8 = pkg.load_lens_file("dgauss11_8lambda.lens")   # 2-term Cauchy fit through C, d, F (SURVEY 8d)
+    w8, _ = pkg.spectral_weights(lens8["lambda_nm"])
     mask = load_texels("pentbig500_14.png")
     W, H, spp, key = 48, 32, 144, 0x8888
     sun, rad, alpha = [0.02, 0.03, -1.0], [1.0, 0.9, 0.5], 0.05
@@ -210,15 +203,8 @@ def test_c3_band_at_full_spp_against_the_independent_tracer(pkg, lf):
 
 
 def _c5_band(pkg, lf, spp, rows_per_call=16):
-    lens3 = pkg.load_lens_file("dgauss11.lens")
-    t = np.linspace(0.0, 2.0, 8)
-    ior8 = np.stack([np.array([np.interp(tt, [0, 1, 2], lens3["ior"][:, k]) for k in range(lens3["n"])])
-                     for tt in t]).astype(np.float32)
-    lens8 = dict(lens3, ior=ior8)
-    w8 = np.zeros((8, 3), np.float32)
-    for l, tt in enumerate(t):
-        for c in range(3):
-            w8[l, c] = max(0.0, 1.0 - abs(tt - c)) / 2.6666667
+    lens8 = pkg.load_lens_file("dgauss11_8lambda.lens")   # 2-term Cauchy fit through C, d, F
+    w8, _ = pkg.spectral_weights(lens8["lambda_nm"])
     mask = load_texels("pentbig500_14.png")
     W, H, key = 3840, 2160, 0xC5C5
     y_top = (int(SUN_NS[1] * H) // 8) * 8 - 8

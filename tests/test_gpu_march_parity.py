@@ -116,18 +116,11 @@ def test_thin_lens_config_c1(pkg, lf):
 
 def test_eight_wavelengths_config_c5_subset(pkg, lf):
     """BASELINE.json configs[4] asks for 8 wavelengths: the march takes any n_lambda <= 8 with an
-    RGB weight per wavelength (lf_set_lambda_rgb).  8 indices by linear interpolation of the lens
-    file's three columns; GPU == oracle bit for bit, and with the 3 original columns + identity
-    weights the 3-wavelength result is reproduced exactly."""
-    lens3 = pkg.load_lens_file("dgauss11.lens")
-    t = np.linspace(0.0, 2.0, 8)
-    ior8 = np.stack([np.array([np.interp(tt, [0, 1, 2], lens3["ior"][:, k]) for k in range(lens3["n"])])
-                     for tt in t]).astype(np.float32)
-    lens8 = dict(lens3, ior=ior8)
-    w8 = np.zeros((8, 3), np.float32)
-    for l, tt in enumerate(t):   # tent weights onto R, G, B
-        for c in range(3):
-            w8[l, c] = max(0.0, 1.0 - abs(tt - c)) / 2.6666667
+    RGB weight per wavelength (lf_set_lambda_rgb).  8 indices by the 2-term Cauchy fit through the lens
+    file's three columns (the committed dgauss11_8lambda.lens); GPU == oracle bit for bit, and with the 3
+    original columns + identity weights inside 8 the 3-wavelength result is reproduced exactly."""
+    lens8 = pkg.load_lens_file("dgauss11_8lambda.lens")   # 2-term Cauchy fit through C, d, F (SURVEY 8d)
+    w8, _ = pkg.spectral_weights(lens8["lambda_nm"])
     mask = load_texels("pentbig500_14.png")
     W, H, spp = 32, 16, 9
     lf.set_frame(W, H)
@@ -143,6 +136,20 @@ def test_eight_wavelengths_config_c5_subset(pkg, lf):
                              SUN["radiance"], SUN["angular_radius"], lambda_rgb=w8)
     assert lf.counters() == ocnt and ocnt["rays_launched"] == W * H * spp * 8 * 46
     assert np.array_equal(g, og) and og.max() > 0
+    # Lambda = 3 inside Lambda = 8 (SURVEY 8c KAT v): eight columns of which the first three are the
+    # file's C, d, F columns with the identity weights and the other five carry no weight reproduce the
+    # 3-wavelength frame exactly (the wavelengths of a sample share its start ray and add as integers)
+    lens3 = pkg.load_lens_file("dgauss11.lens")
+    cols = np.concatenate([lens3["ior"], np.repeat(lens3["ior"][1:2], 5, axis=0)]).astype(np.float32)
+    w38 = np.zeros((8, 3), np.float32)
+    w38[:3] = np.eye(3, dtype=np.float32)
+    lf.set_lens(dict(lens3, ior=cols))
+    lf.set_lambda_rgb(w38)
+    lf.trace_ghosts(spp, 77)
+    g38 = lf.read_buffer(pkg.GHOST_BUFFER)
+    lf.set_lens(lens3)
+    lf.trace_ghosts(spp, 77)
+    assert np.array_equal(g38, lf.read_buffer(pkg.GHOST_BUFFER)) and g38.max() > 0
 
 
 @pytest.mark.parametrize("n_lambda", [1, 2, 4, 5, 6, 7])
@@ -151,14 +158,7 @@ def test_every_wavelength_count_groups_correctly(pkg, lf, n_lambda):
     3+3+1, 3+3+2): every count, short last group included, bit for bit against the oracle -- which
     marches each wavelength of each path on its own."""
     lens3 = pkg.load_lens_file("dgauss11.lens")
-    t = np.linspace(0.0, 2.0, n_lambda) if n_lambda > 1 else np.array([1.0])
-    ior = np.stack([np.array([np.interp(tt, [0, 1, 2], lens3["ior"][:, k]) for k in range(lens3["n"])])
-                    for tt in t]).astype(np.float32)
-    lens = dict(lens3, ior=ior)
-    w = np.zeros((n_lambda, 3), np.float32)
-    for l, tt in enumerate(t):
-        for c in range(3):
-            w[l, c] = max(0.0, 1.0 - abs(tt - c)) * 3.0 / n_lambda
+    lens, w, _ = pkg.spectral_lens(lens3, n_lambda)     # Cauchy-fitted indices at n_lambda wavelengths
     mask = load_texels("pentbig500_14.png")
     W, H, spp = 24, 16, 9
     lf.set_frame(W, H)
