@@ -49,7 +49,7 @@ FLOP_PER_EVENT = 38.0
 FLOP_PER_FRESNEL = 20.0
 SUN_NS = (0.521445, 0.517156)
 TILE_ROWS = 8   # the march kernel's sensor tile is 8x8 pixels
-PMC_FILES = [os.path.join(ROOT, "profiles", n) for n in ("r03_march_pmc.json", "r02_march_pmc.json")]   # newest first
+PMC_FILES = [os.path.join(ROOT, "profiles", n) for n in ("r04_march_pmc.json", "r03_march_pmc.json", "r02_march_pmc.json")]   # newest first
 
 # BASELINE.json configs[1..4]; configs[3] / [4] are 8-GPU jobs there, here one GPU's whole frame
 CONFIGS = {
@@ -63,14 +63,17 @@ CONFIGS = {
     "c4_1gpu": dict(W=3840, H=2160, spp=256, pairs="all", n_lambda=3, scene="pyramid.dae", spectral=False,
                     text="BASELINE.json configs[3] on ONE GPU: 4K 256 spp, the sun is the scene's "
                          "DirectionalLight (dae/dragon.dae is absent from the reference checkout: "
-                         "dae/pyramid.dae, the project's own sun scene), scene term on the device, "
-                         "sun handed to the march by lf_set_sun_from_flares"),
+                         "dae/pyramid.dae, the project's own sun scene); every sensor sample's primary path "
+                         "images the SCENE through the prescription (lf_set_lens_camera: BVH, direct lighting, "
+                         "weighted by the transmitted fraction) and its ghost paths collect the sun (sun handed to "
+                         "the march by lf_set_sun_from_flares)"),
     "c4_maxplanck_1gpu": dict(W=3840, H=2160, spp=256, pairs="all", n_lambda=3, scene="maxplanck.dae", spectral=False,
                               behind_mesh=True,
                               text="configs[3]'s shape on the LARGEST scene file the reference ships that loads "
                                    "(dae/meshedit/maxplanck.dae: 50 801 triangles, its own DirectionalLight is the sun): "
-                                   "4K 256 spp on ONE GPU, camera behind the mesh looking at the sun, scene term on "
-                                   "the device, sun handed to the march by lf_set_sun_from_flares"),
+                                   "4K 256 spp on ONE GPU, camera behind the mesh looking at the sun, the scene imaged "
+                                   "through the prescription (lf_set_lens_camera), sun handed to the march by "
+                                   "lf_set_sun_from_flares"),
     "c5_1gpu": dict(W=3840, H=2160, spp=1024, pairs="all", n_lambda=8, scene=None, spectral=True,
                     text="BASELINE.json configs[4] on ONE GPU: 8 wavelengths (dgauss11_8lambda.lens: 2-term Cauchy "
                          "fit through each glass's C, d, F indices) + spectral starburst, 4K 1024 spp"),
@@ -123,27 +126,34 @@ def source_sha():
 def cpu_baseline(lens, mask, sun, W, H, pairs, lambda_rgb, target_s):
     """The CPU oracle (kind 'port': oracle/lf_geo_oracle.c, one path at a time like any per-path
     tracer) timed on this host's cores on a bounded sample of the same workload: a band of rows
-    of the same frame at reduced spp."""
+    of the same frame at reduced spp -- on ALL host cores (`value`, `cores`) and on one (`value_t1`),
+    as SURVEY 8d asks for the CPU leg."""
     from oracle import lfo
     host_cores = os.cpu_count() or 1
-    cores = min(host_cores, 64)   # the oracle's OpenMP team is capped at 64 threads
+    cores = host_cores
     rows = (H // 2 - 32, H // 2 + 32)
-    t0 = time.time()
-    _, c = lfo.geo_trace(lens, W, H, rows[0], rows[0] + 4, 1, 1, pairs, True, mask, sun,
-                         [1.0, 0.9, 0.5], 0.05, n_threads=cores, lambda_rgb=lambda_rgb)
-    dt = max(time.time() - t0, 1e-3)
-    rate = c["surface_events"] / dt
-    per_sample = c["surface_events"] / (4 * W)
-    spp = int(max(1, min(64, target_s * rate / (per_sample * (rows[1] - rows[0]) * W))))
-    t0 = time.time()
-    _, c = lfo.geo_trace(lens, W, H, rows[0], rows[1], spp, 1, pairs, True, mask, sun,
-                         [1.0, 0.9, 0.5], 0.05, n_threads=cores, lambda_rgb=lambda_rgb)
-    dt = time.time() - t0
-    return {"value": c["surface_events"] / dt / 1e6, "unit": "Mray-surface-intersections/s",
+
+    def run(y0, y1, spp, threads):
+        t0 = time.time()
+        _, c = lfo.geo_trace(lens, W, H, y0, y1, spp, 1, pairs, True, mask, sun, [1.0, 0.9, 0.5], 0.05,
+                             n_threads=threads, lambda_rgb=lambda_rgb)
+        return c["surface_events"], max(time.time() - t0, 1e-3)
+
+    ev, dt = run(rows[0], rows[0] + 4, 1, cores)           # calibration: 4 rows at 1 spp
+    per_row_sample = ev / 4.0
+    spp = int(max(1, min(64, target_s * (ev / dt) / (per_row_sample * (rows[1] - rows[0])))))
+    ev_n, dt_n = run(rows[0], rows[1], spp, cores)
+    # one thread: as many rows at 1 spp as a third of the budget buys at the all-core rate / cores (>= 1 row)
+    rate1_guess = ev_n / dt_n / cores * 1.5
+    rows1 = int(max(1, min(rows[1] - rows[0], (target_s / 3.0) * rate1_guess / per_row_sample)))
+    ev_1, dt_1 = run(rows[0], rows[0] + rows1, 1, 1)
+    return {"value": ev_n / dt_n / 1e6, "unit": "Mray-surface-intersections/s",
             "cores": cores, "host_cores": host_cores, "kind": "port",
+            "value_t1": ev_1 / dt_1 / 1e6, "cores_t1": 1,
             "sample": f"rows {rows[0]}..{rows[1]} of the {W}x{H} frame, {spp} of the spp, every path "
-                      f"marched on its own: {c['surface_events']} intersections in {dt:.1f} s "
-                      f"(oracle/lf_geo_oracle.c, OpenMP); the reference has no geometric lens to time"}
+                      f"marched on its own: {ev_n} intersections in {dt_n:.1f} s on {cores} OpenMP threads; "
+                      f"one thread: rows {rows[0]}..{rows[0] + rows1} at 1 spp, {ev_1} intersections in {dt_1:.1f} s "
+                      f"(oracle/lf_geo_oracle.c); the reference has no geometric lens to time"}
 
 
 def reference_flare_path(pkg, budget_s):
@@ -327,7 +337,12 @@ def main():
             pos = mid - to_sun / np.linalg.norm(to_sun) * (1.5 * ext)
         c2w = pkg.aim_camera(pos, lights[0][:3], SUN_NS, hf, vf)
         lf.set_camera(c2w, pos, hf, vf)
-        lf.set_params(1, 25.0, 1.0)
+        # the scene through the lens: one primary path per sensor sample, as many samples as the march
+        # takes (LF_BENCH_SCENE_SPP / LF_BENCH_PINHOLE_SCENE: experiments), 1 scene unit = 1 m
+        scene_spp = int(os.environ.get("LF_BENCH_SCENE_SPP", spp))
+        lf.set_params(scene_spp, 25.0, 1.0)
+        if not os.environ.get("LF_BENCH_PINHOLE_SCENE"):
+            lf.set_lens_camera(1, 0.001, 0.0)
     else:
         lf.set_camera(np.eye(3), [0, 0, 0], hf, vf)
         ex, ey = math.tan(math.radians(hf) / 2), math.tan(math.radians(vf) / 2)
@@ -441,6 +456,7 @@ def main():
         one_frame()
     barrier()
     lf.reset_counters()
+    lf.reset_scene_counters()
     lf.timing_reset()
     lf.timing_enable(True)
     host_exchange[0] = 0.0
@@ -472,6 +488,8 @@ def main():
     n_launch, march_ms = lf.timing_get("march")
     n_xchg, xchg_ms = lf.timing_get("exchange") if gather_mode == "cabi" else (args.steps, host_exchange[0] * 1e3)
     n_scene, scene_ms = lf.timing_get("scene_term")
+    scene_cnt = lf.scene_counters() if cfg["scene"] else None
+    lens_cam = lf.lens_camera() if cfg["scene"] else None
     rccl_nranks, rccl_rank = lf.comm_info()
     fate_keys = ("rays_launched", "rays_clipped_stop", "rays_vignetted", "rays_tir", "rays_reached_scene", "rays_hit_light")
     ev = torch.tensor([float(cnt["surface_events"]), float(cnt["rays_launched"]), float(stats["executed_events"]),
@@ -613,6 +631,17 @@ def main():
                                       "(overlapped with the next frame's march)" if gather_mode == "cabi" else
                                       "host clock around the exchange incl. its synchronisation" if world > 1 else "no exchange")},
             "per_rank": per_rank,
+            # ---- the scene term (configs with a scene): the sample loop of raytrace_pixel on the device -----
+            # lens_camera.mode != 0: every sample's primary path is marched through the prescription and the
+            # scene's radiance comes back along the exit ray (lf_set_lens_camera); counters over the timed
+            # frames: rays handed to the BVH (camera + shadow), primitive tests, lens samples / that left the lens
+            "scene_term": None if not cfg["scene"] else {
+                "ms_per_frame": max(r["scene_ms"] for r in per_rank),
+                "march_ms_per_frame": max(r["march_ms"] for r in per_rank),
+                "samples_per_pixel": int(os.environ.get("LF_BENCH_SCENE_SPP", spp)),
+                "lens_camera": lens_cam,
+                "counters_rank0": {k: v / args.steps for k, v in scene_cnt.items()},
+                "bvh_rays_per_s_rank0": (scene_cnt["rays"] / args.steps) / (mine["scene_ms"] * 1e-3) if mine["scene_ms"] > 0 else None},
             "roofline": roof,
             "cpu_baseline": cpu,
             "reference_flare_path": ref_path,

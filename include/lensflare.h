@@ -448,7 +448,10 @@ lf_status lf_generate_lens_rays(lf_ctx* ctx, int lambda, size_t n, const float* 
  * at -z; lens millimetres times world_per_mm; the centre of the paraxial entrance pupil sits at the
  * camera position) and weights the radiance it finds by exposure x transmitted weight.  A sample the
  * lens blocks contributes 0 and still counts in the mean (the division by the loop variable,
- * pathtracer.cpp:875, is unchanged).
+ * pathtracer.cpp:875, is unchanged).  The loop visits the march's samples 0 .. ns_aa-1 in a scattered
+ * order (iteration i takes sample (i * step) mod ns_aa, step = the integer nearest ns_aa / 1.618 that is
+ * coprime to ns_aa) so that the reference's adaptive early-out (:862-868) stops on a prefix that covers
+ * the pupil, not on its rim.
  *   mode 0  off: the reference's pinhole camera (default)
  *   mode 1  one ray per sample at the reference wavelength (index n_lambda / 2) carries R, G and B
  *   mode 2  one ray per wavelength; channel c collects lambda_rgb[l][c] of wavelength l's radiance

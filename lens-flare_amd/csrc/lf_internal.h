@@ -218,6 +218,7 @@ struct LfPrimaryDev {
 struct LfLensCamArgs {
   int mode;              // 1 = one reference wavelength carries R, G and B; 2 = one ray per wavelength
   int lambda_ref, n_lambda;
+  int order_step;        // iteration i of the sample loop takes the march's sample (i * order_step) mod ns_aa
   int W, G;              // sample_start's SampleSpec (the march's sampling specification)
   float inv_G;
   int sub_bits;

@@ -70,6 +70,18 @@ void lf_fill_lenscam_args(const lf_ctx* ctx, LfLensCamArgs* a) {
   while ((G + 1) * (G + 1) <= spp) G++;
   while (G * G > spp) G--;
   a->G = G; a->inv_G = 1.0f / (float)G;
+  // The march's sample s aims at pupil cell s (row-major over the G x G strata): fine for a loop that
+  // always runs to its end, but the sample loop of raytrace_pixel may stop early (the adaptive test every
+  // samplesPerBatch samples, pathtracer.cpp:862-868), and the first rows of cells are the pupil's rim.
+  // So the loop visits the SAME samples in a scattered order -- i -> (i * step) mod ns_aa, step the
+  // integer nearest to ns_aa / golden ratio that is coprime to ns_aa (a bijection) -- whose every prefix
+  // is spread over the pupil.  Run to its end the loop has marched exactly the march's samples.
+  {
+    auto gcd = [](int x, int y) { while (y) { const int t = x % y; x = y; y = t; } return x; };
+    int step = std::max(1, (int)std::lround(0.6180339887498949 * (double)spp));
+    while (gcd(step, spp) != 1) step++;
+    a->order_step = step % spp == 0 ? 1 : step;
+  }
   a->sub_bits = ctx->march_sub_bits;
   a->inv_sub = 1.0f / (float)(1 << ctx->march_sub_bits);
   a->pitch = ctx->sensor_w_mm / (float)std::max(1, ctx->W);

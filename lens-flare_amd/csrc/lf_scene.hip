@@ -470,7 +470,9 @@ __device__ __forceinline__ void scene_pixel(const LfSceneDev& sc, const LfEnvDev
       spec.W = W; spec.G = lc.G; spec.inv_G = lc.inv_G; spec.sub_bits = lc.sub_bits; spec.inv_sub = lc.inv_sub;
       spec.key = key2; spec.pitch = lc.pitch; spec.half_w = lc.half_w; spec.half_h = lc.half_h;
       spec.pupil_h = lc.pupil_h; spec.vz = lc.vz; spec.geom_norm = lc.geom_norm;
-      const lfm::StartRay st = lfm::sample_start(spec, x, y, sample - 1);
+      // (the march's samples in an order whose prefixes cover the pupil: lf_fill_lenscam_args)
+      const int s_idx = (int)(((long long)(sample - 1) * (long long)lc.order_step) % (long long)ns_aa);
+      const lfm::StartRay st = lfm::sample_start(spec, x, y, s_idx);
       L = v3(0, 0, 0);
       const int n_rays = lc.mode == 2 ? lc.n_lambda : 1;
       for (int li = 0; li < n_rays; li++) {
