@@ -435,6 +435,15 @@ lf_status lf_trace_ghosts(lf_ctx* ctx, int spp, uint64_t key);
  * alive (1/0)} in lens space (optical axis = z, light travels +z, the scene lies at z < 0). */
 lf_status lf_generate_lens_rays(lf_ctx* ctx, int lambda, size_t n, const float* sensor_xy_mm,
                                 const float* pupil_uv, float* out);
+/* How the flare layer evaluates the two powers of the reference's starburst / falloff code --
+ * `radiance / pow(r, 1.5)` (calculate_irradiance_falloff, pathtracer.cpp:1056) and `pow(factor, 8.0)`
+ * (raytrace_starburst, :982):
+ *   1  exact: the double-precision pow the reference calls (the device's libm, <= 1 ulp like glibc's)
+ *   2  fast:  rsqrt(r^3) and three squarings (~3 and ~4 ulp from exact; 0.34 -> 0.15 ms per 1080p frame)
+ *   0  auto (default): exact in MT19937 parity mode -- the mode that exists to reproduce the reference's
+ *      frames, where agreement must hold by construction -- fast with the counter RNG
+ * Either way the result is far inside the north star's 1e-4 (and the parity tests' 1e-9). */
+lf_status lf_set_flare_arithmetic(lf_ctx* ctx, int mode);
 /* ---- the lens camera of the scene term (round 4) -----------------------------------------------
  * replaces: the call `camera->generate_ray(x, y)` in the sample loop of PathTracer::raytrace_pixel
  * (src/pathtracer/pathtracer.cpp:841-850) -- a pinhole in the reference (camera.cpp:278-305; its

@@ -40,7 +40,7 @@ ABI_SYMBOLS = [
     "lf_load_lens_file", "lf_get_lens_info",
     "lf_set_pupil_target", "lf_get_pupil_target", "lf_aim_at_exit_pupil", "lf_paraxial_exit_pupil", "lf_set_ghost_accumulate",
     "lf_set_lens_camera", "lf_get_lens_camera", "lf_paraxial_entrance_pupil", "lf_focus_lens",
-    "lf_get_scene_counters", "lf_reset_scene_counters",
+    "lf_get_scene_counters", "lf_reset_scene_counters", "lf_set_flare_arithmetic",
     "lf_comm_get_unique_id", "lf_comm_init_rank", "lf_comm_gather", "lf_comm_gather_async", "lf_comm_wait",
     "lf_comm_destroy", "lf_comm_available", "lf_comm_info", "lf_comm_test", "lf_comm_abort",
     "lf_comm_set_exchange_precision",
@@ -663,6 +663,10 @@ class LensFlare:
     def aim_at_exit_pupil(self, margin=1.0):
         self._ck(self.lib.lf_aim_at_exit_pupil(self.ctx, C.c_float(margin)))
         return self.pupil_target()
+
+    def set_flare_arithmetic(self, mode=0):
+        """0 auto (exact pow in MT19937 parity mode, fast forms with the counter RNG), 1 exact, 2 fast."""
+        self._ck(self.lib.lf_set_flare_arithmetic(self.ctx, int(mode)))
 
     def set_lens_camera(self, mode=1, world_per_mm=0.001, exposure=0.0):
         """The scene term's sample loop images the scene through the prescription (0 = pinhole)."""

@@ -325,6 +325,12 @@ lf_status lf_set_params(lf_ctx* ctx, int ns_aa, double flare_radius, double flar
   return LF_OK;
 }
 
+lf_status lf_set_flare_arithmetic(lf_ctx* ctx, int mode) {
+  if (!ctx || mode < 0 || mode > 2) return LF_ERR_INVALID;
+  ctx->flare_arithmetic = mode;
+  return LF_OK;
+}
+
 lf_status lf_set_aperture(lf_ctx* ctx, lf_aperture_slot slot, const float* texels, int width,
                           int height) {
   if (!ctx || !texels || (slot != LF_APERTURE_STARBURST && slot != LF_APERTURE_GHOST))
@@ -683,6 +689,9 @@ lf_status lf_set_lens(lf_ctx* ctx, int n_surfaces, int stop_index, int n_lambda,
       if ((!(ior[l * n_surfaces + k] >= 1.0f) || !std::isfinite(ior[l * n_surfaces + k])) && k != stop_index)
         return lf_fail(ctx, LF_ERR_INVALID, "lens: index of refraction < 1 or not finite");
   }
+  // a pupil target belongs to the prescription it was computed for (lf_aim_at_exit_pupil): a new lens
+  // starts from the default disc, the rear element's clear aperture
+  ctx->pupil_target_h = 0.0f; ctx->pupil_target_z = 0.0f;
   lf_derive_lens(ctx, n_surfaces, stop_index, n_lambda, radius, thickness, ior, semi_aperture,
                  sensor_width_mm);
   ctx->raw_n = n_surfaces; ctx->raw_stop = stop_index;
@@ -818,6 +827,16 @@ lf_status lf_trace_ghosts(lf_ctx* ctx, int spp, uint64_t key) {
     return lf_fail(ctx, LF_ERR_STATE, "lf_trace_ghosts needs lf_set_lens and lf_set_sun");
   if (!ctx->ap[LF_APERTURE_STARBURST].valid)
     return lf_fail(ctx, LF_ERR_STATE, "aperture mask (LF_APERTURE_STARBURST slot) not set");
+  if (ctx->pupil_target_h > 0.0f && ctx->lens.stop >= 0) {
+    // a reduced disc (the stop's image) is an unbiased estimator only for paths that cross the stop before
+    // their first reflection; a pair with both mirrors behind the stop reaches the sensor through parts of
+    // the rear element the disc does not cover
+    for (int q = 0; q < ctx->pairs.n; q++)
+      if (ctx->pairs.ij[q][0] > ctx->lens.stop)
+        return lf_fail(ctx, LF_ERR_STATE,
+                       "a pupil target is set and the pair selection holds a pair with both mirrors behind the stop: "
+                       "such pairs need the default disc (march them in a second launch, lf_set_ghost_accumulate)");
+  }
   LF_HIP(ctx, hipSetDevice(ctx->device));
   lf_status st = lfk_march(ctx, spp, key);
   if (st != LF_OK) return st;

@@ -473,6 +473,10 @@ __device__ inline double convert_coordinate(int p, int length, bool y) {
 
 // calculate_irradiance_falloff(x, y, radius) :1043-1063; the 32 draws of pixel p come from the MT19937
 // table in the reference's visit order (jitter_mode 0) or from the counter RNG
+// EXACT: the reference's own calls -- 1 / pow(r, 1.5) and (raytrace_starburst) pow(factor, 8.0) through the
+// double-precision pow -- instead of the cheaper forms below: what MT19937 parity mode runs, so that
+// agreement with the reference's frames holds by construction and not by rounding luck (lf_set_flare_arithmetic).
+template <bool EXACT>
 __device__ inline void irradiance_falloff(const LfFlares* __restrict__ fl, int n_flares, int x, int y,
                                           size_t p, double radius, double dW, double dH,
                                           const uint32_t* __restrict__ jitter_raw, int jitter_mode,
@@ -504,7 +508,7 @@ __device__ inline void irradiance_falloff(const LfFlares* __restrict__ fl, int n
       // ~3 ulp from the exact value (glibc's pow, which the reference calls, is within 1) at a tenth of
       // the instructions of a general double-precision pow followed by a division -- 16 x n_flares of
       // them per pixel made this kernel compute-bound
-      double rc = rsqrt((r * r) * r);
+      double rc = EXACT ? 1.0 / pow(r, 1.5) : rsqrt((r * r) * r);
       t[0] += rc * fl->radiance[l][0];
       t[1] += rc * fl->radiance[l][1];
       t[2] += rc * fl->radiance[l][2];
@@ -515,14 +519,16 @@ __device__ inline void irradiance_falloff(const LfFlares* __restrict__ fl, int n
 }
 
 // PathTracer::calculate_irradiance_falloff(x, y, radius) on its own
+template <bool EXACT>
 __global__ void k_one_falloff(const LfFlares* __restrict__ fl, int x, int y, double radius, int W, int H,
                               const uint32_t* __restrict__ jitter_raw, int jitter_mode, uint64_t key,
                               double* __restrict__ out) {
   if (threadIdx.x != 0) return;
-  irradiance_falloff(fl, fl->n_flares, x, y, (size_t)x + (size_t)y * W, radius, (double)W, (double)H,
-                     jitter_raw, jitter_mode, key, out);
+  irradiance_falloff<EXACT>(fl, fl->n_flares, x, y, (size_t)x + (size_t)y * W, radius, (double)W, (double)H,
+                            jitter_raw, jitter_mode, key, out);
 }
 
+template <bool EXACT>
 __global__ __launch_bounds__(256) void k_flare_layer(
     const LfFlares* __restrict__ fl, const lf_aperture_stats* __restrict__ st,
     const double* __restrict__ S, const double* __restrict__ ghost,
@@ -562,7 +568,7 @@ __global__ __launch_bounds__(256) void k_flare_layer(
         // pow(factor, 8.0) by three squarings: within 4 ulp of the exact power (the general pow is the
         // most expensive thing this pixel would otherwise do, and nearly every pixel lies out here)
         const double f2 = factor * factor, f4 = f2 * f2;
-        I = (f4 * f4) * I;
+        I = (EXACT ? pow(factor, 8.0) : f4 * f4) * I;
       } else if (d <= flare_radius) {  // flare amplification :986-992
         I = pow(I, d / flare_radius);
       }
@@ -587,7 +593,7 @@ __global__ __launch_bounds__(256) void k_flare_layer(
         double I = (1.0 - tb) * ((1.0 - ta) * s00 + ta * s01) + tb * ((1.0 - ta) * s10 + ta * s11);
         if (d > daw / 2.0) {
           const double factor = (daw / 2.0) / d, f2 = factor * factor, f4 = f2 * f2;
-          I = (f4 * f4) * I;
+          I = (EXACT ? pow(factor, 8.0) : f4 * f4) * I;
         } else if (d <= flare_radius) {
           I = pow(I, d / flare_radius);
         }
@@ -598,7 +604,7 @@ __global__ __launch_bounds__(256) void k_flare_layer(
     }
     // ---- calculate_irradiance_falloff(x, y, 5.0) :1002 -------------------------------------
     double t[3];
-    irradiance_falloff(fl, n_flares, x, y, p, 5.0, dW, dH, jitter_raw, jitter_mode, key, t);
+    irradiance_falloff<EXACT>(fl, n_flares, x, y, p, 5.0, dW, dH, jitter_raw, jitter_mode, key, t);
     star[0] += t[0]; star[1] += t[1]; star[2] += t[2];  // :1004
   }
   // ---- raytrace_pixel :875-891 ---------------------------------------------------------------
@@ -792,8 +798,12 @@ lf_status lfk_compute_phase(lf_ctx* ctx, int flare, double u, double v, double o
 
 lf_status lfk_irradiance_falloff(lf_ctx* ctx, int x, int y, double radius, double out[3]) {
   return probe_doubles(ctx, 3, out, [&](double* d) {
-    hipLaunchKernelGGL(k_one_falloff, dim3(1), dim3(64), 0, ctx->stream, ctx->flares, x, y, radius, ctx->W,
-                       ctx->H, ctx->jitter_raw, ctx->jitter_mode, ctx->jitter_key, d);
+    if (lf_flare_exact(ctx))
+      hipLaunchKernelGGL(k_one_falloff<true>, dim3(1), dim3(64), 0, ctx->stream, ctx->flares, x, y, radius, ctx->W,
+                         ctx->H, ctx->jitter_raw, ctx->jitter_mode, ctx->jitter_key, d);
+    else
+      hipLaunchKernelGGL(k_one_falloff<false>, dim3(1), dim3(64), 0, ctx->stream, ctx->flares, x, y, radius, ctx->W,
+                         ctx->H, ctx->jitter_raw, ctx->jitter_mode, ctx->jitter_key, d);
   });
 }
 
@@ -801,11 +811,14 @@ lf_status lfk_flare_layer(lf_ctx* ctx) {
   size_t n = (size_t)(ctx->y1 - ctx->y0) * ctx->W;
   if (n == 0) return LF_OK;  // empty band: nothing to render (a 0-block launch is an error)
   hipEvent_t ev = lf_timing_begin(ctx, LFK_FLARE_LAYER);
-  hipLaunchKernelGGL(k_flare_layer, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream,
-                     ctx->flares, ctx->ap[LF_APERTURE_STARBURST].stats, ctx->spectrum, ctx->ghost,
-                     ctx->scene, ctx->jitter_raw, ctx->jitter_mode, ctx->jitter_key, ctx->W, ctx->H,
-                     ctx->y0, ctx->y1, ctx->row_phase, ctx->row_period, ctx->ns_aa, ctx->flare_radius,
-                     ctx->flare_intensity, ctx->star_spec, ctx->sample, ctx->star);
+#define LF_LAUNCH_FLARE(EXACT)                                                                      \
+  hipLaunchKernelGGL(k_flare_layer<EXACT>, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream, \
+                     ctx->flares, ctx->ap[LF_APERTURE_STARBURST].stats, ctx->spectrum, ctx->ghost,     \
+                     ctx->scene, ctx->jitter_raw, ctx->jitter_mode, ctx->jitter_key, ctx->W, ctx->H,   \
+                     ctx->y0, ctx->y1, ctx->row_phase, ctx->row_period, ctx->ns_aa, ctx->flare_radius, \
+                     ctx->flare_intensity, ctx->star_spec, ctx->sample, ctx->star)
+  if (lf_flare_exact(ctx)) LF_LAUNCH_FLARE(true); else LF_LAUNCH_FLARE(false);
+#undef LF_LAUNCH_FLARE
   lf_timing_end(ctx, LFK_FLARE_LAYER, ev);
   LF_HIP(ctx, hipGetLastError());
   return LF_OK;

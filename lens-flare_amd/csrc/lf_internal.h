@@ -256,6 +256,7 @@ struct lf_ctx {
   int row_period = 1, row_phase = 0;   // tile rows t (8 sensor rows) with t % period == phase
   int ns_aa = 1;
   double flare_radius = 25.0, flare_intensity = 1.0;
+  int flare_arithmetic = 0;   // lf_set_flare_arithmetic: 0 auto (exact pow in MT19937 parity mode), 1 exact, 2 fast
 
   LfApertureDev ap[2];
   // starburst spectrum |DFT2(aperture)| / total_value, aw*aw doubles; twiddles; row pass scratch
@@ -367,6 +368,10 @@ void lf_timing_end(lf_ctx* ctx, int kernel, hipEvent_t start, hipStream_t stream
       return lf_fail(ctx, LF_ERR_HIP, std::string(#expr) + ": " + hipGetErrorString(e_));     \
   } while (0)
 
+// the flare layer calls the reference's own pow() (exact) or its cheaper equivalents (fast): DESIGN.md section 3
+inline bool lf_flare_exact(const lf_ctx* ctx) {
+  return ctx->flare_arithmetic == 1 || (ctx->flare_arithmetic == 0 && ctx->jitter_mode == 0);
+}
 // kernels launchers (lf_flare_kernels.hip)
 lf_status lfk_aperture_stats(lf_ctx* ctx, int slot);
 lf_status lfk_build_spectrum(lf_ctx* ctx);

@@ -655,8 +655,12 @@ void set_prim_box(HostPrim& p) {
 }
 
 // returns the node id; *depth = levels below (and including) this node
+// (levels_left: how many more levels the SAH may still use below this node; at 0 the subtree is built by
+// median splits, whose depth is logarithmic -- a degenerate scene, e.g. geometrically spaced centroids that
+// leave all but one primitive in one bin at every level, cannot drive the recursion O(n) deep)
 int build_node(std::vector<HostNode>& nodes, std::vector<HostPrim>& prims, int first, int count, bool sah,
-               int leaf_max, int* depth) {
+               int leaf_max, int* depth, int levels_left = 1 << 30) {
+  if (levels_left <= 0) sah = false;
   HostNode nd;
   nd.box = empty_box();
   double cmn[3] = {INFINITY, INFINITY, INFINITY}, cmx[3] = {-INFINITY, -INFINITY, -INFINITY};
@@ -713,8 +717,8 @@ int build_node(std::vector<HostNode>& nodes, std::vector<HostPrim>& prims, int f
                      [axis](const HostPrim& a, const HostPrim& b) { return a.cen[axis] < b.cen[axis]; });
   }
   int dl = 0, dr = 0;
-  const int l = build_node(nodes, prims, first, mid - first, sah, leaf_max, &dl);
-  const int r = build_node(nodes, prims, mid, first + count - mid, sah, leaf_max, &dr);
+  const int l = build_node(nodes, prims, first, mid - first, sah, leaf_max, &dl, levels_left - 1);
+  const int r = build_node(nodes, prims, mid, first + count - mid, sah, leaf_max, &dr, levels_left - 1);
   nodes[id].left = l; nodes[id].right = r;
   *depth = 1 + std::max(dl, dr);
   return id;
@@ -826,7 +830,11 @@ lf_status lf_set_scene(lf_ctx* ctx, int n_spheres, const double* spheres, const 
     bool sah = !(how && std::strcmp(how, "median") == 0);
     const char* lm = std::getenv("LF_BVH_LEAF");
     const int leaf_max = lm ? std::min(4, std::max(1, std::atoi(lm))) : 2;
-    build_node(hnodes, prims, 0, (int)prims.size(), sah, leaf_max, &depth);
+    // the SAH may use 64 levels (a well-behaved scene needs ~log2(n) + a few); below them a subtree is
+    // built by median splits: the host recursion is bounded by 64 + log2(n) frames whatever the scene, and a
+    // tree that ends up deeper than the device's stack is rebuilt by median splits alone (below)
+    const int sah_levels = 64;
+    build_node(hnodes, prims, 0, (int)prims.size(), sah, leaf_max, &depth, sah_levels);
     if (sah && depth - 1 > kStackDepth) {
       hnodes.clear();
       build_node(hnodes, prims, 0, (int)prims.size(), false, leaf_max, &depth);
@@ -861,21 +869,30 @@ lf_status lf_set_scene(lf_ctx* ctx, int n_spheres, const double* spheres, const 
       }
     dprims[i].type = prims[i].type; dprims[i].material = prims[i].material;
   }
-  LfSceneDev& S = ctx->scene_dev;
-  LF_HIP(ctx, hipStreamSynchronize(ctx->stream));
-  void* old[] = {S.nodes, S.prims, S.normals, S.materials, S.lights};
-  for (void* o : old) if (o) (void)hipFree(o);
-  std::memset(&S, 0, sizeof(S));
+  // upload into a fresh set of buffers and swap only when every one of them arrived: a failure half way
+  // leaves the previous scene in place and valid, never a descriptor with null tables
+  LfSceneDev N;
+  std::memset(&N, 0, sizeof(N));
   auto up = [&](void** dst, const void* src, size_t bytes) -> hipError_t {
     hipError_t e = hipMalloc(dst, std::max<size_t>(bytes, 64));
     if (e == hipSuccess && bytes) e = hipMemcpy(*dst, src, bytes, hipMemcpyHostToDevice);
     return e;
   };
-  LF_HIP(ctx, up((void**)&S.nodes, nodes.data(), nodes.size() * sizeof(LfBvhNode)));
-  LF_HIP(ctx, up((void**)&S.prims, dprims.data(), dprims.size() * sizeof(LfPrim)));
-  LF_HIP(ctx, up((void**)&S.normals, dnormals.data(), dnormals.size() * sizeof(LfPrimNormals)));
-  LF_HIP(ctx, up((void**)&S.materials, mats.data(), mats.size() * sizeof(LfMaterial)));
-  LF_HIP(ctx, up((void**)&S.lights, lts.data(), lts.size() * sizeof(LfLight)));
+  hipError_t e = up((void**)&N.nodes, nodes.data(), nodes.size() * sizeof(LfBvhNode));
+  if (e == hipSuccess) e = up((void**)&N.prims, dprims.data(), dprims.size() * sizeof(LfPrim));
+  if (e == hipSuccess) e = up((void**)&N.normals, dnormals.data(), dnormals.size() * sizeof(LfPrimNormals));
+  if (e == hipSuccess) e = up((void**)&N.materials, mats.data(), mats.size() * sizeof(LfMaterial));
+  if (e == hipSuccess) e = up((void**)&N.lights, lts.data(), lts.size() * sizeof(LfLight));
+  if (e != hipSuccess) {
+    void* fresh[] = {N.nodes, N.prims, N.normals, N.materials, N.lights};
+    for (void* o : fresh) if (o) (void)hipFree(o);
+    return lf_fail(ctx, LF_ERR_HIP, std::string("lf_set_scene: upload failed (the previous scene stays): ") + hipGetErrorString(e));
+  }
+  LfSceneDev& S = ctx->scene_dev;
+  LF_HIP(ctx, hipStreamSynchronize(ctx->stream));   // kernels in flight may still walk the old tables
+  void* old[] = {S.nodes, S.prims, S.normals, S.materials, S.lights};
+  for (void* o : old) if (o) (void)hipFree(o);
+  S = N;
   for (int a = 0; a < 3; a++) { ctx->scene_bmin[a] = root.mn[a]; ctx->scene_bmax[a] = root.mx[a]; }
   S.n_nodes = (int)nodes.size(); S.n_prims = (int)prims.size();
   S.n_materials = n_materials; S.n_lights = n_lights; S.n_soft_lights = 0;

@@ -269,6 +269,20 @@ int g64_trace_ray(const g64_lens* L, int lam, int i, int j, double p[3], double 
   return r.dead;
 }
 
+/* ... the same with the tracer's own verdict on how close the ray came to a decision boundary:
+ * out = {fragile (0 / 1 / 2), potential weight} */
+int g64_trace_ray_ex(const g64_lens* L, int lam, int i, int j, double p[3], double d[3], double* w,
+                     const float* mask, int mw, int mh, int* n_events, double out[2]) {
+  g64_system S;
+  lay_out(L, &S);
+  g64_ray r = {V(p[0], p[1], p[2]), V(d[0], d[1], d[2]), *w, *w, 0, 0};
+  const int ev = follow(L, &S, lam, i, j, mask, mw, mh, &r);
+  p[0] = r.o.x; p[1] = r.o.y; p[2] = r.o.z; d[0] = r.d.x; d[1] = r.d.y; d[2] = r.d.z; *w = r.w;
+  if (n_events) *n_events = ev;
+  out[0] = (double)r.fragile; out[1] = r.w_pot;
+  return r.dead;
+}
+
 double g64_sensor_z(const g64_lens* L) {
   g64_system S;
   lay_out(L, &S);
@@ -281,6 +295,10 @@ static double unit_interval(uint32_t bits) { return (double)(bits >> 8) / 167772
  * h <= 0 = the rear element's clear aperture at its vertex plane */
 static double g64_pupil_h = 0.0, g64_pupil_z = 0.0;
 void g64_set_pupil_target(double h, double z) { g64_pupil_h = h; g64_pupil_z = z; }
+/* g64_trace only traces the pixels with x in [x0, x1) (the others stay 0 and launch nothing): a window of
+ * a wide band keeps a full-sample-count check inside a test's time budget.  Default: every column. */
+static int g64_x0 = 0, g64_x1 = 1 << 30;
+void g64_set_x_window(int x0, int x1) { g64_x0 = x0; g64_x1 = x1; }
 
 /* The estimator's sample: sensor point and rear-pupil point of sample s of
  * pixel (x, y).  Returns the start direction and the start weight. */
@@ -342,6 +360,7 @@ void g64_trace(const g64_lens* L, int W, int H, int y0, int y1, int spp, const u
 #pragma omp for schedule(dynamic, 16)
     for (long long p = (long long)y0 * W; p < (long long)y1 * W; p++) {
       const int x = (int)(p % W), y = (int)(p / W);
+      if (x < g64_x0 || x >= g64_x1) continue;
       double sum[3] = {0, 0, 0}, fsum[3] = {0, 0, 0};
       for (int s = 0; s < spp; s++) {
         vec o, d;

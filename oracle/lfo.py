@@ -489,6 +489,28 @@ def g64_trace_ray(lens, lam, i, j, p, d, w=1.0, mask=None):
     return st, np.array(pp[:]), np.array(dd[:]), ww.value, ne.value
 
 
+def g64_trace_ray_ex(lens, lam, i, j, p, d, w=1.0, mask=None, **eps):
+    """-> (dead, exit point, exit direction, weight, events, fragile, potential weight)"""
+    L = g64_lens(lens, **eps)
+    if mask is None:
+        mask = np.ones((4, 4), np.float32)
+    mask = np.ascontiguousarray(mask, np.float32)
+    pp = (C.c_double * 3)(*[float(v) for v in p])
+    dd = (C.c_double * 3)(*[float(v) for v in d])
+    ww = C.c_double(w)
+    ne = C.c_int()
+    out = (C.c_double * 2)()
+    lib().g64_trace_ray_ex.restype = C.c_int
+    st = lib().g64_trace_ray_ex(C.byref(L), int(lam), int(i), int(j), pp, dd, C.byref(ww), _p(mask, C.c_float),
+                                mask.shape[1], mask.shape[0], C.byref(ne), out)
+    return st, np.array(pp[:]), np.array(dd[:]), ww.value, ne.value, int(out[0]), out[1]
+
+
+def g64_set_x_window(x0=0, x1=1 << 30):
+    """g64_trace only traces columns [x0, x1) (default: all)."""
+    lib().g64_set_x_window(int(x0), int(x1))
+
+
 def g64_sensor_z(lens):
     lib().g64_sensor_z.restype = C.c_double
     return lib().g64_sensor_z(C.byref(g64_lens(lens)))

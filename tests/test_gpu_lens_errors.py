@@ -87,3 +87,72 @@ def test_lens_file_parser_refuses_malformed_files(pkg, tmp_path, text):
         assert lf.lens_info()["n"] >= 1
     finally:
         lf.close()
+
+
+def test_a_new_lens_drops_the_pupil_target_and_reduced_discs_refuse_rear_pairs(pkg):
+    """a pupil target is a property of the prescription it was computed for.
+    lf_set_lens / lf_load_lens_file start from the default disc again; and a reduced disc with a pair whose
+    mirrors both sit behind the stop is refused instead of rendered biased."""
+    from goldenlib import load_texels
+    lf = pkg.LensFlare(0)
+    try:
+        lens = pkg.load_lens_file("dgauss11.lens")
+        lf.set_frame(32, 16)
+        lf.set_aperture(pkg.APERTURE_STARBURST, load_texels("pentbig500_14.png"))
+        lf.set_lens(lens)
+        default = lf.pupil_target()
+        aimed = lf.aim_at_exit_pupil(1.2)
+        assert aimed["radius_mm"] != default["radius_mm"] and aimed["z_mm"] != default["z_mm"]
+        lf.set_sun([0.03, 0.02, -1.0], [1.0, 0.9, 0.5], 0.05)
+        # the default pair set holds the 10 pairs behind the stop: refused under a reduced disc
+        with pytest.raises(pkg.LensFlareError, match="behind the stop"):
+            lf.trace_ghosts(4, 1)
+        stop = lens["stop"]
+        front = [(i, j) for i in range(lens["n"]) for j in range(i + 1, lens["n"]) if i != stop and j != stop and i < stop]
+        lf.set_ghost_pairs(front, True)
+        lf.trace_ghosts(4, 1)                          # pairs with a mirror in front of the stop: fine
+        # another prescription: the disc of the old one is gone
+        thin = pkg.load_lens_file("thinlens.lens")
+        lf.set_lens(thin)
+        t = lf.pupil_target()
+        assert t["radius_mm"] == float(thin["semi_aperture"][-1])
+        assert abs(t["z_mm"] - float(thin["thickness"][0])) < 1e-6
+        lf.set_lens(lens)
+        assert lf.pupil_target() == default
+        lf.trace_ghosts(4, 1)                          # default disc + default pairs
+    finally:
+        lf.close()
+
+
+def test_flare_arithmetic_modes_agree_to_a_few_ulp(pkg):
+    """the flare layer keeps the reference's own pow() calls selectable (and uses them in
+    MT19937 parity mode); the fast forms differ from them by a few ulp, stated in include/lensflare.h."""
+    from goldenlib import Case, load_texels
+    case = Case("f64x48_pentbiglines")
+    m = case.meta
+    lf = pkg.LensFlare(0)
+    try:
+        lf.set_frame(case.W, case.H)
+        lf.set_params(m["ns_aa"], m["flare_radius"], m["flare_intensity"])
+        lf.set_aperture(pkg.APERTURE_STARBURST, load_texels(m["aperture"]))
+        lf.set_aperture(pkg.APERTURE_GHOST, load_texels(m["ghost_aperture"]))
+        lf.set_camera(m["c2w"], m["cam_pos"], m["hFov"], m["vFov"])
+        lf.find_sun_pos(m["lights"])
+        lf.generate_ghost_buffer()
+        lf.set_jitter_counter(5)
+        frames = {}
+        for mode in (1, 2, 0):
+            lf.set_flare_arithmetic(mode)
+            lf.render_flare_layer()
+            frames[mode] = lf.read_buffer(pkg.STARBURST_BUFFER)
+        assert np.array_equal(frames[0], frames[2])                 # counter RNG: auto = fast
+        rel = np.abs(frames[1] - frames[2]) / np.abs(frames[1])
+        assert 0 < rel.max() < 4e-15                                # a few ulp, not more -- and not identical
+        lf.set_jitter_mt19937(5489, None)
+        lf.render_flare_layer()
+        auto_mt = lf.read_buffer(pkg.STARBURST_BUFFER)
+        lf.set_flare_arithmetic(1)
+        lf.render_flare_layer()
+        assert np.array_equal(auto_mt, lf.read_buffer(pkg.STARBURST_BUFFER))   # parity mode: auto = exact
+    finally:
+        lf.close()

@@ -55,6 +55,23 @@ def _check_against_f64(img, cnt, ref, frag, c64, min_lit, median_bar=2e-6):
     rel = np.abs(img - ref)[lit] / ref[lit]
     # the bar, with the fragile rays' weight as the only allowance
     assert np.all(np.abs(img - ref)[lit] <= TOL * ref[lit] + 1.05 * frag[lit]), rel.max()
+    # How much of the allowance is actually consumed: for every lit value EITHER the raw deviation is within
+    # 1e-4 OR it is within the summed potential weight of that pixel's fragile rays (frag; the 5 % on top
+    # covers the float32 rounding of those weights themselves).  The histogram of deviation / frag over the
+    # values that need the allowance goes to the test's output.
+    dev = np.abs(img - ref)[lit]
+    over = dev > TOL * ref[lit]
+    if over.any():
+        f = frag[lit][over]
+        assert np.all(f > 0), "a value outside 1e-4 whose pixel has no fragile ray at all"
+        ratio = dev[over] / f
+        assert ratio.max() <= 1.05, ratio.max()
+        hist, _ = np.histogram(ratio, bins=[0, 0.25, 0.5, 0.75, 1.0, 1.05])
+        print(f"  allowance: {int(over.sum())} of {int(lit.sum())} lit values are outside 1e-4; deviation / (summed weight "
+              f"of the pixel's fragile rays) in [0,.25) [.25,.5) [.5,.75) [.75,1) [1,1.05]: {hist.tolist()}, max {ratio.max():.3f}; "
+              f"largest raw deviation {rel.max():.2e}")
+    else:
+        print(f"  allowance: none of {int(lit.sum())} lit values needs it (largest raw deviation {rel.max():.2e})")
     # ... and that allowance is the exception, not the rule
     if rel.size:
         assert (rel <= TOL).mean() >= 0.98, (rel <= TOL).mean()
@@ -160,7 +177,13 @@ def test_pupil_subcells_converge_to_the_independent_estimate(pkg, lf):
 SUN_NS = (0.521445, 0.517156)
 
 
-def _band_against_f64(pkg, lf, lens, W, H, y0, y1, spp, key, mask, lambda_rgb=None, min_lit=200, median_bar=2e-6):
+def _host_threads():
+    import os
+    return int(os.environ.get("LF_LONG_THREADS", os.cpu_count() or 8))
+
+
+def _band_against_f64(pkg, lf, lens, W, H, y0, y1, spp, key, mask, lambda_rgb=None, min_lit=200, median_bar=2e-6,
+                      x_window=None):
     import os
     efl = pkg.paraxial_efl(lens)
     sun = [(SUN_NS[0] - 0.5) * lens["sensor_width_mm"] / efl, (SUN_NS[1] - 0.5) * lens["sensor_width_mm"] * H / W / efl, -1.0]
@@ -178,10 +201,34 @@ def _band_against_f64(pkg, lf, lens, W, H, y0, y1, spp, key, mask, lambda_rgb=No
     img = lf.read_tile(pkg.GHOST_BUFFER, 0, y0, W, y1)
     cnt = lf.counters()
     lf.set_band(0, H)
-    ref, frag, c64 = lfo.g64_trace(lens, W, H, y0, y1, spp, key, None, True, mask, sun, rad, alpha,
-                                   n_threads=int(os.environ.get("LF_LONG_THREADS", min(64, os.cpu_count() or 8))),
-                                   lambda_rgb=lambda_rgb)
+    if x_window is not None:
+        # columns [x0, x1) only: the device marched the whole band (cheap), the float64 tracer the window;
+        # pixels are compared inside it, the ray-fate counters (a whole-band property) are not
+        lfo.g64_set_x_window(*x_window)
+    try:
+        ref, frag, c64 = lfo.g64_trace(lens, W, H, y0, y1, spp, key, None, True, mask, sun, rad, alpha,
+                                       n_threads=_host_threads(), lambda_rgb=lambda_rgb)
+    finally:
+        lfo.g64_set_x_window()
     ref, frag = ref[y0:y1], frag[y0:y1]
+    if x_window is not None:
+        x0, x1 = x_window
+        img, ref, frag = img[:, x0:x1], ref[:, x0:x1], frag[:, x0:x1]
+        lit = ref >= FLOOR
+        assert lit.sum() >= min_lit
+        dev = np.abs(img - ref)
+        assert np.all(dev[lit] <= TOL * ref[lit] + 1.05 * frag[lit]), (dev[lit] / ref[lit]).max()
+        assert np.all(dev[~lit] <= TOL * FLOOR + 1.05 * frag[~lit])
+        rel = dev[lit] / ref[lit]
+        assert (rel <= TOL).mean() >= 0.98 and np.median(rel) < median_bar
+        over = dev[lit] > TOL * ref[lit]
+        if over.any():
+            ratio = dev[lit][over] / frag[lit][over]
+            assert ratio.max() <= 1.05
+            hist, _ = np.histogram(ratio, bins=[0, 0.25, 0.5, 0.75, 1.0, 1.05])
+            print(f"  allowance: {int(over.sum())} of {int(lit.sum())} lit values outside 1e-4; deviation / fragile weight "
+                  f"histogram {hist.tolist()}, max {ratio.max():.3f}; largest raw deviation {rel.max():.2e}")
+        return rel, int(over.sum()), c64
     rel = _check_against_f64(img, cnt, ref, frag, c64, min_lit=min_lit, median_bar=median_bar)
     lit = ref >= FLOOR
     needed = (np.abs(img - ref)[lit] > TOL * ref[lit]).sum()
@@ -200,6 +247,47 @@ def test_c3_band_at_full_spp_against_the_independent_tracer(pkg, lf):
     print(f"c3 band rows {y0}..{y0 + 8}: {rel.size} lit channel values, max rel {rel.max():.2e}, median "
           f"{np.median(rel):.2e}; the fragile-ray allowance was needed by {needed} of them "
           f"({c64['rays_fragile']} fragile rays of {c64['rays_launched']})")
+
+
+def test_c3_lit_band_of_40_rows_against_the_independent_tracer(pkg, lf):
+    """a 40-row band of the benchmark frame across the sun (the rows where most of the
+    frame's light is), 256 spp, all 46 paths x 3 wavelengths -- 2.7e9 rays through the float64 tracer on the
+    host's cores (about a minute on the GPU box's 256; the band shrinks on a smaller host) -- in the
+    DEFAULT run, so that the driver's record carries it and not a builder's log."""
+    import os
+    import time
+    lens = pkg.load_lens_file("dgauss11.lens")
+    mask = load_texels("pentbig500_14.png")
+    W, H, spp, key = 1920, 1080, 256, 0x1e45f1a4e
+    cores = _host_threads()
+    rows = 40 if cores >= 128 else 16 if cores >= 32 else 8
+    y0 = ((int(SUN_NS[1] * H) - rows // 2) // 8) * 8
+    t0 = time.time()
+    rel, needed, c64 = _band_against_f64(pkg, lf, lens, W, H, y0, y0 + rows, spp, key, mask, min_lit=2000)
+    print(f"c3 band rows {y0}..{y0 + rows} ({cores} host threads, {time.time() - t0:.0f} s): {rel.size} lit channel values, "
+          f"max rel {rel.max():.2e}, median {np.median(rel):.2e}; allowance needed by {needed} "
+          f"({c64['rays_fragile']} fragile rays of {c64['rays_launched']})")
+
+
+def test_c5_tile_row_at_its_full_1024_spp_against_the_independent_tracer(pkg, lf):
+    """C5 at the sample count BASELINE.json names -- 4K, 8 wavelengths, 1024 spp -- on
+    the 8-row tile row through the sun, the 960 columns around the sun's image (2.9e9 rays in float64; the
+    window shrinks on a smaller host), in the DEFAULT run."""
+    import time
+    lens8 = pkg.load_lens_file("dgauss11_8lambda.lens")
+    w8, _ = pkg.spectral_weights(lens8["lambda_nm"])
+    mask = load_texels("pentbig500_14.png")
+    W, H, spp, key = 3840, 2160, 1024, 0xC5C5
+    cores = _host_threads()
+    half = 480 if cores >= 128 else 160 if cores >= 32 else 48
+    y0 = (int(SUN_NS[1] * H) // 8) * 8
+    cx = int(SUN_NS[0] * W)
+    t0 = time.time()
+    rel, needed, c64 = _band_against_f64(pkg, lf, lens8, W, H, y0, y0 + 8, spp, key, mask, lambda_rgb=w8,
+                                         min_lit=40 * half // 10, x_window=(cx - half, cx + half))
+    print(f"c5 tile row {y0}..{y0 + 8}, columns {cx - half}..{cx + half} at {spp} spp ({cores} host threads, "
+          f"{time.time() - t0:.0f} s): {rel.size} lit channel values, max rel {rel.max():.2e}, median {np.median(rel):.2e}; "
+          f"allowance needed by {needed} ({c64['rays_fragile']} fragile rays of {c64['rays_launched']})")
 
 
 def _c5_band(pkg, lf, spp, rows_per_call=16):
