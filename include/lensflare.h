@@ -314,6 +314,13 @@ lf_status lf_comm_gather(lf_ctx* ctx, int which);
  * Until then the buffer's rows of the OTHER ranks are undefined; do not change the frame size, band or
  * interleave while an exchange is pending (those calls drain it first). */
 lf_status lf_comm_gather_async(lf_ctx* ctx, int which);
+/* What a rank hands to the collective for a communicator of `world` ranks, computed where lf_comm_gather,
+ * lf_comm_gather_async and lf_group_gather (RCCL and the peer-copy stand-in alike) compute it: out =
+ * {sendcount of the ncclAllGather in elements, bytes per element, byte offset of the receive area in the
+ * staging buffer, staging bytes, groups of `world` consecutive tile rows, elements per tile row}.  Rank q's
+ * sendcount elements arrive at receive area + q * sendcount.  Inspection for tests and hosts that bring
+ * their own transport; nothing is allocated or sent. */
+lf_status lf_comm_exchange_plan(lf_ctx* ctx, int world, uint64_t out[6]);
 lf_status lf_comm_wait(lf_ctx* ctx);
 lf_status lf_comm_destroy(lf_ctx* ctx);
 /* LF_OK if RCCL can be loaded here (dlopen + every entry point): what every rank checks, and agrees

@@ -43,7 +43,7 @@ ABI_SYMBOLS = [
     "lf_get_scene_counters", "lf_reset_scene_counters", "lf_set_flare_arithmetic",
     "lf_comm_get_unique_id", "lf_comm_init_rank", "lf_comm_gather", "lf_comm_gather_async", "lf_comm_wait",
     "lf_comm_destroy", "lf_comm_available", "lf_comm_info", "lf_comm_test", "lf_comm_abort",
-    "lf_comm_set_exchange_precision",
+    "lf_comm_set_exchange_precision", "lf_comm_exchange_plan",
     "lf_group_create", "lf_group_destroy", "lf_group_size", "lf_group_ctx", "lf_group_last_error",
     "lf_group_set_frame", "lf_group_for_each", "lf_group_gather",
 ]
@@ -323,6 +323,12 @@ class LensFlare:
 
     def comm_set_exchange_precision(self, bits):
         self._ck(self.lib.lf_comm_set_exchange_precision(self.ctx, int(bits)))
+
+    def comm_exchange_plan(self, world):
+        v = (C.c_uint64 * 6)()
+        self._ck(self.lib.lf_comm_exchange_plan(self.ctx, int(world), v))
+        return dict(sendcount=int(v[0]), element_bytes=int(v[1]), recv_offset_bytes=int(v[2]),
+                    staging_bytes=int(v[3]), groups=int(v[4]), tile_row_elements=int(v[5]))
 
     def comm_destroy(self):
         self._ck(self.lib.lf_comm_destroy(self.ctx))

@@ -172,6 +172,28 @@ lf_status check_gather_args(lf_ctx* ctx, int which, int world) {
   return LF_OK;
 }
 
+// What ONE rank hands to the collective, in one place: ncclAllGather(send, recv, count, type) delivers rank
+// q's `count` elements at recv + q * count.  lf_comm_gather, lf_comm_gather_async, lf_group_gather's RCCL
+// branch and its peer-copy stand-in (a group whose devices repeat cannot form a communicator) all take their
+// pointers and counts from here, and lf_comm_exchange_plan shows them to the tests.
+struct ExchangePlan {
+  void* send;          // [groups][tile row]: this rank's tile rows, packed
+  void* recv;          // [world][groups][tile row]
+  size_t count;        // elements per rank = groups * 8 rows * W * 3
+  size_t esz;          // bytes per element (double, or float under lf_comm_set_exchange_precision(32))
+  ncclDataType_t type;
+};
+ExchangePlan exchange_plan(lf_ctx* ctx, int world) {
+  const Shape s = shape(ctx, world);
+  ExchangePlan p;
+  p.count = s.groups * s.e;
+  p.esz = ctx->comm_f32 ? sizeof(float) : sizeof(double);
+  p.type = ctx->comm_f32 ? ncclFloat : ncclDouble;
+  p.send = ctx->comm_stage;
+  p.recv = stage_recv(ctx, p.count);
+  return p;
+}
+
 // tests only: run the whole exchange (pack, all-gather, unpack) even with a single rank
 bool force_exchange() { return std::getenv("LF_COMM_FORCE_EXCHANGE") != nullptr; }
 
@@ -236,9 +258,8 @@ lf_status lf_comm_gather(lf_ctx* ctx, int which) {
   invalidate_tonemap(ctx, which);
   hipEvent_t ev = lf_timing_begin(ctx, LFK_EXCHANGE);
   if ((st = launch_pack(ctx, which, rank, world)) != LF_OK) return st;
-  const Shape s = shape(ctx, world);
-  const ncclResult_t rc = r->AllGather(ctx->comm_stage, stage_recv(ctx, s.groups * s.e), s.groups * s.e,
-                                       ctx->comm_f32 ? ncclFloat : ncclDouble, (ncclComm_t)ctx->comm, ctx->stream);
+  const ExchangePlan x = exchange_plan(ctx, world);
+  const ncclResult_t rc = r->AllGather(x.send, x.recv, x.count, x.type, (ncclComm_t)ctx->comm, ctx->stream);
   if (rc != ncclSuccess) return lf_fail(ctx, LF_ERR_HIP, std::string("ncclAllGather: ") + r->GetErrorString(rc));
   st = launch_unpack(ctx, which, rank, world);
   lf_timing_end(ctx, LFK_EXCHANGE, ev);
@@ -268,20 +289,33 @@ lf_status lf_comm_gather_async(lf_ctx* ctx, int which) {
   }
   if ((st = ensure_staging(ctx, world)) != LF_OK) return st;
   invalidate_tonemap(ctx, which);
-  const Shape s = shape(ctx, world);
+  const ExchangePlan x = exchange_plan(ctx, world);
   LF_HIP(ctx, hipEventRecord(ctx->comm_ev_main, ctx->stream));
   LF_HIP(ctx, hipStreamWaitEvent(ctx->comm_stream, ctx->comm_ev_main, 0));
   hipEvent_t ev = lf_timing_begin(ctx, LFK_EXCHANGE, ctx->comm_stream);   // pack -> unpack, on the exchange's own stream
   if ((st = launch_pack(ctx, which, rank, world, ctx->comm_stream)) != LF_OK) return st;
   LF_HIP(ctx, hipEventRecord(ctx->comm_ev_pack, ctx->comm_stream));
   LF_HIP(ctx, hipStreamWaitEvent(ctx->stream, ctx->comm_ev_pack, 0));
-  const ncclResult_t rc = r->AllGather(ctx->comm_stage, stage_recv(ctx, s.groups * s.e), s.groups * s.e,
-                                       ctx->comm_f32 ? ncclFloat : ncclDouble, (ncclComm_t)ctx->comm, ctx->comm_stream);
+  const ncclResult_t rc = r->AllGather(x.send, x.recv, x.count, x.type, (ncclComm_t)ctx->comm, ctx->comm_stream);
   if (rc != ncclSuccess) return lf_fail(ctx, LF_ERR_HIP, std::string("ncclAllGather: ") + r->GetErrorString(rc));
   if ((st = launch_unpack(ctx, which, rank, world, ctx->comm_stream)) != LF_OK) return st;
   lf_timing_end(ctx, LFK_EXCHANGE, ev, ctx->comm_stream);
   LF_HIP(ctx, hipEventRecord(ctx->comm_ev_done, ctx->comm_stream));
   ctx->comm_pending = true;
+  return LF_OK;
+}
+
+lf_status lf_comm_exchange_plan(lf_ctx* ctx, int world, uint64_t out[6]) {
+  if (!ctx || !out || world < 1) return LF_ERR_INVALID;
+  if (ctx->W == 0) return lf_fail(ctx, LF_ERR_STATE, "lf_comm_exchange_plan before lf_set_frame");
+  const Shape s = shape(ctx, world);
+  const size_t esz = ctx->comm_f32 ? sizeof(float) : sizeof(double);
+  out[0] = s.groups * s.e;                       // sendcount (elements per rank) of the ncclAllGather
+  out[1] = esz;                                  // bytes per element
+  out[2] = s.groups * s.e * esz;                 // byte offset of the receive area behind the send area
+  out[3] = (uint64_t)(world + 1) * s.groups * s.e * sizeof(double);   // staging bytes (sized for doubles)
+  out[4] = s.groups;                             // groups of `world` consecutive tile rows
+  out[5] = s.e;                                  // elements of one tile row: 8 rows x W x 3
   return LF_OK;
 }
 
@@ -449,9 +483,6 @@ lf_status lf_group_gather(lf_group* g, int which) {
     if (st == LF_OK) { invalidate_tonemap(c, which); st = launch_pack(c, which, r, n); }
     if (st != LF_OK) { g->err = lf_last_error(c); return st; }
   }
-  const Shape s = shape(g->ctx[0], n);
-  const size_t cnt = s.groups * s.e;
-  const size_t esz = g->ctx[0]->comm_f32 ? sizeof(float) : sizeof(double);
   if (g->rccl) {
     Rccl* rc = rccl();
     ncclResult_t e = rc->GroupStart();
@@ -460,8 +491,8 @@ lf_status lf_group_gather(lf_group* g, int which) {
       lf_ctx* c = g->ctx[r];
       const hipError_t he = hipSetDevice(c->device);
       if (he != hipSuccess) { (void)rc->GroupEnd(); return hip_fail(r, "hipSetDevice", he); }
-      e = rc->AllGather(c->comm_stage, stage_recv(c, cnt), cnt, c->comm_f32 ? ncclFloat : ncclDouble,
-                        (ncclComm_t)c->comm, c->stream);
+      const ExchangePlan x = exchange_plan(c, n);
+      e = rc->AllGather(x.send, x.recv, x.count, x.type, (ncclComm_t)c->comm, c->stream);
       if (e != ncclSuccess) { (void)rc->GroupEnd(); g->err = std::string("ncclAllGather: ") + rc->GetErrorString(e); return LF_ERR_HIP; }
     }
     e = rc->GroupEnd();
@@ -473,12 +504,18 @@ lf_status lf_group_gather(lf_group* g, int which) {
       LF_GROUP_HIP(r, hipSetDevice(g->ctx[r]->device));
       LF_GROUP_HIP(r, hipStreamSynchronize(g->ctx[r]->stream));
     }
+    // (what ncclAllGather(x.send, x.recv, x.count, x.type) does: rank q's x.count elements land at
+    // x.recv + q * x.count -- the same plan, executed with copies)
     for (int r = 0; r < n; r++) {
       lf_ctx* c = g->ctx[r];
       LF_GROUP_HIP(r, hipSetDevice(c->device));
-      for (int q = 0; q < n; q++)
-        LF_GROUP_HIP(r, hipMemcpyPeerAsync((char*)stage_recv(c, cnt) + (size_t)q * cnt * esz, c->device,
-                                           g->ctx[q]->comm_stage, g->ctx[q]->device, cnt * esz, c->stream));
+      const ExchangePlan x = exchange_plan(c, n);
+      for (int q = 0; q < n; q++) {
+        const ExchangePlan xq = exchange_plan(g->ctx[q], n);
+        if (xq.count != x.count || xq.esz != x.esz) { g->err = "the contexts of a group disagree about the exchange's shape"; return LF_ERR_STATE; }
+        LF_GROUP_HIP(r, hipMemcpyPeerAsync((char*)x.recv + (size_t)q * x.count * x.esz, c->device, xq.send,
+                                           g->ctx[q]->device, x.count * x.esz, c->stream));
+      }
     }
   }
   for (int r = 0; r < n; r++) {

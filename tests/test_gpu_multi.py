@@ -262,3 +262,59 @@ def test_tonemapped_frame_is_refreshed_by_an_exchange(pkg):
     grp.gather(pkg.SAMPLE_BUFFER)
     assert np.array_equal(grp.ranks[0].write_to_framebuffer(0, 0, W, H), want)
     grp.close()
+
+
+@pytest.mark.parametrize("W,H,spp", [(1920, 1080, 4), (3840, 2160, 1)])
+@pytest.mark.parametrize("bits", [64, 32])
+def test_eight_ranks_at_bench_sizes(pkg, W, H, spp, bits):
+    """What only an 8-GPU node would otherwise reveal: the exchange's correctness hinges
+    on the [groups][world][tile row] staging layout being what ncclAllGather delivers.  8 contexts on device 0
+    (the peer-copy stand-in executes the SAME plan the RCCL call is given: lf_group.hip exchange_plan) at the
+    two bench frame sizes -- 135 and 270 tile rows, neither divisible by 8, so the padded last group is
+    exercised -- in the f64 and the f32 exchange: every rank ends with the single-context frame, bit for bit
+    (f32: the received rows rounded), and the plan is the one lf_comm_gather hands to ncclAllGather."""
+    n = 8
+    lens = pkg.load_lens_file("dgauss11.lens")
+    mask = load_texels("pentbig500_14.png")
+    one = pkg.LensFlare(0)
+    one.set_frame(W, H)
+    _setup(pkg, one, lens, mask)
+    one.reset_counters()
+    _frame(one, spp, 9)
+    want = one.read_buffer(pkg.SAMPLE_BUFFER)
+    want_cnt = one.counters()
+    one.close()
+    assert want.max() > 0
+    ntrows = (H + 7) // 8
+    assert ntrows % n != 0                                    # the last group of tile rows is short
+    groups = (ntrows + n - 1) // n
+    grp = pkg.LensFlareGroup([0] * n)
+    grp.set_frame(W, H)
+    for r in grp.ranks:
+        _setup(pkg, r, lens, mask)
+        r.reset_counters()
+        r.comm_set_exchange_precision(bits)
+        plan = r.comm_exchange_plan(n)
+        # sendcount / offsets: rank q's `sendcount` elements at recv + q * sendcount, the ncclAllGather contract
+        assert plan["groups"] == groups and plan["tile_row_elements"] == 8 * W * 3
+        assert plan["sendcount"] == groups * 8 * W * 3
+        assert plan["element_bytes"] == bits // 8
+        assert plan["recv_offset_bytes"] == plan["sendcount"] * plan["element_bytes"]
+        assert plan["staging_bytes"] >= (n + 1) * plan["sendcount"] * plan["element_bytes"]
+    grp.for_each(lambda lf, rank: _frame(lf, spp, 9))
+    grp.gather(pkg.SAMPLE_BUFFER)
+    as_float = want.astype(np.float32).astype(np.float64)
+    for r, lf in enumerate(grp.ranks):
+        got = lf.read_buffer(pkg.SAMPLE_BUFFER)
+        if bits == 64:
+            assert np.array_equal(got, want)
+        else:
+            own = (np.arange(H) // 8) % n == r
+            assert np.array_equal(got[own], want[own]) and np.array_equal(got[~own], as_float[~own])
+        del got
+    total = {}
+    for r in grp.ranks:
+        for k, v in r.counters().items():
+            total[k] = total.get(k, 0) + v
+    assert total == want_cnt
+    grp.close()
