@@ -289,7 +289,10 @@ def main():
     nccl_group = None
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("gloo")
+        import datetime
+        # (the control plane's own deadline: a rank that died takes its peers' next gloo collective down
+        # with an error after 10 minutes instead of the default half hour)
+        dist.init_process_group("gloo", timeout=datetime.timedelta(minutes=10))
         if gather_mode == "torch":
             nccl_group = dist.new_group(backend="nccl")
 
@@ -386,10 +389,14 @@ def main():
             all_ok, bad = sharding.agree(dist, ok, why if rank == 0 else "")
         if all_ok:
             ok, why = True, ""
-            try:
-                lf.comm_init_rank(world, rank, box[0])
-            except Exception as e:  # noqa: BLE001
-                ok, why = False, str(e)
+            # ncclCommInitRank blocks on the host until every peer has called it: under the same deadline
+            # as the first exchange (a helper thread that is abandoned, never a re-exec)
+            done, err = sharding.call_with_deadline(lambda: lf.comm_init_rank(world, rank, box[0]),
+                                                    float(os.environ.get("LF_BENCH_COMM_TIMEOUT", "120")))
+            if not done:
+                ok, why = False, "ncclCommInitRank did not return within the deadline (a peer never joined)"
+            elif err is not None:
+                ok, why = False, str(err)
             all_ok, bad = sharding.agree(dist, ok, why)
         if all_ok:
             all_ok, bad = sharding.first_exchange(

@@ -530,6 +530,11 @@ lf_status lf_set_starburst_spectrum(lf_ctx* ctx, int n, const double* scale, con
  * instruction's deviation from the correctly rounded root with this call and hand it to the CPU
  * oracle, which then follows the device bit for bit (oracle/lf_geo_oracle.c, geo_set_sqrt_table). */
 lf_status lf_native_sqrt(lf_ctx* ctx, const float* x, float* y, size_t n);
+/* y[k] = the reciprocal of x[k] exactly as the march computes it (v_rcp_f32, 1 ulp): its divisions on
+ * the per-event and per-sample path are multiplications by this reciprocal (round 4).  As for the root,
+ * the parity tests measure its deviation from the correctly rounded reciprocal -- a function of the
+ * significand alone -- and hand it to the CPU oracle (geo_set_rcp_table). */
+lf_status lf_native_rcp(lf_ctx* ctx, const float* x, float* y, size_t n);
 lf_status lf_get_counters(lf_ctx* ctx, lf_counters* out);
 lf_status lf_reset_counters(lf_ctx* ctx);
 /* Ray-surface events the device actually computed since the last reset: the paths of one sensor

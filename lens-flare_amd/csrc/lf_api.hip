@@ -1232,7 +1232,9 @@ lf_status lf_set_ghost_accumulate(lf_ctx* ctx, int on) {
   return LF_OK;
 }
 
-lf_status lf_native_sqrt(lf_ctx* ctx, const float* x, float* y, size_t n) {
+// one float in, one float out, as a device instruction computes it (lf_native_sqrt, lf_native_rcp)
+static lf_status native_unary(lf_ctx* ctx, const float* x, float* y, size_t n,
+                              lf_status (*launch)(lf_ctx*, const float*, float*, size_t)) {
   if (!ctx || (n && (!x || !y))) return LF_ERR_INVALID;
   if (n == 0) return LF_OK;
   LF_HIP(ctx, hipSetDevice(ctx->device));
@@ -1241,7 +1243,7 @@ lf_status lf_native_sqrt(lf_ctx* ctx, const float* x, float* y, size_t n) {
   if (e == hipSuccess) e = hipMalloc((void**)&d_y, n * sizeof(float));
   if (e == hipSuccess) e = hipMemcpy(d_x, x, n * sizeof(float), hipMemcpyHostToDevice);
   lf_status st = LF_OK;
-  if (e == hipSuccess) st = lfk_native_sqrt(ctx, d_x, d_y, n);
+  if (e == hipSuccess) st = launch(ctx, d_x, d_y, n);
   if (e == hipSuccess && st == LF_OK) e = hipStreamSynchronize(ctx->stream);
   if (e == hipSuccess && st == LF_OK) e = hipMemcpy(y, d_y, n * sizeof(float), hipMemcpyDeviceToHost);
   if (d_x) (void)hipFree(d_x);
@@ -1249,6 +1251,14 @@ lf_status lf_native_sqrt(lf_ctx* ctx, const float* x, float* y, size_t n) {
   if (st != LF_OK) return st;
   LF_HIP(ctx, e);
   return LF_OK;
+}
+
+lf_status lf_native_sqrt(lf_ctx* ctx, const float* x, float* y, size_t n) {
+  return native_unary(ctx, x, y, n, lfk_native_sqrt);
+}
+
+lf_status lf_native_rcp(lf_ctx* ctx, const float* x, float* y, size_t n) {
+  return native_unary(ctx, x, y, n, lfk_native_rcp);
 }
 
 lf_status lf_get_counters(lf_ctx* ctx, lf_counters* out) {

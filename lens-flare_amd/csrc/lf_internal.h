@@ -398,6 +398,7 @@ lf_status lf_upload_primary_table(lf_ctx* ctx);       // LfPrimaryDev from ctx->
 void lf_fill_lenscam_args(const lf_ctx* ctx, LfLensCamArgs* a);
 lf_status lf_build_march_tables(lf_ctx* ctx, std::vector<LfEventRow>& rows, std::vector<int>& skip);
 lf_status lfk_native_sqrt(lf_ctx* ctx, const float* d_x, float* d_y, size_t n);
+lf_status lfk_native_rcp(lf_ctx* ctx, const float* d_x, float* d_y, size_t n);
 void lf_apply_pupil_target(lf_ctx* ctx);
 void lf_derive_lens(lf_ctx* ctx, int n, int stop, int n_lambda, const float* radius,
                     const float* thickness, const float* ior, const float* semi_ap,

@@ -159,6 +159,9 @@ __device__ __forceinline__ LfProgHdr load_phdr(const LfProgHdr* __restrict__ bas
 // long, at the same 24 waves per CU (3 workgroups of 50.8 KB LDS); c3 frame 115.5 -> 114.9 ms, shares of
 // a frame 1-2 % (profiles/r03_march_variants.txt; 6 and 2 waves are worse, 12 no better).
 constexpr int kWgWaves = 8;
+#ifndef LF_SKIP_DEAD_LAMBDA
+#define LF_SKIP_DEAD_LAMBDA 1   // experiments (profiles/r04_march_variants.txt): 0 = no per-wavelength liveness branch
+#endif
 template <int K>
 __global__ __launch_bounds__(64 * kWgWaves, (K == 1 ? 8 : 6))
 void k_march(const LfLensDev* __restrict__ lens, const LfPairsDev* __restrict__ pairs,
@@ -291,7 +294,7 @@ void k_march(const LfLensDev* __restrict__ lens, const LfPairsDev* __restrict__ 
       if (pa != 0.0f || pb != 0.0f) {
         const bool wide = fabsf(pa) > fabsf(pb);
         const float rr = wide ? pa : pb;
-        const float th = 0.78539816339744831f * __fdiv_rn(wide ? pb : pa, rr);
+        const float th = 0.78539816339744831f * ((wide ? pb : pa) * lf_rcp(rr));
         const float t2 = th * th;
         const float sn = th * fmaf(t2, fmaf(t2, fmaf(t2, fmaf(t2, 2.7557319e-6f, -1.9841270e-4f),
                                                      8.3333333e-3f), -1.6666667e-1f), 1.0f);
@@ -302,7 +305,7 @@ void k_march(const LfLensDev* __restrict__ lens, const LfPairsDev* __restrict__ 
       }
       const float vx = fmaf(pupil_h, qx, -X), vy = fmaf(pupil_h, qy, -Y), vz = vz_u;
       const float len = lf_sqrt(fmaf(vx, vx, fmaf(vy, vy, vz * vz)));
-      const float rl = __fdiv_rn(1.0f, len);
+      const float rl = lf_rcp(len);
       const float d0x = vx * rl, d0y = vy * rl, d0z = vz * rl;
       const float c2 = d0z * d0z;
       const float w0 = geom_norm * (c2 * c2);
@@ -403,7 +406,7 @@ void k_march(const LfLensDev* __restrict__ lens, const LfPairsDev* __restrict__ 
               lanemask okv[K], died = 0ull;
 #pragma unroll
               for (int j = 0; j < K; j++) {
-                if (K > 1 && __builtin_expect(alive[j] == 0ull, 0)) { okv[j] = 0ull; continue; }
+                if (LF_SKIP_DEAD_LAMBDA && K > 1 && __builtin_expect(alive[j] == 0ull, 0)) { okv[j] = 0ull; continue; }
                 lanemask geom_ok;
                 LF_HIST(alive[j]);
                 okv[j] = surface_event<kW1>(r[j], cur.dzv, cur.curv, cur.ch, cur.c2, cur.sc, cur.cn22[j], cur.rn2[j],
@@ -435,7 +438,7 @@ void k_march(const LfLensDev* __restrict__ lens, const LfPairsDev* __restrict__ 
                 for (int j = 0; j < K; j++) {
                   // a wavelength whose rays are all gone is not computed (one scalar branch; without
                   // it its lanes would keep marching garbage through every row the others still visit)
-                  if (K > 1 && __builtin_expect(alive[j] == 0ull, 0)) { okv[j] = 0ull; gv[j] = 0ull; continue; }
+                  if (LF_SKIP_DEAD_LAMBDA && K > 1 && __builtin_expect(alive[j] == 0ull, 0)) { okv[j] = 0ull; gv[j] = 0ull; continue; }
                   LF_HIST(alive[j]);
                   okv[j] = surface_event<kW1>(r[j], cur.dzv, cur.curv, cur.ch, cur.c2, cur.sc, cur.cn22[j], cur.rn2[j],
                                               cur.delta[j], cur.h2, false, false, cur.sgn, gv[j]);
@@ -465,7 +468,7 @@ void k_march(const LfLensDev* __restrict__ lens, const LfPairsDev* __restrict__ 
             lanemask okv[K], died = 0ull;
 #pragma unroll
             for (int j = 0; j < K; j++) {
-              if (K > 1 && __builtin_expect(alive[j] == 0ull, 0)) { okv[j] = 0ull; continue; }
+              if (LF_SKIP_DEAD_LAMBDA && K > 1 && __builtin_expect(alive[j] == 0ull, 0)) { okv[j] = 0ull; continue; }
               LF_HIST(alive[j]);
               okv[j] = stop_event<kW1>(r[j], cur.dzv, cur.h2, inv_stop_h, mask, a.mw, a.mh);
               died |= alive[j] & ~okv[j];
@@ -493,7 +496,7 @@ void k_march(const LfLensDev* __restrict__ lens, const LfPairsDev* __restrict__ 
             lanemask okv[K], gv[K], died = 0ull;
 #pragma unroll
             for (int j = 0; j < K; j++) {
-              if (K > 1 && __builtin_expect(alive[j] == 0ull, 0)) { okv[j] = 0ull; gv[j] = 0ull; continue; }
+              if (LF_SKIP_DEAD_LAMBDA && K > 1 && __builtin_expect(alive[j] == 0ull, 0)) { okv[j] = 0ull; gv[j] = 0ull; continue; }
               LF_HIST(alive[j]);
               okv[j] = surface_event<kW1>(r[j], cur.dzv, cur.curv, cur.ch, cur.c2, cur.sc, cur.cn22[j], cur.rn2[j],
                                           cur.delta[j], cur.h2, (fl & LF_EV_REFLECT) != 0,
@@ -683,6 +686,11 @@ __global__ __launch_bounds__(256) void k_lens_rays(const LfLensDev* __restrict__
 __global__ void k_native_sqrt(const float* __restrict__ x, float* __restrict__ y, size_t n) {
   const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i < n) y[i] = lf_sqrt(x[i]);
+}
+
+__global__ void k_native_rcp(const float* __restrict__ x, float* __restrict__ y, size_t n) {
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) y[i] = lf_rcp(x[i]);
 }
 
 __global__ void k_march_finish(const unsigned long long* __restrict__ accum, MarchArgs a,
@@ -1179,6 +1187,13 @@ lf_status lfk_native_sqrt(lf_ctx* ctx, const float* d_x, float* d_y, size_t n) {
   if (n == 0) return LF_OK;
   hipLaunchKernelGGL(k_native_sqrt, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream, d_x,
                      d_y, n);
+  LF_HIP(ctx, hipGetLastError());
+  return LF_OK;
+}
+
+lf_status lfk_native_rcp(lf_ctx* ctx, const float* d_x, float* d_y, size_t n) {
+  if (n == 0) return LF_OK;
+  hipLaunchKernelGGL(k_native_rcp, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream, d_x, d_y, n);
   LF_HIP(ctx, hipGetLastError());
   return LF_OK;
 }

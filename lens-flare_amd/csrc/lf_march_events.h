@@ -34,6 +34,15 @@ __device__ __forceinline__ uint4 philox4x32_10(uint4 ctr, uint2 key) {
 // comparable with the oracle.
 __device__ __forceinline__ float lf_sqrt(float x) { return __builtin_amdgcn_sqrtf(x); }
 
+// Divisions on the per-event / per-sample path are multiplications by the hardware reciprocal v_rcp_f32
+// (1 ulp; one quarter-rate instruction + a multiply where the IEEE division is ~10 instructions around the
+// same v_rcp: round 4, the stop event's division alone was 2.2 % of the bench frame).  Like v_sqrt_f32 the
+// instruction is deterministic and its deviation from the correctly rounded reciprocal depends only on the
+// significand, so the CPU oracle follows it exactly through a table measured once (lf_native_rcp,
+// geo_set_rcp_table).  The rare divisions whose accuracy matters most -- the weight's wn / wd and the lobe
+// factor -- stay IEEE (__fdiv_rn).
+__device__ __forceinline__ float lf_rcp(float x) { return __builtin_amdgcn_rcpf(x); }
+
 __device__ __forceinline__ float u01(unsigned r) { return (float)(r >> 8) * 5.9604644775390625e-8f; }
 
 // The transmitted weight is carried as a fraction wn / wd: every Fresnel factor is a ratio of
@@ -92,7 +101,7 @@ __device__ __forceinline__ lanemask surface_event(Ray& r, float dzv, float c, fl
   const float disc = fmaf(G, G, -cF);
   const float sq = lf_sqrt(disc);                // n |cos(incidence)|
   float t;
-  if (flat) t = __fdiv_rn(Fh + Fh, fmaf(sgn, sq, G));   // wave-uniform branch
+  if (flat) t = (Fh + Fh) * lf_rcp(fmaf(sgn, sq, G));   // wave-uniform branch
   else t = fmaf(-sgn, sq, G) * rn2;
   const float hx = fmaf(t, r.dx, r.px), hy = fmaf(t, r.dy, r.py), hz = fmaf(t, r.dz, oz);
   const float r2 = fmaf(hx, hx, hy * hy);
@@ -151,7 +160,7 @@ __device__ __forceinline__ lanemask surface_event(Ray& r, float dzv, float c, fl
 template <bool W>
 __device__ __forceinline__ lanemask stop_event(Ray& r, float dzv, float h2, float inv_h,
                                                const float* __restrict__ mask, int mw, int mh) {
-  const float t = __fdiv_rn(-(r.hz + dzv), r.dz);
+  const float t = -(r.hz + dzv) * lf_rcp(r.dz);
   const float hx = fmaf(t, r.dx, r.px), hy = fmaf(t, r.dy, r.py);
   const float r2 = fmaf(hx, hx, hy * hy);
   const float fu = fmaf(hx, inv_h, 1.0f) * (0.5f * (float)mw);
@@ -189,7 +198,7 @@ __device__ __forceinline__ void pupil_disc(float pa, float pb, float& qx, float&
   if (pa != 0.0f || pb != 0.0f) {
     const bool wide = fabsf(pa) > fabsf(pb);
     const float rr = wide ? pa : pb;
-    const float th = 0.78539816339744831f * __fdiv_rn(wide ? pb : pa, rr);
+    const float th = 0.78539816339744831f * ((wide ? pb : pa) * lf_rcp(rr));
     const float t2 = th * th;
     const float sn = th * fmaf(t2, fmaf(t2, fmaf(t2, fmaf(t2, 2.7557319e-6f, -1.9841270e-4f),
                                                  8.3333333e-3f), -1.6666667e-1f), 1.0f);
@@ -207,7 +216,7 @@ __device__ __forceinline__ StartRay aim_at_pupil(float X, float Y, float pa, flo
   pupil_disc(pa, pb, qx, qy);
   const float vx = fmaf(pupil_h, qx, -X), vy = fmaf(pupil_h, qy, -Y);
   const float len = lf_sqrt(fmaf(vx, vx, fmaf(vy, vy, vz * vz)));
-  const float rl = __fdiv_rn(1.0f, len);
+  const float rl = lf_rcp(len);
   StartRay s;
   s.X = X; s.Y = Y; s.dx = vx * rl; s.dy = vy * rl; s.dz = vz * rl;
   const float c2 = s.dz * s.dz;

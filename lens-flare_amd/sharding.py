@@ -81,9 +81,35 @@ def agree(dist, ok, why=""):
     return not bad, bad
 
 
+def call_with_deadline(fn, timeout_s):
+    """Run a HOST-BLOCKING call (ncclCommInitRank, or the first collective on a fresh communicator, whose
+    transport set-up blocks the calling thread until every peer has joined) in a helper thread and wait for
+    it at most timeout_s.  Returns (done, error): (True, None) when fn returned, (True, exception) when it
+    raised, (False, None) when it is still blocked -- the thread is then abandoned (a daemon: it cannot keep
+    the process alive) and the caller must treat the communicator as lost (lf_comm_abort, fall back or
+    exit).  Never re-executes anything: a process that has touched the GPU must not exec."""
+    import threading
+    box = {}
+
+    def run():
+        try:
+            fn()
+            box["err"] = None
+        except BaseException as e:  # noqa: BLE001 -- handed to the caller, whatever it is
+            box["err"] = e
+
+    t = threading.Thread(target=run, daemon=True, name="lf-bringup")
+    t.start()
+    t.join(timeout_s)
+    if t.is_alive():
+        return False, None
+    return True, box.get("err")
+
+
 def first_exchange(dist, enqueue, test, timeout_s=120.0, poll_s=0.01, clock=None, sleep=None):
     """Run the first exchange of a fresh communicator so that NO rank can hang: `enqueue()` queues it
-    (non-blocking; may raise), `test()` says whether it has completed on the device (non-blocking).
+    (may raise, may block on the host: it runs under the deadline in a helper thread), `test()` says
+    whether it has completed on the device (non-blocking).
     A rank whose peers never joined sees `test()` stay False and gives up after timeout_s.  Returns
     (all ranks completed?, reasons); on False every rank must abort its communicator (lf_comm_abort)
     before using its streams again."""
@@ -92,7 +118,13 @@ def first_exchange(dist, enqueue, test, timeout_s=120.0, poll_s=0.01, clock=None
     sleep = sleep or time.sleep
     ok, why = True, ""
     try:
-        enqueue()
+        # enqueue() itself may block on the HOST: the first ncclAllGather of a communicator connects its
+        # channels in the calling thread and waits there for every peer.  Same deadline.
+        done, err = call_with_deadline(enqueue, timeout_s)
+        if not done:
+            raise TimeoutError(f"enqueueing the first exchange blocked for more than {timeout_s:g} s (a peer never joined)")
+        if err is not None:
+            raise err
         t0 = clock()
         while not test():
             if clock() - t0 > timeout_s:

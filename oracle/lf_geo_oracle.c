@@ -76,6 +76,28 @@ static float geo_sqrt(float x) {
 }
 float geo_sqrt_f32(float x) { return geo_sqrt(x); }
 
+/* ---- the reciprocal as the device computes it: v_rcp_f32, followed like the root through a table of its
+ * deviation (-1 / 0 / +1 ulp) from the correctly rounded 1 / x, which depends on the significand alone
+ * (2^23 entries, measured through lf_native_rcp).  Without a table: the correctly rounded reciprocal.
+ * The march's divisions on the per-event and per-sample path are multiplications by it. */
+static const int8_t* g_rcp_dev = NULL; /* 2^23 entries, index = float bits & 0x7fffff */
+void geo_set_rcp_table(const int8_t* dev) { g_rcp_dev = dev; }
+static float geo_rcp(float x) {
+  float r = 1.0f / x;
+  if (g_rcp_dev && x == x && fabsf(x) < INFINITY && x != 0.0f) {
+    uint32_t xb, rb;
+    memcpy(&xb, &x, 4);
+    memcpy(&rb, &r, 4);
+    const uint32_t ex = (xb >> 23) & 0xffu, er = (rb >> 23) & 0xffu;
+    if (ex != 0 && er != 0 && er != 0xffu) { /* normal in, normal out */
+      rb += (uint32_t)(int32_t)g_rcp_dev[xb & 0x7fffffu];
+      memcpy(&r, &rb, 4);
+    }
+  }
+  return r;
+}
+float geo_rcp_f32(float x) { return geo_rcp(x); }
+
 static float unit24(uint32_t r) { return (float)(r >> 8) * 5.9604644775390625e-8f; }
 
 /* ---- derived per-interface constants ------------------------------------------------------ */
@@ -164,8 +186,8 @@ static int glass_event(geo_ray* r, float dzv, float c, float rad, float h2, floa
   if (disc < 0.0f) return VIGNETTED;
   float root = geo_sqrt(disc);
   /* the root next to the vertex of c n^2 s^2 - 2 s G + F = 0 (ray o + s K): (G -+ root) R / n^2 for a
-   * curved interface, the quotient F / (G +- root) for flat glass */
-  float t = (c == 0.0f) ? (Fh + Fh) / fmaf(sgn, root, G) : fmaf(-sgn, root, G) * rn2;
+   * curved interface, F times the reciprocal of (G +- root) for flat glass */
+  float t = (c == 0.0f) ? (Fh + Fh) * geo_rcp(fmaf(sgn, root, G)) : fmaf(-sgn, root, G) * rn2;
   float hx = fmaf(t, r->d[0], r->p[0]), hy = fmaf(t, r->d[1], r->p[1]), hz = fmaf(t, r->d[2], oz);
   float r2 = fmaf(hx, hx, hy * hy);
   if (!(r2 <= h2)) return VIGNETTED;
@@ -204,7 +226,7 @@ static int glass_event(geo_ray* r, float dzv, float c, float rad, float h2, floa
 }
 
 static int stop_event(geo_ray* r, float dzv, float h2, float inv_h, const float* mask, int mw, int mh) {
-  float t = -(r->p[2] + dzv) / r->d[2];
+  float t = -(r->p[2] + dzv) * geo_rcp(r->d[2]);
   float hx = fmaf(t, r->d[0], r->p[0]), hy = fmaf(t, r->d[1], r->p[1]);
   float r2 = fmaf(hx, hx, hy * hy);
   if (!(r2 <= h2)) return CLIPPED;
@@ -271,7 +293,7 @@ static void aim_at_pupil(const geo_derived* D, float X, float Y, float pa, float
   if (pa != 0.0f || pb != 0.0f) {
     int wide = fabsf(pa) > fabsf(pb);
     float rr = wide ? pa : pb;
-    float th = 0.78539816339744831f * ((wide ? pb : pa) / rr);
+    float th = 0.78539816339744831f * ((wide ? pb : pa) * geo_rcp(rr));
     float t2 = th * th;
     float sn = th * fmaf(t2, fmaf(t2, fmaf(t2, fmaf(t2, 2.7557319e-6f, -1.9841270e-4f), 8.3333333e-3f),
                                   -1.6666667e-1f), 1.0f);
@@ -282,7 +304,7 @@ static void aim_at_pupil(const geo_derived* D, float X, float Y, float pa, float
   }
   float vx = fmaf(D->pupil_h, qx, -X), vy = fmaf(D->pupil_h, qy, -Y), vz = D->pupil_z - D->z_sensor;
   float len = geo_sqrt(fmaf(vx, vx, fmaf(vy, vy, vz * vz)));
-  float rl = 1.0f / len;
+  float rl = geo_rcp(len);
   r->p[0] = X; r->p[1] = Y; r->p[2] = 0.0f;   /* on the sensor plane, relative to it */
   r->r2 = fmaf(X, X, Y * Y);
   r->d[0] = vx * rl; r->d[1] = vy * rl; r->d[2] = vz * rl;

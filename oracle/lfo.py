@@ -341,6 +341,58 @@ def sqrt_deviation_table(device_sqrt):
     return dev.astype(np.int8)
 
 
+_rcp_table_keepalive = None
+
+
+def geo_set_rcp_table(dev):
+    """int8[2^23]: deviation of the device's v_rcp_f32 from the correctly rounded reciprocal, index = float32
+    bits & 0x7fffff (the significand); None = the correctly rounded reciprocal."""
+    global _rcp_table_keepalive
+    if dev is None:
+        lib().geo_set_rcp_table(None)
+        _rcp_table_keepalive = None
+        return
+    dev = np.ascontiguousarray(dev, np.int8)
+    assert dev.shape == (1 << 23,)
+    _rcp_table_keepalive = dev
+    lib().geo_set_rcp_table(_p(dev, C.c_int8))
+
+
+def rcp_table_inputs():
+    """One float32 per significand, in [1, 2)."""
+    return (np.arange(1 << 23, dtype=np.uint32) | np.uint32(0x3F800000)).view(np.float32)
+
+
+def rcp_deviation_table(device_rcp):
+    """device_rcp: float32 array -> float32 array as the device computes it (lf_native_rcp)."""
+    x = rcp_table_inputs()
+    hw = np.asarray(device_rcp(x), np.float32).view(np.int32)
+    exact = (np.float32(1.0) / x).view(np.int32)     # IEEE float32 division: correctly rounded
+    dev = hw - exact
+    assert np.abs(dev).max() <= 1, "v_rcp_f32 is documented to be accurate to 1 ulp"
+    return dev.astype(np.int8)
+
+
+def geo_follow_device(lf):
+    """Make the float32 oracle reproduce the device's two non-IEEE instructions -- v_sqrt_f32 and v_rcp_f32 --
+    through their measured deviation tables (lf.native_sqrt / lf.native_rcp); None: back to the correctly
+    rounded operations.  lf may also be a (sqrt table, rcp table) pair measured earlier."""
+    if lf is None:
+        geo_set_sqrt_table(None)
+        geo_set_rcp_table(None)
+        return None
+    tabs = lf if isinstance(lf, tuple) else (sqrt_deviation_table(lf.native_sqrt), rcp_deviation_table(lf.native_rcp))
+    geo_set_sqrt_table(tabs[0])
+    geo_set_rcp_table(tabs[1])
+    return tabs
+
+
+def geo_rcp(x):
+    lib().geo_rcp_f32.restype = C.c_float
+    lib().geo_rcp_f32.argtypes = [C.c_float]
+    return np.array([lib().geo_rcp_f32(float(v)) for v in np.asarray(x, np.float32).ravel()], np.float32)
+
+
 def geo_sqrt(x):
     lib().geo_sqrt_f32.restype = C.c_float
     lib().geo_sqrt_f32.argtypes = [C.c_float]

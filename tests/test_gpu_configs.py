@@ -23,9 +23,9 @@ def pkg():
 @pytest.fixture(scope="module")
 def lf(pkg):
     ctx = pkg.LensFlare(0)
-    lfo.geo_set_sqrt_table(lfo.sqrt_deviation_table(ctx.native_sqrt))
+    lfo.geo_follow_device(ctx)
     yield ctx
-    lfo.geo_set_sqrt_table(None)
+    lfo.geo_follow_device(None)
     ctx.close()
 
 

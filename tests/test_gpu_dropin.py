@@ -209,11 +209,11 @@ def test_geometric_march_through_the_reference_surface(route, tmp_path):
     sun = [(nx - 0.5) * lens["sensor_width_mm"] / efl, (ny - 0.5) * lens["sensor_width_mm"] * H / W / efl, -1.0]
     mask = load_texels("pentbig500_14.png")
     lf = pkg.LensFlare(0)
-    lfo.geo_set_sqrt_table(lfo.sqrt_deviation_table(lf.native_sqrt))
+    lfo.geo_follow_device(lf)
     try:
         og, _ = lfo.geo_trace(lens, W, H, 0, H, spp, key, None, True, mask, sun, flares[0][2:5], radius)
     finally:
-        lfo.geo_set_sqrt_table(None)
+        lfo.geo_follow_device(None)
         lf.close()
     assert og.max() > 0
     assert np.array_equal(ghost, og)

@@ -79,7 +79,7 @@ def test_cpp_shim_geometric_ghosts_and_lens_camera(tmp_path):
     assert "chief ray alive=1" in r.stdout
     ghost = np.fromfile(out + ".ghost.f64", np.float64).reshape(H, W, 3)
     lf = pkg.LensFlare(0)
-    lfo.geo_set_sqrt_table(lfo.sqrt_deviation_table(lf.native_sqrt))
+    lfo.geo_follow_device(lf)
     try:
         og, _ = lfo.geo_trace(lens, W, H, 0, H, spp, 0x1e45f1a4e, None, True, mask, sun, [1.0, 0.9, 0.5], 0.05)
         assert np.array_equal(ghost, og) and og.max() > 0
@@ -116,5 +116,5 @@ def test_cpp_shim_geometric_ghosts_and_lens_camera(tmp_path):
             assert np.allclose(rays[i, 3:6], dd, atol=2e-5) and np.allclose(rays[i, 0:3], p, atol=2e-4)
         assert checked > 10
     finally:
-        lfo.geo_set_sqrt_table(None)
+        lfo.geo_follow_device(None)
         lf.close()

@@ -40,9 +40,10 @@ def lf(pkg):
 
 @pytest.fixture(scope="module")
 def sqrt_table(pkg):
-    """the float32 oracle follows the device's v_sqrt_f32 through its measured deviation table"""
+    """the float32 oracle follows the device's v_sqrt_f32 and v_rcp_f32 through their measured deviation tables"""
     ctx = pkg.LensFlare(0)
-    t = lfo.sqrt_deviation_table(ctx.native_sqrt)
+    t = lfo.geo_follow_device(ctx)
+    lfo.geo_follow_device(None)
     ctx.close()
     return t
 
@@ -119,7 +120,7 @@ def test_lens_frame_equals_the_float32_oracle(pkg, lf, sqrt_table):
     got = lf.read_buffer(pkg.SCENE_BUFFER)
     info = lf.lens_camera()
     cnt = lf.scene_counters()
-    lfo.geo_set_sqrt_table(sqrt_table)
+    lfo.geo_follow_device(sqrt_table)
     try:
         exposure = lfo.lens_exposure(lens, W, mask)
         z_ref, _ = pkg.paraxial_entrance_pupil(lens)
@@ -149,7 +150,7 @@ def test_lens_frame_equals_the_float32_oracle(pkg, lf, sqrt_table):
         assert np.abs(got2 - got).max() > 1e-6           # dispersion is visible
         assert np.array_equal(got2[..., 1], got[..., 1])  # the reference wavelength IS wavelength 1
     finally:
-        lfo.geo_set_sqrt_table(None)
+        lfo.geo_follow_device(None)
     # a fixed exposure is taken as given
     lf.set_lens_camera(1, wpm, 2.0 * exposure)
     lf.render_scene_term()

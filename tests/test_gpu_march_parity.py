@@ -27,9 +27,9 @@ def pkg():
 @pytest.fixture(scope="module")
 def lf(pkg):
     ctx = pkg.LensFlare(0)
-    lfo.geo_set_sqrt_table(lfo.sqrt_deviation_table(ctx.native_sqrt))
+    lfo.geo_follow_device(ctx)
     yield ctx
-    lfo.geo_set_sqrt_table(None)
+    lfo.geo_follow_device(None)
     ctx.close()
 
 
@@ -55,6 +55,32 @@ def test_native_sqrt_is_one_ulp_and_scale_invariant(lf):
     # special values: 0 -> 0, negative -> NaN, NaN -> NaN
     sp = lf.native_sqrt(np.array([0.0, -1.0, np.nan], np.float32))
     assert sp[0] == 0.0 and np.isnan(sp[1]) and np.isnan(sp[2])
+
+
+def test_native_rcp_is_one_ulp_and_scale_invariant(lf):
+    """Premises of the oracle's reciprocal emulation (round 4: the march's per-event / per-sample divisions
+    are multiplications by v_rcp_f32): |v_rcp_f32 - correctly rounded 1/x| <= 1 ulp, and the deviation
+    depends only on the significand -- checked on 2^20 random significands at exponents 2^-40 .. 2^+40, both
+    signs (the march feeds it direction cosines and lengths of order 1e-2 .. 1e2)."""
+    table = lfo.rcp_deviation_table(lf.native_rcp)
+    assert set(np.unique(table)) <= {-1, 0, 1}
+    assert (table != 0).any()                 # not the correctly rounded reciprocal: the emulation is needed
+    rng = np.random.default_rng(6)
+    idx = rng.integers(0, 1 << 23, 1 << 20, dtype=np.uint32)
+    for e in (-40, -7, -1, 0, 1, 6, 40):
+        for sign in (0, 1):
+            bits = (idx | np.uint32(0x3F800000)).astype(np.int64) + (e << 23) + (sign << 31)
+            x = bits.astype(np.uint32).view(np.float32)
+            hw = lf.native_rcp(x).view(np.int32)
+            want = (np.float32(1.0) / x).view(np.int32) + table[idx]
+            assert np.array_equal(hw, want), (e, sign)
+    x = ((idx[:2000] | np.uint32(0x3F800000)).view(np.float32) * np.float32(-0.37)).astype(np.float32)
+    lfo.geo_set_rcp_table(None)
+    try:
+        assert np.array_equal(lfo.geo_rcp(x), (np.float32(1.0) / x).astype(np.float32))   # no table: correctly rounded
+    finally:
+        lfo.geo_set_rcp_table(table)       # (the module's oracle keeps following the device)
+    assert np.array_equal(lfo.geo_rcp(x).view(np.int32), lf.native_rcp(x).view(np.int32))
 
 
 def _run(pkg, lf, lens, W, H, spp, key, mask, pairs=None, primary=True, band=None, sun=SUN):

@@ -97,13 +97,13 @@ def test_targeted_march_equals_both_oracles(pkg, lf):
     lf.trace_ghosts(spp, key)
     img, cnt = lf.read_buffer(pkg.GHOST_BUFFER), lf.counters()
     lfo.set_pupil_target(tgt["radius_mm"], tgt["z_mm"])
-    lfo.geo_set_sqrt_table(lfo.sqrt_deviation_table(lf.native_sqrt))
+    lfo.geo_follow_device(lf)
     try:
         og, ocnt = lfo.geo_trace(lens, W, H, 0, H, spp, key, pa, True, mask, sun, rad, alpha)
-        lfo.geo_set_sqrt_table(None)
+        lfo.geo_follow_device(None)
         ref, frag, c64 = lfo.g64_trace(lens, W, H, 0, H, spp, key, pa, True, mask, sun, rad, alpha, n_threads=16)
     finally:
-        lfo.geo_set_sqrt_table(None)
+        lfo.geo_follow_device(None)
         lfo.set_pupil_target(0.0, 0.0)
         lf.set_pupil_target(0.0, 0.0)
     assert cnt == ocnt and np.array_equal(img, og) and og.max() > 0

@@ -114,10 +114,14 @@ def _bringup_worker(rank, world, port, out_dir, fail_rank, stage):
         def enqueue():
             if stage == "exchange" and rank == fail_rank:
                 raise RuntimeError("LF_ERR_HIP: injected launch failure")
+            if stage == "blocked" and rank != fail_rank:
+                # what RCCL does when a peer died before joining: the call never returns
+                import threading
+                threading.Event().wait()
             state["enqueued"] = True
 
         def test():
-            return stage != "exchange"     # completes at once unless a peer is missing
+            return stage not in ("exchange",)     # completes at once unless a peer is missing
 
         ok, bad = sharding.first_exchange(dist, enqueue, test, timeout_s=0.3, poll_s=0.01)
         log.append(("exchange", ok, bad))
@@ -127,7 +131,7 @@ def _bringup_worker(rank, world, port, out_dir, fail_rank, stage):
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("stage", ["none", "preflight", "exchange"])
+@pytest.mark.parametrize("stage", ["none", "preflight", "exchange", "blocked"])
 def test_one_rank_failing_alone_is_noticed_by_all(stage, tmp_path):
     """bench.py's bring-up of the C ABI's RCCL communicator (lens_flare_amd.sharding.agree /
     first_exchange): whatever a single rank's local failure, every rank returns, with the same verdict
@@ -142,6 +146,12 @@ def test_one_rank_failing_alone_is_noticed_by_all(stage, tmp_path):
         assert [x[:2] for x in logs[0]] == [["preflight", True], ["exchange", True]]
     elif stage == "preflight":
         assert logs[0] == [["preflight", False, ["rank 1: librccl.so.1 not found"]]]   # no exchange was attempted
+    elif stage == "blocked":
+        # the two healthy ranks' enqueue blocks on the host for ever (their peer "died"): the helper
+        # thread is abandoned at the deadline, every rank still reaches the verdict
+        name, ok, bad = logs[0][1]
+        assert name == "exchange" and not ok and len(bad) == world - 1
+        assert all("blocked for more than" in b for b in bad)
     else:
         name, ok, bad = logs[0][1]
         assert name == "exchange" and not ok and len(bad) == world
