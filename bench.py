@@ -116,7 +116,7 @@ def source_sha():
     """Identity of the shipped march kernel: the PMC-derived figures are only quoted as this
     binary's when the profile in profiles/ was taken from the same sources and compile flags."""
     h = hashlib.sha256()
-    for f in ("lens-flare_amd/csrc/lf_march.hip", "lens-flare_amd/csrc/lf_internal.h"):
+    for f in ("lens-flare_amd/csrc/lf_march.hip", "lens-flare_amd/csrc/lf_march_events.h", "lens-flare_amd/csrc/lf_internal.h"):
         h.update(open(os.path.join(ROOT, f), "rb").read())
     mk = open(os.path.join(ROOT, "lens-flare_amd", "Makefile")).read()
     h.update(mk[mk.index("FLAGS  :="):mk.index("SRCS   :=")].encode())
@@ -130,7 +130,6 @@ def cpu_baseline(lens, mask, sun, W, H, pairs, lambda_rgb, target_s):
     as SURVEY 8d asks for the CPU leg."""
     from oracle import lfo
     host_cores = os.cpu_count() or 1
-    cores = host_cores
     rows = (H // 2 - 32, H // 2 + 32)
 
     def run(y0, y1, spp, threads):
@@ -139,17 +138,26 @@ def cpu_baseline(lens, mask, sun, W, H, pairs, lambda_rgb, target_s):
                              n_threads=threads, lambda_rgb=lambda_rgb)
         return c["surface_events"], max(time.time() - t0, 1e-3)
 
-    ev, dt = run(rows[0], rows[0] + 4, 1, cores)           # calibration: 4 rows at 1 spp
-    per_row_sample = ev / 4.0
-    spp = int(max(1, min(64, target_s * (ev / dt) / (per_row_sample * (rows[1] - rows[0])))))
+    # How many threads: the host reports host_cores, but a GPU box gives one GPU's user a SHARE of them (a
+    # quota, not an affinity mask: os.cpu_count() does not show it), and an OpenMP team larger than the share
+    # is slower, not faster.  So: a short sweep over team sizes on the band at 1 spp, the fastest is the team
+    # of the timed run; the sweep is part of the record.
+    sweep = {}
+    for t in sorted({host_cores, min(host_cores, 128), min(host_cores, 64), min(host_cores, 32), min(host_cores, 16)}, reverse=True):
+        ev, dt = run(rows[0], rows[1], 1, t)
+        sweep[t] = ev / dt / 1e6
+    cores = max(sweep, key=sweep.get)
+    per_row_sample = ev / float(rows[1] - rows[0])
+    spp = int(max(1, min(64, target_s * sweep[cores] * 1e6 / (per_row_sample * (rows[1] - rows[0])))))
     ev_n, dt_n = run(rows[0], rows[1], spp, cores)
-    # one thread: as many rows at 1 spp as a third of the budget buys at the all-core rate / cores (>= 1 row)
-    rate1_guess = ev_n / dt_n / cores * 1.5
-    rows1 = int(max(1, min(rows[1] - rows[0], (target_s / 3.0) * rate1_guess / per_row_sample)))
+    # one thread: as many rows at 1 spp as a third of the budget buys (>= 1 row)
+    ev_c, dt_c = run(rows[0], rows[0] + 1, 1, 1)
+    rows1 = int(max(1, min(rows[1] - rows[0], (target_s / 3.0) * (ev_c / dt_c) / per_row_sample)))
     ev_1, dt_1 = run(rows[0], rows[0] + rows1, 1, 1)
     return {"value": ev_n / dt_n / 1e6, "unit": "Mray-surface-intersections/s",
             "cores": cores, "host_cores": host_cores, "kind": "port",
             "value_t1": ev_1 / dt_1 / 1e6, "cores_t1": 1,
+            "thread_sweep_M_per_s": {str(k): v for k, v in sweep.items()},
             "sample": f"rows {rows[0]}..{rows[1]} of the {W}x{H} frame, {spp} of the spp, every path "
                       f"marched on its own: {ev_n} intersections in {dt_n:.1f} s on {cores} OpenMP threads; "
                       f"one thread: rows {rows[0]}..{rows[0] + rows1} at 1 spp, {ev_1} intersections in {dt_1:.1f} s "
@@ -477,12 +485,16 @@ def main():
 
     cnt = lf.counters()
     stats = lf.march_stats()
-    # opt-in sampling specifications, timed beside the default (N = 1 only, outside the timed region; what
-    # they cost in image quality is in profiles/r03_sampling_efficiency.json)
+    # other sampling specifications, timed beside the default (N = 1 only, outside the timed region).  The
+    # default since round 4: 16 x 16 pupil sub-cells per stratum shared by a wave whose pixel columns are 8
+    # apart (tile correlation 6.9; profiles/r04_tile_stride.json).  Rounds 1-3: 4 x 4 sub-cells over 8 x 8
+    # adjacent pixels (37.7).  1 x 1 sub-cells = every pixel draws on its own (1.0).
     sampling_variants = None
     if world == 1 and not cfg["scene"] and not args.no_cpu:   # (--no-cpu = the march alone: profiler passes, A/B runs)
         sampling_variants = {}
-        for bits in (4, 0):
+        for name, stride, bits, corr in (("rounds_1_to_3_stride1_subcells_4x4", 1, 2, 37.7),
+                                         ("independent_pixels_subcells_1x1", pkg.DEFAULT_TILE_STRIDE, 0, 1.0)):
+            lf.set_tile_stride(stride)
             lf.set_pupil_subcells(bits)
             one_frame()
             lf.synchronize()
@@ -490,8 +502,12 @@ def main():
             for _ in range(2):
                 one_frame()
             lf.synchronize()
-            sampling_variants[f"pupil_subcells_{1 << bits}x{1 << bits}"] = {"ms_per_step": (time.perf_counter() - t_v) / 2 * 1e3}
-        lf.set_pupil_subcells(2)
+            sampling_variants[name] = {"ms_per_step": (time.perf_counter() - t_v) / 2 * 1e3, "tile_correlation": corr}
+        sampling_variants["default_stride8_subcells_16x16"] = {"ms_per_step": dt / args.steps * 1e3, "tile_correlation": 6.9}
+        sampling_variants["note"] = ("tile_correlation = 64 Var(mean of 8 x 8 adjacent pixels) / mean pixel variance on this frame "
+                                     "(1 = independent pixels, 64 = the block moves as one), profiles/r04_tile_stride.json")
+        lf.set_tile_stride(pkg.DEFAULT_TILE_STRIDE)
+        lf.set_pupil_subcells(pkg.DEFAULT_SUBCELL_BITS)
     n_launch, march_ms = lf.timing_get("march")
     n_xchg, xchg_ms = lf.timing_get("exchange") if gather_mode == "cabi" else (args.steps, host_exchange[0] * 1e3)
     n_scene, scene_ms = lf.timing_get("scene_term")

@@ -431,6 +431,14 @@ lf_status lf_paraxial_exit_pupil(int n_surfaces, int stop_index, const float* ra
 /* on: lf_trace_ghosts ADDS its pixels to ghost_buffer instead of replacing them (a frame composed of
  * launches with different pair sets / pupil targets).  Default off. */
 lf_status lf_set_ghost_accumulate(lf_ctx* ctx, int on);
+/* Which 64 pixels a wave of the march takes (part of the sampling specification, like the pupil
+ * sub-cells: it decides which pixels share a sub-cell draw): 8 rows x 8 columns that are `stride` (1, 2, 4
+ * or 8) apart; `stride` such waves interleave inside a block of 8 * stride columns.  stride 1 (default) =
+ * an 8 x 8 block of adjacent pixels, whose shared sub-cell correlates the noise of neighbouring pixels
+ * (variance of an 8 x 8 tile mean = 38x independent pixels at 4 x 4 sub-cells); stride 8 spreads a wave's
+ * pixels over 64 columns, so that the correlated noise lands on pixels 8 apart.  Per-pixel expectation and
+ * variance do not depend on it; the tile rows (multi-GPU deal) stay 8 rows. */
+lf_status lf_set_tile_stride(lf_ctx* ctx, int stride);
 /* march `spp` sensor samples per pixel of the band through every selected pair and wavelength and
  * accumulate into ghost_buffer (replacing its content).  key seeds the counter RNG. */
 lf_status lf_trace_ghosts(lf_ctx* ctx, int spp, uint64_t key);

@@ -22,6 +22,8 @@ STATUS = {0: "LF_OK", 1: "LF_ERR_INVALID", 2: "LF_ERR_NO_DEVICE", 3: "LF_ERR_HIP
           4: "LF_ERR_STATE", 5: "LF_ERR_OOM"}
 APERTURE_STARBURST, APERTURE_GHOST = 0, 1
 SAMPLE_BUFFER, GHOST_BUFFER, STARBURST_BUFFER, SCENE_BUFFER = 0, 1, 2, 3
+# the sampling specification's defaults (lf_internal.h): 16 x 16 pupil sub-cells, wave tiles with columns 8 apart
+DEFAULT_SUBCELL_BITS, DEFAULT_TILE_STRIDE = 4, 8
 
 # every symbol include/lensflare.h declares
 ABI_SYMBOLS = [
@@ -33,7 +35,7 @@ ABI_SYMBOLS = [
     "lf_set_direct_hemisphere_sample", "lf_collada_check", "lf_render_scene_term",
     "lf_generate_ghost_buffer", "lf_render_flare_layer", "lf_read_tile", "lf_read_pixel",
     "lf_write_to_framebuffer", "lf_save_image_rgba", "lf_device_buffer", "lf_set_lens", "lf_set_lambda_rgb", "lf_set_sun",
-    "lf_set_sun_from_flares", "lf_paraxial_efl", "lf_set_ghost_pairs", "lf_set_pupil_subcells", "lf_trace_ghosts", "lf_generate_lens_rays", "lf_get_counters", "lf_reset_counters", "lf_get_executed_events", "lf_get_march_stats", "lf_native_sqrt", "lf_native_rcp", "lf_set_starburst_spectrum", "lf_load_collada", "lf_march_tables",
+    "lf_set_sun_from_flares", "lf_paraxial_efl", "lf_set_ghost_pairs", "lf_set_pupil_subcells", "lf_set_tile_stride", "lf_trace_ghosts", "lf_generate_lens_rays", "lf_get_counters", "lf_reset_counters", "lf_get_executed_events", "lf_get_march_stats", "lf_native_sqrt", "lf_native_rcp", "lf_set_starburst_spectrum", "lf_load_collada", "lf_march_tables",
     "lf_timing_enable", "lf_timing_reset", "lf_timing_get",
     "lf_clear_ghost_buffer", "lf_draw_ghost", "lf_rasterize_textured_triangle", "lf_fill_textured_pixel",
     "lf_shift_vertex", "lf_compute_phase", "lf_irradiance_falloff", "lf_scene_trace_ray", "lf_scene_shade",
@@ -576,6 +578,9 @@ class LensFlare:
 
     def set_pupil_subcells(self, bits):
         self._ck(self.lib.lf_set_pupil_subcells(self.ctx, int(bits)))
+
+    def set_tile_stride(self, stride):
+        self._ck(self.lib.lf_set_tile_stride(self.ctx, int(stride)))
 
     def trace_ghosts(self, spp, key=0x1e45f1a4e):
         self._ck(self.lib.lf_trace_ghosts(self.ctx, int(spp), C.c_uint64(key)))

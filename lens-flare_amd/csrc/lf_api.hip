@@ -821,6 +821,14 @@ lf_status lf_set_pupil_subcells(lf_ctx* ctx, int bits) {
   return LF_OK;
 }
 
+lf_status lf_set_tile_stride(lf_ctx* ctx, int stride) {
+  if (!ctx) return LF_ERR_INVALID;
+  if (stride != 1 && stride != 2 && stride != 4 && stride != 8)
+    return lf_fail(ctx, LF_ERR_INVALID, "tile stride must be 1, 2, 4 or 8");
+  ctx->march_xstride_log2 = stride == 1 ? 0 : stride == 2 ? 1 : stride == 4 ? 2 : 3;
+  return LF_OK;
+}
+
 lf_status lf_trace_ghosts(lf_ctx* ctx, int spp, uint64_t key) {
   if (!ctx || spp <= 0) return LF_ERR_INVALID;
   if (!ctx->lens_valid || !ctx->sun_valid)

@@ -219,6 +219,7 @@ struct LfLensCamArgs {
   int mode;              // 1 = one reference wavelength carries R, G and B; 2 = one ray per wavelength
   int lambda_ref, n_lambda;
   int order_step;        // iteration i of the sample loop takes the march's sample (i * order_step) mod ns_aa
+  int xs;                // log2 of the wave tile's pixel stride in x (lf_set_tile_stride)
   int W, G;              // sample_start's SampleSpec (the march's sampling specification)
   float inv_G;
   int sub_bits;
@@ -319,7 +320,12 @@ struct lf_ctx {
   // geometric
   LfLensDev lens{};
   bool lens_valid = false, sun_valid = false;
-  int march_sub_bits = 2;  // pupil sub-cells per stratum = 4 x 4 (part of the sampling spec)
+  // the sampling specification's two coherence parameters (round 4 defaults, measured on the bench frame:
+  // profiles/r04_tile_stride.json): 16 x 16 pupil sub-cells per stratum, shared by the 64 pixels of a wave
+  // whose columns are 8 apart -- 109 ms and a tile correlation of 6.9 where rounds 1-3 (4 x 4 sub-cells,
+  // adjacent pixels) had 110 ms and 37.7
+  int march_sub_bits = 4;      // lf_set_pupil_subcells
+  int march_xstride_log2 = 3;  // lf_set_tile_stride: the lanes of a wave take pixels 2^this apart in x
   float sensor_w_mm = 36.0f;
   int raw_n = 0, raw_stop = -1;   // the prescription as handed to lf_set_lens (for lf_paraxial_efl)
   float raw_radius[LF_MAX_SURFACES] = {}, raw_thickness[LF_MAX_SURFACES] = {};

@@ -82,6 +82,7 @@ void lf_fill_lenscam_args(const lf_ctx* ctx, LfLensCamArgs* a) {
     while (gcd(step, spp) != 1) step++;
     a->order_step = step % spp == 0 ? 1 : step;
   }
+  a->xs = ctx->march_xstride_log2;
   a->sub_bits = ctx->march_sub_bits;
   a->inv_sub = 1.0f / (float)(1 << ctx->march_sub_bits);
   a->pitch = ctx->sensor_w_mm / (float)std::max(1, ctx->W);

@@ -96,6 +96,8 @@ struct MarchArgs {
   float vz;            // pupil_z - z_sensor
   float lobe_thr;      // d.s above this may lie inside the sun's lobe (conservative, see lfk_march)
   int accumulate;      // add the launch's pixels to the ghost buffer instead of replacing them
+  int xs;              // log2 of the lanes' pixel stride in x (lf_set_tile_stride): 0 = an 8 x 8 block of
+                       // adjacent pixels per wave, 3 = columns 8 apart (a 64 x 8 block shared by 8 waves)
 };
 
 // The program of a GROUP of up to 3 wavelengths, in two levels (LfProgHdr / LfProgRow in
@@ -215,7 +217,9 @@ void k_march(const LfLensDev* __restrict__ lens, const LfPairsDev* __restrict__ 
   if (tid == 0) s_next = 0;
   __syncthreads();
 
-  const int tiles_x = (a.W + 7) >> 3;
+  // a wave's 64 pixels: 8 rows x 8 columns that are 2^xs apart; 2^xs such waves interleave in a block of
+  // 8 * 2^xs columns.  tx counts waves along x: block (tx >> xs), phase (tx & (2^xs - 1)).
+  const int tiles_x = ((a.W + (8 << a.xs) - 1) >> (3 + a.xs)) << a.xs;
   const int sg = blockIdx.x % a.sgroups, tile_lin = blockIdx.x / a.sgroups;
   const int tx = tile_lin % tiles_x, tj = tile_lin / tiles_x;
   const unsigned tile_id = (unsigned)((a.trow0 + tj * a.tperiod) * tiles_x + tx);  // frame-absolute
@@ -233,7 +237,7 @@ void k_march(const LfLensDev* __restrict__ lens, const LfPairsDev* __restrict__ 
   lanemask active_mask;
   {
     const int lane = tid & 63;
-    const int x = tx * 8 + (lane & 7), y = (a.trow0 + tj * a.tperiod) * 8 + (lane >> 3);
+    const int x = ((tx >> a.xs) << (3 + a.xs)) + ((lane & 7) << a.xs) + (tx & ((1 << a.xs) - 1)), y = (a.trow0 + tj * a.tperiod) * 8 + (lane >> 3);
     active_mask = __ballot(x < a.W && y >= a.y0 && y < a.y1);
   }
 
@@ -268,7 +272,7 @@ void k_march(const LfLensDev* __restrict__ lens, const LfPairsDev* __restrict__ 
       const int s = sg + k * a.sgroups;  // wave-uniform
       if (s >= a.spp) break;
       const int lane = lane_id();
-      const int x = tx * 8 + (lane & 7), y = (a.trow0 + tj * a.tperiod) * 8 + (lane >> 3);
+      const int x = ((tx >> a.xs) << (3 + a.xs)) + ((lane & 7) << a.xs) + (tx & ((1 << a.xs) - 1)), y = (a.trow0 + tj * a.tperiod) * 8 + (lane >> 3);
       const unsigned p = (unsigned)y * (unsigned)a.W + (unsigned)x;
       // ---- sensor sample -> initial ray --------------------------------------------------
       const uint4 rnd = philox4x32_10(make_uint4(p, (unsigned)s, kDomainMarch, 0u), a.key);
@@ -617,7 +621,7 @@ void k_march(const LfLensDev* __restrict__ lens, const LfPairsDev* __restrict__ 
 
   // ---- counters: wave reduce, one LDS add per wave, one global add per workgroup ------------
   const int lane = lane_id();
-  const int x = tx * 8 + (lane & 7), y = (a.trow0 + tj * a.tperiod) * 8 + (lane >> 3);
+  const int x = ((tx >> a.xs) << (3 + a.xs)) + ((lane & 7) << a.xs) + (tx & ((1 << a.xs) - 1)), y = (a.trow0 + tj * a.tperiod) * 8 + (lane >> 3);
   const bool active = x < a.W && y >= a.y0 && y < a.y1;
   const unsigned p = (unsigned)y * (unsigned)a.W + (unsigned)x;
   {
@@ -1113,6 +1117,7 @@ lf_status lfk_march(lf_ctx* ctx, int spp, uint64_t key) {
   a.half_w = 0.5f * (float)ctx->W; a.half_h = 0.5f * (float)ctx->H;
   a.vz = ctx->lens.pupil_z - ctx->lens.z_sensor;
   a.accumulate = ctx->ghost_accumulate ? 1 : 0;
+  a.xs = ctx->march_xstride_log2;
   {
     // candidate selection (the contract, the same expression in oracle/lf_geo_oracle.c): d.s above
     // 1 - 1.0625 (1 - cos alpha) - 4e-7 MAY lie inside the lobe.  The 1/16 margin is relative, the
@@ -1131,7 +1136,7 @@ lf_status lfk_march(lf_ctx* ctx, int spp, uint64_t key) {
   if (first >= t_hi) return LF_OK;
   const int n_trows = (t_hi - 1 - first) / period + 1;
   a.trow0 = first; a.tperiod = period;
-  const size_t tiles = (size_t)n_trows * ((ctx->W + 7) / 8);
+  const size_t tiles = (size_t)n_trows * ((((size_t)ctx->W + (8u << a.xs) - 1) >> (3 + a.xs)) << a.xs);
   // A launch that covers only part of the frame (one GPU's share) splits each tile's samples over
   // `sgroups` workgroups (power of two): more, shorter workgroups keep its tail short -- but a workgroup
   // needs >= 64 samples to amortise its set-up and its 192 global atomics.  The whole frame on one GPU

@@ -183,7 +183,8 @@ struct SampleSpec {
   int W;               // frame width (the pixel index of the counter is x + y W)
   int G;               // G x G pupil strata; samples s >= G * G are unstratified
   float inv_G;
-  int sub_bits;        // 2^sub_bits x 2^sub_bits sub-cells per stratum, drawn per (8 x 8 tile, s)
+  int xs;              // log2 of the pixel stride in x of a wave's tile (lf_set_tile_stride)
+  int sub_bits;        // 2^sub_bits x 2^sub_bits sub-cells per stratum, drawn per (wave tile, s)
   float inv_sub;
   uint2 key;
   float pitch, half_w, half_h;
@@ -231,7 +232,11 @@ __device__ __forceinline__ StartRay sample_start(const SampleSpec& a, int x, int
   float ua = u01(rnd.z), ub = u01(rnd.w);
   if (s < a.G * a.G) {
     const int cy = s / a.G, cx = s - cy * a.G;
-    const unsigned tile_id = (unsigned)((y >> 3) * ((a.W + 7) >> 3) + (x >> 3));
+    // the wave tile of pixel (x, y) as k_march numbers it: tile row y / 8, and along x block x / (8 * 2^xs)
+    // with phase x mod 2^xs
+    const int tiles_x = ((a.W + (8 << a.xs) - 1) >> (3 + a.xs)) << a.xs;
+    const int tx = ((x >> (3 + a.xs)) << a.xs) + (x & ((1 << a.xs) - 1));
+    const unsigned tile_id = (unsigned)((y >> 3) * tiles_x + tx);
     const uint4 r2 = philox4x32_10(make_uint4(tile_id, (unsigned)s, kDomainSubcell, 0u), a.key);
     const unsigned sxi = a.sub_bits ? (r2.x >> (32 - a.sub_bits)) : 0u;
     const unsigned syi = a.sub_bits ? (r2.y >> (32 - a.sub_bits)) : 0u;

@@ -467,7 +467,7 @@ __device__ __forceinline__ void scene_pixel(const LfSceneDev& sc, const LfEnvDev
     V3 L;
     if (LENS) {
       lfm::SampleSpec spec;
-      spec.W = W; spec.G = lc.G; spec.inv_G = lc.inv_G; spec.sub_bits = lc.sub_bits; spec.inv_sub = lc.inv_sub;
+      spec.W = W; spec.xs = lc.xs; spec.G = lc.G; spec.inv_G = lc.inv_G; spec.sub_bits = lc.sub_bits; spec.inv_sub = lc.inv_sub;
       spec.key = key2; spec.pitch = lc.pitch; spec.half_w = lc.half_w; spec.half_h = lc.half_h;
       spec.pupil_h = lc.pupil_h; spec.vz = lc.vz; spec.geom_norm = lc.geom_norm;
       // (the march's samples in an order whose prefixes cover the pupil: lf_fill_lenscam_args)

@@ -297,6 +297,9 @@ static double g64_pupil_h = 0.0, g64_pupil_z = 0.0;
 void g64_set_pupil_target(double h, double z) { g64_pupil_h = h; g64_pupil_z = z; }
 /* g64_trace only traces the pixels with x in [x0, x1) (the others stay 0 and launch nothing): a window of
  * a wide band keeps a full-sample-count check inside a test's time budget.  Default: every column. */
+/* log2 of the pixel stride in x of a wave's tile (lf_set_tile_stride): which pixels share a sub-cell draw */
+static int g64_xs = 3;   /* the library's default: columns 8 apart */
+void g64_set_tile_stride_log2(int xs) { g64_xs = xs; }
 static int g64_x0 = 0, g64_x1 = 1 << 30;
 void g64_set_x_window(int x0, int x1) { g64_x0 = x0; g64_x1 = x1; }
 
@@ -313,7 +316,9 @@ static double sample_ray(const g64_lens* L, const g64_system* S, int W, int H, i
   while (G * G > spp) G--;
   if (s < G * G) {
     const int cy = s / G, cx = s % G;
-    const uint32_t tile = (uint32_t)((y / 8) * ((W + 7) / 8) + x / 8);
+    const int per_block = 1 << g64_xs, block_w = 8 * per_block;
+    const int tiles_x = ((W + block_w - 1) / block_w) * per_block;
+    const uint32_t tile = (uint32_t)((y / 8) * tiles_x + (x / block_w) * per_block + x % per_block);
     const uint32_t c2[4] = {tile, (uint32_t)s, 0x51bce110u, 0u};
     uint32_t r2[4];
     philox64(c2, key, r2);

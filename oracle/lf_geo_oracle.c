@@ -283,8 +283,11 @@ static int strata(int spp) {
 
 /* each stratum is split into 2^SUB_BITS x 2^SUB_BITS sub-cells; the sub-cell of sample s is drawn
  * once per 8x8 sensor tile: Philox(ctr = (tile id, s, 0x51bce110, 0), key) */
-static int g_sub_bits = 2;
+static int g_sub_bits = 4;   /* the library's default (lf_internal.h) */
 void geo_set_sub_bits(int b) { g_sub_bits = b; }
+/* log2 of the pixel stride in x of a wave's tile (lf_set_tile_stride): which pixels share a sub-cell draw */
+static int g_xs = 3;         /* the library's default: columns 8 apart */
+void geo_set_tile_stride_log2(int xs) { g_xs = xs; }
 
 /* sensor point (X, Y) mm + pupil-square point (pa, pb) in [-1, 1]^2 -> start ray (unit direction, weight =
  * the disc's solid-angle factor x cos^4): what k_march, k_lens_rays and the lens camera all start from */
@@ -320,7 +323,9 @@ static float start_ray(const geo_derived* D, int W, int H, int x, int y, int s, 
   if (s < G * G) {
     float inv_g = 1.0f / (float)G, inv_sub = 1.0f / (float)(1 << g_sub_bits);
     int cy = s / G, cx = s - cy * G;
-    uint32_t tile = (uint32_t)((y >> 3) * ((W + 7) >> 3) + (x >> 3));
+    int tiles_x = ((W + (8 << g_xs) - 1) >> (3 + g_xs)) << g_xs;
+    int tx = ((x >> (3 + g_xs)) << g_xs) + (x & ((1 << g_xs) - 1));
+    uint32_t tile = (uint32_t)((y >> 3) * tiles_x + tx);
     uint32_t ctr[4] = {tile, (uint32_t)s, 0x51bce110u, 0u}, r2[4];
     philox(ctr, key, r2);
     uint32_t sxi = g_sub_bits ? (r2[0] >> (32 - g_sub_bits)) : 0u;

@@ -251,6 +251,13 @@ def set_pupil_target(radius_mm=0.0, z_mm=0.0):
     lib().g64_set_pupil_target(C.c_double(float(np.float32(radius_mm))), C.c_double(float(np.float32(z_mm))))
 
 
+def set_tile_stride(stride=8):
+    """Both tracers: the pixel stride in x of a wave's tile (lf_set_tile_stride; 1, 2, 4 or 8)."""
+    xs = {1: 0, 2: 1, 4: 2, 8: 3}[int(stride)]
+    lib().geo_set_tile_stride_log2(xs)
+    lib().g64_set_tile_stride_log2(xs)
+
+
 def all_pairs(lens, include_primary=True):
     n, stop = int(lens["n"]), int(lens["stop"])
     out = [(-1, -1)] if include_primary else []
@@ -497,7 +504,7 @@ G64_COUNTERS = ("rays_launched", "surface_events", "rays_clipped_stop", "rays_vi
 
 
 def g64_trace(lens, W, H, y0, y1, spp, key, pairs, include_primary, mask, sun_dir, sun_radiance,
-              sun_angular_radius, n_threads=8, lambda_rgb=None, sub_bits=2, **eps):
+              sun_angular_radius, n_threads=8, lambda_rgb=None, sub_bits=4, **eps):
     """-> (image, frag, counters): image / frag are H x W x 3; a faithful float32 evaluation of the
     same estimator satisfies |pixel32 - image| <= tol * image + frag (see lf_geo_f64.c)."""
     L = g64_lens(lens, sun_dir, sun_radiance, sun_angular_radius, lambda_rgb, **eps)
@@ -604,7 +611,7 @@ def geo_lens_samples(lens, W, H, ns, key, lam, pixels, mask):
     return out
 
 
-def g64_lens_samples(lens, W, H, ns, key, lam, pixels, mask, sub_bits=2, **eps):
+def g64_lens_samples(lens, W, H, ns, key, lam, pixels, mask, sub_bits=4, **eps):
     """float64 tracer: (n_pix, ns, 10) {origin, unit direction, weight, potential weight, fragile, dead}."""
     L = g64_lens(lens, **eps)
     pixels = np.ascontiguousarray(pixels, np.int32)

@@ -5,7 +5,7 @@
 # Nothing is built here: the library must exist BEFORE the profiler starts (no exec of hipcc under it).
 set -e
 [ -f lens-flare_amd/liblensflare_hip.so ] || { echo "liblensflare_hip.so missing: run __graft_entry__.build() first" >&2; exit 1; }
-TAG=${1:-r03}
+TAG=${1:-r04}
 CFG=${2:-c3}
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
 OUT=gpurun_out/pmc_$TAG

@@ -110,7 +110,7 @@ for bits in (0, 2, 3, 4):
         "mean_total_ratio_to_default": float(m.sum() / m0.sum()),
         # 1 = the 64 pixels of a tile are independent; 64 = they move together
         "tile_correlation": float(64.0 * tv[tl].sum() / v.reshape(H // 8, 8, W // 8, 8).mean(axis=(1, 3))[tl].sum())}
-lf.set_pupil_subcells(2)
+lf.set_pupil_subcells(pkg.DEFAULT_SUBCELL_BITS)
 out["note"] = ("variance = sample variance over independent keys, summed over the lit pixels (mean > 1e-4 of the "
                "peak); tile_correlation = 64 Var(tile mean) / mean pixel variance over fully lit 8x8 tiles")
 print(json.dumps(out, indent=1))

@@ -30,7 +30,7 @@ res = {"kernel": kern, "config": cfg,
        "per_launch": {c: sums[c] / max(1, len(disp[c])) for c in sums},
        "launches": {c: len(disp[c]) for c in sums}}
 h = hashlib.sha256()
-for f in ("lens-flare_amd/csrc/lf_march.hip", "lens-flare_amd/csrc/lf_internal.h"):
+for f in ("lens-flare_amd/csrc/lf_march.hip", "lens-flare_amd/csrc/lf_march_events.h", "lens-flare_amd/csrc/lf_internal.h"):
     h.update(open(os.path.join(root, f), "rb").read())
 mk = open(os.path.join(root, "lens-flare_amd", "Makefile")).read()
 h.update(mk[mk.index("FLAGS  :="):mk.index("SRCS   :=")].encode())   # the compile flags, as bench.py hashes them

@@ -33,7 +33,7 @@ def lf(pkg):
     ctx.close()
 
 
-def _gpu_frame(pkg, lf, lens, W, H, spp, key, mask, sun, rad, alpha, sub_bits=2, pairs=None):
+def _gpu_frame(pkg, lf, lens, W, H, spp, key, mask, sun, rad, alpha, sub_bits=4, pairs=None):
     lf.set_frame(W, H)
     lf.set_aperture(pkg.APERTURE_STARBURST, mask)
     lf.set_lens(lens)
@@ -44,7 +44,7 @@ def _gpu_frame(pkg, lf, lens, W, H, spp, key, mask, sun, rad, alpha, sub_bits=2,
     lf.trace_ghosts(spp, key)
     img = lf.read_buffer(pkg.GHOST_BUFFER)
     cnt = lf.counters()
-    lf.set_pupil_subcells(2)
+    lf.set_pupil_subcells(pkg.DEFAULT_SUBCELL_BITS)
     return img, cnt
 
 
@@ -135,7 +135,7 @@ def test_eight_wavelengths_within_1e4(pkg, lf):
 
 
 def test_pupil_subcells_converge_to_the_independent_estimate(pkg, lf):
-    """All 64 pixels of an 8x8 tile share one pupil sub-cell per sample (coherent fate at the mask):
+    """All 64 pixels of a wave tile share one pupil sub-cell per sample (coherent fate at the mask):
     per pixel that is still a uniform draw from the stratum, so the estimator is unbiased, but the
     noise is correlated inside a tile.  Check against the fully independent estimator (bits = 0):
     the means over 12 keys agree within the Monte-Carlo error per pixel and in total, and the two
@@ -146,10 +146,10 @@ def test_pupil_subcells_converge_to_the_independent_estimate(pkg, lf):
     sun, rad, alpha = [0.03, 0.02, -1.0], [1.0, 0.9, 0.5], 0.05
     keys = [0x1000 + 17 * k for k in range(12)]
     runs = {}
-    for bits in (2, 0):
+    for bits in (4, 0):
         runs[bits] = np.stack([_gpu_frame(pkg, lf, lens, W, H, spp, k, mask, sun, rad, alpha,
                                           sub_bits=bits)[0].sum(axis=2) for k in keys])
-    a, b = runs[2], runs[0]
+    a, b = runs[4], runs[0]
     ma, mb = a.mean(axis=0), b.mean(axis=0)
     se = np.sqrt((a.var(axis=0, ddof=1) + b.var(axis=0, ddof=1)) / len(keys))
     lit = (ma + mb) > 2 * FLOOR

@@ -539,3 +539,37 @@ def test_empty_band_and_tonemap_rows(pkg, lf):
     tile = lf.write_to_framebuffer(0, 32, 32, 48)   # rows outside the band
     assert np.array_equal(tile, case.rgba[32:48, 0:32])
     lf.set_band(0, case.H)
+
+
+@pytest.mark.parametrize("stride,W,H", [(1, 100, 24), (1, 64, 16), (2, 50, 12), (4, 33, 9)])
+def test_tile_stride_bit_exact(pkg, lf, stride, W, H):
+    """lf_set_tile_stride: the lanes of a wave take pixels `stride` apart in x (round 4 default: 8 -- the
+    shared pupil sub-cell then correlates pixels 8 apart instead of neighbours; every other test of this
+    file runs that default).  A sampling-specification parameter like
+    the sub-cells: pixels and counters stay those of the oracle, which derives the sub-cell of a pixel from
+    the same tile numbering -- frame widths that are no multiple of the block included."""
+    lens = pkg.load_lens_file("dgauss11.lens")
+    mask = load_texels("pentbig500_14.png")
+    lf.set_tile_stride(stride)
+    lfo.set_tile_stride(stride)
+    try:
+        g, cnt, og, ocnt = _run(pkg, lf, lens, W, H, 16, 0x57D + stride, mask)
+        assert cnt == ocnt and cnt["rays_launched"] == W * H * 16 * 3 * 46
+        assert np.array_equal(g, og) and og.max() > 0
+        # not the default specification (columns 8 apart): the same key draws other sub-cells there
+        lf.set_tile_stride(pkg.DEFAULT_TILE_STRIDE)
+        lf.trace_ghosts(16, 0x57D + stride)
+        assert not np.array_equal(lf.read_buffer(pkg.GHOST_BUFFER), g)
+        # a band of tile rows under the interleave of a multi-GPU deal
+        lf.set_tile_stride(stride)
+        lf.set_row_interleave(1, 2)
+        lf.clear_ghost_buffer()
+        lf.trace_ghosts(16, 0x57D + stride)
+        part = lf.read_buffer(pkg.GHOST_BUFFER)
+        own = (np.arange(H) // 8) % 2 == 1
+        assert np.array_equal(part[own], og[own]) and not part[~own].any()
+    finally:
+        lf.set_row_interleave(0, 1)
+        lf.set_tile_stride(pkg.DEFAULT_TILE_STRIDE)
+        lfo.set_tile_stride(pkg.DEFAULT_TILE_STRIDE)
+
