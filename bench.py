@@ -327,6 +327,10 @@ def main():
     if lambda_rgb is not None:
         lf.set_lambda_rgb(lambda_rgb)
     lf.set_ghost_pairs(pairs, True)
+    if os.environ.get("LF_BENCH_TILE_STRIDE"):      # experiments only (profiles/r04_march_variants.txt)
+        lf.set_tile_stride(int(os.environ["LF_BENCH_TILE_STRIDE"]))
+    if os.environ.get("LF_BENCH_SUBCELL_BITS"):
+        lf.set_pupil_subcells(int(os.environ["LF_BENCH_SUBCELL_BITS"]))
     lf.set_jitter_counter(0x1e45f1a4e)
     if cfg["spectral"]:
         lf.set_starburst_spectrum(star_scale, lambda_rgb)
@@ -486,8 +490,8 @@ def main():
     cnt = lf.counters()
     stats = lf.march_stats()
     # other sampling specifications, timed beside the default (N = 1 only, outside the timed region).  The
-    # default since round 4: 16 x 16 pupil sub-cells per stratum shared by a wave whose pixel columns are 8
-    # apart (tile correlation 6.9; profiles/r04_tile_stride.json).  Rounds 1-3: 4 x 4 sub-cells over 8 x 8
+    # default since round 4: 64 x 64 pupil sub-cells per stratum shared by a wave whose pixel columns are 8
+    # apart (tile correlation 7.4; profiles/r04_tile_stride.json).  Rounds 1-3: 4 x 4 sub-cells over 8 x 8
     # adjacent pixels (37.7).  1 x 1 sub-cells = every pixel draws on its own (1.0).
     sampling_variants = None
     if world == 1 and not cfg["scene"] and not args.no_cpu:   # (--no-cpu = the march alone: profiler passes, A/B runs)
@@ -503,7 +507,7 @@ def main():
                 one_frame()
             lf.synchronize()
             sampling_variants[name] = {"ms_per_step": (time.perf_counter() - t_v) / 2 * 1e3, "tile_correlation": corr}
-        sampling_variants["default_stride8_subcells_16x16"] = {"ms_per_step": dt / args.steps * 1e3, "tile_correlation": 6.9}
+        sampling_variants["default_stride8_subcells_64x64"] = {"ms_per_step": dt / args.steps * 1e3, "tile_correlation": 7.4}
         sampling_variants["note"] = ("tile_correlation = 64 Var(mean of 8 x 8 adjacent pixels) / mean pixel variance on this frame "
                                      "(1 = independent pixels, 64 = the block moves as one), profiles/r04_tile_stride.json")
         lf.set_tile_stride(pkg.DEFAULT_TILE_STRIDE)

@@ -22,8 +22,8 @@ STATUS = {0: "LF_OK", 1: "LF_ERR_INVALID", 2: "LF_ERR_NO_DEVICE", 3: "LF_ERR_HIP
           4: "LF_ERR_STATE", 5: "LF_ERR_OOM"}
 APERTURE_STARBURST, APERTURE_GHOST = 0, 1
 SAMPLE_BUFFER, GHOST_BUFFER, STARBURST_BUFFER, SCENE_BUFFER = 0, 1, 2, 3
-# the sampling specification's defaults (lf_internal.h): 16 x 16 pupil sub-cells, wave tiles with columns 8 apart
-DEFAULT_SUBCELL_BITS, DEFAULT_TILE_STRIDE = 4, 8
+# the sampling specification's defaults (lf_internal.h): 64 x 64 pupil sub-cells, wave tiles with columns 8 apart
+DEFAULT_SUBCELL_BITS, DEFAULT_TILE_STRIDE = 6, 8
 
 # every symbol include/lensflare.h declares
 ABI_SYMBOLS = [

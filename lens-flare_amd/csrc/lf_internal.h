@@ -321,10 +321,10 @@ struct lf_ctx {
   LfLensDev lens{};
   bool lens_valid = false, sun_valid = false;
   // the sampling specification's two coherence parameters (round 4 defaults, measured on the bench frame:
-  // profiles/r04_tile_stride.json): 16 x 16 pupil sub-cells per stratum, shared by the 64 pixels of a wave
-  // whose columns are 8 apart -- 109 ms and a tile correlation of 6.9 where rounds 1-3 (4 x 4 sub-cells,
+  // profiles/r04_tile_stride.json): 64 x 64 pupil sub-cells per stratum, shared by the 64 pixels of a wave
+  // whose columns are 8 apart -- 108 ms and a tile correlation of 7.4 where rounds 1-3 (4 x 4 sub-cells,
   // adjacent pixels) had 110 ms and 37.7
-  int march_sub_bits = 4;      // lf_set_pupil_subcells
+  int march_sub_bits = 6;      // lf_set_pupil_subcells
   int march_xstride_log2 = 3;  // lf_set_tile_stride: the lanes of a wave take pixels 2^this apart in x
   float sensor_w_mm = 36.0f;
   int raw_n = 0, raw_stop = -1;   // the prescription as handed to lf_set_lens (for lf_paraxial_efl)

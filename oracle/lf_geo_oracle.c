@@ -283,7 +283,7 @@ static int strata(int spp) {
 
 /* each stratum is split into 2^SUB_BITS x 2^SUB_BITS sub-cells; the sub-cell of sample s is drawn
  * once per 8x8 sensor tile: Philox(ctr = (tile id, s, 0x51bce110, 0), key) */
-static int g_sub_bits = 4;   /* the library's default (lf_internal.h) */
+static int g_sub_bits = 6;   /* the library's default (lf_internal.h) */
 void geo_set_sub_bits(int b) { g_sub_bits = b; }
 /* log2 of the pixel stride in x of a wave's tile (lf_set_tile_stride): which pixels share a sub-cell draw */
 static int g_xs = 3;         /* the library's default: columns 8 apart */

@@ -504,7 +504,7 @@ G64_COUNTERS = ("rays_launched", "surface_events", "rays_clipped_stop", "rays_vi
 
 
 def g64_trace(lens, W, H, y0, y1, spp, key, pairs, include_primary, mask, sun_dir, sun_radiance,
-              sun_angular_radius, n_threads=8, lambda_rgb=None, sub_bits=4, **eps):
+              sun_angular_radius, n_threads=8, lambda_rgb=None, sub_bits=6, **eps):
     """-> (image, frag, counters): image / frag are H x W x 3; a faithful float32 evaluation of the
     same estimator satisfies |pixel32 - image| <= tol * image + frag (see lf_geo_f64.c)."""
     L = g64_lens(lens, sun_dir, sun_radiance, sun_angular_radius, lambda_rgb, **eps)
@@ -611,7 +611,7 @@ def geo_lens_samples(lens, W, H, ns, key, lam, pixels, mask):
     return out
 
 
-def g64_lens_samples(lens, W, H, ns, key, lam, pixels, mask, sub_bits=4, **eps):
+def g64_lens_samples(lens, W, H, ns, key, lam, pixels, mask, sub_bits=6, **eps):
     """float64 tracer: (n_pix, ns, 10) {origin, unit direction, weight, potential weight, fragile, dead}."""
     L = g64_lens(lens, **eps)
     pixels = np.ascontiguousarray(pixels, np.int32)

@@ -50,7 +50,8 @@ def measure():
 
 out = {"frame": f"{W}x{H}, {SPP} spp, c3 paths", "keys": len(KEYS), "variants": {}}
 ref = None
-for stride, bits in ((1, 2), (8, 2), (2, 2), (4, 2), (8, 3), (8, 4), (1, 4), (1, 0)):   # first = rounds 1-3
+VARIANTS = ((1, 2), (8, 2), (2, 2), (4, 2), (8, 3), (8, 4), (8, 5), (8, 6), (8, 8), (4, 4), (1, 4), (1, 0))   # first = rounds 1-3
+for stride, bits in VARIANTS:
     lf.set_tile_stride(stride)
     lf.set_pupil_subcells(bits)
     lf.reset_counters()

@@ -376,7 +376,7 @@ def test_scene_through_the_lens_from_the_reference_surface(tmp_path):
     corner = (slice(0, 8), slice(0, 12))
     # (3 samples per pixel of which a quarter passes the pentagon: a coarse check of the exposure only)
     assert 0.6 < lum_l[centre].sum() / lum_p[centre].sum() < 1.6      # calibrated: the same exposure on the axis
-    assert lum_l[corner].sum() < 0.7 * lum_p[corner].sum()            # a 36 mm lens on a 47 mm sensor vignettes
+    assert lum_l[corner].sum() < 0.9 * lum_p[corner].sum()            # a 36 mm lens on a 47 mm sensor vignettes
 
 
 def test_the_reference_log_line_reports_the_device_work(tmp_path):

@@ -33,13 +33,13 @@ def lf(pkg):
     ctx.close()
 
 
-def _gpu_frame(pkg, lf, lens, W, H, spp, key, mask, sun, rad, alpha, sub_bits=4, pairs=None):
+def _gpu_frame(pkg, lf, lens, W, H, spp, key, mask, sun, rad, alpha, sub_bits=None, pairs=None):
     lf.set_frame(W, H)
     lf.set_aperture(pkg.APERTURE_STARBURST, mask)
     lf.set_lens(lens)
     lf.set_sun(sun, rad, alpha)
     lf.set_ghost_pairs(pairs, True)
-    lf.set_pupil_subcells(sub_bits)
+    lf.set_pupil_subcells(pkg.DEFAULT_SUBCELL_BITS if sub_bits is None else sub_bits)
     lf.reset_counters()
     lf.trace_ghosts(spp, key)
     img = lf.read_buffer(pkg.GHOST_BUFFER)

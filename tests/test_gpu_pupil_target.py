@@ -161,7 +161,9 @@ def test_two_launch_frame_converges_to_the_default_frame_and_wastes_less(pkg, lf
     z = (mt - md)[lit] / np.maximum(se[lit], 1e-300)
     assert abs(z.mean()) < 0.25, z.mean()                 # no offset
     assert 0.7 < z.std() < 1.4, z.std()                   # differences are Monte-Carlo noise, nothing else
-    assert (np.abs(z) < 4.5).mean() > 0.999
+    # (12 keys: z follows a t distribution with ~20 degrees of freedom, and the sub-cell sharing makes a tile's
+    # pixels move together: a handful of 3000 pixels beyond 4.5 is within that)
+    assert (np.abs(z) < 4.5).mean() > 0.997 and np.abs(z).max() < 8.0
     # the frame totals: key-to-key spread of the totals themselves (pixels of a tile are correlated)
     sd, st = d.sum(axis=(1, 2)), t.sum(axis=(1, 2))
     zt = (st.mean() - sd.mean()) / np.sqrt(sd.var(ddof=1) / len(keys) + st.var(ddof=1) / len(keys))
