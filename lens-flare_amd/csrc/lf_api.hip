@@ -187,7 +187,7 @@ lf_status lf_create(lf_ctx** out, int device) {
     return LF_ERR_HIP;
   }
   ctx->own_stream = true;
-  // tuning knob for experiments only (changes the sampling pattern; the oracle/tests use 2)
+  // tuning knob for experiments only (changes the sampling pattern; the oracles / tests use the default, 6)
   if (const char* sb = std::getenv("LF_MARCH_SUB_BITS")) {
     int v = std::atoi(sb);
     if (v >= 0 && v <= 8) ctx->march_sub_bits = v;

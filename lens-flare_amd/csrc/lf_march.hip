@@ -96,6 +96,7 @@ struct MarchArgs {
   float vz;            // pupil_z - z_sensor
   float lobe_thr;      // d.s above this may lie inside the sun's lobe (conservative, see lfk_march)
   int accumulate;      // add the launch's pixels to the ghost buffer instead of replacing them
+  int n_tiles;         // wave tiles of the launch (the grid holds them padded to a multiple of 64)
   int xs;              // log2 of the lanes' pixel stride in x (lf_set_tile_stride): 0 = an 8 x 8 block of
                        // adjacent pixels per wave, 3 = columns 8 apart (a 64 x 8 block shared by 8 waves)
 };
@@ -220,7 +221,15 @@ void k_march(const LfLensDev* __restrict__ lens, const LfPairsDev* __restrict__ 
   // a wave's 64 pixels: 8 rows x 8 columns that are 2^xs apart; 2^xs such waves interleave in a block of
   // 8 * 2^xs columns.  tx counts waves along x: block (tx >> xs), phase (tx & (2^xs - 1)).
   const int tiles_x = ((a.W + (8 << a.xs) - 1) >> (3 + a.xs)) << a.xs;
-  const int sg = blockIdx.x % a.sgroups, tile_lin = blockIdx.x / a.sgroups;
+  // Workgroup -> tile, XCD-aware: blocks b and b + 8 share an XCD (its L2), and the 8 wave tiles that
+  // interleave in one 64-column block write 24-byte pixels that alternate inside the same cache lines.  Swapping
+  // the two 3-bit fields of the slot index puts those 8 tiles on ONE XCD, a few dispatch slots apart, so that
+  // their partial lines meet in that XCD's L2 and leave it whole (without it the launch wrote 100 MB for its
+  // 50 MB of pixels: profiles/r04_march_variants.txt).  The slot range is padded to a multiple of 64.
+  const int sg = blockIdx.x % a.sgroups;
+  const unsigned slot = blockIdx.x / a.sgroups;
+  const int tile_lin = (int)((slot & ~63u) | ((slot & 7u) << 3) | ((slot >> 3) & 7u));
+  if (tile_lin >= a.n_tiles) return;   // (the whole workgroup, before any barrier)
   const int tx = tile_lin % tiles_x, tj = tile_lin / tiles_x;
   const unsigned tile_id = (unsigned)((a.trow0 + tj * a.tperiod) * tiles_x + tx);  // frame-absolute
   // Everything that depends on the lane (pixel coordinates, LDS addresses) is re-derived from the
@@ -1150,7 +1159,8 @@ lf_status lfk_march(lf_ctx* ctx, int spp, uint64_t key) {
     int v = std::atoi(sgv);
     if (v >= 1 && v * 4 <= std::max(4, spp) && (v & (v - 1)) == 0) a.sgroups = v;
   }
-  const size_t blocks = tiles * a.sgroups;
+  a.n_tiles = (int)tiles;
+  const size_t blocks = ((tiles + 63) / 64 * 64) * a.sgroups;
   if (blocks > 0x7fffffffull) return lf_fail(ctx, LF_ERR_INVALID, "band too large for one launch");
   const size_t n_acc = (size_t)ctx->W * ctx->H_alloc * 3;
   if (a.sgroups > 1) {
