@@ -100,6 +100,7 @@ struct DeviceState {
   std::string lens_loaded;             // file that is on the device ...
   size_t lens_w = 0, lens_h = 0;       // ... for this frame size (the pixel pitch depends on it)
   bool mirror_ghost = false;           // LF_MIRROR_GHOST_BUFFER: fill the public ghost_buffer field every frame
+  double lens_focus_mm = 0.0;          // object distance the loaded lens was last focused at (0: as the file says)
   double world_per_mm = 0.001;         // LF_WORLD_PER_MM: scene units per lens millimetre (lens camera; 1 unit = 1 m)
   bool log_frame = true;               // LF_QUIET unset: one stdout line per frame for the march / the lens camera
   // what the device's scene kernel counted for the frame (BVHAccel::total_rays / total_isects, bvh.h:136)
@@ -297,7 +298,7 @@ PathTracer::PathTracer() {
   s.sample.clear(); s.rgba.clear(); s.star.clear();
   s.star_ready = s.frame_ready = false;
   s.textures_of = s.scene_of = s.env_of = nullptr;
-  s.lens_loaded.clear(); s.lens_w = s.lens_h = 0;
+  s.lens_loaded.clear(); s.lens_w = s.lens_h = 0; s.lens_focus_mm = 0.0;
   const char* dev = getenv("LF_DEVICE");
   if (lf_create(&s.ctx, dev ? atoi(dev) : 0) != LF_OK) {
     fprintf(stderr, "[PathTracer/MI355X] no gfx950 device: this build has no CPU path\n");
@@ -415,6 +416,7 @@ void PathTracer::generate_ghost_buffer() {                         // pathtracer
     if (s.lens_loaded != lens_file || s.lens_w != W || s.lens_h != H) {
       check(s, lf_load_lens_file(s.ctx, lens_file.c_str()), "lf_load_lens_file");
       s.lens_loaded = lens_file; s.lens_w = W; s.lens_h = H;
+      s.lens_focus_mm = 0.0;
     }
     // no sun in the frame: nothing to march towards (:724-726)
     plan.ghosts = flare_origins.empty() ? LF_FRAME_GHOSTS_NONE : LF_FRAME_GHOSTS_MARCH;
@@ -427,6 +429,20 @@ void PathTracer::generate_ghost_buffer() {                         // pathtracer
     // Camera::generate_ray is not virtual (camera.h:166), so the reference's loop could never reach a
     // lens; the device's loop does.  LF_LENS_PINHOLE_SCENE / LensCamera::image_scene = false keep the
     // reference's pinhole for the scene term (ghosts through the lens, scene through a pinhole: rounds 1-3).
+    // Camera::lensRadius / focalDistance (camera.h:171-172; the -b / -d flags, autofocus): lensRadius > 0 is the
+    // reference's switch for its (stubbed) thin lens.  With a real lens it asks for the focus to FOLLOW
+    // focalDistance -- the sensor moves to the paraxial image of that distance (lf_focus_lens); otherwise the
+    // prescription's own last thickness stands (the shipped files: focus at infinity).
+    {
+      const double wpm = lens_cam ? lens_cam->world_per_mm : s.world_per_mm;
+      const double want = (camera->lensRadius > 0 && std::isfinite(camera->focalDistance) && camera->focalDistance > 0)
+                              ? camera->focalDistance / wpm : 0.0;
+      if (want != s.lens_focus_mm) {
+        if (want > 0) check(s, lf_focus_lens(s.ctx, want, nullptr), "lf_focus_lens");
+        else check(s, lf_load_lens_file(s.ctx, lens_file.c_str()), "lf_load_lens_file");
+        s.lens_focus_mm = want;
+      }
+    }
     const bool through_lens = lens_cam ? lens_cam->image_scene : getenv("LF_LENS_PINHOLE_SCENE") == nullptr;
     if (through_lens) {
       plan.lens_camera_mode = (lens_cam ? lens_cam->chromatic : getenv("LF_LENS_CHROMATIC") != nullptr) ? 2 : 1;

@@ -42,14 +42,14 @@ CASES = ["f64x48_pentbiglines", "f97x65_odd_rotcam", "f80x50_two_suns", "f96x64_
          "q47x31_fuzz0", "q38x52_fuzz1", "q52x40_fuzz4"]
 
 
-def _write_inputs(case, tmp):
+def _write_inputs(case, tmp, focus="4.7 0"):
     m = case.meta
     cam = tmp / "cam.txt"
     sd = case.H / (2 * math.tan(math.radians(m["vFov"]) / 2))
     with open(cam, "w") as f:     # Camera::load_settings (camera.cpp:228-242)
         f.write(f"{m['hFov']!r} {m['vFov']!r} {case.W / case.H!r} 0.01 100\n")
         f.write(" ".join(repr(float(v)) for v in m["cam_pos"]) + " 0 0 0\n1.5 0.7 5 0.5 100\n")
-        f.write(" ".join(repr(float(v)) for v in m["c2w"]) + f"\n{case.W} {case.H} {sd!r}\n4.7 0\n")
+        f.write(" ".join(repr(float(v)) for v in m["c2w"]) + f"\n{case.W} {case.H} {sd!r}\n{focus}\n")   # focalDistance lensRadius
     spec = ";".join(",".join(repr(float(v)) for v in l) for l in m["lights"])
     args = [str(cam), str(case.W), str(case.H), str(m["ns_aa"]), repr(float(m["flare_radius"])),
             repr(float(m["flare_intensity"])), os.path.join(GOLD, "apertures", m["aperture"]),
@@ -327,9 +327,9 @@ def test_scene_through_the_lens_from_the_reference_surface(tmp_path):
     lens_path = os.path.join(ROOT, "lens-flare_amd", "data", "dgauss11.lens")
     spp, key, radius, wpm = 4, 0x51a7, 0.04, 0.002
 
-    def run(extra, sub):
+    def run(extra, sub, focus="4.7 0"):
         (tmp_path / sub).mkdir()
-        args = _write_inputs(case, tmp_path / sub)
+        args = _write_inputs(case, tmp_path / sub, focus)
         args[6] = os.path.join(GOLD, "apertures", "pentbig500_14.png")
         env = dict(os.environ, REF_LENS_CAMERA=lens_path, REF_LENS_SPP=str(spp), REF_LENS_SUN_RADIUS=repr(radius),
                    LF_GEOMETRIC_KEY=hex(key), REF_LENS_WORLD_PER_MM=repr(wpm), **extra)
@@ -367,6 +367,30 @@ def test_scene_through_the_lens_from_the_reference_surface(tmp_path):
     # (the host hands materials over as the value of BSDF::f, the direct call as a reflectance the device
     # divides by pi itself: the last bit of a shaded value may differ, nothing else)
     assert np.allclose(sample, want, rtol=1e-12, atol=0)
+    # Camera::lensRadius > 0 (the reference's switch for its thin-lens stub, the -b flag): the focus follows
+    # Camera::focalDistance -- the frame of a lens refocused at 4.2 units (lf_focus_lens), ghosts included
+    sample_f, ghost_f, _ = run({}, "focused", focus="4.2 0.01")
+    lf = pkg.LensFlare(0)
+    lf.set_frame(case.W, case.H)
+    lf.set_aperture(pkg.APERTURE_STARBURST, load_texels("pentbig500_14.png"))
+    lf.set_aperture(pkg.APERTURE_GHOST, load_texels(m["ghost_aperture"]))
+    lf.load_lens_file(lens_path)
+    sensor_mm = lf.focus_lens(4.2 / wpm)
+    assert sensor_mm > 36.2                                   # the file's back focal distance is 36.106 (infinity)
+    lf.set_camera(m["c2w"], m["cam_pos"], m["hFov"], m["vFov"])
+    lf.set_sampling(32, 0.05, 0.01, 100.0)
+    lf.find_sun_pos(m["lights"])
+    lf.set_scene(spheres, [tuple(t) for t in sc["tris"]], scene_lights(case))
+    lf.set_params(m["ns_aa"], m["flare_radius"], m["flare_intensity"])
+    lf.set_jitter_counter(key)
+    lf.set_lens_camera(1, wpm, 0.0)
+    lf.render_scene_term()
+    lf.set_sun_from_flares(0, 0.0, radius)
+    lf.trace_ghosts(spp, key)
+    lf.render_flare_layer()
+    assert np.array_equal(ghost_f, lf.read_buffer(pkg.GHOST_BUFFER)) and not np.array_equal(ghost_f, ghost)
+    assert np.allclose(sample_f, lf.read_buffer(pkg.SAMPLE_BUFFER), rtol=1e-12, atol=0)
+    lf.close()
     # the pinhole scene under the same ghosts
     sample_p, ghost_p, _ = run({"REF_LENS_IMAGE_SCENE": "0", "LF_COUNTER_JITTER": hex(key)}, "pinhole")
     assert np.array_equal(ghost_p, ghost)

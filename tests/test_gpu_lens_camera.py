@@ -379,3 +379,41 @@ def test_lens_camera_preconditions(pkg, lf):
     lf.set_aperture(pkg.APERTURE_STARBURST, np.zeros((16, 16), np.float32))
     with pytest.raises(pkg.LensFlareError, match="no on-axis sample"):
         lf.render_scene_term()
+
+
+@pytest.mark.parametrize("lens_name,W,H,ns", [("dgauss11.lens", 50, 27, 1), ("dgauss11.lens", 33, 20, 5),
+                                                ("thinlens.lens", 40, 18, 7)])
+def test_odd_frames_sample_counts_and_the_multi_gpu_deal(pkg, lf, sqrt_table, lens_name, W, H, ns):
+    """Frame sizes that are no multiple of the wave tile, sample counts that are no square (part of the
+    samples is unstratified), a lens without a stop -- and the tile-row deal of a multi-GPU frame: a context
+    that owns every second tile row renders exactly those rows of the same frame."""
+    lens = pkg.load_lens_file(lens_name)
+    mask = load_texels("pentbig500_14.png") if int(lens["stop"]) >= 0 else np.ones((8, 8), np.float32)
+    wpm = 0.003
+    pos = [0.2, 0.1, 0.8]
+    c2w = look_at(pos, [0.0, -0.2, -5.5])
+    setup_scene_frame(pkg, lf, lens, mask, W, H, ns, c2w, pos)
+    lf.set_lens_camera(1, wpm, 0.0)
+    lf.render_scene_term()
+    got = lf.read_buffer(pkg.SCENE_BUFFER)
+    info = lf.lens_camera()
+    lfo.geo_follow_device(sqrt_table)
+    try:
+        lam = int(np.asarray(lens["ior"]).shape[0]) // 2
+        smp = lfo.geo_lens_samples(lens, W, H, ns, KEY, lam, np.arange(W * H), mask)
+        want, _, alive = compose(lens, mask, W, H, ns, c2w, pos, wpm, info["entrance_pupil_z_mm"], info["exposure"],
+                                 smp, 6, SPHERES, TRIS, LIGHTS)
+    finally:
+        lfo.geo_follow_device(None)
+    want = want.reshape(H, W, 3)
+    assert alive.any() and (want.max(axis=-1) > 0.01).mean() > 0.2
+    err = np.abs(got - want) / np.maximum(np.abs(want), 1e-12)
+    assert err.max() <= 1e-9, err.max()
+    # rank 1 of 2: only its tile rows are rendered, and they are the same pixels
+    lf.set_scene_term(np.zeros((H, W, 3)))            # (clear what the whole-frame launch left)
+    lf.set_row_interleave(1, 2)
+    lf.render_scene_term()
+    part = lf.read_buffer(pkg.SCENE_BUFFER)
+    lf.set_row_interleave(0, 1)
+    own = (np.arange(H) // 8) % 2 == 1
+    assert np.array_equal(part[own], got[own]) and not part[~own].any()
