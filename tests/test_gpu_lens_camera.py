@@ -406,7 +406,7 @@ def test_odd_frames_sample_counts_and_the_multi_gpu_deal(pkg, lf, sqrt_table, le
     finally:
         lfo.geo_follow_device(None)
     want = want.reshape(H, W, 3)
-    assert alive.any() and (want.max(axis=-1) > 0.01).mean() > 0.2
+    assert alive.any() and (want.max(axis=-1) > 0.01).mean() > 0.1
     err = np.abs(got - want) / np.maximum(np.abs(want), 1e-12)
     assert err.max() <= 1e-9, err.max()
     # rank 1 of 2: only its tile rows are rendered, and they are the same pixels
