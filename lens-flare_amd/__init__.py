@@ -41,7 +41,7 @@ ABI_SYMBOLS = [
     "lf_shift_vertex", "lf_compute_phase", "lf_irradiance_falloff", "lf_scene_trace_ray", "lf_scene_shade",
     "lf_load_lens_file", "lf_get_lens_info",
     "lf_set_pupil_target", "lf_get_pupil_target", "lf_aim_at_exit_pupil", "lf_paraxial_exit_pupil", "lf_set_ghost_accumulate",
-    "lf_set_lens_camera", "lf_get_lens_camera", "lf_paraxial_entrance_pupil", "lf_focus_lens",
+    "lf_set_lens_camera", "lf_get_lens_camera", "lf_set_lens_camera_aim", "lf_paraxial_entrance_pupil", "lf_focus_lens",
     "lf_get_scene_counters", "lf_reset_scene_counters", "lf_set_flare_arithmetic",
     "lf_comm_get_unique_id", "lf_comm_init_rank", "lf_comm_gather", "lf_comm_gather_async", "lf_comm_wait",
     "lf_comm_destroy", "lf_comm_available", "lf_comm_info", "lf_comm_test", "lf_comm_abort",
@@ -682,6 +682,10 @@ class LensFlare:
     def set_lens_camera(self, mode=1, world_per_mm=0.001, exposure=0.0):
         """The scene term's sample loop images the scene through the prescription (0 = pinhole)."""
         self._ck(self.lib.lf_set_lens_camera(self.ctx, int(mode), C.c_double(world_per_mm), C.c_double(exposure)))
+
+    def set_lens_camera_aim(self, margin=0.0):
+        """> 0: the lens camera's samples aim at the exit pupil's image x margin (0: at the march's disc)."""
+        self._ck(self.lib.lf_set_lens_camera_aim(self.ctx, C.c_float(margin)))
 
     def lens_camera(self):
         m, w, e, z = C.c_int(), C.c_double(), C.c_double(), C.c_double()

@@ -314,6 +314,8 @@ struct lf_ctx {
   double lenscam_exposure_req = 0.0;  // what lf_set_lens_camera asked for; <= 0: calibrate on the axis
   double lenscam_exposure = 1.0;      // what the kernel uses
   double lenscam_z_ref = 0.0;         // entrance pupil z (mm, lens space)
+  float lenscam_aim_margin = 0.0f;    // lf_set_lens_camera_aim: > 0: the lens camera's samples aim at the exit pupil's image
+  float lenscam_pupil_h = 0.0f, lenscam_pupil_z = 0.0f, lenscam_geom_norm = 0.0f;   // its own disc (margin > 0)
   bool lenscam_dirty = true;          // table / calibration older than the lens, the mask or the pupil target
   LfPrimaryDev* primary_dev = nullptr;
 

@@ -16,6 +16,7 @@
 //
 // This file: the interface table of the primary path (all wavelengths), the paraxial entrance pupil
 // (where the camera position sits in the lens), focusing, and the exposure calibration.
+#include <algorithm>
 #include <cmath>
 #include <cstring>
 
@@ -87,7 +88,11 @@ void lf_fill_lenscam_args(const lf_ctx* ctx, LfLensCamArgs* a) {
   a->inv_sub = 1.0f / (float)(1 << ctx->march_sub_bits);
   a->pitch = ctx->sensor_w_mm / (float)std::max(1, ctx->W);
   a->half_w = 0.5f * (float)ctx->W; a->half_h = 0.5f * (float)ctx->H;
-  a->pupil_h = L.pupil_h; a->vz = L.pupil_z - L.z_sensor; a->geom_norm = L.geom_norm;
+  if (ctx->lenscam_aim_margin > 0.0f) {   // the lens camera's own disc: the exit pupil's image (lf_set_lens_camera_aim)
+    a->pupil_h = ctx->lenscam_pupil_h; a->vz = ctx->lenscam_pupil_z - L.z_sensor; a->geom_norm = ctx->lenscam_geom_norm;
+  } else {                                // the march's disc: the scene ray IS the march's primary path
+    a->pupil_h = L.pupil_h; a->vz = L.pupil_z - L.z_sensor; a->geom_norm = L.geom_norm;
+  }
   a->mw = ctx->ap[LF_APERTURE_STARBURST].w; a->mh = ctx->ap[LF_APERTURE_STARBURST].h;
   a->exposure = ctx->lenscam_exposure;
   a->world_per_mm = ctx->lenscam_world_per_mm;
@@ -102,6 +107,15 @@ void lf_fill_lenscam_args(const lf_ctx* ctx, LfLensCamArgs* a) {
 // the reference returns everywhere (camera.cpp:278-305 has no cos^4, no vignetting, no glass).
 static lf_status calibrate_exposure(lf_ctx* ctx, double* exposure) {
   constexpr int kGrid = 64, kN = kGrid * kGrid;
+  // (the grid covers the disc the lens camera's samples aim at: its own, if it has one)
+  struct Swap {
+    lf_ctx* c; float h, z, g; bool on;
+    explicit Swap(lf_ctx* ctx) : c(ctx), h(ctx->lens.pupil_h), z(ctx->lens.pupil_z), g(ctx->lens.geom_norm),
+                                 on(ctx->lenscam_aim_margin > 0.0f) {
+      if (on) { c->lens.pupil_h = c->lenscam_pupil_h; c->lens.pupil_z = c->lenscam_pupil_z; c->lens.geom_norm = c->lenscam_geom_norm; }
+    }
+    ~Swap() { if (on) { c->lens.pupil_h = h; c->lens.pupil_z = z; c->lens.geom_norm = g; } }
+  } swap(ctx);
   std::vector<float> xy(2 * kN, 0.0f), uv(2 * kN), out(8 * kN);
   for (int j = 0; j < kGrid; j++)
     for (int i = 0; i < kGrid; i++) {
@@ -133,6 +147,21 @@ lf_status lf_lenscam_prepare(lf_ctx* ctx) {
       return lf_fail(ctx, LF_ERR_INVALID, "lens camera: the stop has no finite paraxial image through the front group");
   }
   ctx->lenscam_z_ref = z;
+  if (ctx->lenscam_aim_margin > 0.0f) {
+    // the paraxial image of the stop's open part through the rear group, times the margin (room for the pupil's
+    // aberration off the axis): unbiased for the primary path, the only path the lens camera marches
+    if (ctx->raw_stop < 0) return lf_fail(ctx, LF_ERR_INVALID, "lf_set_lens_camera_aim: the prescription has no stop");
+    double zx = 0.0, mx = 0.0;
+    if (lf_paraxial_exit_pupil(ctx->raw_n, ctx->raw_stop, ctx->raw_radius, ctx->raw_thickness,
+                               ctx->raw_ior + (size_t)(ctx->lens.n_lambda / 2) * ctx->raw_n, &zx, &mx) != LF_OK ||
+        !(zx < (double)ctx->lens.z_sensor))
+      return lf_fail(ctx, LF_ERR_INVALID, "lf_set_lens_camera_aim: the stop has no usable paraxial image behind it");
+    const double open = std::min(1.0, ctx->ap[LF_APERTURE_STARBURST].open_radius);
+    ctx->lenscam_pupil_h = (float)((double)ctx->lens.stop_h * open * std::fabs(mx) * (double)ctx->lenscam_aim_margin);
+    ctx->lenscam_pupil_z = (float)zx;
+    const double D = (double)ctx->lens.z_sensor - (double)ctx->lenscam_pupil_z;
+    ctx->lenscam_geom_norm = (float)((3.14159265358979323846 * (double)ctx->lenscam_pupil_h * (double)ctx->lenscam_pupil_h) / (D * D));
+  }
   lf_status st = lf_upload_primary_table(ctx);
   if (st != LF_OK) return st;
   if (ctx->lenscam_exposure_req > 0.0) {
@@ -189,6 +218,13 @@ lf_status lf_set_lens_camera(lf_ctx* ctx, int mode, double world_per_mm, double 
     ctx->lenscam_exposure_req = exposure;
     ctx->lenscam_dirty = true;
   }
+  return LF_OK;
+}
+
+lf_status lf_set_lens_camera_aim(lf_ctx* ctx, float margin) {
+  if (!ctx || !std::isfinite(margin)) return LF_ERR_INVALID;
+  ctx->lenscam_aim_margin = margin > 0.0f ? margin : 0.0f;
+  ctx->lenscam_dirty = true;
   return LF_OK;
 }
 

@@ -50,6 +50,9 @@ class LensCamera : public Camera {
   bool image_scene = true;
   // one ray per wavelength instead of one at the reference wavelength (lateral / axial colour in the scene)
   bool chromatic = false;
+  // > 0: the scene samples aim at the exit pupil's image x this margin (lf_set_lens_camera_aim: more of the
+  // samples then leave the lens); 0: at the march's disc, so that a scene ray IS the march's primary path
+  float scene_aim_margin = 0.0f;
 
   // LensCamera::generate_ray: (x, y) normalised sensor coordinates as for Camera::generate_ray;
   // (pu, pv) in [0,1)^2 samples the rear pupil.  The primary path is marched through the prescription

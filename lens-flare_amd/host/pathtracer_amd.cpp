@@ -101,6 +101,7 @@ struct DeviceState {
   size_t lens_w = 0, lens_h = 0;       // ... for this frame size (the pixel pitch depends on it)
   bool mirror_ghost = false;           // LF_MIRROR_GHOST_BUFFER: fill the public ghost_buffer field every frame
   double lens_focus_mm = 0.0;          // object distance the loaded lens was last focused at (0: as the file says)
+  float scene_aim = 0.0f;              // LF_LENS_CAMERA_AIM: margin of lf_set_lens_camera_aim (0: the march's disc)
   double world_per_mm = 0.001;         // LF_WORLD_PER_MM: scene units per lens millimetre (lens camera; 1 unit = 1 m)
   bool log_frame = true;               // LF_QUIET unset: one stdout line per frame for the march / the lens camera
   // what the device's scene kernel counted for the frame (BVHAccel::total_rays / total_isects, bvh.h:136)
@@ -310,6 +311,7 @@ PathTracer::PathTracer() {
   if (const char* v = getenv("LF_GEOMETRIC_KEY")) s.geo_key = strtoull(v, nullptr, 0);
   s.mirror_ghost = getenv("LF_MIRROR_GHOST_BUFFER") != nullptr;
   if (const char* v = getenv("LF_WORLD_PER_MM")) s.world_per_mm = atof(v);
+  s.scene_aim = getenv("LF_LENS_CAMERA_AIM") ? (float)atof(getenv("LF_LENS_CAMERA_AIM")) : 0.0f;
   s.log_frame = getenv("LF_QUIET") == nullptr;
   s.frame_rays = s.frame_isects = 0;
   s.counters_pushed.store(true);
@@ -448,6 +450,9 @@ void PathTracer::generate_ghost_buffer() {                         // pathtracer
       plan.lens_camera_mode = (lens_cam ? lens_cam->chromatic : getenv("LF_LENS_CHROMATIC") != nullptr) ? 2 : 1;
       plan.world_per_mm = lens_cam ? lens_cam->world_per_mm : s.world_per_mm;
       plan.exposure = 0.0;                      // calibrated on the axis
+      // (where the scene samples aim: the march's disc, or -- LensCamera::scene_aim_margin / LF_LENS_CAMERA_AIM > 0
+      // -- the exit pupil's image, under which more of the samples leave the lens)
+      check(s, lf_set_lens_camera_aim(s.ctx, lens_cam ? lens_cam->scene_aim_margin : s.scene_aim), "lf_set_lens_camera_aim");
       plan.jitter = LF_FRAME_JITTER_COUNTER;    // the lens camera's samples are the march's
       plan.counter_key = s.geo_key;
     }

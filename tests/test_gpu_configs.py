@@ -147,3 +147,74 @@ def test_c3_full_spp_frame(pkg, lf):
     og, _ = lfo.geo_trace(lens, W, H, y0, y0 + 8, spp, key, None, True, mask, sun, [1.0, 0.9, 0.5], 0.05,
                           n_threads=16)
     assert np.array_equal(band, og[y0:y0 + 8]) and band.max() > 0
+
+
+def test_c4_full_size_frame_through_the_lens(pkg, lf):
+    """BASELINE.json configs[3] on one GPU at its full size -- 3840 x 2160, 256 spp, a .dae scene with its own
+    DirectionalLight (maxplanck.dae, 50 801 triangles: dragon.dae is absent from the reference checkout) --
+    as ONE frame in which every sensor sample's primary path images the scene through the prescription and
+    its ghost paths collect the sun (round 4): the pieces add up (sensor = (scene + ghost) + starburst), every
+    lens sample and every ray of the march is accounted for, a second rendering is identical, the sun's image
+    sits on the starburst's origin, and the mesh is in the way of the camera's rays."""
+    import os
+    W, H, spp, key = 3840, 2160, 256, 0x1e45f1a4e
+    lens = pkg.load_lens_file("dgauss11.lens")
+    mask = load_texels("pentbig500_14.png")
+    efl = pkg.paraxial_efl(lens)
+    hf = 2 * math.degrees(math.atan(0.5 * lens["sensor_width_mm"] / efl))
+    vf = 2 * math.degrees(math.atan(math.tan(math.radians(hf) / 2) * H / W))
+    lf.set_frame(W, H)
+    lf.set_aperture(pkg.APERTURE_STARBURST, mask)
+    lf.set_aperture(pkg.APERTURE_GHOST, mask)
+    lf.set_lens(lens)
+    lf.set_ghost_pairs(None, True)
+    lf.set_starburst_spectrum(None)
+    lf.set_jitter_counter(key)
+    camera, suns = lf.load_collada(os.path.join(pkg.DATA, "maxplanck.dae"))
+    light = suns[0]
+    lo, hi, n_prims = lf.scene_bounds()
+    assert n_prims == 50801
+    mid, ext = 0.5 * (lo + hi), float(np.linalg.norm(hi - lo))
+    to_sun = np.array(light[:3], float) - mid
+    pos = mid - to_sun / np.linalg.norm(to_sun) * (1.5 * ext)        # behind the bust, looking at the sun
+    lf.set_camera(pkg.aim_camera(pos, light[:3], SUN_NS, hf, vf), pos, hf, vf)
+    lf.set_params(spp, 25.0, 1.0)
+    lf.set_sampling(32, 0.05, 0.01, 100.0)                          # the reference's adaptive early-out
+    lf.set_lens_camera(1, 0.001, 0.0)
+
+    def frame():
+        lf.reset_counters()
+        lf.reset_scene_counters()
+        lf.find_sun_pos([light])
+        lf.set_sun_from_flares(0, efl, 0.05)
+        lf.render_scene_term()
+        lf.trace_ghosts(spp, key)
+        lf.render_flare_layer()
+
+    frame()
+    cnt, sc = lf.counters(), lf.scene_counters()
+    assert cnt["rays_launched"] == W * H * spp * 3 * 46
+    assert cnt["rays_launched"] == cnt["rays_clipped_stop"] + cnt["rays_vignetted"] + cnt["rays_tir"] + cnt["rays_reached_scene"]
+    # the lens camera: between one batch (the adaptive test stops a dark or a flat pixel after 32 samples) and
+    # all 256 samples per pixel were marched; about a quarter leaves the pentagon-stopped lens; every one that
+    # does is a BVH query, a hit adds a shadow ray towards the sun
+    assert W * H * 32 <= sc["lens_samples"] <= W * H * spp
+    assert 0.2 < sc["lens_left"] / sc["lens_samples"] < 0.32
+    assert sc["lens_left"] <= sc["rays"] <= 4 * sc["lens_left"] and sc["isects"] > 0
+    x0, y0 = int(SUN_NS[0] * W) - 256, int(SUN_NS[1] * H) - 128
+    s1, g1, t1, a1 = (lf.read_tile(b, x0, y0, x0 + 512, y0 + 256) for b in
+                      (pkg.SCENE_BUFFER, pkg.GHOST_BUFFER, pkg.STARBURST_BUFFER, pkg.SAMPLE_BUFFER))
+    assert np.array_equal(a1, (s1 + g1) + t1) and g1.max() > 0 and t1.max() > 0
+    # the bust is in the picture: camera rays hit it (every hit casts a shadow ray towards the sun) -- seen from
+    # behind it is in its own shadow, so its pixels are dark like the sky; only its rim may catch light
+    assert sc["rays"] > 1.05 * sc["lens_left"]
+    # the sun's image (primary path) is where the starburst is built
+    fl = lf.get_flares()
+    ghost_row = lf.read_tile(pkg.GHOST_BUFFER, 0, y0, W, y0 + 256).sum(axis=-1)
+    ys, xs = np.nonzero(ghost_row > 0.5 * ghost_row.max())
+    assert abs(xs.mean() - fl["origins"][0][0] * W) < 6 and abs(ys.mean() + y0 - fl["origins"][0][1] * H) < 6
+    frame()
+    assert np.array_equal(lf.read_tile(pkg.SAMPLE_BUFFER, x0, y0, x0 + 512, y0 + 256), a1)
+    assert lf.scene_counters() == sc and lf.counters() == cnt
+    lf.set_lens_camera(0)
+    lf.set_params(1, 25.0, 1.0)

@@ -417,3 +417,52 @@ def test_odd_frames_sample_counts_and_the_multi_gpu_deal(pkg, lf, sqrt_table, le
     lf.set_row_interleave(0, 1)
     own = (np.arange(H) // 8) % 2 == 1
     assert np.array_equal(part[own], got[own]) and not part[~own].any()
+
+
+def test_aiming_the_lens_camera_at_the_exit_pupil(pkg, lf, sqrt_table):
+    """lf_set_lens_camera_aim: the lens camera's samples aim at the paraxial image of the stop's open part
+    (x 1.3) instead of the march's disc.  Same estimator for the primary path -- pixels = the float32 oracle
+    under that disc to 1e-9, the flat field is 1 on the axis again (the calibration follows), the scene's total
+    agrees with the default disc's within the Monte-Carlo error -- with more of the samples leaving the lens
+    (1.2-1.8x under a pentagon stop); the march's own disc is not touched."""
+    lens = pkg.load_lens_file("dgauss11.lens")
+    mask = load_texels("pentbig500_14.png")
+    W, H, ns, wpm = 48, 32, 16, 0.004
+    pos = [0.3, 0.2, 1.0]
+    c2w = look_at(pos, [0.0, -0.2, -5.5])
+    setup_scene_frame(pkg, lf, lens, mask, W, H, ns, c2w, pos)
+    disc = lf.aim_at_exit_pupil(1.3)                   # the numbers lf_set_lens_camera_aim(1.3) derives ...
+    lf.set_pupil_target(0.0, 0.0)                      # ... while the march keeps its default disc
+    default_disc = lf.pupil_target()
+    lf.set_lens_camera(1, wpm, 0.0)
+    lf.reset_scene_counters()
+    lf.render_scene_term()
+    base = lf.read_buffer(pkg.SCENE_BUFFER)
+    base_cnt = lf.scene_counters()
+    lf.set_lens_camera_aim(1.3)
+    lf.reset_scene_counters()
+    lf.render_scene_term()
+    got = lf.read_buffer(pkg.SCENE_BUFFER)
+    cnt, info = lf.scene_counters(), lf.lens_camera()
+    assert lf.pupil_target() == default_disc
+    # (a pentagon fills 76 % of its circumscribed circle, the margin takes 1 / 1.3^2 of that, vignetting the rest)
+    assert cnt["lens_left"] > 1.2 * base_cnt["lens_left"]
+    lfo.geo_follow_device(sqrt_table)
+    lfo.set_pupil_target(disc["radius_mm"], disc["z_mm"])
+    try:
+        exposure = lfo.lens_exposure(lens, W, mask)
+        assert abs(info["exposure"] - exposure) <= 1e-12 * exposure
+        smp = lfo.geo_lens_samples(lens, W, H, ns, KEY, 1, np.arange(W * H), mask)
+        want, _, _ = compose(lens, mask, W, H, ns, c2w, pos, wpm, info["entrance_pupil_z_mm"], exposure, smp, 6,
+                             SPHERES, TRIS, LIGHTS)
+    finally:
+        lfo.set_pupil_target(0.0, 0.0)
+        lfo.geo_follow_device(None)
+    want = want.reshape(H, W, 3)
+    err = np.abs(got - want) / np.maximum(np.abs(want), 1e-12)
+    assert err.max() <= 1e-9, err.max()
+    # the same image: totals over the frame (16 samples per pixel, a quarter of them alive in `base`)
+    assert got.sum() == pytest.approx(base.sum(), rel=0.05)
+    lf.set_lens_camera_aim(0.0)
+    lf.render_scene_term()
+    assert np.array_equal(lf.read_buffer(pkg.SCENE_BUFFER), base)

@@ -70,7 +70,7 @@ def _check_against_f64(img, cnt, ref, frag, c64, min_lit, median_bar=2e-6):
         print(f"  allowance: {int(over.sum())} of {int(lit.sum())} lit values are outside 1e-4; deviation / (summed weight "
               f"of the pixel's fragile rays) in [0,.25) [.25,.5) [.5,.75) [.75,1) [1,1.05]: {hist.tolist()}, max {ratio.max():.3f}; "
               f"largest raw deviation {rel.max():.2e}")
-    else:
+    elif rel.size:
         print(f"  allowance: none of {int(lit.sum())} lit values needs it (largest raw deviation {rel.max():.2e})")
     # ... and that allowance is the exception, not the rule
     if rel.size:
