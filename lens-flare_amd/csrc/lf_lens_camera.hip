@@ -214,17 +214,19 @@ lf_status lf_set_lens_camera(lf_ctx* ctx, int mode, double world_per_mm, double 
     return lf_fail(ctx, LF_ERR_INVALID, "lens camera: world_per_mm must be > 0 and finite");
   ctx->lenscam_mode = mode;
   if (mode != 0) {
+    // (a host that repeats the call every frame does not trigger a new calibration)
+    if (exposure != ctx->lenscam_exposure_req) ctx->lenscam_dirty = true;
     ctx->lenscam_world_per_mm = world_per_mm;
     ctx->lenscam_exposure_req = exposure;
-    ctx->lenscam_dirty = true;
   }
   return LF_OK;
 }
 
 lf_status lf_set_lens_camera_aim(lf_ctx* ctx, float margin) {
   if (!ctx || !std::isfinite(margin)) return LF_ERR_INVALID;
-  ctx->lenscam_aim_margin = margin > 0.0f ? margin : 0.0f;
-  ctx->lenscam_dirty = true;
+  const float m = margin > 0.0f ? margin : 0.0f;
+  if (m != ctx->lenscam_aim_margin) ctx->lenscam_dirty = true;
+  ctx->lenscam_aim_margin = m;
   return LF_OK;
 }
 

@@ -11,6 +11,7 @@
 // calls, no CGL declarations.
 #pragma once
 
+#include <stddef.h>
 #include <stdint.h>
 
 #include "lensflare.h"
