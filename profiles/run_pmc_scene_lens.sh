@@ -1,0 +1,41 @@
+#!/bin/bash
+# Counters of the lens-imaged scene term k_scene_term<SOFT, LENS = true> (round 4) on the C4-shaped frame with the
+# largest shipped scene (bench.py --config c4_maxplanck_1gpu: 4K, 256 samples per pixel offered, 50 801 triangles),
+# and of the same frame with the reference's pinhole (LF_BENCH_PINHOLE_SCENE=1): rocprofv3 kernel trace + SQ
+# counters in their own pass.   bash profiles/run_pmc_scene_lens.sh <tag>       (GPU box, repo root)
+[ -f lens-flare_amd/liblensflare_hip.so ] || { echo "liblensflare_hip.so missing" >&2; exit 1; }
+TAG=${1:-r04}
+cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
+OUT=gpurun_out/pmc_scene_lens_$TAG
+rm -rf $OUT; mkdir -p $OUT
+for mode in lens pinhole; do
+  if [ $mode = pinhole ]; then export LF_BENCH_PINHOLE_SCENE=1; else unset LF_BENCH_PINHOLE_SCENE; fi
+  rocprofv3 --kernel-trace --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_VMEM_RD SQ_INSTS_LDS SQ_WAVE_CYCLES SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_ACTIVE_INST_VALU --output-format csv -d $OUT/sq_$mode -- python3 bench.py --config c4_maxplanck_1gpu --steps 1 --warmup 0 --no-cpu > $OUT/sq_$mode.json 2> $OUT/sq_$mode.err
+done
+unset LF_BENCH_PINHOLE_SCENE
+python3 - $OUT <<'Q'
+import csv, glob, json, sys
+from collections import defaultdict
+out = sys.argv[1]
+res = {"frame": "bench.py --config c4_maxplanck_1gpu (3840x2160, 256 samples per pixel offered, maxplanck.dae: 50 801 triangles)"}
+for mode in ("lens", "pinhole"):
+    sums, disp, t = defaultdict(float), defaultdict(set), []
+    for f in glob.glob(out + f"/sq_{mode}/*/*counter_collection.csv"):
+        for r in csv.DictReader(open(f)):
+            if "k_scene_term" in r["Kernel_Name"]:
+                sums[r["Counter_Name"]] += float(r["Counter_Value"]); disp[r["Counter_Name"]].add(r["Dispatch_Id"])
+                name = "k_scene_term<" + r["Kernel_Name"].split("k_scene_term<")[1].split(">")[0] + ">"
+    for f in glob.glob(out + f"/sq_{mode}/*/*kernel_trace.csv"):
+        for r in csv.DictReader(open(f)):
+            if "k_scene_term" in r["Kernel_Name"]:
+                t.append((float(r["End_Timestamp"]) - float(r["Start_Timestamp"])) * 1e-6)
+    e = {"kernel": name if sums else None, "ms_per_launch_under_pmc": sum(t) / len(t) if t else None,
+         "per_launch": {c: sums[c] / max(1, len(disp[c])) for c in sums}}
+    try:
+        b = json.loads([l for l in open(out + f"/sq_{mode}.json") if l.startswith("{")][-1])
+        e["scene_term"] = b["scene_term"]
+    except Exception as ex:  # noqa: BLE001
+        e["note"] = str(ex)
+    res[mode] = e
+print(json.dumps(res, indent=1))
+Q
