@@ -392,8 +392,10 @@ lf_status lf_set_sun(lf_ctx* ctx, const float dir[3], const float radiance[3],
  * lf_set_sun, so that the geometric ghosts and the starburst agree about where the sun is: the
  * direction is the one a lens of focal length efl_mm images at that sensor point,
  *   (  (nx - 1/2) sensor_w / efl,  (ny - 1/2) sensor_w (H/W) / efl,  -1  )  normalised.
- * efl_mm <= 0 takes the paraxial focal length of the prescription (lf_paraxial_efl at the middle
- * wavelength).  Needs lf_set_frame, lf_set_lens and a flare state.  No reference counterpart (the
+ * efl_mm <= 0 takes the paraxial image scale of the prescription at the middle wavelength: where the chief
+ * ray of a distant point lands on the sensor per unit field angle -- the focal length (lf_paraxial_efl) while
+ * the sensor sits in the focal plane, as in the shipped files, and what a sensor moved by lf_focus_lens really
+ * sees otherwise.  Needs lf_set_frame, lf_set_lens and a flare state.  No reference counterpart (the
  * reference's ghosts take only `angle_to_sun`, pathtracer.cpp:50, :735-762). */
 lf_status lf_set_sun_from_flares(lf_ctx* ctx, int flare, double efl_mm, float angular_radius);
 /* Paraxial effective focal length of a prescription at one wavelength (host arithmetic, no

@@ -754,6 +754,31 @@ lf_status lf_paraxial_efl(int n, int stop, const float* radius, const float* thi
   return LF_OK;
 }
 
+// Where a collimated beam from field angle theta (small) lands on the sensor plane, per unit of theta: the
+// height of its CHIEF ray (the one through the stop's centre) -- the centre of the beam's image whether the
+// sensor sits in the focal plane (then this is the focal length) or not (a lens refocused by lf_focus_lens:
+// focal length + sensor shift x the chief ray's exit slope).  Paraxial, the reference's T / R operators.
+static bool paraxial_image_scale(int n, int stop, const float* radius, const float* thickness, const float* ior_row,
+                                 double* scale) {
+  // two rays from the first vertex, (height 1, slope 0) and (height 0, slope 1): everything is linear in them
+  double y[2] = {1.0, 0.0}, u[2] = {0.0, 1.0}, ys[2] = {1.0, 0.0};
+  double n1 = 1.0;
+  for (int k = 0; k < n; k++) {
+    if (k == stop) { ys[0] = y[0]; ys[1] = y[1]; }
+    else {
+      const double c = radius[k] == 0.0f ? 0.0 : 1.0 / (double)radius[k], n2 = ior_row[k];
+      if (!(n2 >= 1.0)) return false;
+      for (int r = 0; r < 2; r++) u[r] = c * (n1 - n2) / n2 * y[r] + n1 / n2 * u[r];
+      n1 = n2;
+    }
+    for (int r = 0; r < 2; r++) y[r] += (double)thickness[k] * u[r];   // (the last thickness: to the sensor)
+  }
+  // chief ray of slope 1: height y0 at the first vertex such that it crosses the stop's centre
+  const double y0 = (stop >= 0 && ys[0] != 0.0) ? -ys[1] / ys[0] : 0.0;
+  *scale = y0 * y[0] + y[1];
+  return std::isfinite(*scale) && *scale != 0.0;
+}
+
 lf_status lf_set_sun_from_flares(lf_ctx* ctx, int flare, double efl_mm, float angular_radius) {
   if (!ctx || flare < 0 || flare >= LF_MAX_FLARES) return LF_ERR_INVALID;
   if (ctx->W == 0) return lf_fail(ctx, LF_ERR_STATE, "lf_set_sun_from_flares before lf_set_frame");
@@ -765,10 +790,11 @@ lf_status lf_set_sun_from_flares(lf_ctx* ctx, int flare, double efl_mm, float an
   LF_HIP(ctx, hipMemcpy(&f, ctx->flares, sizeof(f), hipMemcpyDeviceToHost));
   if (flare >= f.n_flares) return lf_fail(ctx, LF_ERR_INVALID, "lf_set_sun_from_flares: no such flare in the frame");
   if (!(efl_mm > 0.0)) {
-    const lf_status st = lf_paraxial_efl(ctx->raw_n, ctx->raw_stop, ctx->raw_radius, ctx->raw_thickness,
-                                         ctx->raw_ior + (size_t)(ctx->lens.n_lambda / 2) * ctx->raw_n, &efl_mm);
-    if (st != LF_OK || !(efl_mm > 0.0))
-      return lf_fail(ctx, LF_ERR_INVALID, "lf_set_sun_from_flares: the prescription has no positive focal length");
+    // the image scale of THIS sensor position: the focal length when the sensor sits in the focal plane (the
+    // shipped prescriptions), the chief ray's landing height per unit field angle when lf_focus_lens has moved it
+    if (!paraxial_image_scale(ctx->raw_n, ctx->raw_stop, ctx->raw_radius, ctx->raw_thickness,
+                              ctx->raw_ior + (size_t)(ctx->lens.n_lambda / 2) * ctx->raw_n, &efl_mm) || !(efl_mm > 0.0))
+      return lf_fail(ctx, LF_ERR_INVALID, "lf_set_sun_from_flares: the prescription images no distant point on its sensor");
   }
   const double sw = ctx->sensor_w_mm, sh = sw * (double)ctx->H / (double)ctx->W;
   const float dir[3] = {(float)((f.origin[flare][0] - 0.5) * sw / efl_mm),

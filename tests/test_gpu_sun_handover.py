@@ -124,3 +124,48 @@ def test_c4_shaped_frame_scene_light_feeds_the_march(pkg):
     gx, gy = (g2 * (xs + 0.5)).sum() / g2.sum(), (g2 * (ys + 0.5)).sum() / g2.sum()
     assert abs(gx + x0 - ox) < 10 and abs(gy + y0 - oy) < 10, (gx + x0, gy + y0, ox, oy)
     lf.close()
+
+
+@pytest.mark.gpu
+def test_refocused_lens_still_puts_the_sun_where_the_starburst_is(pkg):
+    """lf_focus_lens moves the sensor out of the focal plane: a distant point's image then sits where its CHIEF ray
+    lands -- focal length + sensor shift x the chief ray's exit slope, not the focal length alone.
+    lf_set_sun_from_flares (efl <= 0) uses that scale, so the sun's (now defocused) image stays centred on the
+    flare origin the starburst is built around; with the plain focal length it would sit 8 % further out."""
+    lf = pkg.LensFlare(0)
+    W, H = 384, 216
+    lens = pkg.load_lens_file("dgauss11.lens")
+    sun_ns = (0.78, 0.70)                                  # well off the axis: a scale error shows
+    efl = pkg.paraxial_efl(lens)
+    hf = 2 * math.degrees(math.atan(0.5 * lens["sensor_width_mm"] / efl))
+    vf = 2 * math.degrees(math.atan(math.tan(math.radians(hf) / 2) * H / W))
+    lf.set_frame(W, H)
+    lf.set_params(1, 25.0, 1.0)
+    lf.set_aperture(pkg.APERTURE_STARBURST, pkg.load_aperture_png("pentbig500_14.png"))
+    lf.set_aperture(pkg.APERTURE_GHOST, load_texels("octagonbokeh.png"))
+    lf.set_lens(lens)
+    pos, sun_point = [0.0, 0.0, 0.0], [3.0, 2.0, -40.0]
+    lf.set_camera(pkg.aim_camera(pos, sun_point, sun_ns, hf, vf), pos, hf, vf)
+    lf.set_jitter_counter(7)
+    lf.set_ghost_pairs([(-1, -1)], False)                  # the primary path alone: the sun's image
+    lf.find_sun_pos([sun_point + [1.0, 0.9, 0.5]])
+    fl = lf.get_flares()
+    assert fl["n"] == 1
+
+    def centroid(efl_arg):
+        lf.set_sun_from_flares(0, efl_arg, 0.02)
+        lf.trace_ghosts(256, 11)
+        g = lf.read_buffer(pkg.GHOST_BUFFER).sum(axis=-1)
+        ys, xs = np.nonzero(g > 0.2 * g.max())
+        w = g[ys, xs]
+        return np.array([(xs * w).sum() / w.sum() + 0.5, (ys * w).sum() / w.sum() + 0.5])
+
+    want = np.array([fl["origins"][0][0] * W, fl["origins"][0][1] * H])
+    assert np.abs(centroid(0.0) - want).max() < 1.5        # in the focal plane: as before
+    shift = lf.focus_lens(500.0) - float(lens["thickness"][-1])
+    assert 4.0 < shift < 8.0                               # focusing at half a metre moves the sensor ~5.7 mm back
+    auto = centroid(0.0)
+    plain = centroid(efl)                                  # the focal length alone: what rounds 2-3 would have used
+    assert np.abs(auto - want).max() < 2.5, (auto, want)
+    assert np.linalg.norm(plain - want) > 3 * np.linalg.norm(auto - want) and np.linalg.norm(plain - want) > 6.0
+    lf.close()
