@@ -480,6 +480,8 @@ void PathTracer::generate_ghost_buffer() {                         // pathtracer
       if (plan.ghosts == LF_FRAME_GHOSTS_MARCH && launches > 0 && ms > 0.0)
         fprintf(stdout, "[PathTracer/MI355X] Lens march executed %llu ray-surface intersections in %.3f ms "
                         "(%.4f million per second).\n", (unsigned long long)ev, ms, (double)ev / ms * 1e-3);
+      fprintf(stdout, "[PathTracer/MI355X] Scene kernel traced %llu rays with %llu primitive tests (device counters).\n",
+              (unsigned long long)sc[0], (unsigned long long)sc[1]);
       if (plan.lens_camera_mode)
         fprintf(stdout, "[PathTracer/MI355X] Lens camera marched %llu sensor samples, %llu left the front element.\n",
                 (unsigned long long)sc[2], (unsigned long long)sc[3]);

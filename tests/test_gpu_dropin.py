@@ -422,6 +422,10 @@ def test_the_reference_log_line_reports_the_device_work(tmp_path):
     # at least one camera ray per sample; a hit adds one shadow ray per light
     assert rays[0] >= W * H * ns and rays[0] <= W * H * ns * 8
     assert 0.0 < per[0] < 64.0 and speed[0] > 0.0
+    # ... and they ARE the device's counters: what the reference's log line prints = what the scene kernel counted
+    dev = re.findall(r"Scene kernel traced (\d+) rays with (\d+) primitive tests", r.stdout)
+    assert dev and int(dev[0][0]) == rays[0]
+    assert abs(int(dev[0][1]) / int(dev[0][0]) - per[0]) <= 1e-5 * per[0] + 1e-6
     # ... and with a lens selected by LF_LENS_FILE the march's own line appears beside it
     env = dict(os.environ, LF_LENS_FILE=os.path.join(ROOT, "lens-flare_amd", "data", "dgauss11.lens"), LF_GEOMETRIC_SPP="8")
     r2 = subprocess.run([APP] + args, capture_output=True, text=True, timeout=600, cwd=str(tmp_path), env=env)
