@@ -404,6 +404,12 @@ lf_status lf_set_sun_from_flares(lf_ctx* ctx, int flare, double efl_mm, float an
  * lf_set_lens. */
 lf_status lf_paraxial_efl(int n_surfaces, int stop_index, const float* radius, const float* thickness,
                           const float* ior_row, double* efl_mm);
+/* Paraxial image scale of a prescription AS ITS SENSOR SITS (host arithmetic, no device): the height at
+ * which the chief ray of a distant point lands on the sensor per unit field angle -- what
+ * lf_set_sun_from_flares(efl_mm <= 0) divides by.  Equal to lf_paraxial_efl when the last thickness puts the
+ * sensor in the paraxial focal plane; a file focused elsewhere, or a sensor moved by lf_focus_lens, differs. */
+lf_status lf_paraxial_image_scale(int n_surfaces, int stop_index, const float* radius, const float* thickness,
+                                  const float* ior_row, double* scale_mm);
 /* ghost pairs to enumerate: pairs = n x {i, j} interface indices (i < j, neither the stop);
  * i = j = -1 is the primary (no reflection) path.  n = 0 / NULL = all glass pairs. */
 lf_status lf_set_ghost_pairs(lf_ctx* ctx, const int* pairs, int n_pairs, int include_primary);

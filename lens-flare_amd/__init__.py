@@ -35,7 +35,7 @@ ABI_SYMBOLS = [
     "lf_set_direct_hemisphere_sample", "lf_collada_check", "lf_render_scene_term",
     "lf_generate_ghost_buffer", "lf_render_flare_layer", "lf_read_tile", "lf_read_pixel",
     "lf_write_to_framebuffer", "lf_save_image_rgba", "lf_device_buffer", "lf_set_lens", "lf_set_lambda_rgb", "lf_set_sun",
-    "lf_set_sun_from_flares", "lf_paraxial_efl", "lf_set_ghost_pairs", "lf_set_pupil_subcells", "lf_set_tile_stride", "lf_trace_ghosts", "lf_generate_lens_rays", "lf_get_counters", "lf_reset_counters", "lf_get_executed_events", "lf_get_march_stats", "lf_native_sqrt", "lf_native_rcp", "lf_set_starburst_spectrum", "lf_load_collada", "lf_march_tables",
+    "lf_set_sun_from_flares", "lf_paraxial_efl", "lf_paraxial_image_scale", "lf_set_ghost_pairs", "lf_set_pupil_subcells", "lf_set_tile_stride", "lf_trace_ghosts", "lf_generate_lens_rays", "lf_get_counters", "lf_reset_counters", "lf_get_executed_events", "lf_get_march_stats", "lf_native_sqrt", "lf_native_rcp", "lf_set_starburst_spectrum", "lf_load_collada", "lf_march_tables",
     "lf_timing_enable", "lf_timing_reset", "lf_timing_get",
     "lf_clear_ghost_buffer", "lf_draw_ghost", "lf_rasterize_textured_triangle", "lf_fill_textured_pixel",
     "lf_shift_vertex", "lf_compute_phase", "lf_irradiance_falloff", "lf_scene_trace_ray", "lf_scene_shade",
@@ -227,6 +227,23 @@ def paraxial_efl(lens, lam=None):
                              _fp(row, C.c_float), C.byref(out))
     if st != 0:
         raise LensFlareError(st, "lf_paraxial_efl")
+    return out.value
+
+
+def paraxial_image_scale(lens, lam=None):
+    """lf_paraxial_image_scale: chief-ray landing height per unit field angle on the sensor as the
+    prescription dict places it (what lf_set_sun_from_flares(efl_mm <= 0) uses; host arithmetic)."""
+    lib = load_library()
+    ior = np.ascontiguousarray(lens["ior"], np.float32)
+    lam = ior.shape[0] // 2 if lam is None else lam
+    r = np.ascontiguousarray(lens["radius"], np.float32)
+    t = np.ascontiguousarray(lens["thickness"], np.float32)
+    row = np.ascontiguousarray(ior[lam], np.float32)
+    out = C.c_double()
+    st = lib.lf_paraxial_image_scale(int(lens["n"]), int(lens["stop"]), _fp(r, C.c_float), _fp(t, C.c_float),
+                                     _fp(row, C.c_float), C.byref(out))
+    if st != 0:
+        raise LensFlareError(st, "lf_paraxial_image_scale")
     return out.value
 
 

@@ -779,6 +779,12 @@ static bool paraxial_image_scale(int n, int stop, const float* radius, const flo
   return std::isfinite(*scale) && *scale != 0.0;
 }
 
+lf_status lf_paraxial_image_scale(int n, int stop, const float* radius, const float* thickness, const float* ior_row,
+                                  double* scale_mm) {
+  if (n <= 0 || !radius || !thickness || !ior_row || !scale_mm) return LF_ERR_INVALID;
+  return paraxial_image_scale(n, stop, radius, thickness, ior_row, scale_mm) ? LF_OK : LF_ERR_INVALID;
+}
+
 lf_status lf_set_sun_from_flares(lf_ctx* ctx, int flare, double efl_mm, float angular_radius) {
   if (!ctx || flare < 0 || flare >= LF_MAX_FLARES) return LF_ERR_INVALID;
   if (ctx->W == 0) return lf_fail(ctx, LF_ERR_STATE, "lf_set_sun_from_flares before lf_set_frame");

@@ -204,7 +204,8 @@ def test_geometric_march_through_the_reference_surface(route, tmp_path):
     case, flares, ghost, sample = _geometric_frame(tmp_path, env)
     assert len(flares) == 1
     lens = pkg.load_lens_file("dgauss11.lens")
-    efl = pkg.paraxial_efl(lens)
+    efl = pkg.paraxial_image_scale(lens)      # what lf_set_sun_from_flares(efl_mm <= 0) divides by
+    assert efl == pytest.approx(pkg.paraxial_efl(lens), rel=2e-3)
     nx, ny = flares[0][0], flares[0][1]
     sun = [(nx - 0.5) * lens["sensor_width_mm"] / efl, (ny - 0.5) * lens["sensor_width_mm"] * H / W / efl, -1.0]
     mask = load_texels("pentbig500_14.png")

@@ -103,3 +103,26 @@ def test_both_tracers_agree_on_the_lens_cameras_samples():
     assert np.all(dev <= 2e-3 * np.abs(f64) + allow + 1e-13)
     assert (dev <= 1e-4 * np.abs(f64) + allow + 1e-13).mean() > 0.99
     assert (f64.max(axis=-1) > 0.01).mean() > 0.3
+
+
+def test_image_scale_is_the_focal_length_in_the_focal_plane_and_follows_the_sensor():
+    """lf_paraxial_image_scale (what lf_set_sun_from_flares(efl_mm <= 0) divides by): equal to the focal length when
+    the last thickness is the paraxial back focal distance; with the sensor moved by s it changes by s x the chief
+    ray's exit slope = s x efl / (distance exit pupil -> focal plane) ... checked through the exit pupil."""
+    pkg = _pkg()
+    lens = pkg.load_lens_file("dgauss11.lens")
+    efl = pkg.paraxial_efl(lens)
+    scale = pkg.paraxial_image_scale(lens)
+    assert abs(scale / efl - 1.0) < 2e-3                   # the file's sensor sits (nearly) in the focal plane
+    z_xp, _ = pkg.paraxial_exit_pupil(lens)                # prescription coordinates: z = 0 at the first vertex
+    to_sensor = float(np.sum(lens["thickness"], dtype=np.float64)) - z_xp
+    moved = dict(lens, thickness=lens["thickness"].copy())
+    moved["thickness"][-1] += 1.5
+    scale_m = pkg.paraxial_image_scale(moved)
+    # a chief ray leaves the exit pupil's centre: similar triangles over the distances pupil -> sensor
+    assert scale_m > scale
+    assert abs(scale_m / scale - (to_sensor + 1.5) / to_sensor) < 1e-6
+    # a thin lens with the stop at the lens: the chief ray goes straight through the vertex
+    tl = pkg.load_lens_file("thinlens.lens")
+    s = pkg.paraxial_image_scale(tl)
+    assert abs(s / pkg.paraxial_efl(tl) - 1.0) < 0.05 and s > 0
