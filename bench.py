@@ -48,6 +48,22 @@ FP32_PEAK_TFLOPS = 256 * 4 * 32 * 2 * CLOCK_HZ / 1e12   # 157.3: 32 lanes x FMA 
 FLOP_PER_EVENT = 38.0
 FLOP_PER_FRESNEL = 20.0
 SUN_NS = (0.521445, 0.517156)
+ABLATION_FILE = os.path.join(ROOT, "profiles", "r04_all_weights_ablation.json")
+
+
+def every_event_weighted():
+    """The like-for-like figure for SURVEY 8d's unit (intersect + refract/reflect + Fresnel on EVERY event), as
+    recorded by the ablation build (never shipped: its pixels are wrong); None if the record is absent."""
+    try:
+        with open(ABLATION_FILE) as f:
+            rec = json.load(f)
+        return {"recorded_in": os.path.relpath(ABLATION_FILE, ROOT), "config": "c3",
+                "ms_per_frame": rec["all_weights"]["ms_per_frame"],
+                "executed_events_per_s": rec["all_weights"]["executed_events_per_s"],
+                "time_over_shipped": rec["ratio_time"],
+                "note": "not measured by this run: -DLF_MARCH_ALL_WEIGHTS timing build, same box as its shipped leg"}
+    except Exception:  # noqa: BLE001
+        return None
 TILE_ROWS = 8   # the march kernel's sensor tile is 8x8 pixels
 PMC_FILES = [os.path.join(ROOT, "profiles", n) for n in ("r04_march_pmc.json", "r03_march_pmc.json", "r02_march_pmc.json")]   # newest first
 
@@ -633,9 +649,11 @@ def main():
             # Fresnel / aperture WEIGHT is computed by marching a finished path a second time, only where a
             # lane reached the light's lobe: `remarch_events` (counted, NEVER added to `value`) is how many
             # events that second march evaluated for the lanes that needed them, and
-            # fresnel_evaluated_fraction = that / executed.  profiles/r03_all_weights_ablation.json prices
-            # the event of SURVEY 8d (weight on every event) against this.
+            # fresnel_evaluated_fraction = that / executed.  profiles/r04_all_weights_ablation.json prices
+            # the event of SURVEY 8d (weight on every event) against this: `every_event_weighted` quotes that
+            # RECORDED measurement (c3 frame, a timing-only build) -- it is not measured by this run.
             "event_accounting": {
+                "every_event_weighted": every_event_weighted(),
                 "fresnel_evaluated_fraction": remarch_lane / executed if executed else None,
                 "remarch_events": remarch_lane / args.steps,
                 "remarch_rows_x64": 64.0 * remarch_rows / args.steps,

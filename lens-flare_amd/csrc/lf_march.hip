@@ -179,8 +179,15 @@ void k_march(const LfLensDev* __restrict__ lens, const LfPairsDev* __restrict__ 
   // end uses the carried weight instead of marching the path again (fork states do not carry the
   // weight here, so pixels are wrong; events, fates and the instruction mix are the real thing)
   constexpr bool kW1 = true;
+  // ... with the row's real Fresnel scale factors, fetched beside the row like the re-march fetches them
+#define LF_WROW_INIT LfWeightRow curw = load_wrec(wrecs, (unsigned)hdr.rec);
+#define LF_WROW_LOAD(rec) curw = load_wrec(wrecs, (rec))
+#define LF_WROW_ARGS(j) , curw.fs[j], curw.fo[j], curw.fi[j]
 #else
   constexpr bool kW1 = false;
+#define LF_WROW_INIT
+#define LF_WROW_LOAD(rec) do { } while (0)
+#define LF_WROW_ARGS(j)
 #endif
   __shared__ unsigned long long s_acc[64 * 3];
   __shared__ unsigned long long s_cnt[kMarchCounters];
@@ -388,12 +395,14 @@ void k_march(const LfLensDev* __restrict__ lens, const LfPairsDev* __restrict__ 
         // last iteration has already fetched the row the dispatch below looks at next
         LfProgHdr hdr = load_phdr(prog, e);
         LfProgRow cur = load_prec(recs, (unsigned)hdr.rec);
+        LF_WROW_INIT
         // the next row: its header and -- named by the current header -- its record, issued together
         auto step = [&]() {
           const unsigned rn = (unsigned)hdr.rec_next;
           e += kHdr;
           hdr = load_phdr(prog, e);
           cur = load_prec(recs, rn);
+          LF_WROW_LOAD(rn);
         };
         while (e != prog_end) {
           const unsigned fl = (unsigned)hdr.flags;
@@ -423,7 +432,7 @@ void k_march(const LfLensDev* __restrict__ lens, const LfPairsDev* __restrict__ 
                 lanemask geom_ok;
                 LF_HIST(alive[j]);
                 okv[j] = surface_event<kW1>(r[j], cur.dzv, cur.curv, cur.ch, cur.c2, cur.sc, cur.cn22[j], cur.rn2[j],
-                                            cur.delta[j], cur.h2, true, false, cur.sgn, geom_ok);
+                                            cur.delta[j], cur.h2, true, false, cur.sgn, geom_ok LF_WROW_ARGS(j));
                 died |= alive[j] & ~okv[j];
               }
               if (__builtin_expect(died != 0ull, 0)) {
@@ -454,7 +463,7 @@ void k_march(const LfLensDev* __restrict__ lens, const LfPairsDev* __restrict__ 
                   if (LF_SKIP_DEAD_LAMBDA && K > 1 && __builtin_expect(alive[j] == 0ull, 0)) { okv[j] = 0ull; gv[j] = 0ull; continue; }
                   LF_HIST(alive[j]);
                   okv[j] = surface_event<kW1>(r[j], cur.dzv, cur.curv, cur.ch, cur.c2, cur.sc, cur.cn22[j], cur.rn2[j],
-                                              cur.delta[j], cur.h2, false, false, cur.sgn, gv[j]);
+                                              cur.delta[j], cur.h2, false, false, cur.sgn, gv[j] LF_WROW_ARGS(j));
                   died |= alive[j] & ~okv[j];
                 }
               }
@@ -513,7 +522,7 @@ void k_march(const LfLensDev* __restrict__ lens, const LfPairsDev* __restrict__ 
               LF_HIST(alive[j]);
               okv[j] = surface_event<kW1>(r[j], cur.dzv, cur.curv, cur.ch, cur.c2, cur.sc, cur.cn22[j], cur.rn2[j],
                                           cur.delta[j], cur.h2, (fl & LF_EV_REFLECT) != 0,
-                                          (fl & LF_EV_FLAT) != 0, cur.sgn, gv[j]);
+                                          (fl & LF_EV_FLAT) != 0, cur.sgn, gv[j] LF_WROW_ARGS(j));
               died |= alive[j] & ~okv[j];
             }
             if (__builtin_expect(died != 0ull, 0)) {
@@ -539,6 +548,7 @@ void k_march(const LfLensDev* __restrict__ lens, const LfPairsDev* __restrict__ 
             e = e - kHdr + (((unsigned)sk & ~3u) << 2);  // (sk >> 2) rows of 16 bytes
             hdr = load_phdr(prog, e);
             cur = load_prec(recs, (unsigned)hdr.rec);
+            LF_WROW_LOAD((unsigned)hdr.rec);
             if ((sk & 3) == 1) unpark_all(1, alive1);
             else if ((sk & 3) == 2) unpark_all(0, alive0);
           } else if (endfl & LF_EV_END) {
