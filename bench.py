@@ -39,6 +39,13 @@ HBM_PEAK_GBS = 8000.0                     # MI355X_MICROARCH.md: HBM3E 8 TB/s sp
 CLOCK_HZ = 2.4e9
 VALU_PEAK = 256 * 4 * CLOCK_HZ / 2.0      # wave64 instructions / s: 1024 SIMD-32, 2 clk each
 VALU_PRACTICAL = 1.05e12                  # profiles/microbench/valu_issue.hip (independent v_fma_f32)
+# What one SIMD spends per wave64 instruction when 8 waves issue (profiles/microbench/valu_issue_result_3.txt):
+# a dependent v_fma_f32 chain sustains 1.06e12 instr/s on the 1024 SIMDs; a v_sqrt_f32 INSIDE such a chain
+# (7 fma + 1 root: 6.78e11; the march's event mix of 25 + 2: 7.88e11, wherever the roots are placed) costs
+# 5.4 ns = 13 clocks -- the quarter rate (8.1 clocks back to back) plus the switch in and out of the
+# transcendental pipe -- and nothing overlaps it.
+T_VALU_NS = 1024.0 / 1.06e12 * 1e9        # 0.966 ns per SIMD
+T_TRANS_NS = 5.4
 SCALAR_PEAK = 256 * CLOCK_HZ              # one scalar unit per CU, one instruction per clock
 FP32_PEAK_TFLOPS = 256 * 4 * 32 * 2 * CLOCK_HZ / 1e12   # 157.3: 32 lanes x FMA per clock and SIMD (dense vector FP32)
 # arithmetic of ONE executed event as lf_march.hip's surface_event<false> codes it (a refraction at a curved
@@ -612,6 +619,17 @@ def main():
             roof["achieved"] = ev_rate_gpu * vi
             roof["frac"] = roof["achieved"] / VALU_PEAK
             roof["frac_of_practical"] = roof["achieved"] / VALU_PRACTICAL
+            trans = (pmc.get("per_launch") or {}).get("SQ_INSTS_VALU_TRANS_F32")
+            valu = pmc.get("valu_wave_instr_per_launch")
+            if trans and valu:
+                # the rate the vector pipe sustains for THIS instruction mix (a fraction f of v_sqrt_f32 / v_rcp_f32)
+                f = trans / valu
+                mix_peak = 1024.0 / (((1.0 - f) * T_VALU_NS + f * T_TRANS_NS) * 1e-9)
+                roof["mix"] = {"transcendental_fraction": f, "peak": mix_peak, "frac": roof["achieved"] / mix_peak,
+                               "unit": "wave-instr/s",
+                               "note": "peak = 1024 SIMDs / ((1 - f) x 0.966 ns + f x 5.4 ns): what the pipe sustains for a "
+                                       "dependent chain with this share of quarter-rate roots at 8 waves per SIMD, measured "
+                                       "(profiles/microbench/valu_issue.hip, result_3); the march runs 6 waves per SIMD"}
             roof["valu_wave_instr_per_executed_event"] = vi
             roof["scalar"] = {"achieved": ev_rate_gpu * si, "peak": SCALAR_PEAK, "unit": "instr/s",
                               "frac": ev_rate_gpu * si / SCALAR_PEAK,

@@ -62,6 +62,40 @@ __global__ __launch_bounds__(256) void k(float* out, int iters, float seed) {
                      "v_pk_add_f32 %3, %3, %5\n v_pk_mul_f32 %0, %0, %4\n v_pk_add_f32 %1, %1, %5\n"
                      "v_pk_mul_f32 %2, %2, %4\n v_pk_add_f32 %3, %3, %5\n"
                      : "+v"(p0), "+v"(p1), "+v"(p2), "+v"(p3) : "v"(pm), "v"(pc));
+      } else if (MODE == 9) {  // 8 dependent v_sqrt_f32: the transcendental rate alone
+        asm volatile("v_sqrt_f32 %0, %0\n s_nop 0\n v_sqrt_f32 %0, %0\n s_nop 0\n v_sqrt_f32 %0, %0\n s_nop 0\n v_sqrt_f32 %0, %0\n s_nop 0\n"
+                     "v_sqrt_f32 %0, %0\n s_nop 0\n v_sqrt_f32 %0, %0\n s_nop 0\n v_sqrt_f32 %0, %0\n s_nop 0\n v_sqrt_f32 %0, %0\n s_nop 0\n"
+                     : "+v"(a0));
+      } else if (MODE == 10) {  // 7 fma + 1 sqrt, dependent: does the root overlap other waves' fma?
+        asm volatile("v_fma_f32 %0, %0, %1, %2\n v_fma_f32 %0, %0, %1, %2\n v_fma_f32 %0, %0, %1, %2\n"
+                     "v_sqrt_f32 %0, %0\n s_nop 0\n v_fma_f32 %0, %0, %1, %2\n v_fma_f32 %0, %0, %1, %2\n"
+                     "v_fma_f32 %0, %0, %1, %2\n v_fma_f32 %0, %0, %1, %2\n"
+                     : "+v"(a0) : "v"(m), "v"(c));
+      } else if (MODE == 11) {  // 4 fma + 4 sqrt alternating, dependent
+        asm volatile("v_fma_f32 %0, %0, %1, %2\n v_sqrt_f32 %0, %0\n s_nop 0\n v_fma_f32 %0, %0, %1, %2\n v_sqrt_f32 %0, %0\n s_nop 0\n"
+                     "v_fma_f32 %0, %0, %1, %2\n v_sqrt_f32 %0, %0\n s_nop 0\n v_fma_f32 %0, %0, %1, %2\n v_sqrt_f32 %0, %0\n s_nop 0\n"
+                     : "+v"(a0) : "v"(m), "v"(c));
+      } else if (MODE == 12) {  // the march's event mix: 25 fma-class + 2 sqrt, dependent (x8 per iteration -> scaled below)
+        asm volatile("v_fma_f32 %0, %0, %1, %2\n v_fma_f32 %0, %0, %1, %2\n v_fma_f32 %0, %0, %1, %2\n v_fma_f32 %0, %0, %1, %2\n"
+                     "v_fma_f32 %0, %0, %1, %2\n v_fma_f32 %0, %0, %1, %2\n v_fma_f32 %0, %0, %1, %2\n v_fma_f32 %0, %0, %1, %2\n"
+                     "v_fma_f32 %0, %0, %1, %2\n v_sqrt_f32 %0, %0\n s_nop 0\n v_fma_f32 %0, %0, %1, %2\n v_fma_f32 %0, %0, %1, %2\n"
+                     "v_fma_f32 %0, %0, %1, %2\n v_fma_f32 %0, %0, %1, %2\n v_fma_f32 %0, %0, %1, %2\n v_fma_f32 %0, %0, %1, %2\n"
+                     "v_sqrt_f32 %0, %0\n s_nop 0\n v_fma_f32 %0, %0, %1, %2\n v_fma_f32 %0, %0, %1, %2\n v_fma_f32 %0, %0, %1, %2\n"
+                     "v_fma_f32 %0, %0, %1, %2\n v_fma_f32 %0, %0, %1, %2\n v_fma_f32 %0, %0, %1, %2\n v_fma_f32 %0, %0, %1, %2\n"
+                     "v_fma_f32 %0, %0, %1, %2\n v_fma_f32 %0, %0, %1, %2\n v_fma_f32 %0, %0, %1, %2\n"
+                     : "+v"(a0) : "v"(m), "v"(c));
+      } else if (MODE == 13) {  // event mix, the two roots ADJACENT (the second one's input does not need the first)
+        asm volatile("v_fma_f32 %0, %0, %4, %5\n v_fma_f32 %0, %0, %4, %5\n v_fma_f32 %0, %0, %4, %5\n v_fma_f32 %0, %0, %4, %5\n v_fma_f32 %0, %0, %4, %5\n v_fma_f32 %0, %0, %4, %5\n v_fma_f32 %0, %0, %4, %5\n v_fma_f32 %0, %0, %4, %5\n v_add_f32 %1, %0, %5\n v_sqrt_f32 %2, %0\n v_sqrt_f32 %3, %1\n s_nop 0\n"
+                     "v_fma_f32 %0, %2, %4, %3\n v_fma_f32 %0, %0, %4, %5\n v_fma_f32 %0, %0, %4, %5\n v_fma_f32 %0, %0, %4, %5\n v_fma_f32 %0, %0, %4, %5\n v_fma_f32 %0, %0, %4, %5\n v_fma_f32 %0, %0, %4, %5\n v_fma_f32 %0, %0, %4, %5\n v_fma_f32 %0, %0, %4, %5\n v_fma_f32 %0, %0, %4, %5\n v_fma_f32 %0, %0, %4, %5\n v_fma_f32 %0, %0, %4, %5\n v_fma_f32 %0, %0, %4, %5\n v_fma_f32 %0, %0, %4, %5\n v_fma_f32 %0, %0, %4, %5\n v_fma_f32 %0, %0, %4, %5\n "
+                     : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3) : "v"(m), "v"(c));
+      } else if (MODE == 14) {  // event mix, three independent fma between each root and its first use
+        asm volatile("v_fma_f32 %0, %0, %4, %5\n v_fma_f32 %0, %0, %4, %5\n v_fma_f32 %0, %0, %4, %5\n v_fma_f32 %0, %0, %4, %5\n v_fma_f32 %0, %0, %4, %5\n v_fma_f32 %0, %0, %4, %5\n v_fma_f32 %0, %0, %4, %5\n v_fma_f32 %0, %0, %4, %5\n v_fma_f32 %0, %0, %4, %5\n v_sqrt_f32 %2, %0\n v_fma_f32 %1, %1, %4, %5\n v_fma_f32 %1, %1, %4, %5\n v_fma_f32 %1, %1, %4, %5\n v_fma_f32 %0, %2, %4, %5\n v_fma_f32 %0, %0, %4, %5\n v_fma_f32 %0, %0, %4, %5\n "
+                     "v_sqrt_f32 %3, %0\n v_fma_f32 %1, %1, %4, %5\n v_fma_f32 %1, %1, %4, %5\n v_fma_f32 %1, %1, %4, %5\n v_fma_f32 %0, %3, %4, %5\n v_fma_f32 %0, %0, %4, %5\n v_fma_f32 %0, %0, %4, %5\n v_fma_f32 %0, %0, %4, %5\n v_fma_f32 %0, %0, %4, %5\n v_fma_f32 %0, %0, %4, %5\n v_fma_f32 %0, %0, %4, %5\n "
+                     : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3) : "v"(m), "v"(c));
+      } else if (MODE == 15) {  // event mix, roots adjacent AND three independent fma before the first use
+        asm volatile("v_fma_f32 %0, %0, %4, %5\n v_fma_f32 %0, %0, %4, %5\n v_fma_f32 %0, %0, %4, %5\n v_fma_f32 %0, %0, %4, %5\n v_fma_f32 %0, %0, %4, %5\n v_fma_f32 %0, %0, %4, %5\n v_fma_f32 %0, %0, %4, %5\n v_fma_f32 %0, %0, %4, %5\n v_add_f32 %1, %0, %5\n v_sqrt_f32 %2, %0\n v_sqrt_f32 %3, %1\n v_fma_f32 %1, %1, %4, %5\n v_fma_f32 %1, %1, %4, %5\n v_fma_f32 %1, %1, %4, %5\n "
+                     "v_fma_f32 %0, %2, %4, %3\n v_fma_f32 %0, %0, %4, %5\n v_fma_f32 %0, %0, %4, %5\n v_fma_f32 %0, %0, %4, %5\n v_fma_f32 %0, %0, %4, %5\n v_fma_f32 %0, %0, %4, %5\n v_fma_f32 %0, %0, %4, %5\n v_fma_f32 %0, %0, %4, %5\n v_fma_f32 %0, %0, %4, %5\n v_fma_f32 %0, %0, %4, %5\n v_fma_f32 %0, %0, %4, %5\n v_fma_f32 %0, %0, %4, %5\n v_fma_f32 %0, %0, %4, %5\n "
+                     : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3) : "v"(m), "v"(c));
       } else if (MODE == 6) {  // cmp + cndmask pairs through VCC, dependent
         asm volatile("v_cmp_gt_f32 vcc, %0, %2\n v_cndmask_b32 %0, %0, %1, vcc\n v_fma_f32 %0, %0, %1, %2\n"
                      "v_cmp_gt_f32 vcc, %0, %2\n v_cndmask_b32 %0, %0, %1, vcc\n v_fma_f32 %0, %0, %1, %2\n"
@@ -95,10 +129,13 @@ int main() {
   const char* names[] = {"8 independent fma chains", "1 dependent fma chain", "2 interleaved chains",
                          "8 indep fma + 4 SALU per 8", "dependent fma + 4 SALU per 8",
                          "dependent: 6 fma + sqrt + rcp", "dependent: 2x(cmp+cndmask) + 4 fma",
-                         "4 indep v_pk_fma_f32 chains", "v_pk_mul/v_pk_add alternating"};
+                         "4 indep v_pk_fma_f32 chains", "v_pk_mul/v_pk_add alternating",
+                         "dependent: 8 v_sqrt_f32", "dependent: 7 fma + 1 sqrt", "dependent: 4 x (fma, sqrt)",
+                         "dependent: event mix 25 fma + 2 sqrt", "event mix, roots adjacent",
+                         "event mix, 3 indep fma after each root", "event mix, adjacent + 3 indep"};
   for (int wps : {2, 8}) {  // waves per SIMD = blocks per CU (256 threads = 4 waves = 1/SIMD)
     int blocks = 256 * wps;
-    double r[9];
+    double r[16];
     r[0] = run<0>(d, blocks, 20000, 8);
     r[1] = run<1>(d, blocks, 20000, 8);
     r[2] = run<2>(d, blocks, 20000, 8);
@@ -108,7 +145,14 @@ int main() {
     r[6] = run<6>(d, blocks, 20000, 8);
     r[7] = run<7>(d, blocks, 20000, 8);
     r[8] = run<8>(d, blocks, 20000, 8);
-    for (int i = 0; i < 9; i++)
+    r[9] = run<9>(d, blocks, 20000, 8);
+    r[10] = run<10>(d, blocks, 20000, 8);
+    r[11] = run<11>(d, blocks, 20000, 8);
+    r[12] = run<12>(d, blocks, 6000, 27);
+    r[13] = run<13>(d, blocks, 6000, 27);
+    r[14] = run<14>(d, blocks, 6000, 27);
+    r[15] = run<15>(d, blocks, 6000, 27);
+    for (int i = 0; i < 16; i++)
       if (i != 3 && i != 4) printf("waves/SIMD %d  %-36s %.3e VALU wave-instr/s  (%.2f cyc/instr/SIMD @2.4GHz)\n", wps, names[i],
              r[i], 1024 * 2.4e9 / r[i]);
   }
