@@ -19,6 +19,9 @@ pkg = g.load_package()
 out = {}
 for name, (W, H) in {"1080p": (1920, 1080), "4k": (3840, 2160)}.items():
     for jitter in ("counter", "mt19937"):
+        # LF_FLARE_JITTER=counter | mt19937: one mode only (per-mode counters: profiles/run_pmc_flare.sh)
+        if os.environ.get("LF_FLARE_JITTER", jitter) != jitter:
+            continue
         lf = pkg.LensFlare(0)
         lf.timing_enable(True)
         lf.set_frame(W, H)
