@@ -313,8 +313,14 @@ def main():
     # rank together, should the C ABI's communicator fail to initialise.
     # LF_BENCH_REHEARSAL=1: several ranks share GPU 0 on a one-GPU box (no RCCL communicator is
     # possible there: the exchange is staged through host memory over gloo).
-    rehearsal = os.environ.get("LF_BENCH_REHEARSAL") == "1"
-    gather_mode = "none" if world == 1 else ("host" if rehearsal else os.environ.get("LF_BENCH_GATHER", "cabi"))
+    # LF_BENCH_REHEARSAL=rccl: the same sharing, but the C ABI's RCCL bring-up is ATTEMPTED on the shared GPU
+    # (agree -> id over gloo -> ncclCommInitRank under the deadline -> first exchange -> common verdict); RCCL
+    # is expected to refuse two ranks on one device, which then exercises the real failure path (every rank
+    # aborts together, the exchange falls back to the host staging) on real hardware.
+    rehearsal_rccl = os.environ.get("LF_BENCH_REHEARSAL") == "rccl"
+    rehearsal = os.environ.get("LF_BENCH_REHEARSAL") == "1" or rehearsal_rccl
+    gather_mode = "none" if world == 1 else ("cabi" if rehearsal_rccl else "host" if rehearsal
+                                             else os.environ.get("LF_BENCH_GATHER", "cabi"))
     local = local % max(1, torch.cuda.device_count()) if rehearsal else local
     torch.cuda.set_device(local)
     nccl_group = None
@@ -442,9 +448,13 @@ def main():
                 lf.comm_abort()
             except Exception:  # noqa: BLE001
                 pass
-            gather_mode = "torch"
-            gather_note = "C-ABI RCCL exchange unavailable (" + "; ".join(bad) + "): torch.distributed nccl exchange"
-            nccl_group = dist.new_group(backend="nccl")
+            if rehearsal:
+                gather_mode = "host"
+                gather_note = "C-ABI RCCL exchange unavailable (" + "; ".join(bad) + "): exchange staged through the host (rehearsal)"
+            else:
+                gather_mode = "torch"
+                gather_note = "C-ABI RCCL exchange unavailable (" + "; ".join(bad) + "): torch.distributed nccl exchange"
+                nccl_group = dist.new_group(backend="nccl")
             lf.set_row_interleave(rank, world)
     if gather_mode in ("torch", "host"):
         ptr, nbytes = lf.device_buffer(pkg.SAMPLE_BUFFER)
