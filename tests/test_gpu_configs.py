@@ -213,6 +213,15 @@ def test_c4_full_size_frame_through_the_lens(pkg, lf):
     ghost_row = lf.read_tile(pkg.GHOST_BUFFER, 0, y0, W, y0 + 256).sum(axis=-1)
     ys, xs = np.nonzero(ghost_row > 0.5 * ghost_row.max())
     assert abs(xs.mean() - fl["origins"][0][0] * W) < 6 and abs(ys.mean() + y0 - fl["origins"][0][1] * H) < 6
+    # ... and the tile row of the 4K frame that holds it, at the configuration's full 256 spp, against the float32
+    # oracle bit for bit (the sun = what the hand-over made of the scene's own DirectionalLight)
+    nx, ny = fl["origins"][0]
+    sun = [(nx - 0.5) * lens["sensor_width_mm"] / efl, (ny - 0.5) * lens["sensor_width_mm"] * H / W / efl, -1.0]
+    yt = (int(ny * H) // 8) * 8
+    band = lf.read_tile(pkg.GHOST_BUFFER, 0, yt, W, yt + 8)
+    og, _ = lfo.geo_trace(lens, W, H, yt, yt + 8, spp, key, None, True, mask, sun, list(fl["radiance"][0]), 0.05,
+                          n_threads=16)
+    assert band.max() > 0 and np.array_equal(band, og[yt:yt + 8])
     frame()
     assert np.array_equal(lf.read_tile(pkg.SAMPLE_BUFFER, x0, y0, x0 + 512, y0 + 256), a1)
     assert lf.scene_counters() == sc and lf.counters() == cnt

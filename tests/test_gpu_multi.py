@@ -264,8 +264,9 @@ def test_tonemapped_frame_is_refreshed_by_an_exchange(pkg):
     grp.close()
 
 
-@pytest.mark.parametrize("W,H,spp", [(1920, 1080, 4), (3840, 2160, 1)])
-@pytest.mark.parametrize("bits", [64, 32])
+@pytest.mark.parametrize("W,H,spp,bits", [(1920, 1080, 4, 64), (3840, 2160, 1, 64), (1920, 1080, 4, 32), (3840, 2160, 1, 32),
+                                          # ... and at the configurations' own sample counts: c3 / C4's march as 8 ranks render it
+                                          (1920, 1080, 256, 64), (3840, 2160, 256, 64)])
 def test_eight_ranks_at_bench_sizes(pkg, W, H, spp, bits):
     """What only an 8-GPU node would otherwise reveal: the exchange's correctness hinges
     on the [groups][world][tile row] staging layout being what ncclAllGather delivers.  8 contexts on device 0
