@@ -266,7 +266,9 @@ def test_tonemapped_frame_is_refreshed_by_an_exchange(pkg):
 
 @pytest.mark.parametrize("W,H,spp,bits", [(1920, 1080, 4, 64), (3840, 2160, 1, 64), (1920, 1080, 4, 32), (3840, 2160, 1, 32),
                                           # ... and at the configurations' own sample counts: c3 / C4's march as 8 ranks render it
-                                          (1920, 1080, 256, 64), (3840, 2160, 256, 64)])
+                                          (1920, 1080, 256, 64), (3840, 2160, 256, 64),
+                                          # C5: 8 wavelengths (the committed Cauchy-fit prescription) at 4K x 1024 spp
+                                          (3840, 2160, 1024, 64)])
 def test_eight_ranks_at_bench_sizes(pkg, W, H, spp, bits):
     """What only an 8-GPU node would otherwise reveal: the exchange's correctness hinges
     on the [groups][world][tile row] staging layout being what ncclAllGather delivers.  8 contexts on device 0
@@ -275,11 +277,14 @@ def test_eight_ranks_at_bench_sizes(pkg, W, H, spp, bits):
     exercised -- in the f64 and the f32 exchange: every rank ends with the single-context frame, bit for bit
     (f32: the received rows rounded), and the plan is the one lf_comm_gather hands to ncclAllGather."""
     n = 8
-    lens = pkg.load_lens_file("dgauss11.lens")
+    lens = pkg.load_lens_file("dgauss11_8lambda.lens" if spp == 1024 else "dgauss11.lens")
+    w8 = pkg.spectral_weights(lens["lambda_nm"])[0] if spp == 1024 else None
     mask = load_texels("pentbig500_14.png")
     one = pkg.LensFlare(0)
     one.set_frame(W, H)
     _setup(pkg, one, lens, mask)
+    if w8 is not None:
+        one.set_lambda_rgb(w8)
     one.reset_counters()
     _frame(one, spp, 9)
     want = one.read_buffer(pkg.SAMPLE_BUFFER)
@@ -293,6 +298,8 @@ def test_eight_ranks_at_bench_sizes(pkg, W, H, spp, bits):
     grp.set_frame(W, H)
     for r in grp.ranks:
         _setup(pkg, r, lens, mask)
+        if w8 is not None:
+            r.set_lambda_rgb(w8)
         r.reset_counters()
         r.comm_set_exchange_precision(bits)
         plan = r.comm_exchange_plan(n)
