@@ -1,7 +1,8 @@
 """BASELINE.json's configurations as whole frames through the C ABI ("configs only
 exercised in pieces"): C5 = 8-wavelength march + spectral starburst composed in ONE frame (small
-size against the oracles, 4K x 1 spp by properties); C3 at its full 1080p x 256 spp (properties + a
-row crop bit for bit against the oracle)."""
+size against the oracles, 4K x 1 spp and 4K x 1024 spp by properties); C3 at its full 1080p x 256 spp
+(properties + a row crop bit for bit against the oracle); C4 at its full 4K x 256 spp with the scene imaged
+through the lens (properties + the sun's tile row bit for bit against the oracle)."""
 import math
 
 import numpy as np
@@ -90,11 +91,13 @@ def test_c5_one_frame_small(pkg, lf):
         assert np.all(np.abs((star[y, x] - mono[y, x]) - (o_spec - o_mono)) <= tol), (x, y)
 
 
-def test_c5_whole_4k_frame_properties(pkg, lf):
-    """C5's frame size with 8 wavelengths + spectral starburst, 1 spp: exact ray budget, every ray
-    accounted for, sensor = ghost + starburst on a window, identical when rendered twice, and the
-    first 16 rows bit for bit against the oracle."""
-    W, H, spp, key = 3840, 2160, 1, 0x5C
+@pytest.mark.parametrize("spp", [1, 1024])
+def test_c5_whole_4k_frame_properties(pkg, lf, spp):
+    """C5's frame size with 8 wavelengths + spectral starburst, at 1 spp and at the configuration's full
+    1024 spp: exact ray budget, every ray accounted for, sensor = ghost + starburst on a window, identical
+    when rendered twice, and (1 spp) the first 16 rows bit for bit against the oracle -- at 1024 spp the
+    oracle's share is the tile row of tests/test_gpu_march_f64.py and the 8-rank form of test_gpu_multi.py."""
+    W, H, key = 3840, 2160, 0x5C
     lens8, w8, scale, mask, efl, hf, vf, light = _c5_setup(pkg, lf, W, H)
     lf.find_sun_pos([light])
     lf.set_sun_from_flares(0, efl, 0.05)
@@ -112,6 +115,8 @@ def test_c5_whole_4k_frame_properties(pkg, lf):
     lf.trace_ghosts(spp, key)
     lf.render_flare_layer()
     assert np.array_equal(lf.read_tile(pkg.SAMPLE_BUFFER, x0, y0, x0 + 512, y0 + 256), a1)
+    if spp > 1:
+        return
     sun = [(SUN_NS[0] - 0.5) * lens8["sensor_width_mm"] / efl, (SUN_NS[1] - 0.5) * lens8["sensor_width_mm"] * H / W / efl, -1.0]
     og, _ = lfo.geo_trace(lens8, W, H, 0, 16, spp, key, None, True, mask, sun, [1.0, 0.9, 0.5], 0.05,
                           n_threads=16, lambda_rgb=w8)
