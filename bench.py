@@ -3,6 +3,8 @@
 
     python bench.py [--gpus N --steps K --warmup W] [--config c2|c3|c4_1gpu|c5_1gpu]
     python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N --steps K --warmup W
+(`python bench.py --gpus N` with N > 1 and no torchrun environment starts the N ranks itself, as child
+processes, before it touches the GPU: lens_flare_amd.sharding.self_launch.)
 
 Default workload = BASELINE.json configs[2], the one its metric is quoted on ("c3"): Double-Gauss
 11-interface prescription (lens-flare_amd/data/dgauss11.lens), primary path + all 45 ghost pairs,
@@ -294,16 +296,23 @@ def main():
     cfg = dict(CONFIGS[args.config])
     W, H, spp = args.width or cfg["W"], args.height or cfg["H"], args.spp or cfg["spp"]
 
+    import __graft_entry__ as g
+    pkg = g.load_package()          # (ctypes + numpy: nothing here touches the GPU)
+    from lens_flare_amd import sharding
+    if sharding.needs_self_launch(args.gpus, os.environ):
+        # `python3 bench.py --gpus N` without torchrun: this process starts the N ranks as children (one per GPU,
+        # the same arguments), relays rank 0's JSON line and exits with their verdict.  It has not imported
+        # torch.cuda nor made any HIP call, and it never execs.
+        raise SystemExit(sharding.self_launch(os.path.abspath(__file__), sys.argv[1:], args.gpus))
+
     import torch
     import torch.distributed as dist
-    import __graft_entry__ as g
-    pkg = g.load_package()
 
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
     if args.gpus > 1 and world != args.gpus:
-        raise SystemExit(f"--gpus {args.gpus} needs WORLD_SIZE={args.gpus} (launch with torch.distributed.run)")
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: the launcher's rank count and --gpus must agree")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the hot path has no CPU fallback")
     # Control plane (rendezvous, the RCCL id, barriers, the final sums): torch.distributed over gloo.
@@ -322,6 +331,9 @@ def main():
     gather_mode = "none" if world == 1 else ("cabi" if rehearsal_rccl else "host" if rehearsal
                                              else os.environ.get("LF_BENCH_GATHER", "cabi"))
     local = local % max(1, torch.cuda.device_count()) if rehearsal else local
+    if local >= torch.cuda.device_count():
+        raise SystemExit(f"rank {rank}: local rank {local} has no GPU (this node shows {torch.cuda.device_count()}); "
+                         "LF_BENCH_REHEARSAL=1 lets several ranks share GPU 0")
     torch.cuda.set_device(local)
     nccl_group = None
     if world > 1:
@@ -394,7 +406,6 @@ def main():
 
     # sensor tile rows (8 rows each) are dealt round-robin: tile row t belongs to rank t % world.
     # One march launch per frame covers all of this rank's tile rows.
-    from lens_flare_amd import sharding
     my_trows = len(sharding.my_tile_rows(H, rank, world))
     lf.set_band(0, H)
     lf.set_row_interleave(rank, world)

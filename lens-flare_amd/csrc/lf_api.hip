@@ -1327,10 +1327,17 @@ lf_status lf_get_march_stats(lf_ctx* ctx, uint64_t out[4]) {
   LF_HIP(ctx, hipStreamSynchronize(ctx->stream));
   LF_HIP(ctx, hipMemcpy(c, ctx->counters_dev, sizeof(c), hipMemcpyDeviceToHost));
   out[0] = c[7]; out[1] = c[8]; out[2] = c[9]; out[3] = 0;
-  if (std::getenv("LF_MARCH_PRINT_HIST")) {   // instrumented builds only (LF_MARCH_LIVE_HIST): the slots stay 0 otherwise
-    std::fprintf(stderr, "LIVE_HIST");
-    for (int b = 0; b < 9; b++) std::fprintf(stderr, " %llu", c[kMarchCounters + b]);
-    std::fprintf(stderr, "\n");
+  if (std::getenv("LF_MARCH_PRINT_HIST")) {   // instrumented builds only (LF_MARCH_LIVE_HIST / _PAIR_STATS): the slots stay 0 otherwise
+    static const char* kinds[3] = {"refraction", "mirror_or_flat", "stop"};
+    for (int k = 0; k < 3; k++) {
+      std::fprintf(stderr, "LIVE_HIST %s", kinds[k]);
+      for (int b = 0; b < 9; b++) std::fprintf(stderr, " %llu", c[kMarchHistSlot + 9 * k + b]);
+      std::fprintf(stderr, "\n");
+    }
+    for (int q = 0; q < ctx->pairs.n && q < 64; q++)
+      if (c[kMarchPairSlot + q] | c[kMarchPairSlot + 64 + q])
+        std::fprintf(stderr, "PAIR_STAT %d %d %d %llu %llu %llu\n", q, ctx->pairs.ij[q][0], ctx->pairs.ij[q][1],
+                     c[kMarchPairSlot + q], c[kMarchPairSlot + 64 + q], c[kMarchPairSlot + 128 + q]);
   }
   return LF_OK;
 }

@@ -13,7 +13,9 @@
 // ---- limits -------------------------------------------------------------------------------
 // k_march's counters: the seven of lf_counters, executed events, re-march lane events, re-march rows
 constexpr int kMarchCounters = 10;
-constexpr int kMarchCounterSlots = 32;   // allocated (instrumented experiment builds append a histogram)
+constexpr int kMarchCounterSlots = 256;  // allocated (instrumented experiment builds append their tallies)
+constexpr int kMarchHistSlot = 16;       // -DLF_MARCH_LIVE_HIST: 3 row kinds x 9 live-lane buckets
+constexpr int kMarchPairSlot = 64;       // -DLF_MARCH_PAIR_STATS: 3 x 64 per-path tallies
 constexpr int kMaxParaxialGhosts = 3 * 105;          // 3 colours x C(15,2) pairs
 constexpr int kMaxGhostTris = 2 * kMaxParaxialGhosts; // two triangles per quad
 

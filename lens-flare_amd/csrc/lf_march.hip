@@ -195,11 +195,21 @@ void k_march(const LfLensDev* __restrict__ lens, const LfPairsDev* __restrict__ 
 #ifdef LF_MARCH_LIVE_HIST
   // instrumented build (profiles/r03_march_variants.txt), never shipped: executed wave-ray events by
   // the number of live lanes, bucket = lanes / 8 (8 = all 64)
-  __shared__ unsigned long long s_hist[9];
-  if (threadIdx.x < 9) s_hist[threadIdx.x] = 0ull;
-#define LF_HIST(mask) do { if ((mask) != 0ull && lane_id() == 0) atomicAdd(&s_hist[__popcll(mask) >> 3], 1ull); } while (0)
+  // ... per row kind (round 5): 0 = refraction at a curved interface (the rows of a run), 1 = mirror / flat glass, 2 = the stop
+  __shared__ unsigned long long s_hist[3 * 9];
+  if (threadIdx.x < 27) s_hist[threadIdx.x] = 0ull;
+#define LF_HIST(kind, mask) do { if ((mask) != 0ull && lane_id() == 0) atomicAdd(&s_hist[(kind) * 9 + (__popcll(mask) >> 3)], 1ull); } while (0)
 #else
-#define LF_HIST(mask) do { } while (0)
+#define LF_HIST(kind, mask) do { } while (0)
+#endif
+#ifdef LF_MARCH_PAIR_STATS
+  // instrumented build (profiles/r05_pair_table.json), never shipped: per path q, wave-rays (wave x wavelength)
+  // that complete it with a live lane, those with a lane inside the sun's lobe pre-test, and those lanes
+  __shared__ unsigned long long s_pair[3 * 64];
+  if (threadIdx.x < 192) s_pair[threadIdx.x] = 0ull;
+#define LF_PAIR_STAT(which, q, n) do { if ((n) != 0u && lane_id() == 0) atomicAdd(&s_pair[(which) * 64 + ((q) & 63)], (unsigned long long)(n)); } while (0)
+#else
+#define LF_PAIR_STAT(which, q, n) do { } while (0)
 #endif
   // parked ray states: [wave][slot][ray][px py|pz dx|dy dz][lane]
   // fork slot 1 (the reflection at j, parked and restored once per pair) is parked here; slot 0 (the
@@ -430,7 +440,7 @@ void k_march(const LfLensDev* __restrict__ lens, const LfPairsDev* __restrict__ 
               for (int j = 0; j < K; j++) {
                 if (LF_SKIP_DEAD_LAMBDA && K > 1 && __builtin_expect(alive[j] == 0ull, 0)) { okv[j] = 0ull; continue; }
                 lanemask geom_ok;
-                LF_HIST(alive[j]);
+                LF_HIST(1, alive[j]);
                 okv[j] = surface_event<kW1>(r[j], cur.dzv, cur.curv, cur.ch, cur.c2, cur.sc, cur.cn22[j], cur.rn2[j],
                                             cur.delta[j], cur.h2, true, false, cur.sgn, geom_ok LF_WROW_ARGS(j));
                 died |= alive[j] & ~okv[j];
@@ -461,7 +471,7 @@ void k_march(const LfLensDev* __restrict__ lens, const LfPairsDev* __restrict__ 
                   // a wavelength whose rays are all gone is not computed (one scalar branch; without
                   // it its lanes would keep marching garbage through every row the others still visit)
                   if (LF_SKIP_DEAD_LAMBDA && K > 1 && __builtin_expect(alive[j] == 0ull, 0)) { okv[j] = 0ull; gv[j] = 0ull; continue; }
-                  LF_HIST(alive[j]);
+                  LF_HIST(0, alive[j]);
                   okv[j] = surface_event<kW1>(r[j], cur.dzv, cur.curv, cur.ch, cur.c2, cur.sc, cur.cn22[j], cur.rn2[j],
                                               cur.delta[j], cur.h2, false, false, cur.sgn, gv[j] LF_WROW_ARGS(j));
                   died |= alive[j] & ~okv[j];
@@ -491,7 +501,7 @@ void k_march(const LfLensDev* __restrict__ lens, const LfPairsDev* __restrict__ 
 #pragma unroll
             for (int j = 0; j < K; j++) {
               if (LF_SKIP_DEAD_LAMBDA && K > 1 && __builtin_expect(alive[j] == 0ull, 0)) { okv[j] = 0ull; continue; }
-              LF_HIST(alive[j]);
+              LF_HIST(2, alive[j]);
               okv[j] = stop_event<kW1>(r[j], cur.dzv, cur.h2, inv_stop_h, mask, a.mw, a.mh);
               died |= alive[j] & ~okv[j];
             }
@@ -519,7 +529,7 @@ void k_march(const LfLensDev* __restrict__ lens, const LfPairsDev* __restrict__ 
 #pragma unroll
             for (int j = 0; j < K; j++) {
               if (LF_SKIP_DEAD_LAMBDA && K > 1 && __builtin_expect(alive[j] == 0ull, 0)) { okv[j] = 0ull; gv[j] = 0ull; continue; }
-              LF_HIST(alive[j]);
+              LF_HIST(1, alive[j]);
               okv[j] = surface_event<kW1>(r[j], cur.dzv, cur.curv, cur.ch, cur.c2, cur.sc, cur.cn22[j], cur.rn2[j],
                                           cur.delta[j], cur.h2, (fl & LF_EV_REFLECT) != 0,
                                           (fl & LF_EV_FLAT) != 0, cur.sgn, gv[j] LF_WROW_ARGS(j));
@@ -564,6 +574,9 @@ void k_march(const LfLensDev* __restrict__ lens, const LfPairsDev* __restrict__ 
               const float cg = fmaf(r[j].dx, sx, fmaf(r[j].dy, sy, r[j].dz * sz));
               lit[j] = alive[j] & __ballot(cg > lobe_thr);
               lit_any |= lit[j];
+              LF_PAIR_STAT(0, endfl >> 24, alive[j] != 0ull ? 1u : 0u);
+              LF_PAIR_STAT(1, endfl >> 24, lit[j] != 0ull ? 1u : 0u);
+              LF_PAIR_STAT(2, endfl >> 24, (unsigned)__popcll(lit[j]));
             }
             if (lit_any != 0ull) {
               // rare (about 1 % of the wave-paths): march this path again, alone and with the
@@ -658,7 +671,11 @@ void k_march(const LfLensDev* __restrict__ lens, const LfPairsDev* __restrict__ 
   __syncthreads();
   if (wave == 0 && lane < kMarchCounters && s_cnt[lane]) atomicAdd(&counters[lane], s_cnt[lane]);
 #ifdef LF_MARCH_LIVE_HIST
-  if (wave == 0 && lane < 9 && s_hist[lane]) atomicAdd(&counters[kMarchCounters + lane], s_hist[lane]);
+  if (wave == 0 && lane < 27 && s_hist[lane]) atomicAdd(&counters[kMarchHistSlot + lane], s_hist[lane]);
+#endif
+#ifdef LF_MARCH_PAIR_STATS
+  for (int i = tid; i < 192; i += 64 * kWgWaves)
+    if (s_pair[i]) atomicAdd(&counters[kMarchPairSlot + i], s_pair[i]);
 #endif
 
   // ---- the tile's pixels: 8 rows of 8 x 24 contiguous bytes -----------------------------------

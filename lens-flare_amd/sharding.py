@@ -64,6 +64,65 @@ def gather_frame(frame, W, H, rank, world, dist, elems_per_pixel=3, scratch=None
     v.copy_(recv.permute(1, 0, 2))
 
 
+# ---- one rank per GPU: who starts them --------------------------------------------------------------
+# The reference scales out inside its host: start_raytracing() spawns numWorkerThreads std::threads over
+# one tile queue (raytraced_renderer.cpp:352-354).  Here a rank is a PROCESS (one per GPU), so something has
+# to start N of them: either the caller (python -m torch.distributed.run ... script --gpus N: RANK /
+# WORLD_SIZE are in the environment) or, when the script is started plainly as `python script --gpus N`,
+# the script itself -- through launch_command / self_launch below, BEFORE anything in it touches the GPU.
+def launch_command(script, argv, n_ranks, port, python=None):
+    """The torch.distributed.run command line that starts n_ranks copies of `script argv` on this node
+    (static rendezvous on 127.0.0.1: the container's hostname may not resolve)."""
+    import sys
+    return [python or sys.executable, "-m", "torch.distributed.run", "--nnodes=1",
+            f"--nproc-per-node={int(n_ranks)}", "--master-addr", "127.0.0.1", "--master-port", str(int(port)),
+            script] + [str(a) for a in argv]
+
+
+def free_port():
+    import socket
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def needs_self_launch(n_ranks, environ):
+    """True when the script was asked for n_ranks > 1 and nobody has started the ranks yet."""
+    return int(n_ranks) > 1 and "WORLD_SIZE" not in environ and "RANK" not in environ
+
+
+def self_launch(script, argv, n_ranks, environ=None, out=None, err=None, timeout_s=None):
+    """Start the n_ranks processes as CHILDREN (never an exec: the caller keeps running, and must not have
+    touched the GPU), relay what they print -- lines that are JSON objects to `out`, everything else to `err`
+    -- and return the launcher's exit code: non-zero as soon as any rank fails (torch.distributed.run ends the
+    others), so that a failed rank is a failed run, never a restart."""
+    import os
+    import subprocess
+    import sys
+    out = out or sys.stdout
+    err = err or sys.stderr
+    env = dict(os.environ if environ is None else environ)
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_PORT"):
+        env.pop(k, None)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")   # dmabuf IPC: what RCCL across processes needs on this driver
+    env.setdefault("OMP_NUM_THREADS", "1")
+    cmd = launch_command(script, argv, n_ranks, free_port())
+    print("self-launch: " + " ".join(cmd), file=err, flush=True)
+    p = subprocess.Popen(cmd, env=env, stdout=subprocess.PIPE, stderr=None if err is sys.stderr else subprocess.STDOUT,
+                         text=True, bufsize=1)
+    try:
+        for line in p.stdout:
+            (out if line.lstrip().startswith("{") else err).write(line)
+            (out if line.lstrip().startswith("{") else err).flush()
+        return p.wait(timeout=timeout_s)
+    except BaseException:
+        p.kill()
+        p.wait()
+        raise
+
+
 # ---- bringing up the data-path communicator without ever hanging --------------------------------
 # One process per GPU: a rank that fails LOCALLY (library missing, bad argument, a launch error) while
 # its peers are inside a blocking collective leaves them there for good.  Two rules avoid that:

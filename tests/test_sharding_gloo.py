@@ -157,3 +157,80 @@ def test_one_rank_failing_alone_is_noticed_by_all(stage, tmp_path):
         assert name == "exchange" and not ok and len(bad) == world
         assert "rank 1: RuntimeError: LF_ERR_HIP: injected launch failure" in bad
         assert all("did not complete within" in b for b in bad if not b.startswith("rank 1"))
+
+
+# ---- `python bench.py --gpus N` starts its own ranks (round 5) ------------------------------------------
+_PROBE = """
+import json, os, sys
+rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
+print("noise from rank", rank)                       # not JSON: must go to the launcher's stderr side
+if rank == 0:
+    print(json.dumps({"rank": rank, "world": world, "argv": sys.argv[1:], "local": os.environ["LOCAL_RANK"],
+                      "master": os.environ["MASTER_ADDR"], "ipc": os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY")}))
+sys.exit(int(os.environ.get("PROBE_FAIL_CODE", "3")) if rank == int(os.environ.get("PROBE_FAIL_RANK", "-1")) else 0)
+"""
+
+
+def _sharding():
+    sys.path.insert(0, ROOT)
+    import __graft_entry__ as g
+    g.load_package()
+    from lens_flare_amd import sharding
+    return sharding
+
+
+def test_self_launch_decision_and_command():
+    sharding = _sharding()
+    assert not sharding.needs_self_launch(1, {})
+    assert sharding.needs_self_launch(2, {})
+    assert sharding.needs_self_launch(8, {"HOME": "/root"})
+    # under a launcher (torchrun sets both) behaviour is unchanged: the script is a rank, not a launcher
+    assert not sharding.needs_self_launch(8, {"WORLD_SIZE": "8", "RANK": "3"})
+    assert not sharding.needs_self_launch(2, {"RANK": "0"})
+    cmd = sharding.launch_command("/x/bench.py", ["--gpus", 4, "--steps", "7", "--warmup", 2], 4, 29517, python="py")
+    assert cmd[:3] == ["py", "-m", "torch.distributed.run"]
+    assert "--nproc-per-node=4" in cmd and "--nnodes=1" in cmd
+    assert cmd[cmd.index("--master-addr") + 1] == "127.0.0.1" and cmd[cmd.index("--master-port") + 1] == "29517"
+    i = cmd.index("/x/bench.py")
+    assert cmd[i + 1:] == ["--gpus", "4", "--steps", "7", "--warmup", "2"]   # the script's own arguments, in order, last
+
+
+def test_self_launch_relays_arguments_and_json(tmp_path):
+    import io
+    import json
+    sharding = _sharding()
+    script = tmp_path / "probe.py"
+    script.write_text(_PROBE)
+    out, err = io.StringIO(), io.StringIO()
+    env = {k: v for k, v in os.environ.items() if k not in ("PROBE_FAIL_RANK",)}
+    env["WORLD_SIZE"] = "99"     # a stale variable of the caller must not reach the ranks
+    rc = sharding.self_launch(str(script), ["--gpus", "2", "--steps", "3", "--config", "c3"], 2, environ=env, out=out, err=err)
+    assert rc == 0, err.getvalue()
+    lines = [l for l in out.getvalue().splitlines() if l.strip()]
+    assert len(lines) == 1, out.getvalue()                      # ONE JSON line: rank 0's
+    rec = json.loads(lines[0])
+    assert rec["world"] == 2 and rec["rank"] == 0 and rec["local"] == "0" and rec["master"] == "127.0.0.1"
+    assert rec["argv"] == ["--gpus", "2", "--steps", "3", "--config", "c3"]
+    assert rec["ipc"] == "0"
+    assert "noise from rank 1" in err.getvalue() and "noise" not in out.getvalue()
+
+
+def test_self_launch_exit_code_when_a_rank_fails(tmp_path):
+    import io
+    sharding = _sharding()
+    script = tmp_path / "probe.py"
+    script.write_text(_PROBE)
+    out, err = io.StringIO(), io.StringIO()
+    env = dict(os.environ, PROBE_FAIL_RANK="1", PROBE_FAIL_CODE="5")
+    rc = sharding.self_launch(str(script), ["--gpus", "2"], 2, environ=env, out=out, err=err)
+    assert rc != 0                                              # a failed rank is a failed run
+
+
+def test_bench_refuses_a_rank_count_that_disagrees_with_gpus():
+    """under an existing launcher environment bench.py stays a rank: --gpus must equal WORLD_SIZE (checked
+    before torch.cuda is touched)"""
+    import subprocess
+    env = dict(os.environ, WORLD_SIZE="1", RANK="0", LOCAL_RANK="0")
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1"], env=env,
+                       capture_output=True, text=True, timeout=300)
+    assert p.returncode != 0 and "WORLD_SIZE=1" in p.stderr
