@@ -380,10 +380,20 @@ lf_status lf_load_lens_file(lf_ctx* ctx, const char* path);
  * the middle wavelength (0 for an afocal prescription) */
 lf_status lf_get_lens_info(lf_ctx* ctx, int* n_surfaces, int* stop_index, int* n_lambda, float* sensor_width_mm,
                            double* efl_mm);
-/* RGB weight of each wavelength (n_lambda x 3); default: identity for n_lambda == 3 */
+/* RGB weight of each wavelength (n_lambda x 3); default: identity for n_lambda == 3.
+ * RANGE CONTRACT of the march's accumulators (lf_set_lambda_rgb, lf_set_sun, lf_trace_ghosts): a pixel
+ * channel is the sum of UNSIGNED 64-bit fixed-point contributions (u64)(v 2^bits), so every weight and every
+ * radiance must be finite and >= 0 -- anything else is refused with LF_ERR_INVALID (a host whose colour
+ * matrix has negative lobes renders the positive and the negative weights as two frames and subtracts).
+ * The magnitude is free: lf_trace_ghosts chooses `bits` per launch -- 36 (a grid of 1.5e-11 per sample)
+ * unless the largest sum the launch could produce, spp x paths x (pupil solid angle) x
+ * max_c sum_l radiance[c] weights[l][c], would then reach 2^62; in that case the largest exponent that
+ * keeps it below (an HDR sun of radiance 1e7 at 1024 spp x 8 wavelengths: 2^24).  No sum can wrap, and a
+ * frame at 2^k x the radiance is 2^k x the frame, bit for bit, once both leave the default grid.
+ * lf_get_march_fix_bits reports the last launch's exponent. */
 lf_status lf_set_lambda_rgb(lf_ctx* ctx, const float* weights);
-/* the light: unit direction from the lens towards the sun in lens space (z < 0), radiance,
- * angular radius of its (smooth) lobe in radians */
+/* the light: unit direction from the lens towards the sun in lens space (z < 0), radiance (finite, >= 0: see
+ * the range contract above), angular radius of its (smooth) lobe in radians */
 lf_status lf_set_sun(lf_ctx* ctx, const float dir[3], const float radiance[3],
                      float angular_radius);
 /* Sun hand-over from the scene to the march: turn in-frame flare `flare` of lf_find_sun_pos /
@@ -417,7 +427,9 @@ lf_status lf_set_ghost_pairs(lf_ctx* ctx, const int* pairs, int n_pairs, int inc
  * counterpart): each pupil stratum is split into 2^bits x 2^bits sub-cells and all 64 pixels of an
  * 8x8 sensor tile aim sample s at the same, randomly drawn sub-cell (coherent fate at the aperture
  * mask).  bits = 0 draws every pixel's pupil point independently inside its stratum; every value
- * is an unbiased estimator of the same image (tests/test_gpu_march_f64.py).  Default 2; 0..8. */
+ * is an unbiased estimator of the same image (tests/test_gpu_march_f64.py).  0..8; default 6 (64 x 64
+ * sub-cells) since round 4 -- rounds 1-3 shipped 2 (4 x 4): a frame of those rounds is reproduced by
+ * lf_set_pupil_subcells(2) + lf_set_tile_stride(1). */
 lf_status lf_set_pupil_subcells(lf_ctx* ctx, int bits);
 /* Part of the sampling specification (no reference counterpart): the disc every sensor sample aims its
  * pupil point at -- radius and axial position z in the prescription's coordinates (z = 0 at the first
@@ -441,15 +453,20 @@ lf_status lf_paraxial_exit_pupil(int n_surfaces, int stop_index, const float* ra
 lf_status lf_set_ghost_accumulate(lf_ctx* ctx, int on);
 /* Which 64 pixels a wave of the march takes (part of the sampling specification, like the pupil
  * sub-cells: it decides which pixels share a sub-cell draw): 8 rows x 8 columns that are `stride` (1, 2, 4
- * or 8) apart; `stride` such waves interleave inside a block of 8 * stride columns.  stride 1 (default) =
- * an 8 x 8 block of adjacent pixels, whose shared sub-cell correlates the noise of neighbouring pixels
- * (variance of an 8 x 8 tile mean = 38x independent pixels at 4 x 4 sub-cells); stride 8 spreads a wave's
- * pixels over 64 columns, so that the correlated noise lands on pixels 8 apart.  Per-pixel expectation and
- * variance do not depend on it; the tile rows (multi-GPU deal) stay 8 rows. */
+ * or 8) apart; `stride` such waves interleave inside a block of 8 * stride columns.  stride 1 (the default
+ * of rounds 1-3) = an 8 x 8 block of adjacent pixels, whose shared sub-cell correlates the noise of
+ * neighbouring pixels (variance of an 8 x 8 tile mean = 38x independent pixels at 4 x 4 sub-cells);
+ * stride 8 (THE DEFAULT since round 4) spreads a wave's pixels over 64 columns, so that the correlated noise
+ * lands on pixels 8 apart (7.4x with the 64 x 64 sub-cells that are the default beside it).  Per-pixel
+ * expectation and variance do not depend on it; the tile rows (multi-GPU deal) stay 8 rows.  The same key
+ * gives DIFFERENT pixels under a different stride / sub-cell setting: a host or an oracle that wants the
+ * frames of rounds 1-3 calls lf_set_tile_stride(1) + lf_set_pupil_subcells(2). */
 lf_status lf_set_tile_stride(lf_ctx* ctx, int stride);
 /* march `spp` sensor samples per pixel of the band through every selected pair and wavelength and
  * accumulate into ghost_buffer (replacing its content).  key seeds the counter RNG. */
 lf_status lf_trace_ghosts(lf_ctx* ctx, int spp, uint64_t key);
+/* the fixed-point exponent the last lf_trace_ghosts used (36 unless the range contract above lowered it) */
+lf_status lf_get_march_fix_bits(lf_ctx* ctx, int* bits);
 /* replaces: LensCamera::generate_ray of the north star / Camera::generate_ray_for_thin_lens
  * (declared camera.h:168, a stub in camera_lens.cpp:22-30), batched: for n sensor samples -- sensor
  * position in mm (x, y; the lens inverts the image) and a rear-pupil sample in [-1,1]^2 -- march the

@@ -707,6 +707,11 @@ lf_status lf_set_lens(lf_ctx* ctx, int n_surfaces, int stop_index, int n_lambda,
 lf_status lf_set_lambda_rgb(lf_ctx* ctx, const float* weights) {
   if (!ctx || !weights) return LF_ERR_INVALID;
   if (!ctx->lens_valid) return lf_fail(ctx, LF_ERR_STATE, "lf_set_lambda_rgb before lf_set_lens");
+  // the march's sums are UNSIGNED fixed point: a weight must be finite and >= 0 (a host whose colour matrix has
+  // negative lobes renders the positive and the negative part as two frames and subtracts)
+  for (int k = 0; k < 3 * ctx->lens.n_lambda; k++)
+    if (!std::isfinite(weights[k]) || weights[k] < 0.0f)
+      return lf_fail(ctx, LF_ERR_INVALID, "lf_set_lambda_rgb: weights must be finite and >= 0");
   for (int l = 0; l < ctx->lens.n_lambda; l++)
     for (int c = 0; c < 3; c++) ctx->lens.lambda_rgb[l][c] = weights[3 * l + c];
   return LF_OK;
@@ -718,6 +723,9 @@ lf_status lf_set_sun(lf_ctx* ctx, const float dir[3], const float radiance[3],
   double n = std::sqrt((double)dir[0] * dir[0] + (double)dir[1] * dir[1] + (double)dir[2] * dir[2]);
   if (!(n > 0) || !(dir[2] < 0) || !(angular_radius > 0) || angular_radius > 1.5f)
     return lf_fail(ctx, LF_ERR_INVALID, "sun: direction must have z < 0, 0 < angular radius <= 1.5");
+  for (int c = 0; c < 3; c++)   // unsigned fixed-point sums: see lf_set_lambda_rgb; any finite magnitude is fine (lf_march_fix_bits)
+    if (!std::isfinite(radiance[c]) || radiance[c] < 0.0f || !std::isfinite(dir[c]))
+      return lf_fail(ctx, LF_ERR_INVALID, "sun: radiance must be finite and >= 0, the direction finite");
   for (int c = 0; c < 3; c++) {
     ctx->lens.sun_dir[c] = (float)(dir[c] / n);
     ctx->lens.sun_radiance[c] = radiance[c];
@@ -881,6 +889,12 @@ lf_status lf_trace_ghosts(lf_ctx* ctx, int spp, uint64_t key) {
   lf_status st = lfk_march(ctx, spp, key);
   if (st != LF_OK) return st;
   ctx->ghost_valid = true;
+  return LF_OK;
+}
+
+lf_status lf_get_march_fix_bits(lf_ctx* ctx, int* bits) {
+  if (!ctx || !bits) return LF_ERR_INVALID;
+  *bits = ctx->march_fix_bits;
   return LF_OK;
 }
 

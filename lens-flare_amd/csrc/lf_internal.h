@@ -345,6 +345,7 @@ struct lf_ctx {
   unsigned char* prog_dev = nullptr;           // the packed program: headers, then records (lf_march.hip pack_program)
   size_t prog_cap = 0, prog_rec_off = 0, prog_wrec_off = 0, prog_seq_off = 0;   // bytes; offsets of the records / weight records / pair sequences
   int march_k = 1;                             // wavelengths (rays per lane) that walk together
+  int march_fix_bits = 36;                     // the last launch's fixed-point exponent (lf_get_march_fix_bits)
   bool events_dirty = true;
 
   // multi-GPU (lf_group.hip): the communicator this context belongs to, staging for the exchange
@@ -410,6 +411,7 @@ lf_status lf_build_march_tables(lf_ctx* ctx, std::vector<LfEventRow>& rows, std:
 lf_status lfk_native_sqrt(lf_ctx* ctx, const float* d_x, float* d_y, size_t n);
 lf_status lfk_native_rcp(lf_ctx* ctx, const float* d_x, float* d_y, size_t n);
 void lf_apply_pupil_target(lf_ctx* ctx);
+int lf_march_fix_bits(const LfLensDev& L, int n_paths, int spp);
 void lf_derive_lens(lf_ctx* ctx, int n, int stop, int n_lambda, const float* radius,
                     const float* thickness, const float* ior, const float* semi_ap,
                     float sensor_w_mm);

@@ -35,6 +35,7 @@
 // finish.  The CPU oracle (oracle/lf_geo_oracle.c) follows the same contract and marches every
 // path on its own, which makes pixels and event counters comparable bit for bit.
 #include <algorithm>
+#include <cmath>
 #include <cstring>
 #include <utility>
 
@@ -99,6 +100,8 @@ struct MarchArgs {
   int n_tiles;         // wave tiles of the launch (the grid holds them padded to a multiple of 64)
   int xs;              // log2 of the lanes' pixel stride in x (lf_set_tile_stride): 0 = an 8 x 8 block of
                        // adjacent pixels per wave, 3 = columns 8 apart (a 64 x 8 block shared by 8 waves)
+  float fix_scale;     // 2^fix_bits: the launch's fixed-point grid (lf_march_fix_bits; 2^36 unless that could wrap)
+  double inv_fix;      // 2^-fix_bits
 };
 
 // The program of a GROUP of up to 3 wavelengths, in two levels (LfProgHdr / LfProgRow in
@@ -636,7 +639,7 @@ void k_march(const LfLensDev* __restrict__ lens, const LfPairsDev* __restrict__ 
                   // straight into the tile's LDS sums (integers: any order gives the same bits);
                   // lit lanes are ~0.4 % of the rays, six registers of per-lane sums are not worth it
                   const float v = contrib * (lens->sun_radiance[c] * lens->lambda_rgb[l][c]);
-                  const unsigned long long fx = (unsigned long long)(v * kFixScale);
+                  const unsigned long long fx = (unsigned long long)(v * a.fix_scale);
                   if (fx) atomicAdd(&s_acc[lane * 3 + c], fx);
                 }
               }
@@ -683,7 +686,7 @@ void k_march(const LfLensDev* __restrict__ lens, const LfPairsDev* __restrict__ 
     if (a.sgroups == 1) {
 #pragma unroll
       for (int c = 0; c < 3; c++) {
-        const double v = ((double)s_acc[lane * 3 + c] * (1.0 / 68719476736.0)) / (double)a.spp;
+        const double v = ((double)s_acc[lane * 3 + c] * a.inv_fix) / (double)a.spp;
         ghost[3 * (size_t)p + c] = a.accumulate ? ghost[3 * (size_t)p + c] + v : v;
       }
     } else {
@@ -741,12 +744,32 @@ __global__ void k_march_finish(const unsigned long long* __restrict__ accum, Mar
   if (t < a.trow0 || (t - a.trow0) % a.tperiod != 0) return;
 #pragma unroll
   for (int c = 0; c < 3; c++) {
-    const double v = ((double)accum[3 * p + c] * (1.0 / 68719476736.0)) / (double)a.spp;
+    const double v = ((double)accum[3 * p + c] * a.inv_fix) / (double)a.spp;
     ghost[3 * p + c] = a.accumulate ? ghost[3 * p + c] + v : v;
   }
 }
 
 }  // namespace
+
+// host: the fixed-point grid of a launch.  Every contribution is added as (u64)(v * 2^bits), v = weight x lobe x
+// (sun_radiance[c] * lambda_rgb[l][c]) <= geom_norm x that product, into 64-bit sums per pixel and channel: the
+// largest sum a launch can produce is spp x paths x geom_norm x max_c sum_l (radiance[c] * lambda_rgb[l][c]).
+// bits = 36 (the grid of rounds 1-4: every golden and oracle comparison holds) unless that bound times 2^bits
+// reaches 2^62; then the largest exponent that keeps it below (an HDR sun of 1e7 at 1024 spp x 8 wavelengths: 2^25).
+// The result is scale-covariant: a frame at radiance 2^k x L is 2^k x the frame at L, bit for bit, once both
+// leave the default grid.  Mirrored by oracle/lf_geo_oracle.c (geo_fix_bits).
+int lf_march_fix_bits(const LfLensDev& L, int n_paths, int spp) {
+  double worst = 0.0;
+  for (int c = 0; c < 3; c++) {
+    double s = 0.0;
+    for (int l = 0; l < L.n_lambda; l++) s += (double)(L.sun_radiance[c] * L.lambda_rgb[l][c]);
+    worst = std::max(worst, s);
+  }
+  worst *= (double)spp * (double)n_paths * (double)L.geom_norm;
+  int bits = 36;
+  while (bits > -100 && std::ldexp(worst, bits) >= 4611686018427387904.0) bits--;   // 2^62
+  return bits;
+}
 
 // host: the disc every sensor sample aims at -- by default the rear element's clear aperture at its
 // vertex plane, or what lf_set_pupil_target names (part of the sampling specification) -- and the
@@ -1154,6 +1177,12 @@ lf_status lfk_march(lf_ctx* ctx, int spp, uint64_t key) {
   a.vz = ctx->lens.pupil_z - ctx->lens.z_sensor;
   a.accumulate = ctx->ghost_accumulate ? 1 : 0;
   a.xs = ctx->march_xstride_log2;
+  {
+    const int bits = lf_march_fix_bits(ctx->lens, ctx->pairs.n, spp);
+    a.fix_scale = std::ldexp(1.0f, bits);
+    a.inv_fix = std::ldexp(1.0, -bits);
+    ctx->march_fix_bits = bits;
+  }
   {
     // candidate selection (the contract, the same expression in oracle/lf_geo_oracle.c): d.s above
     // 1 - 1.0625 (1 - cos alpha) - 4e-7 MAY lie inside the lobe.  The 1/16 margin is relative, the

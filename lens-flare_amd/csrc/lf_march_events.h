@@ -9,7 +9,6 @@
 
 namespace lfm {
 
-constexpr float kFixScale = 68719476736.0f;  // 2^36
 constexpr unsigned kDomainMarch = 0x6e5f1a2eu;
 constexpr unsigned kDomainSubcell = 0x51bce110u;
 

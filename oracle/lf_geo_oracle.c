@@ -399,6 +399,22 @@ void geo_lens_samples(const geo_lens* L, int W, int H, int ns, const uint32_t ke
   }
 }
 
+/* the fixed-point grid of a launch (lens-flare_amd/csrc/lf_march.hip lf_march_fix_bits, the same double
+ * arithmetic): 2^36 unless spp x paths x geom_norm x max_c sum_l (radiance[c] * lambda_rgb[l][c]) x 2^bits would
+ * reach 2^62 -- then the largest exponent that keeps the largest possible pixel sum below it */
+int geo_fix_bits(const geo_lens* L, float geom_norm, int n_paths, int spp) {
+  double worst = 0.0;
+  for (int c = 0; c < 3; c++) {
+    double s = 0.0;
+    for (int l = 0; l < L->n_lambda; l++) s += (double)(L->sun_radiance[c] * L->lambda_rgb[l][c]);
+    if (s > worst) worst = s;
+  }
+  worst *= (double)spp * (double)n_paths * (double)geom_norm;
+  int bits = 36;
+  while (bits > -100 && ldexp(worst, bits) >= 4611686018427387904.0) bits--;
+  return bits;
+}
+
 /* March `spp` samples of every pixel in rows [y0, y1); pairs = n x (i, j), (-1,-1) = primary.
  * ghost: W*H*3 doubles (only the band is written).  Returns counters. */
 void geo_trace(const geo_lens* L, int W, int H, int y0, int y1, int spp, const uint32_t key[2],
@@ -409,6 +425,9 @@ void geo_trace(const geo_lens* L, int W, int H, int y0, int y1, int spp, const u
   geo_counters total;
   memset(&total, 0, sizeof(total));
   if (n_threads < 1) n_threads = 1;
+  const int fix_bits = geo_fix_bits(L, D.geom_norm, n_pairs, spp);
+  const float fix_scale = ldexpf(1.0f, fix_bits);
+  const double inv_fix = ldexp(1.0, -fix_bits);
 #pragma omp parallel num_threads(n_threads)
   {
     geo_counters c;
@@ -472,14 +491,14 @@ void geo_trace(const geo_lens* L, int W, int H, int y0, int y1, int spp, const u
                 c.rays_hit_light++;
                 for (int ch = 0; ch < 3; ch++) {
                   float v = contrib * (L->sun_radiance[ch] * L->lambda_rgb[l][ch]);
-                  acc[ch] += (uint64_t)(v * 68719476736.0f);
+                  acc[ch] += (uint64_t)(v * fix_scale);
                 }
               }
             }
           }
       }
       for (int ch = 0; ch < 3; ch++)
-        ghost[3 * p + ch] = ((double)acc[ch] * (1.0 / 68719476736.0)) / (double)spp;
+        ghost[3 * p + ch] = ((double)acc[ch] * inv_fix) / (double)spp;
     }
 #pragma omp critical
     {
