@@ -465,6 +465,25 @@ lf_status lf_set_tile_stride(lf_ctx* ctx, int stride);
 /* march `spp` sensor samples per pixel of the band through every selected pair and wavelength and
  * accumulate into ghost_buffer (replacing its content).  key seeds the counter RNG. */
 lf_status lf_trace_ghosts(lf_ctx* ctx, int spp, uint64_t key);
+/* PATH CULLING (round 5; no reference counterpart -- the reference enumerates 13 fixed pairs per channel and
+ * draws each as one quad, pathtracer.cpp:735-762, :452-508).  lf_trace_ghosts does not start a path where it
+ * cannot carry light: a pre-pass bounds, for every block of 64 x 64 sensor pixels, every stratum of the pupil
+ * square and every selected path, where the rays of that 4-D box can go -- on each diaphragm of the path and in
+ * direction space at the exit -- and the march starts only the paths whose box may end inside the sun's lobe.
+ * A path that is not started would have contributed exactly 0, so ghost_buffer is the buffer of the full
+ * enumeration BIT FOR BIT; lf_counters / lf_get_executed_events count the rays that were started.
+ *   mode 1 (default): on; the table is reused while lens, pairs, sun, frame, pupil disc, mask and sample
+ *                     count are unchanged.   2: on, rebuilt at every lf_trace_ghosts.
+ *   mode 0: off -- every sample marches every selected path (rounds 1-4; the shared-leg path tree).
+ * Applies to at most 64 paths and 4096 samples per pixel; beyond, lf_trace_ghosts marches everything.
+ * lf_get_cull_info: {mode, did the last lf_trace_ghosts cull, blocks_x, blocks_y, cells per block (the pupil
+ * strata G x G), G, pre-pass cells per axis, block size in pixels}.  lf_get_cull_table: the masks the last
+ * launch used, [blocks_y * blocks_x][cells + 1] (bit q = path q of the selection in lf_set_ghost_pairs order,
+ * the primary path first; entry `cells` = the union, used by the unstratified samples s >= G * G), so that a
+ * checker can march exactly what the device marched. */
+lf_status lf_set_march_culling(lf_ctx* ctx, int mode);
+lf_status lf_get_cull_info(lf_ctx* ctx, int info[8]);
+lf_status lf_get_cull_table(lf_ctx* ctx, uint64_t* out, size_t n_entries);
 /* the fixed-point exponent the last lf_trace_ghosts used (36 unless the range contract above lowered it) */
 lf_status lf_get_march_fix_bits(lf_ctx* ctx, int* bits);
 /* replaces: LensCamera::generate_ray of the north star / Camera::generate_ray_for_thin_lens

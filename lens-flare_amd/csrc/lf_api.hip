@@ -72,7 +72,7 @@ void lf_timing_end(lf_ctx* ctx, int kernel, hipEvent_t start, hipStream_t stream
 namespace {
 
 const char* kKernelNames[LFK_COUNT] = {"march", "flare_layer", "ghost_raster", "dft",
-                                       "frame_setup", "tonemap", "exchange", "scene_term"};
+                                       "frame_setup", "tonemap", "exchange", "scene_term", "cull_prepass"};
 
 // the reference's hard-coded prescription (pathtracer.cpp:541-556); literals narrowed to float
 // where the reference narrows them
@@ -231,7 +231,7 @@ lf_status lf_destroy(lf_ctx* ctx) {
                   ctx->prog_dev, ctx->sun_lights_dev,
                   ctx->scene_dev.nodes, ctx->scene_dev.prims, ctx->scene_dev.normals, ctx->scene_dev.materials,
                   ctx->scene_dev.lights, ctx->env_block, ctx->probe_dev, ctx->scene_counters_dev,
-                  ctx->primary_dev};
+                  ctx->primary_dev, ctx->cull_dev, ctx->cull_list[0], ctx->cull_list[1], ctx->cull_counts};
   for (void* p : ptrs) if (p) (void)hipFree(p);
   if (ctx->own_stream && ctx->stream) (void)hipStreamDestroy(ctx->stream);
   delete ctx;
@@ -363,6 +363,18 @@ lf_status lf_set_aperture(lf_ctx* ctx, lf_aperture_slot slot, const float* texel
   }
   a.valid = true;
   if (slot == LF_APERTURE_STARBURST) {
+    // occupancy of the stop mask for the march's cull pre-pass (lf_cull.hip): which of kCullOcc x kCullOcc cells
+    // of the mask holds a texel > 0 (a texel belongs to every cell it touches)
+    for (int r = 0; r < kCullOcc; r++) ctx->cull_occ[r] = 0u;
+    for (int y = 0; y < height; y++)
+      for (int x = 0; x < width; x++)
+        if (texels[(size_t)y * width + x] > 0.0f) {
+          const int cx0 = (int)((long long)x * kCullOcc / width), cx1 = (int)(((long long)(x + 1) * kCullOcc - 1) / width);
+          const int cy0 = (int)((long long)y * kCullOcc / height), cy1 = (int)(((long long)(y + 1) * kCullOcc - 1) / height);
+          for (int cy = cy0; cy <= cy1 && cy < kCullOcc; cy++)
+            for (int cx = cx0; cx <= cx1 && cx < kCullOcc; cx++) ctx->cull_occ[cy] |= 1u << cx;
+        }
+    ctx->mask_generation++;
     ctx->spectrum_valid = false;
     ctx->lenscam_dirty = true;   // the stop mask is part of the lens camera's exposure calibration
     size_t rows = a.host_stats.max_y >= a.host_stats.min_y
@@ -889,6 +901,34 @@ lf_status lf_trace_ghosts(lf_ctx* ctx, int spp, uint64_t key) {
   lf_status st = lfk_march(ctx, spp, key);
   if (st != LF_OK) return st;
   ctx->ghost_valid = true;
+  return LF_OK;
+}
+
+lf_status lf_set_march_culling(lf_ctx* ctx, int mode) {
+  if (!ctx) return LF_ERR_INVALID;
+  if (mode < 0 || mode > 2) return lf_fail(ctx, LF_ERR_INVALID, "march culling: 0 off, 1 on, 2 on and rebuilt at every launch");
+  ctx->march_cull = mode;
+  return LF_OK;
+}
+
+lf_status lf_get_cull_info(lf_ctx* ctx, int info[8]) {
+  if (!ctx || !info) return LF_ERR_INVALID;
+  info[0] = ctx->march_cull;
+  info[1] = ctx->last_march_culled ? 1 : 0;
+  info[2] = ctx->cull_bx; info[3] = ctx->cull_by; info[4] = ctx->cull_cells; info[5] = ctx->cull_G; info[6] = ctx->cull_P;
+  info[7] = 1 << kCullBlockLog2;
+  return LF_OK;
+}
+
+lf_status lf_get_cull_table(lf_ctx* ctx, uint64_t* out, size_t n_entries) {
+  if (!ctx || !out) return LF_ERR_INVALID;
+  if (!ctx->last_march_culled || !ctx->cull_dev || ctx->cull_hash == 0)
+    return lf_fail(ctx, LF_ERR_STATE, "lf_get_cull_table: the last lf_trace_ghosts did not cull (or none has run)");
+  const size_t n = (size_t)ctx->cull_bx * ctx->cull_by * (size_t)(ctx->cull_cells + 1);
+  if (n_entries != n) return lf_fail(ctx, LF_ERR_INVALID, "lf_get_cull_table: size must be blocks_x * blocks_y * (cells + 1)");
+  LF_HIP(ctx, hipSetDevice(ctx->device));
+  LF_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  LF_HIP(ctx, hipMemcpy(out, ctx->cull_dev, n * sizeof(uint64_t), hipMemcpyDeviceToHost));
   return LF_OK;
 }
 

@@ -1,0 +1,701 @@
+// lf_cull.hip -- spend the rays where the light is (round 5).
+//
+// The north star's loop -- for each sensor sample, enumerate the ghost pairs, march each path, accumulate --
+// leaves open which of those marches are worth starting.  On the bench frame 99.4 % of the (wave tile, sample,
+// path, wavelength) combinations end with no lane inside the sun's lobe: their paths run into a diaphragm or
+// leave the front element pointing elsewhere, and add exactly 0 to the sensor (profiles/r05_pair_table.json).
+// Which ones can be known in advance: for a path q the map (sensor point x, pupil point u) -> exit direction
+// is smooth, so over a small 4-D box (a block of 64 x 64 sensor pixels times one stratum of the pupil square)
+// a handful of marched rays bound where the whole box can go -- on every diaphragm of the path and in
+// direction space when it leaves the lens.
+//
+//   k_cull_prepass   one 16-lane row per (sensor block, pupil cell, path): 13 rays (a 3 x 3 grid over the cell
+//                    at the block's centre + 4 at the cell's centre towards the block's edges) are marched
+//                    WITHOUT dying on a diaphragm; after every event the row forms the footprint of the box on
+//                    that interface -- centre sample +- (largest deviation over the cell + the deviations towards
+//                    the block's edges), inflated -- and drops the box when the footprint lies wholly outside
+//                    the clear aperture (the stop: outside its housing or on closed cells of the mask's occupancy
+//                    grid); at the end the same in direction space against the sun's lobe.  A box that loses a ray to
+//                    total reflection or a missed sphere is KEPT (nothing is known about it).  Result: per
+//                    (block, cell) a 64-bit mask of the paths that may contribute.
+//   k_march_cull<K>  the march of exactly those paths: per wave tile and sample one scalar load tells which
+//                    paths to start; each is marched alone along its own event sequence, K wavelengths
+//                    together, WITH its Fresnel / aperture weight (almost every path that is started ends near
+//                    the lobe: the geometry-first / re-march split of k_march has nothing left to save), the
+//                    event arithmetic being lf_march_events.h's -- so a started ray is bit for bit the ray
+//                    k_march and the oracle march, and since an unstarted one contributes 0 the PIXELS are
+//                    those of the full enumeration.  Counters count what was started (the oracle follows the
+//                    same table: oracle/lf_geo_oracle.c geo_set_cull).
+//
+// No reference counterpart: the reference enumerates 13 fixed pairs per channel and draws each as one textured
+// quad (src/pathtracer/pathtracer.cpp:735-762, :452-508) -- its "cull" is that a quad covers few pixels.
+#include <algorithm>
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+
+#include "lf_internal.h"
+#include "lf_march_events.h"
+#include "lf_march_common.h"
+
+namespace {
+
+using namespace lfm;
+
+// ---- the pre-pass ------------------------------------------------------------------------------------
+constexpr int kCullSamples = 13;   // per box: a 3 x 3 grid over the pupil cell at the block's centre (0 .. 8, 4 = the
+                                   // centre) + the cell's centre at the block's +x, -x, +y, -y edges (9 .. 12)
+struct CullLevelArgs {
+  int W, H;
+  float pitch, half_w, half_h;
+  int blocks_x, blocks_y;
+  int P;                   // pupil cells per axis at THIS level
+  int P_final;             // ... of the table (the last level)
+  int last;                // the last level writes the table, the others the next level's work list
+  int n_paths;
+  int n_test, lam[3];      // wavelengths marched
+  int march_k, prog_recs;  // how the record table is grouped (lf_march.hip pack_program)
+  float pupil_h, vz, geom_norm;
+  float stop_h, inv_stop_h;
+  float sx, sy, rho;       // the sun's direction (x, y) and the lobe's radius in direction space
+  float margin;            // footprint inflation at this level
+  unsigned list_stride;    // entries per path in the work lists
+  unsigned occ[kCullOcc];  // occupancy rows of the stop mask
+};
+
+// One LANE = one box (sensor block x pupil cell) of path blockIdx.y; its 13 rays live in registers, so a wave
+// marches 64 boxes of ONE path in lockstep -- wave-uniform event sequence, rows through the scalar cache, no
+// cross-lane traffic.  (The first version gave a box to a 16-lane row and reduced with ds_bpermute: 19 ms
+// for the bench frame's 6e6 boxes at P = 16; profiles/r05_march_variants.txt.)
+// Work: `items` = this level's list for the path (cell index = block * P * P + cell; null = every box of the
+// level); a box that cannot be ruled out appends its four children to `next` (cells of 2P) or, on the last
+// level, sets the path's bit in the table.
+__global__ __launch_bounds__(256) void k_cull_level(const LfLensDev* __restrict__ lens,
+                                                    const LfPairsDev* __restrict__ pairs,
+                                                    const int* __restrict__ seq_table,
+                                                    const LfProgRow* __restrict__ rec_table, CullLevelArgs a,
+                                                    const unsigned* __restrict__ items,
+                                                    const unsigned* __restrict__ counts, unsigned items_stride,
+                                                    unsigned* __restrict__ next, unsigned* __restrict__ next_counts,
+                                                    unsigned long long* __restrict__ table,
+                                                    unsigned long long* __restrict__ stats) {
+  const int q = blockIdx.y;
+  const unsigned PP = (unsigned)(a.P * a.P);
+  const unsigned n_items = items ? min(counts[q], items_stride) : (unsigned)(a.blocks_x * a.blocks_y) * PP;
+  const unsigned i = blockIdx.x * blockDim.x + threadIdx.x;
+  // (whole waves past the end leave; a partial last wave keeps its idle lanes: the loop below is wave-uniform)
+  if ((i & ~63u) >= n_items) return;
+  const bool valid = i < n_items;
+  const unsigned item = valid ? (items ? items[(size_t)q * items_stride + i] : i) : 0u;
+  const int blk = (int)(item / PP), cell = (int)(item % PP);
+  const int ci = cell % a.P, cj = cell / a.P;
+  const int bx = blk % a.blocks_x, by = blk / a.blocks_x;
+
+  const float px0 = (float)(bx << kCullBlockLog2), px1 = fminf((float)a.W, (float)((bx + 1) << kCullBlockLog2));
+  const float py0 = (float)(by << kCullBlockLog2), py1 = fminf((float)a.H, (float)((by + 1) << kCullBlockLog2));
+  const float Xc = -((0.5f * (px0 + px1)) - a.half_w) * a.pitch, Yc = -((0.5f * (py0 + py1)) - a.half_h) * a.pitch;
+  const float hX = 0.5f * (px1 - px0) * a.pitch, hY = 0.5f * (py1 - py0) * a.pitch;
+  const float invP = 1.0f / (float)a.P;
+
+  const int n_ev = pairs->ev_cnt[q];
+  const int* const seq = seq_table + pairs->ev_off[q];
+  const float inf = __int_as_float(0x7f800000);
+  const int lane = (int)(threadIdx.x & 63u);
+  bool enabled = false;
+  int why_last = 0;
+  for (int li = 0; li < a.n_test; li++) {
+    if (__ballot(valid && !enabled) == 0ull) break;
+    const int l = a.lam[li];
+    const int g = l / a.march_k, j = l - g * a.march_k;
+    const LfProgRow* const recs = rec_table + (size_t)g * (size_t)a.prog_recs;
+    const float ns = lens->n_start[l];
+    Ray r[kCullSamples];
+#pragma unroll
+    for (int t = 0; t < kCullSamples; t++) {
+      float X = Xc, Y = Yc, fu = 0.5f, fv = 0.5f;
+      if (t < 9) { fu = 0.5f * (float)(t % 3); fv = 0.5f * (float)(t / 3); }
+      else if (t == 9) X = Xc + hX;
+      else if (t == 10) X = Xc - hX;
+      else if (t == 11) Y = Yc + hY;
+      else Y = Yc - hY;
+      const float ua = ((float)ci + fu) * invP, ub = ((float)cj + fv) * invP;
+      const StartRay s0 = aim_at_pupil(X, Y, fmaf(2.0f, ua, -1.0f), fmaf(2.0f, ub, -1.0f), a.pupil_h, a.vz, a.geom_norm);
+      r[t] = Ray{X, Y, 0.0f, fmaf(X, X, Y * Y), s0.dx * ns, s0.dy * ns, s0.dz * ns, 0.0f, 0.0f};
+    }
+    // `live`: bit t = sample t is still on the path (not lost to a missed sphere or to total reflection).  A box
+    // that has lost samples is PARTIAL: what is left of it lies next to a region where the path ends, the map
+    // is steep there, and its footprints are inflated twice as much.
+    unsigned live = 0x1fffu;
+    bool culled = !valid || enabled, keep = false, partial = false;
+    int why = 0;
+    // Footprint of the box in a plane (an interface's, or direction space).  With all 13 samples in use the
+    // image of the box is modelled as a ZONOTOPE: centre c + the four generators g1, g2 (half the cell along the
+    // two pupil axes: central differences of the mid-edge samples), gx, gy (half the block along x and y) + an
+    // isotropic slack for what the linear model misses (largest deviation of the nine pupil samples and of the
+    // edge mid-points from it).  Its extent along a unit vector n is sum |g . n|: a separating-axis test against
+    // a disc needs only that -- far tighter than a ball around c for the elongated footprints of defocused ghosts.
+    // A box that has lost samples falls back to a ball around a sample still in use, inflated twice as much.
+    struct Foot { float cx, cy, g1x, g1y, g2x, g2y, gxx, gxy, gyx, gyy, slack, ball; bool zono; };
+    auto footprint = [&](const float* vx, const float* vy, unsigned use, float eps) {
+      Foot f;
+      f.zono = use == 0x1fffu;
+      const int ref = (use & 0x10u) ? 4 : (use ? __ffs((int)use) - 1 : 4);
+      f.cx = vx[4]; f.cy = vy[4];
+#pragma unroll
+      for (int t = 0; t < kCullSamples; t++) if (t != 4 && ref == t) { f.cx = vx[t]; f.cy = vy[t]; }
+      f.g1x = 0.5f * (vx[5] - vx[3]); f.g1y = 0.5f * (vy[5] - vy[3]);
+      f.g2x = 0.5f * (vx[7] - vx[1]); f.g2y = 0.5f * (vy[7] - vy[1]);
+      f.gxx = 0.5f * (vx[9] - vx[10]); f.gxy = 0.5f * (vy[9] - vy[10]);
+      f.gyx = 0.5f * (vx[11] - vx[12]); f.gyy = 0.5f * (vy[11] - vy[12]);
+      float dev2 = 0.0f, ru2 = 0.0f, rx2 = 0.0f, ry2 = 0.0f;
+#pragma unroll
+      for (int t = 0; t < kCullSamples; t++) {
+        const float ex = vx[t] - f.cx, ey = vy[t] - f.cy;
+        const float d2 = ((use >> t) & 1u) ? fmaf(ex, ex, ey * ey) : 0.0f;
+        if (t < 9) {
+          ru2 = fmaxf(ru2, d2);
+          const float at = (float)(t % 3 - 1), bt = (float)(t / 3 - 1);
+          const float mx = ex - fmaf(at, f.g1x, bt * f.g2x), my = ey - fmaf(at, f.g1y, bt * f.g2y);
+          dev2 = fmaxf(dev2, fmaf(mx, mx, my * my));
+        } else if (t < 11) rx2 = fmaxf(rx2, d2);
+        else ry2 = fmaxf(ry2, d2);
+      }
+      {   // the edge mid-points against the centre: second order along x and y
+        const float mx = 0.5f * (vx[9] + vx[10]) - vx[4], my = 0.5f * (vy[9] + vy[10]) - vy[4];
+        const float nx = 0.5f * (vx[11] + vx[12]) - vx[4], ny = 0.5f * (vy[11] + vy[12]) - vy[4];
+        dev2 = fmaxf(dev2, fmaxf(fmaf(mx, mx, my * my), fmaf(nx, nx, ny * ny)));
+      }
+      const float ru = lf_sqrt(ru2);
+      const float rx = (use & 0x600u) ? lf_sqrt(rx2) : ru, ry = (use & 0x1800u) ? lf_sqrt(ry2) : ru;
+      f.ball = fmaf(partial ? 2.0f * a.margin : a.margin, (ru + rx) + ry, eps);
+      f.slack = fmaf(2.0f, lf_sqrt(dev2), eps);
+      return f;
+    };
+    // extent of the footprint along the unit vector (nx, ny), and along the axes (for the mask's grid)
+    auto extent = [&](const Foot& f, float nx, float ny) {
+      if (!f.zono) return f.ball;
+      const float e = fabsf(fmaf(f.g1x, nx, f.g1y * ny)) + fabsf(fmaf(f.g2x, nx, f.g2y * ny)) +
+                      fabsf(fmaf(f.gxx, nx, f.gxy * ny)) + fabsf(fmaf(f.gyx, nx, f.gyy * ny));
+      return fminf(f.ball, fmaf(a.margin, e, f.slack));
+    };
+    for (int e = 0; e < n_ev; e++) {
+      if (__ballot(!culled && !keep) == 0ull) break;      // every box of the wave is decided
+      const unsigned se = (unsigned)*(const int __attribute__((address_space(4)))*)(seq + e);
+      const LfProgRow wr = load_prec(recs, se & 0xffffu);
+      const unsigned kind = se >> 16;
+      const float cn22 = j == 0 ? wr.cn22[0] : j == 1 ? wr.cn22[1] : wr.cn22[2];
+      const float rn2 = j == 0 ? wr.rn2[0] : j == 1 ? wr.rn2[1] : wr.rn2[2];
+      const float delta = j == 0 ? wr.delta[0] : j == 1 ? wr.delta[1] : wr.delta[2];
+      unsigned hit = 0u, okm = 0u;
+      float vx[kCullSamples], vy[kCullSamples];
+#pragma unroll
+      for (int t = 0; t < kCullSamples; t++) {
+        bool ok;
+        if (kind & LF_EV_STOP) {
+          const float tt = -(r[t].hz + wr.dzv) * lf_rcp(r[t].dz);
+          const float hx = fmaf(tt, r[t].dx, r[t].px), hy = fmaf(tt, r[t].dy, r[t].py);
+          r[t].px = hx; r[t].py = hy; r[t].hz = 0.0f; r[t].r2 = fmaf(hx, hx, hy * hy);
+          ok = r[t].r2 == r[t].r2;
+        } else {
+          lanemask geom_ok;
+          const lanemask m = surface_event<false>(r[t], wr.dzv, wr.curv, wr.ch, wr.c2, wr.sc, cn22, rn2, delta, inf,
+                                                  (kind & LF_EV_REFLECT) != 0, (kind & LF_EV_FLAT) != 0, wr.sgn, geom_ok);
+          ok = ((m >> lane) & 1ull) != 0ull;
+        }
+        vx[t] = r[t].px; vy[t] = r[t].py;
+        if (r[t].r2 == r[t].r2) hit |= 1u << t;     // (a totally reflected ray did reach the interface)
+        if (ok) okm |= 1u << t;
+      }
+      hit &= live;
+      const Foot f = footprint(vx, vy, hit, 1e-3f);
+      live &= okm;
+      if (!culled && !keep) {
+        if (hit == 0u) { culled = true; why = 4; }             // no sample reaches the interface: nor does the box
+        else {
+          const float cx = f.cx, cy = f.cy;
+          const float cr = lf_sqrt(fmaf(cx, cx, cy * cy));
+          const float icr = cr > 0.0f ? lf_rcp(cr) : 0.0f;
+          if (cr - extent(f, cx * icr, cy * icr) > lf_sqrt(wr.h2)) { culled = true; why = 4; }   // wholly outside the clear aperture
+          else if (kind & LF_EV_STOP) {
+            // ... or on closed cells of the mask: texel coordinate = (h / stop_h + 1) / 2 of the mask's width
+            const float s = 0.5f * (float)kCullOcc;
+            const float radx = extent(f, 1.0f, 0.0f), rady = extent(f, 0.0f, 1.0f);
+            const int ix0 = max(0, (int)floorf(fmaf(cx - radx, a.inv_stop_h, 1.0f) * s));
+            const int ix1 = min(kCullOcc - 1, (int)floorf(fmaf(cx + radx, a.inv_stop_h, 1.0f) * s));
+            const int iy0 = max(0, (int)floorf(fmaf(cy - rady, a.inv_stop_h, 1.0f) * s));
+            const int iy1 = min(kCullOcc - 1, (int)floorf(fmaf(cy + rady, a.inv_stop_h, 1.0f) * s));
+            bool open = false;
+            if (ix0 <= ix1) {
+              const unsigned span = (ix1 - ix0 >= 31 ? 0xffffffffu : ((2u << (ix1 - ix0)) - 1u)) << ix0;
+              for (int iy = iy0; iy <= iy1; iy++) open = open || (a.occ[iy] & span) != 0u;
+            }
+            if (!open) { culled = true; why = 5; }
+          }
+          if (!culled) {
+            if ((live & 0x1ffu) == 0u) { culled = true; why = 7; }            // every pupil sample ends here
+            else if (__popc(live & 0x1ffu) < 3) { keep = true; why = 2; }     // too little left to bound anything
+            else if (live != 0x1fffu) partial = true;
+          }
+        }
+      }
+    }
+    if (!culled && !keep) {
+      // the path is complete: where can the box point?  (K is the unit direction in air again)
+      float vx[kCullSamples], vy[kCullSamples];
+#pragma unroll
+      for (int t = 0; t < kCullSamples; t++) { vx[t] = r[t].dx; vy[t] = r[t].dy; }
+      const Foot f = footprint(vx, vy, live, 2e-5f);
+      const float ex = a.sx - f.cx, ey = a.sy - f.cy;
+      const float dist = lf_sqrt(fmaf(ex, ex, ey * ey));
+      const float id = dist > 0.0f ? lf_rcp(dist) : 0.0f;
+      if (dist - extent(f, ex * id, ey * id) > a.rho) { culled = true; why = 6; }
+      else { keep = true; why = partial ? 1 : 3; }
+    }
+    if (stats && valid && why) atomicAdd(&stats[why + 8 * li], 1ull);
+    if (valid && keep) { enabled = true; why_last = why; }
+  }
+  (void)why_last;
+  if (a.last) {
+    if (valid && enabled) {
+      unsigned long long* row = table + (size_t)blk * (size_t)(a.P * a.P + 1);
+      const unsigned long long bit = 1ull << q;
+      atomicOr(&row[cell], bit);
+      atomicOr(&row[a.P * a.P], bit);
+    }
+  } else {
+    // the four children (cells of 2P) of every box kept, appended to the path's next list: one atomic per wave
+    const lanemask em = __ballot(valid && enabled);
+    if (em != 0ull) {
+      unsigned base = 0u;
+      if (lane == (int)__builtin_ctzll(em)) base = atomicAdd(&next_counts[q], 4u * (unsigned)__popcll(em));
+      base = __shfl(base, (int)__builtin_ctzll(em));
+      if (valid && enabled) {
+        const unsigned at = base + 4u * (unsigned)__popcll(em & ((1ull << lane) - 1ull));
+        const unsigned P2 = 2u * (unsigned)a.P;
+        unsigned* out = next + (size_t)q * a.list_stride;
+        if (at + 3u < a.list_stride) {
+#pragma unroll
+          for (int c = 0; c < 4; c++)
+            out[at + c] = (unsigned)blk * (P2 * P2) + (unsigned)(2 * cj + (c >> 1)) * P2 + (unsigned)(2 * ci + (c & 1));
+        }
+      }
+    }
+  }
+}
+
+// ---- the march of the enabled paths ---------------------------------------------------------------------
+constexpr int kWgWaves = 8;
+constexpr int kListMax = 4096;   // samples of one tile's workgroup (spp / sgroups) listed at a time
+
+template <int K>
+__global__ __launch_bounds__(64 * kWgWaves, (K == 1 ? 8 : 6))
+void k_march_cull(const LfLensDev* __restrict__ lens, const LfPairsDev* __restrict__ pairs,
+                  const int* __restrict__ seq_table, const LfProgRow* __restrict__ rec_table,
+                  const LfWeightRow* __restrict__ wrec_table, const float* __restrict__ mask, MarchArgs a,
+                  LfCullArgs cull, double* __restrict__ ghost, unsigned long long* __restrict__ accum,
+                  unsigned long long* __restrict__ counters) {
+  __shared__ unsigned long long s_acc[64 * 3];
+  __shared__ unsigned long long s_cnt[kMarchCounters];
+  __shared__ int s_next, s_nlist;
+  __shared__ unsigned short s_list[kListMax];
+  const int tid = threadIdx.x;
+  if (tid < 64 * 3) s_acc[tid] = 0ull;
+  if (tid < kMarchCounters) s_cnt[tid] = 0ull;
+  if (tid == 0) { s_next = 0; s_nlist = 0; }
+  __syncthreads();
+
+  // tile of the workgroup: as k_march (XCD-aware slot swizzle, wave tile = 8 rows x 8 columns 2^xs apart)
+  const int tiles_x = ((a.W + (8 << a.xs) - 1) >> (3 + a.xs)) << a.xs;
+  const int sg = blockIdx.x % a.sgroups;
+  const unsigned slot = blockIdx.x / a.sgroups;
+  const int tile_lin = (int)((slot & ~63u) | ((slot & 7u) << 3) | ((slot >> 3) & 7u));
+  if (tile_lin >= a.n_tiles) return;
+  const int tx = tile_lin % tiles_x, tj = tile_lin / tiles_x;
+  const int trow = a.trow0 + tj * a.tperiod;
+  const unsigned tile_id = (unsigned)(trow * tiles_x + tx);
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int lane = tid & 63;
+  const int x = ((tx >> a.xs) << (3 + a.xs)) + ((lane & 7) << a.xs) + (tx & ((1 << a.xs) - 1)), y = trow * 8 + (lane >> 3);
+  const bool active = x < a.W && y >= a.y0 && y < a.y1;
+  const lanemask active_mask = __ballot(active);
+  const unsigned p = (unsigned)y * (unsigned)a.W + (unsigned)x;
+  // the tile's cull row: its 64 columns and 8 rows lie inside one 64 x 64 block
+  const int blk = ((trow * 8) >> kCullBlockLog2) * cull.blocks_x + ((((tx >> a.xs) << (3 + a.xs))) >> kCullBlockLog2);
+  const unsigned long long* const crow = cull.table + (size_t)blk * (size_t)(cull.cells + 1);
+
+  const int n_lambda = lens->n_lambda;
+  const int prog_recs = pairs->prog_recs;
+  const int n_groups = (n_lambda + K - 1) / K;
+  const float pitch = lens->pitch, pupil_h = lens->pupil_h, geom_norm = lens->geom_norm;
+  const float inv_stop_h = a.inv_stop_h, half_w = a.half_w, half_h = a.half_h, vz_u = a.vz;
+  const float sx = lens->sun_dir[0], sy = lens->sun_dir[1], sz = lens->sun_dir[2];
+  const float inv_1mc = lens->sun_inv_one_minus_cos, sun_ss = lens->sun_ss;
+  const float lobe_thr = a.lobe_thr;
+  const int GG = a.G * a.G;
+
+  unsigned n_light = 0;                  // per lane
+  unsigned long long n_rays = 0, events = 0, n_clip = 0, n_vign = 0, n_tir = 0, n_scene = 0;   // per wave
+
+  const int n_mine = (a.spp - sg + a.sgroups - 1) / a.sgroups;     // samples sg, sg + sgroups, ...
+  for (int chunk0 = 0; chunk0 < n_mine; chunk0 += kListMax) {
+    // ---- which of the tile's samples start any path at all (most do not) -----------------------------
+    const int chunk_n = min(kListMax, n_mine - chunk0);
+    for (int k = tid; k < chunk_n; k += 64 * kWgWaves) {
+      const int s = sg + (chunk0 + k) * a.sgroups;
+      int entry = cull.cells;
+      if (s < GG) {
+        // the table cell of the sub-cell the wave's lanes all aim sample s at (the draw of the sample loop below)
+        const uint4 r2 = philox4x32_10(make_uint4(tile_id, (unsigned)s, kDomainSubcell, 0u), a.key);
+        const unsigned sxi = a.sub_bits ? (r2.x >> (32 - a.sub_bits)) : 0u, syi = a.sub_bits ? (r2.y >> (32 - a.sub_bits)) : 0u;
+        const int cy = s / a.G, cx = s - cy * a.G;
+        entry = (cy * cull.m + (int)((syi << cull.m_shift) >> a.sub_bits)) * cull.P + cx * cull.m + (int)((sxi << cull.m_shift) >> a.sub_bits);
+      }
+      if (crow[entry] != 0ull) s_list[atomicAdd(&s_nlist, 1)] = (unsigned short)k;
+    }
+    __syncthreads();
+    const int n_list = s_nlist;
+    for (;;) {
+      int k = 0;
+      if (lane == 0) k = atomicAdd(&s_next, 1);
+      k = __builtin_amdgcn_readfirstlane(k);
+      if (k >= n_list) break;
+      const int s = sg + (chunk0 + (int)s_list[k]) * a.sgroups;       // wave-uniform
+      // ---- sensor sample -> initial ray (the expressions of k_march / sample_start) -----------------
+      const uint4 rnd = philox4x32_10(make_uint4(p, (unsigned)s, kDomainMarch, 0u), a.key);
+      const float jx = u01(rnd.x), jy = u01(rnd.y);
+      float ua = u01(rnd.z), ub = u01(rnd.w);
+      int entry = cull.cells;
+      if (s < GG) {
+        const int cy = s / a.G, cx = s - cy * a.G;
+        const uint4 r2 = philox4x32_10(make_uint4(tile_id, (unsigned)s, kDomainSubcell, 0u), a.key);
+        const unsigned sxi = a.sub_bits ? (r2.x >> (32 - a.sub_bits)) : 0u;
+        const unsigned syi = a.sub_bits ? (r2.y >> (32 - a.sub_bits)) : 0u;
+        ua = ((float)cx + ((float)sxi + ua) * a.inv_sub) * a.inv_G;
+        ub = ((float)cy + ((float)syi + ub) * a.inv_sub) * a.inv_G;
+        entry = (cy * cull.m + (int)((syi << cull.m_shift) >> a.sub_bits)) * cull.P + cx * cull.m + (int)((sxi << cull.m_shift) >> a.sub_bits);
+      }
+      const unsigned long long todo = crow[entry];                    // the paths to start (scalar load)
+      const float pa = fmaf(2.0f, ua, -1.0f), pb = fmaf(2.0f, ub, -1.0f);
+      const float X = -(((float)x + jx) - half_w) * pitch;
+      const float Y = -(((float)y + jy) - half_h) * pitch;
+      const StartRay s0 = aim_at_pupil(X, Y, pa, pb, pupil_h, vz_u, geom_norm);
+
+      unsigned long long left_q = todo;
+      while (left_q != 0ull) {
+        const int q = __builtin_ctzll(left_q);
+        left_q &= left_q - 1ull;
+        const int n_ev = pairs->ev_cnt[q];
+        const int* const seq = seq_table + pairs->ev_off[q];
+        for (int g = 0; g < n_groups; g++) {
+          const LfProgRow* const recs = rec_table + (size_t)g * (size_t)prog_recs;
+          const LfWeightRow* const wrecs = wrec_table + (size_t)g * (size_t)prog_recs;
+          Ray r[K];
+          lanemask alive[K];
+          unsigned nlive = 0u;
+#pragma unroll
+          for (int j = 0; j < K; j++) {
+            r[j] = Ray{X, Y, 0.0f, fmaf(X, X, Y * Y), s0.dx, s0.dy, s0.dz, s0.w0, 1.0f};
+            const float ns = lens->n_start[min(g * K + j, n_lambda - 1)];
+            r[j].dx *= ns; r[j].dy *= ns; r[j].dz *= ns;
+            alive[j] = (g * K + j < n_lambda) ? active_mask : 0ull;
+            nlive += (unsigned)__popcll(alive[j]);
+          }
+          n_rays += nlive;
+          unsigned ev32 = 0u;
+          unsigned se = (unsigned)*(const int __attribute__((address_space(4)))*)(seq);
+          for (int e = 0; e < n_ev && nlive != 0u; e++) {
+            const unsigned cur = se;
+            if (e + 1 < n_ev) se = (unsigned)*(const int __attribute__((address_space(4)))*)(seq + e + 1);
+            const LfProgRow wr = load_prec(recs, cur & 0xffffu);
+            const LfWeightRow ww = load_wrec(wrecs, cur & 0xffffu);
+            const unsigned kind = cur >> 16;
+            lanemask okv[K], gv[K], died = 0ull;
+            if (kind & LF_EV_STOP) {
+#pragma unroll
+              for (int j = 0; j < K; j++) {
+                if (K > 1 && __builtin_expect(alive[j] == 0ull, 0)) { okv[j] = 0ull; gv[j] = 0ull; continue; }
+                okv[j] = stop_event<true>(r[j], wr.dzv, wr.h2, inv_stop_h, mask, a.mw, a.mh);
+                gv[j] = okv[j];
+                died |= alive[j] & ~okv[j];
+              }
+              if (__builtin_expect(died != 0ull, 0)) {
+#pragma unroll
+                for (int j = 0; j < K; j++) {
+                  const unsigned nd = (unsigned)__popcll(alive[j] & ~okv[j]);
+                  n_clip += nd; nlive -= nd; alive[j] &= okv[j];
+                }
+              }
+            } else {
+              if (kind == 0u) {          // refraction at a curved interface: the common row, straight-line
+#pragma unroll
+                for (int j = 0; j < K; j++) {
+                  if (K > 1 && __builtin_expect(alive[j] == 0ull, 0)) { okv[j] = 0ull; gv[j] = 0ull; continue; }
+                  okv[j] = surface_event<true>(r[j], wr.dzv, wr.curv, wr.ch, wr.c2, wr.sc, wr.cn22[j], wr.rn2[j],
+                                               wr.delta[j], wr.h2, false, false, wr.sgn, gv[j], ww.fs[j], ww.fo[j], ww.fi[j]);
+                  died |= alive[j] & ~okv[j];
+                }
+              } else {
+#pragma unroll
+                for (int j = 0; j < K; j++) {
+                  if (K > 1 && __builtin_expect(alive[j] == 0ull, 0)) { okv[j] = 0ull; gv[j] = 0ull; continue; }
+                  okv[j] = surface_event<true>(r[j], wr.dzv, wr.curv, wr.ch, wr.c2, wr.sc, wr.cn22[j], wr.rn2[j],
+                                               wr.delta[j], wr.h2, (kind & LF_EV_REFLECT) != 0, (kind & LF_EV_FLAT) != 0,
+                                               wr.sgn, gv[j], ww.fs[j], ww.fo[j], ww.fi[j]);
+                  died |= alive[j] & ~okv[j];
+                }
+              }
+              if (__builtin_expect(died != 0ull, 0)) {
+#pragma unroll
+                for (int j = 0; j < K; j++) {
+                  n_vign += (unsigned)__popcll(alive[j] & ~gv[j]);
+                  n_tir += (unsigned)__popcll(alive[j] & gv[j] & ~okv[j]);
+                  nlive -= (unsigned)__popcll(alive[j] & ~okv[j]);
+                  alive[j] &= okv[j];
+                }
+              }
+            }
+            ev32 += nlive;       // events completed: one per ray still alive after the row
+          }
+          events += ev32;
+          if (nlive == 0u) continue;
+          // ---- the path is complete for nlive rays --------------------------------------------------
+          n_scene += nlive;
+#pragma unroll
+          for (int j = 0; j < K; j++) {
+            if (alive[j] == 0ull) continue;
+            const int l = g * K + j;
+            const float cg = fmaf(r[j].dx, sx, fmaf(r[j].dy, sy, r[j].dz * sz));
+            const lanemask lit = alive[j] & __ballot(cg > lobe_thr);
+            if (lit == 0ull) continue;
+            const float qq = lobe_q(r[j].dx, r[j].dy, r[j].dz, sx, sy, sz, sun_ss, inv_1mc);
+            const float om = 1.0f - qq;
+            float contrib = __fdiv_rn(r[j].wn, r[j].wd) * (om * om);
+            contrib = (((lit >> lane) & 1ull) != 0ull && qq < 1.0f && contrib > 0.0f) ? contrib : 0.0f;
+            n_light += contrib > 0.0f ? 1u : 0u;
+#pragma unroll
+            for (int c = 0; c < 3; c++) {
+              const float v = contrib * (lens->sun_radiance[c] * lens->lambda_rgb[l][c]);
+              const unsigned long long fx = (unsigned long long)(v * a.fix_scale);
+              if (fx) atomicAdd(&s_acc[lane * 3 + c], fx);
+            }
+          }
+        }
+      }
+    }
+    __syncthreads();
+    if (tid == 0) { s_next = 0; s_nlist = 0; }
+    __syncthreads();
+  }
+
+  // ---- counters: one LDS add per wave, one global add per workgroup (slots as k_march: executed events =
+  // events, every path marched on its own; no second march) ---------------------------------------------
+  {
+    unsigned long long v6 = n_light;
+    for (int off = 32; off > 0; off >>= 1) v6 += __shfl_down(v6, off);
+    const unsigned long long vals[kMarchCounters] = {n_rays, events, n_clip, n_vign, n_tir, n_scene, v6, events, 0ull, 0ull};
+    if (lane == 0) {
+#pragma unroll
+      for (int i = 0; i < kMarchCounters; i++)
+        if (vals[i]) atomicAdd(&s_cnt[i], vals[i]);
+    }
+  }
+  __syncthreads();
+  if (wave == 0 && lane < kMarchCounters && s_cnt[lane]) atomicAdd(&counters[lane], s_cnt[lane]);
+
+  if (wave == 0 && active) {
+    if (a.sgroups == 1) {
+#pragma unroll
+      for (int c = 0; c < 3; c++) {
+        const double v = ((double)s_acc[lane * 3 + c] * a.inv_fix) / (double)a.spp;
+        ghost[3 * (size_t)p + c] = a.accumulate ? ghost[3 * (size_t)p + c] + v : v;
+      }
+    } else {
+#pragma unroll
+      for (int c = 0; c < 3; c++)
+        if (s_acc[lane * 3 + c]) atomicAdd(&accum[3 * (size_t)p + c], s_acc[lane * 3 + c]);
+    }
+  }
+}
+
+uint64_t fnv(uint64_t h, const void* data, size_t n) {
+  const unsigned char* b = static_cast<const unsigned char*>(data);
+  for (size_t i = 0; i < n; i++) { h ^= b[i]; h *= 0x100000001b3ull; }
+  return h;
+}
+
+}  // namespace
+
+// table cells per axis inside one stratum: as fine as the sampling specification lets a wave know where it is
+// (its lanes share ONE of 2^sub_bits sub-cells per axis), at most 4, and a table of at most 128 cells per axis
+static int cull_m(const lf_ctx* ctx, int G) {
+  int m = 4;
+  if (const char* e = std::getenv("LF_CULL_M")) m = std::max(1, std::atoi(e));   // experiments only
+  while (m > 1 && (m > (1 << ctx->march_sub_bits) || G * m > 128)) m >>= 1;
+  return m;
+}
+
+bool lf_cull_applies(const lf_ctx* ctx, int G) {
+  if (ctx->march_cull == 0) return false;
+  if (const char* e = std::getenv("LF_MARCH_CULL")) if (std::atoi(e) == 0) return false;   // experiments only
+  // a mask has 64 bits; the strata of more than 4096 samples per pixel would need a table of their own size
+  return ctx->pairs.n <= kCullMaxPaths && G >= 1 && G <= 64 && ctx->lens.stop >= 0;
+}
+
+lf_status lfk_cull_prepass(lf_ctx* ctx, int G) {
+  const LfLensDev& L = ctx->lens;
+  CullLevelArgs a;
+  std::memset(&a, 0, sizeof(a));
+  a.W = ctx->W; a.H = ctx->H;
+  a.pitch = L.pitch; a.half_w = 0.5f * (float)ctx->W; a.half_h = 0.5f * (float)ctx->H;
+  a.blocks_x = (ctx->W + (1 << kCullBlockLog2) - 1) >> kCullBlockLog2;
+  a.blocks_y = (ctx->H + (1 << kCullBlockLog2) - 1) >> kCullBlockLog2;
+  const int m = cull_m(ctx, G);
+  a.P_final = G * m;
+  a.n_paths = ctx->pairs.n;
+  // dispersion is monotonic in the wavelength: the two ends of the spectrum bracket what lies between
+  a.n_test = std::min(L.n_lambda, 2);
+  a.lam[0] = 0; a.lam[1] = L.n_lambda - 1; a.lam[2] = L.n_lambda - 1;
+  if (std::getenv("LF_CULL_ALL_LAMBDA") && L.n_lambda >= 3) { a.n_test = 3; a.lam[1] = (L.n_lambda - 1) / 2; }
+  a.march_k = ctx->march_k; a.prog_recs = ctx->pairs.prog_recs;
+  a.pupil_h = L.pupil_h; a.vz = L.pupil_z - L.z_sensor; a.geom_norm = L.geom_norm;
+  a.stop_h = L.stop_h; a.inv_stop_h = 1.0f / L.stop_h;
+  a.sx = L.sun_dir[0]; a.sy = L.sun_dir[1];
+  {
+    // a ray contributes only if d.s > lobe_thr (lfk_march): |d - s|^2 = 2 - 2 d.s < 2 (1 - thr) for unit vectors,
+    // and the (x, y) projection is no longer than the vector; the float march's directions are unit to ~1e-6
+    const double thr = 1.0 - (1.0625 / (double)L.sun_inv_one_minus_cos) * (1.0 + 1e-6) - 4e-7;
+    a.rho = (float)(std::sqrt(2.0 * (1.0 - thr)) * 1.001 + 1e-5);
+  }
+  float margin = ctx->cull_margin;
+  if (const char* e = std::getenv("LF_CULL_MARGIN")) { const double v = std::atof(e); if (v > 0.0) margin = (float)v; }
+  std::memcpy(a.occ, ctx->cull_occ, sizeof(a.occ));
+  // the levels: P_final, halved while it stays even and >= 8 (a coarser box is too curved for 13 rays to bound)
+  int levels[8], n_levels = 0;
+  {
+    int P = a.P_final;
+    levels[n_levels++] = P;
+    int coarsest = 8;
+    if (const char* e = std::getenv("LF_CULL_P0")) coarsest = std::max(2, std::atoi(e));   // experiments only
+    while (n_levels < 8 && P % 2 == 0 && P / 2 >= coarsest) { P /= 2; levels[n_levels++] = P; }
+    std::reverse(levels, levels + n_levels);
+  }
+
+  // is the resident table the one these inputs give?
+  uint64_t h = 0xcbf29ce484222325ull;
+  a.margin = margin;
+  h = fnv(h, &a, sizeof(a));
+  h = fnv(h, levels, sizeof(int) * (size_t)n_levels);
+  h = fnv(h, &L, sizeof(L));
+  h = fnv(h, ctx->pairs.ij, sizeof(int) * 2 * (size_t)ctx->pairs.n);
+  h = fnv(h, &ctx->mask_generation, sizeof(ctx->mask_generation));
+  if (h == 0) h = 1;
+  const size_t nblk = (size_t)a.blocks_x * a.blocks_y;
+  const size_t entries = nblk * ((size_t)a.P_final * a.P_final + 1);
+  const bool reuse = ctx->march_cull == 1 && ctx->cull_dev && ctx->cull_hash == h && !std::getenv("LF_CULL_NO_REUSE");
+  ctx->cull_bx = a.blocks_x; ctx->cull_by = a.blocks_y; ctx->cull_cells = a.P_final * a.P_final; ctx->cull_G = G;
+  ctx->cull_P = a.P_final; ctx->cull_m = m;
+  if (reuse) return LF_OK;
+  if (entries > ctx->cull_cap) {
+    LF_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    if (ctx->cull_dev) (void)hipFree(ctx->cull_dev);
+    ctx->cull_dev = nullptr; ctx->cull_cap = 0; ctx->cull_hash = 0;
+    LF_HIP(ctx, hipMalloc((void**)&ctx->cull_dev, entries * sizeof(unsigned long long)));
+    ctx->cull_cap = entries;
+  }
+  if (!ctx->cull_counts) LF_HIP(ctx, hipMalloc((void**)&ctx->cull_counts, 8 * kCullMaxPaths * sizeof(unsigned)));
+  ctx->cull_hash = 0;
+  unsigned long long* stats_dev = nullptr;
+  if (std::getenv("LF_CULL_STATS")) {
+    LF_HIP(ctx, hipMalloc((void**)&stats_dev, 32 * sizeof(unsigned long long)));
+  }
+  hipEvent_t ev = lf_timing_begin(ctx, LFK_CULL);
+  LF_HIP(ctx, hipMemsetAsync(ctx->cull_dev, 0, entries * sizeof(unsigned long long), ctx->stream));
+  LF_HIP(ctx, hipMemsetAsync(ctx->cull_counts, 0, 8 * kCullMaxPaths * sizeof(unsigned), ctx->stream));
+  unsigned max_items = 0;     // of the level about to run (per path); level 0 runs every box
+  for (int lv = 0; lv < n_levels; lv++) {
+    a.P = levels[lv];
+    a.last = lv + 1 == n_levels ? 1 : 0;
+    // coarse boxes are more curved than 13 rays show: more inflation the larger the pupil cell
+    a.margin = margin * (a.P >= 64 ? 1.0f : a.P >= 32 ? 1.15f : a.P >= 16 ? 1.4f : 2.0f);
+    const size_t n_items = lv == 0 ? nblk * (size_t)a.P * a.P : (size_t)max_items;
+    if (n_items == 0) break;
+    const unsigned* items = lv == 0 ? nullptr : ctx->cull_list[(lv - 1) & 1];
+    const unsigned in_stride = a.list_stride;    // (of the list being read: set when it was written)
+    unsigned* next = nullptr;
+    unsigned out_stride = 0;
+    if (!a.last) {
+      // every box may keep its four children
+      const size_t need = n_items * 4;
+      if (need > 0x7fffffffull) return lf_fail(ctx, LF_ERR_INVALID, "cull pre-pass: frame too large");
+      out_stride = (unsigned)need;
+      const size_t total = need * (size_t)a.n_paths;
+      const int slot = lv & 1;
+      if (total > ctx->cull_list_cap[slot]) {
+        LF_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        if (ctx->cull_list[slot]) (void)hipFree(ctx->cull_list[slot]);
+        ctx->cull_list[slot] = nullptr; ctx->cull_list_cap[slot] = 0;
+        LF_HIP(ctx, hipMalloc((void**)&ctx->cull_list[slot], total * sizeof(unsigned)));
+        ctx->cull_list_cap[slot] = total;
+      }
+      next = ctx->cull_list[slot];
+    }
+    if (stats_dev) LF_HIP(ctx, hipMemsetAsync(stats_dev, 0, 32 * sizeof(unsigned long long), ctx->stream));
+    // the kernel reads its input with the stride it was written with and writes with the new one
+    CullLevelArgs k = a;
+    k.list_stride = a.last ? in_stride : out_stride;
+    // (two strides are needed when reading AND writing: the input's travels in `items_stride`)
+    const dim3 grid((unsigned)((n_items + 255) / 256), (unsigned)a.n_paths);
+    hipLaunchKernelGGL(k_cull_level, grid, dim3(256), 0, ctx->stream, ctx->lens_dev, ctx->pairs_dev,
+                       (const int*)(ctx->prog_dev + ctx->prog_seq_off), (const LfProgRow*)(ctx->prog_dev + ctx->prog_rec_off),
+                       k, items, lv == 0 ? nullptr : ctx->cull_counts + (size_t)(lv - 1) * kCullMaxPaths, in_stride, next,
+                       ctx->cull_counts + (size_t)lv * kCullMaxPaths, ctx->cull_dev, stats_dev);
+    LF_HIP(ctx, hipGetLastError());
+    a.list_stride = out_stride;
+    if (stats_dev) {   // experiments only: why the boxes of this level ended as they did, per tested wavelength
+      unsigned long long hs[32];
+      LF_HIP(ctx, hipStreamSynchronize(ctx->stream));
+      LF_HIP(ctx, hipMemcpy(hs, stats_dev, sizeof(hs), hipMemcpyDeviceToHost));
+      static const char* names[8] = {"", "kept_inside_lobe_partial_box", "kept_too_few_samples_left", "kept_inside_lobe",
+                                     "culled_aperture", "culled_mask", "culled_lobe", "culled_all_samples_lost"};
+      for (int li = 0; li < a.n_test; li++)
+        for (int w = 1; w < 8; w++)
+          std::fprintf(stderr, "CULL_STATS P %d lambda %d %s %llu\n", a.P, a.lam[li], names[w], hs[w + 8 * li]);
+    }
+    if (!a.last) {
+      // how long the next level's lists are: the grid needs the longest
+      unsigned cnt[kCullMaxPaths];
+      LF_HIP(ctx, hipMemcpyAsync(cnt, ctx->cull_counts + (size_t)lv * kCullMaxPaths, sizeof(cnt), hipMemcpyDeviceToHost, ctx->stream));
+      LF_HIP(ctx, hipStreamSynchronize(ctx->stream));
+      max_items = 0;
+      for (int q = 0; q < a.n_paths; q++) max_items = std::max(max_items, std::min(cnt[q], out_stride));
+    }
+  }
+  lf_timing_end(ctx, LFK_CULL, ev);
+  if (stats_dev) (void)hipFree(stats_dev);
+  ctx->cull_hash = h;
+  return LF_OK;
+}
+
+lf_status lfk_march_culled(lf_ctx* ctx, const MarchArgs& a, size_t blocks, size_t dyn_lds) {
+  const LfApertureDev& m = ctx->ap[LF_APERTURE_STARBURST];
+  LfCullArgs c;
+  c.table = ctx->cull_dev; c.blocks_x = ctx->cull_bx; c.blocks_y = ctx->cull_by; c.cells = ctx->cull_cells;
+  c.P = ctx->cull_P; c.m = ctx->cull_m; c.m_shift = ctx->cull_m == 4 ? 2 : ctx->cull_m == 2 ? 1 : 0;
+  hipEvent_t ev = lf_timing_begin(ctx, LFK_MARCH);
+#define LF_LAUNCH_CULL(KK)                                                                                   \
+  hipLaunchKernelGGL(k_march_cull<KK>, dim3((unsigned)blocks), dim3(64 * kWgWaves), dyn_lds, ctx->stream, ctx->lens_dev, \
+                     ctx->pairs_dev, (const int*)(ctx->prog_dev + ctx->prog_seq_off),                         \
+                     (const LfProgRow*)(ctx->prog_dev + ctx->prog_rec_off),                                  \
+                     (const LfWeightRow*)(ctx->prog_dev + ctx->prog_wrec_off), m.texels, a, c, ctx->ghost,   \
+                     ctx->accum, ctx->counters_dev)
+  switch (ctx->march_k) {
+    case 1: LF_LAUNCH_CULL(1); break;
+    case 2: LF_LAUNCH_CULL(2); break;
+    default: LF_LAUNCH_CULL(3); break;
+  }
+#undef LF_LAUNCH_CULL
+  lf_timing_end(ctx, LFK_MARCH, ev);
+  LF_HIP(ctx, hipGetLastError());
+  return LF_OK;
+}

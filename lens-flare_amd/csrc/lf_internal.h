@@ -197,6 +197,26 @@ struct alignas(64) LfWeightRow {
 //                  tallied per logical path, exactly as if each had been marched on its own)
 enum { LF_EV_REST1 = 8, LF_EV_SAVE0 = 0x10, LF_EV_SAVE1 = 0x20, LF_EV_END = 0x40, LF_EV_REST0 = 0x80 };
 
+// ---- path culling (round 5; lf_cull.hip) ------------------------------------------------------------
+// Which paths can carry light from the sun to which part of the sensor through which part of the pupil: for
+// every block of 64 x 64 sensor pixels and every cell of a P x P grid over the pupil square (P = G * m: m x m
+// cells inside each of the march's G x G strata -- a wave aims all its lanes at ONE sub-cell of its stratum, so
+// it knows which table cell it is in) a 64-bit mask of the selected paths, built by a coarse-to-fine pre-pass
+// (k_cull_level) that marches 13 rays per (block, cell, path) and bounds where the whole 4-D box can go.  The
+// march then starts ONLY the paths whose bit is set: the others end outside the sun's lobe or on a diaphragm,
+// i.e. add exactly 0 -- the pixels are those of the full enumeration, bit for bit.  Entry `cells` of a block
+// is the union over its cells (the unstratified samples s >= G * G of a non-square sample count).
+constexpr int kCullBlockLog2 = 6;        // sensor blocks of 64 x 64 pixels (a wave tile of any stride lies inside one)
+constexpr int kCullMaxPaths = 64;        // bits of a mask
+constexpr int kCullOcc = 32;             // the stop mask's occupancy grid: kCullOcc x kCullOcc cells, any texel > 0
+struct LfCullArgs {
+  const unsigned long long* table;   // [blocks_y * blocks_x][cells + 1]; null = every path everywhere
+  int blocks_x, blocks_y;
+  int cells;                          // P * P, P = G * m cells per axis of the pupil square
+  int P, m, m_shift;                  // m (1, 2 or 4) table cells per axis inside one stratum; m = 2^m_shift <= the
+                                      // sub-cells per axis of the sampling specification (lf_set_pupil_subcells)
+};
+
 // ---- lens camera (round 4): the scene imaged through the prescription --------------------------
 // The primary path N-1 .. 0 of a sensor sample (the ray travels -z, against the light), one row per
 // interface in the order the ray meets them, the constants of surface_event for EVERY wavelength
@@ -240,7 +260,7 @@ constexpr int kSceneCounters = 4;
 
 // ---- timing ---------------------------------------------------------------------------------
 enum LfKernelId { LFK_MARCH = 0, LFK_FLARE_LAYER, LFK_GHOST_RASTER, LFK_DFT, LFK_FRAME_SETUP,
-                  LFK_TONEMAP, LFK_EXCHANGE, LFK_SCENE, LFK_COUNT };
+                  LFK_TONEMAP, LFK_EXCHANGE, LFK_SCENE, LFK_CULL, LFK_COUNT };
 
 struct LfTimedLaunch { int kernel; hipEvent_t start, stop; };
 
@@ -344,6 +364,21 @@ struct lf_ctx {
   unsigned long long* accum = nullptr;         // W*H_alloc*3 fixed-point partial sums (split launches)
   unsigned char* prog_dev = nullptr;           // the packed program: headers, then records (lf_march.hip pack_program)
   size_t prog_cap = 0, prog_rec_off = 0, prog_wrec_off = 0, prog_seq_off = 0;   // bytes; offsets of the records / weight records / pair sequences
+  // path culling (lf_cull.hip): 0 = off (k_march walks every path of every sample), 1 = on, the table is reused
+  // while its inputs (lens, pairs, sun, frame, pupil disc, mask, strata) are unchanged, 2 = on, rebuilt at every launch
+  int march_cull = 1;
+  unsigned long long* cull_dev = nullptr;
+  size_t cull_cap = 0;                         // entries allocated
+  unsigned* cull_list[2] = {nullptr, nullptr}; // work lists of the pre-pass levels (per path: list_stride entries)
+  size_t cull_list_cap[2] = {0, 0};
+  unsigned* cull_counts = nullptr;             // [levels][kCullMaxPaths] list lengths
+  int cull_m = 1;                              // table cells per axis inside one stratum
+  uint64_t cull_hash = 0;                      // of the inputs the resident table was built from (0 = none)
+  int cull_bx = 0, cull_by = 0, cull_cells = 0, cull_G = 0, cull_P = 0;
+  float cull_margin = 1.25f;                   // footprint inflation of the pre-pass (LF_CULL_MARGIN: experiments)
+  unsigned cull_occ[kCullOcc] = {};            // occupancy of the stop mask (host, lf_set_aperture)
+  uint64_t mask_generation = 0;                // bumped by lf_set_aperture(STARBURST)
+  bool last_march_culled = false;              // what the last lf_trace_ghosts ran
   int march_k = 1;                             // wavelengths (rays per lane) that walk together
   int march_fix_bits = 36;                     // the last launch's fixed-point exponent (lf_get_march_fix_bits)
   bool events_dirty = true;
@@ -412,6 +447,11 @@ lf_status lfk_native_sqrt(lf_ctx* ctx, const float* d_x, float* d_y, size_t n);
 lf_status lfk_native_rcp(lf_ctx* ctx, const float* d_x, float* d_y, size_t n);
 void lf_apply_pupil_target(lf_ctx* ctx);
 int lf_march_fix_bits(const LfLensDev& L, int n_paths, int spp);
+// lf_cull.hip (a = the launch's arguments as lfk_march set them up: lf_march_common.h)
+namespace lfm { struct MarchArgs; }
+bool lf_cull_applies(const lf_ctx* ctx, int G);
+lf_status lfk_cull_prepass(lf_ctx* ctx, int G);
+lf_status lfk_march_culled(lf_ctx* ctx, const lfm::MarchArgs& a, size_t blocks, size_t dyn_lds);
 void lf_derive_lens(lf_ctx* ctx, int n, int stop, int n_lambda, const float* radius,
                     const float* thickness, const float* ior, const float* semi_ap,
                     float sensor_w_mm);

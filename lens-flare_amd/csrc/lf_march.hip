@@ -36,11 +36,15 @@
 // path on its own, which makes pixels and event counters comparable bit for bit.
 #include <algorithm>
 #include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <vector>
 #include <cstring>
 #include <utility>
 
 #include "lf_internal.h"
 #include "lf_march_events.h"
+#include "lf_march_common.h"
 
 namespace {
 
@@ -65,88 +69,6 @@ __device__ __forceinline__ void unpark(const float2* __restrict__ slot, int lane
   r.r2 = fmaf(r.px, r.px, r.py * r.py);   // the same expression that produced it: the same bits
 }
 
-// The sun's lobe: q = (1 - cos theta) / (1 - cos alpha), theta between the ray and the sun.
-// 1 - d.s would cancel (d.s ~ 0.999: an absolute error of 1e-7 is 1e-4 of a 0.05 rad lobe, and the
-// float unit vectors are only unit to 1e-7 as well), so
-//   1 - cos theta = sin^2 theta / (1 + cos theta) = |d x s|^2 / (|d|^2 |s|^2 + sqrt(|d|^2 |s|^2) d.s)
-// which has no cancellation and does not assume |d| = |s| = 1 (ss = |s|^2 from the host).  Valid for
-// d.s > 0, which the pre-test guarantees.  (tests/test_gpu_march_f64.py checks the march against an
-// independent float64 tracer; with the plain 1 - d.s the pixels were off by up to 1e-2.)
-__device__ __forceinline__ float lobe_q(float dx, float dy, float dz, float sx, float sy, float sz,
-                                        float ss, float inv_1mc) {
-  const float cg = fmaf(dx, sx, fmaf(dy, sy, dz * sz));
-  const float cx = fmaf(dy, sz, -(dz * sy)), cy = fmaf(dz, sx, -(dx * sz)), cz = fmaf(dx, sy, -(dy * sx));
-  const float c2 = fmaf(cx, cx, fmaf(cy, cy, cz * cz));
-  const float dd = fmaf(dx, dx, fmaf(dy, dy, dz * dz));
-  const float ds = dd * ss;
-  const float den = fmaf(lf_sqrt(ds), cg, ds);
-  return __fdiv_rn(c2, den) * inv_1mc;
-}
-
-struct MarchArgs {
-  int mw, mh, W, H, y0, y1;
-  int spp, G;          // G x G pupil strata, G = floor(sqrt(spp))
-  float inv_G;
-  int sub_bits;        // each stratum is split into 2^sub_bits x 2^sub_bits sub-cells
-  float inv_sub;
-  int trow0, tperiod;  // tile rows handled: trow0 + j * tperiod, j = 0 ..
-  int sgroups;         // the samples of a tile are split over this many workgroups (power of two)
-  uint2 key;
-  float inv_stop_h;    // 1 / stop_h (correctly rounded)
-  float half_w, half_h;  // 0.5 * W, 0.5 * H
-  float vz;            // pupil_z - z_sensor
-  float lobe_thr;      // d.s above this may lie inside the sun's lobe (conservative, see lfk_march)
-  int accumulate;      // add the launch's pixels to the ghost buffer instead of replacing them
-  int n_tiles;         // wave tiles of the launch (the grid holds them padded to a multiple of 64)
-  int xs;              // log2 of the lanes' pixel stride in x (lf_set_tile_stride): 0 = an 8 x 8 block of
-                       // adjacent pixels per wave, 3 = columns 8 apart (a 64 x 8 block shared by 8 waves)
-  float fix_scale;     // 2^fix_bits: the launch's fixed-point grid (lf_march_fix_bits; 2^36 unless that could wrap)
-  double inv_fix;      // 2^-fix_bits
-};
-
-// The program of a GROUP of up to 3 wavelengths, in two levels (LfProgHdr / LfProgRow in
-// lf_internal.h): per row a 16-byte header (ONE s_load_dwordx4), per distinct (interface, direction)
-// a 64-byte record (ONE s_load_dwordx16: the geometry once, the index ratios of each wavelength of
-// the group).  A header names its own record and the NEXT row's, so stepping to the next row issues
-// both loads at once; only a jump (a wave that died as a whole) loads header, then record.
-typedef int lf_i16 __attribute__((ext_vector_type(16)));
-typedef int lf_i4 __attribute__((ext_vector_type(4)));
-typedef const lf_i16 __attribute__((address_space(4))) * lf_const_prow_ptr;
-typedef const lf_i4 __attribute__((address_space(4))) * lf_const_phdr_ptr;
-__device__ __forceinline__ LfProgRow load_prec(const LfProgRow* __restrict__ base, unsigned off) {
-  // (base + 32-bit byte offset: the load takes it as its SGPR offset)
-  typedef const char __attribute__((address_space(4))) * cptr;
-  const lf_i16 v = *(lf_const_prow_ptr)((cptr)(base) + off);
-  LfProgRow r;
-  r.dzv = __int_as_float(v[0]); r.curv = __int_as_float(v[1]); r.h2 = __int_as_float(v[2]);
-  r.sc = __int_as_float(v[3]); r.sgn = __int_as_float(v[4]);
-#pragma unroll
-  for (int j = 0; j < 3; j++) {
-    r.delta[j] = __int_as_float(v[5 + j]); r.cn22[j] = __int_as_float(v[8 + j]); r.rn2[j] = __int_as_float(v[12 + j]);
-  }
-  r.ch = __int_as_float(v[11]); r.c2 = __int_as_float(v[15]);
-  return r;
-}
-__device__ __forceinline__ LfWeightRow load_wrec(const LfWeightRow* __restrict__ base, unsigned off) {
-  typedef const char __attribute__((address_space(4))) * cptr;
-  const lf_i16 v = *(lf_const_prow_ptr)((cptr)(base) + off);
-  LfWeightRow r;
-#pragma unroll
-  for (int j = 0; j < 3; j++) {
-    r.fs[j] = __int_as_float(v[j]); r.fo[j] = __int_as_float(v[4 + j]); r.fi[j] = __int_as_float(v[8 + j]);
-  }
-  r.pad0 = r.pad1 = r.pad2 = 0.0f;
-  r.pad3[0] = r.pad3[1] = r.pad3[2] = r.pad3[3] = 0.0f;
-  return r;
-}
-__device__ __forceinline__ LfProgHdr load_phdr(const LfProgHdr* __restrict__ base, unsigned off) {
-  typedef const char __attribute__((address_space(4))) * cptr;
-  const lf_i4 v = *(lf_const_phdr_ptr)((cptr)(base) + off);
-  LfProgHdr h;
-  h.flags = v[0]; h.skip = v[1]; h.rec = v[2]; h.rec_next = v[3];
-  return h;
-}
-
 // K = rays per lane: the K wavelengths of a group walk the program TOGETHER.  They start as the same
 // ray and differ only by dispersion, so they share their fate almost always -- and the whole scalar
 // side of the walk (row load, dispatch on the row kind, loop control, fork/join, dead-wave jumps) is
@@ -165,6 +87,12 @@ __device__ __forceinline__ LfProgHdr load_phdr(const LfProgHdr* __restrict__ bas
 // long, at the same 24 waves per CU (3 workgroups of 50.8 KB LDS); c3 frame 115.5 -> 114.9 ms, shares of
 // a frame 1-2 % (profiles/r03_march_variants.txt; 6 and 2 waves are worse, 12 no better).
 constexpr int kWgWaves = 8;
+#ifdef LF_MARCH_LIT_MAP
+// instrumented build (profiles/r05_cull_floor.json), never shipped: which (sensor block, pupil cell at resolution P,
+// path) combinations EVER end with a lane inside the lobe pre-test -- the floor of any table-driven cull at that
+// granularity.  Eight maps: blocks of 64 x 64 and of 64 x 8 pixels, P = 16, 32, 64, 128 cells per pupil axis.
+__device__ unsigned long long* g_lit_map[8];
+#endif
 #ifndef LF_SKIP_DEAD_LAMBDA
 #define LF_SKIP_DEAD_LAMBDA 1   // experiments (profiles/r04_march_variants.txt): 0 = no per-wavelength liveness branch
 #endif
@@ -307,6 +235,9 @@ void k_march(const LfLensDev* __restrict__ lens, const LfPairsDev* __restrict__ 
       const uint4 rnd = philox4x32_10(make_uint4(p, (unsigned)s, kDomainMarch, 0u), a.key);
       const float jx = u01(rnd.x), jy = u01(rnd.y);
       float ua = u01(rnd.z), ub = u01(rnd.w);
+#ifdef LF_MARCH_LIT_MAP
+      float lm_u = 0.5f, lm_v = 0.5f;   // the wave's sub-cell centre in the pupil square (wave-uniform)
+#endif
       if (s < GG) {  // stratum (s % G, s / G) of the pupil square
         const int cy = s / a.G, cx = s - cy * a.G;
         // ... and inside it ONE of sub x sub sub-cells, drawn per (tile, s): wave-uniform, so the
@@ -318,6 +249,10 @@ void k_march(const LfLensDev* __restrict__ lens, const LfPairsDev* __restrict__ 
         const unsigned syi = a.sub_bits ? (r2.y >> (32 - a.sub_bits)) : 0u;
         ua = ((float)cx + ((float)sxi + ua) * a.inv_sub) * a.inv_G;
         ub = ((float)cy + ((float)syi + ub) * a.inv_sub) * a.inv_G;
+#ifdef LF_MARCH_LIT_MAP
+        lm_u = ((float)cx + ((float)sxi + 0.5f) * a.inv_sub) * a.inv_G;
+        lm_v = ((float)cy + ((float)syi + 0.5f) * a.inv_sub) * a.inv_G;
+#endif
       }
       const float pa = fmaf(2.0f, ua, -1.0f), pb = fmaf(2.0f, ub, -1.0f);
       const float X = -(((float)x + jx) - half_w) * pitch;
@@ -581,6 +516,19 @@ void k_march(const LfLensDev* __restrict__ lens, const LfPairsDev* __restrict__ 
               LF_PAIR_STAT(1, endfl >> 24, lit[j] != 0ull ? 1u : 0u);
               LF_PAIR_STAT(2, endfl >> 24, (unsigned)__popcll(lit[j]));
             }
+#ifdef LF_MARCH_LIT_MAP
+            if (lit_any != 0ull && g_lit_map[0] != nullptr && lane_id() == 0) {
+              const int bx64 = (tx >> a.xs) << (3 + a.xs) >> 6, trow_ = a.trow0 + tj * a.tperiod;
+              const int nbx = (a.W + 63) >> 6;
+              const int blkA = ((trow_ * 8) >> 6) * nbx + bx64, blkB = trow_ * nbx + bx64;
+              for (int m = 0; m < 4; m++) {
+                const int P = 16 << m;
+                const int fx = min(P - 1, (int)(lm_u * (float)P)), fy = min(P - 1, (int)(lm_v * (float)P));
+                atomicOr(&g_lit_map[m][((size_t)blkA * P + fy) * P + fx], 1ull << (endfl >> 24));
+                atomicOr(&g_lit_map[4 + m][((size_t)blkB * P + fy) * P + fx], 1ull << (endfl >> 24));
+              }
+            }
+#endif
             if (lit_any != 0ull) {
               // rare (about 1 % of the wave-paths): march this path again, alone and with the
               // weight, along its own row sequence -- once per wavelength that has a lit lane
@@ -1229,6 +1177,38 @@ lf_status lfk_march(lf_ctx* ctx, int spp, uint64_t key) {
   // profiles/r03_march_variants.txt)
   size_t dyn_lds = 0;
   if (const char* dl = std::getenv("LF_MARCH_DYN_LDS")) dyn_lds = (size_t)std::max(0, std::atoi(dl));
+#ifdef LF_MARCH_LIT_MAP
+  static unsigned long long* lit_dev[8] = {};
+  static size_t lit_n[8] = {};
+  if (std::getenv("LF_LIT_MAP") && !lit_dev[0]) {
+    const size_t nbx = (ctx->W + 63) >> 6, nA = nbx * ((ctx->H + 63) >> 6), nB = nbx * ((ctx->H + 7) >> 3);
+    for (int m = 0; m < 8; m++) {
+      const size_t P = 16u << (m & 3);
+      lit_n[m] = (m < 4 ? nA : nB) * P * P;
+      LF_HIP(ctx, hipMalloc((void**)&lit_dev[m], lit_n[m] * 8));
+      LF_HIP(ctx, hipMemset(lit_dev[m], 0, lit_n[m] * 8));
+    }
+    LF_HIP(ctx, hipMemcpyToSymbol(HIP_SYMBOL(g_lit_map), lit_dev, sizeof(lit_dev)));
+  }
+  if (std::getenv("LF_LIT_MAP_DUMP") && lit_dev[0]) {
+    LF_HIP(ctx, hipDeviceSynchronize());
+    for (int m = 0; m < 8; m++) {
+      std::vector<unsigned long long> h(lit_n[m]);
+      LF_HIP(ctx, hipMemcpy(h.data(), lit_dev[m], lit_n[m] * 8, hipMemcpyDeviceToHost));
+      unsigned long long bits = 0, nz = 0;
+      for (unsigned long long v : h) { bits += (unsigned long long)__builtin_popcountll(v); nz += v != 0; }
+      std::fprintf(stderr, "LIT_MAP block %s P %d entries %zu nonzero %llu bits %llu fraction_of_entry_paths %.5f\n",
+                   m < 4 ? "64x64" : "64x8", 16 << (m & 3), lit_n[m], nz, bits, (double)bits / ((double)lit_n[m] * ctx->pairs.n));
+    }
+  }
+#endif
+  // the paths a pre-pass found able to reach the light (lf_cull.hip) -- or every path of every sample
+  ctx->last_march_culled = lf_cull_applies(ctx, a.G);
+  if (ctx->last_march_culled) {
+    lf_status st = lfk_cull_prepass(ctx, a.G);
+    if (st == LF_OK) st = lfk_march_culled(ctx, a, blocks, dyn_lds);
+    if (st != LF_OK) return st;
+  } else {
   hipEvent_t ev = lf_timing_begin(ctx, LFK_MARCH);
 #define LF_LAUNCH_MARCH(KK)                                                                        \
   hipLaunchKernelGGL(k_march<KK>, dim3((unsigned)blocks), dim3(64 * kWgWaves), dyn_lds, ctx->stream, ctx->lens_dev, \
@@ -1245,6 +1225,7 @@ lf_status lfk_march(lf_ctx* ctx, int spp, uint64_t key) {
 #undef LF_LAUNCH_MARCH
   lf_timing_end(ctx, LFK_MARCH, ev);
   LF_HIP(ctx, hipGetLastError());
+  }
   if (a.sgroups > 1) {
     const size_t px = (size_t)(ctx->y1 - ctx->y0) * ctx->W;
     hipLaunchKernelGGL(k_march_finish, dim3((unsigned)((px + 255) / 256)), dim3(256), 0, ctx->stream,

@@ -348,6 +348,16 @@ static double sample_ray(const g64_lens* L, const g64_system* S, int W, int H, i
   return (M_PI * pupil_h * pupil_h / (dist * dist)) * cos2 * cos2;
 }
 
+/* The device's path culling (lf_get_cull_table), as in lf_geo_oracle.c: with a table installed the IMAGE is still
+ * the full enumeration's -- the independent evidence that what the device skips adds nothing -- while the
+ * counters count the rays the device starts (block = 64 x 64 pixels, entry = the sample's pupil stratum). */
+static const uint64_t* g64_cull = NULL;
+static int g64_cull_bx = 0, g64_cull_cells = 0;
+void g64_set_cull(const uint64_t* table, int blocks_x, int blocks_y, int cells) {
+  (void)blocks_y;
+  g64_cull = table; g64_cull_bx = blocks_x; g64_cull_cells = cells;
+}
+
 /* image, frag: W*H*3 doubles (rows [y0, y1) are written); counters: launched, events, clipped at
  * the stop, vignetted, totally reflected, reached the scene, hit the light, fragile rays */
 void g64_trace(const g64_lens* L, int W, int H, int y0, int y1, int spp, const uint32_t key[2],
@@ -359,9 +369,13 @@ void g64_trace(const g64_lens* L, int W, int H, int y0, int y1, int spp, const u
   const vec sun = normalise(V(L->sun_dir[0], L->sun_dir[1], L->sun_dir[2])); /* the angle is between directions */
   uint64_t total[8] = {0};
   if (n_threads < 1) n_threads = 1;
+  int G = (int)floor(sqrt((double)spp));
+  while ((G + 1) * (G + 1) <= spp) G++;
+  while (G * G > spp) G--;
+  const int GG = G * G;
 #pragma omp parallel num_threads(n_threads)
   {
-    uint64_t c[8] = {0};
+    uint64_t counted[8] = {0}, skipped[8] = {0};
 #pragma omp for schedule(dynamic, 16)
     for (long long p = (long long)y0 * W; p < (long long)y1 * W; p++) {
       const int x = (int)(p % W), y = (int)(p / W);
@@ -370,8 +384,26 @@ void g64_trace(const g64_lens* L, int W, int H, int y0, int y1, int spp, const u
       for (int s = 0; s < spp; s++) {
         vec o, d;
         const double w0 = sample_ray(L, &S, W, H, x, y, s, spp, sub_bits, key, &o, &d);
+        uint64_t started = ~(uint64_t)0;
+        if (g64_cull) {
+          /* P = G m table cells per axis; the cell of the sub-cell the pixel's wave tile aims sample s at */
+          int entry = g64_cull_cells;
+          if (s < GG) {
+            const int P = (int)(sqrt((double)g64_cull_cells) + 0.5), m = P / G;
+            const int cy = s / G, cx = s % G;
+            const int per_block = 1 << g64_xs, block_w = 8 * per_block;
+            const int tiles_x = ((W + block_w - 1) / block_w) * per_block;
+            const uint32_t c2[4] = {(uint32_t)((y / 8) * tiles_x + (x / block_w) * per_block + x % per_block), (uint32_t)s, 0x51bce110u, 0u};
+            uint32_t r2[4];
+            philox64(c2, key, r2);
+            const uint32_t sxi = sub_bits ? (r2[0] >> (32 - sub_bits)) : 0u, syi = sub_bits ? (r2[1] >> (32 - sub_bits)) : 0u;
+            entry = (cy * m + (int)((syi * (uint32_t)m) >> sub_bits)) * P + cx * m + (int)((sxi * (uint32_t)m) >> sub_bits);
+          }
+          started = g64_cull[((size_t)(y >> 6) * g64_cull_bx + (x >> 6)) * (size_t)(g64_cull_cells + 1) + (size_t)entry];
+        }
         for (int lam = 0; lam < L->n_lambda; lam++)
           for (int q = 0; q < n_pairs; q++) {
+            uint64_t* const c = (q >= 64 || ((started >> q) & 1u)) ? counted : skipped;
             g64_ray r = {o, d, w0, w0, 0, 0};
             c[0]++;
             c[1] += (uint64_t)follow(L, &S, lam, pairs[2 * q], pairs[2 * q + 1], mask, mw, mh, &r);
@@ -401,7 +433,7 @@ void g64_trace(const g64_lens* L, int W, int H, int y0, int y1, int spp, const u
       }
     }
 #pragma omp critical
-    for (int k = 0; k < 8; k++) total[k] += c[k];
+    for (int k = 0; k < 8; k++) total[k] += counted[k];
   }
   if (counters) memcpy(counters, total, sizeof(total));
 }

@@ -399,6 +399,20 @@ void geo_lens_samples(const geo_lens* L, int W, int H, int ns, const uint32_t ke
   }
 }
 
+/* The device's path culling (lens-flare_amd/csrc/lf_cull.hip, lf_get_cull_table): table[block][cell] = mask of the
+ * paths the device STARTS for sample cell `cell` (its pupil stratum s < G*G, else entry `cells`) of the pixels of
+ * sensor block (x >> 6, y >> 6).  With a table installed geo_trace still marches EVERY path -- its pixels are the
+ * full enumeration's, so that equality with the device's pixels proves that nothing the device skipped could
+ * have contributed -- but its counters count only the rays the device starts; culled_lit tallies skipped rays
+ * that did reach the light (must stay 0). */
+static const uint64_t* g_cull = NULL;
+static int g_cull_bx = 0, g_cull_by = 0, g_cull_cells = 0;
+static uint64_t g_culled_lit = 0;
+void geo_set_cull(const uint64_t* table, int blocks_x, int blocks_y, int cells) {
+  g_cull = table; g_cull_bx = blocks_x; g_cull_by = blocks_y; g_cull_cells = cells;
+}
+uint64_t geo_culled_lit(void) { return g_culled_lit; }
+
 /* the fixed-point grid of a launch (lens-flare_amd/csrc/lf_march.hip lf_march_fix_bits, the same double
  * arithmetic): 2^36 unless spp x paths x geom_norm x max_c sum_l (radiance[c] * lambda_rgb[l][c]) x 2^bits would
  * reach 2^62 -- then the largest exponent that keeps the largest possible pixel sum below it */
@@ -428,10 +442,14 @@ void geo_trace(const geo_lens* L, int W, int H, int y0, int y1, int spp, const u
   const int fix_bits = geo_fix_bits(L, D.geom_norm, n_pairs, spp);
   const float fix_scale = ldexpf(1.0f, fix_bits);
   const double inv_fix = ldexp(1.0, -fix_bits);
+  const int GG = strata(spp) * strata(spp);
+  uint64_t culled_lit_total = 0;
 #pragma omp parallel num_threads(n_threads)
   {
-    geo_counters c;
+    geo_counters c, skipped;
     memset(&c, 0, sizeof(c));
+    memset(&skipped, 0, sizeof(skipped));
+    uint64_t culled_lit = 0;
     geo_step seq[3 * GEO_MAX_SURF];
 #pragma omp for schedule(dynamic, 64)
     for (long long p = (long long)y0 * W; p < (long long)y1 * W; p++) {
@@ -442,14 +460,35 @@ void geo_trace(const geo_lens* L, int W, int H, int y0, int y1, int spp, const u
         philox(ctr, key, rnd);
         geo_ray r0;
         start_ray(&D, W, H, x, y, s, strata(spp), key, rnd, &r0);
+        uint64_t started = ~(uint64_t)0;
+        if (g_cull) {
+          /* the table cell of the sub-cell this pixel's wave tile aims sample s at: P = G m cells per axis, m x m
+           * inside the stratum (cx, cy), the one that holds sub-cell (sxi, syi) of start_ray's draw */
+          int entry = g_cull_cells;
+          if (s < GG) {
+            const int G = strata(spp), P = (int)(sqrt((double)g_cull_cells) + 0.5), m = P / G;
+            const int cy = s / G, cx = s - cy * G;
+            int tiles_x = ((W + (8 << g_xs) - 1) >> (3 + g_xs)) << g_xs;
+            int tx = ((x >> (3 + g_xs)) << g_xs) + (x & ((1 << g_xs) - 1));
+            uint32_t c2[4] = {(uint32_t)((y >> 3) * tiles_x + tx), (uint32_t)s, 0x51bce110u, 0u}, r2[4];
+            philox(c2, key, r2);
+            const uint32_t sxi = g_sub_bits ? (r2[0] >> (32 - g_sub_bits)) : 0u, syi = g_sub_bits ? (r2[1] >> (32 - g_sub_bits)) : 0u;
+            entry = (cy * m + (int)((syi * (uint32_t)m) >> g_sub_bits)) * P + cx * m + (int)((sxi * (uint32_t)m) >> g_sub_bits);
+          }
+          started = g_cull[((size_t)(y >> 6) * g_cull_bx + (x >> 6)) * (size_t)(g_cull_cells + 1) + (size_t)entry];
+        }
         for (int l = 0; l < L->n_lambda; l++)
           for (int q = 0; q < n_pairs; q++) {
+            /* a path the device does not start: marched all the same (the pixels are the full enumeration's),
+             * tallied aside */
+            const int on = q >= 64 || ((started >> q) & 1u);
+            geo_counters* const cc = on ? &c : &skipped;
             int n = build_sequence(L->n_surf, pairs[2 * q], pairs[2 * q + 1], seq);
             geo_ray r = r0;
             { const float ns = D.n_start[l]; r.d[0] *= ns; r.d[1] *= ns; r.d[2] *= ns; }   /* K = n d */
             int st = OK_;
             float z_from = D.z_sensor;   /* vertex z of where the ray sits: the sensor, then each interface */
-            c.rays_launched++;
+            cc->rays_launched++;
             for (int e = 0; e < n; e++) {
               int k = seq[e].k;
               float dzv = z_from - D.zv[k];
@@ -462,12 +501,12 @@ void geo_trace(const geo_lens* L, int W, int H, int y0, int y1, int spp, const u
                                  seq[e].forward);
               if (st != OK_) break;
               z_from = D.zv[k];
-              c.surface_events++;
+              cc->surface_events++;
             }
-            if (st == CLIPPED) { c.rays_clipped_stop++; continue; }
-            if (st == VIGNETTED) { c.rays_vignetted++; continue; }
-            if (st == TIR) { c.rays_tir++; continue; }
-            c.rays_reached_scene++;
+            if (st == CLIPPED) { cc->rays_clipped_stop++; continue; }
+            if (st == VIGNETTED) { cc->rays_vignetted++; continue; }
+            if (st == TIR) { cc->rays_tir++; continue; }
+            cc->rays_reached_scene++;
             /* the sun's lobe, DESIGN.md "march arithmetic": candidates are selected on d.s alone
              * against the conservative threshold of geo_derive (1 - d.s cancels: it cannot decide),
              * then 1 - cos(theta) = |d x s|^2 / (|d|^2 |s|^2 + sqrt(|d|^2 |s|^2) d.s), which has no
@@ -488,7 +527,8 @@ void geo_trace(const geo_lens* L, int W, int H, int y0, int y1, int spp, const u
               float om = 1.0f - qq;
               float contrib = (r.wn / r.wd) * (om * om);
               if (contrib > 0.0f) {
-                c.rays_hit_light++;
+                cc->rays_hit_light++;
+                if (!on) culled_lit++;
                 for (int ch = 0; ch < 3; ch++) {
                   float v = contrib * (L->sun_radiance[ch] * L->lambda_rgb[l][ch]);
                   acc[ch] += (uint64_t)(v * fix_scale);
@@ -506,8 +546,10 @@ void geo_trace(const geo_lens* L, int W, int H, int y0, int y1, int spp, const u
       total.rays_clipped_stop += c.rays_clipped_stop; total.rays_vignetted += c.rays_vignetted;
       total.rays_tir += c.rays_tir; total.rays_reached_scene += c.rays_reached_scene;
       total.rays_hit_light += c.rays_hit_light;
+      culled_lit_total += culled_lit;
     }
   }
+  g_culled_lit = culled_lit_total;
   if (cnt) *cnt = total;
 }
 

@@ -265,9 +265,39 @@ def all_pairs(lens, include_primary=True):
     return np.array(out, np.int32)
 
 
+_followed_lf = None        # the device geo_follow_device() follows: its cull table is applied to the counters
+last_culled_lit = 0        # rays the device's table skips that DID reach the light in the last geo_trace (must be 0)
+
+
+def _device_cull(cull, W, H, spp):
+    """cull: None (count every ray), "auto" (the table of the followed device's last trace_ghosts, if it culled)
+    or a table from LensFlare.cull_table().  -> contiguous uint64 array (blocks_y, blocks_x, cells + 1) or None."""
+    if isinstance(cull, str):
+        assert cull == "auto"
+        cull = _followed_lf.cull_table() if _followed_lf is not None and hasattr(_followed_lf, "cull_table") else None
+    if cull is None:
+        return None
+    cull = np.ascontiguousarray(cull, np.uint64)
+    G = int(np.floor(np.sqrt(spp)))
+    while (G + 1) * (G + 1) <= spp:
+        G += 1
+    while G * G > spp:
+        G -= 1
+    want = [((H + 63) // 64, (W + 63) // 64, (G * m) ** 2 + 1) for m in (1, 2, 4)]
+    assert cull.shape in want, f"cull table {cull.shape} is not the one of a {W}x{H} frame at {spp} spp {want}: " \
+                               "the device's last trace_ghosts was another launch"
+    return cull
+
+
 def geo_trace(lens, W, H, y0, y1, spp, key, pairs, include_primary, mask, sun_dir, sun_radiance,
-              sun_angular_radius, n_threads=8, lambda_rgb=None):
+              sun_angular_radius, n_threads=8, lambda_rgb=None, cull="auto"):
+    """-> (ghost H x W x 3, counters).  The PIXELS are always the full enumeration's (every path of every sample
+    is marched); with a cull table (default: the followed device's, geo_follow_device) the COUNTERS count only
+    the rays the device starts -- so `pixels equal and counters equal` says both that the device's arithmetic is
+    the oracle's and that nothing it skipped could have contributed."""
+    global last_culled_lit
     L = geo_lens(lens, sun_dir, sun_radiance, sun_angular_radius, lambda_rgb)
+    table = _device_cull(cull, W, H, spp)
     if pairs is None:
         pairs = all_pairs(lens, include_primary)
     else:
@@ -279,9 +309,18 @@ def geo_trace(lens, W, H, y0, y1, spp, key, pairs, include_primary, mask, sun_di
     ghost = np.zeros((H, W, 3), np.float64)
     cnt = GeoCounters()
     k = (C.c_uint32 * 2)(key & 0xffffffff, (key >> 32) & 0xffffffff)
-    lib().geo_trace(C.byref(L), W, H, y0, y1, spp, k, _p(pairs, C.c_int), len(pairs),
-                    _p(mask, C.c_float), mask.shape[1], mask.shape[0], _p(ghost, C.c_double),
-                    C.byref(cnt), n_threads)
+    lib().geo_culled_lit.restype = C.c_uint64
+    if table is not None:
+        lib().geo_set_cull(_p(table, C.c_uint64), table.shape[1], table.shape[0], table.shape[2] - 1)
+    try:
+        lib().geo_trace(C.byref(L), W, H, y0, y1, spp, k, _p(pairs, C.c_int), len(pairs),
+                        _p(mask, C.c_float), mask.shape[1], mask.shape[0], _p(ghost, C.c_double),
+                        C.byref(cnt), n_threads)
+    finally:
+        lib().geo_set_cull(None, 0, 0, 0)
+    last_culled_lit = int(lib().geo_culled_lit())
+    if last_culled_lit:
+        print(f"lfo.geo_trace: {last_culled_lit} rays that the device's cull table skips reached the light")
     return ghost, {n: int(getattr(cnt, n)) for n, _ in cnt._fields_}
 
 
@@ -384,10 +423,13 @@ def geo_follow_device(lf):
     """Make the float32 oracle reproduce the device's two non-IEEE instructions -- v_sqrt_f32 and v_rcp_f32 --
     through their measured deviation tables (lf.native_sqrt / lf.native_rcp); None: back to the correctly
     rounded operations.  lf may also be a (sqrt table, rcp table) pair measured earlier."""
+    global _followed_lf
     if lf is None:
         geo_set_sqrt_table(None)
         geo_set_rcp_table(None)
+        _followed_lf = None
         return None
+    _followed_lf = None if isinstance(lf, tuple) else lf     # (its cull table is read when geo_trace runs)
     tabs = lf if isinstance(lf, tuple) else (sqrt_deviation_table(lf.native_sqrt), rcp_deviation_table(lf.native_rcp))
     geo_set_sqrt_table(tabs[0])
     geo_set_rcp_table(tabs[1])
@@ -504,10 +546,12 @@ G64_COUNTERS = ("rays_launched", "surface_events", "rays_clipped_stop", "rays_vi
 
 
 def g64_trace(lens, W, H, y0, y1, spp, key, pairs, include_primary, mask, sun_dir, sun_radiance,
-              sun_angular_radius, n_threads=8, lambda_rgb=None, sub_bits=6, **eps):
+              sun_angular_radius, n_threads=8, lambda_rgb=None, sub_bits=6, cull=None, **eps):
     """-> (image, frag, counters): image / frag are H x W x 3; a faithful float32 evaluation of the
-    same estimator satisfies |pixel32 - image| <= tol * image + frag (see lf_geo_f64.c)."""
+    same estimator satisfies |pixel32 - image| <= tol * image + frag (see lf_geo_f64.c).  cull: a table from
+    LensFlare.cull_table() -- the image stays the full enumeration's, the counters count the rays the device starts."""
     L = g64_lens(lens, sun_dir, sun_radiance, sun_angular_radius, lambda_rgb, **eps)
+    table = _device_cull(cull, W, H, spp) if cull is not None else None
     if pairs is None:
         pairs = all_pairs(lens, include_primary)
     else:
@@ -520,9 +564,14 @@ def g64_trace(lens, W, H, y0, y1, spp, key, pairs, include_primary, mask, sun_di
     frag = np.zeros((H, W, 3), np.float64)
     cnt = (C.c_uint64 * 8)()
     k = (C.c_uint32 * 2)(key & 0xffffffff, (key >> 32) & 0xffffffff)
-    lib().g64_trace(C.byref(L), W, H, y0, y1, spp, k, int(sub_bits), _p(pairs, C.c_int), len(pairs),
-                    _p(mask, C.c_float), mask.shape[1], mask.shape[0], _p(image, C.c_double),
-                    _p(frag, C.c_double), cnt, n_threads)
+    if table is not None:
+        lib().g64_set_cull(_p(table, C.c_uint64), table.shape[1], table.shape[0], table.shape[2] - 1)
+    try:
+        lib().g64_trace(C.byref(L), W, H, y0, y1, spp, k, int(sub_bits), _p(pairs, C.c_int), len(pairs),
+                        _p(mask, C.c_float), mask.shape[1], mask.shape[0], _p(image, C.c_double),
+                        _p(frag, C.c_double), cnt, n_threads)
+    finally:
+        lib().g64_set_cull(None, 0, 0, 0)
     return image, frag, dict(zip(G64_COUNTERS, (int(v) for v in cnt)))
 
 

@@ -11,7 +11,7 @@ OUT=$PKG/build_ab/$NAME
 mkdir -p $OUT
 FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=off -fhip-fp32-correctly-rounded-divide-sqrt -Wall -Wno-unused-function -mllvm -structurizecfg-skip-uniform-regions -fno-slp-vectorize -I$PKG/../include -I$PKG/csrc"
 OBJS=""
-for f in csrc/lf_api.hip csrc/lf_flare_kernels.hip csrc/lf_march.hip csrc/lf_scene.hip csrc/lf_lens_camera.hip csrc/lf_group.hip; do
+for f in csrc/lf_api.hip csrc/lf_flare_kernels.hip csrc/lf_march.hip csrc/lf_cull.hip csrc/lf_scene.hip csrc/lf_lens_camera.hip csrc/lf_group.hip; do
   b=$(basename $f .hip)
   if [[ " $FILES " == *" $f "* ]]; then
     /opt/rocm/bin/hipcc $FLAGS $EXTRA -c $PKG/$f -o $OUT/$b.o
