@@ -443,8 +443,10 @@ def main():
             ok, why = True, ""
             # ncclCommInitRank blocks on the host until every peer has called it: under the same deadline
             # as the first exchange (a helper thread that is abandoned, never a re-exec)
+            # (on expiry the context is told that the blocked call must publish nothing when it comes back: lf_comm_poison)
             done, err = sharding.call_with_deadline(lambda: lf.comm_init_rank(world, rank, box[0]),
-                                                    float(os.environ.get("LF_BENCH_COMM_TIMEOUT", "120")))
+                                                    float(os.environ.get("LF_BENCH_COMM_TIMEOUT", "120")),
+                                                    on_expire=lf.comm_poison)
             if not done:
                 ok, why = False, "ncclCommInitRank did not return within the deadline (a peer never joined)"
             elif err is not None:
@@ -453,7 +455,7 @@ def main():
         if all_ok:
             all_ok, bad = sharding.first_exchange(
                 dist, lambda: lf.comm_gather(pkg.SAMPLE_BUFFER), lf.comm_test,
-                timeout_s=float(os.environ.get("LF_BENCH_COMM_TIMEOUT", "120")))
+                timeout_s=float(os.environ.get("LF_BENCH_COMM_TIMEOUT", "120")), on_expire=lf.comm_poison)
         if not all_ok:
             try:
                 lf.comm_abort()

@@ -340,6 +340,15 @@ lf_status lf_comm_abort(lf_ctx* ctx);
  * 32: as floats -- half the bytes on the wire (SURVEY 8e budgets f32: 12.4 MB per rank at 4K), the
  * rows a rank receives are rounded to float, its own stay as rendered.  Same value on every rank. */
 lf_status lf_comm_set_exchange_precision(lf_ctx* ctx, int bits);
+/* Giving up on a communicator call that is BLOCKED in another host thread (ncclCommInitRank and a communicator's
+ * first collective block until every peer has joined; a peer that died never does).  The thread that waited for
+ * the deadline calls lf_comm_poison: from then on the blocked call -- should it ever return -- publishes nothing
+ * into the context (a communicator that arrives late is aborted where it stands), every lf_comm_* call on the
+ * context returns LF_ERR_STATE, lf_comm_abort still ends what can be ended, and lf_destroy returns LF_ERR_STATE
+ * WITHOUT freeing anything while the blocked call has not come back (the context is leaked on purpose: the
+ * blocked thread still stands on it).  There is no way back: the process falls back to another exchange or exits. */
+lf_status lf_comm_poison(lf_ctx* ctx);
+int lf_comm_is_poisoned(lf_ctx* ctx);
 /* One process, n devices (a C++ host such as the CGL application): one context + stream per device
  * and one communicator over them (ncclCommInitAll).  Set-up calls go to every context
  * (lf_group_ctx); lf_group_set_frame = lf_set_frame + the round-robin deal on every context;

@@ -45,7 +45,7 @@ ABI_SYMBOLS = [
     "lf_get_scene_counters", "lf_reset_scene_counters", "lf_set_flare_arithmetic",
     "lf_comm_get_unique_id", "lf_comm_init_rank", "lf_comm_gather", "lf_comm_gather_async", "lf_comm_wait",
     "lf_comm_destroy", "lf_comm_available", "lf_comm_info", "lf_comm_test", "lf_comm_abort",
-    "lf_comm_set_exchange_precision", "lf_comm_exchange_plan",
+    "lf_comm_set_exchange_precision", "lf_comm_poison", "lf_comm_is_poisoned", "lf_comm_exchange_plan",
     "lf_group_create", "lf_group_destroy", "lf_group_size", "lf_group_ctx", "lf_group_last_error",
     "lf_group_set_frame", "lf_group_for_each", "lf_group_gather",
 ]
@@ -308,8 +308,19 @@ class LensFlare:
 
     def close(self):
         if self.ctx and self._owned:
-            self.lib.lf_destroy(self.ctx)
+            # (LF_ERR_STATE: a communicator call this host gave up on -- comm_poison -- is still blocked in another
+            # thread and stands on the context: the library leaks it on purpose rather than free it under that thread)
+            self.leaked = self.lib.lf_destroy(self.ctx) != 0
         self.ctx = C.c_void_p()
+
+    def comm_poison(self):
+        """Give up on a communicator call that is blocked in another thread (sharding.call_with_deadline's on_expire):
+        whatever that call still does, it publishes nothing into this context any more; every later comm_* call is
+        refused; close() leaks the context while the call has not come back."""
+        self.lib.lf_comm_poison(self.ctx)
+
+    def comm_is_poisoned(self):
+        return bool(self.lib.lf_comm_is_poisoned(self.ctx))
 
     # ---- multi-GPU, one process per GPU
     def comm_init_rank(self, nranks, rank, unique_id):

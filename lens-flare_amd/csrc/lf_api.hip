@@ -215,6 +215,9 @@ lf_status lf_create(lf_ctx** out, int device) {
 
 lf_status lf_destroy(lf_ctx* ctx) {
   if (!ctx) return LF_ERR_INVALID;
+  // a communicator call the host gave up on (lf_comm_poison) may still be blocked in another thread, standing on
+  // this context: nothing is freed then -- the context is LEAKED on purpose (the process is on its way out anyway)
+  if (ctx->comm_poisoned.load() && ctx->comm_busy.load() > 0) return LF_ERR_STATE;
   (void)hipSetDevice(ctx->device);
   (void)hipDeviceSynchronize();
   (void)lf_comm_destroy(ctx);

@@ -103,9 +103,10 @@ __global__ __launch_bounds__(256) void k_cull_level(const LfLensDev* __restrict_
   const float inf = __int_as_float(0x7f800000);
   const int lane = (int)(threadIdx.x & 63u);
   bool enabled = false;
+  bool firm = false;       // ruled out with room to spare: the other end of the spectrum cannot bring the box back
   int why_last = 0;
   for (int li = 0; li < a.n_test; li++) {
-    if (__ballot(valid && !enabled) == 0ull) break;
+    if (__ballot(valid && !enabled && !firm) == 0ull) break;
     const int l = a.lam[li];
     const int g = l / a.march_k, j = l - g * a.march_k;
     const LfProgRow* const recs = rec_table + (size_t)g * (size_t)a.prog_recs;
@@ -127,7 +128,7 @@ __global__ __launch_bounds__(256) void k_cull_level(const LfLensDev* __restrict_
     // that has lost samples is PARTIAL: what is left of it lies next to a region where the path ends, the map
     // is steep there, and its footprints are inflated twice as much.
     unsigned live = 0x1fffu;
-    bool culled = !valid || enabled, keep = false, partial = false;
+    bool culled = !valid || enabled || firm, keep = false, partial = false;
     int why = 0;
     // Footprint of the box in a plane (an interface's, or direction space).  With all 13 samples in use the
     // image of the box is modelled as a ZONOTOPE: centre c + the four generators g1, g2 (half the cell along the
@@ -137,7 +138,10 @@ __global__ __launch_bounds__(256) void k_cull_level(const LfLensDev* __restrict_
     // a disc needs only that -- far tighter than a ball around c for the elongated footprints of defocused ghosts.
     // A box that has lost samples falls back to a ball around a sample still in use, inflated twice as much.
     struct Foot { float cx, cy, g1x, g1y, g2x, g2y, gxx, gxy, gyx, gyy, slack, ball; bool zono; };
-    auto footprint = [&](const float* vx, const float* vy, unsigned use, float eps) {
+    auto footprint = [&](bool dirs, unsigned use, float eps) {
+      float vx[kCullSamples], vy[kCullSamples];
+#pragma unroll
+      for (int t = 0; t < kCullSamples; t++) { vx[t] = dirs ? r[t].dx : r[t].px; vy[t] = dirs ? r[t].dy : r[t].py; }
       Foot f;
       f.zono = use == 0x1fffu;
       const int ref = (use & 0x10u) ? 4 : (use ? __ffs((int)use) - 1 : 4);
@@ -188,10 +192,10 @@ __global__ __launch_bounds__(256) void k_cull_level(const LfLensDev* __restrict_
       const float rn2 = j == 0 ? wr.rn2[0] : j == 1 ? wr.rn2[1] : wr.rn2[2];
       const float delta = j == 0 ? wr.delta[0] : j == 1 ? wr.delta[1] : wr.delta[2];
       unsigned hit = 0u, okm = 0u;
-      float vx[kCullSamples], vy[kCullSamples];
 #pragma unroll
       for (int t = 0; t < kCullSamples; t++) {
         bool ok;
+        r[t].r2 = fmaf(r[t].px, r[t].px, r[t].py * r[t].py);   // (recomputed, not carried: 13 registers less)
         if (kind & LF_EV_STOP) {
           const float tt = -(r[t].hz + wr.dzv) * lf_rcp(r[t].dz);
           const float hx = fmaf(tt, r[t].dx, r[t].px), hy = fmaf(tt, r[t].dy, r[t].py);
@@ -203,12 +207,11 @@ __global__ __launch_bounds__(256) void k_cull_level(const LfLensDev* __restrict_
                                                   (kind & LF_EV_REFLECT) != 0, (kind & LF_EV_FLAT) != 0, wr.sgn, geom_ok);
           ok = ((m >> lane) & 1ull) != 0ull;
         }
-        vx[t] = r[t].px; vy[t] = r[t].py;
-        if (r[t].r2 == r[t].r2) hit |= 1u << t;     // (a totally reflected ray did reach the interface)
+        if (r[t].px == r[t].px) hit |= 1u << t;     // (a totally reflected ray did reach the interface)
         if (ok) okm |= 1u << t;
       }
       hit &= live;
-      const Foot f = footprint(vx, vy, hit, 1e-3f);
+      const Foot f = footprint(false, hit, 1e-3f);
       live &= okm;
       if (!culled && !keep) {
         if (hit == 0u) { culled = true; why = 4; }             // no sample reaches the interface: nor does the box
@@ -216,7 +219,11 @@ __global__ __launch_bounds__(256) void k_cull_level(const LfLensDev* __restrict_
           const float cx = f.cx, cy = f.cy;
           const float cr = lf_sqrt(fmaf(cx, cx, cy * cy));
           const float icr = cr > 0.0f ? lf_rcp(cr) : 0.0f;
-          if (cr - extent(f, cx * icr, cy * icr) > lf_sqrt(wr.h2)) { culled = true; why = 4; }   // wholly outside the clear aperture
+          const float ext = extent(f, cx * icr, cy * icr), hh = lf_sqrt(wr.h2);
+          if (cr - ext > hh) {                                   // wholly outside the clear aperture
+            culled = true; why = 4;
+            firm = cr - ext - hh > fmaf(0.25f, ext, 0.03f * hh);
+          }
           else if (kind & LF_EV_STOP) {
             // ... or on closed cells of the mask: texel coordinate = (h / stop_h + 1) / 2 of the mask's width
             const float s = 0.5f * (float)kCullOcc;
@@ -242,15 +249,15 @@ __global__ __launch_bounds__(256) void k_cull_level(const LfLensDev* __restrict_
     }
     if (!culled && !keep) {
       // the path is complete: where can the box point?  (K is the unit direction in air again)
-      float vx[kCullSamples], vy[kCullSamples];
-#pragma unroll
-      for (int t = 0; t < kCullSamples; t++) { vx[t] = r[t].dx; vy[t] = r[t].dy; }
-      const Foot f = footprint(vx, vy, live, 2e-5f);
+      const Foot f = footprint(true, live, 2e-5f);
       const float ex = a.sx - f.cx, ey = a.sy - f.cy;
       const float dist = lf_sqrt(fmaf(ex, ex, ey * ey));
       const float id = dist > 0.0f ? lf_rcp(dist) : 0.0f;
-      if (dist - extent(f, ex * id, ey * id) > a.rho) { culled = true; why = 6; }
-      else { keep = true; why = partial ? 1 : 3; }
+      const float ext = extent(f, ex * id, ey * id);
+      if (dist - ext > a.rho) {
+        culled = true; why = 6;
+        firm = dist - ext - a.rho > 0.25f * (ext + a.rho);
+      } else { keep = true; why = partial ? 1 : 3; }
     }
     if (stats && valid && why) atomicAdd(&stats[why + 8 * li], 1ull);
     if (valid && keep) { enabled = true; why_last = why; }
@@ -644,6 +651,10 @@ lf_status lfk_cull_prepass(lf_ctx* ctx, int G) {
     // the kernel reads its input with the stride it was written with and writes with the new one
     CullLevelArgs k = a;
     k.list_stride = a.last ? in_stride : out_stride;
+    if (!a.last && !std::getenv("LF_CULL_ALL_LAMBDA")) {
+      // coarse boxes: their inflation dwarfs the dispersion -- the middle of the spectrum alone
+      k.n_test = 1; k.lam[0] = (L.n_lambda - 1) / 2;
+    }
     // (two strides are needed when reading AND writing: the input's travels in `items_stride`)
     const dim3 grid((unsigned)((n_items + 255) / 256), (unsigned)a.n_paths);
     hipLaunchKernelGGL(k_cull_level, grid, dim3(256), 0, ctx->stream, ctx->lens_dev, ctx->pairs_dev,

@@ -228,8 +228,18 @@ lf_status lf_comm_get_unique_id(unsigned char id[LF_COMM_ID_BYTES]) {
   return LF_OK;
 }
 
+// (a call that may block: counted while inside; see lf_ctx::comm_poisoned)
+struct CommBusy {
+  lf_ctx* c;
+  explicit CommBusy(lf_ctx* ctx) : c(ctx) { c->comm_busy.fetch_add(1); }
+  ~CommBusy() { c->comm_busy.fetch_sub(1); }
+};
+#define LF_COMM_REFUSE_POISONED(ctx)                                                                             \
+  do { if ((ctx)->comm_poisoned.load()) return LF_ERR_STATE; } while (0)   /* (no lf_fail: the error string is the blocked thread's too) */
+
 lf_status lf_comm_init_rank(lf_ctx* ctx, int nranks, int rank, const unsigned char id[LF_COMM_ID_BYTES]) {
   if (!ctx || !id || nranks < 1 || rank < 0 || rank >= nranks) return LF_ERR_INVALID;
+  LF_COMM_REFUSE_POISONED(ctx);
   if (ctx->W == 0) return lf_fail(ctx, LF_ERR_STATE, "lf_comm_init_rank before lf_set_frame");
   Rccl* r = rccl();
   if (!r) return lf_fail(ctx, LF_ERR_STATE, "RCCL is not available: librccl.so.1 could not be loaded");
@@ -237,15 +247,37 @@ lf_status lf_comm_init_rank(lf_ctx* ctx, int nranks, int rank, const unsigned ch
   LF_HIP(ctx, hipSetDevice(ctx->device));
   ncclUniqueId u;
   std::memcpy(u.internal, id, LF_COMM_ID_BYTES);
+  // the blocking call works on state THIS call owns; the context sees the communicator only if nobody has
+  // given up on the call in the meantime
   ncclComm_t c = nullptr;
-  const ncclResult_t rc = r->CommInitRank(&c, nranks, u, rank);
+  ncclResult_t rc;
+  {
+    CommBusy busy(ctx);
+    rc = r->CommInitRank(&c, nranks, u, rank);
+    std::lock_guard<std::mutex> lock(ctx->comm_mu);
+    if (ctx->comm_poisoned.load()) {
+      if (rc == ncclSuccess && c) (void)r->CommAbort(c);   // it arrived late: never published, never leaked
+      return LF_ERR_STATE;
+    }
+    if (rc == ncclSuccess) { ctx->comm = c; ctx->comm_nranks = nranks; ctx->comm_rank = rank; }
+  }
   if (rc != ncclSuccess) return lf_fail(ctx, LF_ERR_HIP, std::string("ncclCommInitRank: ") + r->GetErrorString(rc));
-  ctx->comm = c; ctx->comm_nranks = nranks; ctx->comm_rank = rank;
   return lf_set_row_interleave(ctx, rank, nranks);   // the deal: tile row t belongs to rank t % nranks
 }
 
+lf_status lf_comm_poison(lf_ctx* ctx) {
+  if (!ctx) return LF_ERR_INVALID;
+  std::lock_guard<std::mutex> lock(ctx->comm_mu);
+  ctx->comm_poisoned.store(true);
+  return LF_OK;
+}
+
+int lf_comm_is_poisoned(lf_ctx* ctx) { return ctx && ctx->comm_poisoned.load() ? 1 : 0; }
+
 lf_status lf_comm_gather(lf_ctx* ctx, int which) {
   if (!ctx) return LF_ERR_INVALID;
+  LF_COMM_REFUSE_POISONED(ctx);
+  CommBusy busy(ctx);
   if (!ctx->comm) return lf_fail(ctx, LF_ERR_STATE, "lf_comm_gather before lf_comm_init_rank");
   const int world = ctx->comm_nranks, rank = ctx->comm_rank;
   lf_status st = check_gather_args(ctx, which, world);
@@ -260,6 +292,7 @@ lf_status lf_comm_gather(lf_ctx* ctx, int which) {
   if ((st = launch_pack(ctx, which, rank, world)) != LF_OK) return st;
   const ExchangePlan x = exchange_plan(ctx, world);
   const ncclResult_t rc = r->AllGather(x.send, x.recv, x.count, x.type, (ncclComm_t)ctx->comm, ctx->stream);
+  LF_COMM_REFUSE_POISONED(ctx);      // the host gave up on this call while it was blocked: touch nothing any more
   if (rc != ncclSuccess) return lf_fail(ctx, LF_ERR_HIP, std::string("ncclAllGather: ") + r->GetErrorString(rc));
   st = launch_unpack(ctx, which, rank, world);
   lf_timing_end(ctx, LFK_EXCHANGE, ev);
@@ -274,6 +307,8 @@ lf_status lf_comm_gather(lf_ctx* ctx, int which) {
 // the two streams again.
 lf_status lf_comm_gather_async(lf_ctx* ctx, int which) {
   if (!ctx) return LF_ERR_INVALID;
+  LF_COMM_REFUSE_POISONED(ctx);
+  CommBusy busy(ctx);
   if (!ctx->comm) return lf_fail(ctx, LF_ERR_STATE, "lf_comm_gather_async before lf_comm_init_rank");
   const int world = ctx->comm_nranks, rank = ctx->comm_rank;
   lf_status st = check_gather_args(ctx, which, world);
@@ -297,6 +332,7 @@ lf_status lf_comm_gather_async(lf_ctx* ctx, int which) {
   LF_HIP(ctx, hipEventRecord(ctx->comm_ev_pack, ctx->comm_stream));
   LF_HIP(ctx, hipStreamWaitEvent(ctx->stream, ctx->comm_ev_pack, 0));
   const ncclResult_t rc = r->AllGather(x.send, x.recv, x.count, x.type, (ncclComm_t)ctx->comm, ctx->comm_stream);
+  LF_COMM_REFUSE_POISONED(ctx);
   if (rc != ncclSuccess) return lf_fail(ctx, LF_ERR_HIP, std::string("ncclAllGather: ") + r->GetErrorString(rc));
   if ((st = launch_unpack(ctx, which, rank, world, ctx->comm_stream)) != LF_OK) return st;
   lf_timing_end(ctx, LFK_EXCHANGE, ev, ctx->comm_stream);
@@ -354,12 +390,20 @@ lf_status lf_comm_test(lf_ctx* ctx, int* done) {
 
 lf_status lf_comm_abort(lf_ctx* ctx) {
   if (!ctx) return LF_ERR_INVALID;
-  if (!ctx->comm) return LF_OK;
+  void* comm = nullptr;
+  {
+    // (ncclCommAbort is what unblocks a collective stuck in another thread: it may run beside a blocked call, but
+    // the communicator is taken out of the context under the lock, so that nobody publishes or reads it half-way)
+    std::lock_guard<std::mutex> lock(ctx->comm_mu);
+    comm = ctx->comm;
+    ctx->comm = nullptr; ctx->comm_nranks = 1; ctx->comm_rank = 0;
+    ctx->comm_pending = false;
+  }
+  if (!comm) return LF_OK;
   Rccl* r = rccl();
   (void)hipSetDevice(ctx->device);
-  const ncclResult_t rc = r->CommAbort((ncclComm_t)ctx->comm);   // ends the collectives in flight on this rank
-  ctx->comm = nullptr; ctx->comm_nranks = 1; ctx->comm_rank = 0;
-  ctx->comm_pending = false;
+  const ncclResult_t rc = r->CommAbort((ncclComm_t)comm);   // ends the collectives in flight on this rank
+  if (ctx->comm_busy.load() > 0) return LF_OK;   // a blocked call is on its way out: the streams are its to leave
   if (ctx->comm_stream) (void)hipStreamSynchronize(ctx->comm_stream);
   (void)hipStreamSynchronize(ctx->stream);
   if (rc != ncclSuccess) return lf_fail(ctx, LF_ERR_HIP, std::string("ncclCommAbort: ") + r->GetErrorString(rc));

@@ -4,7 +4,9 @@
 
 #include <hip/hip_runtime.h>
 
+#include <atomic>
 #include <cstdint>
+#include <mutex>
 #include <string>
 #include <vector>
 
@@ -393,6 +395,14 @@ struct lf_ctx {
   hipEvent_t comm_ev_main = nullptr, comm_ev_pack = nullptr, comm_ev_done = nullptr;
   bool comm_pending = false;     // an exchange on comm_stream the main stream has not yet waited for
   bool comm_f32 = false;         // lf_comm_set_exchange_precision(32): the tile rows travel as floats
+  // A communicator call can block the calling HOST thread for good (ncclCommInitRank, the first collective's
+  // enqueue: a peer that never joins).  A host that gives up on such a call from another thread says so with
+  // lf_comm_poison: from then on the blocked call -- should it ever return -- publishes NOTHING into the context
+  // (a communicator that arrives late is aborted where it stands), every lf_comm_* call is refused, and lf_destroy
+  // leaks the context instead of freeing what the blocked thread still stands on.
+  std::atomic<int> comm_busy{0};         // threads inside a call that may block
+  std::atomic<bool> comm_poisoned{false};
+  std::mutex comm_mu;                    // publication of comm / comm_nranks / comm_rank / comm_pending
 
   bool timing = false;
   std::vector<LfTimedLaunch> timed;       // launches not folded yet (bounded, see lf_api.hip)

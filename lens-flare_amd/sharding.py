@@ -140,32 +140,48 @@ def agree(dist, ok, why=""):
     return not bad, bad
 
 
-def call_with_deadline(fn, timeout_s):
+def call_with_deadline(fn, timeout_s, on_expire=None):
     """Run a HOST-BLOCKING call (ncclCommInitRank, or the first collective on a fresh communicator, whose
     transport set-up blocks the calling thread until every peer has joined) in a helper thread and wait for
     it at most timeout_s.  Returns (done, error): (True, None) when fn returned, (True, exception) when it
     raised, (False, None) when it is still blocked -- the thread is then abandoned (a daemon: it cannot keep
     the process alive) and the caller must treat the communicator as lost (lf_comm_abort, fall back or
-    exit).  Never re-executes anything: a process that has touched the GPU must not exec."""
+    exit).  Never re-executes anything: a process that has touched the GPU must not exec.
+
+    The abandoned thread is still INSIDE the call and may come back at any later time.  on_expire (the C ABI's
+    lf_comm_poison: LensFlare.comm_poison) runs before this function reports the expiry and tells the callee's
+    side that whatever the call still produces must not be published: a communicator that arrives late is
+    aborted where it stands, the context is leaked rather than freed under the blocked thread.  On this side
+    nothing the thread returns or raises after the deadline is looked at: its result box is dropped."""
     import threading
     box = {}
+    gate = threading.Lock()       # the verdict: whoever takes it first decides whether the result counts
+    state = {"expired": False}
 
     def run():
         try:
             fn()
-            box["err"] = None
+            err = None
         except BaseException as e:  # noqa: BLE001 -- handed to the caller, whatever it is
-            box["err"] = e
+            err = e
+        with gate:
+            if not state["expired"]:
+                box["err"] = err
+                box["done"] = True
 
     t = threading.Thread(target=run, daemon=True, name="lf-bringup")
     t.start()
     t.join(timeout_s)
-    if t.is_alive():
-        return False, None
-    return True, box.get("err")
+    with gate:
+        if box.get("done"):
+            return True, box.get("err")
+        state["expired"] = True
+    if on_expire is not None:
+        on_expire()
+    return False, None
 
 
-def first_exchange(dist, enqueue, test, timeout_s=120.0, poll_s=0.01, clock=None, sleep=None):
+def first_exchange(dist, enqueue, test, timeout_s=120.0, poll_s=0.01, clock=None, sleep=None, on_expire=None):
     """Run the first exchange of a fresh communicator so that NO rank can hang: `enqueue()` queues it
     (may raise, may block on the host: it runs under the deadline in a helper thread), `test()` says
     whether it has completed on the device (non-blocking).
@@ -179,7 +195,7 @@ def first_exchange(dist, enqueue, test, timeout_s=120.0, poll_s=0.01, clock=None
     try:
         # enqueue() itself may block on the HOST: the first ncclAllGather of a communicator connects its
         # channels in the calling thread and waits there for every peer.  Same deadline.
-        done, err = call_with_deadline(enqueue, timeout_s)
+        done, err = call_with_deadline(enqueue, timeout_s, on_expire)
         if not done:
             raise TimeoutError(f"enqueueing the first exchange blocked for more than {timeout_s:g} s (a peer never joined)")
         if err is not None:

@@ -326,3 +326,31 @@ def test_eight_ranks_at_bench_sizes(pkg, W, H, spp, bits):
             total[k] = total.get(k, 0) + v
     assert total == want_cnt
     grp.close()
+
+
+def test_a_poisoned_context_refuses_communicator_calls_and_still_renders(pkg):
+    """lf_comm_poison (what a host calls when it gives up on a bring-up call blocked in another thread):
+    every lf_comm_* call is refused afterwards -- nothing a late-returning call produces can be published -- the
+    rest of the context works, and with no call left inside lf_destroy frees it normally."""
+    lens = pkg.load_lens_file("dgauss11.lens")
+    mask = load_texels("pentbig500_14.png")
+    lf = pkg.LensFlare(0)
+    lf.set_frame(64, 32)
+    _setup(pkg, lf, lens, mask)
+    _frame(lf, 4, 5)
+    before = lf.read_buffer(pkg.SAMPLE_BUFFER)
+    uid = pkg.comm_unique_id()
+    assert not lf.comm_is_poisoned()
+    lf.comm_poison()
+    assert lf.comm_is_poisoned()
+    for call in (lambda: lf.comm_init_rank(1, 0, uid), lambda: lf.comm_gather(pkg.SAMPLE_BUFFER),
+                 lambda: lf.comm_gather_async(pkg.SAMPLE_BUFFER)):
+        with pytest.raises(pkg.LensFlareError) as e:
+            call()
+        assert e.value.status == 4          # LF_ERR_STATE
+    assert lf.comm_info() == (1, 0)         # no communicator was published
+    lf.comm_abort()                         # still allowed, nothing to end
+    _frame(lf, 4, 5)
+    assert np.array_equal(lf.read_buffer(pkg.SAMPLE_BUFFER), before)
+    lf.close()
+    assert getattr(lf, "leaked", None) is False     # no call was left inside: freed

@@ -234,3 +234,52 @@ def test_bench_refuses_a_rank_count_that_disagrees_with_gpus():
     p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1"], env=env,
                        capture_output=True, text=True, timeout=300)
     assert p.returncode != 0 and "WORLD_SIZE=1" in p.stderr
+
+
+# ---- a blocked bring-up call that comes back AFTER the verdict ---------------------------------
+def test_a_call_that_returns_after_the_deadline_publishes_nothing():
+    """call_with_deadline gives up on a blocked call, tells the callee's side (on_expire = lf_comm_poison) BEFORE it
+    reports the expiry, and ignores whatever the call returns or raises later: a late return must not look like a
+    success to anybody."""
+    import threading
+    import time
+    sharding = _sharding()
+    release, came_back = threading.Event(), threading.Event()
+    log = []
+
+    class FakeCtx:                       # the protocol of lf_comm_init_rank / lf_comm_poison (lf_group.hip)
+        def __init__(self):
+            self.mu, self.poisoned, self.comm = threading.Lock(), False, None
+
+        def init_rank(self):
+            release.wait()               # ncclCommInitRank blocked on a peer that never joined ... until much later
+            with self.mu:
+                if self.poisoned:
+                    log.append("late communicator aborted, not published")
+                else:
+                    self.comm = "communicator"
+            came_back.set()
+
+        def poison(self):
+            with self.mu:
+                self.poisoned = True
+            log.append("poisoned")
+
+    ctx = FakeCtx()
+    t0 = time.monotonic()
+    done, err = sharding.call_with_deadline(ctx.init_rank, 0.2, on_expire=ctx.poison)
+    assert (done, err) == (False, None) and time.monotonic() - t0 < 5.0
+    assert log == ["poisoned"]           # the callee knew before the caller went on
+    # ... the caller takes its verdict, aborts, falls back; THEN the blocked call returns
+    release.set()
+    assert came_back.wait(5.0)
+    assert ctx.comm is None and log == ["poisoned", "late communicator aborted, not published"]
+    # a call that makes the deadline is reported as before, and on_expire stays out of it
+    calls = []
+    assert sharding.call_with_deadline(lambda: calls.append(1), 5.0, on_expire=lambda: calls.append("expired")) == (True, None)
+    assert calls == [1]
+    boom = RuntimeError("x")
+
+    def raises():
+        raise boom
+    assert sharding.call_with_deadline(raises, 5.0) == (True, boom)
