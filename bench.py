@@ -74,7 +74,8 @@ def every_event_weighted():
     except Exception:  # noqa: BLE001
         return None
 TILE_ROWS = 8   # the march kernel's sensor tile is 8x8 pixels
-PMC_FILES = [os.path.join(ROOT, "profiles", n) for n in ("r04_march_pmc.json", "r03_march_pmc.json", "r02_march_pmc.json")]   # newest first
+PMC_FILES = [os.path.join(ROOT, "profiles", n) for n in ("r05_march_pmc.json", "r04_march_pmc.json", "r03_march_pmc.json", "r02_march_pmc.json")]   # newest first
+R04_C3_MS = 105.22        # BENCH_r04.json: the c3 frame of round 4 (every sample marches every path), driver-timed
 
 # BASELINE.json configs[1..4]; configs[3] / [4] are 8-GPU jobs there, here one GPU's whole frame
 CONFIGS = {
@@ -141,7 +142,8 @@ def source_sha():
     """Identity of the shipped march kernel: the PMC-derived figures are only quoted as this
     binary's when the profile in profiles/ was taken from the same sources and compile flags."""
     h = hashlib.sha256()
-    for f in ("lens-flare_amd/csrc/lf_march.hip", "lens-flare_amd/csrc/lf_march_events.h", "lens-flare_amd/csrc/lf_internal.h"):
+    for f in ("lens-flare_amd/csrc/lf_march.hip", "lens-flare_amd/csrc/lf_cull.hip", "lens-flare_amd/csrc/lf_march_common.h",
+              "lens-flare_amd/csrc/lf_march_events.h", "lens-flare_amd/csrc/lf_internal.h"):
         h.update(open(os.path.join(ROOT, f), "rb").read())
     mk = open(os.path.join(ROOT, "lens-flare_amd", "Makefile")).read()
     h.update(mk[mk.index("FLAGS  :="):mk.index("SRCS   :=")].encode())
@@ -373,6 +375,12 @@ def main():
     if os.environ.get("LF_BENCH_SUBCELL_BITS"):
         lf.set_pupil_subcells(int(os.environ["LF_BENCH_SUBCELL_BITS"]))
     lf.set_jitter_counter(0x1e45f1a4e)
+    # Path culling (lf_cull.hip): the march starts only the paths a pre-pass found able to carry light from the sun to
+    # the tile through the sample's pupil cell; ghost_buffer is the full enumeration's, bit for bit.  Mode 2 = the
+    # table is REBUILT AT EVERY FRAME, so that the timed frame holds the whole cost (a host that renders the same
+    # sun again would take mode 1 and reuse it).  LF_BENCH_CULL=0: every sample marches every path (rounds 1-4).
+    cull_mode = int(os.environ.get("LF_BENCH_CULL", "2"))
+    lf.set_march_culling(cull_mode)
     if cfg["spectral"]:
         lf.set_starburst_spectrum(star_scale, lambda_rgb)
     # the camera has the lens' own field of view, so that the pinhole projection of find_sun_pos and
@@ -542,23 +550,45 @@ def main():
     sampling_variants = None
     if world == 1 and not cfg["scene"] and not args.no_cpu:   # (--no-cpu = the march alone: profiler passes, A/B runs)
         sampling_variants = {}
-        for name, stride, bits, corr in (("rounds_1_to_3_stride1_subcells_4x4", 1, 2, 37.7),
-                                         ("independent_pixels_subcells_1x1", pkg.DEFAULT_TILE_STRIDE, 0, 1.0)):
-            lf.set_tile_stride(stride)
-            lf.set_pupil_subcells(bits)
+
+        def timed_variant():
             one_frame()
             lf.synchronize()
+            lf.reset_counters()
             t_v = time.perf_counter()
             for _ in range(2):
                 one_frame()
             lf.synchronize()
-            sampling_variants[name] = {"ms_per_step": (time.perf_counter() - t_v) / 2 * 1e3, "tile_correlation": corr}
-        sampling_variants["default_stride8_subcells_64x64"] = {"ms_per_step": dt / args.steps * 1e3, "tile_correlation": 7.4}
-        sampling_variants["note"] = ("tile_correlation = 64 Var(mean of 8 x 8 adjacent pixels) / mean pixel variance on this frame "
-                                     "(1 = independent pixels, 64 = the block moves as one), profiles/r04_tile_stride.json")
+            ms = (time.perf_counter() - t_v) / 2 * 1e3
+            return ms, lf.march_stats()["executed_events"] / 2.0
+
+        for name, stride, bits, corr in (("rounds_1_to_3_stride1_subcells_4x4", 1, 2, 37.7),
+                                         ("independent_pixels_subcells_1x1", pkg.DEFAULT_TILE_STRIDE, 0, 1.0)):
+            lf.set_tile_stride(stride)
+            lf.set_pupil_subcells(bits)
+            ms_v, ev_v = timed_variant()
+            sampling_variants[name] = {"ms_per_step": ms_v, "executed_events_per_s": ev_v / (ms_v * 1e-3),
+                                       "tile_correlation": {"value": corr, "recorded_in": "profiles/r04_tile_stride.json"}}
         lf.set_tile_stride(pkg.DEFAULT_TILE_STRIDE)
         lf.set_pupil_subcells(pkg.DEFAULT_SUBCELL_BITS)
+        sampling_variants["default_stride8_subcells_64x64"] = {"ms_per_step": dt / args.steps * 1e3,
+                                                               "tile_correlation": {"value": 7.4, "recorded_in": "profiles/r04_tile_stride.json"}}
+        # the same frame without the cull (identical pixels): every sample marches every path through the path tree
+        # (the round-4 frame), and with the cull table kept between frames
+        for name, mode in (("full_enumeration_path_tree", 0), ("culled_table_reused", 1)):
+            if mode != cull_mode:
+                lf.set_march_culling(mode)
+                ms_v, ev_v = timed_variant()
+                sampling_variants[name] = {"ms_per_step": ms_v, "executed_events_per_s": ev_v / (ms_v * 1e-3),
+                                           "executed_events_per_frame": ev_v}
+        lf.set_march_culling(cull_mode)
+        sampling_variants["note"] = ("tile_correlation = 64 Var(mean of 8 x 8 adjacent pixels) / mean pixel variance on this frame "
+                                     "(1 = independent pixels, 64 = the block moves as one); every variant runs under the frame's "
+                                     "culling mode except the two named after theirs")
     n_launch, march_ms = lf.timing_get("march")
+    n_cull, cull_ms = lf.timing_get("cull_prepass")
+    cull_info = lf.cull_info()
+    cull_frac = lf.cull_started_fraction() if cull_info["culled"] else None
     n_xchg, xchg_ms = lf.timing_get("exchange") if gather_mode == "cabi" else (args.steps, host_exchange[0] * 1e3)
     n_scene, scene_ms = lf.timing_get("scene_term")
     scene_cnt = lf.scene_counters() if cfg["scene"] else None
@@ -592,6 +622,8 @@ def main():
         # mask + the lens / program tables it reads
         rows_per_launch = min(my_trows * TILE_ROWS, H)
         alg_bytes = rows_per_launch * W * 24 + mask.size * 4 + 64 * 1024
+        if cull_info["culled"]:   # + the cull table, read once
+            alg_bytes += cull_info["blocks_x"] * cull_info["blocks_y"] * (cull_info["cells"] + 1) * 8
         avg_ms = march_ms / max(n_launch, 1)
         hbm_achieved = alg_bytes / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0
         ev_per_launch = executed / max(1, n_launch * world)
@@ -615,7 +647,7 @@ def main():
             except Exception as e:  # noqa: BLE001
                 pmc_note = f"unreadable PMC summary: {e}"
         roof = {"bound": "valu", "unit": "wave-instr/s", "peak": VALU_PEAK, "achieved": None, "frac": None,
-                "traffic": None, "kernel": "k_march", "launches": n_launch, "avg_launch_ms": avg_ms,
+                "traffic": None, "kernel": "k_march_cull" if cull_info["culled"] else "k_march", "launches": n_launch, "avg_launch_ms": avg_ms,
                 "executed_events_per_s_per_gpu": ev_rate_gpu, "practical_peak": VALU_PRACTICAL,
                 "pmc_source": pmc_note,
                 "note": "register-resident march: compulsory HBM traffic is O(frame), the binding resource "
@@ -625,7 +657,9 @@ def main():
                 "hbm": {"achieved": hbm_achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                         "frac": hbm_achieved / HBM_PEAK_GBS, "algorithmic_bytes_per_launch": alg_bytes,
                         "traffic_bytes_per_launch": None}}
-        alg_flop_s = (executed * FLOP_PER_EVENT + remarch_lane * FLOP_PER_FRESNEL) / dt / world
+        # (the culled march evaluates the Fresnel weight on EVERY event it executes; the path tree on the re-marched ones)
+        weighted_events = executed if cull_info["culled"] else remarch_lane
+        alg_flop_s = (executed * FLOP_PER_EVENT + weighted_events * FLOP_PER_FRESNEL) / dt / world
         roof["flops"] = {"achieved": alg_flop_s / 1e12, "peak": FP32_PEAK_TFLOPS, "unit": "TFLOP/s",
                          "frac": alg_flop_s / 1e12 / FP32_PEAK_TFLOPS,
                          "algorithmic_flop_per_executed_event": FLOP_PER_EVENT,
@@ -695,7 +729,7 @@ def main():
             # RECORDED measurement (c3 frame, a timing-only build) -- it is not measured by this run.
             "event_accounting": {
                 "every_event_weighted": every_event_weighted(),
-                "fresnel_evaluated_fraction": remarch_lane / executed if executed else None,
+                "fresnel_evaluated_fraction": (1.0 if cull_info["culled"] else remarch_lane / executed) if executed else None,
                 "remarch_events": remarch_lane / args.steps,
                 "remarch_rows_x64": 64.0 * remarch_rows / args.steps,
                 "remarch_rows_over_executed": 64.0 * remarch_rows / executed if executed else None,
@@ -704,6 +738,27 @@ def main():
             "fates": {k[5:]: (fate_tot[k] / fate_tot["rays_launched"] if fate_tot["rays_launched"] else None)
                       for k in fate_keys[1:]},
             "events_per_ray": {"executed": executed / rays if rays else None, "logical": logical / rays if rays else None},
+            # ---- where the rays go: what the frame spends per unit of light ------------------------
+            # culling: the pre-pass (k_cull_level, coarse to fine over the pupil square) and what its table starts;
+            # with mode 2 its time is inside ms_per_step at every frame.  light: rays that leave the front element / end
+            # inside the sun's lobe per second of the WHOLE frame.  equal_variance: the culled frame's pixels are the
+            # round-4 default's bit for bit (same estimator, same samples), so its variance ratio is exactly 1 and
+            # the frame time at equal variance is the frame time.
+            "culling": {"mode": cull_mode, "culled": cull_info["culled"],
+                        "prepass_ms_per_frame": cull_ms / args.steps, "prepass_builds": n_cull,
+                        "started_fraction": cull_frac,
+                        "table": {k: cull_info[k] for k in ("blocks_x", "blocks_y", "cells", "G", "P", "block_px")},
+                        "note": "started_fraction = of all (64 x 64 pixel block, pupil cell, path) combinations, the part the march starts; "
+                                "ghost_buffer is bit-identical to the full enumeration (tests/test_gpu_cull.py)"},
+            "light": {"rays_reaching_scene_per_s": fate_tot["rays_reached_scene"] / dt,
+                      "rays_hitting_light_per_s": fate_tot["rays_hit_light"] / dt,
+                      "reached_scene_fraction_of_started": fate_tot["rays_reached_scene"] / fate_tot["rays_launched"] if fate_tot["rays_launched"] else None,
+                      "hit_light_fraction_of_started": fate_tot["rays_hit_light"] / fate_tot["rays_launched"] if fate_tot["rays_launched"] else None},
+            "equal_variance": None if args.config != "c3" or world != 1 else {
+                "variance_ratio_vs_r04_default_at_equal_spp": 1.0,
+                "ms_per_frame_equal_variance": dt / args.steps * 1e3,
+                "r04_ms_per_frame": R04_C3_MS, "ratio_to_r04": dt / args.steps * 1e3 / R04_C3_MS,
+                "basis": "identical pixels: the cull removes only paths that contribute exactly 0 (same samples, same arithmetic)"},
             # `value` is measured with the default sampling specification (4x4 pupil sub-cells per tile and
             # sample: pixels, counters and goldens of rounds 1-2 hold).  More coherence is faster at the
             # same per-pixel variance but correlates the noise inside an 8x8 tile further, none is slower

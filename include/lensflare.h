@@ -493,6 +493,10 @@ lf_status lf_trace_ghosts(lf_ctx* ctx, int spp, uint64_t key);
 lf_status lf_set_march_culling(lf_ctx* ctx, int mode);
 lf_status lf_get_cull_info(lf_ctx* ctx, int info[8]);
 lf_status lf_get_cull_table(lf_ctx* ctx, uint64_t* out, size_t n_entries);
+/* of all (block, cell, path) combinations, the fraction the last pre-pass found able to carry light.  Above 0.12
+ * lf_trace_ghosts marches everything after all (the path tree shares legs and lets rays die early; the culled
+ * march starts each path alone): a very wide sun or a handful of samples per pixel. */
+lf_status lf_get_cull_started_fraction(lf_ctx* ctx, double* fraction);
 /* the fixed-point exponent the last lf_trace_ghosts used (36 unless the range contract above lowered it) */
 lf_status lf_get_march_fix_bits(lf_ctx* ctx, int* bits);
 /* replaces: LensCamera::generate_ray of the north star / Camera::generate_ray_for_thin_lens

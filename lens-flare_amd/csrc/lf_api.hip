@@ -923,6 +923,12 @@ lf_status lf_get_cull_info(lf_ctx* ctx, int info[8]) {
   return LF_OK;
 }
 
+lf_status lf_get_cull_started_fraction(lf_ctx* ctx, double* fraction) {
+  if (!ctx || !fraction) return LF_ERR_INVALID;
+  *fraction = ctx->cull_started_fraction;
+  return LF_OK;
+}
+
 lf_status lf_get_cull_table(lf_ctx* ctx, uint64_t* out, size_t n_entries) {
   if (!ctx || !out) return LF_ERR_INVALID;
   if (!ctx->last_march_culled || !ctx->cull_dev || ctx->cull_hash == 0)

@@ -30,6 +30,7 @@
 // No reference counterpart: the reference enumerates 13 fixed pairs per channel and draws each as one textured
 // quad (src/pathtracer/pathtracer.cpp:735-762, :452-508) -- its "cull" is that a quad covers few pixels.
 #include <algorithm>
+#include <chrono>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -44,8 +45,9 @@ namespace {
 using namespace lfm;
 
 // ---- the pre-pass ------------------------------------------------------------------------------------
-constexpr int kCullSamples = 13;   // per box: a 3 x 3 grid over the pupil cell at the block's centre (0 .. 8, 4 = the
-                                   // centre) + the cell's centre at the block's +x, -x, +y, -y edges (9 .. 12)
+constexpr int kCullSamples = 13;   // per box: a 3 x 3 grid over the pupil cell (0 .. 8, 4 = the centre; the mid-edge
+                                   // ones at the block's centre, the corners on the block's corners) + the cell's
+                                   // centre at the block's +x, -x, +y, -y edges (9 .. 12)
 struct CullLevelArgs {
   int W, H;
   float pitch, half_w, half_h;
@@ -60,9 +62,43 @@ struct CullLevelArgs {
   float stop_h, inv_stop_h;
   float sx, sy, rho;       // the sun's direction (x, y) and the lobe's radius in direction space
   float margin;            // footprint inflation at this level
+  int keep_partial;        // a box that lost samples (total reflection, a missed sphere) is never dropped by the lobe test
+  float lost_rel, lost_abs;  // "every sample ends here" drops a box only beyond this margin (see firmly_lost)
+  int disable;             // experiments: bit 0 no aperture test, 1 no mask test, 2 no lobe test, 3 no all-samples-lost test
   unsigned list_stride;    // entries per path in the work lists
   unsigned occ[kCullOcc];  // occupancy rows of the stop mask
 };
+
+// A glass event of the pre-pass: the arithmetic of surface_event<false> (lf_march_events.h) WITHOUT a clear aperture
+// -- the sample goes on wherever the sphere is -- that also hands out HOW FAR the sample is from being lost:
+// miss = disc / (G^2 + |c n^2 F|) (< 0: no intersection), tir = k2 / (disc + |delta|) (< 0: total reflection of a
+// refraction), both relative and of order 1 away from the boundaries.  Not bit-critical: nothing here reaches a pixel.
+__device__ __forceinline__ void virtual_event(Ray& r, const LfProgRow& w, float cn22, float rn2, float delta, bool reflect,
+                                              bool flat, float& miss, float& tir) {
+  const float oz = r.hz + w.dzv;
+  const float od = fmaf(r.px, r.dx, fmaf(r.py, r.dy, oz * r.dz));
+  const float oo = fmaf(oz, oz, fmaf(r.px, r.px, r.py * r.py));
+  const float Fh = fmaf(w.ch, oo, -oz);
+  const float G = fmaf(-w.curv, od, r.dz);
+  const float cF = cn22 * Fh;
+  const float G2 = G * G;
+  const float disc = G2 - cF;
+  miss = disc * lf_rcp(G2 + fabsf(cF) + 1e-30f);
+  const float sq = lf_sqrt(disc);
+  const float t = flat ? (Fh + Fh) * lf_rcp(fmaf(w.sgn, sq, G)) : fmaf(-w.sgn, sq, G) * rn2;
+  const float hx = fmaf(t, r.dx, r.px), hy = fmaf(t, r.dy, r.py), hz = fmaf(t, r.dz, oz);
+  if (reflect) {
+    tir = 1.0f;
+    const float m = sq * (w.c2 * w.sgn);
+    r.dx = fmaf(m, hx, r.dx); r.dy = fmaf(m, hy, r.dy); r.dz = fmaf(m, hz, fmaf(-2.0f * w.sgn, sq, r.dz));
+  } else {
+    const float k2 = disc + delta;
+    tir = k2 * lf_rcp(fabsf(disc) + fabsf(delta) + 1e-30f);
+    const float gs = lf_sqrt(k2) - sq, gcs = gs * w.sc;
+    r.dx = fmaf(-gcs, hx, r.dx); r.dy = fmaf(-gcs, hy, r.dy); r.dz = fmaf(-gcs, hz, fmaf(w.sgn, gs, r.dz));
+  }
+  r.px = hx; r.py = hy; r.hz = hz;
+}
 
 // One LANE = one box (sensor block x pupil cell) of path blockIdx.y; its 13 rays live in registers, so a wave
 // marches 64 boxes of ONE path in lockstep -- wave-uniform event sequence, rows through the scalar cache, no
@@ -100,7 +136,6 @@ __global__ __launch_bounds__(256) void k_cull_level(const LfLensDev* __restrict_
 
   const int n_ev = pairs->ev_cnt[q];
   const int* const seq = seq_table + pairs->ev_off[q];
-  const float inf = __int_as_float(0x7f800000);
   const int lane = (int)(threadIdx.x & 63u);
   bool enabled = false;
   bool firm = false;       // ruled out with room to spare: the other end of the spectrum cannot bring the box back
@@ -115,7 +150,12 @@ __global__ __launch_bounds__(256) void k_cull_level(const LfLensDev* __restrict_
 #pragma unroll
     for (int t = 0; t < kCullSamples; t++) {
       float X = Xc, Y = Yc, fu = 0.5f, fv = 0.5f;
-      if (t < 9) { fu = 0.5f * (float)(t % 3); fv = 0.5f * (float)(t / 3); }
+      if (t < 9) {
+        fu = 0.5f * (float)(t % 3); fv = 0.5f * (float)(t / 3);
+        // the four corners of the pupil cell sit on the four corners of the BLOCK as well (diagonals of the 4-D
+        // box): what they deviate from the linear model by holds the cross terms between sensor and pupil
+        if ((t % 3) != 1 && (t / 3) != 1) { X = Xc + (float)(t % 3 - 1) * hX; Y = Yc + (float)(t / 3 - 1) * hY; }
+      }
       else if (t == 9) X = Xc + hX;
       else if (t == 10) X = Xc - hX;
       else if (t == 11) Y = Yc + hY;
@@ -160,7 +200,9 @@ __global__ __launch_bounds__(256) void k_cull_level(const LfLensDev* __restrict_
         if (t < 9) {
           ru2 = fmaxf(ru2, d2);
           const float at = (float)(t % 3 - 1), bt = (float)(t / 3 - 1);
-          const float mx = ex - fmaf(at, f.g1x, bt * f.g2x), my = ey - fmaf(at, f.g1y, bt * f.g2y);
+          const bool corner = (t % 3) != 1 && (t / 3) != 1;     // (also displaced to the block's corner)
+          const float mx = ex - fmaf(at, f.g1x, bt * f.g2x) - (corner ? fmaf(at, f.gxx, bt * f.gyx) : 0.0f);
+          const float my = ey - fmaf(at, f.g1y, bt * f.g2y) - (corner ? fmaf(at, f.gxy, bt * f.gyy) : 0.0f);
           dev2 = fmaxf(dev2, fmaf(mx, mx, my * my));
         } else if (t < 11) rx2 = fmaxf(rx2, d2);
         else ry2 = fmaxf(ry2, d2);
@@ -192,35 +234,51 @@ __global__ __launch_bounds__(256) void k_cull_level(const LfLensDev* __restrict_
       const float rn2 = j == 0 ? wr.rn2[0] : j == 1 ? wr.rn2[1] : wr.rn2[2];
       const float delta = j == 0 ? wr.delta[0] : j == 1 ? wr.delta[1] : wr.delta[2];
       unsigned hit = 0u, okm = 0u;
+      // the total-reflection margins (virtual_event) of the samples that reach the interface: their range over the
+      // box, and the one nearest to going on among those that end here by total reflection
+      float t_max = -2.0f, t_min = 2.0f, t_lost = -2.0f;
 #pragma unroll
       for (int t = 0; t < kCullSamples; t++) {
         bool ok;
-        r[t].r2 = fmaf(r[t].px, r[t].px, r[t].py * r[t].py);   // (recomputed, not carried: 13 registers less)
         if (kind & LF_EV_STOP) {
           const float tt = -(r[t].hz + wr.dzv) * lf_rcp(r[t].dz);
           const float hx = fmaf(tt, r[t].dx, r[t].px), hy = fmaf(tt, r[t].dy, r[t].py);
-          r[t].px = hx; r[t].py = hy; r[t].hz = 0.0f; r[t].r2 = fmaf(hx, hx, hy * hy);
-          ok = r[t].r2 == r[t].r2;
+          r[t].px = hx; r[t].py = hy; r[t].hz = 0.0f;
+          ok = hx == hx && hy == hy;
+          if (ok) hit |= 1u << t;
         } else {
-          lanemask geom_ok;
-          const lanemask m = surface_event<false>(r[t], wr.dzv, wr.curv, wr.ch, wr.c2, wr.sc, cn22, rn2, delta, inf,
-                                                  (kind & LF_EV_REFLECT) != 0, (kind & LF_EV_FLAT) != 0, wr.sgn, geom_ok);
-          ok = ((m >> lane) & 1ull) != 0ull;
+          float miss, tir;
+          virtual_event(r[t], wr, cn22, rn2, delta, (kind & LF_EV_REFLECT) != 0, (kind & LF_EV_FLAT) != 0, miss, tir);
+          const bool reaches = miss >= 0.0f;
+          if (reaches) hit |= 1u << t;                // (a totally reflected ray did reach the interface)
+          ok = reaches && tir >= 0.0f;
+          if (reaches && ((live >> t) & 1u)) {
+            t_max = fmaxf(t_max, tir); t_min = fminf(t_min, tir);
+            if (tir < 0.0f) t_lost = fmaxf(t_lost, tir);
+          }
         }
-        if (r[t].px == r[t].px) hit |= 1u << t;     // (a totally reflected ray did reach the interface)
         if (ok) okm |= 1u << t;
       }
       hit &= live;
+      // "Every sample ends here" drops the box only with a margin.  A sample that finds NO intersection needs none:
+      // what lies between it and a sample that does hit meets the sphere further out than the clear aperture reaches.
+      // Total reflection happens INSIDE the clear aperture (the steep rear surface of the front group), and a sliver
+      // of the box may go on between samples that all end: the box is dropped only if even the sample nearest to
+      // going on is further from it than the margins vary over the box (found by comparing with the full
+      // enumeration on frames with larger blocks: pair (3, 7), profiles/r05_march_variants.txt).
+      const bool firmly_lost = t_lost < -1.5f || t_lost < -(fmaf(a.lost_rel, t_max - t_min, a.lost_abs));
       const Foot f = footprint(false, hit, 1e-3f);
       live &= okm;
       if (!culled && !keep) {
-        if (hit == 0u) { culled = true; why = 4; }             // no sample reaches the interface: nor does the box
+        if (hit == 0u) {                                       // no sample reaches the interface
+          if (firmly_lost && !(a.disable & 8)) { culled = true; why = 7; } else { keep = true; why = 2; }
+        }
         else {
           const float cx = f.cx, cy = f.cy;
           const float cr = lf_sqrt(fmaf(cx, cx, cy * cy));
           const float icr = cr > 0.0f ? lf_rcp(cr) : 0.0f;
           const float ext = extent(f, cx * icr, cy * icr), hh = lf_sqrt(wr.h2);
-          if (cr - ext > hh) {                                   // wholly outside the clear aperture
+          if (cr - ext > hh && !(a.disable & 1)) {               // wholly outside the clear aperture
             culled = true; why = 4;
             firm = cr - ext - hh > fmaf(0.25f, ext, 0.03f * hh);
           }
@@ -237,10 +295,10 @@ __global__ __launch_bounds__(256) void k_cull_level(const LfLensDev* __restrict_
               const unsigned span = (ix1 - ix0 >= 31 ? 0xffffffffu : ((2u << (ix1 - ix0)) - 1u)) << ix0;
               for (int iy = iy0; iy <= iy1; iy++) open = open || (a.occ[iy] & span) != 0u;
             }
-            if (!open) { culled = true; why = 5; }
+            if (!open && !(a.disable & 2)) { culled = true; why = 5; }
           }
           if (!culled) {
-            if ((live & 0x1ffu) == 0u) { culled = true; why = 7; }            // every pupil sample ends here
+            if (live == 0u && firmly_lost && !(a.disable & 8)) { culled = true; why = 7; }   // every sample ends here, by a margin
             else if (__popc(live & 0x1ffu) < 3) { keep = true; why = 2; }     // too little left to bound anything
             else if (live != 0x1fffu) partial = true;
           }
@@ -254,7 +312,8 @@ __global__ __launch_bounds__(256) void k_cull_level(const LfLensDev* __restrict_
       const float dist = lf_sqrt(fmaf(ex, ex, ey * ey));
       const float id = dist > 0.0f ? lf_rcp(dist) : 0.0f;
       const float ext = extent(f, ex * id, ey * id);
-      if (dist - ext > a.rho) {
+      if (partial && a.keep_partial) { keep = true; why = 1; }
+      else if (dist - ext > a.rho && !(a.disable & 4)) {
         culled = true; why = 6;
         firm = dist - ext - a.rho > 0.25f * (ext + a.rho);
       } else { keep = true; why = partial ? 1 : 3; }
@@ -270,6 +329,9 @@ __global__ __launch_bounds__(256) void k_cull_level(const LfLensDev* __restrict_
       atomicOr(&row[cell], bit);
       atomicOr(&row[a.P * a.P], bit);
     }
+    // how many (block, cell, path) combinations the march will start: one add per wave
+    const lanemask em = __ballot(valid && enabled);
+    if (em != 0ull && lane == (int)__builtin_ctzll(em)) atomicAdd(&next_counts[q], (unsigned)__popcll(em));
   } else {
     // the four children (cells of 2P) of every box kept, appended to the path's next list: one atomic per wave
     const lanemask em = __ballot(valid && enabled);
@@ -545,7 +607,12 @@ static int cull_m(const lf_ctx* ctx, int G) {
 bool lf_cull_applies(const lf_ctx* ctx, int G) {
   if (ctx->march_cull == 0) return false;
   if (const char* e = std::getenv("LF_MARCH_CULL")) if (std::atoi(e) == 0) return false;   // experiments only
-  // a mask has 64 bits; the strata of more than 4096 samples per pixel would need a table of their own size
+  // a mask has 64 bits; the strata of more than 4096 samples per pixel would need a table of their own size; and a
+  // block must be SMALL on the sensor for 13 rays to bound it: 64 pixels <= 1.8 mm (the full-enumeration comparison
+  // finds the first skipped lit ray at blocks of 4.8 mm, none up to 3.6 mm: profiles/r05_cull_block_size.json) --
+  // frames narrower than 1280 pixels on a 36 mm sensor march everything, which costs them little
+  const double block_mm = (double)(1 << kCullBlockLog2) * (double)ctx->sensor_w_mm / (double)std::max(1, ctx->W);
+  if (block_mm > kCullMaxBlockMm && !std::getenv("LF_CULL_ANY_BLOCK")) return false;
   return ctx->pairs.n <= kCullMaxPaths && G >= 1 && G <= 64 && ctx->lens.stop >= 0;
 }
 
@@ -577,6 +644,10 @@ lf_status lfk_cull_prepass(lf_ctx* ctx, int G) {
   float margin = ctx->cull_margin;
   if (const char* e = std::getenv("LF_CULL_MARGIN")) { const double v = std::atof(e); if (v > 0.0) margin = (float)v; }
   std::memcpy(a.occ, ctx->cull_occ, sizeof(a.occ));
+  a.keep_partial = std::getenv("LF_CULL_KEEP_PARTIAL") ? std::atoi(std::getenv("LF_CULL_KEEP_PARTIAL")) : 0;
+  a.lost_rel = std::getenv("LF_CULL_LOST_REL") ? (float)std::atof(std::getenv("LF_CULL_LOST_REL")) : 0.5f;
+  a.lost_abs = std::getenv("LF_CULL_LOST_ABS") ? (float)std::atof(std::getenv("LF_CULL_LOST_ABS")) : 0.002f;
+  a.disable = std::getenv("LF_CULL_DISABLE") ? std::atoi(std::getenv("LF_CULL_DISABLE")) : 0;
   // the levels: P_final, halved while it stays even and >= 8 (a coarser box is too curved for 13 rays to bound)
   int levels[8], n_levels = 0;
   {
@@ -648,6 +719,8 @@ lf_status lfk_cull_prepass(lf_ctx* ctx, int G) {
       next = ctx->cull_list[slot];
     }
     if (stats_dev) LF_HIP(ctx, hipMemsetAsync(stats_dev, 0, 32 * sizeof(unsigned long long), ctx->stream));
+    std::chrono::steady_clock::time_point t_lv;
+    if (stats_dev) { LF_HIP(ctx, hipStreamSynchronize(ctx->stream)); t_lv = std::chrono::steady_clock::now(); }
     // the kernel reads its input with the stride it was written with and writes with the new one
     CullLevelArgs k = a;
     k.list_stride = a.last ? in_stride : out_stride;
@@ -666,6 +739,8 @@ lf_status lfk_cull_prepass(lf_ctx* ctx, int G) {
     if (stats_dev) {   // experiments only: why the boxes of this level ended as they did, per tested wavelength
       unsigned long long hs[32];
       LF_HIP(ctx, hipStreamSynchronize(ctx->stream));
+      std::fprintf(stderr, "CULL_LEVEL P %d items_per_path_max %zu ms %.3f\n", a.P, n_items,
+                   std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_lv).count());
       LF_HIP(ctx, hipMemcpy(hs, stats_dev, sizeof(hs), hipMemcpyDeviceToHost));
       static const char* names[8] = {"", "kept_inside_lobe_partial_box", "kept_too_few_samples_left", "kept_inside_lobe",
                                      "culled_aperture", "culled_mask", "culled_lobe", "culled_all_samples_lost"};
@@ -684,6 +759,15 @@ lf_status lfk_cull_prepass(lf_ctx* ctx, int G) {
   }
   lf_timing_end(ctx, LFK_CULL, ev);
   if (stats_dev) (void)hipFree(stats_dev);
+  {
+    // what fraction of all (block, cell, path) combinations the table starts
+    unsigned cnt[kCullMaxPaths];
+    LF_HIP(ctx, hipMemcpyAsync(cnt, ctx->cull_counts + (size_t)(n_levels - 1) * kCullMaxPaths, sizeof(cnt), hipMemcpyDeviceToHost, ctx->stream));
+    LF_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    double on = 0.0;
+    for (int q = 0; q < a.n_paths; q++) on += (double)cnt[q];
+    ctx->cull_started_fraction = on / ((double)nblk * (double)a.P_final * (double)a.P_final * (double)a.n_paths);
+  }
   ctx->cull_hash = h;
   return LF_OK;
 }

@@ -210,6 +210,7 @@ enum { LF_EV_REST1 = 8, LF_EV_SAVE0 = 0x10, LF_EV_SAVE1 = 0x20, LF_EV_END = 0x40
 // is the union over its cells (the unstratified samples s >= G * G of a non-square sample count).
 constexpr int kCullBlockLog2 = 6;        // sensor blocks of 64 x 64 pixels (a wave tile of any stride lies inside one)
 constexpr int kCullMaxPaths = 64;        // bits of a mask
+constexpr double kCullMaxBlockMm = 1.8;  // a block may be this large on the sensor at most (lf_cull_applies)
 constexpr int kCullOcc = 32;             // the stop mask's occupancy grid: kCullOcc x kCullOcc cells, any texel > 0
 struct LfCullArgs {
   const unsigned long long* table;   // [blocks_y * blocks_x][cells + 1]; null = every path everywhere
@@ -375,6 +376,12 @@ struct lf_ctx {
   size_t cull_list_cap[2] = {0, 0};
   unsigned* cull_counts = nullptr;             // [levels][kCullMaxPaths] list lengths
   int cull_m = 1;                              // table cells per axis inside one stratum
+  double cull_started_fraction = 0.0;          // of all (block, cell, path) combinations, what the resident table starts
+  // Above this the culled march loses to the path tree: it marches every started path on its own and with its
+  // weight, the tree shares legs and lets rays die early (measured crossover on the 1080p frame: a sun of 0.2 rad
+  // starts 17 % and ties, profiles/r05_march_variants.txt).  lf_set_march_culling's mode stays what it is; the
+  // launch just takes the other kernel.
+  double cull_max_fraction = 0.12;
   uint64_t cull_hash = 0;                      // of the inputs the resident table was built from (0 = none)
   int cull_bx = 0, cull_by = 0, cull_cells = 0, cull_G = 0, cull_P = 0;
   float cull_margin = 1.25f;                   // footprint inflation of the pre-pass (LF_CULL_MARGIN: experiments)

@@ -1206,7 +1206,12 @@ lf_status lfk_march(lf_ctx* ctx, int spp, uint64_t key) {
   ctx->last_march_culled = lf_cull_applies(ctx, a.G);
   if (ctx->last_march_culled) {
     lf_status st = lfk_cull_prepass(ctx, a.G);
-    if (st == LF_OK) st = lfk_march_culled(ctx, a, blocks, dyn_lds);
+    if (st != LF_OK) return st;
+    // a table that starts most of everything (a very wide sun, a handful of samples): the path tree is faster
+    if (ctx->cull_started_fraction > ctx->cull_max_fraction && !std::getenv("LF_CULL_FORCE")) ctx->last_march_culled = false;
+  }
+  if (ctx->last_march_culled) {
+    lf_status st = lfk_march_culled(ctx, a, blocks, dyn_lds);
     if (st != LF_OK) return st;
   } else {
   hipEvent_t ev = lf_timing_begin(ctx, LFK_MARCH);

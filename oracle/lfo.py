@@ -272,7 +272,8 @@ last_culled_lit = 0        # rays the device's table skips that DID reach the li
 def _device_cull(cull, W, H, spp):
     """cull: None (count every ray), "auto" (the table of the followed device's last trace_ghosts, if it culled)
     or a table from LensFlare.cull_table().  -> contiguous uint64 array (blocks_y, blocks_x, cells + 1) or None."""
-    if isinstance(cull, str):
+    auto = isinstance(cull, str)
+    if auto:
         assert cull == "auto"
         cull = _followed_lf.cull_table() if _followed_lf is not None and hasattr(_followed_lf, "cull_table") else None
     if cull is None:
@@ -284,6 +285,8 @@ def _device_cull(cull, W, H, spp):
     while G * G > spp:
         G -= 1
     want = [((H + 63) // 64, (W + 63) // 64, (G * m) ** 2 + 1) for m in (1, 2, 4)]
+    if auto and cull.shape not in want:
+        return None      # the followed device's last launch was another frame (it did not render this one): count every ray
     assert cull.shape in want, f"cull table {cull.shape} is not the one of a {W}x{H} frame at {spp} spp {want}: " \
                                "the device's last trace_ghosts was another launch"
     return cull

@@ -52,3 +52,12 @@ def rel_err(a, b, floor=0.0):
     a = np.asarray(a, np.float64)
     b = np.asarray(b, np.float64)
     return np.abs(a - b) / np.maximum(np.abs(b), floor if floor > 0 else np.finfo(np.float64).tiny)
+
+
+def ray_budget(lf, counters, budget):
+    """The march's rays_launched against the full enumeration's budget (pixels x samples x wavelengths x paths):
+    equal when the launch marched every path of every sample (lf_set_march_culling(0), or a table that starts too
+    much to pay); with the path cull on (the default, lens-flare_amd/csrc/lf_cull.hip) it counts the rays that were
+    STARTED -- a part of the budget, never more, and never nothing on a frame with light in it."""
+    n = counters["rays_launched"]
+    return n == budget if not lf.cull_info()["culled"] else 0 < n <= budget

@@ -1,0 +1,250 @@
+"""Path culling of the geometric march (lens-flare_amd/csrc/lf_cull.hip, round 5; no reference counterpart -- the
+reference draws 13 fixed pairs per channel as quads, src/pathtracer/pathtracer.cpp:735-762).  lf_trace_ghosts starts
+only the paths a pre-pass found able to carry light from the sun to a block of the sensor through a cell of the
+pupil.  What must hold, and is held here:
+
+  * ghost_buffer = the buffer of the FULL enumeration, bit for bit -- against the path-tree kernel that marches
+    every path of every sample (lf_set_march_culling(0)) and against the float32 oracle, which always marches
+    everything; the oracle also reports how many rays the device's table skips that did reach the light: none;
+  * counters = the oracle's, restricted to the rays the device started (it reads the device's own table);
+  * on frames where the table would start most of everything the launch takes the path tree by itself.
+
+The frames the oracle can afford are small.  A cull block (64 x 64 pixels) must be small ON THE SENSOR (<= 1.8 mm:
+lf_cull_applies), so the small frames here are CROPS: the bench's pixel pitch (36 mm / 1920) on a narrower sensor around
+the axis.  There the table starts more than the 12 % above which a launch takes the path tree by itself;
+LF_CULL_FORCE=1 (a test hook of lfk_march) keeps the culled kernel."""
+import numpy as np
+import pytest
+
+from goldenlib import load_texels, ray_budget
+from oracle import lfo
+
+pytestmark = pytest.mark.gpu
+RAD = [1.0, 0.9, 0.5]
+
+
+@pytest.fixture(scope="module")
+def pkg():
+    import __graft_entry__ as g
+    return g.load_package()
+
+
+@pytest.fixture(scope="module")
+def lf(pkg):
+    ctx = pkg.LensFlare(0)
+    lfo.geo_follow_device(ctx)
+    yield ctx
+    lfo.geo_follow_device(None)
+    ctx.close()
+
+
+@pytest.fixture()
+def forced(monkeypatch):
+    monkeypatch.setenv("LF_CULL_FORCE", "1")
+
+
+def _crop(lens, W, pitch_of=1920):
+    """the prescription on a sensor W pixels wide at the pixel pitch of a 36 mm sensor `pitch_of` pixels wide"""
+    c = dict(lens)
+    c["sensor_width_mm"] = 36.0 * W / pitch_of
+    return c
+
+
+def _setup(pkg, lf, lens, W, H, sun, alpha, mask, pairs=None, primary=True, lambda_rgb=None):
+    lf.set_frame(W, H)
+    lf.set_aperture(pkg.APERTURE_STARBURST, mask)
+    lf.set_lens(lens)
+    if lambda_rgb is not None:
+        lf.set_lambda_rgb(lambda_rgb)
+    lf.set_sun(sun, RAD, alpha)
+    lf.set_ghost_pairs(pairs, primary)
+    lf.set_band(0, H)
+    lf.set_row_interleave(0, 1)
+
+
+def _both(pkg, lf, spp, key):
+    """-> culled pixels + counters + table info, full-enumeration pixels + counters"""
+    lf.set_march_culling(2)
+    lf.reset_counters()
+    lf.trace_ghosts(spp, key)
+    info = lf.cull_info()
+    g1, c1 = lf.read_buffer(pkg.GHOST_BUFFER), lf.counters()
+    lf.set_march_culling(0)
+    lf.reset_counters()
+    lf.trace_ghosts(spp, key)
+    g0, c0 = lf.read_buffer(pkg.GHOST_BUFFER), lf.counters()
+    assert not lf.cull_info()["culled"]
+    lf.set_march_culling(1)
+    return g1, c1, info, g0, c0
+
+
+@pytest.mark.parametrize("W,H,spp,sun,alpha", [
+    (96, 64, 64, [0.03, 0.02, -1.0], 0.05), (130, 70, 16, [-0.06, 0.04, -1.0], 0.05), (64, 64, 256, [0.0, 0.0, -1.0], 0.02),
+    (48, 32, 5, [-0.02, 0.01, -1.0], 0.05), (40, 24, 300, [0.001, -0.0015, -1.0], 0.004), (72, 40, 1, [0.03, 0.02, -1.0], 0.1),
+    (96, 64, 36, [0.1, 0.02, -1.0], 0.05)])
+def test_culled_march_is_the_full_enumeration_and_the_oracle(pkg, lf, forced, W, H, spp, sun, alpha):
+    lens = _crop(pkg.load_lens_file("dgauss11.lens"), W)
+    mask = load_texels("pentbig500_14.png")
+    _setup(pkg, lf, lens, W, H, sun, alpha, mask)
+    key = 0xC011 + spp
+    g1, c1, info, g0, c0 = _both(pkg, lf, spp, key)
+    assert info["culled"] and info["block_px"] == 64 and info["blocks_x"] == (W + 63) // 64
+    assert np.array_equal(g1, g0)                                   # nothing that was skipped could have contributed
+    assert c0["rays_launched"] == W * H * spp * 3 * 46 and 0 < c1["rays_launched"] <= c0["rays_launched"]
+    assert c1["rays_hit_light"] == c0["rays_hit_light"]             # every lit ray was started
+    assert c1["rays_launched"] == c1["rays_clipped_stop"] + c1["rays_vignetted"] + c1["rays_tir"] + c1["rays_reached_scene"]
+    assert lf.executed_events() > 0
+    # the oracle: pixels of the full enumeration, counters of what the device's table starts
+    lf.set_march_culling(2)
+    lf.reset_counters()
+    lf.trace_ghosts(spp, key)
+    assert lf.executed_events() == c1["surface_events"]             # each started path marched on its own
+    og, oc = lfo.geo_trace(lens, W, H, 0, H, spp, key, None, True, mask, sun, RAD, alpha, n_threads=16)
+    assert lfo.last_culled_lit == 0
+    assert np.array_equal(g1, og) and oc == c1
+    og0, oc0 = lfo.geo_trace(lens, W, H, 0, H, spp, key, None, True, mask, sun, RAD, alpha, n_threads=16, cull=None)
+    assert np.array_equal(og0, og) and oc0 == c0                    # (and the path tree's counters are the full oracle's)
+    lf.set_march_culling(1)
+
+
+@pytest.mark.parametrize("stride,bits", [(1, 2), (8, 0), (4, 1), (2, 8)])
+def test_every_sampling_specification(pkg, lf, forced, stride, bits):
+    """the table cell a wave looks up follows the sub-cell it aims at: 4 x 4 cells per stratum where the
+    specification has at least that many sub-cells, fewer otherwise (independent pixels: the whole stratum)"""
+    W, H, spp, sun = 80, 48, 64, [0.05, -0.03, -1.0]
+    lens = _crop(pkg.load_lens_file("dgauss11.lens"), W)
+    mask = load_texels("pentbig500_14.png")
+    _setup(pkg, lf, lens, W, H, sun, 0.05, mask)
+    lf.set_tile_stride(stride)
+    lf.set_pupil_subcells(bits)
+    lfo.set_tile_stride(stride)
+    lfo.lib().geo_set_sub_bits(bits)
+    try:
+        g1, c1, info, g0, c0 = _both(pkg, lf, spp, 77)
+        assert info["culled"] and info["P"] == 8 * min(4, 1 << bits)
+        assert np.array_equal(g1, g0) and c1["rays_hit_light"] == c0["rays_hit_light"] > 0
+        lf.set_march_culling(2)
+        lf.reset_counters()
+        lf.trace_ghosts(spp, 77)
+        og, oc = lfo.geo_trace(lens, W, H, 0, H, spp, 77, None, True, mask, sun, RAD, 0.05, n_threads=16)
+        assert np.array_equal(g1, og) and oc == c1 and lfo.last_culled_lit == 0
+    finally:
+        lf.set_tile_stride(pkg.DEFAULT_TILE_STRIDE)
+        lf.set_pupil_subcells(pkg.DEFAULT_SUBCELL_BITS)
+        lfo.set_tile_stride(pkg.DEFAULT_TILE_STRIDE)
+        lfo.lib().geo_set_sub_bits(pkg.DEFAULT_SUBCELL_BITS)
+        lf.set_march_culling(1)
+
+
+def test_eight_wavelengths_pair_subsets_bands_and_a_pupil_target(pkg, lf, forced):
+    mask = load_texels("pentbig500_14.png")
+    W, H, spp, sun = 96, 72, 64, [0.04, 0.03, -1.0]
+    lens8 = _crop(pkg.load_lens_file("dgauss11_8lambda.lens"), W)
+    w8, _ = pkg.spectral_weights(lens8["lambda_nm"])
+    _setup(pkg, lf, lens8, W, H, sun, 0.05, mask, lambda_rgb=w8)
+    g1, c1, info, g0, c0 = _both(pkg, lf, spp, 5)
+    assert info["culled"] and np.array_equal(g1, g0) and c1["rays_hit_light"] == c0["rays_hit_light"] > 0
+    # a subset of the pairs without the primary path: the bits follow the selection's order
+    lens = _crop(pkg.load_lens_file("dgauss11.lens"), W)
+    pairs = [(1, 3), (0, 2), (6, 8), (2, 9)]
+    _setup(pkg, lf, lens, W, H, sun, 0.05, mask, pairs=pairs, primary=False)
+    g1, c1, info, g0, c0 = _both(pkg, lf, spp, 6)
+    assert np.array_equal(g1, g0) and g0.max() > 0 and c0["rays_launched"] == W * H * spp * 3 * 4
+    lf.set_march_culling(2)
+    lf.trace_ghosts(spp, 6)
+    t = lf.cull_table()
+    assert t.shape == (2, 2, info["cells"] + 1) and int(t.max()) < 16      # four paths, four bits
+    # one rank's share of the frame (tile rows dealt round-robin) and a band: the same pixels where they render
+    _setup(pkg, lf, lens, W, H, sun, 0.05, mask)
+    whole, _, _, _, _ = _both(pkg, lf, spp, 9)
+    for rank in range(3):
+        lf.set_row_interleave(rank, 3)
+        lf.set_march_culling(2)
+        lf.trace_ghosts(spp, 9)
+        part = lf.read_buffer(pkg.GHOST_BUFFER)
+        rows = [y for y in range(H) if (y // 8) % 3 == rank]
+        assert np.array_equal(part[rows], whole[rows])
+    lf.set_row_interleave(0, 1)
+    lf.set_band(16, 40)
+    lf.trace_ghosts(spp, 9)
+    assert np.array_equal(lf.read_buffer(pkg.GHOST_BUFFER)[16:40], whole[16:40])
+    lf.set_band(0, H)
+    # samples aimed at the exit pupil's image (primary + the pairs with a mirror in front of the stop)
+    n, stop = lens["n"], lens["stop"]
+    front = [(i, j) for i in range(n) for j in range(i + 1, n) if i != stop and j != stop and i < stop]
+    _setup(pkg, lf, lens, W, H, sun, 0.05, mask, pairs=front)
+    lf.aim_at_exit_pupil(1.1)
+    try:
+        g1, c1, info, g0, c0 = _both(pkg, lf, spp, 10)
+        assert info["culled"] and np.array_equal(g1, g0) and g0.max() > 0
+    finally:
+        lf.set_pupil_target(0.0, 0.0)
+        lf.set_ghost_pairs(None, True)
+        lf.set_march_culling(1)
+
+
+def test_table_reuse_rebuild_and_the_automatic_choice(pkg, lf):
+    lens = pkg.load_lens_file("dgauss11.lens")
+    mask = load_texels("pentbig500_14.png")
+    W, H, spp = 1280, 720, 64
+    _setup(pkg, lf, lens, W, H, [0.03, 0.02, -1.0], 0.05, mask)
+    lf.timing_reset()
+    lf.timing_enable(True)
+    lf.set_march_culling(1)
+    for _ in range(3):
+        lf.trace_ghosts(spp, 3)
+    lf.synchronize()
+    assert lf.cull_info()["culled"] and lf.timing_get("cull_prepass")[0] == 1       # built once, reused twice
+    frac = lf.cull_started_fraction()
+    assert 0.0 < frac < 0.12
+    first = lf.read_buffer(pkg.GHOST_BUFFER)
+    lf.set_sun([0.031, 0.02, -1.0], RAD, 0.05)                                      # the sun moved: a new table
+    lf.trace_ghosts(spp, 3)
+    lf.synchronize()
+    assert lf.timing_get("cull_prepass")[0] == 2
+    lf.set_sun([0.03, 0.02, -1.0], RAD, 0.05)
+    lf.set_march_culling(2)
+    for _ in range(2):
+        lf.trace_ghosts(spp, 3)
+    lf.synchronize()
+    assert lf.timing_get("cull_prepass")[0] == 4                                    # mode 2: at every launch
+    assert np.array_equal(lf.read_buffer(pkg.GHOST_BUFFER), first)
+    lf.timing_enable(False)
+    # a sun as wide as the field: the table would start most of everything -- the launch marches the path tree
+    lf.set_sun([0.0, 0.0, -1.0], RAD, 0.6)
+    lf.reset_counters()
+    lf.trace_ghosts(spp, 3)
+    assert not lf.cull_info()["culled"] and lf.cull_started_fraction() > 0.12
+    assert lf.counters()["rays_launched"] == W * H * spp * 3 * 46
+    assert lf.cull_table() is None
+    with pytest.raises(pkg.LensFlareError):
+        lf.set_march_culling(3)
+    # a frame whose blocks are large on the sensor (640 pixels on 36 mm: 3.6 mm): every path is marched
+    _setup(pkg, lf, lens, 640, 360, [0.03, 0.02, -1.0], 0.05, mask)
+    lf.reset_counters()
+    lf.trace_ghosts(4, 1)
+    assert not lf.cull_info()["culled"] and lf.counters()["rays_launched"] == 640 * 360 * 4 * 3 * 46
+    # no stop in the prescription: nothing to bound a pupil with -- every path is marched
+    thin = pkg.load_lens_file("thinlens.lens")
+    _setup(pkg, lf, thin, 64, 64, [0.0, 0.0, -1.0], 0.1, np.ones((8, 8), np.float32))
+    lf.reset_counters()
+    lf.trace_ghosts(4, 1)
+    c = lf.counters()
+    assert not lf.cull_info()["culled"] and ray_budget(lf, c, 64 * 64 * 4 * 3 * 2)
+    lf.set_march_culling(1)
+
+
+def test_bench_frame_culled_equals_full_on_other_suns(pkg, lf):
+    """1080p, all 46 paths, the automatic choice: four suns the bench does not use (off axis, near a corner, outside
+    the frame, a small one) -- whole frames, culled = full enumeration bit for bit, and what it saves"""
+    lens = pkg.load_lens_file("dgauss11.lens")
+    mask = load_texels("pentbig500_14.png")
+    W, H, spp = 1920, 1080, 64
+    for sun, alpha in (([0.12, 0.08, -1.0], 0.05), ([0.30, -0.17, -1.0], 0.05), ([0.45, 0.1, -1.0], 0.05), ([0.05, 0.02, -1.0], 0.004)):
+        _setup(pkg, lf, lens, W, H, sun, alpha, mask)
+        g1, c1, info, g0, c0 = _both(pkg, lf, spp, 0x5EED)
+        assert info["culled"]
+        assert np.array_equal(g1, g0) and c1["rays_hit_light"] == c0["rays_hit_light"]
+        assert c1["rays_launched"] < 0.1 * c0["rays_launched"]
+        print(f"sun {sun} alpha {alpha}: started {c1['rays_launched'] / c0['rays_launched']:.4f} of the rays, "
+              f"reached the scene {c1['rays_reached_scene'] / c1['rays_launched']:.3f} (full: {c0['rays_reached_scene'] / c0['rays_launched']:.3f})")
