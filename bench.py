@@ -150,45 +150,112 @@ def source_sha():
     return h.hexdigest()[:16]
 
 
-def cpu_baseline(lens, mask, sun, W, H, pairs, lambda_rgb, target_s):
-    """The CPU oracle (kind 'port': oracle/lf_geo_oracle.c, one path at a time like any per-path
-    tracer) timed on this host's cores on a bounded sample of the same workload: a band of rows
-    of the same frame at reduced spp -- on ALL host cores (`value`, `cores`) and on one (`value_t1`),
-    as SURVEY 8d asks for the CPU leg."""
+def host_cpu_info():
+    """What the host offers: logical CPUs, the affinity mask, a cgroup CPU quota if there is one, and the
+    topology lscpu reports (threads per core, cores, sockets, NUMA nodes)."""
+    import subprocess
+    info = {"logical": os.cpu_count() or 1}
+    try:
+        info["affinity"] = len(os.sched_getaffinity(0))
+    except Exception:  # noqa: BLE001
+        info["affinity"] = info["logical"]
+    try:
+        q, per = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        info["cgroup_quota_cpus"] = None if q == "max" else float(q) / float(per)
+    except Exception:  # noqa: BLE001
+        info["cgroup_quota_cpus"] = None
+    try:
+        txt = subprocess.run(["lscpu"], capture_output=True, text=True, timeout=10).stdout
+        kv = {l.split(":", 1)[0].strip(): l.split(":", 1)[1].strip() for l in txt.splitlines() if ":" in l}
+        info["threads_per_core"] = int(kv.get("Thread(s) per core", "1"))
+        info["cores_per_socket"] = int(kv.get("Core(s) per socket", "0"))
+        info["sockets"] = int(kv.get("Socket(s)", "1"))
+        info["numa_nodes"] = int(kv.get("NUMA node(s)", "1"))
+        info["model"] = kv.get("Model name", "")
+    except Exception:  # noqa: BLE001
+        pass
+    phys = info.get("cores_per_socket", 0) * info.get("sockets", 1)
+    info["physical_cores"] = phys if phys > 0 else max(1, info["logical"] // max(1, info.get("threads_per_core", 1)))
+    return info
+
+
+def cpu_leg(config, W, H, rows, spp):
+    """One timed leg of the CPU baseline, run in a CHILD process (bench.py --cpu-leg ...) whose environment pins the
+    OpenMP team (OMP_NUM_THREADS / OMP_PROC_BIND=close / OMP_PLACES=cores are read when libgomp loads): the oracle's
+    march of rows [rows[0], rows[1]) of the config's frame at spp samples, every path on its own.  Never touches the GPU."""
+    import __graft_entry__ as g
+    pkg = g.load_package()
     from oracle import lfo
-    host_cores = os.cpu_count() or 1
+    cfg = CONFIGS[config]
+    lens = pkg.load_lens_file("dgauss11.lens")
+    mask = pkg.load_aperture_png("pentbig500_14.png")
+    lambda_rgb = None
+    if cfg["n_lambda"] == 8:
+        lens, lambda_rgb, _ = lens_8_lambda(pkg)
+    sun = sun_direction(lens, pkg.paraxial_efl(lens), W, H)
+    pairs = pair_list(lens, cfg["pairs"])
+    threads = int(os.environ.get("OMP_NUM_THREADS", "1"))
+    t0 = time.time()
+    _, c = lfo.geo_trace(lens, W, H, rows[0], rows[1], spp, 1, pairs, True, mask, sun, [1.0, 0.9, 0.5], 0.05,
+                         n_threads=threads, lambda_rgb=lambda_rgb, cull=None)
+    print(json.dumps({"events": c["surface_events"], "seconds": max(time.time() - t0, 1e-6), "threads": threads}))
+
+
+def cpu_baseline(config, W, H, target_s):
+    """The CPU oracle (kind 'port': oracle/lf_geo_oracle.c, one path at a time like any per-path tracer -- the
+    reference has no geometric lens to time) on this host's cores, on a bounded sample of the same workload: a band
+    of rows of the same frame at reduced spp.  Every leg is a child process with a PINNED OpenMP team
+    (OMP_PROC_BIND=close, OMP_PLACES=cores) that runs >= 3 s; `value` = the team of all physical cores the
+    process may use (affinity mask, cgroup quota), `value_t1` = one thread, the sweep is side data."""
+    import subprocess
+    info = host_cpu_info()
+    usable = min(info["affinity"], info["logical"])
+    if info.get("cgroup_quota_cpus"):
+        usable = max(1, min(usable, int(info["cgroup_quota_cpus"])))
+    full_team = max(1, min(usable, info["physical_cores"]))
     rows = (H // 2 - 32, H // 2 + 32)
 
-    def run(y0, y1, spp, threads):
-        t0 = time.time()
-        _, c = lfo.geo_trace(lens, W, H, y0, y1, spp, 1, pairs, True, mask, sun, [1.0, 0.9, 0.5], 0.05,
-                             n_threads=threads, lambda_rgb=lambda_rgb)
-        return c["surface_events"], max(time.time() - t0, 1e-3)
+    def leg(threads, rows_, spp):
+        env = dict(os.environ, OMP_NUM_THREADS=str(threads), OMP_PROC_BIND="close", OMP_PLACES="cores", OMP_DYNAMIC="false")
+        p = subprocess.run([sys.executable, os.path.abspath(__file__), "--config", config, "--width", str(W), "--height", str(H),
+                            "--cpu-leg", json.dumps({"rows": list(rows_), "spp": spp})], env=env, capture_output=True, text=True)
+        line = [l for l in p.stdout.splitlines() if l.startswith("{")]
+        if p.returncode != 0 or not line:
+            raise RuntimeError(f"cpu leg failed: {p.stderr[-400:]}")
+        r = json.loads(line[-1])
+        return r["events"], r["seconds"]
 
-    # How many threads: the host reports host_cores, but a GPU box gives one GPU's user a SHARE of them (a
-    # quota, not an affinity mask: os.cpu_count() does not show it), and an OpenMP team larger than the share
-    # is slower, not faster.  So: a short sweep over team sizes on the band at 1 spp, the fastest is the team
-    # of the timed run; the sweep is part of the record.
-    sweep = {}
-    for t in sorted({host_cores, min(host_cores, 128), min(host_cores, 64), min(host_cores, 32), min(host_cores, 16)}, reverse=True):
-        ev, dt = run(rows[0], rows[1], 1, t)
-        sweep[t] = ev / dt / 1e6
-    cores = max(sweep, key=sweep.get)
-    per_row_sample = ev / float(rows[1] - rows[0])
-    spp = int(max(1, min(64, target_s * sweep[cores] * 1e6 / (per_row_sample * (rows[1] - rows[0])))))
-    ev_n, dt_n = run(rows[0], rows[1], spp, cores)
-    # one thread: as many rows at 1 spp as a third of the budget buys (>= 1 row)
-    ev_c, dt_c = run(rows[0], rows[0] + 1, 1, 1)
-    rows1 = int(max(1, min(rows[1] - rows[0], (target_s / 3.0) * (ev_c / dt_c) / per_row_sample)))
-    ev_1, dt_1 = run(rows[0], rows[0] + rows1, 1, 1)
-    return {"value": ev_n / dt_n / 1e6, "unit": "Mray-surface-intersections/s",
-            "cores": cores, "host_cores": host_cores, "kind": "port",
-            "value_t1": ev_1 / dt_1 / 1e6, "cores_t1": 1,
+    # calibration: one row at 1 spp on one thread -> intersections per second and per (row, sample)
+    ev_c, dt_c = leg(1, (rows[0], rows[0] + 1), 1)
+    rate1, per_row_sample = ev_c / dt_c, float(ev_c)
+    leg_s = max(4.5, target_s / 6.0)      # (the calibration row runs a little faster than a sustained leg: >= 3 s in practice)
+    teams = sorted({t for t in (1, 4, 16, 32, 64, 128, full_team, usable) if 1 <= t <= usable})
+    sweep, secs = {}, {}
+    eff = 1.0        # scaling efficiency seen so far, to size the next leg
+    for t in teams:
+        budget_rs = leg_s * rate1 * t * eff / per_row_sample          # (row, sample) units this leg can afford
+        n_rows = int(max(1, min(rows[1] - rows[0], budget_rs)))
+        spp = int(max(1, min(256, budget_rs / n_rows)))
+        ev, dt = leg(t, (rows[0], rows[0] + n_rows), spp)
+        sweep[t], secs[t] = ev / dt / 1e6, dt
+        eff = max(0.05, min(1.0, (ev / dt) / (rate1 * t)))
+    upto = [t for t in teams if t <= info["physical_cores"]]
+    monotonic = all(sweep[b] >= 0.9 * sweep[a] for a, b in zip(upto, upto[1:]))
+    cause = None
+    if not monotonic or any(sweep[t] < 0.9 * sweep[max(upto)] for t in teams if t > info["physical_cores"]):
+        cause = (f"lscpu: {info.get('sockets')} socket(s) x {info.get('cores_per_socket')} cores x {info.get('threads_per_core')} "
+                 f"threads, {info.get('numa_nodes')} NUMA node(s); the process may use {usable} CPUs"
+                 + (f" under a cgroup quota of {info['cgroup_quota_cpus']:.1f}" if info.get("cgroup_quota_cpus") else "")
+                 + ": teams beyond the physical cores share cores (SMT) and span NUMA domains")
+    return {"value": sweep[full_team], "unit": "Mray-surface-intersections/s", "cores": full_team,
+            "host_cores": info["logical"], "physical_cores": info["physical_cores"], "usable_cpus": usable, "kind": "port",
+            "value_t1": sweep[1], "cores_t1": 1, "pinning": "OMP_PROC_BIND=close OMP_PLACES=cores, one child process per leg",
             "thread_sweep_M_per_s": {str(k): v for k, v in sweep.items()},
-            "sample": f"rows {rows[0]}..{rows[1]} of the {W}x{H} frame, {spp} of the spp, every path "
-                      f"marched on its own: {ev_n} intersections in {dt_n:.1f} s on {cores} OpenMP threads; "
-                      f"one thread: rows {rows[0]}..{rows[0] + rows1} at 1 spp, {ev_1} intersections in {dt_1:.1f} s "
-                      f"(oracle/lf_geo_oracle.c); the reference has no geometric lens to time"}
+            "thread_sweep_seconds": {str(k): v for k, v in secs.items()},
+            "monotonic_up_to_physical_cores_within_10pct": monotonic, "stated_cause": cause, "host": info,
+            "sample": f"rows {rows[0]}.. of the {W}x{H} frame at reduced spp, every path marched on its own, each leg sized to "
+                      f">= {leg_s:.0f} s on its team ({full_team} threads: {secs[full_team]:.1f} s; one thread: {secs[1]:.1f} s); "
+                      f"oracle/lf_geo_oracle.c; the reference has no geometric lens to time"}
 
 
 def reference_flare_path(pkg, budget_s):
@@ -291,12 +358,17 @@ def main():
     ap.add_argument("--width", type=int, default=0)
     ap.add_argument("--height", type=int, default=0)
     ap.add_argument("--spp", type=int, default=0)
-    ap.add_argument("--cpu-seconds", type=float, default=15.0)
+    ap.add_argument("--cpu-seconds", type=float, default=24.0)
     ap.add_argument("--ref-seconds", type=float, default=12.0)
     ap.add_argument("--no-cpu", action="store_true")
+    ap.add_argument("--cpu-leg", default=None, help=argparse.SUPPRESS)   # internal: one leg of cpu_baseline, in a child process
     args = ap.parse_args()
     cfg = dict(CONFIGS[args.config])
     W, H, spp = args.width or cfg["W"], args.height or cfg["H"], args.spp or cfg["spp"]
+    if args.cpu_leg:
+        spec = json.loads(args.cpu_leg)
+        cpu_leg(args.config, W, H, spec["rows"], spec["spp"])
+        return
 
     import __graft_entry__ as g
     pkg = g.load_package()          # (ctypes + numpy: nothing here touches the GPU)
@@ -358,7 +430,7 @@ def main():
 
     cpu, ref_path = None, None
     if rank == 0 and world == 1 and not args.no_cpu:
-        cpu = cpu_baseline(lens, mask, sun, W, H, pairs, lambda_rgb, args.cpu_seconds)
+        cpu = cpu_baseline(args.config, W, H, args.cpu_seconds)
         ref_path = reference_flare_path(pkg, args.ref_seconds)
 
     lf = pkg.LensFlare(local)
