@@ -397,7 +397,8 @@ lf_status lf_get_lens_info(lf_ctx* ctx, int* n_surfaces, int* stop_index, int* n
  * The magnitude is free: lf_trace_ghosts chooses `bits` per launch -- 36 (a grid of 1.5e-11 per sample)
  * unless the largest sum the launch could produce, spp x paths x (pupil solid angle) x
  * max_c sum_l radiance[c] weights[l][c], would then reach 2^62; in that case the largest exponent that
- * keeps it below (an HDR sun of radiance 1e7 at 1024 spp x 8 wavelengths: 2^24).  No sum can wrap, and a
+ * keeps it below (a sun of radiance 1e9 at 1024 spp x 8 wavelengths: 2^17; on the fixed 2^-36 grid of rounds
+ * 1-4 such a frame wrapped from a radiance of ~6e7 on).  No sum can wrap, and a
  * frame at 2^k x the radiance is 2^k x the frame, bit for bit, once both leave the default grid.
  * lf_get_march_fix_bits reports the last launch's exponent. */
 lf_status lf_set_lambda_rgb(lf_ctx* ctx, const float* weights);

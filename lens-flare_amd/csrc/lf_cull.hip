@@ -45,9 +45,10 @@ namespace {
 using namespace lfm;
 
 // ---- the pre-pass ------------------------------------------------------------------------------------
-constexpr int kCullSamples = 13;   // per box: a 3 x 3 grid over the pupil cell (0 .. 8, 4 = the centre; the mid-edge
-                                   // ones at the block's centre, the corners on the block's corners) + the cell's
-                                   // centre at the block's +x, -x, +y, -y edges (9 .. 12)
+constexpr int kCullSamples = 15;   // per box, at the middle wavelength: a 3 x 3 grid over the pupil cell (0 .. 8, 4 = the
+                                   // centre; the mid-edge ones at the block's centre, the corners on the block's
+                                   // corners) + the cell's centre at the block's +x, -x, +y, -y edges (9 .. 12);
+                                   // and the centre sample at the first and the last wavelength (13, 14)
 struct CullLevelArgs {
   int W, H;
   float pitch, half_w, half_h;
@@ -56,7 +57,7 @@ struct CullLevelArgs {
   int P_final;             // ... of the table (the last level)
   int last;                // the last level writes the table, the others the next level's work list
   int n_paths;
-  int n_test, lam[3];      // wavelengths marched
+  int lam[3];              // the wavelengths marched: the middle one (13 samples), the first and the last (the centre sample)
   int march_k, prog_recs;  // how the record table is grouped (lf_march.hip pack_program)
   float pupil_h, vz, geom_norm;
   float stop_h, inv_stop_h;
@@ -137,191 +138,201 @@ __global__ __launch_bounds__(256) void k_cull_level(const LfLensDev* __restrict_
   const int n_ev = pairs->ev_cnt[q];
   const int* const seq = seq_table + pairs->ev_off[q];
   const int lane = (int)(threadIdx.x & 63u);
-  bool enabled = false;
-  bool firm = false;       // ruled out with room to spare: the other end of the spectrum cannot bring the box back
-  int why_last = 0;
-  for (int li = 0; li < a.n_test; li++) {
-    if (__ballot(valid && !enabled && !firm) == 0ull) break;
-    const int l = a.lam[li];
-    const int g = l / a.march_k, j = l - g * a.march_k;
-    const LfProgRow* const recs = rec_table + (size_t)g * (size_t)a.prog_recs;
-    const float ns = lens->n_start[l];
-    Ray r[kCullSamples];
+  // ---- the box's 15 rays: 13 at the middle of the spectrum + the centre sample at its two ends ----------------
+  // Dispersion moves the whole footprint, monotonically in the wavelength, between where the two ends of the spectrum
+  // put it: the box must be ruled out for everything in between, so the centre sample is marched at both ends
+  // as well and its largest deviation from the middle one widens every footprint.  (Testing the ends one after the
+  // other and dropping the box when EACH misses is wrong -- the lobe may lie between them: 7042 of 1.3e10 lit rays
+  // of the 8-wavelength 4K frame were lost that way, found by the full-enumeration comparison.)
+  constexpr unsigned kAll = (1u << kCullSamples) - 1u;
+  const LfProgRow* recs_of[3];
+  int j_of[3];
+  float ns_of[3];
+#pragma unroll
+  for (int w = 0; w < 3; w++) {
+    const int l = a.lam[w], g = l / a.march_k;
+    j_of[w] = l - g * a.march_k;
+    recs_of[w] = rec_table + (size_t)g * (size_t)a.prog_recs;
+    ns_of[w] = lens->n_start[l];
+  }
+  Ray r[kCullSamples];
+#pragma unroll
+  for (int t = 0; t < kCullSamples; t++) {
+    float X = Xc, Y = Yc, fu = 0.5f, fv = 0.5f;
+    if (t < 9) {
+      fu = 0.5f * (float)(t % 3); fv = 0.5f * (float)(t / 3);
+      // the four corners of the pupil cell sit on the four corners of the BLOCK as well (diagonals of the 4-D
+      // box): what they deviate from the linear model by holds the cross terms between sensor and pupil
+      if ((t % 3) != 1 && (t / 3) != 1) { X = Xc + (float)(t % 3 - 1) * hX; Y = Yc + (float)(t / 3 - 1) * hY; }
+    }
+    else if (t == 9) X = Xc + hX;
+    else if (t == 10) X = Xc - hX;
+    else if (t == 11) Y = Yc + hY;
+    else if (t == 12) Y = Yc - hY;
+    const float ns = t == 13 ? ns_of[1] : t == 14 ? ns_of[2] : ns_of[0];
+    const float ua = ((float)ci + fu) * invP, ub = ((float)cj + fv) * invP;
+    const StartRay s0 = aim_at_pupil(X, Y, fmaf(2.0f, ua, -1.0f), fmaf(2.0f, ub, -1.0f), a.pupil_h, a.vz, a.geom_norm);
+    r[t] = Ray{X, Y, 0.0f, 0.0f, s0.dx * ns, s0.dy * ns, s0.dz * ns, 0.0f, 0.0f};
+  }
+  // `live`: bit t = sample t is still on the path (not lost to a missed sphere or to total reflection).  A box
+  // that has lost samples is PARTIAL: what is left of it lies next to a region where the path ends, the map
+  // is steep there, and its footprints are inflated twice as much.
+  unsigned live = kAll;
+  bool culled = !valid, keep = false, partial = false;
+  int why = 0;
+  // Footprint of the box in a plane (an interface's, or direction space).  With every sample in use the
+  // image of the box is modelled as a ZONOTOPE: centre c + the four generators g1, g2 (half the cell along the
+  // two pupil axes: central differences of the mid-edge samples), gx, gy (half the block along x and y) + an
+  // isotropic slack: what the linear model misses (largest deviation of the nine pupil samples and of the
+  // edge mid-points from it) and how far the ends of the spectrum move the centre.  Its extent along a unit vector
+  // n is sum |g . n|: a separating-axis test against a disc needs only that -- far tighter than a ball around c for
+  // the elongated footprints of defocused ghosts.  A box that has lost samples falls back to a ball around a
+  // sample still in use, inflated twice as much.
+  struct Foot { float cx, cy, g1x, g1y, g2x, g2y, gxx, gxy, gyx, gyy, slack, ball; bool zono; };
+  auto footprint = [&](bool dirs, unsigned use, float eps) {
+    float vx[kCullSamples], vy[kCullSamples];
+#pragma unroll
+    for (int t = 0; t < kCullSamples; t++) { vx[t] = dirs ? r[t].dx : r[t].px; vy[t] = dirs ? r[t].dy : r[t].py; }
+    Foot f;
+    f.zono = use == kAll;
+    const int ref = (use & 0x10u) ? 4 : (use ? __ffs((int)use) - 1 : 4);
+    f.cx = vx[4]; f.cy = vy[4];
+#pragma unroll
+    for (int t = 0; t < kCullSamples; t++) if (t != 4 && ref == t) { f.cx = vx[t]; f.cy = vy[t]; }
+    f.g1x = 0.5f * (vx[5] - vx[3]); f.g1y = 0.5f * (vy[5] - vy[3]);
+    f.g2x = 0.5f * (vx[7] - vx[1]); f.g2y = 0.5f * (vy[7] - vy[1]);
+    f.gxx = 0.5f * (vx[9] - vx[10]); f.gxy = 0.5f * (vy[9] - vy[10]);
+    f.gyx = 0.5f * (vx[11] - vx[12]); f.gyy = 0.5f * (vy[11] - vy[12]);
+    float dev2 = 0.0f, ru2 = 0.0f, rx2 = 0.0f, ry2 = 0.0f, rl2 = 0.0f;
 #pragma unroll
     for (int t = 0; t < kCullSamples; t++) {
-      float X = Xc, Y = Yc, fu = 0.5f, fv = 0.5f;
+      const float ex = vx[t] - f.cx, ey = vy[t] - f.cy;
+      const float d2 = ((use >> t) & 1u) ? fmaf(ex, ex, ey * ey) : 0.0f;
       if (t < 9) {
-        fu = 0.5f * (float)(t % 3); fv = 0.5f * (float)(t / 3);
-        // the four corners of the pupil cell sit on the four corners of the BLOCK as well (diagonals of the 4-D
-        // box): what they deviate from the linear model by holds the cross terms between sensor and pupil
-        if ((t % 3) != 1 && (t / 3) != 1) { X = Xc + (float)(t % 3 - 1) * hX; Y = Yc + (float)(t / 3 - 1) * hY; }
-      }
-      else if (t == 9) X = Xc + hX;
-      else if (t == 10) X = Xc - hX;
-      else if (t == 11) Y = Yc + hY;
-      else Y = Yc - hY;
-      const float ua = ((float)ci + fu) * invP, ub = ((float)cj + fv) * invP;
-      const StartRay s0 = aim_at_pupil(X, Y, fmaf(2.0f, ua, -1.0f), fmaf(2.0f, ub, -1.0f), a.pupil_h, a.vz, a.geom_norm);
-      r[t] = Ray{X, Y, 0.0f, fmaf(X, X, Y * Y), s0.dx * ns, s0.dy * ns, s0.dz * ns, 0.0f, 0.0f};
+        ru2 = fmaxf(ru2, d2);
+        const float at = (float)(t % 3 - 1), bt = (float)(t / 3 - 1);
+        const bool corner = (t % 3) != 1 && (t / 3) != 1;     // (also displaced to the block's corner)
+        const float mx = ex - fmaf(at, f.g1x, bt * f.g2x) - (corner ? fmaf(at, f.gxx, bt * f.gyx) : 0.0f);
+        const float my = ey - fmaf(at, f.g1y, bt * f.g2y) - (corner ? fmaf(at, f.gxy, bt * f.gyy) : 0.0f);
+        dev2 = fmaxf(dev2, fmaf(mx, mx, my * my));
+      } else if (t < 11) rx2 = fmaxf(rx2, d2);
+      else if (t < 13) ry2 = fmaxf(ry2, d2);
+      else rl2 = fmaxf(rl2, d2);                               // the ends of the spectrum
     }
-    // `live`: bit t = sample t is still on the path (not lost to a missed sphere or to total reflection).  A box
-    // that has lost samples is PARTIAL: what is left of it lies next to a region where the path ends, the map
-    // is steep there, and its footprints are inflated twice as much.
-    unsigned live = 0x1fffu;
-    bool culled = !valid || enabled || firm, keep = false, partial = false;
-    int why = 0;
-    // Footprint of the box in a plane (an interface's, or direction space).  With all 13 samples in use the
-    // image of the box is modelled as a ZONOTOPE: centre c + the four generators g1, g2 (half the cell along the
-    // two pupil axes: central differences of the mid-edge samples), gx, gy (half the block along x and y) + an
-    // isotropic slack for what the linear model misses (largest deviation of the nine pupil samples and of the
-    // edge mid-points from it).  Its extent along a unit vector n is sum |g . n|: a separating-axis test against
-    // a disc needs only that -- far tighter than a ball around c for the elongated footprints of defocused ghosts.
-    // A box that has lost samples falls back to a ball around a sample still in use, inflated twice as much.
-    struct Foot { float cx, cy, g1x, g1y, g2x, g2y, gxx, gxy, gyx, gyy, slack, ball; bool zono; };
-    auto footprint = [&](bool dirs, unsigned use, float eps) {
-      float vx[kCullSamples], vy[kCullSamples];
-#pragma unroll
-      for (int t = 0; t < kCullSamples; t++) { vx[t] = dirs ? r[t].dx : r[t].px; vy[t] = dirs ? r[t].dy : r[t].py; }
-      Foot f;
-      f.zono = use == 0x1fffu;
-      const int ref = (use & 0x10u) ? 4 : (use ? __ffs((int)use) - 1 : 4);
-      f.cx = vx[4]; f.cy = vy[4];
-#pragma unroll
-      for (int t = 0; t < kCullSamples; t++) if (t != 4 && ref == t) { f.cx = vx[t]; f.cy = vy[t]; }
-      f.g1x = 0.5f * (vx[5] - vx[3]); f.g1y = 0.5f * (vy[5] - vy[3]);
-      f.g2x = 0.5f * (vx[7] - vx[1]); f.g2y = 0.5f * (vy[7] - vy[1]);
-      f.gxx = 0.5f * (vx[9] - vx[10]); f.gxy = 0.5f * (vy[9] - vy[10]);
-      f.gyx = 0.5f * (vx[11] - vx[12]); f.gyy = 0.5f * (vy[11] - vy[12]);
-      float dev2 = 0.0f, ru2 = 0.0f, rx2 = 0.0f, ry2 = 0.0f;
-#pragma unroll
-      for (int t = 0; t < kCullSamples; t++) {
-        const float ex = vx[t] - f.cx, ey = vy[t] - f.cy;
-        const float d2 = ((use >> t) & 1u) ? fmaf(ex, ex, ey * ey) : 0.0f;
-        if (t < 9) {
-          ru2 = fmaxf(ru2, d2);
-          const float at = (float)(t % 3 - 1), bt = (float)(t / 3 - 1);
-          const bool corner = (t % 3) != 1 && (t / 3) != 1;     // (also displaced to the block's corner)
-          const float mx = ex - fmaf(at, f.g1x, bt * f.g2x) - (corner ? fmaf(at, f.gxx, bt * f.gyx) : 0.0f);
-          const float my = ey - fmaf(at, f.g1y, bt * f.g2y) - (corner ? fmaf(at, f.gxy, bt * f.gyy) : 0.0f);
-          dev2 = fmaxf(dev2, fmaf(mx, mx, my * my));
-        } else if (t < 11) rx2 = fmaxf(rx2, d2);
-        else ry2 = fmaxf(ry2, d2);
-      }
-      {   // the edge mid-points against the centre: second order along x and y
-        const float mx = 0.5f * (vx[9] + vx[10]) - vx[4], my = 0.5f * (vy[9] + vy[10]) - vy[4];
-        const float nx = 0.5f * (vx[11] + vx[12]) - vx[4], ny = 0.5f * (vy[11] + vy[12]) - vy[4];
-        dev2 = fmaxf(dev2, fmaxf(fmaf(mx, mx, my * my), fmaf(nx, nx, ny * ny)));
-      }
-      const float ru = lf_sqrt(ru2);
-      const float rx = (use & 0x600u) ? lf_sqrt(rx2) : ru, ry = (use & 0x1800u) ? lf_sqrt(ry2) : ru;
-      f.ball = fmaf(partial ? 2.0f * a.margin : a.margin, (ru + rx) + ry, eps);
-      f.slack = fmaf(2.0f, lf_sqrt(dev2), eps);
-      return f;
-    };
-    // extent of the footprint along the unit vector (nx, ny), and along the axes (for the mask's grid)
-    auto extent = [&](const Foot& f, float nx, float ny) {
-      if (!f.zono) return f.ball;
-      const float e = fabsf(fmaf(f.g1x, nx, f.g1y * ny)) + fabsf(fmaf(f.g2x, nx, f.g2y * ny)) +
-                      fabsf(fmaf(f.gxx, nx, f.gxy * ny)) + fabsf(fmaf(f.gyx, nx, f.gyy * ny));
-      return fminf(f.ball, fmaf(a.margin, e, f.slack));
-    };
-    for (int e = 0; e < n_ev; e++) {
-      if (__ballot(!culled && !keep) == 0ull) break;      // every box of the wave is decided
-      const unsigned se = (unsigned)*(const int __attribute__((address_space(4)))*)(seq + e);
-      const LfProgRow wr = load_prec(recs, se & 0xffffu);
-      const unsigned kind = se >> 16;
-      const float cn22 = j == 0 ? wr.cn22[0] : j == 1 ? wr.cn22[1] : wr.cn22[2];
-      const float rn2 = j == 0 ? wr.rn2[0] : j == 1 ? wr.rn2[1] : wr.rn2[2];
-      const float delta = j == 0 ? wr.delta[0] : j == 1 ? wr.delta[1] : wr.delta[2];
-      unsigned hit = 0u, okm = 0u;
-      // the total-reflection margins (virtual_event) of the samples that reach the interface: their range over the
-      // box, and the one nearest to going on among those that end here by total reflection
-      float t_max = -2.0f, t_min = 2.0f, t_lost = -2.0f;
-#pragma unroll
-      for (int t = 0; t < kCullSamples; t++) {
-        bool ok;
-        if (kind & LF_EV_STOP) {
-          const float tt = -(r[t].hz + wr.dzv) * lf_rcp(r[t].dz);
-          const float hx = fmaf(tt, r[t].dx, r[t].px), hy = fmaf(tt, r[t].dy, r[t].py);
-          r[t].px = hx; r[t].py = hy; r[t].hz = 0.0f;
-          ok = hx == hx && hy == hy;
-          if (ok) hit |= 1u << t;
-        } else {
-          float miss, tir;
-          virtual_event(r[t], wr, cn22, rn2, delta, (kind & LF_EV_REFLECT) != 0, (kind & LF_EV_FLAT) != 0, miss, tir);
-          const bool reaches = miss >= 0.0f;
-          if (reaches) hit |= 1u << t;                // (a totally reflected ray did reach the interface)
-          ok = reaches && tir >= 0.0f;
-          if (reaches && ((live >> t) & 1u)) {
-            t_max = fmaxf(t_max, tir); t_min = fminf(t_min, tir);
-            if (tir < 0.0f) t_lost = fmaxf(t_lost, tir);
-          }
-        }
-        if (ok) okm |= 1u << t;
-      }
-      hit &= live;
-      // "Every sample ends here" drops the box only with a margin.  A sample that finds NO intersection needs none:
-      // what lies between it and a sample that does hit meets the sphere further out than the clear aperture reaches.
-      // Total reflection happens INSIDE the clear aperture (the steep rear surface of the front group), and a sliver
-      // of the box may go on between samples that all end: the box is dropped only if even the sample nearest to
-      // going on is further from it than the margins vary over the box (found by comparing with the full
-      // enumeration on frames with larger blocks: pair (3, 7), profiles/r05_march_variants.txt).
-      const bool firmly_lost = t_lost < -1.5f || t_lost < -(fmaf(a.lost_rel, t_max - t_min, a.lost_abs));
-      const Foot f = footprint(false, hit, 1e-3f);
-      live &= okm;
-      if (!culled && !keep) {
-        if (hit == 0u) {                                       // no sample reaches the interface
-          if (firmly_lost && !(a.disable & 8)) { culled = true; why = 7; } else { keep = true; why = 2; }
-        }
-        else {
-          const float cx = f.cx, cy = f.cy;
-          const float cr = lf_sqrt(fmaf(cx, cx, cy * cy));
-          const float icr = cr > 0.0f ? lf_rcp(cr) : 0.0f;
-          const float ext = extent(f, cx * icr, cy * icr), hh = lf_sqrt(wr.h2);
-          if (cr - ext > hh && !(a.disable & 1)) {               // wholly outside the clear aperture
-            culled = true; why = 4;
-            firm = cr - ext - hh > fmaf(0.25f, ext, 0.03f * hh);
-          }
-          else if (kind & LF_EV_STOP) {
-            // ... or on closed cells of the mask: texel coordinate = (h / stop_h + 1) / 2 of the mask's width
-            const float s = 0.5f * (float)kCullOcc;
-            const float radx = extent(f, 1.0f, 0.0f), rady = extent(f, 0.0f, 1.0f);
-            const int ix0 = max(0, (int)floorf(fmaf(cx - radx, a.inv_stop_h, 1.0f) * s));
-            const int ix1 = min(kCullOcc - 1, (int)floorf(fmaf(cx + radx, a.inv_stop_h, 1.0f) * s));
-            const int iy0 = max(0, (int)floorf(fmaf(cy - rady, a.inv_stop_h, 1.0f) * s));
-            const int iy1 = min(kCullOcc - 1, (int)floorf(fmaf(cy + rady, a.inv_stop_h, 1.0f) * s));
-            bool open = false;
-            if (ix0 <= ix1) {
-              const unsigned span = (ix1 - ix0 >= 31 ? 0xffffffffu : ((2u << (ix1 - ix0)) - 1u)) << ix0;
-              for (int iy = iy0; iy <= iy1; iy++) open = open || (a.occ[iy] & span) != 0u;
-            }
-            if (!open && !(a.disable & 2)) { culled = true; why = 5; }
-          }
-          if (!culled) {
-            if (live == 0u && firmly_lost && !(a.disable & 8)) { culled = true; why = 7; }   // every sample ends here, by a margin
-            else if (__popc(live & 0x1ffu) < 3) { keep = true; why = 2; }     // too little left to bound anything
-            else if (live != 0x1fffu) partial = true;
-          }
-        }
-      }
+    {   // the edge mid-points against the centre: second order along x and y
+      const float mx = 0.5f * (vx[9] + vx[10]) - vx[4], my = 0.5f * (vy[9] + vy[10]) - vy[4];
+      const float nx = 0.5f * (vx[11] + vx[12]) - vx[4], ny = 0.5f * (vy[11] + vy[12]) - vy[4];
+      dev2 = fmaxf(dev2, fmaxf(fmaf(mx, mx, my * my), fmaf(nx, nx, ny * ny)));
     }
+    const float ru = lf_sqrt(ru2), rl = lf_sqrt(rl2);
+    const float rx = (use & 0x600u) ? lf_sqrt(rx2) : ru, ry = (use & 0x1800u) ? lf_sqrt(ry2) : ru;
+    f.ball = fmaf(partial ? 2.0f * a.margin : a.margin, ((ru + rx) + ry) + rl, eps);
+    f.slack = fmaf(2.0f, lf_sqrt(dev2), fmaf(a.margin, rl, eps));
+    return f;
+  };
+  // extent of the footprint along the unit vector (nx, ny), and along the axes (for the mask's grid)
+  auto extent = [&](const Foot& f, float nx, float ny) {
+    if (!f.zono) return f.ball;
+    const float e = fabsf(fmaf(f.g1x, nx, f.g1y * ny)) + fabsf(fmaf(f.g2x, nx, f.g2y * ny)) +
+                    fabsf(fmaf(f.gxx, nx, f.gxy * ny)) + fabsf(fmaf(f.gyx, nx, f.gyy * ny));
+    return fminf(f.ball, fmaf(a.margin, e, f.slack));
+  };
+  for (int e = 0; e < n_ev; e++) {
+    if (__ballot(!culled && !keep) == 0ull) break;      // every box of the wave is decided
+    const unsigned se = (unsigned)*(const int __attribute__((address_space(4)))*)(seq + e);
+    const unsigned kind = se >> 16;
+    // the interface once (its geometry is the same in every wavelength group), the index terms of the three wavelengths
+    const LfProgRow wr = load_prec(recs_of[0], se & 0xffffu);
+    float cn22_of[3], rn2_of[3], delta_of[3];
+#pragma unroll
+    for (int w = 0; w < 3; w++) {
+      const LfProgRow x = w == 0 ? wr : load_prec(recs_of[w], se & 0xffffu);
+      const int j = j_of[w];
+      cn22_of[w] = j == 0 ? x.cn22[0] : j == 1 ? x.cn22[1] : x.cn22[2];
+      rn2_of[w] = j == 0 ? x.rn2[0] : j == 1 ? x.rn2[1] : x.rn2[2];
+      delta_of[w] = j == 0 ? x.delta[0] : j == 1 ? x.delta[1] : x.delta[2];
+    }
+    unsigned hit = 0u, okm = 0u;
+    // the total-reflection margins (virtual_event) of the samples that reach the interface: their range over the
+    // box, and the one nearest to going on among those that end here by total reflection
+    float t_max = -2.0f, t_min = 2.0f, t_lost = -2.0f;
+#pragma unroll
+    for (int t = 0; t < kCullSamples; t++) {
+      const int w = t == 13 ? 1 : t == 14 ? 2 : 0;
+      bool ok;
+      if (kind & LF_EV_STOP) {
+        const float tt = -(r[t].hz + wr.dzv) * lf_rcp(r[t].dz);
+        const float hx = fmaf(tt, r[t].dx, r[t].px), hy = fmaf(tt, r[t].dy, r[t].py);
+        r[t].px = hx; r[t].py = hy; r[t].hz = 0.0f;
+        ok = hx == hx && hy == hy;
+        if (ok) hit |= 1u << t;
+      } else {
+        float miss, tir;
+        virtual_event(r[t], wr, cn22_of[w], rn2_of[w], delta_of[w], (kind & LF_EV_REFLECT) != 0, (kind & LF_EV_FLAT) != 0, miss, tir);
+        const bool reaches = miss >= 0.0f;
+        if (reaches) hit |= 1u << t;                // (a totally reflected ray did reach the interface)
+        ok = reaches && tir >= 0.0f;
+        if (reaches && ((live >> t) & 1u)) {
+          t_max = fmaxf(t_max, tir); t_min = fminf(t_min, tir);
+          if (tir < 0.0f) t_lost = fmaxf(t_lost, tir);
+        }
+      }
+      if (ok) okm |= 1u << t;
+    }
+    hit &= live;
+    // "Every sample ends here" drops the box only with a margin.  A sample that finds NO intersection needs none:
+    // what lies between it and a sample that does hit meets the sphere further out than the clear aperture reaches.
+    // Total reflection happens INSIDE the clear aperture (the steep rear surface of the front group), and a sliver
+    // of the box may go on between samples that all end: the box is dropped only if even the sample nearest to
+    // going on is further from it than the margins vary over the box (found by comparing with the full
+    // enumeration on frames with larger blocks: pair (3, 7), profiles/r05_march_variants.txt).
+    const bool firmly_lost = t_lost < -1.5f || t_lost < -(fmaf(a.lost_rel, t_max - t_min, a.lost_abs));
+    const Foot f = footprint(false, hit, 1e-3f);
+    live &= okm;
     if (!culled && !keep) {
-      // the path is complete: where can the box point?  (K is the unit direction in air again)
-      const Foot f = footprint(true, live, 2e-5f);
-      const float ex = a.sx - f.cx, ey = a.sy - f.cy;
-      const float dist = lf_sqrt(fmaf(ex, ex, ey * ey));
-      const float id = dist > 0.0f ? lf_rcp(dist) : 0.0f;
-      const float ext = extent(f, ex * id, ey * id);
-      if (partial && a.keep_partial) { keep = true; why = 1; }
-      else if (dist - ext > a.rho && !(a.disable & 4)) {
-        culled = true; why = 6;
-        firm = dist - ext - a.rho > 0.25f * (ext + a.rho);
-      } else { keep = true; why = partial ? 1 : 3; }
+      if (hit == 0u) {                                       // no sample reaches the interface
+        if (firmly_lost && !(a.disable & 8)) { culled = true; why = 7; } else { keep = true; why = 2; }
+      }
+      else {
+        const float cx = f.cx, cy = f.cy;
+        const float cr = lf_sqrt(fmaf(cx, cx, cy * cy));
+        const float icr = cr > 0.0f ? lf_rcp(cr) : 0.0f;
+        if (cr - extent(f, cx * icr, cy * icr) > lf_sqrt(wr.h2) && !(a.disable & 1)) { culled = true; why = 4; }   // wholly outside the clear aperture
+        else if (kind & LF_EV_STOP) {
+          // ... or on closed cells of the mask: texel coordinate = (h / stop_h + 1) / 2 of the mask's width
+          const float s = 0.5f * (float)kCullOcc;
+          const float radx = extent(f, 1.0f, 0.0f), rady = extent(f, 0.0f, 1.0f);
+          const int ix0 = max(0, (int)floorf(fmaf(cx - radx, a.inv_stop_h, 1.0f) * s));
+          const int ix1 = min(kCullOcc - 1, (int)floorf(fmaf(cx + radx, a.inv_stop_h, 1.0f) * s));
+          const int iy0 = max(0, (int)floorf(fmaf(cy - rady, a.inv_stop_h, 1.0f) * s));
+          const int iy1 = min(kCullOcc - 1, (int)floorf(fmaf(cy + rady, a.inv_stop_h, 1.0f) * s));
+          bool open = false;
+          if (ix0 <= ix1) {
+            const unsigned span = (ix1 - ix0 >= 31 ? 0xffffffffu : ((2u << (ix1 - ix0)) - 1u)) << ix0;
+            for (int iy = iy0; iy <= iy1; iy++) open = open || (a.occ[iy] & span) != 0u;
+          }
+          if (!open && !(a.disable & 2)) { culled = true; why = 5; }
+        }
+        if (!culled) {
+          if (live == 0u && firmly_lost && !(a.disable & 8)) { culled = true; why = 7; }   // every sample ends here, by a margin
+          else if (__popc(live & 0x1ffu) < 3) { keep = true; why = 2; }     // too little left to bound anything
+          else if (live != kAll) partial = true;
+        }
+      }
     }
-    if (stats && valid && why) atomicAdd(&stats[why + 8 * li], 1ull);
-    if (valid && keep) { enabled = true; why_last = why; }
   }
-  (void)why_last;
+  if (!culled && !keep) {
+    // the path is complete: where can the box point?  (K is the unit direction in air again)
+    const Foot f = footprint(true, live, 2e-5f);
+    const float ex = a.sx - f.cx, ey = a.sy - f.cy;
+    const float dist = lf_sqrt(fmaf(ex, ex, ey * ey));
+    const float id = dist > 0.0f ? lf_rcp(dist) : 0.0f;
+    if (partial && a.keep_partial) { keep = true; why = 1; }
+    else if (dist - extent(f, ex * id, ey * id) > a.rho && !(a.disable & 4)) { culled = true; why = 6; }
+    else { keep = true; why = partial ? 1 : 3; }
+  }
+  if (stats && valid && why) atomicAdd(&stats[why], 1ull);
+  const bool enabled = valid && keep;
   if (a.last) {
     if (valid && enabled) {
       unsigned long long* row = table + (size_t)blk * (size_t)(a.P * a.P + 1);
@@ -628,9 +639,7 @@ lf_status lfk_cull_prepass(lf_ctx* ctx, int G) {
   a.P_final = G * m;
   a.n_paths = ctx->pairs.n;
   // dispersion is monotonic in the wavelength: the two ends of the spectrum bracket what lies between
-  a.n_test = std::min(L.n_lambda, 2);
-  a.lam[0] = 0; a.lam[1] = L.n_lambda - 1; a.lam[2] = L.n_lambda - 1;
-  if (std::getenv("LF_CULL_ALL_LAMBDA") && L.n_lambda >= 3) { a.n_test = 3; a.lam[1] = (L.n_lambda - 1) / 2; }
+  a.lam[0] = (L.n_lambda - 1) / 2; a.lam[1] = 0; a.lam[2] = L.n_lambda - 1;
   a.march_k = ctx->march_k; a.prog_recs = ctx->pairs.prog_recs;
   a.pupil_h = L.pupil_h; a.vz = L.pupil_z - L.z_sensor; a.geom_norm = L.geom_norm;
   a.stop_h = L.stop_h; a.inv_stop_h = 1.0f / L.stop_h;
@@ -724,10 +733,7 @@ lf_status lfk_cull_prepass(lf_ctx* ctx, int G) {
     // the kernel reads its input with the stride it was written with and writes with the new one
     CullLevelArgs k = a;
     k.list_stride = a.last ? in_stride : out_stride;
-    if (!a.last && !std::getenv("LF_CULL_ALL_LAMBDA")) {
-      // coarse boxes: their inflation dwarfs the dispersion -- the middle of the spectrum alone
-      k.n_test = 1; k.lam[0] = (L.n_lambda - 1) / 2;
-    }
+
     // (two strides are needed when reading AND writing: the input's travels in `items_stride`)
     const dim3 grid((unsigned)((n_items + 255) / 256), (unsigned)a.n_paths);
     hipLaunchKernelGGL(k_cull_level, grid, dim3(256), 0, ctx->stream, ctx->lens_dev, ctx->pairs_dev,
@@ -744,9 +750,7 @@ lf_status lfk_cull_prepass(lf_ctx* ctx, int G) {
       LF_HIP(ctx, hipMemcpy(hs, stats_dev, sizeof(hs), hipMemcpyDeviceToHost));
       static const char* names[8] = {"", "kept_inside_lobe_partial_box", "kept_too_few_samples_left", "kept_inside_lobe",
                                      "culled_aperture", "culled_mask", "culled_lobe", "culled_all_samples_lost"};
-      for (int li = 0; li < a.n_test; li++)
-        for (int w = 1; w < 8; w++)
-          std::fprintf(stderr, "CULL_STATS P %d lambda %d %s %llu\n", a.P, a.lam[li], names[w], hs[w + 8 * li]);
+      for (int w = 1; w < 8; w++) std::fprintf(stderr, "CULL_STATS P %d %s %llu\n", a.P, names[w], hs[w]);
     }
     if (!a.last) {
       // how long the next level's lists are: the grid needs the longest

@@ -703,7 +703,7 @@ __global__ void k_march_finish(const unsigned long long* __restrict__ accum, Mar
 // (sun_radiance[c] * lambda_rgb[l][c]) <= geom_norm x that product, into 64-bit sums per pixel and channel: the
 // largest sum a launch can produce is spp x paths x geom_norm x max_c sum_l (radiance[c] * lambda_rgb[l][c]).
 // bits = 36 (the grid of rounds 1-4: every golden and oracle comparison holds) unless that bound times 2^bits
-// reaches 2^62; then the largest exponent that keeps it below (an HDR sun of 1e7 at 1024 spp x 8 wavelengths: 2^25).
+// reaches 2^62; then the largest exponent that keeps it below (a sun of radiance 1e9 at 1024 spp x 8 wavelengths: 2^17).
 // The result is scale-covariant: a frame at radiance 2^k x L is 2^k x the frame at L, bit for bit, once both
 // leave the default grid.  Mirrored by oracle/lf_geo_oracle.c (geo_fix_bits).
 int lf_march_fix_bits(const LfLensDev& L, int n_paths, int spp) {

@@ -1,8 +1,8 @@
 """Range contract of the march's accumulators (include/lensflare.h, "RANGE CONTRACT"; round 5).  A pixel
 channel is a sum of unsigned 64-bit fixed-point contributions: negative or non-finite radiances / spectral
-weights are refused, and the grid's exponent is chosen per launch so that no sum can wrap -- an HDR sun of
-radiance 1e7 at 1024 spp x 8 wavelengths is this path's use case (on the 2^-36 grid of rounds 1-4 its image
-wrapped near radiance 2e6).  No reference counterpart (the reference's ghosts are f64 sums,
+weights are refused, and the grid's exponent is chosen per launch so that no sum can wrap -- an HDR sun is this
+path's use case: on the fixed 2^-36 grid of rounds 1-4 a pixel channel wrapped once sum v >= 2^28, which the sun's
+own image on the test frame below reaches at a radiance of 6.5e7 (1024 spp x 8 wavelengths).  No reference counterpart (the reference's ghosts are f64 sums,
 src/pathtracer/pathtracer.cpp:305-410)."""
 import numpy as np
 import pytest
@@ -58,22 +58,22 @@ def test_hdr_sun_does_not_wrap_and_bad_inputs_are_refused(pkg):
             return lf.read_buffer(pkg.GHOST_BUFFER), lf.counters(), lf.march_fix_bits()
 
         one, c1, b1 = frame(1.0)
-        big, c7, b7 = frame(1e7)
+        big, c7, b7 = frame(1e9)
         assert b1 == 36 and b7 < 36 and c1 == c7
         assert one.max() > 0
         # the old grid WOULD have wrapped: the brightest channel's sum exceeds 2^28 (2^64 / 2^36)
         assert big.max() * spp >= 2.0 ** 28
-        # ... and the new one did not: 1e7 x the radiance-1 frame (float rounding of each contribution's
+        # ... and the new one did not: 1e9 x the radiance-1 frame (float rounding of each contribution's
         # radiance product, 2^-24 relative, + one grid step per contribution)
         lit = one > 0
         step = 2.0 ** -b7
         n_contrib = spp * 46 * 8
-        assert np.all(np.abs(big - 1e7 * one)[lit] <= 2e-7 * 1e7 * one[lit] + step * n_contrib / spp + 1e7 * 2.0 ** -36 * n_contrib / spp)
+        assert np.all(np.abs(big - 1e9 * one)[lit] <= 2e-7 * 1e9 * one[lit] + step * n_contrib / spp + 1e9 * 2.0 ** -36 * n_contrib / spp)
         assert np.all(big[~lit] <= step * n_contrib / spp)
-        # the oracle follows the exponent: bit for bit at 1e7
+        # the oracle follows the exponent: bit for bit at 1e9
         lfo.geo_follow_device(lf)
         try:
-            og, oc = lfo.geo_trace(lens, W, H, 0, H, spp, key, None, True, mask, sun, [1e7, 0.9e7, 0.5e7], 0.05,
+            og, oc = lfo.geo_trace(lens, W, H, 0, H, spp, key, None, True, mask, sun, [1e9, 0.9e9, 0.5e9], 0.05,
                                    n_threads=16, lambda_rgb=w8)
         finally:
             lfo.geo_follow_device(None)

@@ -348,7 +348,7 @@ def test_a_poisoned_context_refuses_communicator_calls_and_still_renders(pkg):
         with pytest.raises(pkg.LensFlareError) as e:
             call()
         assert e.value.status == 4          # LF_ERR_STATE
-    assert lf.comm_info() == (1, 0)         # no communicator was published
+    assert lf.comm_info() == (0, -1)        # no communicator was published
     lf.comm_abort()                         # still allowed, nothing to end
     _frame(lf, 4, 5)
     assert np.array_equal(lf.read_buffer(pkg.SAMPLE_BUFFER), before)
