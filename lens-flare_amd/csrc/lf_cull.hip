@@ -368,7 +368,11 @@ __global__ __launch_bounds__(256) void k_cull_level(const LfLensDev* __restrict_
 constexpr int kWgWaves = 8;
 constexpr int kListMax = 4096;   // samples of one tile's workgroup (spp / sgroups) listed at a time
 
-template <int K>
+// W1: the first (and then only) march of a started path carries its Fresnel / aperture weight.  false = geometry first,
+// and the path is marched again with the weight, one wavelength at a time, only where a lane ended inside the lobe
+// pre-test (k_march's scheme: 6 % of the STARTED rays are lit on the bench frame, so the weight's 17 of 44 vector
+// instructions per event are mostly wasted in the first march: measured in profiles/r05_march_variants.txt).
+template <int K, bool W1>
 __global__ __launch_bounds__(64 * kWgWaves, (K == 1 ? 8 : 6))
 void k_march_cull(const LfLensDev* __restrict__ lens, const LfPairsDev* __restrict__ pairs,
                   const int* __restrict__ seq_table, const LfProgRow* __restrict__ rec_table,
@@ -416,6 +420,7 @@ void k_march_cull(const LfLensDev* __restrict__ lens, const LfPairsDev* __restri
 
   unsigned n_light = 0;                  // per lane
   unsigned long long n_rays = 0, events = 0, n_clip = 0, n_vign = 0, n_tir = 0, n_scene = 0;   // per wave
+  unsigned long long n_rm_lane = 0, n_rm_rows = 0;   // the weight re-march (W1 = false; lf_get_march_stats)
 
   const int n_mine = (a.spp - sg + a.sgroups - 1) / a.sgroups;     // samples sg, sg + sgroups, ...
   for (int chunk0 = 0; chunk0 < n_mine; chunk0 += kListMax) {
@@ -488,14 +493,16 @@ void k_march_cull(const LfLensDev* __restrict__ lens, const LfPairsDev* __restri
             const unsigned cur = se;
             if (e + 1 < n_ev) se = (unsigned)*(const int __attribute__((address_space(4)))*)(seq + e + 1);
             const LfProgRow wr = load_prec(recs, cur & 0xffffu);
-            const LfWeightRow ww = load_wrec(wrecs, cur & 0xffffu);
+            LfWeightRow ww;
+            if (W1) ww = load_wrec(wrecs, cur & 0xffffu);
+            else { for (int j = 0; j < 3; j++) { ww.fs[j] = 1.0f; ww.fo[j] = 1.0f; ww.fi[j] = 1.0f; } }
             const unsigned kind = cur >> 16;
             lanemask okv[K], gv[K], died = 0ull;
             if (kind & LF_EV_STOP) {
 #pragma unroll
               for (int j = 0; j < K; j++) {
                 if (K > 1 && __builtin_expect(alive[j] == 0ull, 0)) { okv[j] = 0ull; gv[j] = 0ull; continue; }
-                okv[j] = stop_event<true>(r[j], wr.dzv, wr.h2, inv_stop_h, mask, a.mw, a.mh);
+                okv[j] = stop_event<W1>(r[j], wr.dzv, wr.h2, inv_stop_h, mask, a.mw, a.mh);
                 gv[j] = okv[j];
                 died |= alive[j] & ~okv[j];
               }
@@ -511,17 +518,17 @@ void k_march_cull(const LfLensDev* __restrict__ lens, const LfPairsDev* __restri
 #pragma unroll
                 for (int j = 0; j < K; j++) {
                   if (K > 1 && __builtin_expect(alive[j] == 0ull, 0)) { okv[j] = 0ull; gv[j] = 0ull; continue; }
-                  okv[j] = surface_event<true>(r[j], wr.dzv, wr.curv, wr.ch, wr.c2, wr.sc, wr.cn22[j], wr.rn2[j],
-                                               wr.delta[j], wr.h2, false, false, wr.sgn, gv[j], ww.fs[j], ww.fo[j], ww.fi[j]);
+                  okv[j] = surface_event<W1>(r[j], wr.dzv, wr.curv, wr.ch, wr.c2, wr.sc, wr.cn22[j], wr.rn2[j],
+                                             wr.delta[j], wr.h2, false, false, wr.sgn, gv[j], ww.fs[j], ww.fo[j], ww.fi[j]);
                   died |= alive[j] & ~okv[j];
                 }
               } else {
 #pragma unroll
                 for (int j = 0; j < K; j++) {
                   if (K > 1 && __builtin_expect(alive[j] == 0ull, 0)) { okv[j] = 0ull; gv[j] = 0ull; continue; }
-                  okv[j] = surface_event<true>(r[j], wr.dzv, wr.curv, wr.ch, wr.c2, wr.sc, wr.cn22[j], wr.rn2[j],
-                                               wr.delta[j], wr.h2, (kind & LF_EV_REFLECT) != 0, (kind & LF_EV_FLAT) != 0,
-                                               wr.sgn, gv[j], ww.fs[j], ww.fo[j], ww.fi[j]);
+                  okv[j] = surface_event<W1>(r[j], wr.dzv, wr.curv, wr.ch, wr.c2, wr.sc, wr.cn22[j], wr.rn2[j],
+                                             wr.delta[j], wr.h2, (kind & LF_EV_REFLECT) != 0, (kind & LF_EV_FLAT) != 0,
+                                             wr.sgn, gv[j], ww.fs[j], ww.fo[j], ww.fi[j]);
                   died |= alive[j] & ~okv[j];
                 }
               }
@@ -541,17 +548,52 @@ void k_march_cull(const LfLensDev* __restrict__ lens, const LfPairsDev* __restri
           if (nlive == 0u) continue;
           // ---- the path is complete for nlive rays --------------------------------------------------
           n_scene += nlive;
+          lanemask lit[K], lit_any = 0ull;
 #pragma unroll
           for (int j = 0; j < K; j++) {
-            if (alive[j] == 0ull) continue;
-            const int l = g * K + j;
             const float cg = fmaf(r[j].dx, sx, fmaf(r[j].dy, sy, r[j].dz * sz));
-            const lanemask lit = alive[j] & __ballot(cg > lobe_thr);
-            if (lit == 0ull) continue;
-            const float qq = lobe_q(r[j].dx, r[j].dy, r[j].dz, sx, sy, sz, sun_ss, inv_1mc);
+            lit[j] = alive[j] & __ballot(cg > lobe_thr);
+            lit_any |= lit[j];
+          }
+          if (lit_any == 0ull) continue;
+          for (int j = 0; j < K; j++) {        // not unrolled (W1 = false): one copy of the weighted march
+            lanemask lj = lit[0];
+#pragma unroll
+            for (int jj = 1; jj < K; jj++) lj = (j == jj) ? lit[jj] : lj;
+            if (lj == 0ull) continue;
+            const int l = g * K + j;
+            Ray rw = j == 0 ? r[0] : j == 1 ? r[K > 1 ? 1 : 0] : r[K > 2 ? 2 : 0];
+            if (!W1) {
+              // the path again, alone and with its weight: the same arithmetic on the ray, so the same ray bit for bit
+              rw = Ray{X, Y, 0.0f, fmaf(X, X, Y * Y), s0.dx, s0.dy, s0.dz, s0.w0, 1.0f};
+              { const float ns = lens->n_start[l]; rw.dx *= ns; rw.dy *= ns; rw.dz *= ns; }
+              n_rm_lane += (unsigned long long)((unsigned)n_ev * (unsigned)__popcll(lj));
+              n_rm_rows += (unsigned)n_ev;
+              const int* w = seq;
+              for (int left = n_ev; left > 0; --left, ++w) {
+                const unsigned se2 = (unsigned)*(const int __attribute__((address_space(4)))*)(w);
+                const LfProgRow wr = load_prec(recs, se2 & 0xffffu);
+                const LfWeightRow ww = load_wrec(wrecs, se2 & 0xffffu);
+                const unsigned wfl = se2 >> 16;
+                const float w_cn22 = j == 0 ? wr.cn22[0] : j == 1 ? wr.cn22[1] : wr.cn22[2];
+                const float w_rn2 = j == 0 ? wr.rn2[0] : j == 1 ? wr.rn2[1] : wr.rn2[2];
+                const float w_delta = j == 0 ? wr.delta[0] : j == 1 ? wr.delta[1] : wr.delta[2];
+                const float w_fs = j == 0 ? ww.fs[0] : j == 1 ? ww.fs[1] : ww.fs[2];
+                const float w_fo = j == 0 ? ww.fo[0] : j == 1 ? ww.fo[1] : ww.fo[2];
+                const float w_fi = j == 0 ? ww.fi[0] : j == 1 ? ww.fi[1] : ww.fi[2];
+                if (wfl & LF_EV_STOP) {
+                  (void)stop_event<true>(rw, wr.dzv, wr.h2, inv_stop_h, mask, a.mw, a.mh);
+                } else {
+                  lanemask geom_ok;
+                  (void)surface_event<true>(rw, wr.dzv, wr.curv, wr.ch, wr.c2, wr.sc, w_cn22, w_rn2, w_delta, wr.h2,
+                                            (wfl & LF_EV_REFLECT) != 0, (wfl & LF_EV_FLAT) != 0, wr.sgn, geom_ok, w_fs, w_fo, w_fi);
+                }
+              }
+            }
+            const float qq = lobe_q(rw.dx, rw.dy, rw.dz, sx, sy, sz, sun_ss, inv_1mc);
             const float om = 1.0f - qq;
-            float contrib = __fdiv_rn(r[j].wn, r[j].wd) * (om * om);
-            contrib = (((lit >> lane) & 1ull) != 0ull && qq < 1.0f && contrib > 0.0f) ? contrib : 0.0f;
+            float contrib = __fdiv_rn(rw.wn, rw.wd) * (om * om);
+            contrib = (((lj >> lane) & 1ull) != 0ull && qq < 1.0f && contrib > 0.0f) ? contrib : 0.0f;
             n_light += contrib > 0.0f ? 1u : 0u;
 #pragma unroll
             for (int c = 0; c < 3; c++) {
@@ -573,7 +615,7 @@ void k_march_cull(const LfLensDev* __restrict__ lens, const LfPairsDev* __restri
   {
     unsigned long long v6 = n_light;
     for (int off = 32; off > 0; off >>= 1) v6 += __shfl_down(v6, off);
-    const unsigned long long vals[kMarchCounters] = {n_rays, events, n_clip, n_vign, n_tir, n_scene, v6, events, 0ull, 0ull};
+    const unsigned long long vals[kMarchCounters] = {n_rays, events, n_clip, n_vign, n_tir, n_scene, v6, events, n_rm_lane, n_rm_rows};
     if (lane == 0) {
 #pragma unroll
       for (int i = 0; i < kMarchCounters; i++)
@@ -782,18 +824,21 @@ lf_status lfk_march_culled(lf_ctx* ctx, const MarchArgs& a, size_t blocks, size_
   c.table = ctx->cull_dev; c.blocks_x = ctx->cull_bx; c.blocks_y = ctx->cull_by; c.cells = ctx->cull_cells;
   c.P = ctx->cull_P; c.m = ctx->cull_m; c.m_shift = ctx->cull_m == 4 ? 2 : ctx->cull_m == 2 ? 1 : 0;
   hipEvent_t ev = lf_timing_begin(ctx, LFK_MARCH);
-#define LF_LAUNCH_CULL(KK)                                                                                   \
-  hipLaunchKernelGGL(k_march_cull<KK>, dim3((unsigned)blocks), dim3(64 * kWgWaves), dyn_lds, ctx->stream, ctx->lens_dev, \
+#define LF_LAUNCH_CULL1(KK, WW)                                                                               \
+  hipLaunchKernelGGL((k_march_cull<KK, WW>), dim3((unsigned)blocks), dim3(64 * kWgWaves), dyn_lds, ctx->stream, ctx->lens_dev, \
                      ctx->pairs_dev, (const int*)(ctx->prog_dev + ctx->prog_seq_off),                         \
                      (const LfProgRow*)(ctx->prog_dev + ctx->prog_rec_off),                                  \
                      (const LfWeightRow*)(ctx->prog_dev + ctx->prog_wrec_off), m.texels, a, c, ctx->ghost,   \
                      ctx->accum, ctx->counters_dev)
+#define LF_LAUNCH_CULL(KK) do { if (weights_first) LF_LAUNCH_CULL1(KK, true); else LF_LAUNCH_CULL1(KK, false); } while (0)
+  const bool weights_first = std::getenv("LF_CULL_WEIGHTS_FIRST") != nullptr;   // experiments only
   switch (ctx->march_k) {
     case 1: LF_LAUNCH_CULL(1); break;
     case 2: LF_LAUNCH_CULL(2); break;
     default: LF_LAUNCH_CULL(3); break;
   }
 #undef LF_LAUNCH_CULL
+#undef LF_LAUNCH_CULL1
   lf_timing_end(ctx, LFK_MARCH, ev);
   LF_HIP(ctx, hipGetLastError());
   return LF_OK;

@@ -48,7 +48,7 @@ def _gpu_frame(pkg, lf, lens, W, H, spp, key, mask, sun, rad, alpha, sub_bits=No
     return img, cnt
 
 
-def _check_against_f64(img, cnt, ref, frag, c64, min_lit, median_bar=2e-6):
+def _check_against_f64(img, cnt, ref, frag, c64, min_lit, median_bar=2e-6, culled=False):
     assert c64["rays_launched"] == cnt["rays_launched"]
     lit = ref >= FLOOR
     assert lit.sum() >= min_lit, "the test frame must have converged pixels above the floor"
@@ -80,7 +80,9 @@ def _check_against_f64(img, cnt, ref, frag, c64, min_lit, median_bar=2e-6):
     assert np.all(np.abs(img - ref)[~lit] <= TOL * FLOOR + 1.05 * frag[~lit])
     # ray fates agree except for the fragile rays
     n_frag = c64["rays_fragile"]
-    assert n_frag < 1e-2 * c64["rays_launched"]
+    # (fragile rays are the rare ones -- 0.3 % of a full enumeration; a culled launch starts few rays besides those
+    # that pass near an edge of something, so there they are a larger part of what is counted: 1.3 % on the c3 band)
+    assert n_frag < (5e-2 if culled else 1e-2) * c64["rays_launched"]
     for name in ("rays_clipped_stop", "rays_vignetted", "rays_tir", "rays_reached_scene", "rays_hit_light"):
         assert abs(c64[name] - cnt[name]) <= n_frag, (name, c64[name], cnt[name])
     assert abs(c64["surface_events"] - cnt["surface_events"]) <= 30 * n_frag
@@ -230,7 +232,7 @@ def _band_against_f64(pkg, lf, lens, W, H, y0, y1, spp, key, mask, lambda_rgb=No
             print(f"  allowance: {int(over.sum())} of {int(lit.sum())} lit values outside 1e-4; deviation / fragile weight "
                   f"histogram {hist.tolist()}, max {ratio.max():.3f}; largest raw deviation {rel.max():.2e}")
         return rel, int(over.sum()), c64
-    rel = _check_against_f64(img, cnt, ref, frag, c64, min_lit=min_lit, median_bar=median_bar)
+    rel = _check_against_f64(img, cnt, ref, frag, c64, min_lit=min_lit, median_bar=median_bar, culled=lf.cull_info()["culled"])
     lit = ref >= FLOOR
     needed = (np.abs(img - ref)[lit] > TOL * ref[lit]).sum()
     return rel, needed, c64
