@@ -729,9 +729,7 @@ def main():
                 "hbm": {"achieved": hbm_achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                         "frac": hbm_achieved / HBM_PEAK_GBS, "algorithmic_bytes_per_launch": alg_bytes,
                         "traffic_bytes_per_launch": None}}
-        # (the culled march evaluates the Fresnel weight on EVERY event it executes; the path tree on the re-marched ones)
-        weighted_events = executed if cull_info["culled"] else remarch_lane
-        alg_flop_s = (executed * FLOP_PER_EVENT + weighted_events * FLOP_PER_FRESNEL) / dt / world
+        alg_flop_s = (executed * FLOP_PER_EVENT + remarch_lane * FLOP_PER_FRESNEL) / dt / world
         roof["flops"] = {"achieved": alg_flop_s / 1e12, "peak": FP32_PEAK_TFLOPS, "unit": "TFLOP/s",
                          "frac": alg_flop_s / 1e12 / FP32_PEAK_TFLOPS,
                          "algorithmic_flop_per_executed_event": FLOP_PER_EVENT,
@@ -801,7 +799,7 @@ def main():
             # RECORDED measurement (c3 frame, a timing-only build) -- it is not measured by this run.
             "event_accounting": {
                 "every_event_weighted": every_event_weighted(),
-                "fresnel_evaluated_fraction": (1.0 if cull_info["culled"] else remarch_lane / executed) if executed else None,
+                "fresnel_evaluated_fraction": remarch_lane / executed if executed else None,
                 "remarch_events": remarch_lane / args.steps,
                 "remarch_rows_x64": 64.0 * remarch_rows / args.steps,
                 "remarch_rows_over_executed": 64.0 * remarch_rows / executed if executed else None,

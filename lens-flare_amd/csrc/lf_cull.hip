@@ -417,6 +417,9 @@ void k_march_cull(const LfLensDev* __restrict__ lens, const LfPairsDev* __restri
   const float inv_1mc = lens->sun_inv_one_minus_cos, sun_ss = lens->sun_ss;
   const float lobe_thr = a.lobe_thr;
   const int GG = a.G * a.G;
+  // do the lanes of a wave aim a stratified sample at ONE cell of the table?  (they share a sub-cell of the stratum;
+  // the table has m cells per stratum axis)
+  const bool per_lane = (1 << a.sub_bits) < cull.m;
 
   unsigned n_light = 0;                  // per lane
   unsigned long long n_rays = 0, events = 0, n_clip = 0, n_vign = 0, n_tir = 0, n_scene = 0;   // per wave
@@ -428,15 +431,15 @@ void k_march_cull(const LfLensDev* __restrict__ lens, const LfPairsDev* __restri
     const int chunk_n = min(kListMax, n_mine - chunk0);
     for (int k = tid; k < chunk_n; k += 64 * kWgWaves) {
       const int s = sg + (chunk0 + k) * a.sgroups;
-      int entry = cull.cells;
-      if (s < GG) {
+      bool work = true;     // (a sample whose lanes look their cells up one by one is listed: the sample loop finds out)
+      if (s < GG && !per_lane) {
         // the table cell of the sub-cell the wave's lanes all aim sample s at (the draw of the sample loop below)
         const uint4 r2 = philox4x32_10(make_uint4(tile_id, (unsigned)s, kDomainSubcell, 0u), a.key);
         const unsigned sxi = a.sub_bits ? (r2.x >> (32 - a.sub_bits)) : 0u, syi = a.sub_bits ? (r2.y >> (32 - a.sub_bits)) : 0u;
         const int cy = s / a.G, cx = s - cy * a.G;
-        entry = (cy * cull.m + (int)((syi << cull.m_shift) >> a.sub_bits)) * cull.P + cx * cull.m + (int)((sxi << cull.m_shift) >> a.sub_bits);
+        work = crow[(cy * cull.m + (int)((syi << cull.m_shift) >> a.sub_bits)) * cull.P + cx * cull.m + (int)((sxi << cull.m_shift) >> a.sub_bits)] != 0ull;
       }
-      if (crow[entry] != 0ull) s_list[atomicAdd(&s_nlist, 1)] = (unsigned short)k;
+      if (work) s_list[atomicAdd(&s_nlist, 1)] = (unsigned short)k;
     }
     __syncthreads();
     const int n_list = s_nlist;
@@ -450,7 +453,7 @@ void k_march_cull(const LfLensDev* __restrict__ lens, const LfPairsDev* __restri
       const uint4 rnd = philox4x32_10(make_uint4(p, (unsigned)s, kDomainMarch, 0u), a.key);
       const float jx = u01(rnd.x), jy = u01(rnd.y);
       float ua = u01(rnd.z), ub = u01(rnd.w);
-      int entry = cull.cells;
+      int entry = -1;
       if (s < GG) {
         const int cy = s / a.G, cx = s - cy * a.G;
         const uint4 r2 = philox4x32_10(make_uint4(tile_id, (unsigned)s, kDomainSubcell, 0u), a.key);
@@ -458,9 +461,20 @@ void k_march_cull(const LfLensDev* __restrict__ lens, const LfPairsDev* __restri
         const unsigned syi = a.sub_bits ? (r2.y >> (32 - a.sub_bits)) : 0u;
         ua = ((float)cx + ((float)sxi + ua) * a.inv_sub) * a.inv_G;
         ub = ((float)cy + ((float)syi + ub) * a.inv_sub) * a.inv_G;
-        entry = (cy * cull.m + (int)((syi << cull.m_shift) >> a.sub_bits)) * cull.P + cx * cull.m + (int)((sxi << cull.m_shift) >> a.sub_bits);
+        if (!per_lane) entry = (cy * cull.m + (int)((syi << cull.m_shift) >> a.sub_bits)) * cull.P + cx * cull.m + (int)((sxi << cull.m_shift) >> a.sub_bits);
       }
-      const unsigned long long todo = crow[entry];                    // the paths to start (scalar load)
+      // the paths to start: one scalar load for the wave -- or, where the lanes aim at different cells of the table
+      // (independent pixels, an unstratified sample), each lane's own mask and their union
+      unsigned long long mine, todo;
+      if (entry >= 0) { todo = crow[entry]; mine = todo; }
+      else {
+        const int fx = min(cull.P - 1, (int)(ua * (float)cull.P)), fy = min(cull.P - 1, (int)(ub * (float)cull.P));
+        mine = active ? crow[fy * cull.P + fx] : 0ull;
+        unsigned lo = (unsigned)mine, hi = (unsigned)(mine >> 32);
+        for (int off = 32; off > 0; off >>= 1) { lo |= __shfl_xor(lo, off); hi |= __shfl_xor(hi, off); }
+        todo = ((unsigned long long)__builtin_amdgcn_readfirstlane(hi) << 32) | (unsigned long long)__builtin_amdgcn_readfirstlane(lo);
+        if (todo == 0ull) continue;
+      }
       const float pa = fmaf(2.0f, ua, -1.0f), pb = fmaf(2.0f, ub, -1.0f);
       const float X = -(((float)x + jx) - half_w) * pitch;
       const float Y = -(((float)y + jy) - half_h) * pitch;
@@ -472,6 +486,7 @@ void k_march_cull(const LfLensDev* __restrict__ lens, const LfPairsDev* __restri
         left_q &= left_q - 1ull;
         const int n_ev = pairs->ev_cnt[q];
         const int* const seq = seq_table + pairs->ev_off[q];
+        const lanemask start_mask = active_mask & __ballot(((mine >> q) & 1ull) != 0ull);   // (all active lanes when the wave shares a cell)
         for (int g = 0; g < n_groups; g++) {
           const LfProgRow* const recs = rec_table + (size_t)g * (size_t)prog_recs;
           const LfWeightRow* const wrecs = wrec_table + (size_t)g * (size_t)prog_recs;
@@ -483,7 +498,7 @@ void k_march_cull(const LfLensDev* __restrict__ lens, const LfPairsDev* __restri
             r[j] = Ray{X, Y, 0.0f, fmaf(X, X, Y * Y), s0.dx, s0.dy, s0.dz, s0.w0, 1.0f};
             const float ns = lens->n_start[min(g * K + j, n_lambda - 1)];
             r[j].dx *= ns; r[j].dy *= ns; r[j].dz *= ns;
-            alive[j] = (g * K + j < n_lambda) ? active_mask : 0ull;
+            alive[j] = (g * K + j < n_lambda) ? start_mask : 0ull;
             nlive += (unsigned)__popcll(alive[j]);
           }
           n_rays += nlive;
@@ -648,12 +663,14 @@ uint64_t fnv(uint64_t h, const void* data, size_t n) {
 
 }  // namespace
 
-// table cells per axis inside one stratum: as fine as the sampling specification lets a wave know where it is
-// (its lanes share ONE of 2^sub_bits sub-cells per axis), at most 4, and a table of at most 128 cells per axis
+// table cells per axis inside one stratum: 4, in a table of at most 128 cells per axis.  Where a wave's lanes share
+// one sub-cell of the stratum (2^sub_bits >= m sub-cells per axis) the wave looks its cell up ONCE; otherwise
+// (independent pixels, unstratified samples) every lane looks up the cell of its own pupil point.
 static int cull_m(const lf_ctx* ctx, int G) {
+  (void)ctx;
   int m = 4;
   if (const char* e = std::getenv("LF_CULL_M")) m = std::max(1, std::atoi(e));   // experiments only
-  while (m > 1 && (m > (1 << ctx->march_sub_bits) || G * m > 128)) m >>= 1;
+  while (m > 1 && G * m > 128) m >>= 1;
   return m;
 }
 

@@ -305,6 +305,7 @@ void g64_set_x_window(int x0, int x1) { g64_x0 = x0; g64_x1 = x1; }
 
 /* The estimator's sample: sensor point and rear-pupil point of sample s of
  * pixel (x, y).  Returns the start direction and the start weight. */
+static _Thread_local double t64_ua = 0.5, t64_ub = 0.5;   /* the pupil-square point of this thread's last sample_ray */
 static double sample_ray(const g64_lens* L, const g64_system* S, int W, int H, int x, int y, int s, int spp,
                          int sub_bits, const uint32_t key[2], vec* origin, vec* dir) {
   const uint32_t ctr[4] = {(uint32_t)(y * W + x), (uint32_t)s, 0x6e5f1a2eu, 0u};
@@ -328,6 +329,7 @@ static double sample_ray(const g64_lens* L, const g64_system* S, int W, int H, i
     ua = (cx + (sx + ua) / sub) / G;
     ub = (cy + (sy + ub) / sub) / G;
   }
+  t64_ua = ua; t64_ub = ub;
   const double pitch = L->sensor_w_mm / W;
   const double X = -((x + unit_interval(rnd[0])) - 0.5 * W) * pitch;
   const double Y = -((y + unit_interval(rnd[1])) - 0.5 * H) * pitch;
@@ -388,8 +390,13 @@ void g64_trace(const g64_lens* L, int W, int H, int y0, int y1, int spp, const u
         if (g64_cull) {
           /* P = G m table cells per axis; the cell of the sub-cell the pixel's wave tile aims sample s at */
           int entry = g64_cull_cells;
-          if (s < GG) {
-            const int P = (int)(sqrt((double)g64_cull_cells) + 0.5), m = P / G;
+          const int P = (int)(sqrt((double)g64_cull_cells) + 0.5), m = P / G;
+          if (s >= GG || (1 << sub_bits) < m) {   /* the cell of the pixel's own pupil point (the device: in float) */
+            int fx = (int)(t64_ua * P), fy = (int)(t64_ub * P);
+            if (fx > P - 1) fx = P - 1;
+            if (fy > P - 1) fy = P - 1;
+            entry = fy * P + fx;
+          } else {
             const int cy = s / G, cx = s % G;
             const int per_block = 1 << g64_xs, block_w = 8 * per_block;
             const int tiles_x = ((W + block_w - 1) / block_w) * per_block;

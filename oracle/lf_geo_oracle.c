@@ -316,6 +316,8 @@ static void aim_at_pupil(const geo_derived* D, float X, float Y, float pa, float
   r->wd = 1.0f;
 }
 
+/* the pupil-square coordinates of the last start_ray of this thread (the device's cull table is looked up by them) */
+static _Thread_local float t_ua = 0.5f, t_ub = 0.5f;
 static float start_ray(const geo_derived* D, int W, int H, int x, int y, int s, int G,
                        const uint32_t key[2], const uint32_t rnd[4], geo_ray* r) {
   float jx = unit24(rnd[0]), jy = unit24(rnd[1]);
@@ -333,6 +335,7 @@ static float start_ray(const geo_derived* D, int W, int H, int x, int y, int s, 
     ua = ((float)cx + ((float)sxi + ua) * inv_sub) * inv_g;
     ub = ((float)cy + ((float)syi + ub) * inv_sub) * inv_g;
   }
+  t_ua = ua; t_ub = ub;
   float pa = fmaf(2.0f, ua, -1.0f), pb = fmaf(2.0f, ub, -1.0f);
   float X = -(((float)x + jx) - 0.5f * (float)W) * D->pitch;
   float Y = -(((float)y + jy) - 0.5f * (float)H) * D->pitch;
@@ -462,11 +465,18 @@ void geo_trace(const geo_lens* L, int W, int H, int y0, int y1, int spp, const u
         start_ray(&D, W, H, x, y, s, strata(spp), key, rnd, &r0);
         uint64_t started = ~(uint64_t)0;
         if (g_cull) {
-          /* the table cell of the sub-cell this pixel's wave tile aims sample s at: P = G m cells per axis, m x m
-           * inside the stratum (cx, cy), the one that holds sub-cell (sxi, syi) of start_ray's draw */
+          /* The table cell of the pupil point the sample aims at; P = G m cells per axis.  A stratified sample of a
+           * specification with at least m sub-cells per stratum axis: the cell of the sub-cell (sxi, syi) the pixel's
+           * wave tile drew (one scalar lookup per wave on the device).  Otherwise -- independent pixels, an
+           * unstratified sample -- the cell that holds the pixel's own point: floor(ua P), floor(ub P) in float. */
           int entry = g_cull_cells;
-          if (s < GG) {
-            const int G = strata(spp), P = (int)(sqrt((double)g_cull_cells) + 0.5), m = P / G;
+          const int G = strata(spp), P = (int)(sqrt((double)g_cull_cells) + 0.5), m = P / G;
+          if (s >= GG || (1 << g_sub_bits) < m) {
+            int fx = (int)(t_ua * (float)P), fy = (int)(t_ub * (float)P);
+            if (fx > P - 1) fx = P - 1;
+            if (fy > P - 1) fy = P - 1;
+            entry = fy * P + fx;
+          } else {
             const int cy = s / G, cx = s - cy * G;
             int tiles_x = ((W + (8 << g_xs) - 1) >> (3 + g_xs)) << g_xs;
             int tx = ((x >> (3 + g_xs)) << g_xs) + (x & ((1 << g_xs) - 1));

@@ -21,16 +21,29 @@ for f in glob.glob(out_dir + "/*/*/*counter_collection.csv"):
         continue
     for row in csv.DictReader(open(f)):
         name = row["Kernel_Name"]
-        if kern + "(" not in name and kern + "<" not in name:   # k_march / k_march<K>, not k_march_finish
+        if kern + "(" not in name and kern + "<" not in name:   # k_march / k_march<K>, not k_march_finish / k_march_cull
             continue
         c = row["Counter_Name"]
         sums[c] += float(row["Counter_Value"])
         disp[c].add(row["Dispatch_Id"])
+# the pre-pass of the path cull (k_cull_level: several launches per frame, one per level) beside the march
+pre, pre_disp = defaultdict(float), defaultdict(set)
+for f in glob.glob(out_dir + "/*/*/*counter_collection.csv"):
+    if "/stats/" in f:
+        continue
+    for row in csv.DictReader(open(f)):
+        if "k_cull_level" in row["Kernel_Name"]:
+            pre[row["Counter_Name"]] += float(row["Counter_Value"])
+            pre_disp[row["Counter_Name"]].add(row["Dispatch_Id"])
 res = {"kernel": kern, "config": cfg,
        "per_launch": {c: sums[c] / max(1, len(disp[c])) for c in sums},
        "launches": {c: len(disp[c]) for c in sums}}
+if pre:
+    res["cull_prepass"] = {"kernel": "k_cull_level", "launches": {c: len(pre_disp[c]) for c in pre},
+                           "sum_over_launches": dict(pre)}
 h = hashlib.sha256()
-for f in ("lens-flare_amd/csrc/lf_march.hip", "lens-flare_amd/csrc/lf_march_events.h", "lens-flare_amd/csrc/lf_internal.h"):
+for f in ("lens-flare_amd/csrc/lf_march.hip", "lens-flare_amd/csrc/lf_cull.hip", "lens-flare_amd/csrc/lf_march_common.h",
+          "lens-flare_amd/csrc/lf_march_events.h", "lens-flare_amd/csrc/lf_internal.h"):
     h.update(open(os.path.join(root, f), "rb").read())
 mk = open(os.path.join(root, "lens-flare_amd", "Makefile")).read()
 h.update(mk[mk.index("FLAGS  :="):mk.index("SRCS   :=")].encode())   # the compile flags, as bench.py hashes them
