@@ -568,6 +568,10 @@ lf_status lf_paraxial_entrance_pupil(int n_surfaces, int stop_index, const float
  * selection, wavelength weights and a still-valid pupil target survive; march program, lens-camera
  * table and calibration are rebuilt on next use.  sensor_distance_mm: the new last thickness. */
 lf_status lf_focus_lens(lf_ctx* ctx, double object_distance_mm, float* sensor_distance_mm);
+/* the same with the distance measured from the CAMERA POSITION of the lens camera -- the centre of the paraxial
+ * entrance pupil (lf_paraxial_entrance_pupil; 19.95 mm behind the double Gauss's first vertex) -- which is what
+ * Camera::focalDistance means (camera.h:174: the drop-in passes it here) */
+lf_status lf_focus_lens_from_pupil(lf_ctx* ctx, double distance_from_entrance_pupil_mm, float* sensor_distance_mm);
 /* replaces: BVHAccel::total_rays / total_isects (src/scene/bvh.h:85,105,136; bvh.cpp:211), the numbers
  * behind the reference's end-of-frame log (raytraced_renderer.cpp:706-709), as the device's scene
  * kernel counts them since the last reset: out = {rays handed to the closest-hit / occlusion search

@@ -41,7 +41,7 @@ ABI_SYMBOLS = [
     "lf_shift_vertex", "lf_compute_phase", "lf_irradiance_falloff", "lf_scene_trace_ray", "lf_scene_shade",
     "lf_load_lens_file", "lf_get_lens_info",
     "lf_set_pupil_target", "lf_get_pupil_target", "lf_aim_at_exit_pupil", "lf_paraxial_exit_pupil", "lf_set_ghost_accumulate",
-    "lf_set_lens_camera", "lf_get_lens_camera", "lf_set_lens_camera_aim", "lf_paraxial_entrance_pupil", "lf_focus_lens",
+    "lf_set_lens_camera", "lf_get_lens_camera", "lf_set_lens_camera_aim", "lf_paraxial_entrance_pupil", "lf_focus_lens", "lf_focus_lens_from_pupil",
     "lf_get_scene_counters", "lf_reset_scene_counters", "lf_set_flare_arithmetic",
     "lf_comm_get_unique_id", "lf_comm_init_rank", "lf_comm_gather", "lf_comm_gather_async", "lf_comm_wait",
     "lf_comm_destroy", "lf_comm_available", "lf_comm_info", "lf_comm_test", "lf_comm_abort",
@@ -752,6 +752,13 @@ class LensFlare:
     def focus_lens(self, object_distance_mm):
         d = C.c_float()
         self._ck(self.lib.lf_focus_lens(self.ctx, C.c_double(object_distance_mm), C.byref(d)))
+        return d.value
+
+    def focus_lens_from_pupil(self, distance_mm):
+        """focus_lens with the distance counted from the lens camera's position (the entrance pupil's centre):
+        what Camera::focalDistance means"""
+        d = C.c_float()
+        self._ck(self.lib.lf_focus_lens_from_pupil(self.ctx, C.c_double(distance_mm), C.byref(d)))
         return d.value
 
     def scene_counters(self):

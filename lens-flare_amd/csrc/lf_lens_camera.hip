@@ -245,6 +245,24 @@ lf_status lf_get_lens_camera(lf_ctx* ctx, int* mode, double* world_per_mm, doubl
   return LF_OK;
 }
 
+// Camera::focalDistance is measured from the CAMERA POSITION, and the lens camera puts that at the centre of the
+// paraxial entrance pupil (z_ep behind the first vertex: +19.95 mm for the double Gauss) -- not at the first vertex,
+// from which lf_focus_lens measures.  At 4 m the 2 cm do not matter; at 0.3 - 0.5 m they are several pixels of blur.
+lf_status lf_focus_lens_from_pupil(lf_ctx* ctx, double distance_from_entrance_pupil_mm, float* sensor_distance_mm) {
+  if (!ctx) return LF_ERR_INVALID;
+  if (!ctx->lens_valid) return lf_fail(ctx, LF_ERR_STATE, "lf_focus_lens_from_pupil before lf_set_lens");
+  if (!(distance_from_entrance_pupil_mm > 0.0) || std::isinf(distance_from_entrance_pupil_mm))
+    return lf_focus_lens(ctx, distance_from_entrance_pupil_mm, sensor_distance_mm);   // infinity
+  double z_ep = 0.0, mag = 1.0;
+  if (ctx->raw_stop >= 0 &&
+      lf_paraxial_entrance_pupil(ctx->raw_n, ctx->raw_stop, ctx->raw_radius, ctx->raw_thickness,
+                                 ctx->raw_ior + (size_t)(ctx->lens.n_lambda / 2) * ctx->raw_n, &z_ep, &mag) != LF_OK)
+    z_ep = 0.0;
+  const double from_vertex = distance_from_entrance_pupil_mm - z_ep;
+  if (!(from_vertex > 0.0)) return lf_fail(ctx, LF_ERR_INVALID, "lf_focus_lens_from_pupil: the object lies inside the lens");
+  return lf_focus_lens(ctx, from_vertex, sensor_distance_mm);
+}
+
 lf_status lf_focus_lens(lf_ctx* ctx, double object_distance_mm, float* sensor_distance_mm) {
   if (!ctx) return LF_ERR_INVALID;
   if (!ctx->lens_valid) return lf_fail(ctx, LF_ERR_STATE, "lf_focus_lens before lf_set_lens");

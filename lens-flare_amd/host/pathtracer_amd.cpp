@@ -440,7 +440,8 @@ void PathTracer::generate_ghost_buffer() {                         // pathtracer
       const double want = (camera->lensRadius > 0 && std::isfinite(camera->focalDistance) && camera->focalDistance > 0)
                               ? camera->focalDistance / wpm : 0.0;
       if (want != s.lens_focus_mm) {
-        if (want > 0) check(s, lf_focus_lens(s.ctx, want, nullptr), "lf_focus_lens");
+        // (focalDistance counts from the camera position = the entrance pupil's centre, not from the first vertex)
+        if (want > 0) check(s, lf_focus_lens_from_pupil(s.ctx, want, nullptr), "lf_focus_lens_from_pupil");
         else check(s, lf_load_lens_file(s.ctx, lens_file.c_str()), "lf_load_lens_file");
         s.lens_focus_mm = want;
       }
