@@ -368,6 +368,163 @@ __global__ __launch_bounds__(256) void k_cull_level(const LfLensDev* __restrict_
 constexpr int kWgWaves = 8;
 constexpr int kListMax = 4096;   // samples of one tile's workgroup (spp / sgroups) listed at a time
 
+// what a wave tallies while it marches (slots of lf_counters / lf_get_march_stats)
+struct PathTally {
+  unsigned long long n_rays = 0, events = 0, n_clip = 0, n_vign = 0, n_tir = 0, n_scene = 0, n_rm_lane = 0, n_rm_rows = 0;
+  unsigned n_light = 0;   // per lane
+};
+
+// One STARTED path q of one sensor sample per lane (start ray X, Y, s0; lanes in start_mask), every wavelength group:
+// the events of the path's own sequence, K wavelengths together, tallies, the lobe test, the weighted second march
+// (W1 = false) and the fixed-point add into the tile's LDS sums at pixel slot acc_slot.  Shared by the two culled
+// kernels below: lane = pixel (k_march_cull) and lane = one compacted (pixel, sample) item (k_march_items).
+template <int K, bool W1>
+__device__ __forceinline__ void march_started_path(const LfLensDev* __restrict__ lens, const LfPairsDev* __restrict__ pairs,
+                                                   const int* __restrict__ seq_table, const LfProgRow* __restrict__ rec_table,
+                                                   const LfWeightRow* __restrict__ wrec_table, const float* __restrict__ mask,
+                                                   const MarchArgs& a, int q, lanemask start_mask, float X, float Y,
+                                                   const StartRay& s0, int lane, int acc_slot,
+                                                   unsigned long long* __restrict__ s_acc, PathTally& T) {
+  const int n_lambda = lens->n_lambda, prog_recs = pairs->prog_recs;
+  const int n_groups = (n_lambda + K - 1) / K;
+  const float inv_stop_h = a.inv_stop_h, lobe_thr = a.lobe_thr;
+  const float sx = lens->sun_dir[0], sy = lens->sun_dir[1], sz = lens->sun_dir[2];
+  const float inv_1mc = lens->sun_inv_one_minus_cos, sun_ss = lens->sun_ss;
+  const int n_ev = pairs->ev_cnt[q];
+  const int* const seq = seq_table + pairs->ev_off[q];
+  for (int g = 0; g < n_groups; g++) {
+    const LfProgRow* const recs = rec_table + (size_t)g * (size_t)prog_recs;
+    const LfWeightRow* const wrecs = wrec_table + (size_t)g * (size_t)prog_recs;
+    Ray r[K];
+    lanemask alive[K];
+    unsigned nlive = 0u;
+#pragma unroll
+    for (int j = 0; j < K; j++) {
+      r[j] = Ray{X, Y, 0.0f, fmaf(X, X, Y * Y), s0.dx, s0.dy, s0.dz, s0.w0, 1.0f};
+      const float ns = lens->n_start[min(g * K + j, n_lambda - 1)];
+      r[j].dx *= ns; r[j].dy *= ns; r[j].dz *= ns;
+      alive[j] = (g * K + j < n_lambda) ? start_mask : 0ull;
+      nlive += (unsigned)__popcll(alive[j]);
+    }
+    T.n_rays += nlive;
+    unsigned ev32 = 0u;
+    unsigned se = (unsigned)*(const int __attribute__((address_space(4)))*)(seq);
+    for (int e = 0; e < n_ev && nlive != 0u; e++) {
+      const unsigned cur = se;
+      if (e + 1 < n_ev) se = (unsigned)*(const int __attribute__((address_space(4)))*)(seq + e + 1);
+      const LfProgRow wr = load_prec(recs, cur & 0xffffu);
+      LfWeightRow ww;
+      if (W1) ww = load_wrec(wrecs, cur & 0xffffu);
+      else { for (int j = 0; j < 3; j++) { ww.fs[j] = 1.0f; ww.fo[j] = 1.0f; ww.fi[j] = 1.0f; } }
+      const unsigned kind = cur >> 16;
+      lanemask okv[K], gv[K], died = 0ull;
+      if (kind & LF_EV_STOP) {
+#pragma unroll
+        for (int j = 0; j < K; j++) {
+          if (K > 1 && __builtin_expect(alive[j] == 0ull, 0)) { okv[j] = 0ull; gv[j] = 0ull; continue; }
+          okv[j] = stop_event<W1>(r[j], wr.dzv, wr.h2, inv_stop_h, mask, a.mw, a.mh);
+          gv[j] = okv[j];
+          died |= alive[j] & ~okv[j];
+        }
+        if (__builtin_expect(died != 0ull, 0)) {
+#pragma unroll
+          for (int j = 0; j < K; j++) {
+            const unsigned nd = (unsigned)__popcll(alive[j] & ~okv[j]);
+            T.n_clip += nd; nlive -= nd; alive[j] &= okv[j];
+          }
+        }
+      } else {
+        if (kind == 0u) {          // refraction at a curved interface: the common row, straight-line
+#pragma unroll
+          for (int j = 0; j < K; j++) {
+            if (K > 1 && __builtin_expect(alive[j] == 0ull, 0)) { okv[j] = 0ull; gv[j] = 0ull; continue; }
+            okv[j] = surface_event<W1>(r[j], wr.dzv, wr.curv, wr.ch, wr.c2, wr.sc, wr.cn22[j], wr.rn2[j],
+                                       wr.delta[j], wr.h2, false, false, wr.sgn, gv[j], ww.fs[j], ww.fo[j], ww.fi[j]);
+            died |= alive[j] & ~okv[j];
+          }
+        } else {
+#pragma unroll
+          for (int j = 0; j < K; j++) {
+            if (K > 1 && __builtin_expect(alive[j] == 0ull, 0)) { okv[j] = 0ull; gv[j] = 0ull; continue; }
+            okv[j] = surface_event<W1>(r[j], wr.dzv, wr.curv, wr.ch, wr.c2, wr.sc, wr.cn22[j], wr.rn2[j],
+                                       wr.delta[j], wr.h2, (kind & LF_EV_REFLECT) != 0, (kind & LF_EV_FLAT) != 0,
+                                       wr.sgn, gv[j], ww.fs[j], ww.fo[j], ww.fi[j]);
+            died |= alive[j] & ~okv[j];
+          }
+        }
+        if (__builtin_expect(died != 0ull, 0)) {
+#pragma unroll
+          for (int j = 0; j < K; j++) {
+            T.n_vign += (unsigned)__popcll(alive[j] & ~gv[j]);
+            T.n_tir += (unsigned)__popcll(alive[j] & gv[j] & ~okv[j]);
+            nlive -= (unsigned)__popcll(alive[j] & ~okv[j]);
+            alive[j] &= okv[j];
+          }
+        }
+      }
+      ev32 += nlive;       // events completed: one per ray still alive after the row
+    }
+    T.events += ev32;
+    if (nlive == 0u) continue;
+    // ---- the path is complete for nlive rays --------------------------------------------------
+    T.n_scene += nlive;
+    lanemask lit[K], lit_any = 0ull;
+#pragma unroll
+    for (int j = 0; j < K; j++) {
+      const float cg = fmaf(r[j].dx, sx, fmaf(r[j].dy, sy, r[j].dz * sz));
+      lit[j] = alive[j] & __ballot(cg > lobe_thr);
+      lit_any |= lit[j];
+    }
+    if (lit_any == 0ull) continue;
+    for (int j = 0; j < K; j++) {        // not unrolled (W1 = false): one copy of the weighted march
+      lanemask lj = lit[0];
+#pragma unroll
+      for (int jj = 1; jj < K; jj++) lj = (j == jj) ? lit[jj] : lj;
+      if (lj == 0ull) continue;
+      const int l = g * K + j;
+      Ray rw = j == 0 ? r[0] : j == 1 ? r[K > 1 ? 1 : 0] : r[K > 2 ? 2 : 0];
+      if (!W1) {
+        // the path again, alone and with its weight: the same arithmetic on the ray, so the same ray bit for bit
+        rw = Ray{X, Y, 0.0f, fmaf(X, X, Y * Y), s0.dx, s0.dy, s0.dz, s0.w0, 1.0f};
+        { const float ns = lens->n_start[l]; rw.dx *= ns; rw.dy *= ns; rw.dz *= ns; }
+        T.n_rm_lane += (unsigned long long)((unsigned)n_ev * (unsigned)__popcll(lj));
+        T.n_rm_rows += (unsigned)n_ev;
+        const int* w = seq;
+        for (int left = n_ev; left > 0; --left, ++w) {
+          const unsigned se2 = (unsigned)*(const int __attribute__((address_space(4)))*)(w);
+          const LfProgRow wr = load_prec(recs, se2 & 0xffffu);
+          const LfWeightRow ww = load_wrec(wrecs, se2 & 0xffffu);
+          const unsigned wfl = se2 >> 16;
+          const float w_cn22 = j == 0 ? wr.cn22[0] : j == 1 ? wr.cn22[1] : wr.cn22[2];
+          const float w_rn2 = j == 0 ? wr.rn2[0] : j == 1 ? wr.rn2[1] : wr.rn2[2];
+          const float w_delta = j == 0 ? wr.delta[0] : j == 1 ? wr.delta[1] : wr.delta[2];
+          const float w_fs = j == 0 ? ww.fs[0] : j == 1 ? ww.fs[1] : ww.fs[2];
+          const float w_fo = j == 0 ? ww.fo[0] : j == 1 ? ww.fo[1] : ww.fo[2];
+          const float w_fi = j == 0 ? ww.fi[0] : j == 1 ? ww.fi[1] : ww.fi[2];
+          if (wfl & LF_EV_STOP) {
+            (void)stop_event<true>(rw, wr.dzv, wr.h2, inv_stop_h, mask, a.mw, a.mh);
+          } else {
+            lanemask geom_ok;
+            (void)surface_event<true>(rw, wr.dzv, wr.curv, wr.ch, wr.c2, wr.sc, w_cn22, w_rn2, w_delta, wr.h2,
+                                      (wfl & LF_EV_REFLECT) != 0, (wfl & LF_EV_FLAT) != 0, wr.sgn, geom_ok, w_fs, w_fo, w_fi);
+          }
+        }
+      }
+      const float qq = lobe_q(rw.dx, rw.dy, rw.dz, sx, sy, sz, sun_ss, inv_1mc);
+      const float om = 1.0f - qq;
+      float contrib = __fdiv_rn(rw.wn, rw.wd) * (om * om);
+      contrib = (((lj >> lane) & 1ull) != 0ull && qq < 1.0f && contrib > 0.0f) ? contrib : 0.0f;
+      T.n_light += contrib > 0.0f ? 1u : 0u;
+#pragma unroll
+      for (int c = 0; c < 3; c++) {
+        const float v = contrib * (lens->sun_radiance[c] * lens->lambda_rgb[l][c]);
+        const unsigned long long fx = (unsigned long long)(v * a.fix_scale);
+        if (fx) atomicAdd(&s_acc[acc_slot * 3 + c], fx);
+      }
+    }
+  }
+}
+
 // W1: the first (and then only) march of a started path carries its Fresnel / aperture weight.  false = geometry first,
 // and the path is marched again with the weight, one wavelength at a time, only where a lane ended inside the lobe
 // pre-test (k_march's scheme: 6 % of the STARTED rays are lit on the bench frame, so the weight's 17 of 44 vector
@@ -408,22 +565,14 @@ void k_march_cull(const LfLensDev* __restrict__ lens, const LfPairsDev* __restri
   const int blk = ((trow * 8) >> kCullBlockLog2) * cull.blocks_x + ((((tx >> a.xs) << (3 + a.xs))) >> kCullBlockLog2);
   const unsigned long long* const crow = cull.table + (size_t)blk * (size_t)(cull.cells + 1);
 
-  const int n_lambda = lens->n_lambda;
-  const int prog_recs = pairs->prog_recs;
-  const int n_groups = (n_lambda + K - 1) / K;
   const float pitch = lens->pitch, pupil_h = lens->pupil_h, geom_norm = lens->geom_norm;
-  const float inv_stop_h = a.inv_stop_h, half_w = a.half_w, half_h = a.half_h, vz_u = a.vz;
-  const float sx = lens->sun_dir[0], sy = lens->sun_dir[1], sz = lens->sun_dir[2];
-  const float inv_1mc = lens->sun_inv_one_minus_cos, sun_ss = lens->sun_ss;
-  const float lobe_thr = a.lobe_thr;
+  const float half_w = a.half_w, half_h = a.half_h, vz_u = a.vz;
   const int GG = a.G * a.G;
   // do the lanes of a wave aim a stratified sample at ONE cell of the table?  (they share a sub-cell of the stratum;
   // the table has m cells per stratum axis)
   const bool per_lane = (1 << a.sub_bits) < cull.m;
 
-  unsigned n_light = 0;                  // per lane
-  unsigned long long n_rays = 0, events = 0, n_clip = 0, n_vign = 0, n_tir = 0, n_scene = 0;   // per wave
-  unsigned long long n_rm_lane = 0, n_rm_rows = 0;   // the weight re-march (W1 = false; lf_get_march_stats)
+  PathTally T;
 
   const int n_mine = (a.spp - sg + a.sgroups - 1) / a.sgroups;     // samples sg, sg + sgroups, ...
   for (int chunk0 = 0; chunk0 < n_mine; chunk0 += kListMax) {
@@ -484,140 +633,8 @@ void k_march_cull(const LfLensDev* __restrict__ lens, const LfPairsDev* __restri
       while (left_q != 0ull) {
         const int q = __builtin_ctzll(left_q);
         left_q &= left_q - 1ull;
-        const int n_ev = pairs->ev_cnt[q];
-        const int* const seq = seq_table + pairs->ev_off[q];
         const lanemask start_mask = active_mask & __ballot(((mine >> q) & 1ull) != 0ull);   // (all active lanes when the wave shares a cell)
-        for (int g = 0; g < n_groups; g++) {
-          const LfProgRow* const recs = rec_table + (size_t)g * (size_t)prog_recs;
-          const LfWeightRow* const wrecs = wrec_table + (size_t)g * (size_t)prog_recs;
-          Ray r[K];
-          lanemask alive[K];
-          unsigned nlive = 0u;
-#pragma unroll
-          for (int j = 0; j < K; j++) {
-            r[j] = Ray{X, Y, 0.0f, fmaf(X, X, Y * Y), s0.dx, s0.dy, s0.dz, s0.w0, 1.0f};
-            const float ns = lens->n_start[min(g * K + j, n_lambda - 1)];
-            r[j].dx *= ns; r[j].dy *= ns; r[j].dz *= ns;
-            alive[j] = (g * K + j < n_lambda) ? start_mask : 0ull;
-            nlive += (unsigned)__popcll(alive[j]);
-          }
-          n_rays += nlive;
-          unsigned ev32 = 0u;
-          unsigned se = (unsigned)*(const int __attribute__((address_space(4)))*)(seq);
-          for (int e = 0; e < n_ev && nlive != 0u; e++) {
-            const unsigned cur = se;
-            if (e + 1 < n_ev) se = (unsigned)*(const int __attribute__((address_space(4)))*)(seq + e + 1);
-            const LfProgRow wr = load_prec(recs, cur & 0xffffu);
-            LfWeightRow ww;
-            if (W1) ww = load_wrec(wrecs, cur & 0xffffu);
-            else { for (int j = 0; j < 3; j++) { ww.fs[j] = 1.0f; ww.fo[j] = 1.0f; ww.fi[j] = 1.0f; } }
-            const unsigned kind = cur >> 16;
-            lanemask okv[K], gv[K], died = 0ull;
-            if (kind & LF_EV_STOP) {
-#pragma unroll
-              for (int j = 0; j < K; j++) {
-                if (K > 1 && __builtin_expect(alive[j] == 0ull, 0)) { okv[j] = 0ull; gv[j] = 0ull; continue; }
-                okv[j] = stop_event<W1>(r[j], wr.dzv, wr.h2, inv_stop_h, mask, a.mw, a.mh);
-                gv[j] = okv[j];
-                died |= alive[j] & ~okv[j];
-              }
-              if (__builtin_expect(died != 0ull, 0)) {
-#pragma unroll
-                for (int j = 0; j < K; j++) {
-                  const unsigned nd = (unsigned)__popcll(alive[j] & ~okv[j]);
-                  n_clip += nd; nlive -= nd; alive[j] &= okv[j];
-                }
-              }
-            } else {
-              if (kind == 0u) {          // refraction at a curved interface: the common row, straight-line
-#pragma unroll
-                for (int j = 0; j < K; j++) {
-                  if (K > 1 && __builtin_expect(alive[j] == 0ull, 0)) { okv[j] = 0ull; gv[j] = 0ull; continue; }
-                  okv[j] = surface_event<W1>(r[j], wr.dzv, wr.curv, wr.ch, wr.c2, wr.sc, wr.cn22[j], wr.rn2[j],
-                                             wr.delta[j], wr.h2, false, false, wr.sgn, gv[j], ww.fs[j], ww.fo[j], ww.fi[j]);
-                  died |= alive[j] & ~okv[j];
-                }
-              } else {
-#pragma unroll
-                for (int j = 0; j < K; j++) {
-                  if (K > 1 && __builtin_expect(alive[j] == 0ull, 0)) { okv[j] = 0ull; gv[j] = 0ull; continue; }
-                  okv[j] = surface_event<W1>(r[j], wr.dzv, wr.curv, wr.ch, wr.c2, wr.sc, wr.cn22[j], wr.rn2[j],
-                                             wr.delta[j], wr.h2, (kind & LF_EV_REFLECT) != 0, (kind & LF_EV_FLAT) != 0,
-                                             wr.sgn, gv[j], ww.fs[j], ww.fo[j], ww.fi[j]);
-                  died |= alive[j] & ~okv[j];
-                }
-              }
-              if (__builtin_expect(died != 0ull, 0)) {
-#pragma unroll
-                for (int j = 0; j < K; j++) {
-                  n_vign += (unsigned)__popcll(alive[j] & ~gv[j]);
-                  n_tir += (unsigned)__popcll(alive[j] & gv[j] & ~okv[j]);
-                  nlive -= (unsigned)__popcll(alive[j] & ~okv[j]);
-                  alive[j] &= okv[j];
-                }
-              }
-            }
-            ev32 += nlive;       // events completed: one per ray still alive after the row
-          }
-          events += ev32;
-          if (nlive == 0u) continue;
-          // ---- the path is complete for nlive rays --------------------------------------------------
-          n_scene += nlive;
-          lanemask lit[K], lit_any = 0ull;
-#pragma unroll
-          for (int j = 0; j < K; j++) {
-            const float cg = fmaf(r[j].dx, sx, fmaf(r[j].dy, sy, r[j].dz * sz));
-            lit[j] = alive[j] & __ballot(cg > lobe_thr);
-            lit_any |= lit[j];
-          }
-          if (lit_any == 0ull) continue;
-          for (int j = 0; j < K; j++) {        // not unrolled (W1 = false): one copy of the weighted march
-            lanemask lj = lit[0];
-#pragma unroll
-            for (int jj = 1; jj < K; jj++) lj = (j == jj) ? lit[jj] : lj;
-            if (lj == 0ull) continue;
-            const int l = g * K + j;
-            Ray rw = j == 0 ? r[0] : j == 1 ? r[K > 1 ? 1 : 0] : r[K > 2 ? 2 : 0];
-            if (!W1) {
-              // the path again, alone and with its weight: the same arithmetic on the ray, so the same ray bit for bit
-              rw = Ray{X, Y, 0.0f, fmaf(X, X, Y * Y), s0.dx, s0.dy, s0.dz, s0.w0, 1.0f};
-              { const float ns = lens->n_start[l]; rw.dx *= ns; rw.dy *= ns; rw.dz *= ns; }
-              n_rm_lane += (unsigned long long)((unsigned)n_ev * (unsigned)__popcll(lj));
-              n_rm_rows += (unsigned)n_ev;
-              const int* w = seq;
-              for (int left = n_ev; left > 0; --left, ++w) {
-                const unsigned se2 = (unsigned)*(const int __attribute__((address_space(4)))*)(w);
-                const LfProgRow wr = load_prec(recs, se2 & 0xffffu);
-                const LfWeightRow ww = load_wrec(wrecs, se2 & 0xffffu);
-                const unsigned wfl = se2 >> 16;
-                const float w_cn22 = j == 0 ? wr.cn22[0] : j == 1 ? wr.cn22[1] : wr.cn22[2];
-                const float w_rn2 = j == 0 ? wr.rn2[0] : j == 1 ? wr.rn2[1] : wr.rn2[2];
-                const float w_delta = j == 0 ? wr.delta[0] : j == 1 ? wr.delta[1] : wr.delta[2];
-                const float w_fs = j == 0 ? ww.fs[0] : j == 1 ? ww.fs[1] : ww.fs[2];
-                const float w_fo = j == 0 ? ww.fo[0] : j == 1 ? ww.fo[1] : ww.fo[2];
-                const float w_fi = j == 0 ? ww.fi[0] : j == 1 ? ww.fi[1] : ww.fi[2];
-                if (wfl & LF_EV_STOP) {
-                  (void)stop_event<true>(rw, wr.dzv, wr.h2, inv_stop_h, mask, a.mw, a.mh);
-                } else {
-                  lanemask geom_ok;
-                  (void)surface_event<true>(rw, wr.dzv, wr.curv, wr.ch, wr.c2, wr.sc, w_cn22, w_rn2, w_delta, wr.h2,
-                                            (wfl & LF_EV_REFLECT) != 0, (wfl & LF_EV_FLAT) != 0, wr.sgn, geom_ok, w_fs, w_fo, w_fi);
-                }
-              }
-            }
-            const float qq = lobe_q(rw.dx, rw.dy, rw.dz, sx, sy, sz, sun_ss, inv_1mc);
-            const float om = 1.0f - qq;
-            float contrib = __fdiv_rn(rw.wn, rw.wd) * (om * om);
-            contrib = (((lj >> lane) & 1ull) != 0ull && qq < 1.0f && contrib > 0.0f) ? contrib : 0.0f;
-            n_light += contrib > 0.0f ? 1u : 0u;
-#pragma unroll
-            for (int c = 0; c < 3; c++) {
-              const float v = contrib * (lens->sun_radiance[c] * lens->lambda_rgb[l][c]);
-              const unsigned long long fx = (unsigned long long)(v * a.fix_scale);
-              if (fx) atomicAdd(&s_acc[lane * 3 + c], fx);
-            }
-          }
-        }
+        march_started_path<K, W1>(lens, pairs, seq_table, rec_table, wrec_table, mask, a, q, start_mask, X, Y, s0, lane, lane, s_acc, T);
       }
     }
     __syncthreads();
@@ -628,9 +645,9 @@ void k_march_cull(const LfLensDev* __restrict__ lens, const LfPairsDev* __restri
   // ---- counters: one LDS add per wave, one global add per workgroup (slots as k_march: executed events =
   // events, every path marched on its own; no second march) ---------------------------------------------
   {
-    unsigned long long v6 = n_light;
+    unsigned long long v6 = T.n_light;
     for (int off = 32; off > 0; off >>= 1) v6 += __shfl_down(v6, off);
-    const unsigned long long vals[kMarchCounters] = {n_rays, events, n_clip, n_vign, n_tir, n_scene, v6, events, n_rm_lane, n_rm_rows};
+    const unsigned long long vals[kMarchCounters] = {T.n_rays, T.events, T.n_clip, T.n_vign, T.n_tir, T.n_scene, v6, T.events, T.n_rm_lane, T.n_rm_rows};
     if (lane == 0) {
 #pragma unroll
       for (int i = 0; i < kMarchCounters; i++)
@@ -651,6 +668,194 @@ void k_march_cull(const LfLensDev* __restrict__ lens, const LfPairsDev* __restri
 #pragma unroll
       for (int c = 0; c < 3; c++)
         if (s_acc[lane * 3 + c]) atomicAdd(&accum[3 * (size_t)p + c], s_acc[lane * 3 + c]);
+    }
+  }
+}
+
+// ---- the same march, COMPACTED: one lane = one (pixel, sample) that starts the path --------------------------
+// Where every pixel draws its own pupil point (lf_set_pupil_subcells(0): the independent-pixel estimator) the lanes of
+// a wave tile aim at different cells of the table, want different paths, and a wave that marches path q for its tile
+// and sample does so with the few lanes that want it: the same events as the coherent specification in 2.4 x the
+// time (profiles/r05_march_variants.txt).  Here the tile's workgroup first LISTS what is to be started -- for a chunk
+// of samples every (pixel, sample) looks its mask up, the paths are counted by ballot, and the (pixel, sample) items
+// are written into one LDS array sorted by path -- and then marches the list: a wave takes 64 items of ONE path,
+// rebuilds each lane's start ray from its (pixel, sample) and marches with every lane started.  Sums are integers
+// in LDS, so pixels and counters do not depend on the order: bit for bit the frame of k_march_cull and of the oracle.
+constexpr int kItemCap = 16384;      // items of a chunk (2 bytes each)
+constexpr int kItemChunk = 256;      // samples per chunk at most (8 bits of an item; the pixel takes 6)
+
+template <int K>
+__global__ __launch_bounds__(64 * kWgWaves, (K == 1 ? 8 : 6))
+void k_march_items(const LfLensDev* __restrict__ lens, const LfPairsDev* __restrict__ pairs,
+                   const int* __restrict__ seq_table, const LfProgRow* __restrict__ rec_table,
+                   const LfWeightRow* __restrict__ wrec_table, const float* __restrict__ mask, MarchArgs a,
+                   LfCullArgs cull, double* __restrict__ ghost, unsigned long long* __restrict__ accum,
+                   unsigned long long* __restrict__ counters) {
+  __shared__ unsigned long long s_acc[64 * 3];
+  __shared__ unsigned long long s_cnt[kMarchCounters];
+  __shared__ int s_pcount[kCullMaxPaths], s_poff[kCullMaxPaths + 1], s_goff[kCullMaxPaths + 1], s_pfill[kCullMaxPaths];
+  __shared__ int s_next;
+  __shared__ unsigned short s_items[kItemCap];
+  const int tid = threadIdx.x;
+  if (tid < 64 * 3) s_acc[tid] = 0ull;
+  if (tid < kMarchCounters) s_cnt[tid] = 0ull;
+  __syncthreads();
+
+  const int tiles_x = ((a.W + (8 << a.xs) - 1) >> (3 + a.xs)) << a.xs;
+  const int sg = blockIdx.x % a.sgroups;
+  const unsigned slot = blockIdx.x / a.sgroups;
+  const int tile_lin = (int)((slot & ~63u) | ((slot & 7u) << 3) | ((slot >> 3) & 7u));
+  if (tile_lin >= a.n_tiles) return;
+  const int tx = tile_lin % tiles_x, tj = tile_lin / tiles_x;
+  const int trow = a.trow0 + tj * a.tperiod;
+  const unsigned tile_id = (unsigned)(trow * tiles_x + tx);
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int lane = tid & 63;
+  const int n_paths = pairs->n;
+  const int blk = ((trow * 8) >> kCullBlockLog2) * cull.blocks_x + ((((tx >> a.xs) << (3 + a.xs))) >> kCullBlockLog2);
+  const unsigned long long* const crow = cull.table + (size_t)blk * (size_t)(cull.cells + 1);
+  const float pitch = lens->pitch, pupil_h = lens->pupil_h, geom_norm = lens->geom_norm;
+  const float half_w = a.half_w, half_h = a.half_h, vz_u = a.vz;
+  const int GG = a.G * a.G;
+  // pixel `px` of the tile (the lane order of k_march / k_march_cull)
+  auto pixel_of = [&](int px, int& x, int& y) {
+    x = ((tx >> a.xs) << (3 + a.xs)) + ((px & 7) << a.xs) + (tx & ((1 << a.xs) - 1));
+    y = trow * 8 + (px >> 3);
+    return x < a.W && y >= a.y0 && y < a.y1;
+  };
+  // sample s of pixel (x, y): the point of the pupil square it aims at (the expressions of sample_start), with the
+  // pixel jitter beside it
+  auto pupil_point = [&](int x, int y, int s, float& ua, float& ub, float& jx, float& jy) {
+    const uint4 rnd = philox4x32_10(make_uint4((unsigned)y * (unsigned)a.W + (unsigned)x, (unsigned)s, kDomainMarch, 0u), a.key);
+    jx = u01(rnd.x); jy = u01(rnd.y);
+    ua = u01(rnd.z); ub = u01(rnd.w);
+    if (s < GG) {
+      const int cy = s / a.G, cx = s - cy * a.G;
+      unsigned sxi = 0u, syi = 0u;
+      if (a.sub_bits) {     // (no sub-cells, no draw: s differs from lane to lane here, the draw would be a vector one)
+        const uint4 r2 = philox4x32_10(make_uint4(tile_id, (unsigned)s, kDomainSubcell, 0u), a.key);
+        sxi = r2.x >> (32 - a.sub_bits); syi = r2.y >> (32 - a.sub_bits);
+      }
+      ua = ((float)cx + ((float)sxi + ua) * a.inv_sub) * a.inv_G;
+      ub = ((float)cy + ((float)syi + ub) * a.inv_sub) * a.inv_G;
+    }
+  };
+  // the paths pixel (lane) starts for the chunk's k-th sample: the mask of the table cell that holds its pupil point
+  auto mask_of = [&](int k_global) -> unsigned long long {
+    int x, y;
+    if (!pixel_of(lane, x, y)) return 0ull;
+    const int s = sg + k_global * a.sgroups;
+    float ua, ub, jx, jy;
+    pupil_point(x, y, s, ua, ub, jx, jy);
+    const int fx = min(cull.P - 1, (int)(ua * (float)cull.P)), fy = min(cull.P - 1, (int)(ub * (float)cull.P));
+    return crow[fy * cull.P + fx];
+  };
+  auto wave_or = [](unsigned long long v) {
+    unsigned lo = (unsigned)v, hi = (unsigned)(v >> 32);
+    for (int off = 32; off > 0; off >>= 1) { lo |= __shfl_xor(lo, off); hi |= __shfl_xor(hi, off); }
+    return ((unsigned long long)__builtin_amdgcn_readfirstlane(hi) << 32) | (unsigned long long)__builtin_amdgcn_readfirstlane(lo);
+  };
+
+  PathTally T;
+  const int n_mine = (a.spp - sg + a.sgroups - 1) / a.sgroups;     // samples sg, sg + sgroups, ...
+  int c0 = 0, ch = min(kItemChunk, n_mine);
+  while (c0 < n_mine) {
+    const int chn = min(ch, n_mine - c0);
+    // ---- count: how many (pixel, sample) items of this chunk start each path (a wave = one sample's 64 pixels) ---
+    if (tid < kCullMaxPaths) { s_pcount[tid] = 0; s_pfill[tid] = 0; }
+    if (tid == 0) s_next = 0;
+    __syncthreads();
+    for (int k = wave; k < chn; k += kWgWaves) {
+      const unsigned long long mine = mask_of(c0 + k);
+      unsigned long long u = wave_or(mine);
+      while (u != 0ull) {
+        const int q = __builtin_ctzll(u);
+        u &= u - 1ull;
+        const int c = __popcll(__ballot(((mine >> q) & 1ull) != 0ull));
+        if (lane == 0) atomicAdd(&s_pcount[q], c);
+      }
+    }
+    __syncthreads();
+    if (tid == 0) {
+      int off = 0, goff = 0;
+      for (int q = 0; q < n_paths; q++) { s_poff[q] = off; s_goff[q] = goff; off += s_pcount[q]; goff += (s_pcount[q] + 63) >> 6; }
+      s_poff[n_paths] = off; s_goff[n_paths] = goff;
+    }
+    __syncthreads();
+    const int total = s_poff[n_paths];
+    if (total > kItemCap && chn > 1) {      // too many for the list: a shorter chunk (one sample's 64 x 46 always fit)
+      ch = max(1, chn >> 1);
+      __syncthreads();
+      continue;
+    }
+    // ---- fill: the items, sorted by path ------------------------------------------------------------------------
+    for (int k = wave; k < chn; k += kWgWaves) {
+      const unsigned long long mine = mask_of(c0 + k);
+      unsigned long long u = wave_or(mine);
+      while (u != 0ull) {
+        const int q = __builtin_ctzll(u);
+        u &= u - 1ull;
+        const lanemask b = __ballot(((mine >> q) & 1ull) != 0ull);
+        int base = 0;
+        if (lane == 0) base = atomicAdd(&s_pfill[q], (int)__popcll(b));
+        base = __builtin_amdgcn_readfirstlane(base);
+        if ((b >> lane) & 1ull)
+          s_items[s_poff[q] + base + (int)__popcll(b & ((1ull << lane) - 1ull))] = (unsigned short)((k << 6) | lane);
+      }
+    }
+    __syncthreads();
+    // ---- march the list: 64 items of one path per wave ------------------------------------------------------------
+    const int n_groups_total = s_goff[n_paths];
+    for (;;) {
+      int gi = 0;
+      if (lane == 0) gi = atomicAdd(&s_next, 1);
+      gi = __builtin_amdgcn_readfirstlane(gi);
+      if (gi >= n_groups_total) break;
+      int q = 0;
+      while (s_goff[q + 1] <= gi) q++;      // (wave-uniform: the path whose groups hold gi)
+      const int first = s_poff[q] + ((gi - s_goff[q]) << 6), end = s_poff[q] + s_pcount[q];
+      const bool have = first + lane < end;
+      const unsigned item = have ? (unsigned)s_items[first + lane] : 0u;
+      const int px = (int)(item & 63u), s = sg + (c0 + (int)(item >> 6)) * a.sgroups;
+      int x, y;
+      (void)pixel_of(px, x, y);
+      float ua, ub, jx, jy;
+      pupil_point(x, y, s, ua, ub, jx, jy);
+      const float X = -(((float)x + jx) - half_w) * pitch;
+      const float Y = -(((float)y + jy) - half_h) * pitch;
+      const StartRay s0 = aim_at_pupil(X, Y, fmaf(2.0f, ua, -1.0f), fmaf(2.0f, ub, -1.0f), pupil_h, vz_u, geom_norm);
+      march_started_path<K, false>(lens, pairs, seq_table, rec_table, wrec_table, mask, a, q, __ballot(have), X, Y, s0, lane, px, s_acc, T);
+    }
+    __syncthreads();
+    c0 += chn;
+  }
+
+  {
+    unsigned long long v6 = T.n_light;
+    for (int off = 32; off > 0; off >>= 1) v6 += __shfl_down(v6, off);
+    const unsigned long long vals[kMarchCounters] = {T.n_rays, T.events, T.n_clip, T.n_vign, T.n_tir, T.n_scene, v6, T.events, T.n_rm_lane, T.n_rm_rows};
+    if (lane == 0) {
+#pragma unroll
+      for (int i = 0; i < kMarchCounters; i++)
+        if (vals[i]) atomicAdd(&s_cnt[i], vals[i]);
+    }
+  }
+  __syncthreads();
+  if (wave == 0 && lane < kMarchCounters && s_cnt[lane]) atomicAdd(&counters[lane], s_cnt[lane]);
+  int x, y;
+  const bool active = pixel_of(lane, x, y);
+  if (wave == 0 && active) {
+    const size_t p = (size_t)y * (size_t)a.W + (size_t)x;
+    if (a.sgroups == 1) {
+#pragma unroll
+      for (int c = 0; c < 3; c++) {
+        const double v = ((double)s_acc[lane * 3 + c] * a.inv_fix) / (double)a.spp;
+        ghost[3 * p + c] = a.accumulate ? ghost[3 * p + c] + v : v;
+      }
+    } else {
+#pragma unroll
+      for (int c = 0; c < 3; c++)
+        if (s_acc[lane * 3 + c]) atomicAdd(&accum[3 * p + c], s_acc[lane * 3 + c]);
     }
   }
 }
@@ -847,8 +1052,18 @@ lf_status lfk_march_culled(lf_ctx* ctx, const MarchArgs& a, size_t blocks, size_
                      (const LfProgRow*)(ctx->prog_dev + ctx->prog_rec_off),                                  \
                      (const LfWeightRow*)(ctx->prog_dev + ctx->prog_wrec_off), m.texels, a, c, ctx->ghost,   \
                      ctx->accum, ctx->counters_dev)
-#define LF_LAUNCH_CULL(KK) do { if (weights_first) LF_LAUNCH_CULL1(KK, true); else LF_LAUNCH_CULL1(KK, false); } while (0)
+#define LF_LAUNCH_ITEMS(KK)                                                                                  \
+  hipLaunchKernelGGL(k_march_items<KK>, dim3((unsigned)blocks), dim3(64 * kWgWaves), dyn_lds, ctx->stream, ctx->lens_dev, \
+                     ctx->pairs_dev, (const int*)(ctx->prog_dev + ctx->prog_seq_off),                         \
+                     (const LfProgRow*)(ctx->prog_dev + ctx->prog_rec_off),                                  \
+                     (const LfWeightRow*)(ctx->prog_dev + ctx->prog_wrec_off), m.texels, a, c, ctx->ghost,   \
+                     ctx->accum, ctx->counters_dev)
+#define LF_LAUNCH_CULL(KK) do { if (items) LF_LAUNCH_ITEMS(KK); else if (weights_first) LF_LAUNCH_CULL1(KK, true); else LF_LAUNCH_CULL1(KK, false); } while (0)
   const bool weights_first = std::getenv("LF_CULL_WEIGHTS_FIRST") != nullptr;   // experiments only
+  // every pixel its own pupil point (no sub-cells at all): the compacted march.  (2 x 2 sub-cells, where the lanes of a
+  // wave still look their cells up one by one, stay with k_march_cull: 48 against 59 ms on the bench frame)
+  bool items = ctx->march_sub_bits == 0;
+  if (const char* e = std::getenv("LF_CULL_ITEMS")) items = std::atoi(e) != 0;   // experiments only
   switch (ctx->march_k) {
     case 1: LF_LAUNCH_CULL(1); break;
     case 2: LF_LAUNCH_CULL(2); break;
@@ -856,6 +1071,7 @@ lf_status lfk_march_culled(lf_ctx* ctx, const MarchArgs& a, size_t blocks, size_
   }
 #undef LF_LAUNCH_CULL
 #undef LF_LAUNCH_CULL1
+#undef LF_LAUNCH_ITEMS
   lf_timing_end(ctx, LFK_MARCH, ev);
   LF_HIP(ctx, hipGetLastError());
   return LF_OK;
