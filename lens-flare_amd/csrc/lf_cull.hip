@@ -518,7 +518,7 @@ __device__ __forceinline__ void march_started_path(const LfLensDev* __restrict__
 #pragma unroll
       for (int c = 0; c < 3; c++) {
         const float v = contrib * (lens->sun_radiance[c] * lens->lambda_rgb[l][c]);
-        const unsigned long long fx = (unsigned long long)(v * a.fix_scale);
+        const unsigned long long fx = (unsigned long long)(v * 68719476736.0f);
         if (fx) atomicAdd(&s_acc[acc_slot * 3 + c], fx);
       }
     }
@@ -661,7 +661,7 @@ void k_march_cull(const LfLensDev* __restrict__ lens, const LfPairsDev* __restri
     if (a.sgroups == 1) {
 #pragma unroll
       for (int c = 0; c < 3; c++) {
-        const double v = ((double)s_acc[lane * 3 + c] * a.inv_fix) / (double)a.spp;
+        const double v = ((double)s_acc[lane * 3 + c] * (1.0 / 68719476736.0)) / (double)a.spp;
         ghost[3 * (size_t)p + c] = a.accumulate ? ghost[3 * (size_t)p + c] + v : v;
       }
     } else {
@@ -849,7 +849,7 @@ void k_march_items(const LfLensDev* __restrict__ lens, const LfPairsDev* __restr
     if (a.sgroups == 1) {
 #pragma unroll
       for (int c = 0; c < 3; c++) {
-        const double v = ((double)s_acc[lane * 3 + c] * a.inv_fix) / (double)a.spp;
+        const double v = ((double)s_acc[lane * 3 + c] * (1.0 / 68719476736.0)) / (double)a.spp;
         ghost[3 * p + c] = a.accumulate ? ghost[3 * p + c] + v : v;
       }
     } else {

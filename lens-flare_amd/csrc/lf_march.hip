@@ -587,7 +587,7 @@ void k_march(const LfLensDev* __restrict__ lens, const LfPairsDev* __restrict__ 
                   // straight into the tile's LDS sums (integers: any order gives the same bits);
                   // lit lanes are ~0.4 % of the rays, six registers of per-lane sums are not worth it
                   const float v = contrib * (lens->sun_radiance[c] * lens->lambda_rgb[l][c]);
-                  const unsigned long long fx = (unsigned long long)(v * a.fix_scale);
+                                    const unsigned long long fx = (unsigned long long)(v * 68719476736.0f);
                   if (fx) atomicAdd(&s_acc[lane * 3 + c], fx);
                 }
               }
@@ -634,7 +634,7 @@ void k_march(const LfLensDev* __restrict__ lens, const LfPairsDev* __restrict__ 
     if (a.sgroups == 1) {
 #pragma unroll
       for (int c = 0; c < 3; c++) {
-        const double v = ((double)s_acc[lane * 3 + c] * a.inv_fix) / (double)a.spp;
+        const double v = ((double)s_acc[lane * 3 + c] * (1.0 / 68719476736.0)) / (double)a.spp;
         ghost[3 * (size_t)p + c] = a.accumulate ? ghost[3 * (size_t)p + c] + v : v;
       }
     } else {
@@ -684,6 +684,19 @@ __global__ void k_native_rcp(const float* __restrict__ x, float* __restrict__ y,
   if (i < n) y[i] = lf_rcp(x[i]);
 }
 
+// the launch's rows of ghost_buffer times a power of two (exact): the kernels accumulate on the fixed 2^-36 grid of
+// rounds 1-4; a launch whose sums need another exponent (lf_march_fix_bits: an HDR sun) is brought there by scaling the
+// device's copy of the radiance by 2^(bits - 36) before and the rows it wrote by 2^(36 - bits) after -- so that the
+// path tree's scalar-register-tight walk carries no value it did not carry in round 4 (one more costs it 3-6 %)
+__global__ void k_scale_rows(double* __restrict__ ghost, MarchArgs a, double factor) {
+  const size_t p = (size_t)a.y0 * a.W + (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (p >= (size_t)a.y1 * a.W) return;
+  const int t = (int)(p / a.W) >> 3;
+  if (t < a.trow0 || (t - a.trow0) % a.tperiod != 0) return;
+#pragma unroll
+  for (int c = 0; c < 3; c++) ghost[3 * p + c] *= factor;
+}
+
 __global__ void k_march_finish(const unsigned long long* __restrict__ accum, MarchArgs a,
                                double* __restrict__ ghost) {
   const size_t p = (size_t)a.y0 * a.W + (size_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -692,7 +705,7 @@ __global__ void k_march_finish(const unsigned long long* __restrict__ accum, Mar
   if (t < a.trow0 || (t - a.trow0) % a.tperiod != 0) return;
 #pragma unroll
   for (int c = 0; c < 3; c++) {
-    const double v = ((double)accum[3 * p + c] * a.inv_fix) / (double)a.spp;
+    const double v = ((double)accum[3 * p + c] * (1.0 / 68719476736.0)) / (double)a.spp;
     ghost[3 * p + c] = a.accumulate ? ghost[3 * p + c] + v : v;
   }
 }
@@ -1105,8 +1118,17 @@ lf_status lfk_march(lf_ctx* ctx, int spp, uint64_t key) {
     lf_status st = build_event_table(ctx);
     if (st != LF_OK) return st;
   }
-  LF_HIP(ctx, hipMemcpyAsync(ctx->lens_dev, &ctx->lens, sizeof(LfLensDev), hipMemcpyHostToDevice,
-                             ctx->stream));
+  {
+    // the launch's fixed-point grid: the kernels scale by the literal 2^36 and back by 2^-36, the device's sun_radiance
+    // carries 2^(bits - 36) (exact: a power of two) and k_scale_rows takes it out of the rows the launch wrote --
+    // together (u64)(v 2^bits) and back, as the contract says
+    const int bits = lf_march_fix_bits(ctx->lens, ctx->pairs.n, spp);
+    ctx->march_fix_bits = bits;
+    LfLensDev up = ctx->lens;
+    for (int c = 0; c < 3; c++) up.sun_radiance[c] = std::ldexp(ctx->lens.sun_radiance[c], bits - 36);
+    // (pageable source of an asynchronous copy: the runtime stages it before the call returns)
+    LF_HIP(ctx, hipMemcpyAsync(ctx->lens_dev, &up, sizeof(LfLensDev), hipMemcpyHostToDevice, ctx->stream));
+  }
   LF_HIP(ctx, hipMemcpyAsync(ctx->pairs_dev, &ctx->pairs, sizeof(LfPairsDev), hipMemcpyHostToDevice,
                              ctx->stream));
   if (ctx->y1 <= ctx->y0) return LF_OK;
@@ -1125,12 +1147,6 @@ lf_status lfk_march(lf_ctx* ctx, int spp, uint64_t key) {
   a.vz = ctx->lens.pupil_z - ctx->lens.z_sensor;
   a.accumulate = ctx->ghost_accumulate ? 1 : 0;
   a.xs = ctx->march_xstride_log2;
-  {
-    const int bits = lf_march_fix_bits(ctx->lens, ctx->pairs.n, spp);
-    a.fix_scale = std::ldexp(1.0f, bits);
-    a.inv_fix = std::ldexp(1.0, -bits);
-    ctx->march_fix_bits = bits;
-  }
   {
     // candidate selection (the contract, the same expression in oracle/lf_geo_oracle.c): d.s above
     // 1 - 1.0625 (1 - cos alpha) - 4e-7 MAY lie inside the lobe.  The 1/16 margin is relative, the
@@ -1202,6 +1218,13 @@ lf_status lfk_march(lf_ctx* ctx, int spp, uint64_t key) {
     }
   }
 #endif
+  const int fix_shift = 36 - ctx->march_fix_bits;       // != 0: an HDR launch (see k_scale_rows)
+  const size_t band_px = (size_t)(ctx->y1 - ctx->y0) * ctx->W;
+  if (fix_shift != 0 && a.accumulate) {                   // what the buffer holds joins the launch's grid, exactly
+    hipLaunchKernelGGL(k_scale_rows, dim3((unsigned)((band_px + 255) / 256)), dim3(256), 0, ctx->stream, ctx->ghost, a,
+                       std::ldexp(1.0, -fix_shift));
+    LF_HIP(ctx, hipGetLastError());
+  }
   // the paths a pre-pass found able to reach the light (lf_cull.hip) -- or every path of every sample
   ctx->last_march_culled = lf_cull_applies(ctx, a.G);
   if (ctx->last_march_culled) {
@@ -1235,6 +1258,11 @@ lf_status lfk_march(lf_ctx* ctx, int spp, uint64_t key) {
     const size_t px = (size_t)(ctx->y1 - ctx->y0) * ctx->W;
     hipLaunchKernelGGL(k_march_finish, dim3((unsigned)((px + 255) / 256)), dim3(256), 0, ctx->stream,
                        ctx->accum, a, ctx->ghost);
+    LF_HIP(ctx, hipGetLastError());
+  }
+  if (fix_shift != 0) {
+    hipLaunchKernelGGL(k_scale_rows, dim3((unsigned)((band_px + 255) / 256)), dim3(256), 0, ctx->stream, ctx->ghost, a,
+                       std::ldexp(1.0, fix_shift));
     LF_HIP(ctx, hipGetLastError());
   }
   return LF_OK;

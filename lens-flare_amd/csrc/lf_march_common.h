@@ -43,8 +43,6 @@ struct MarchArgs {
   int n_tiles;         // wave tiles of the launch (the grid holds them padded to a multiple of 64)
   int xs;              // log2 of the lanes' pixel stride in x (lf_set_tile_stride): 0 = an 8 x 8 block of
                        // adjacent pixels per wave, 3 = columns 8 apart (a 64 x 8 block shared by 8 waves)
-  float fix_scale;     // 2^fix_bits: the launch's fixed-point grid (lf_march_fix_bits; 2^36 unless that could wrap)
-  double inv_fix;      // 2^-fix_bits
 };
 
 // The program of a GROUP of up to 3 wavelengths, in two levels (LfProgHdr / LfProgRow in

@@ -82,6 +82,27 @@ def test_hdr_sun_does_not_wrap_and_bad_inputs_are_refused(pkg):
         a, _, ba = frame(2.0 ** 30)
         b, _, bb = frame(2.0 ** 40)
         assert ba - bb == 10 and np.array_equal(b, a * 1024.0) and a.max() > 0
+        # a frame composed of two launches (lf_set_ghost_accumulate) on an HDR grid: what the buffer holds is
+        # brought to the launch's grid and back by exact powers of two -- the sum of the two frames, bit for bit
+        lf.set_sun(sun, [2.0 ** 30, 2.0 ** 29, 2.0 ** 28], 0.05)
+        n, stop = lens["n"], lens["stop"]
+        allp = [(i, j) for i in range(n) for j in range(i + 1, n) if i != stop and j != stop]
+        front, rear = [p for p in allp if p[0] < stop], [p for p in allp if p[0] > stop]
+        lf.set_ghost_pairs(front, True)
+        lf.trace_ghosts(spp, key)
+        fa = lf.read_buffer(pkg.GHOST_BUFFER)
+        lf.set_ghost_pairs(rear, False)
+        lf.trace_ghosts(spp, key)
+        fb = lf.read_buffer(pkg.GHOST_BUFFER)
+        assert lf.march_fix_bits() < 36 and fa.max() > 0 and fb.max() > 0
+        lf.set_ghost_pairs(front, True)
+        lf.trace_ghosts(spp, key)
+        lf.set_ghost_pairs(rear, False)
+        lf.set_ghost_accumulate(True)
+        lf.trace_ghosts(spp, key)
+        lf.set_ghost_accumulate(False)
+        assert np.array_equal(lf.read_buffer(pkg.GHOST_BUFFER), fa + fb)
+        lf.set_ghost_pairs(None, True)
         # refused inputs leave the context usable
         for bad in ([np.nan, 1, 1], [1, -1e-3, 1], [1, 1, np.inf], [-0.0 - 1.0, 0, 0]):
             with pytest.raises(pkg.LensFlareError) as e:
