@@ -477,8 +477,8 @@ lf_status lf_set_tile_stride(lf_ctx* ctx, int stride);
 lf_status lf_trace_ghosts(lf_ctx* ctx, int spp, uint64_t key);
 /* PATH CULLING (round 5; no reference counterpart -- the reference enumerates 13 fixed pairs per channel and
  * draws each as one quad, pathtracer.cpp:735-762, :452-508).  lf_trace_ghosts does not start a path where it
- * cannot carry light: a pre-pass bounds, for every block of 64 x 64 sensor pixels, every stratum of the pupil
- * square and every selected path, where the rays of that 4-D box can go -- on each diaphragm of the path and in
+ * cannot carry light: a pre-pass bounds, for every block of 64 x 64 sensor pixels (128 x 128 where that is still
+ * <= 1.25 mm on the sensor and the launch has few samples: 4K below 256 spp x 3 wavelengths), every cell of the pupil square and every selected path, where the rays of that 4-D box can go -- on each diaphragm of the path and in
  * direction space at the exit -- and the march starts only the paths whose box may end inside the sun's lobe.
  * A path that is not started would have contributed exactly 0, so ghost_buffer is the buffer of the full
  * enumeration BIT FOR BIT; lf_counters / lf_get_executed_events count the rays that were started.
@@ -488,7 +488,7 @@ lf_status lf_trace_ghosts(lf_ctx* ctx, int spp, uint64_t key);
  * Applies to at most 64 paths and 4096 samples per pixel; beyond, lf_trace_ghosts marches everything.
  * lf_get_cull_info: {mode, did the last lf_trace_ghosts cull, blocks_x, blocks_y, cells per block (the pupil
  * strata G x G), G, pre-pass cells per axis, block size in pixels}.  lf_get_cull_table: the masks the last
- * launch used, [blocks_y * blocks_x][cells + 1] (bit q = path q of the selection in lf_set_ghost_pairs order,
+ * launch used, [blocks_y * blocks_x][cells + 1] (block side = info[7] pixels; bit q = path q of the selection in lf_set_ghost_pairs order,
  * the primary path first; entry `cells` = the union, used by the unstratified samples s >= G * G), so that a
  * checker can march exactly what the device marched. */
 lf_status lf_set_march_culling(lf_ctx* ctx, int mode);

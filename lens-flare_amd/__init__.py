@@ -637,6 +637,11 @@ class LensFlare:
         self._ck(self.lib.lf_get_cull_table(self.ctx, _fp(t, C.c_uint64), C.c_size_t(t.size)))
         return t
 
+    def cull_table_and_block(self):
+        """(table, block side in pixels) for a checker (lfo.geo_trace / g64_trace cull=...); None if not culled."""
+        t = self.cull_table()
+        return None if t is None else (t, self.cull_info()["block_px"])
+
     def march_fix_bits(self):
         b = C.c_int(0)
         self._ck(self.lib.lf_get_march_fix_bits(self.ctx, C.byref(b)))

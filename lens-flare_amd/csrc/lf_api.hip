@@ -919,7 +919,7 @@ lf_status lf_get_cull_info(lf_ctx* ctx, int info[8]) {
   info[0] = ctx->march_cull;
   info[1] = ctx->last_march_culled ? 1 : 0;
   info[2] = ctx->cull_bx; info[3] = ctx->cull_by; info[4] = ctx->cull_cells; info[5] = ctx->cull_G; info[6] = ctx->cull_P;
-  info[7] = 1 << kCullBlockLog2;
+  info[7] = 1 << ctx->cull_blk_log2;
   return LF_OK;
 }
 

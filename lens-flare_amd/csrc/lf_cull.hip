@@ -52,7 +52,7 @@ constexpr int kCullSamples = 15;   // per box, at the middle wavelength: a 3 x 3
 struct CullLevelArgs {
   int W, H;
   float pitch, half_w, half_h;
-  int blocks_x, blocks_y;
+  int blocks_x, blocks_y, blk_log2;
   int P;                   // pupil cells per axis at THIS level
   int P_final;             // ... of the table (the last level)
   int last;                // the last level writes the table, the others the next level's work list
@@ -129,8 +129,8 @@ __global__ __launch_bounds__(256) void k_cull_level(const LfLensDev* __restrict_
   const int ci = cell % a.P, cj = cell / a.P;
   const int bx = blk % a.blocks_x, by = blk / a.blocks_x;
 
-  const float px0 = (float)(bx << kCullBlockLog2), px1 = fminf((float)a.W, (float)((bx + 1) << kCullBlockLog2));
-  const float py0 = (float)(by << kCullBlockLog2), py1 = fminf((float)a.H, (float)((by + 1) << kCullBlockLog2));
+  const float px0 = (float)(bx << a.blk_log2), px1 = fminf((float)a.W, (float)((bx + 1) << a.blk_log2));
+  const float py0 = (float)(by << a.blk_log2), py1 = fminf((float)a.H, (float)((by + 1) << a.blk_log2));
   const float Xc = -((0.5f * (px0 + px1)) - a.half_w) * a.pitch, Yc = -((0.5f * (py0 + py1)) - a.half_h) * a.pitch;
   const float hX = 0.5f * (px1 - px0) * a.pitch, hY = 0.5f * (py1 - py0) * a.pitch;
   const float invP = 1.0f / (float)a.P;
@@ -562,7 +562,7 @@ void k_march_cull(const LfLensDev* __restrict__ lens, const LfPairsDev* __restri
   const lanemask active_mask = __ballot(active);
   const unsigned p = (unsigned)y * (unsigned)a.W + (unsigned)x;
   // the tile's cull row: its 64 columns and 8 rows lie inside one 64 x 64 block
-  const int blk = ((trow * 8) >> kCullBlockLog2) * cull.blocks_x + ((((tx >> a.xs) << (3 + a.xs))) >> kCullBlockLog2);
+  const int blk = ((trow * 8) >> cull.blk_log2) * cull.blocks_x + ((((tx >> a.xs) << (3 + a.xs))) >> cull.blk_log2);
   const unsigned long long* const crow = cull.table + (size_t)blk * (size_t)(cull.cells + 1);
 
   const float pitch = lens->pitch, pupil_h = lens->pupil_h, geom_norm = lens->geom_norm;
@@ -712,7 +712,7 @@ void k_march_items(const LfLensDev* __restrict__ lens, const LfPairsDev* __restr
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int lane = tid & 63;
   const int n_paths = pairs->n;
-  const int blk = ((trow * 8) >> kCullBlockLog2) * cull.blocks_x + ((((tx >> a.xs) << (3 + a.xs))) >> kCullBlockLog2);
+  const int blk = ((trow * 8) >> cull.blk_log2) * cull.blocks_x + ((((tx >> a.xs) << (3 + a.xs))) >> cull.blk_log2);
   const unsigned long long* const crow = cull.table + (size_t)blk * (size_t)(cull.cells + 1);
   const float pitch = lens->pitch, pupil_h = lens->pupil_h, geom_norm = lens->geom_norm;
   const float half_w = a.half_w, half_h = a.half_h, vz_u = a.vz;
@@ -886,19 +886,26 @@ bool lf_cull_applies(const lf_ctx* ctx, int G) {
   // block must be SMALL on the sensor for 13 rays to bound it: 64 pixels <= 1.8 mm (the full-enumeration comparison
   // finds the first skipped lit ray at blocks of 4.8 mm, none up to 3.6 mm: profiles/r05_cull_block_size.json) --
   // frames narrower than 1280 pixels on a 36 mm sensor march everything, which costs them little
-  const double block_mm = (double)(1 << kCullBlockLog2) * (double)ctx->sensor_w_mm / (double)std::max(1, ctx->W);
+  const double block_mm = (double)(1 << kCullBlockLog2) * (double)ctx->sensor_w_mm / (double)std::max(1, ctx->W);   // (the smallest block)
   if (block_mm > kCullMaxBlockMm && !std::getenv("LF_CULL_ANY_BLOCK")) return false;
   return ctx->pairs.n <= kCullMaxPaths && G >= 1 && G <= 64 && ctx->lens.stop >= 0;
 }
 
-lf_status lfk_cull_prepass(lf_ctx* ctx, int G) {
+lf_status lfk_cull_prepass(lf_ctx* ctx, int G, int spp) {
   const LfLensDev& L = ctx->lens;
   CullLevelArgs a;
   std::memset(&a, 0, sizeof(a));
   a.W = ctx->W; a.H = ctx->H;
   a.pitch = L.pitch; a.half_w = 0.5f * (float)ctx->W; a.half_h = 0.5f * (float)ctx->H;
-  a.blocks_x = (ctx->W + (1 << kCullBlockLog2) - 1) >> kCullBlockLog2;
-  a.blocks_y = (ctx->H + (1 << kCullBlockLog2) - 1) >> kCullBlockLog2;
+  a.blk_log2 = kCullBlockLog2;
+  // 128-pixel blocks -- a quarter of the pre-pass's boxes, a looser table (4K: 3.5 % started against 2.2 %) -- where
+  // they are still small on the sensor AND the march is short enough for the pre-pass to matter: measured at 4K,
+  // 256 spp x 3 wavelengths tie (139.8 / 139.3 ms), 1024 x 8 lose (1035 against 761 ms): profiles/r05_march_variants.txt
+  if ((double)(2 << kCullBlockLog2) * (double)ctx->sensor_w_mm / (double)std::max(1, ctx->W) <= kCullBigBlockMm &&
+      (long long)spp * L.n_lambda < 768 && !std::getenv("LF_CULL_SMALL_BLOCKS"))
+    a.blk_log2 = kCullBlockLog2 + 1;
+  a.blocks_x = (ctx->W + (1 << a.blk_log2) - 1) >> a.blk_log2;
+  a.blocks_y = (ctx->H + (1 << a.blk_log2) - 1) >> a.blk_log2;
   const int m = cull_m(ctx, G);
   a.P_final = G * m;
   a.n_paths = ctx->pairs.n;
@@ -945,7 +952,7 @@ lf_status lfk_cull_prepass(lf_ctx* ctx, int G) {
   const size_t entries = nblk * ((size_t)a.P_final * a.P_final + 1);
   const bool reuse = ctx->march_cull == 1 && ctx->cull_dev && ctx->cull_hash == h && !std::getenv("LF_CULL_NO_REUSE");
   ctx->cull_bx = a.blocks_x; ctx->cull_by = a.blocks_y; ctx->cull_cells = a.P_final * a.P_final; ctx->cull_G = G;
-  ctx->cull_P = a.P_final; ctx->cull_m = m;
+  ctx->cull_P = a.P_final; ctx->cull_m = m; ctx->cull_blk_log2 = a.blk_log2;
   if (reuse) return LF_OK;
   if (entries > ctx->cull_cap) {
     LF_HIP(ctx, hipStreamSynchronize(ctx->stream));
@@ -1044,6 +1051,7 @@ lf_status lfk_march_culled(lf_ctx* ctx, const MarchArgs& a, size_t blocks, size_
   const LfApertureDev& m = ctx->ap[LF_APERTURE_STARBURST];
   LfCullArgs c;
   c.table = ctx->cull_dev; c.blocks_x = ctx->cull_bx; c.blocks_y = ctx->cull_by; c.cells = ctx->cull_cells;
+  c.blk_log2 = ctx->cull_blk_log2;
   c.P = ctx->cull_P; c.m = ctx->cull_m; c.m_shift = ctx->cull_m == 4 ? 2 : ctx->cull_m == 2 ? 1 : 0;
   hipEvent_t ev = lf_timing_begin(ctx, LFK_MARCH);
 #define LF_LAUNCH_CULL1(KK, WW)                                                                               \

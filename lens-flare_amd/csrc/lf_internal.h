@@ -208,13 +208,18 @@ enum { LF_EV_REST1 = 8, LF_EV_SAVE0 = 0x10, LF_EV_SAVE1 = 0x20, LF_EV_END = 0x40
 // march then starts ONLY the paths whose bit is set: the others end outside the sun's lobe or on a diaphragm,
 // i.e. add exactly 0 -- the pixels are those of the full enumeration, bit for bit.  Entry `cells` of a block
 // is the union over its cells (the unstratified samples s >= G * G of a non-square sample count).
-constexpr int kCullBlockLog2 = 6;        // sensor blocks of 64 x 64 pixels (a wave tile of any stride lies inside one)
+// sensor blocks of 2^6 = 64 or 2^7 = 128 pixels a side (lf_cull_block_log2): a wave tile of any stride lies inside one;
+// 128 where that is still <= 1.25 mm on the sensor (4K on 36 mm: the blocks of 1080p in millimetres, a quarter of the
+// pre-pass's boxes) and the launch has few samples (lfk_cull_prepass)
+constexpr int kCullBlockLog2 = 6;
+constexpr double kCullBigBlockMm = 1.25;
 constexpr int kCullMaxPaths = 64;        // bits of a mask
 constexpr double kCullMaxBlockMm = 1.8;  // a block may be this large on the sensor at most (lf_cull_applies)
 constexpr int kCullOcc = 32;             // the stop mask's occupancy grid: kCullOcc x kCullOcc cells, any texel > 0
 struct LfCullArgs {
   const unsigned long long* table;   // [blocks_y * blocks_x][cells + 1]; null = every path everywhere
   int blocks_x, blocks_y;
+  int blk_log2;                       // log2 of a block's side in pixels
   int cells;                          // P * P, P = G * m cells per axis of the pupil square
   int P, m, m_shift;                  // m (1, 2 or 4) table cells per axis inside one stratum; m = 2^m_shift <= the
                                       // sub-cells per axis of the sampling specification (lf_set_pupil_subcells)
@@ -383,7 +388,7 @@ struct lf_ctx {
   // launch just takes the other kernel.
   double cull_max_fraction = 0.12;
   uint64_t cull_hash = 0;                      // of the inputs the resident table was built from (0 = none)
-  int cull_bx = 0, cull_by = 0, cull_cells = 0, cull_G = 0, cull_P = 0;
+  int cull_bx = 0, cull_by = 0, cull_cells = 0, cull_G = 0, cull_P = 0, cull_blk_log2 = 6;
   float cull_margin = 1.25f;                   // footprint inflation of the pre-pass (LF_CULL_MARGIN: experiments)
   unsigned cull_occ[kCullOcc] = {};            // occupancy of the stop mask (host, lf_set_aperture)
   uint64_t mask_generation = 0;                // bumped by lf_set_aperture(STARBURST)
@@ -467,7 +472,7 @@ int lf_march_fix_bits(const LfLensDev& L, int n_paths, int spp);
 // lf_cull.hip (a = the launch's arguments as lfk_march set them up: lf_march_common.h)
 namespace lfm { struct MarchArgs; }
 bool lf_cull_applies(const lf_ctx* ctx, int G);
-lf_status lfk_cull_prepass(lf_ctx* ctx, int G);
+lf_status lfk_cull_prepass(lf_ctx* ctx, int G, int spp);
 lf_status lfk_march_culled(lf_ctx* ctx, const lfm::MarchArgs& a, size_t blocks, size_t dyn_lds);
 void lf_derive_lens(lf_ctx* ctx, int n, int stop, int n_lambda, const float* radius,
                     const float* thickness, const float* ior, const float* semi_ap,

@@ -1228,7 +1228,7 @@ lf_status lfk_march(lf_ctx* ctx, int spp, uint64_t key) {
   // the paths a pre-pass found able to reach the light (lf_cull.hip) -- or every path of every sample
   ctx->last_march_culled = lf_cull_applies(ctx, a.G);
   if (ctx->last_march_culled) {
-    lf_status st = lfk_cull_prepass(ctx, a.G);
+    lf_status st = lfk_cull_prepass(ctx, a.G, spp);
     if (st != LF_OK) return st;
     // a table that starts most of everything (a very wide sun, a handful of samples): the path tree is faster
     if (ctx->cull_started_fraction > ctx->cull_max_fraction && !std::getenv("LF_CULL_FORCE")) ctx->last_march_culled = false;

@@ -354,10 +354,11 @@ static double sample_ray(const g64_lens* L, const g64_system* S, int W, int H, i
  * the full enumeration's -- the independent evidence that what the device skips adds nothing -- while the
  * counters count the rays the device starts (block = 64 x 64 pixels, entry = the sample's pupil stratum). */
 static const uint64_t* g64_cull = NULL;
-static int g64_cull_bx = 0, g64_cull_cells = 0;
-void g64_set_cull(const uint64_t* table, int blocks_x, int blocks_y, int cells) {
+static int g64_cull_bx = 0, g64_cull_cells = 0, g64_cull_shift = 6;
+void g64_set_cull(const uint64_t* table, int blocks_x, int blocks_y, int cells, int block_px) {
   (void)blocks_y;
   g64_cull = table; g64_cull_bx = blocks_x; g64_cull_cells = cells;
+  g64_cull_shift = block_px == 128 ? 7 : 6;
 }
 
 /* image, frag: W*H*3 doubles (rows [y0, y1) are written); counters: launched, events, clipped at
@@ -406,7 +407,7 @@ void g64_trace(const g64_lens* L, int W, int H, int y0, int y1, int spp, const u
             const uint32_t sxi = sub_bits ? (r2[0] >> (32 - sub_bits)) : 0u, syi = sub_bits ? (r2[1] >> (32 - sub_bits)) : 0u;
             entry = (cy * m + (int)((syi * (uint32_t)m) >> sub_bits)) * P + cx * m + (int)((sxi * (uint32_t)m) >> sub_bits);
           }
-          started = g64_cull[((size_t)(y >> 6) * g64_cull_bx + (x >> 6)) * (size_t)(g64_cull_cells + 1) + (size_t)entry];
+          started = g64_cull[((size_t)(y >> g64_cull_shift) * g64_cull_bx + (x >> g64_cull_shift)) * (size_t)(g64_cull_cells + 1) + (size_t)entry];
         }
         for (int lam = 0; lam < L->n_lambda; lam++)
           for (int q = 0; q < n_pairs; q++) {

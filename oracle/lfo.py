@@ -278,18 +278,23 @@ def _device_cull(cull, W, H, spp):
         cull = _followed_lf.cull_table() if _followed_lf is not None and hasattr(_followed_lf, "cull_table") else None
     if cull is None:
         return None
+    if isinstance(cull, tuple):      # (table, block_px)
+        return np.ascontiguousarray(cull[0], np.uint64), int(cull[1])
     cull = np.ascontiguousarray(cull, np.uint64)
     G = int(np.floor(np.sqrt(spp)))
     while (G + 1) * (G + 1) <= spp:
         G += 1
     while G * G > spp:
         G -= 1
-    want = [((H + 63) // 64, (W + 63) // 64, (G * m) ** 2 + 1) for m in (1, 2, 4)]
+    want = {((H + bp - 1) // bp, (W + bp - 1) // bp, (G * m) ** 2 + 1): bp for bp in (128, 64) for m in (1, 2, 4)}
     if auto and cull.shape not in want:
         return None      # the followed device's last launch was another frame (it did not render this one): count every ray
-    assert cull.shape in want, f"cull table {cull.shape} is not the one of a {W}x{H} frame at {spp} spp {want}: " \
+    assert cull.shape in want, f"cull table {cull.shape} is not the one of a {W}x{H} frame at {spp} spp {list(want)}: " \
                                "the device's last trace_ghosts was another launch"
-    return cull
+    block_px = want[cull.shape]
+    if auto:
+        block_px = _followed_lf.cull_info()["block_px"]
+    return cull, block_px
 
 
 def geo_trace(lens, W, H, y0, y1, spp, key, pairs, include_primary, mask, sun_dir, sun_radiance,
@@ -314,13 +319,14 @@ def geo_trace(lens, W, H, y0, y1, spp, key, pairs, include_primary, mask, sun_di
     k = (C.c_uint32 * 2)(key & 0xffffffff, (key >> 32) & 0xffffffff)
     lib().geo_culled_lit.restype = C.c_uint64
     if table is not None:
-        lib().geo_set_cull(_p(table, C.c_uint64), table.shape[1], table.shape[0], table.shape[2] - 1)
+        table, block_px = table
+        lib().geo_set_cull(_p(table, C.c_uint64), table.shape[1], table.shape[0], table.shape[2] - 1, block_px)
     try:
         lib().geo_trace(C.byref(L), W, H, y0, y1, spp, k, _p(pairs, C.c_int), len(pairs),
                         _p(mask, C.c_float), mask.shape[1], mask.shape[0], _p(ghost, C.c_double),
                         C.byref(cnt), n_threads)
     finally:
-        lib().geo_set_cull(None, 0, 0, 0)
+        lib().geo_set_cull(None, 0, 0, 0, 64)
     last_culled_lit = int(lib().geo_culled_lit())
     if last_culled_lit:
         print(f"lfo.geo_trace: {last_culled_lit} rays that the device's cull table skips reached the light")
@@ -568,13 +574,14 @@ def g64_trace(lens, W, H, y0, y1, spp, key, pairs, include_primary, mask, sun_di
     cnt = (C.c_uint64 * 8)()
     k = (C.c_uint32 * 2)(key & 0xffffffff, (key >> 32) & 0xffffffff)
     if table is not None:
-        lib().g64_set_cull(_p(table, C.c_uint64), table.shape[1], table.shape[0], table.shape[2] - 1)
+        table, block_px = table
+        lib().g64_set_cull(_p(table, C.c_uint64), table.shape[1], table.shape[0], table.shape[2] - 1, block_px)
     try:
         lib().g64_trace(C.byref(L), W, H, y0, y1, spp, k, int(sub_bits), _p(pairs, C.c_int), len(pairs),
                         _p(mask, C.c_float), mask.shape[1], mask.shape[0], _p(image, C.c_double),
                         _p(frag, C.c_double), cnt, n_threads)
     finally:
-        lib().g64_set_cull(None, 0, 0, 0)
+        lib().g64_set_cull(None, 0, 0, 0, 64)
     return image, frag, dict(zip(G64_COUNTERS, (int(v) for v in cnt)))
 
 

@@ -97,7 +97,7 @@ def test_dgauss_converged_pixels_within_1e4(pkg, lf):
     sun, rad, alpha = [0.03, 0.02, -1.0], [1.0, 0.9, 0.5], 0.05
     img, cnt = _gpu_frame(pkg, lf, lens, W, H, spp, key, mask, sun, rad, alpha)
     ref, frag, c64 = lfo.g64_trace(lens, W, H, 0, H, spp, key, None, True, mask, sun, rad, alpha,
-                                   n_threads=16, cull=lf.cull_table())
+                                   n_threads=16, cull=lf.cull_table_and_block())
     rel = _check_against_f64(img, cnt, ref, frag, c64, min_lit=150)
     print(f"dgauss: {rel.size} converged channel values, max rel {rel.max():.2e}, median {np.median(rel):.2e}")
 
@@ -110,7 +110,7 @@ def test_thin_lens_converged_pixels_within_1e4(pkg, lf):
     sun, rad, alpha = [0.02, -0.01, -1.0], [1.0, 1.0, 1.0], 0.1
     img, cnt = _gpu_frame(pkg, lf, lens, W, H, spp, key, mask, sun, rad, alpha)
     ref, frag, c64 = lfo.g64_trace(lens, W, H, 0, H, spp, key, None, True, mask, sun, rad, alpha,
-                                   n_threads=16, cull=lf.cull_table())
+                                   n_threads=16, cull=lf.cull_table_and_block())
     rel = _check_against_f64(img, cnt, ref, frag, c64, min_lit=1000)
     print(f"thin lens: {rel.size} converged channel values, max rel {rel.max():.2e}")
 
@@ -132,7 +132,7 @@ def test_eight_wavelengths_within_1e4(pkg, lf):
     lf.trace_ghosts(spp, key)
     img, cnt = lf.read_buffer(pkg.GHOST_BUFFER), lf.counters()
     ref, frag, c64 = lfo.g64_trace(lens8, W, H, 0, H, spp, key, None, True, mask, sun, rad, alpha,
-                                   n_threads=16, lambda_rgb=w8, cull=lf.cull_table())
+                                   n_threads=16, lambda_rgb=w8, cull=lf.cull_table_and_block())
     _check_against_f64(img, cnt, ref, frag, c64, min_lit=50)
 
 
@@ -221,7 +221,7 @@ def _band_against_f64(pkg, lf, lens, W, H, y0, y1, spp, key, mask, lambda_rgb=No
     try:
         ref, frag, c64 = lfo.g64_trace(lens, W, H, y0, y1, spp, key, None, True, mask, sun, rad, alpha,
                                        n_threads=_host_threads(), lambda_rgb=lambda_rgb,
-                                       cull=lf.cull_table())   # (pixels: the full enumeration's; counters: the rays the device started)
+                                       cull=lf.cull_table_and_block())   # (pixels: the full enumeration's; counters: the rays the device started)
     finally:
         lfo.g64_set_x_window()
     ref, frag = ref[y0:y1], frag[y0:y1]

@@ -101,7 +101,7 @@ def test_targeted_march_equals_both_oracles(pkg, lf):
     try:
         og, ocnt = lfo.geo_trace(lens, W, H, 0, H, spp, key, pa, True, mask, sun, rad, alpha)
         lfo.geo_follow_device(None)
-        ref, frag, c64 = lfo.g64_trace(lens, W, H, 0, H, spp, key, pa, True, mask, sun, rad, alpha, n_threads=16, cull=lf.cull_table())
+        ref, frag, c64 = lfo.g64_trace(lens, W, H, 0, H, spp, key, pa, True, mask, sun, rad, alpha, n_threads=16, cull=lf.cull_table_and_block())
     finally:
         lfo.geo_follow_device(None)
         lfo.set_pupil_target(0.0, 0.0)
