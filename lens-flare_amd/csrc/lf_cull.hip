@@ -72,19 +72,19 @@ struct CullLevelArgs {
 
 // A glass event of the pre-pass: the arithmetic of surface_event<false> (lf_march_events.h) WITHOUT a clear aperture
 // -- the sample goes on wherever the sphere is -- that also hands out HOW FAR the sample is from being lost:
-// miss = disc / (G^2 + |c n^2 F|) (< 0: no intersection), tir = k2 / (disc + |delta|) (< 0: total reflection of a
-// refraction), both relative and of order 1 away from the boundaries.  Not bit-critical: nothing here reaches a pixel.
+// disc (< 0: no intersection) and, for a refraction, tir = (n' cos t')^2 / (|disc| + |n'^2 - n^2|) (< 0: total
+// reflection), relative and of order 1 away from the boundary.  Not bit-critical: nothing here reaches a pixel.
+// (The raw (n' cos t')^2 with one scale per box saves the reciprocal and 1.5 ms of the bench frame's pre-pass but
+// loses its first lit ray on 3.6 mm blocks instead of 4.8 mm: profiles/r05_march_variants.txt.)
 __device__ __forceinline__ void virtual_event(Ray& r, const LfProgRow& w, float cn22, float rn2, float delta, bool reflect,
-                                              bool flat, float& miss, float& tir) {
+                                              bool flat, float& disc_out, float& tir) {
   const float oz = r.hz + w.dzv;
   const float od = fmaf(r.px, r.dx, fmaf(r.py, r.dy, oz * r.dz));
   const float oo = fmaf(oz, oz, fmaf(r.px, r.px, r.py * r.py));
   const float Fh = fmaf(w.ch, oo, -oz);
   const float G = fmaf(-w.curv, od, r.dz);
-  const float cF = cn22 * Fh;
-  const float G2 = G * G;
-  const float disc = G2 - cF;
-  miss = disc * lf_rcp(G2 + fabsf(cF) + 1e-30f);
+  const float disc = fmaf(G, G, -(cn22 * Fh));
+  disc_out = disc;
   const float sq = lf_sqrt(disc);
   const float t = flat ? (Fh + Fh) * lf_rcp(fmaf(w.sgn, sq, G)) : fmaf(-w.sgn, sq, G) * rn2;
   const float hx = fmaf(t, r.dx, r.px), hy = fmaf(t, r.dy, r.py), hz = fmaf(t, r.dz, oz);
@@ -267,9 +267,9 @@ __global__ __launch_bounds__(256) void k_cull_level(const LfLensDev* __restrict_
         ok = hx == hx && hy == hy;
         if (ok) hit |= 1u << t;
       } else {
-        float miss, tir;
-        virtual_event(r[t], wr, cn22_of[w], rn2_of[w], delta_of[w], (kind & LF_EV_REFLECT) != 0, (kind & LF_EV_FLAT) != 0, miss, tir);
-        const bool reaches = miss >= 0.0f;
+        float disc, tir;
+        virtual_event(r[t], wr, cn22_of[w], rn2_of[w], delta_of[w], (kind & LF_EV_REFLECT) != 0, (kind & LF_EV_FLAT) != 0, disc, tir);
+        const bool reaches = disc >= 0.0f;
         if (reaches) hit |= 1u << t;                // (a totally reflected ray did reach the interface)
         ok = reaches && tir >= 0.0f;
         if (reaches && ((live >> t) & 1u)) {

@@ -248,3 +248,35 @@ def test_bench_frame_culled_equals_full_on_other_suns(pkg, lf):
         assert c1["rays_launched"] < 0.1 * c0["rays_launched"]
         print(f"sun {sun} alpha {alpha}: started {c1['rays_launched'] / c0['rays_launched']:.4f} of the rays, "
               f"reached the scene {c1['rays_reached_scene'] / c1['rays_launched']:.3f} (full: {c0['rays_reached_scene'] / c0['rays_launched']:.3f})")
+
+
+@pytest.mark.parametrize("mask_name,refocus_mm,lens_name", [
+    ("pentbiglines.png", 0.0, "dgauss11.lens"),       # a small pentagon with thin bright lines: the occupancy grid, not a bounding box
+    ("octagonbokeh.png", 0.0, "dgauss11.lens"),       # a nearly full stop
+    ("pentbig500_14.png", 500.0, "dgauss11.lens"),    # the lens refocused to half a metre (the sensor 5.7 mm further back)
+    ("pentbig500_14.png", 0.0, "dgauss11_8lambda.lens"),
+    ("synthetic_ring", 0.0, "dgauss11.lens")])        # an annular stop: open cells around a closed centre
+def test_other_masks_focus_and_prescriptions_at_1080p(pkg, lf, mask_name, refocus_mm, lens_name):
+    """whole 1080p frames, the automatic choice: culled = full enumeration bit for bit under other stop masks (the cull
+    reads a 32 x 32 occupancy grid of the mask), a refocused lens and the 8-wavelength prescription"""
+    lens = pkg.load_lens_file(lens_name)
+    if mask_name == "synthetic_ring":
+        yy, xx = np.mgrid[0:256, 0:256]
+        rr = np.hypot(xx - 127.5, yy - 127.5) / 128.0
+        mask = ((rr > 0.35) & (rr < 0.8)).astype(np.float32)
+    else:
+        mask = load_texels(mask_name)
+    W, H, spp = 1920, 1080, 16
+    lam = None
+    if lens_name.endswith("8lambda.lens"):
+        lam, _ = pkg.spectral_weights(lens["lambda_nm"])
+    for sun, alpha in (([0.03, 0.02, -1.0], 0.05), ([-0.15, 0.2, -1.0], 0.03)):
+        _setup(pkg, lf, lens, W, H, sun, alpha, mask, lambda_rgb=lam)
+        if refocus_mm > 0:
+            lf.focus_lens(refocus_mm)
+        g1, c1, info, g0, c0 = _both(pkg, lf, spp, 0xF0C5)
+        assert np.array_equal(g1, g0) and c1["rays_hit_light"] == c0["rays_hit_light"]
+        if info["culled"]:
+            assert c1["rays_launched"] < 0.5 * c0["rays_launched"]
+        print(f"{mask_name} {lens_name} refocus {refocus_mm} sun {sun}: culled {info['culled']}, started "
+              f"{c1['rays_launched'] / c0['rays_launched']:.4f}, lit rays {c0['rays_hit_light']}")
