@@ -654,6 +654,16 @@ def main():
                 sampling_variants[name] = {"ms_per_step": ms_v, "executed_events_per_s": ev_v / (ms_v * 1e-3),
                                            "executed_events_per_frame": ev_v}
         lf.set_march_culling(cull_mode)
+        if cull_mode != 0 and lf.cull_info()["culled"]:
+            # SURVEY 8d's unit event (intersect + refract / reflect + Fresnel) on EVERY executed event: k_march_cull<K, true>,
+            # the same pixels (tests/test_gpu_cull.py::test_weight_on_every_event_is_the_same_frame), timed by this run
+            os.environ["LF_CULL_WEIGHTS_FIRST"] = "1"
+            try:
+                ms_v, ev_v = timed_variant()
+            finally:
+                del os.environ["LF_CULL_WEIGHTS_FIRST"]
+            sampling_variants["every_event_weighted"] = {"ms_per_step": ms_v, "executed_events_per_s": ev_v / (ms_v * 1e-3),
+                                                         "executed_events_per_frame": ev_v}
         sampling_variants["note"] = ("tile_correlation = 64 Var(mean of 8 x 8 adjacent pixels) / mean pixel variance on this frame "
                                      "(1 = independent pixels, 64 = the block moves as one); every variant runs under the frame's "
                                      "culling mode except the two named after theirs")

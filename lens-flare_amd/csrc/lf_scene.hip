@@ -582,6 +582,187 @@ __global__ __launch_bounds__(256, LF_SCENE_WAVES) void k_scene_term(LfSceneDev s
   if (threadIdx.x < kSceneCounters && s_cnt[threadIdx.x]) atomicAdd(&counters[threadIdx.x], s_cnt[threadIdx.x]);
 }
 
+// ---- the lens camera with its scene rays compacted (round 5) ------------------------------------------
+// k_scene_term<.., true> walks the tree with the lanes whose sample LEFT the lens: a quarter of them on the
+// bench frames (the rest end at the stop or a clear aperture), so three quarters of every traversal
+// instruction are idle lanes.  Here a wave still owns one 8 x 8 tile and marches ITS lanes' primary paths in
+// lockstep (the loop variable `sample` is wave-uniform: lanes only drop out at a batch's convergence check),
+// but a sample that leaves the lens is appended to a queue in LDS (exit state in float32, owner lane,
+// wavelength, round) and the tree is walked 64 queue entries at a time, every lane busy, by whichever lane
+// the entry lands on.  The radiance of an entry depends on (pixel, sample, ray) only -- the Philox counter is
+// the OWNER's -- and goes back to the owner through LDS in queue order = sample order, so every pixel sees
+// the additions of scene_pixel<.., true> in the same order: bit-identical frames
+// (tests/test_gpu_lens_camera.py compares the two kernels).  A sample the lens blocks adds +0.0 to every sum
+// of scene_pixel and is simply never queued.
+constexpr int kLensQueue = 128;      // < 64 left over + one round of <= 64
+template <bool SOFT>
+__global__ __launch_bounds__(256, 3) void k_scene_lens(LfSceneDev sc, LfEnvDev ev, LfCamera cam, ScenePixelArgs a,
+                                                       int y0, int y1, int row_phase, int row_period, LfLensCamArgs lc,
+                                                       const LfPrimaryDev* __restrict__ prim,
+                                                       const float* __restrict__ mask,
+                                                       unsigned long long* __restrict__ counters,
+                                                       double* __restrict__ scene) {
+  __shared__ int s_stack[kStackDepth * 256];
+  __shared__ unsigned long long s_cnt[kSceneCounters];
+  __shared__ float s_qf[4][7][kLensQueue];       // px py hz dx dy dz, transmitted weight
+  __shared__ unsigned s_qt[4][kLensQueue];       // owner lane | wavelength << 6 | round << 10
+  __shared__ double s_res[4][3][64];             // a round's results on their way back, by owner lane
+  __shared__ unsigned s_stamp[4][64];            // round + 1 of the result that lies in s_res
+  if (threadIdx.x < kSceneCounters) s_cnt[threadIdx.x] = 0ull;
+  const int wv = (int)threadIdx.x >> 6, lane = threadIdx.x & 63;
+  s_stamp[wv][lane] = 0u;
+  __syncthreads();
+  int* const stack = s_stack + threadIdx.x;
+  const int tile_x = ((int)blockIdx.x * 4 + wv) * 8, tile_y = ((y0 >> 3) + (int)blockIdx.y) * 8;
+  const int x = tile_x + (lane & 7), y = tile_y + (lane >> 3);
+  const bool mine = x < a.W && y >= y0 && y < y1 && !(row_period > 1 && (y >> 3) % row_period != row_phase);
+  const int ns_aa = a.ns_aa;
+  const uint2 key2 = make_uint2((unsigned)a.key, (unsigned)(a.key >> 32));
+  SceneTally tally{0u, 0u};
+  unsigned lens_started = 0u, lens_left = 0u;
+  lfm::SampleSpec spec;
+  spec.W = a.W; spec.xs = lc.xs; spec.G = lc.G; spec.inv_G = lc.inv_G; spec.sub_bits = lc.sub_bits; spec.inv_sub = lc.inv_sub;
+  spec.key = key2; spec.pitch = lc.pitch; spec.half_w = lc.half_w; spec.half_h = lc.half_h;
+  spec.pupil_h = lc.pupil_h; spec.vz = lc.vz; spec.geom_norm = lc.geom_norm;
+  const int n_rays = lc.mode == 2 ? lc.n_lambda : 1;
+
+  // the owner's sums (scene_pixel's total / s1 / s2) and the sample whose rays are still arriving
+  V3 total = v3(0, 0, 0), Lcur = v3(0, 0, 0);
+  float s1 = 0.0f, s2 = 0.0f;
+  int cur_s = 0, final_sample = 0;
+  bool active = mine;
+  int q_count = 0;
+  auto finish_sample = [&]() {
+    if (cur_s) {
+      const float illum = (float)((0.2126f * Lcur.x + 0.7152f * Lcur.y) + 0.0722f * Lcur.z);
+      s1 += illum;
+      s2 += illum * illum;
+      total = total + Lcur;
+      cur_s = 0;
+    }
+  };
+  // the first n entries of the queue: radiance along each, back to the owners round by round, queue shifted
+  auto flush = [&](int n) {
+    const bool work = lane < n;
+    unsigned tag = 0u;
+    V3 C = v3(0, 0, 0);
+    if (work) {
+      tag = s_qt[wv][lane];
+      const float px = s_qf[wv][0][lane], py = s_qf[wv][1][lane], hz = s_qf[wv][2][lane];
+      const float dx = s_qf[wv][3][lane], dy = s_qf[wv][4][lane], dz = s_qf[wv][5][lane], wq = s_qf[wv][6][lane];
+      const int owner = (int)(tag & 63u), l = (int)((tag >> 6) & 15u), sample = (int)(tag >> 10) / n_rays + 1;
+      const size_t p = (size_t)(tile_y + (owner >> 3)) * a.W + (tile_x + (owner & 7));
+      const double wt = (double)wq * lc.exposure;
+      const double wpm = lc.world_per_mm;
+      const V3 oc = v3((double)px * wpm, (double)py * wpm, ((double)(prim->front_zv + hz) - lc.z_ref_mm) * wpm);
+      const V3 dc = unit(v3((double)dx, (double)dy, (double)dz));
+      const V3 ow = v3(cam.pos[0] + ((oc.x * cam.c2w[0] + oc.y * cam.c2w[1]) + oc.z * cam.c2w[2]),
+                       cam.pos[1] + ((oc.x * cam.c2w[3] + oc.y * cam.c2w[4]) + oc.z * cam.c2w[5]),
+                       cam.pos[2] + ((oc.x * cam.c2w[6] + oc.y * cam.c2w[7]) + oc.z * cam.c2w[8]));
+      const DRay ray = make_ray(ow,
+                                v3((dc.x * cam.c2w[0] + dc.y * cam.c2w[1]) + dc.z * cam.c2w[2],
+                                   (dc.x * cam.c2w[3] + dc.y * cam.c2w[4]) + dc.z * cam.c2w[5],
+                                   (dc.x * cam.c2w[6] + dc.y * cam.c2w[7]) + dc.z * cam.c2w[8]),
+                                cam.n_clip, cam.f_clip);
+      const V3 Ll = radiance<SOFT>(sc, ev, a.hemisphere != 0, ray, stack, a.ns_area_light,
+                                   make_uint4((unsigned)p, (unsigned)sample, 0u, 0u), key2, tally);
+      if (lc.mode == 2)
+        C = v3(Ll.x * (wt * (double)lc.lambda_rgb[l][0]), Ll.y * (wt * (double)lc.lambda_rgb[l][1]),
+               Ll.z * (wt * (double)lc.lambda_rgb[l][2]));
+      else
+        C = Ll * wt;
+    }
+    // back to the owners: one round at a time (within a round every owner has at most one entry), in queue order
+    lfm::lanemask pend = __ballot(work);
+    while (pend) {
+      const int src = __ffsll((long long)pend) - 1;
+      const unsigned r0 = (unsigned)__builtin_amdgcn_readlane((int)(tag >> 10), src);
+      const bool snd = work && (tag >> 10) == r0;
+      if (snd) {
+        const int owner = (int)(tag & 63u);
+        s_res[wv][0][owner] = C.x; s_res[wv][1][owner] = C.y; s_res[wv][2][owner] = C.z;
+        s_stamp[wv][owner] = r0 + 1u;
+      }
+      __builtin_amdgcn_wave_barrier();
+      if (s_stamp[wv][lane] == r0 + 1u) {
+        const int sample = (int)r0 / n_rays + 1;
+        if (sample != cur_s) { finish_sample(); cur_s = sample; Lcur = v3(0, 0, 0); }
+        Lcur = Lcur + v3(s_res[wv][0][lane], s_res[wv][1][lane], s_res[wv][2][lane]);
+        s_stamp[wv][lane] = 0u;                // (a round can straddle two flushes: taken once)
+      }
+      __builtin_amdgcn_wave_barrier();
+      pend &= ~__ballot(snd);
+    }
+    // what is left moves to the front
+    const int rem = q_count - n;
+    unsigned mt = 0u; float mf[7];
+    const bool mv = lane < rem;
+    if (mv) { mt = s_qt[wv][n + lane]; for (int k = 0; k < 7; k++) mf[k] = s_qf[wv][k][n + lane]; }
+    __builtin_amdgcn_wave_barrier();
+    if (mv) { s_qt[wv][lane] = mt; for (int k = 0; k < 7; k++) s_qf[wv][k][lane] = mf[k]; }
+    __builtin_amdgcn_wave_barrier();
+    q_count = rem;
+  };
+
+  int sample;
+  for (sample = 1; sample <= ns_aa; sample++) {     // wave-uniform
+    if (__ballot(active) == 0ull) break;
+    lfm::StartRay st{0.0f, 0.0f, 0.0f, 0.0f, -1.0f, 0.0f};
+    if (active) {
+      const int s_idx = (int)(((long long)(sample - 1) * (long long)lc.order_step) % (long long)ns_aa);
+      st = lfm::sample_start(spec, x, y, s_idx);
+    }
+    for (int li = 0; li < n_rays; li++) {
+      const int l = lc.mode == 2 ? li : lc.lambda_ref;
+      bool left = false;
+      lfm::Ray r{st.X, st.Y, 0.0f, fmaf(st.X, st.X, st.Y * st.Y), st.dx, st.dy, st.dz, st.w0, 1.0f};
+      if (active) {
+        left = lfm::primary_path(prim, l, r, mask, lc.mw, lc.mh, lane);
+        lens_started++;
+        if (left) lens_left++;
+      }
+      const lfm::lanemask lm = __ballot(left);
+      if (lm) {
+        if (left) {
+          const int slot = q_count + (int)__builtin_amdgcn_mbcnt_hi((unsigned)(lm >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)lm, 0u));
+          s_qf[wv][0][slot] = r.px; s_qf[wv][1][slot] = r.py; s_qf[wv][2][slot] = r.hz;
+          s_qf[wv][3][slot] = r.dx; s_qf[wv][4][slot] = r.dy; s_qf[wv][5][slot] = r.dz;
+          s_qf[wv][6][slot] = __fdiv_rn(r.wn, r.wd);
+          s_qt[wv][slot] = (unsigned)lane | ((unsigned)l << 6) | ((unsigned)((sample - 1) * n_rays + li) << 10);
+        }
+        q_count += __popcll(lm);
+        __builtin_amdgcn_wave_barrier();
+        if (q_count >= 64) flush(64);
+      }
+    }
+    if (sample > 1 && sample % a.samples_per_batch == 0) {  // pathtracer.cpp:862-868, with every ray of the batch in
+      while (q_count > 0) flush(q_count < 64 ? q_count : 64);
+      if (active) {
+        finish_sample();
+        const float sd = (float)sqrt(1.0 / (sample - 1) * (double)(s2 - s1 * s1 / (float)sample));
+        const float ci = (float)(1.96 * (double)sd / sqrt((double)sample));
+        if ((double)ci <= a.max_tolerance * (double)s1 / (double)sample) { active = false; final_sample = sample; }
+      }
+    }
+  }
+  while (q_count > 0) flush(q_count < 64 ? q_count : 64);
+  finish_sample();
+  if (mine) {
+    if (active) final_sample = ns_aa + 1;              // the loop ran to its end (:875)
+    const size_t p = (size_t)y * a.W + x;
+    const double rc = 1. / (double)final_sample;
+    scene[3 * p] = total.x * rc;
+    scene[3 * p + 1] = total.y * rc;
+    scene[3 * p + 2] = total.z * rc;
+  }
+  if (tally.rays) atomicAdd(&s_cnt[0], (unsigned long long)tally.rays);
+  if (tally.isects) atomicAdd(&s_cnt[1], (unsigned long long)tally.isects);
+  if (lens_started) atomicAdd(&s_cnt[2], (unsigned long long)lens_started);
+  if (lens_left) atomicAdd(&s_cnt[3], (unsigned long long)lens_left);
+  __syncthreads();
+  if (threadIdx.x < kSceneCounters && s_cnt[threadIdx.x]) atomicAdd(&counters[threadIdx.x], s_cnt[threadIdx.x]);
+}
+
 // ---- single-ray forms of the integrator's public members (pathtracer.h:66-77) ----------------
 struct LfProbeRay { double o[3], d[3], min_t, max_t; };
 // est_radiance_global_illumination(r) (:282-302) and the closest hit behind autofocus (:1065-1072):
@@ -1096,10 +1277,20 @@ lf_status lf_render_scene_term(lf_ctx* ctx) {
   LfLensCamArgs lc;
   lf_fill_lenscam_args(ctx, &lc);
   hipEvent_t ev = lf_timing_begin(ctx, LFK_SCENE);
-  if (lens) { if (soft) LF_LAUNCH_SCENE(true, true); else LF_LAUNCH_SCENE(false, true); }
+#define LF_LAUNCH_SCENE_LENS(SOFT)                                                                         \
+  hipLaunchKernelGGL((k_scene_lens<SOFT>), dim3((unsigned)((ctx->W + 31) / 32), (unsigned)(((ctx->y1 + 7) >> 3) - (ctx->y0 >> 3))), \
+                     dim3(256), 0, ctx->stream, ctx->scene_dev, ctx->env_dev, ctx->cam, pa, ctx->y0, ctx->y1, \
+                     ctx->row_phase, ctx->row_period, lc, ctx->primary_dev,                                \
+                     ctx->ap[LF_APERTURE_STARBURST].texels, ctx->scene_counters_dev, ctx->scene)
+  // (LF_SCENE_COMPACT=0: the round-4 kernel, one traversal per lane's own sample -- kept as the A/B of the tests)
+  const char* cenv = std::getenv("LF_SCENE_COMPACT");      // (read per call: the tests switch it between two frames)
+  const bool compact = !(cenv && atoi(cenv) == 0);
+  if (lens && compact) { if (soft) LF_LAUNCH_SCENE_LENS(true); else LF_LAUNCH_SCENE_LENS(false); }
+  else if (lens) { if (soft) LF_LAUNCH_SCENE(true, true); else LF_LAUNCH_SCENE(false, true); }
   else { if (soft) LF_LAUNCH_SCENE(true, false); else LF_LAUNCH_SCENE(false, false); }
   lf_timing_end(ctx, LFK_SCENE, ev);
 #undef LF_LAUNCH_SCENE
+#undef LF_LAUNCH_SCENE_LENS
   LF_HIP(ctx, hipGetLastError());
   return LF_OK;
 }

@@ -280,3 +280,24 @@ def test_other_masks_focus_and_prescriptions_at_1080p(pkg, lf, mask_name, refocu
             assert c1["rays_launched"] < 0.5 * c0["rays_launched"]
         print(f"{mask_name} {lens_name} refocus {refocus_mm} sun {sun}: culled {info['culled']}, started "
               f"{c1['rays_launched'] / c0['rays_launched']:.4f}, lit rays {c0['rays_hit_light']}")
+
+
+def test_weight_on_every_event_is_the_same_frame(pkg, lf, monkeypatch):
+    """k_march_cull<K, true> (LF_CULL_WEIGHTS_FIRST, bench.py's `every_event_weighted` leg): the Fresnel / mask weight
+    evaluated on EVERY executed event of every started ray -- SURVEY 8d's unit event -- instead of on a second march of
+    the lanes that reach the lobe.  Same weights, same order of additions: the same pixels and counters."""
+    lens = pkg.load_lens_file("dgauss11.lens")
+    _setup(pkg, lf, lens, 1920, 64, [0.12, 0.08, -1.0], 0.05, load_texels("pentbiglines.png"))
+    lf.set_march_culling(2)
+    out = []
+    for first in (False, True):
+        if first:
+            monkeypatch.setenv("LF_CULL_WEIGHTS_FIRST", "1")
+        lf.reset_counters()
+        lf.trace_ghosts(64, 77)
+        assert lf.cull_info()["culled"]
+        c = lf.counters()
+        out.append((lf.read_buffer(pkg.GHOST_BUFFER), {k: v for k, v in c.items() if not k.startswith("remarch")}))
+    lf.set_march_culling(1)
+    assert out[0][0].any() and np.array_equal(out[0][0], out[1][0])
+    assert out[0][1] == out[1][1], (out[0][1], out[1][1])

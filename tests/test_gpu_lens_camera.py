@@ -502,3 +502,42 @@ def test_aiming_the_lens_camera_at_the_exit_pupil(pkg, lf, sqrt_table):
     lf.set_lens_camera_aim(0.0)
     lf.render_scene_term()
     assert np.array_equal(lf.read_buffer(pkg.SCENE_BUFFER), base)
+
+
+@pytest.mark.parametrize("what", ["delta_one_lambda", "adaptive_batches", "per_wavelength", "area_light", "odd_rows"])
+def test_compacted_scene_rays_equal_the_per_lane_kernel(pkg, lf, what, monkeypatch):
+    """Round 5: k_scene_lens queues the samples that LEFT the lens and walks the tree with full waves; every pixel
+    must see the additions of k_scene_term<.., true> (one traversal per lane's own sample, LF_SCENE_COMPACT=0) in
+    the same order: frames and counters bit for bit -- with and without the adaptive early-out (lanes leaving at
+    batch ends), one ray per wavelength (several entries per sample), sampled lights (Philox counters of the
+    OWNER's pixel and sample), frame edges and the multi-GPU row deal."""
+    lens = pkg.load_lens_file("dgauss11.lens")
+    mask = load_texels("pentbig500_14.png")
+    W, H, ns = (77, 45, 9) if what == "odd_rows" else (96, 64, 64)
+    pos = [0.2, 0.1, 0.8]
+    c2w = look_at(pos, [0.0, -0.2, -5.5])
+    setup_scene_frame(pkg, lf, lens, mask, W, H, ns, c2w, pos)
+    if what in ("adaptive_batches", "area_light"):
+        lf.set_sampling(8, 0.25, 0.01, 100.0)
+    if what == "area_light":
+        # {type, rgb, v0..v3}: the sun as a DirectionalLight + an AreaLight (position, direction, dim_x, dim_y) above
+        lf.set_scene_lights([[0.0, 2.0, 1.8, 1.5, 0.3 / 1.0, 0.8, 0.52] + [0.0] * 9,
+                             [3.0, 6.0, 6.0, 5.0, 0.0, 2.5, -5.0, 0.0, -1.0, 0.0, 1.0, 0.0, 0.0, 0.0, 0.0, 1.0]])
+        lf.set_light_samples(4)
+    lf.set_lens_camera(2 if what == "per_wavelength" else 1, 0.003, 0.0)
+    if what == "odd_rows":
+        lf.set_row_interleave(1, 2)
+    frames, counters = [], []
+    for compact in ("1", "0"):
+        monkeypatch.setenv("LF_SCENE_COMPACT", compact)
+        lf.set_scene_term(np.zeros((H, W, 3)))
+        lf.reset_scene_counters()
+        lf.render_scene_term()
+        frames.append(lf.read_buffer(pkg.SCENE_BUFFER))
+        counters.append(lf.scene_counters())
+    assert (frames[0].max(axis=-1) > 1e-3).mean() > 0.1
+    assert np.array_equal(frames[0], frames[1]), np.abs(frames[0] - frames[1]).max()
+    assert counters[0] == counters[1], counters
+    if what in ("adaptive_batches", "area_light"):
+        full = H * W * ns * (1 if what != "per_wavelength" else 3)
+        assert counters[0]["lens_samples"] < 0.9 * full        # (some pixels did leave early)
