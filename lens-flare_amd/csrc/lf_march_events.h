@@ -269,6 +269,7 @@ __device__ __forceinline__ bool primary_path(const LfPrimaryDev* __restrict__ P,
                                w.fs[lambda], w.fo[lambda], w.fi[lambda]);
     }
     alive = alive && ((ok >> lane) & 1ull) != 0ull;
+    if (__ballot(alive) == 0ull) break;   // every lane of the wave is blocked (a closed part of the pupil): nothing left to march
   }
   return alive;
 }

@@ -362,13 +362,15 @@ def test_blur_disc_has_the_thin_lens_circle_of_confusion(pkg, lf):
 def test_close_focus_counts_from_the_entrance_pupil(pkg, lf):
     """ADVICE r4: Camera::focalDistance is measured from the camera position, which the lens camera puts at the centre of
     the entrance pupil -- 19.95 mm BEHIND the double Gauss's first vertex, from which lf_focus_lens measures.  An emitter
-    10 focal lengths away: focused with lf_focus_lens_from_pupil (what the drop-in passes focalDistance to) it is a few
-    pixels; focused to the same number counted from the first vertex the sensor sits 0.25 mm off and the disc is larger."""
+    5 focal lengths away: focused with lf_focus_lens_from_pupil (what the drop-in passes focalDistance to) it is a few
+    pixels; focused to the same number counted from the first vertex the sensor sits more than a millimetre off and the
+    disc is several times larger.  (At 10 focal lengths the 0.24 mm between the two sensor positions is what this
+    prescription's spherical aberration moves the best focus by, towards the lens too: both spots measure 4 x 4 pixels.)"""
     lens = pkg.load_lens_file("dgauss11.lens")
     mask = load_texels("pentbig500_14.png")
     W, H, ns, wpm = 200, 200, 1024, 0.001
     lens["sensor_width_mm"] = np.float32(4.0)       # 0.02 mm pixels around the axis
-    d_o, r_e = 0.5, 0.0002
+    d_o, r_e = 0.25, 0.0001
     emitter = [(0.0, 0.0, -d_o, r_e, "e", 5.0, 5.0, 5.0)]
     setup_scene_frame(pkg, lf, lens, mask, W, H, ns, np.eye(3).reshape(-1), [0.0, 0.0, 0.0], spheres=emitter, tris=[], lights=[])
     z_ep, _ = pkg.paraxial_entrance_pupil(lens)
@@ -380,13 +382,13 @@ def test_close_focus_counts_from_the_entrance_pupil(pkg, lf):
     lf.render_scene_term()
     sharp = lf.read_buffer(pkg.SCENE_BUFFER).sum(axis=-1)
     v_vertex = lf.focus_lens(d_o * 1000.0)          # the same number, counted from the first vertex
-    assert v_pupil - v_vertex > 0.15                # the sensor is a quarter of a millimetre off
+    assert v_pupil - v_vertex > 1.0                 # the sensor is more than a millimetre off
     lf.render_scene_term()
     soft = lf.read_buffer(pkg.SCENE_BUFFER).sum(axis=-1)
     a_sharp, a_soft = (sharp > 0.04 * sharp.max()).sum(), (soft > 0.04 * soft.max()).sum()
     print(f"close focus at {d_o} m: entrance pupil {z_ep:.2f} mm behind the first vertex, sensor {v_pupil:.3f} vs {v_vertex:.3f} mm, "
           f"image area {a_sharp} px focused from the pupil, {a_soft} px focused from the vertex")
-    assert sharp.max() > 0 and a_sharp < 0.6 * a_soft
+    assert sharp.max() > 0 and a_sharp < 0.25 * a_soft
     lf.set_lens_camera(0)
 
 
