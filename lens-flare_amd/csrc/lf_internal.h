@@ -335,6 +335,7 @@ struct lf_ctx {
   bool hemisphere_sample = false; // PathTracer::direct_hemisphere_sample (pathtracer.h:114; the -H flag)
   int samples_per_batch = 32;     // PathTracer::samplesPerBatch default (raytraced_renderer.h:67-81)
   double max_tolerance = 0.05;    // PathTracer::maxTolerance
+  int scene_tree_depth = 24;                          // levels of the resident BVH (lf_set_scene): sizes k_scene_lens's stack
   unsigned long long* scene_counters_dev = nullptr;   // kSceneCounters x u64 (lf_get_scene_counters)
 
   // lens camera (lf_lens_camera.hip): the scene term's sample loop marches each sensor sample's primary

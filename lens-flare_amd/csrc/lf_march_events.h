@@ -224,21 +224,28 @@ __device__ __forceinline__ StartRay aim_at_pupil(float X, float Y, float pa, flo
   return s;
 }
 
-__device__ __forceinline__ StartRay sample_start(const SampleSpec& a, int x, int y, int s) {
+// the wave tile of pixel (x, y) as k_march numbers it: tile row y / 8, and along x block x / (8 * 2^xs) with phase
+// x mod 2^xs
+__device__ __forceinline__ unsigned sample_tile_id(const SampleSpec& a, int x, int y) {
+  const int tiles_x = ((a.W + (8 << a.xs) - 1) >> (3 + a.xs)) << a.xs;
+  const int tx = ((x >> (3 + a.xs)) << a.xs) + (x & ((1 << a.xs) - 1));
+  return (unsigned)((y >> 3) * tiles_x + tx);
+}
+// the sub-cell of its stratum that wave tile `tile_id` draws for sample s (< G * G)
+__device__ __forceinline__ void sample_subcell(const SampleSpec& a, unsigned tile_id, int s, unsigned& sxi, unsigned& syi) {
+  const uint4 r2 = philox4x32_10(make_uint4(tile_id, (unsigned)s, kDomainSubcell, 0u), a.key);
+  sxi = a.sub_bits ? (r2.x >> (32 - a.sub_bits)) : 0u;
+  syi = a.sub_bits ? (r2.y >> (32 - a.sub_bits)) : 0u;
+}
+// ... and the sample itself, given its stratum (cx, cy) = (s mod G, s / G) and that sub-cell (all four unused for the
+// unstratified samples s >= G * G)
+__device__ __forceinline__ StartRay sample_start_in(const SampleSpec& a, int x, int y, int s, int cx, int cy, unsigned sxi,
+                                                    unsigned syi) {
   const unsigned p = (unsigned)y * (unsigned)a.W + (unsigned)x;
   const uint4 rnd = philox4x32_10(make_uint4(p, (unsigned)s, kDomainMarch, 0u), a.key);
   const float jx = u01(rnd.x), jy = u01(rnd.y);
   float ua = u01(rnd.z), ub = u01(rnd.w);
   if (s < a.G * a.G) {
-    const int cy = s / a.G, cx = s - cy * a.G;
-    // the wave tile of pixel (x, y) as k_march numbers it: tile row y / 8, and along x block x / (8 * 2^xs)
-    // with phase x mod 2^xs
-    const int tiles_x = ((a.W + (8 << a.xs) - 1) >> (3 + a.xs)) << a.xs;
-    const int tx = ((x >> (3 + a.xs)) << a.xs) + (x & ((1 << a.xs) - 1));
-    const unsigned tile_id = (unsigned)((y >> 3) * tiles_x + tx);
-    const uint4 r2 = philox4x32_10(make_uint4(tile_id, (unsigned)s, kDomainSubcell, 0u), a.key);
-    const unsigned sxi = a.sub_bits ? (r2.x >> (32 - a.sub_bits)) : 0u;
-    const unsigned syi = a.sub_bits ? (r2.y >> (32 - a.sub_bits)) : 0u;
     ua = ((float)cx + ((float)sxi + ua) * a.inv_sub) * a.inv_G;
     ub = ((float)cy + ((float)syi + ub) * a.inv_sub) * a.inv_G;
   }
@@ -246,6 +253,12 @@ __device__ __forceinline__ StartRay sample_start(const SampleSpec& a, int x, int
   const float X = -(((float)x + jx) - a.half_w) * a.pitch;
   const float Y = -(((float)y + jy) - a.half_h) * a.pitch;
   return aim_at_pupil(X, Y, pa, pb, a.pupil_h, a.vz, a.geom_norm);
+}
+__device__ __forceinline__ StartRay sample_start(const SampleSpec& a, int x, int y, int s) {
+  unsigned sxi = 0u, syi = 0u;
+  const int cy = s / a.G, cx = s - cy * a.G;
+  if (s < a.G * a.G) sample_subcell(a, sample_tile_id(a, x, y), s, sxi, syi);
+  return sample_start_in(a, x, y, s, cx, cy, sxi, syi);
 }
 
 // ---- the primary path N-1 .. 0 with its weight (LensCamera::generate_ray) ---------------------------

@@ -595,26 +595,38 @@ __global__ __launch_bounds__(256, LF_SCENE_WAVES) void k_scene_term(LfSceneDev s
 // (tests/test_gpu_lens_camera.py compares the two kernels).  A sample the lens blocks adds +0.0 to every sum
 // of scene_pixel and is simply never queued.
 constexpr int kLensQueue = 128;      // < 64 left over + one round of <= 64
+constexpr int kLensStridedMaxPrims = 1024;
+// (the traversal stack is dynamic LDS sized by the tree at hand -- [levels][256] ints -- so that a shallow tree leaves
+// the CU's LDS to more workgroups: 25.6 KB of queues + 1 KB per level)
+#ifndef LF_SCENE_LENS_WAVES
+#define LF_SCENE_LENS_WAVES 3     // (2 / 3 / 4 / 5 waves per SIMD: 10.0 / 8.2 / 10.3 / 14.2 ms on the c4 bench frame -- spills beyond 3)
+#endif
 template <bool SOFT>
-__global__ __launch_bounds__(256, 3) void k_scene_lens(LfSceneDev sc, LfEnvDev ev, LfCamera cam, ScenePixelArgs a,
-                                                       int y0, int y1, int row_phase, int row_period, LfLensCamArgs lc,
+__global__ __launch_bounds__(256, LF_SCENE_LENS_WAVES) void k_scene_lens(LfSceneDev sc, LfEnvDev ev, LfCamera cam, ScenePixelArgs a,
+                                                       int y0, int y1, int row_phase, int row_period, int mxs, LfLensCamArgs lc,
                                                        const LfPrimaryDev* __restrict__ prim,
                                                        const float* __restrict__ mask,
                                                        unsigned long long* __restrict__ counters,
                                                        double* __restrict__ scene) {
-  __shared__ int s_stack[kStackDepth * 256];
+  extern __shared__ int s_stack[];
   __shared__ unsigned long long s_cnt[kSceneCounters];
   __shared__ float s_qf[4][7][kLensQueue];       // px py hz dx dy dz, transmitted weight
-  __shared__ unsigned s_qt[4][kLensQueue];       // owner lane | wavelength << 6 | round << 10
+  __shared__ unsigned s_qt[4][kLensQueue];       // owner lane | wavelength slot << 6 | sample << 10: tag >> 6 = the ROUND, rising along the queue
   __shared__ double s_res[4][3][64];             // a round's results on their way back, by owner lane
-  __shared__ unsigned s_stamp[4][64];            // round + 1 of the result that lies in s_res
+  __shared__ unsigned s_stamp[4][64];            // round of the result that lies in s_res (0: none)
   if (threadIdx.x < kSceneCounters) s_cnt[threadIdx.x] = 0ull;
   const int wv = (int)threadIdx.x >> 6, lane = threadIdx.x & 63;
   s_stamp[wv][lane] = 0u;
   __syncthreads();
   int* const stack = s_stack + threadIdx.x;
-  const int tile_x = ((int)blockIdx.x * 4 + wv) * 8, tile_y = ((y0 >> 3) + (int)blockIdx.y) * 8;
-  const int x = tile_x + (lane & 7), y = tile_y + (lane >> 3);
+  // which 64 pixels a wave owns (any choice gives the same frame).  mxs = xs: the MARCH's wave tile, 8 columns 2^xs
+  // apart (lf_set_tile_stride) -- its lanes share the sub-cell of the pupil a sample draws (lfm::sample_start), so where
+  // the pupil is closed it is closed for the whole wave and primary_path stops early.  mxs = 0: 8 x 8 adjacent pixels,
+  // whose scene rays walk the same part of a large tree.  Measured at 4K (4 / 50 801 triangles): 7.9 / 18.5 ms against
+  // 8.2 / 16.4 ms -- the host picks by the size of the tree (lf_render_scene_term).
+  const int tile = (int)blockIdx.x * 4 + wv;
+  const int tile_x = ((tile >> mxs) << (3 + mxs)) + (tile & ((1 << mxs) - 1)), tile_y = ((y0 >> 3) + (int)blockIdx.y) * 8;
+  const int x = tile_x + ((lane & 7) << mxs), y = tile_y + (lane >> 3);
   const bool mine = x < a.W && y >= y0 && y < y1 && !(row_period > 1 && (y >> 3) % row_period != row_phase);
   const int ns_aa = a.ns_aa;
   const uint2 key2 = make_uint2((unsigned)a.key, (unsigned)(a.key >> 32));
@@ -650,8 +662,8 @@ __global__ __launch_bounds__(256, 3) void k_scene_lens(LfSceneDev sc, LfEnvDev e
       tag = s_qt[wv][lane];
       const float px = s_qf[wv][0][lane], py = s_qf[wv][1][lane], hz = s_qf[wv][2][lane];
       const float dx = s_qf[wv][3][lane], dy = s_qf[wv][4][lane], dz = s_qf[wv][5][lane], wq = s_qf[wv][6][lane];
-      const int owner = (int)(tag & 63u), l = (int)((tag >> 6) & 15u), sample = (int)(tag >> 10) / n_rays + 1;
-      const size_t p = (size_t)(tile_y + (owner >> 3)) * a.W + (tile_x + (owner & 7));
+      const int owner = (int)(tag & 63u), l = lc.mode == 2 ? (int)((tag >> 6) & 15u) : lc.lambda_ref, sample = (int)(tag >> 10);
+      const size_t p = (size_t)(tile_y + (owner >> 3)) * a.W + (tile_x + ((owner & 7) << mxs));
       const double wt = (double)wq * lc.exposure;
       const double wpm = lc.world_per_mm;
       const V3 oc = v3((double)px * wpm, (double)py * wpm, ((double)(prim->front_zv + hz) - lc.z_ref_mm) * wpm);
@@ -676,16 +688,16 @@ __global__ __launch_bounds__(256, 3) void k_scene_lens(LfSceneDev sc, LfEnvDev e
     lfm::lanemask pend = __ballot(work);
     while (pend) {
       const int src = __ffsll((long long)pend) - 1;
-      const unsigned r0 = (unsigned)__builtin_amdgcn_readlane((int)(tag >> 10), src);
-      const bool snd = work && (tag >> 10) == r0;
+      const unsigned r0 = (unsigned)__builtin_amdgcn_readlane((int)(tag >> 6), src);
+      const bool snd = work && (tag >> 6) == r0;
       if (snd) {
         const int owner = (int)(tag & 63u);
         s_res[wv][0][owner] = C.x; s_res[wv][1][owner] = C.y; s_res[wv][2][owner] = C.z;
-        s_stamp[wv][owner] = r0 + 1u;
+        s_stamp[wv][owner] = r0;
       }
       __builtin_amdgcn_wave_barrier();
-      if (s_stamp[wv][lane] == r0 + 1u) {
-        const int sample = (int)r0 / n_rays + 1;
+      if (s_stamp[wv][lane] == r0) {
+        const int sample = (int)(r0 >> 4);
         if (sample != cur_s) { finish_sample(); cur_s = sample; Lcur = v3(0, 0, 0); }
         Lcur = Lcur + v3(s_res[wv][0][lane], s_res[wv][1][lane], s_res[wv][2][lane]);
         s_stamp[wv][lane] = 0u;                // (a round can straddle two flushes: taken once)
@@ -704,14 +716,25 @@ __global__ __launch_bounds__(256, 3) void k_scene_lens(LfSceneDev sc, LfEnvDev e
     q_count = rem;
   };
 
-  int sample;
+  int sample, s_idx = 0;
+  const int s_step = (int)((long long)lc.order_step % (long long)ns_aa);
+  const unsigned g_magic = spec.G > 1 ? (unsigned)(0x100000000ull / (unsigned long long)spec.G) : 0xffffffffu;
+  int next_check = a.samples_per_batch > 1 ? a.samples_per_batch : 2;      // the first multiple of samples_per_batch above 1
   for (sample = 1; sample <= ns_aa; sample++) {     // wave-uniform
     if (__ballot(active) == 0ull) break;
     lfm::StartRay st{0.0f, 0.0f, 0.0f, 0.0f, -1.0f, 0.0f};
+    // (the march's samples in an order whose prefixes cover the pupil, scene_pixel: ((sample - 1) order_step) mod ns_aa)
     if (active) {
-      const int s_idx = (int)(((long long)(sample - 1) * (long long)lc.order_step) % (long long)ns_aa);
-      st = lfm::sample_start(spec, x, y, s_idx);
+      // s_idx / G without the division: the quotient by floor(2^32 / G) is the true one or one less
+      unsigned cy = __umulhi((unsigned)s_idx, g_magic);
+      if ((unsigned)s_idx - cy * (unsigned)spec.G >= (unsigned)spec.G) cy++;
+      const int cx = s_idx - (int)cy * spec.G;
+      unsigned sxi = 0u, syi = 0u;
+      if (s_idx < spec.G * spec.G) lfm::sample_subcell(spec, lfm::sample_tile_id(spec, x, y), s_idx, sxi, syi);
+      st = lfm::sample_start_in(spec, x, y, s_idx, cx, (int)cy, sxi, syi);
     }
+    s_idx += s_step;
+    if (s_idx >= ns_aa) s_idx -= ns_aa;
     for (int li = 0; li < n_rays; li++) {
       const int l = lc.mode == 2 ? li : lc.lambda_ref;
       bool left = false;
@@ -728,14 +751,15 @@ __global__ __launch_bounds__(256, 3) void k_scene_lens(LfSceneDev sc, LfEnvDev e
           s_qf[wv][0][slot] = r.px; s_qf[wv][1][slot] = r.py; s_qf[wv][2][slot] = r.hz;
           s_qf[wv][3][slot] = r.dx; s_qf[wv][4][slot] = r.dy; s_qf[wv][5][slot] = r.dz;
           s_qf[wv][6][slot] = __fdiv_rn(r.wn, r.wd);
-          s_qt[wv][slot] = (unsigned)lane | ((unsigned)l << 6) | ((unsigned)((sample - 1) * n_rays + li) << 10);
+          s_qt[wv][slot] = (unsigned)lane | ((unsigned)li << 6) | ((unsigned)sample << 10);
         }
         q_count += __popcll(lm);
         __builtin_amdgcn_wave_barrier();
         if (q_count >= 64) flush(64);
       }
     }
-    if (sample > 1 && sample % a.samples_per_batch == 0) {  // pathtracer.cpp:862-868, with every ray of the batch in
+    if (sample == next_check) {  // sample > 1 && sample % samples_per_batch == 0 (pathtracer.cpp:862-868), every ray of the batch in
+      next_check += a.samples_per_batch;
       while (q_count > 0) flush(q_count < 64 ? q_count : 64);
       if (active) {
         finish_sample();
@@ -1022,6 +1046,7 @@ lf_status lf_set_scene(lf_ctx* ctx, int n_spheres, const double* spheres, const 
     }
     if (depth - 1 > kStackDepth)
       return lf_fail(ctx, LF_ERR_INVALID, "scene: BVH deeper than the device traversal stack");
+    ctx->scene_tree_depth = depth;
     root = hnodes[0].box;
     if (hnodes[0].left >= 0) {
       flatten(hnodes, 0, nodes);
@@ -1035,6 +1060,7 @@ lf_status lf_set_scene(lf_ctx* ctx, int n_spheres, const double* spheres, const 
     LfBvhNode e; std::memset(&e, 0, sizeof(e));
     e.child[0] = e.child[1] = kLfNoChild;
     nodes.push_back(e);
+    ctx->scene_tree_depth = 0;
     for (int a = 0; a < 3; a++) { root.mn[a] = 0; root.mx[a] = 0; }
     root.mn[0] = 1; root.mx[0] = -1;   // (what lf_scene_bounds reported for it before)
   }
@@ -1278,10 +1304,16 @@ lf_status lf_render_scene_term(lf_ctx* ctx) {
   lf_fill_lenscam_args(ctx, &lc);
   hipEvent_t ev = lf_timing_begin(ctx, LFK_SCENE);
 #define LF_LAUNCH_SCENE_LENS(SOFT)                                                                         \
-  hipLaunchKernelGGL((k_scene_lens<SOFT>), dim3((unsigned)((ctx->W + 31) / 32), (unsigned)(((ctx->y1 + 7) >> 3) - (ctx->y0 >> 3))), \
-                     dim3(256), 0, ctx->stream, ctx->scene_dev, ctx->env_dev, ctx->cam, pa, ctx->y0, ctx->y1, \
-                     ctx->row_phase, ctx->row_period, lc, ctx->primary_dev,                                \
+  hipLaunchKernelGGL((k_scene_lens<SOFT>), dim3((unsigned)((lens_tiles_x + 3) / 4), (unsigned)(((ctx->y1 + 7) >> 3) - (ctx->y0 >> 3))), \
+                     dim3(256), (size_t)std::min(kStackDepth, std::max(1, ctx->scene_tree_depth + 1)) * 256 * sizeof(int), \
+                     ctx->stream, ctx->scene_dev, ctx->env_dev, ctx->cam, pa, ctx->y0, ctx->y1,           \
+                     ctx->row_phase, ctx->row_period, lens_mxs, lc, ctx->primary_dev,                      \
                      ctx->ap[LF_APERTURE_STARBURST].texels, ctx->scene_counters_dev, ctx->scene)
+  // a small tree is resident in the caches whichever lanes walk it: the wave takes the march's strided tile (see the
+  // kernel); LF_SCENE_LENS_STRIDED = 0 / 1 forces the choice (measurements)
+  int lens_mxs = ctx->scene_dev.n_prims <= kLensStridedMaxPrims ? lc.xs : 0;
+  if (const char* e = std::getenv("LF_SCENE_LENS_STRIDED")) lens_mxs = std::atoi(e) ? lc.xs : 0;
+  const int lens_tiles_x = ((ctx->W + (8 << lens_mxs) - 1) >> (3 + lens_mxs)) << lens_mxs;   // wave tiles along x
   // (LF_SCENE_COMPACT=0: the round-4 kernel, one traversal per lane's own sample -- kept as the A/B of the tests)
   const char* cenv = std::getenv("LF_SCENE_COMPACT");      // (read per call: the tests switch it between two frames)
   const bool compact = !(cenv && atoi(cenv) == 0);

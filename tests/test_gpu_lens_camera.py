@@ -530,16 +530,18 @@ def test_compacted_scene_rays_equal_the_per_lane_kernel(pkg, lf, what, monkeypat
     if what == "odd_rows":
         lf.set_row_interleave(1, 2)
     frames, counters = [], []
-    for compact in ("1", "0"):
+    for compact, strided in (("1", "1"), ("0", "0"), ("1", "0")):      # (the wave's pixels: the march's strided tile / 8 x 8 adjacent)
         monkeypatch.setenv("LF_SCENE_COMPACT", compact)
+        monkeypatch.setenv("LF_SCENE_LENS_STRIDED", strided)
         lf.set_scene_term(np.zeros((H, W, 3)))
         lf.reset_scene_counters()
         lf.render_scene_term()
         frames.append(lf.read_buffer(pkg.SCENE_BUFFER))
         counters.append(lf.scene_counters())
     assert (frames[0].max(axis=-1) > 1e-3).mean() > 0.1
-    assert np.array_equal(frames[0], frames[1]), np.abs(frames[0] - frames[1]).max()
-    assert counters[0] == counters[1], counters
+    for k in (1, 2):
+        assert np.array_equal(frames[0], frames[k]), (k, np.abs(frames[0] - frames[k]).max())
+        assert counters[0] == counters[k], (k, counters)
     if what in ("adaptive_batches", "area_light"):
         full = H * W * ns * (1 if what != "per_wavelength" else 3)
         assert counters[0]["lens_samples"] < 0.9 * full        # (some pixels did leave early)
