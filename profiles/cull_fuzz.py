@@ -1,0 +1,183 @@
+#!/usr/bin/env python3
+"""Randomised search for a frame on which the culled march differs from the full enumeration.
+
+The cull pre-pass (lens-flare_amd/csrc/lf_cull.hip) drops (sensor block, pupil cell, path) boxes on the evidence of 15
+rays per box; its margins were set by comparing with the full enumeration on the frames of profiles/cull_check.py and
+cull_block_size.py.  This script draws frames those scans did not: random suns over the field, lobe widths from 0.17 to
+9 degrees, the shipped masks and synthetic ones (rings, slits, polygons, speckle), refocused / scaled / bent
+prescriptions and the 8-wavelength one, cropped and enlarged sensors (cull blocks from 0.6 to 1.8 mm), pair subsets,
+every sampling specification, sample counts that are no squares, bands and the multi-GPU row deal -- and compares
+lf_trace_ghosts under lf_set_march_culling(2) with lf_set_march_culling(0) bit for bit, with the counter of rays that
+reached the light.  LF_CULL_FORCE=1 keeps the culled kernel where the launch would fall back to the path tree.
+
+    LF_CULL_FORCE=1 python3 profiles/cull_fuzz.py [cases] [seed] > gpurun_out/r05_cull_fuzz.json
+"""
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import __graft_entry__ as g  # noqa: E402
+
+pkg = g.load_package()
+N = int(sys.argv[1]) if len(sys.argv) > 1 else 200
+SEED = int(sys.argv[2]) if len(sys.argv) > 2 else 20261004
+rng = np.random.default_rng(SEED)
+
+
+def synthetic_mask(kind):
+    n = 256
+    yy, xx = np.mgrid[0:n, 0:n]
+    u, v = (xx - (n - 1) / 2) / (n / 2), (yy - (n - 1) / 2) / (n / 2)
+    rr = np.hypot(u, v)
+    if kind == "ring":
+        a = rng.uniform(0.2, 0.6)
+        return ((rr > a) & (rr < a + rng.uniform(0.1, 0.35))).astype(np.float32)
+    if kind == "slit":
+        th = rng.uniform(0, np.pi)
+        d = np.abs(u * np.cos(th) + v * np.sin(th))
+        return ((d < rng.uniform(0.02, 0.15)) & (rr < 0.9)).astype(np.float32)
+    if kind == "polygon":
+        k = int(rng.integers(3, 9))
+        th0, r0 = rng.uniform(0, 2 * np.pi), rng.uniform(0.25, 0.9)
+        m = np.ones((n, n), bool)
+        for i in range(k):
+            t = th0 + 2 * np.pi * i / k
+            m &= (u * np.cos(t) + v * np.sin(t)) < r0 * np.cos(np.pi / k)
+        cx, cy = rng.uniform(-0.2, 0.2, 2)            # off-centre: (shift by rolling)
+        return np.roll(np.roll(m, int(cx * n / 2), 1), int(cy * n / 2), 0).astype(np.float32)
+    if kind == "speckle":                             # a few small holes: the occupancy grid is mostly closed
+        m = np.zeros((n, n), np.float32)
+        for _ in range(int(rng.integers(1, 6))):
+            cx, cy, r = rng.uniform(-0.6, 0.6), rng.uniform(-0.6, 0.6), rng.uniform(0.03, 0.12)
+            m[np.hypot(u - cx, v - cy) < r] = rng.uniform(0.3, 1.0)
+        return m
+    raise ValueError(kind)
+
+
+MASKS = ["pentbig500_14.png", "pentbiglines.png", "octagonbokeh.png", "ring", "slit", "polygon", "speckle"]
+_png = {}
+
+
+def draw_mask():
+    k = MASKS[int(rng.integers(len(MASKS)))]
+    if k.endswith(".png"):
+        if k not in _png:
+            _png[k] = pkg.load_aperture_png(k)
+        return k, _png[k]
+    return k, synthetic_mask(k)
+
+
+def draw_lens():
+    name = ["dgauss11.lens", "dgauss11.lens", "dgauss11_8lambda.lens"][int(rng.integers(3))]
+    lens = dict(pkg.load_lens_file(name))
+    how = ["as_is", "as_is", "scaled", "bent", "stop_moved"][int(rng.integers(5))]
+    if how == "scaled":                               # the same design at another focal length
+        k = rng.uniform(0.7, 1.4)
+        for key in ("radius", "thickness", "semi_aperture"):
+            lens[key] = (np.asarray(lens[key], np.float32) * np.float32(k)).astype(np.float32)
+    elif how == "bent":                               # every curvature off by up to 3 %: another aberration balance
+        r = np.asarray(lens["radius"], np.float32).copy()
+        r *= (1.0 + rng.uniform(-0.03, 0.03, r.shape)).astype(np.float32)
+        lens["radius"] = r
+    elif how == "stop_moved":                         # the diaphragm 1 mm towards the front or the rear group
+        t = np.asarray(lens["thickness"], np.float32).copy()
+        s, d = int(lens["stop"]), np.float32(rng.uniform(-1.0, 1.0))
+        t[s - 1] += d; t[s] -= d
+        lens["thickness"] = t
+    return name, how, lens
+
+
+def main():
+    lf = pkg.LensFlare(0)
+    out, bad = [], 0
+    t0 = time.time()
+    for case in range(N):
+        lname, how, lens = draw_lens()
+        mname, mask = draw_mask()
+        big = rng.random() < 0.08
+        W, H = [(1920, 1080), (1920, 1080), (1920, 1080), (1280, 720), (1900, 1000), (2560, 1440)][int(rng.integers(6))]
+        if big:
+            W, H = 3840, 2160
+        # sensor width: cull blocks (64 px) between 0.6 mm and the 1.8 mm limit
+        blk = rng.uniform(0.6, 1.8)
+        lens["sensor_width_mm"] = np.float32(min(48.0, blk * W / 64.0))
+        spp = int([4, 9, 16, 16, 36, 50, 64, 100, 200, 256][int(rng.integers(10))]) if not big else int([4, 16][int(rng.integers(2))])
+        half = 0.5 * float(lens["sensor_width_mm"]) / 50.0
+        sun = [float(rng.uniform(-1.1, 1.1) * half), float(rng.uniform(-1.1, 1.1) * half * H / W), -1.0]
+        alpha = float(np.exp(rng.uniform(np.log(0.003), np.log(0.16))))
+        stride, bits = int([1, 2, 4, 8, 8][int(rng.integers(5))]), int([0, 1, 2, 4, 6, 6, 8][int(rng.integers(7))])
+        rec = {"case": case, "lens": lname, "how": how, "mask": mname, "W": W, "H": H, "spp": spp, "sun": sun, "alpha": alpha,
+               "block_mm": 64.0 * float(lens["sensor_width_mm"]) / W, "stride": stride, "subcell_bits": bits}
+        try:
+            lf.set_frame(W, H)
+            lf.set_aperture(pkg.APERTURE_STARBURST, mask)
+            lf.set_lens(lens)
+            if lname.endswith("8lambda.lens"):
+                lam, _ = pkg.spectral_weights(lens["lambda_nm"])
+                lf.set_lambda_rgb(lam)
+            if rng.random() < 0.3:
+                rec["focus_mm"] = float(rng.uniform(300.0, 5000.0))
+                lf.focus_lens(rec["focus_mm"])
+            lf.set_sun(sun, [1.0, 0.9, 0.5], alpha)
+            n_if = int(lens["n"])
+            pick = rng.random()
+            if pick < 0.6:
+                lf.set_ghost_pairs(None, True)
+                rec["pairs"] = "all"
+            else:
+                allp = [(j, i) for i in range(n_if) for j in range(i) if i != int(lens["stop"]) and j != int(lens["stop"])]
+                k = int(rng.integers(1, len(allp)))
+                sel = [allp[i] for i in rng.choice(len(allp), k, replace=False)]
+                lf.set_ghost_pairs(sel, bool(rng.random() < 0.7))
+                rec["pairs"] = k
+            lf.set_tile_stride(stride)
+            lf.set_pupil_subcells(bits)
+            if rng.random() < 0.2:
+                y0 = int(rng.integers(0, H // 2)) & ~7
+                lf.set_band(y0, int(min(H, y0 + int(rng.integers(8, H)))))
+            else:
+                lf.set_band(0, H)
+            if rng.random() < 0.2:
+                per = int(rng.integers(2, 9))
+                lf.set_row_interleave(int(rng.integers(per)), per)
+            else:
+                lf.set_row_interleave(0, 1)
+            key = int(rng.integers(1, 2 ** 40))
+            res = {}
+            for mode in (0, 2):
+                lf.set_march_culling(mode)
+                lf.reset_counters()
+                lf.trace_ghosts(spp, key)
+                res[mode] = (lf.read_buffer(pkg.GHOST_BUFFER), lf.counters(), lf.cull_info()["culled"])
+            d = res[0][0] != res[2][0]
+            rec.update(culled=res[2][2], values_differing=int(d.sum()), lit_values=int((res[0][0] > 0).sum()),
+                       lit_rays_full=res[0][1]["rays_hit_light"], lit_rays_culled=res[2][1]["rays_hit_light"],
+                       started=res[2][1]["rays_launched"] / max(1, res[0][1]["rays_launched"]))
+            if rec["values_differing"] or rec["lit_rays_full"] != rec["lit_rays_culled"]:
+                bad += 1
+                rec["BAD"] = True
+                rec["key"] = key
+        except pkg.LensFlareError as e:                # (a drawn prescription the library refuses: not a finding)
+            rec["refused"] = str(e)[:200]
+        out.append(rec)
+        print(json.dumps(rec), file=sys.stderr, flush=True)
+    lf.close()
+    done = [r for r in out if "culled" in r]
+    summary = {"seed": SEED, "cases": N, "compared": len(done), "refused": N - len(done),
+               "culled_kernel_ran": sum(1 for r in done if r["culled"]), "frames_differing": bad,
+               "lit_rays_compared": int(sum(r["lit_rays_full"] for r in done)),
+               "frames_with_light": sum(1 for r in done if r["lit_rays_full"] > 0),
+               "started_min_median_max": [float(np.min([r["started"] for r in done])), float(np.median([r["started"] for r in done])),
+                                          float(np.max([r["started"] for r in done]))] if done else None,
+               "seconds": time.time() - t0}
+    print(json.dumps({"summary": summary, "cases": out}, indent=1))
+    print("SUMMARY", json.dumps(summary), file=sys.stderr)
+
+
+if __name__ == "__main__":
+    main()
