@@ -838,7 +838,13 @@ def main():
                 "variance_ratio_vs_r04_default_at_equal_spp": 1.0,
                 "ms_per_frame_equal_variance": dt / args.steps * 1e3,
                 "r04_ms_per_frame": R04_C3_MS, "ratio_to_r04": dt / args.steps * 1e3 / R04_C3_MS,
-                "basis": "identical pixels: the cull removes only paths that contribute exactly 0 (same samples, same arithmetic)"},
+                "basis": "identical pixels: the cull removes only paths that contribute exactly 0 (same samples, same arithmetic)",
+                # the events the SAME frame costs when every sample marches every path (this run's path-tree leg), per
+                # second of the shipped frame: the rate at which the full enumeration's work is disposed of -- for
+                # comparison with round 4's `value` only, it is NOT `value` (which counts executed events)
+                "full_enumeration_events_per_frame": (sampling_variants or {}).get("full_enumeration_path_tree", {}).get("executed_events_per_frame"),
+                "full_enumeration_events_disposed_per_s": ((sampling_variants or {}).get("full_enumeration_path_tree", {}).get("executed_events_per_frame") or 0.0)
+                                                          / (dt / args.steps) or None},
             # `value` is measured with the default sampling specification (4x4 pupil sub-cells per tile and
             # sample: pixels, counters and goldens of rounds 1-2 hold).  More coherence is faster at the
             # same per-pixel variance but correlates the noise inside an 8x8 tile further, none is slower

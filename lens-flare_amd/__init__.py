@@ -638,7 +638,7 @@ class LensFlare:
         return t
 
     def cull_table_and_block(self):
-        """(table, block side in pixels) for a checker (lfo.geo_trace / g64_trace cull=...); None if not culled."""
+        """(table, block side in pixels) for a checker that follows the device's table; None if not culled."""
         t = self.cull_table()
         return None if t is None else (t, self.cull_info()["block_px"])
 

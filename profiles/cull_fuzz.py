@@ -24,9 +24,7 @@ sys.path.insert(0, ROOT)
 import __graft_entry__ as g  # noqa: E402
 
 pkg = g.load_package()
-N = int(sys.argv[1]) if len(sys.argv) > 1 else 200
-SEED = int(sys.argv[2]) if len(sys.argv) > 2 else 20261004
-rng = np.random.default_rng(SEED)
+rng = None        # (set by run)
 
 
 def synthetic_mask(kind):
@@ -92,7 +90,10 @@ def draw_lens():
     return name, how, lens
 
 
-def main():
+def run(N, SEED, log=sys.stderr):
+    """-> {"summary": ..., "cases": [...]}"""
+    global rng
+    rng = np.random.default_rng(SEED)
     lf = pkg.LensFlare(0)
     out, bad = [], 0
     t0 = time.time()
@@ -165,7 +166,8 @@ def main():
         except pkg.LensFlareError as e:                # (a drawn prescription the library refuses: not a finding)
             rec["refused"] = str(e)[:200]
         out.append(rec)
-        print(json.dumps(rec), file=sys.stderr, flush=True)
+        if log:
+            print(json.dumps(rec), file=log, flush=True)
     lf.close()
     done = [r for r in out if "culled" in r]
     summary = {"seed": SEED, "cases": N, "compared": len(done), "refused": N - len(done),
@@ -175,9 +177,10 @@ def main():
                "started_min_median_max": [float(np.min([r["started"] for r in done])), float(np.median([r["started"] for r in done])),
                                           float(np.max([r["started"] for r in done]))] if done else None,
                "seconds": time.time() - t0}
-    print(json.dumps({"summary": summary, "cases": out}, indent=1))
-    print("SUMMARY", json.dumps(summary), file=sys.stderr)
+    return {"summary": summary, "cases": out}
 
 
 if __name__ == "__main__":
-    main()
+    r = run(int(sys.argv[1]) if len(sys.argv) > 1 else 200, int(sys.argv[2]) if len(sys.argv) > 2 else 20261004)
+    print(json.dumps(r, indent=1))
+    print("SUMMARY", json.dumps(r["summary"]), file=sys.stderr)

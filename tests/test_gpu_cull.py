@@ -301,3 +301,18 @@ def test_weight_on_every_event_is_the_same_frame(pkg, lf, monkeypatch):
     lf.set_march_culling(1)
     assert out[0][0].any() and np.array_equal(out[0][0], out[1][0])
     assert out[0][1] == out[1][1], (out[0][1], out[1][1])
+
+
+def test_random_frames_culled_equals_full(pkg, forced):
+    """profiles/cull_fuzz.py (2000 frames recorded in profiles/r05_cull_fuzz.json), a fresh draw of 80 here: random
+    masks, prescriptions, sensors, suns, pair subsets, sampling specifications and bands -- the culled kernel (forced)
+    against the full enumeration, pixels and the count of rays that reached the light."""
+    import os
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "profiles"))
+    import cull_fuzz
+    r = cull_fuzz.run(80, 7, log=None)
+    s = r["summary"]
+    print(s)
+    assert s["compared"] == 80 and s["culled_kernel_ran"] == 80 and s["frames_with_light"] > 60
+    assert s["frames_differing"] == 0, [c for c in r["cases"] if c.get("BAD")]
