@@ -326,14 +326,14 @@ def test_c5_band_of_the_4k_frame_against_the_independent_tracer(pkg, lf):
 
 
 @pytest.mark.skipif(__import__("os").environ.get("LF_LONG_CHECKS") != "1",
-                    reason="minutes of host time on a many-core box: LF_LONG_CHECKS=1 (record: profiles/r03_f64_whole_frame.log)")
+                    reason="minutes of host time on a many-core box: LF_LONG_CHECKS=1 (record: profiles/r05_f64_c5_band.log)")
 def test_c5_band_at_full_spp_against_the_independent_tracer(pkg, lf):
     """The same band of the C5 frame at its FULL 1024 spp (2.3e10 rays: a third of the whole c3 frame)."""
     _c5_band(pkg, lf, 1024, rows_per_call=4)
 
 
 @pytest.mark.skipif(__import__("os").environ.get("LF_LONG_CHECKS") != "1",
-                    reason="minutes of host time on a many-core box: LF_LONG_CHECKS=1 (record: profiles/r03_f64_whole_frame.log)")
+                    reason="27 minutes of the box's 16 host CPUs: LF_LONG_CHECKS=1, in two calls (LF_LONG_Y0 / LF_LONG_Y1); record: profiles/r05_f64_whole_frame.log")
 def test_c3_whole_frame_against_the_independent_tracer(pkg, lf):
     """The WHOLE benchmark frame -- 1920x1080, 256 spp, primary + 45 pairs x 3 wavelengths, 7.3e10 rays --
     band by band against the float64 tracer, each band to the same bar as the 8-row test above.  Not
