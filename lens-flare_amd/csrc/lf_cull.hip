@@ -63,6 +63,7 @@ struct CullLevelArgs {
   float stop_h, inv_stop_h;
   float sx, sy, rho;       // the sun's direction (x, y) and the lobe's radius in direction space
   float margin;            // footprint inflation at this level
+  float geo_margin;        // ... of the zonotope's generators alone (experiments: LF_CULL_GEO_MARGIN)
   int keep_partial;        // a box that lost samples (total reflection, a missed sphere) is never dropped by the lobe test
   float lost_rel, lost_abs;  // "every sample ends here" drops a box only beyond this margin (see firmly_lost)
   int disable;             // experiments: bit 0 no aperture test, 1 no mask test, 2 no lobe test, 3 no all-samples-lost test
@@ -235,7 +236,7 @@ __global__ __launch_bounds__(256) void k_cull_level(const LfLensDev* __restrict_
     if (!f.zono) return f.ball;
     const float e = fabsf(fmaf(f.g1x, nx, f.g1y * ny)) + fabsf(fmaf(f.g2x, nx, f.g2y * ny)) +
                     fabsf(fmaf(f.gxx, nx, f.gxy * ny)) + fabsf(fmaf(f.gyx, nx, f.gyy * ny));
-    return fminf(f.ball, fmaf(a.margin, e, f.slack));
+    return fminf(f.ball, fmaf(a.geo_margin, e, f.slack));
   };
   for (int e = 0; e < n_ev; e++) {
     if (__ballot(!culled && !keep) == 0ull) break;      // every box of the wave is decided
@@ -976,6 +977,8 @@ lf_status lfk_cull_prepass(lf_ctx* ctx, int G, int spp) {
     a.last = lv + 1 == n_levels ? 1 : 0;
     // coarse boxes are more curved than 13 rays show: more inflation the larger the pupil cell
     a.margin = margin * (a.P >= 64 ? 1.0f : a.P >= 32 ? 1.15f : a.P >= 16 ? 1.4f : 2.0f);
+    a.geo_margin = a.margin;
+    if (const char* e = std::getenv("LF_CULL_GEO_MARGIN")) a.geo_margin = (float)std::atof(e) * (a.P >= 64 ? 1.0f : a.P >= 32 ? 1.15f : a.P >= 16 ? 1.4f : 2.0f);
     const size_t n_items = lv == 0 ? nblk * (size_t)a.P * a.P : (size_t)max_items;
     if (n_items == 0) break;
     const unsigned* items = lv == 0 ? nullptr : ctx->cull_list[(lv - 1) & 1];
