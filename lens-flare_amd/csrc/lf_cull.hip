@@ -64,6 +64,7 @@ struct CullLevelArgs {
   float sx, sy, rho;       // the sun's direction (x, y) and the lobe's radius in direction space
   float margin;            // footprint inflation at this level
   float geo_margin;        // ... of the zonotope's generators alone (experiments: LF_CULL_GEO_MARGIN)
+  int slack_mode;          // experiments: LF_CULL_SLACK (1: second order summed over the four axes + twice the corners' cross terms)
   int keep_partial;        // a box that lost samples (total reflection, a missed sphere) is never dropped by the lobe test
   float lost_rel, lost_abs;  // "every sample ends here" drops a box only beyond this margin (see firmly_lost)
   int disable;             // experiments: bit 0 no aperture test, 1 no mask test, 2 no lobe test, 3 no all-samples-lost test
@@ -229,6 +230,27 @@ __global__ __launch_bounds__(256) void k_cull_level(const LfLensDev* __restrict_
     const float rx = (use & 0x600u) ? lf_sqrt(rx2) : ru, ry = (use & 0x1800u) ? lf_sqrt(ry2) : ru;
     f.ball = fmaf(partial ? 2.0f * a.margin : a.margin, ((ru + rx) + ry) + rl, eps);
     f.slack = fmaf(2.0f, lf_sqrt(dev2), fmaf(a.margin, rl, eps));
+    if (a.slack_mode == 1) {
+      // second order per axis (mid-points of opposite samples against the centre), SUMMED: at the extreme vertex of the
+      // box all four add; and what the corners deviate by beyond that sum (cross terms), twice
+      const float dax = 0.5f * (vx[5] + vx[3]) - vx[4], day = 0.5f * (vy[5] + vy[3]) - vy[4];
+      const float dbx = 0.5f * (vx[7] + vx[1]) - vx[4], dby = 0.5f * (vy[7] + vy[1]) - vy[4];
+      const float dxx = 0.5f * (vx[9] + vx[10]) - vx[4], dxy = 0.5f * (vy[9] + vy[10]) - vy[4];
+      const float dyx = 0.5f * (vx[11] + vx[12]) - vx[4], dyy = 0.5f * (vy[11] + vy[12]) - vy[4];
+      const float sx = (dax + dbx) + (dxx + dyx), sy = (day + dby) + (dxy + dyy);
+      float c2 = 0.0f;
+#pragma unroll
+      for (int t = 0; t < 9; t += 2) {
+        if (t == 4) continue;
+        const float at = (float)(t % 3 - 1), bt = (float)(t / 3 - 1);
+        const float mx = (vx[t] - vx[4]) - fmaf(at, f.g1x + f.gxx, bt * (f.g2x + f.gyx)) - sx;
+        const float my = (vy[t] - vy[4]) - fmaf(at, f.g1y + f.gxy, bt * (f.g2y + f.gyy)) - sy;
+        c2 = fmaxf(c2, fmaf(mx, mx, my * my));
+      }
+      const float sum2 = lf_sqrt(fmaf(dax, dax, day * day)) + lf_sqrt(fmaf(dbx, dbx, dby * dby)) +
+                         lf_sqrt(fmaf(dxx, dxx, dxy * dxy)) + lf_sqrt(fmaf(dyx, dyx, dyy * dyy));
+      f.slack = sum2 + fmaf(2.0f, lf_sqrt(c2), fmaf(a.margin, rl, eps));
+    }
     return f;
   };
   // extent of the footprint along the unit vector (nx, ny), and along the axes (for the mask's grid)
@@ -928,6 +950,7 @@ lf_status lfk_cull_prepass(lf_ctx* ctx, int G, int spp) {
   a.keep_partial = std::getenv("LF_CULL_KEEP_PARTIAL") ? std::atoi(std::getenv("LF_CULL_KEEP_PARTIAL")) : 0;
   a.lost_rel = std::getenv("LF_CULL_LOST_REL") ? (float)std::atof(std::getenv("LF_CULL_LOST_REL")) : 0.5f;
   a.lost_abs = std::getenv("LF_CULL_LOST_ABS") ? (float)std::atof(std::getenv("LF_CULL_LOST_ABS")) : 0.002f;
+  a.slack_mode = std::getenv("LF_CULL_SLACK") ? std::atoi(std::getenv("LF_CULL_SLACK")) : 0;
   a.disable = std::getenv("LF_CULL_DISABLE") ? std::atoi(std::getenv("LF_CULL_DISABLE")) : 0;
   // the levels: P_final, halved while it stays even and >= 8 (a coarser box is too curved for 13 rays to bound)
   int levels[8], n_levels = 0;
@@ -976,9 +999,20 @@ lf_status lfk_cull_prepass(lf_ctx* ctx, int G, int spp) {
     a.P = levels[lv];
     a.last = lv + 1 == n_levels ? 1 : 0;
     // coarse boxes are more curved than 13 rays show: more inflation the larger the pupil cell
+    // The ball of a box that lost samples and the dispersion slack grow with the level; the zonotope's generators are
+    // inflated by the same factor at every level: lowered one level at a time, each loses its first lit ray between
+    // x 0.9 and x 1.0 (a zonotope is EXACT for the linear part of the map, the measured slack covers the rest), so
+    // x 1.25 keeps the same factor 1.3 everywhere -- the x 2 / 1.4 / 1.15 the coarse levels carried until then cost
+    // 1.6 ms of pre-pass and bought nothing on any frame of the scans (profiles/r05_march_variants.txt)
     a.margin = margin * (a.P >= 64 ? 1.0f : a.P >= 32 ? 1.15f : a.P >= 16 ? 1.4f : 2.0f);
-    a.geo_margin = a.margin;
+    a.geo_margin = margin;
     if (const char* e = std::getenv("LF_CULL_GEO_MARGIN")) a.geo_margin = (float)std::atof(e) * (a.P >= 64 ? 1.0f : a.P >= 32 ? 1.15f : a.P >= 16 ? 1.4f : 2.0f);
+    if (const char* e = std::getenv("LF_CULL_LEVEL_MARGINS")) {   // "m8,m16,m32": absolute generator margins of the coarse levels
+      float m8 = 0, m16 = 0, m32 = 0;
+      if (std::sscanf(e, "%f,%f,%f", &m8, &m16, &m32) == 3 && !a.last) a.geo_margin = a.P >= 32 ? m32 : a.P >= 16 ? m16 : m8;
+    }
+    if (const char* e = std::getenv("LF_CULL_GEO_MARGIN_LAST")) { if (a.last) a.geo_margin = (float)std::atof(e); }
+    if (const char* e = std::getenv("LF_CULL_GEO_MARGIN_COARSE")) { if (!a.last) a.geo_margin = (float)std::atof(e) * (a.P >= 64 ? 1.0f : a.P >= 32 ? 1.15f : a.P >= 16 ? 1.4f : 2.0f); }
     const size_t n_items = lv == 0 ? nblk * (size_t)a.P * a.P : (size_t)max_items;
     if (n_items == 0) break;
     const unsigned* items = lv == 0 ? nullptr : ctx->cull_list[(lv - 1) & 1];
