@@ -809,6 +809,8 @@ def main():
             # RECORDED measurement (c3 frame, a timing-only build) -- it is not measured by this run.
             "event_accounting": {
                 "every_event_weighted": every_event_weighted(),
+                # ... and since round 5 the run times it itself, on the shipped library (sampling_variants.every_event_weighted):
+                "every_event_weighted_this_run": (sampling_variants or {}).get("every_event_weighted"),
                 "fresnel_evaluated_fraction": remarch_lane / executed if executed else None,
                 "remarch_events": remarch_lane / args.steps,
                 "remarch_rows_x64": 64.0 * remarch_rows / args.steps,
