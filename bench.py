@@ -138,6 +138,13 @@ class DevView:
                                          "data": (ptr, False), "version": 2}
 
 
+class DevViewI64(DevView):
+    """... the cull table's u64 masks, as the int64 torch can move"""
+
+    def __init__(self, ptr, n):
+        self.__cuda_array_interface__ = {"shape": (n,), "typestr": "<i8", "data": (ptr, False), "version": 2}
+
+
 def source_sha():
     """Identity of the shipped march kernel: the PMC-derived figures are only quoted as this
     binary's when the profile in profiles/ was taken from the same sources and compile flags."""
@@ -549,6 +556,17 @@ def main():
                 gather_note = "C-ABI RCCL exchange unavailable (" + "; ".join(bad) + "): torch.distributed nccl exchange"
                 nccl_group = dist.new_group(backend="nccl")
             lf.set_row_interleave(rank, world)
+    # The cull pre-pass is shared between the ranks (each builds 1 / world of the table, one all-gather completes it):
+    # through the C ABI's communicator where that stands, through the exchange the frame itself falls back to otherwise.
+    # LF_BENCH_CULL_SHARE=0: every rank builds the whole table (A/B).
+    cull_share = None
+    if world > 1 and cull_mode != 0 and os.environ.get("LF_BENCH_CULL_SHARE", "1") != "0":
+        if gather_mode == "cabi":
+            lf.comm_share_cull(True)
+            cull_share = "rccl (C ABI)"
+        elif gather_mode in ("torch", "host"):
+            lf.set_cull_share(rank, world)
+            cull_share = "torch.distributed nccl" if gather_mode == "torch" else "host (rehearsal)"
     if gather_mode in ("torch", "host"):
         ptr, nbytes = lf.device_buffer(pkg.SAMPLE_BUFFER)
         frame_t = torch.as_tensor(DevView(ptr, nbytes // 8), device=f"cuda:{local}")
@@ -565,6 +583,22 @@ def main():
         lf.set_sun_from_flares(0, efl, 0.05)   # the sun hand-over: the in-frame light feeds the march
         if cfg["scene"]:
             lf.render_scene_term()
+        if cull_share and gather_mode in ("torch", "host"):
+            # the host owns the table's exchange: this rank's slab, one in-place all-gather, take-over
+            lf.cull_prepare(spp)
+            tptr, tn, _ = lf.cull_table_view()
+            if tn:
+                t_x = time.perf_counter()
+                tab = torch.as_tensor(DevViewI64(tptr, tn), device=f"cuda:{local}")
+                if gather_mode == "torch":
+                    sharding.complete_cull_table(tab, rank, world, GroupDist)
+                else:
+                    htab = tab.cpu()
+                    sharding.complete_cull_table(htab, rank, world, dist)
+                    tab.copy_(htab)
+                torch.cuda.synchronize()
+                host_exchange[0] += time.perf_counter() - t_x
+            lf.cull_commit()
         lf.trace_ghosts(spp, 0x1e45f1a4e)
         lf.render_flare_layer()
         # the exchange step: every rank ends up with the whole frame -- ONE all-gather per frame
@@ -826,7 +860,7 @@ def main():
             # inside the sun's lobe per second of the WHOLE frame.  equal_variance: the culled frame's pixels are the
             # round-4 default's bit for bit (same estimator, same samples), so its variance ratio is exactly 1 and
             # the frame time at equal variance is the frame time.
-            "culling": {"mode": cull_mode, "culled": cull_info["culled"],
+            "culling": {"mode": cull_mode, "culled": cull_info["culled"], "prepass_shared_between_ranks": cull_share,
                         "prepass_ms_per_frame": cull_ms / args.steps, "prepass_builds": n_cull,
                         "started_fraction": cull_frac,
                         "table": {k: cull_info[k] for k in ("blocks_x", "blocks_y", "cells", "G", "P", "block_px")},

@@ -498,6 +498,28 @@ lf_status lf_get_cull_table(lf_ctx* ctx, uint64_t* out, size_t n_entries);
  * lf_trace_ghosts marches everything after all (the path tree shares legs and lets rays die early; the culled
  * march starts each path alone): a very wide sun or a handful of samples per pixel. */
 lf_status lf_get_cull_started_fraction(lf_ctx* ctx, double* fraction);
+/* THE PRE-PASS OF A MULTI-GPU FRAME, SHARED.  The table covers the whole frame (a block of 64 sensor rows holds tile
+ * rows of every rank), so N ranks that each build all of it spend the same time on it as one GPU does: the part of a
+ * frame that does not shrink with N.  Shared, rank r builds the rows of the blocks b with b % N == r (dealt round
+ * robin: what a block costs depends on the ghosts that cross it), the rows of one rank lie together (its slab; equal
+ * slabs, the last ones padded) and ONE all-gather per table completes it on every rank -- the second and last
+ * collective of a frame.  Every rank must make the same launches with the same inputs (lens, pairs, sun, frame,
+ * mask, sample count): the exchange is collective.  ghost_buffer, counters and lf_get_cull_table (handed out in block
+ * order whatever the layout) are those of a table built alone, bit for bit.
+ *   lf_comm_share_cull(ctx, 1)     after lf_comm_init_rank: lf_trace_ghosts completes the table itself, by an
+ *                                  ncclAllGather on the communicator's stream (in place, between pre-pass and march).
+ *   lf_set_cull_share(rank, N)     the HOST owns the exchange (no usable RCCL communicator: torch.distributed, MPI,
+ *                                  a rehearsal on one device): per launch lf_cull_prepare(spp) builds this rank's slab,
+ *                                  lf_cull_table_view hands out the device table {pointer, entries, entries per rank}
+ *                                  (all zero if this launch does not cull) for an in-place all-gather of slabs in rank
+ *                                  order, lf_cull_commit takes the completed table over, and the lf_trace_ghosts that
+ *                                  follows (same spp, same inputs) marches with it; a launch without them is refused.
+ *                                  (1 rank: off.) */
+lf_status lf_comm_share_cull(lf_ctx* ctx, int on);
+lf_status lf_set_cull_share(lf_ctx* ctx, int rank, int nranks);
+lf_status lf_cull_prepare(lf_ctx* ctx, int spp);
+lf_status lf_cull_table_view(lf_ctx* ctx, void** device_ptr, uint64_t* entries, uint64_t* entries_per_rank);
+lf_status lf_cull_commit(lf_ctx* ctx);
 /* the fixed-point exponent the last lf_trace_ghosts used (36 unless the range contract above lowered it) */
 lf_status lf_get_march_fix_bits(lf_ctx* ctx, int* bits);
 /* replaces: LensCamera::generate_ray of the north star / Camera::generate_ray_for_thin_lens

@@ -35,7 +35,7 @@ ABI_SYMBOLS = [
     "lf_set_direct_hemisphere_sample", "lf_collada_check", "lf_render_scene_term",
     "lf_generate_ghost_buffer", "lf_render_flare_layer", "lf_read_tile", "lf_read_pixel",
     "lf_write_to_framebuffer", "lf_save_image_rgba", "lf_device_buffer", "lf_set_lens", "lf_set_lambda_rgb", "lf_set_sun",
-    "lf_set_sun_from_flares", "lf_paraxial_efl", "lf_paraxial_image_scale", "lf_set_ghost_pairs", "lf_set_pupil_subcells", "lf_set_tile_stride", "lf_trace_ghosts", "lf_set_march_culling", "lf_get_cull_info", "lf_get_cull_table", "lf_get_cull_started_fraction", "lf_get_march_fix_bits", "lf_generate_lens_rays", "lf_get_counters", "lf_reset_counters", "lf_get_executed_events", "lf_get_march_stats", "lf_native_sqrt", "lf_native_rcp", "lf_set_starburst_spectrum", "lf_load_collada", "lf_march_tables",
+    "lf_set_sun_from_flares", "lf_paraxial_efl", "lf_paraxial_image_scale", "lf_set_ghost_pairs", "lf_set_pupil_subcells", "lf_set_tile_stride", "lf_trace_ghosts", "lf_set_march_culling", "lf_get_cull_info", "lf_get_cull_table", "lf_get_cull_started_fraction", "lf_comm_share_cull", "lf_set_cull_share", "lf_cull_prepare", "lf_cull_table_view", "lf_cull_commit", "lf_get_march_fix_bits", "lf_generate_lens_rays", "lf_get_counters", "lf_reset_counters", "lf_get_executed_events", "lf_get_march_stats", "lf_native_sqrt", "lf_native_rcp", "lf_set_starburst_spectrum", "lf_load_collada", "lf_march_tables",
     "lf_timing_enable", "lf_timing_reset", "lf_timing_get",
     "lf_clear_ghost_buffer", "lf_draw_ghost", "lf_rasterize_textured_triangle", "lf_fill_textured_pixel",
     "lf_shift_vertex", "lf_compute_phase", "lf_irradiance_falloff", "lf_scene_trace_ray", "lf_scene_shade",
@@ -627,6 +627,25 @@ class LensFlare:
         f = C.c_double(0.0)
         self._ck(self.lib.lf_get_cull_started_fraction(self.ctx, C.byref(f)))
         return f.value
+
+    # ---- the pre-pass of a multi-GPU frame, shared (include/lensflare.h)
+    def comm_share_cull(self, on=True):
+        self._ck(self.lib.lf_comm_share_cull(self.ctx, int(bool(on))))
+
+    def set_cull_share(self, rank, nranks):
+        self._ck(self.lib.lf_set_cull_share(self.ctx, int(rank), int(nranks)))
+
+    def cull_prepare(self, spp):
+        self._ck(self.lib.lf_cull_prepare(self.ctx, int(spp)))
+
+    def cull_table_view(self):
+        """(device pointer, entries, entries per rank) of the table the host completes; (0, 0, 0): this launch does not cull"""
+        p, n, k = C.c_void_p(), C.c_uint64(), C.c_uint64()
+        self._ck(self.lib.lf_cull_table_view(self.ctx, C.byref(p), C.byref(n), C.byref(k)))
+        return p.value or 0, n.value, k.value
+
+    def cull_commit(self):
+        self._ck(self.lib.lf_cull_commit(self.ctx))
 
     def cull_table(self):
         """The path masks of the last trace_ghosts, (blocks_y, blocks_x, cells + 1) uint64; None if it did not cull."""

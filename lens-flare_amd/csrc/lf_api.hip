@@ -914,6 +914,53 @@ lf_status lf_set_march_culling(lf_ctx* ctx, int mode) {
   return LF_OK;
 }
 
+// ---- the pre-pass of a multi-GPU frame, shared ----------------------------------------------
+lf_status lf_set_cull_share(lf_ctx* ctx, int rank, int nranks) {
+  if (!ctx) return LF_ERR_INVALID;
+  if (nranks < 1 || nranks > 64 || rank < 0 || rank >= nranks) return lf_fail(ctx, LF_ERR_INVALID, "lf_set_cull_share: 0 <= rank < nranks <= 64");
+  if (ctx->cull_share_how == 1) return lf_fail(ctx, LF_ERR_STATE, "lf_set_cull_share: the table is shared through the communicator (lf_comm_share_cull)");
+  ctx->cull_share_how = nranks > 1 ? 2 : 0;
+  ctx->cull_share_rank = nranks > 1 ? rank : 0;
+  ctx->cull_share_n = nranks;
+  ctx->cull_hash = 0; ctx->cull_hash_pending = 0; ctx->cull_fresh = false;
+  return LF_OK;
+}
+
+lf_status lf_cull_prepare(lf_ctx* ctx, int spp) {
+  if (!ctx) return LF_ERR_INVALID;
+  if (ctx->cull_share_how != 2) return lf_fail(ctx, LF_ERR_STATE, "lf_cull_prepare without lf_set_cull_share(rank, nranks > 1)");
+  if (!ctx->lens_valid || !ctx->ap[LF_APERTURE_STARBURST].valid || ctx->W == 0)
+    return lf_fail(ctx, LF_ERR_STATE, "lf_cull_prepare: frame, prescription and aperture mask come first");
+  if (spp < 1) return LF_ERR_INVALID;
+  LF_HIP(ctx, hipSetDevice(ctx->device));
+  return lfk_cull_prepare(ctx, spp);
+}
+
+lf_status lf_cull_table_view(lf_ctx* ctx, void** device_ptr, uint64_t* entries, uint64_t* entries_per_rank) {
+  if (!ctx || !device_ptr || !entries || !entries_per_rank) return LF_ERR_INVALID;
+  *device_ptr = nullptr; *entries = 0; *entries_per_rank = 0;
+  if (ctx->cull_hash_pending == 0) return LF_OK;           // (this launch does not cull: nothing to exchange)
+  LF_HIP(ctx, hipSetDevice(ctx->device));
+  LF_HIP(ctx, hipStreamSynchronize(ctx->stream));          // the slab is written when the host's exchange reads it
+  *entries_per_rank = (uint64_t)ctx->cull_share_nb * (uint64_t)(ctx->cull_cells + 1);
+  *entries = *entries_per_rank * (uint64_t)ctx->cull_share_n_resident;
+  *device_ptr = ctx->cull_dev;
+  return LF_OK;
+}
+
+lf_status lf_cull_commit(lf_ctx* ctx) {
+  if (!ctx) return LF_ERR_INVALID;
+  if (ctx->cull_share_how != 2) return lf_fail(ctx, LF_ERR_STATE, "lf_cull_commit without lf_set_cull_share(rank, nranks > 1)");
+  if (ctx->cull_hash_pending == 0) return LF_OK;
+  LF_HIP(ctx, hipSetDevice(ctx->device));
+  const lf_status st = lfk_cull_finish(ctx);
+  if (st != LF_OK) return st;
+  ctx->cull_hash = ctx->cull_hash_pending;
+  ctx->cull_hash_pending = 0;
+  ctx->cull_fresh = true;
+  return LF_OK;
+}
+
 lf_status lf_get_cull_info(lf_ctx* ctx, int info[8]) {
   if (!ctx || !info) return LF_ERR_INVALID;
   info[0] = ctx->march_cull;
@@ -937,6 +984,15 @@ lf_status lf_get_cull_table(lf_ctx* ctx, uint64_t* out, size_t n_entries) {
   if (n_entries != n) return lf_fail(ctx, LF_ERR_INVALID, "lf_get_cull_table: size must be blocks_x * blocks_y * (cells + 1)");
   LF_HIP(ctx, hipSetDevice(ctx->device));
   LF_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  if (ctx->cull_share_nb > 0 && ctx->cull_share_n_resident > 1) {
+    // a shared table lies slab by slab (lf_cull_row_of_block): handed out in block order all the same
+    const size_t re = (size_t)(ctx->cull_cells + 1), rows = (size_t)ctx->cull_share_nb * ctx->cull_share_n_resident;
+    std::vector<uint64_t> raw(rows * re);
+    LF_HIP(ctx, hipMemcpy(raw.data(), ctx->cull_dev, raw.size() * sizeof(uint64_t), hipMemcpyDeviceToHost));
+    for (int b = 0; b < ctx->cull_bx * ctx->cull_by; b++)
+      std::memcpy(out + (size_t)b * re, raw.data() + lf_cull_row_of_block(b, ctx->cull_share_n_resident, ctx->cull_share_nb) * re, re * sizeof(uint64_t));
+    return LF_OK;
+  }
   LF_HIP(ctx, hipMemcpy(out, ctx->cull_dev, n * sizeof(uint64_t), hipMemcpyDeviceToHost));
   return LF_OK;
 }

@@ -53,6 +53,7 @@ struct CullLevelArgs {
   int W, H;
   float pitch, half_w, half_h;
   int blocks_x, blocks_y, blk_log2;
+  int share_rank, share_n, share_nb;   // a shared table (lf_cull_row_of_block): the first level runs this rank's blocks only
   int P;                   // pupil cells per axis at THIS level
   int P_final;             // ... of the table (the last level)
   int last;                // the last level writes the table, the others the next level's work list
@@ -121,12 +122,16 @@ __global__ __launch_bounds__(256) void k_cull_level(const LfLensDev* __restrict_
                                                     unsigned long long* __restrict__ stats) {
   const int q = blockIdx.y;
   const unsigned PP = (unsigned)(a.P * a.P);
-  const unsigned n_items = items ? min(counts[q], items_stride) : (unsigned)(a.blocks_x * a.blocks_y) * PP;
+  // (first level: every box of the blocks this rank builds -- all of them unless the table is shared)
+  const unsigned n_blk = (unsigned)(a.blocks_x * a.blocks_y);
+  const unsigned n_mine = (n_blk + (unsigned)a.share_n - 1u - (unsigned)a.share_rank) / (unsigned)a.share_n;
+  const unsigned n_items = items ? min(counts[q], items_stride) : n_mine * PP;
   const unsigned i = blockIdx.x * blockDim.x + threadIdx.x;
   // (whole waves past the end leave; a partial last wave keeps its idle lanes: the loop below is wave-uniform)
   if ((i & ~63u) >= n_items) return;
   const bool valid = i < n_items;
-  const unsigned item = valid ? (items ? items[(size_t)q * items_stride + i] : i) : 0u;
+  const unsigned item = valid ? (items ? items[(size_t)q * items_stride + i]
+                                       : ((unsigned)a.share_rank + (unsigned)a.share_n * (i / PP)) * PP + i % PP) : 0u;
   const int blk = (int)(item / PP), cell = (int)(item % PP);
   const int ci = cell % a.P, cj = cell / a.P;
   const int bx = blk % a.blocks_x, by = blk / a.blocks_x;
@@ -358,7 +363,7 @@ __global__ __launch_bounds__(256) void k_cull_level(const LfLensDev* __restrict_
   const bool enabled = valid && keep;
   if (a.last) {
     if (valid && enabled) {
-      unsigned long long* row = table + (size_t)blk * (size_t)(a.P * a.P + 1);
+      unsigned long long* row = table + lf_cull_row_of_block(blk, a.share_n, a.share_nb) * (size_t)(a.P * a.P + 1);
       const unsigned long long bit = 1ull << q;
       atomicOr(&row[cell], bit);
       atomicOr(&row[a.P * a.P], bit);
@@ -586,7 +591,7 @@ void k_march_cull(const LfLensDev* __restrict__ lens, const LfPairsDev* __restri
   const unsigned p = (unsigned)y * (unsigned)a.W + (unsigned)x;
   // the tile's cull row: its 64 columns and 8 rows lie inside one 64 x 64 block
   const int blk = ((trow * 8) >> cull.blk_log2) * cull.blocks_x + ((((tx >> a.xs) << (3 + a.xs))) >> cull.blk_log2);
-  const unsigned long long* const crow = cull.table + (size_t)blk * (size_t)(cull.cells + 1);
+  const unsigned long long* const crow = cull.table + lf_cull_row_of_block(blk, cull.share_n, cull.share_nb) * (size_t)(cull.cells + 1);
 
   const float pitch = lens->pitch, pupil_h = lens->pupil_h, geom_norm = lens->geom_norm;
   const float half_w = a.half_w, half_h = a.half_h, vz_u = a.vz;
@@ -736,7 +741,7 @@ void k_march_items(const LfLensDev* __restrict__ lens, const LfPairsDev* __restr
   const int lane = tid & 63;
   const int n_paths = pairs->n;
   const int blk = ((trow * 8) >> cull.blk_log2) * cull.blocks_x + ((((tx >> a.xs) << (3 + a.xs))) >> cull.blk_log2);
-  const unsigned long long* const crow = cull.table + (size_t)blk * (size_t)(cull.cells + 1);
+  const unsigned long long* const crow = cull.table + lf_cull_row_of_block(blk, cull.share_n, cull.share_nb) * (size_t)(cull.cells + 1);
   const float pitch = lens->pitch, pupil_h = lens->pupil_h, geom_norm = lens->geom_norm;
   const float half_w = a.half_w, half_h = a.half_h, vz_u = a.vz;
   const int GG = a.G * a.G;
@@ -914,6 +919,34 @@ bool lf_cull_applies(const lf_ctx* ctx, int G) {
   return ctx->pairs.n <= kCullMaxPaths && G >= 1 && G <= 64 && ctx->lens.stop >= 0;
 }
 
+// set bits of the table's cells (not of the union entries): the (block, cell, path) combinations the march will start
+__global__ void k_cull_popcount(const unsigned long long* __restrict__ table, size_t rows, int cells,
+                                unsigned long long* __restrict__ out) {
+  const size_t n = rows * (size_t)(cells + 1);
+  unsigned long long sum = 0ull;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x)
+    if ((int)(i % (size_t)(cells + 1)) != cells) sum += (unsigned long long)__popcll(table[i]);
+  for (int o = 32; o > 0; o >>= 1) sum += __shfl_xor(sum, o);
+  if ((threadIdx.x & 63u) == 0u && sum) atomicAdd(out, sum);
+}
+
+// The table is complete (built here, or completed by an all-gather): what fraction of all (block, cell, path)
+// combinations it starts -- counted from the table itself, so that every rank of a shared table finds the same number
+// and takes the same kernel.
+lf_status lfk_cull_finish(lf_ctx* ctx) {
+  if (!ctx->cull_popc_dev) LF_HIP(ctx, hipMalloc((void**)&ctx->cull_popc_dev, sizeof(unsigned long long)));
+  LF_HIP(ctx, hipMemsetAsync(ctx->cull_popc_dev, 0, sizeof(unsigned long long), ctx->stream));
+  const size_t rows = ctx->cull_share_nb > 0 ? (size_t)ctx->cull_share_nb * (size_t)std::max(1, ctx->cull_share_n_resident)
+                                             : (size_t)ctx->cull_bx * ctx->cull_by;
+  hipLaunchKernelGGL(k_cull_popcount, dim3(1024), dim3(256), 0, ctx->stream, ctx->cull_dev, rows, ctx->cull_cells, ctx->cull_popc_dev);
+  LF_HIP(ctx, hipGetLastError());
+  unsigned long long on = 0ull;
+  LF_HIP(ctx, hipMemcpyAsync(&on, ctx->cull_popc_dev, sizeof(on), hipMemcpyDeviceToHost, ctx->stream));
+  LF_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  ctx->cull_started_fraction = (double)on / ((double)ctx->cull_bx * ctx->cull_by * (double)ctx->cull_cells * (double)std::max(1, ctx->pairs.n));
+  return LF_OK;
+}
+
 lf_status lfk_cull_prepass(lf_ctx* ctx, int G, int spp) {
   const LfLensDev& L = ctx->lens;
   CullLevelArgs a;
@@ -929,6 +962,11 @@ lf_status lfk_cull_prepass(lf_ctx* ctx, int G, int spp) {
     a.blk_log2 = kCullBlockLog2 + 1;
   a.blocks_x = (ctx->W + (1 << a.blk_log2) - 1) >> a.blk_log2;
   a.blocks_y = (ctx->H + (1 << a.blk_log2) - 1) >> a.blk_log2;
+  // a table shared between ranks: this one builds the rows of the blocks b with b % n == rank (lf_cull_row_of_block)
+  const bool shared = ctx->cull_share_how != 0 && ctx->cull_share_n > 1;
+  a.share_n = shared ? ctx->cull_share_n : 1;
+  a.share_rank = shared ? ctx->cull_share_rank : 0;
+  a.share_nb = (a.blocks_x * a.blocks_y + a.share_n - 1) / a.share_n;
   const int m = cull_m(ctx, G);
   a.P_final = G * m;
   a.n_paths = ctx->pairs.n;
@@ -973,11 +1011,20 @@ lf_status lfk_cull_prepass(lf_ctx* ctx, int G, int spp) {
   h = fnv(h, &ctx->mask_generation, sizeof(ctx->mask_generation));
   if (h == 0) h = 1;
   const size_t nblk = (size_t)a.blocks_x * a.blocks_y;
-  const size_t entries = nblk * ((size_t)a.P_final * a.P_final + 1);
-  const bool reuse = ctx->march_cull == 1 && ctx->cull_dev && ctx->cull_hash == h && !std::getenv("LF_CULL_NO_REUSE");
+  const size_t rows = (size_t)a.share_nb * (size_t)a.share_n;         // (= nblk unless shared: equal slabs, the last ones padded)
+  const size_t row_entries = (size_t)a.P_final * a.P_final + 1;
+  const size_t entries = rows * row_entries;
+  // (mode 2 rebuilds at every launch -- except the table lf_cull_commit has just completed for this very launch)
+  const bool reuse = (ctx->march_cull == 1 || ctx->cull_fresh) && ctx->cull_dev && ctx->cull_hash == h && !std::getenv("LF_CULL_NO_REUSE");
+  ctx->cull_fresh = false;
   ctx->cull_bx = a.blocks_x; ctx->cull_by = a.blocks_y; ctx->cull_cells = a.P_final * a.P_final; ctx->cull_G = G;
   ctx->cull_P = a.P_final; ctx->cull_m = m; ctx->cull_blk_log2 = a.blk_log2;
   if (reuse) return LF_OK;
+  if (shared && ctx->cull_share_how == 2 && !ctx->cull_prepare_only)
+    return lf_fail(ctx, LF_ERR_STATE, "the cull table is shared through the host (lf_set_cull_share): lf_cull_prepare, the host's "
+                                      "all-gather and lf_cull_commit come before lf_trace_ghosts, with the same inputs");
+  ctx->cull_share_nb = shared ? a.share_nb : 0;
+  ctx->cull_share_n_resident = a.share_n;
   if (entries > ctx->cull_cap) {
     LF_HIP(ctx, hipStreamSynchronize(ctx->stream));
     if (ctx->cull_dev) (void)hipFree(ctx->cull_dev);
@@ -1013,7 +1060,8 @@ lf_status lfk_cull_prepass(lf_ctx* ctx, int G, int spp) {
     }
     if (const char* e = std::getenv("LF_CULL_GEO_MARGIN_LAST")) { if (a.last) a.geo_margin = (float)std::atof(e); }
     if (const char* e = std::getenv("LF_CULL_GEO_MARGIN_COARSE")) { if (!a.last) a.geo_margin = (float)std::atof(e) * (a.P >= 64 ? 1.0f : a.P >= 32 ? 1.15f : a.P >= 16 ? 1.4f : 2.0f); }
-    const size_t n_items = lv == 0 ? nblk * (size_t)a.P * a.P : (size_t)max_items;
+    const size_t n_mine = (nblk + (size_t)a.share_n - 1 - (size_t)a.share_rank) / (size_t)a.share_n;   // blocks this rank builds
+    const size_t n_items = lv == 0 ? n_mine * (size_t)a.P * a.P : (size_t)max_items;
     if (n_items == 0) break;
     const unsigned* items = lv == 0 ? nullptr : ctx->cull_list[(lv - 1) & 1];
     const unsigned in_stride = a.list_stride;    // (of the list being read: set when it was written)
@@ -1069,16 +1117,21 @@ lf_status lfk_cull_prepass(lf_ctx* ctx, int G, int spp) {
       for (int q = 0; q < a.n_paths; q++) max_items = std::max(max_items, std::min(cnt[q], out_stride));
     }
   }
+  // (LF_COMM_FORCE_EXCHANGE: tests only -- the collective also with a single rank, as lf_comm_gather does)
+  if (ctx->cull_share_how == 1 && (shared || std::getenv("LF_COMM_FORCE_EXCHANGE"))) {
+    // every rank has built its slab: one in-place all-gather completes the table everywhere
+    const lf_status st = lf_comm_allgather_u64_inplace(ctx, ctx->cull_dev, (size_t)a.share_nb * row_entries);
+    if (st != LF_OK) return st;
+  }
   lf_timing_end(ctx, LFK_CULL, ev);
   if (stats_dev) (void)hipFree(stats_dev);
+  if (ctx->cull_prepare_only) {       // the host's exchange is outstanding: lf_cull_commit finishes
+    ctx->cull_hash_pending = h;
+    return LF_OK;
+  }
   {
-    // what fraction of all (block, cell, path) combinations the table starts
-    unsigned cnt[kCullMaxPaths];
-    LF_HIP(ctx, hipMemcpyAsync(cnt, ctx->cull_counts + (size_t)(n_levels - 1) * kCullMaxPaths, sizeof(cnt), hipMemcpyDeviceToHost, ctx->stream));
-    LF_HIP(ctx, hipStreamSynchronize(ctx->stream));
-    double on = 0.0;
-    for (int q = 0; q < a.n_paths; q++) on += (double)cnt[q];
-    ctx->cull_started_fraction = on / ((double)nblk * (double)a.P_final * (double)a.P_final * (double)a.n_paths);
+    const lf_status st = lfk_cull_finish(ctx);
+    if (st != LF_OK) return st;
   }
   ctx->cull_hash = h;
   return LF_OK;
@@ -1088,6 +1141,7 @@ lf_status lfk_march_culled(lf_ctx* ctx, const MarchArgs& a, size_t blocks, size_
   const LfApertureDev& m = ctx->ap[LF_APERTURE_STARBURST];
   LfCullArgs c;
   c.table = ctx->cull_dev; c.blocks_x = ctx->cull_bx; c.blocks_y = ctx->cull_by; c.cells = ctx->cull_cells;
+  c.share_n = ctx->cull_share_nb > 0 ? ctx->cull_share_n_resident : 1; c.share_nb = ctx->cull_share_nb;
   c.blk_log2 = ctx->cull_blk_log2;
   c.P = ctx->cull_P; c.m = ctx->cull_m; c.m_shift = ctx->cull_m == 4 ? 2 : ctx->cull_m == 2 ? 1 : 0;
   hipEvent_t ev = lf_timing_begin(ctx, LFK_MARCH);

@@ -214,6 +214,36 @@ lf_status lf_comm_join(lf_ctx* ctx) {
   return LF_OK;
 }
 
+lf_status lf_comm_allgather_u64_inplace(lf_ctx* ctx, unsigned long long* base, size_t count_per_rank) {
+  if (ctx->comm_poisoned.load()) return LF_ERR_STATE;
+  if (!ctx->comm) return lf_fail(ctx, LF_ERR_STATE, "shared cull table: no communicator (lf_comm_init_rank)");
+  Rccl* r = rccl();
+  if (!r) return lf_fail(ctx, LF_ERR_STATE, "RCCL is not available");
+  ctx->comm_busy.fetch_add(1);
+  struct Leave { lf_ctx* c; ~Leave() { c->comm_busy.fetch_sub(1); } } leave{ctx};
+  LF_HIP(ctx, hipSetDevice(ctx->device));
+  if (!ctx->comm_stream) {
+    LF_HIP(ctx, hipStreamCreateWithFlags(&ctx->comm_stream, hipStreamNonBlocking));
+    LF_HIP(ctx, hipEventCreateWithFlags(&ctx->comm_ev_main, hipEventDisableTiming));
+    LF_HIP(ctx, hipEventCreateWithFlags(&ctx->comm_ev_pack, hipEventDisableTiming));
+    LF_HIP(ctx, hipEventCreateWithFlags(&ctx->comm_ev_done, hipEventDisableTiming));
+  }
+  if (!ctx->comm_ev_table) {
+    LF_HIP(ctx, hipEventCreateWithFlags(&ctx->comm_ev_table, hipEventDisableTiming));
+    LF_HIP(ctx, hipEventCreateWithFlags(&ctx->comm_ev_table_done, hipEventDisableTiming));
+  }
+  LF_HIP(ctx, hipEventRecord(ctx->comm_ev_table, ctx->stream));
+  LF_HIP(ctx, hipStreamWaitEvent(ctx->comm_stream, ctx->comm_ev_table, 0));
+  // in place: this rank's slab already lies where the collective would put it
+  const ncclResult_t rc = r->AllGather(base + (size_t)ctx->comm_rank * count_per_rank, base, count_per_rank, ncclUint64,
+                                       (ncclComm_t)ctx->comm, ctx->comm_stream);
+  if (ctx->comm_poisoned.load()) return LF_ERR_STATE;
+  if (rc != ncclSuccess) return lf_fail(ctx, LF_ERR_HIP, std::string("ncclAllGather (cull table): ") + r->GetErrorString(rc));
+  LF_HIP(ctx, hipEventRecord(ctx->comm_ev_table_done, ctx->comm_stream));
+  LF_HIP(ctx, hipStreamWaitEvent(ctx->stream, ctx->comm_ev_table_done, 0));
+  return LF_OK;
+}
+
 extern "C" {
 
 // ---------------------------------------------------------------- one process per GPU -----------
@@ -341,6 +371,20 @@ lf_status lf_comm_gather_async(lf_ctx* ctx, int which) {
   return LF_OK;
 }
 
+// The cull pre-pass shared between the ranks (lf_cull.hip): every rank has built the slab of table rows that is its
+// own; ONE in-place all-gather of equal slabs completes the table everywhere.  On the communicator's stream -- the only
+// stream RCCL calls of this context are ever queued on, so that every rank issues them in one order (the previous
+// frame's exchange, then this) -- after what the main stream has queued (the pre-pass), and the main stream goes on
+// (the march) when it is done.
+lf_status lf_comm_share_cull(lf_ctx* ctx, int on) {
+  if (!ctx) return LF_ERR_INVALID;
+  if (!on) { ctx->cull_share_how = 0; ctx->cull_share_n = 1; ctx->cull_share_rank = 0; return LF_OK; }
+  LF_COMM_REFUSE_POISONED(ctx);
+  if (!ctx->comm) return lf_fail(ctx, LF_ERR_STATE, "lf_comm_share_cull before lf_comm_init_rank");
+  ctx->cull_share_how = 1; ctx->cull_share_n = ctx->comm_nranks; ctx->cull_share_rank = ctx->comm_rank;
+  return LF_OK;
+}
+
 lf_status lf_comm_exchange_plan(lf_ctx* ctx, int world, uint64_t out[6]) {
   if (!ctx || !out || world < 1) return LF_ERR_INVALID;
   if (ctx->W == 0) return lf_fail(ctx, LF_ERR_STATE, "lf_comm_exchange_plan before lf_set_frame");
@@ -398,6 +442,8 @@ lf_status lf_comm_abort(lf_ctx* ctx) {
     comm = ctx->comm;
     ctx->comm = nullptr; ctx->comm_nranks = 1; ctx->comm_rank = 0;
     ctx->comm_pending = false;
+    // (a table shared through this communicator: back to every rank building its own)
+    if (ctx->cull_share_how == 1) { ctx->cull_share_how = 0; ctx->cull_share_n = 1; ctx->cull_share_rank = 0; ctx->cull_hash = 0; }
   }
   if (!comm) return LF_OK;
   Rccl* r = rccl();
@@ -426,6 +472,8 @@ lf_status lf_comm_destroy(lf_ctx* ctx) {
     (void)hipStreamSynchronize(ctx->comm_stream);
     (void)hipEventDestroy(ctx->comm_ev_main); (void)hipEventDestroy(ctx->comm_ev_pack);
     (void)hipEventDestroy(ctx->comm_ev_done);
+    if (ctx->comm_ev_table) { (void)hipEventDestroy(ctx->comm_ev_table); (void)hipEventDestroy(ctx->comm_ev_table_done); }
+    ctx->comm_ev_table = ctx->comm_ev_table_done = nullptr;
     (void)hipStreamDestroy(ctx->comm_stream);
     ctx->comm_stream = nullptr; ctx->comm_ev_main = ctx->comm_ev_pack = ctx->comm_ev_done = nullptr;
     ctx->comm_pending = false;
@@ -436,6 +484,7 @@ lf_status lf_comm_destroy(lf_ctx* ctx) {
     Rccl* r = rccl();
     if (r) (void)r->CommDestroy((ncclComm_t)ctx->comm);
     ctx->comm = nullptr; ctx->comm_nranks = 1; ctx->comm_rank = 0;
+    if (ctx->cull_share_how == 1) { ctx->cull_share_how = 0; ctx->cull_share_n = 1; ctx->cull_share_rank = 0; ctx->cull_hash = 0; }
   }
   return LF_OK;
 }

@@ -216,9 +216,17 @@ constexpr double kCullBigBlockMm = 1.25;
 constexpr int kCullMaxPaths = 64;        // bits of a mask
 constexpr double kCullMaxBlockMm = 1.8;  // a block may be this large on the sensor at most (lf_cull_applies)
 constexpr int kCullOcc = 32;             // the stop mask's occupancy grid: kCullOcc x kCullOcc cells, any texel > 0
+// A table SHARED between n ranks (lf_set_cull_share): rank b mod n builds block b's row, the rows a rank builds lie
+// together (its slab, share_nb rows), the slabs follow each other in rank order -- one in-place all-gather of equal
+// slabs completes the table everywhere.  Dealing the blocks round-robin balances the pre-pass: what a block costs
+// depends on how many ghosts cross it.  n = 1: row b is block b.
+__host__ __device__ inline size_t lf_cull_row_of_block(int b, int share_n, int share_nb) {
+  return share_n > 1 ? (size_t)(b % share_n) * (size_t)share_nb + (size_t)(b / share_n) : (size_t)b;
+}
 struct LfCullArgs {
-  const unsigned long long* table;   // [blocks_y * blocks_x][cells + 1]; null = every path everywhere
+  const unsigned long long* table;   // [rows][cells + 1], row = lf_cull_row_of_block(block); null = every path everywhere
   int blocks_x, blocks_y;
+  int share_n, share_nb;              // see lf_cull_row_of_block
   int blk_log2;                       // log2 of a block's side in pixels
   int cells;                          // P * P, P = G * m cells per axis of the pupil square
   int P, m, m_shift;                  // m (1, 2 or 4) table cells per axis inside one stratum; m = 2^m_shift <= the
@@ -382,6 +390,15 @@ struct lf_ctx {
   size_t cull_list_cap[2] = {0, 0};
   unsigned* cull_counts = nullptr;             // [levels][kCullMaxPaths] list lengths
   int cull_m = 1;                              // table cells per axis inside one stratum
+  // the pre-pass shared between the ranks of a multi-GPU frame (lf_set_cull_share / lf_comm_share_cull):
+  int cull_share_rank = 0, cull_share_n = 1;   // this context builds the rows of the blocks b with b % n == rank
+  int cull_share_how = 0;                      // 1: the library's RCCL communicator completes the table inside lf_trace_ghosts;
+                                               // 2: the host does (lf_cull_prepare -> its own all-gather -> lf_cull_commit)
+  int cull_share_nb = 0, cull_share_n_resident = 1;   // rows per slab and slabs of the RESIDENT table (0 / 1: not shared)
+  uint64_t cull_hash_pending = 0;              // of the slab lf_cull_prepare built (the host's exchange is outstanding)
+  bool cull_prepare_only = false;              // (lf_cull_prepare is inside lfk_march)
+  bool cull_fresh = false;                     // lf_cull_commit just completed the table: the next launch takes it even in mode 2
+  unsigned long long* cull_popc_dev = nullptr; // one u64: set bits of the table (k_cull_popcount)
   double cull_started_fraction = 0.0;          // of all (block, cell, path) combinations, what the resident table starts
   // Above this the culled march loses to the path tree: it marches every started path on its own and with its
   // weight, the tree shares legs and lets rays die early (measured crossover on the 1080p frame: a sun of 0.2 rad
@@ -406,6 +423,7 @@ struct lf_ctx {
   // lf_comm_gather_async: the exchange of frame k runs on its own stream while frame k + 1 is marched
   hipStream_t comm_stream = nullptr;
   hipEvent_t comm_ev_main = nullptr, comm_ev_pack = nullptr, comm_ev_done = nullptr;
+  hipEvent_t comm_ev_table = nullptr, comm_ev_table_done = nullptr;   // the shared cull table's all-gather (lf_comm_allgather_u64_inplace)
   bool comm_pending = false;     // an exchange on comm_stream the main stream has not yet waited for
   bool comm_f32 = false;         // lf_comm_set_exchange_precision(32): the tile rows travel as floats
   // A communicator call can block the calling HOST thread for good (ncclCommInitRank, the first collective's
@@ -474,6 +492,11 @@ int lf_march_fix_bits(const LfLensDev& L, int n_paths, int spp);
 namespace lfm { struct MarchArgs; }
 bool lf_cull_applies(const lf_ctx* ctx, int G);
 lf_status lfk_cull_prepass(lf_ctx* ctx, int G, int spp);
+lf_status lfk_cull_finish(lf_ctx* ctx);
+lf_status lfk_cull_prepare(lf_ctx* ctx, int spp);   // lf_march.hip          // the table is complete: count what it starts
+// lf_group.hip: in-place all-gather of equal slabs of u64 on the communicator's stream, ordered after what the main
+// stream has queued and before what it queues next
+lf_status lf_comm_allgather_u64_inplace(lf_ctx* ctx, unsigned long long* base, size_t count_per_rank);
 lf_status lfk_march_culled(lf_ctx* ctx, const lfm::MarchArgs& a, size_t blocks, size_t dyn_lds);
 void lf_derive_lens(lf_ctx* ctx, int n, int stop, int n_lambda, const float* radius,
                     const float* thickness, const float* ior, const float* semi_ap,

@@ -1111,8 +1111,15 @@ static lf_status build_event_table(lf_ctx* ctx) {
   return LF_OK;
 }
 
-lf_status lfk_march(lf_ctx* ctx, int spp, uint64_t key) {
-  const LfApertureDev& m = ctx->ap[LF_APERTURE_STARBURST];
+static int march_strata(int spp) {
+  int G = (int)std::floor(std::sqrt((double)spp));
+  while ((G + 1) * (G + 1) <= spp) G++;
+  while (G * G > spp) G--;
+  return G;
+}
+
+// what a launch uploads before anything runs: the event program, the lens (with the launch's fixed-point grid), the paths
+static lf_status march_upload(lf_ctx* ctx, int spp) {
   ctx->lens.pitch = ctx->sensor_w_mm / (float)ctx->W;
   if (ctx->events_dirty) {
     lf_status st = build_event_table(ctx);
@@ -1131,13 +1138,40 @@ lf_status lfk_march(lf_ctx* ctx, int spp, uint64_t key) {
   }
   LF_HIP(ctx, hipMemcpyAsync(ctx->pairs_dev, &ctx->pairs, sizeof(LfPairsDev), hipMemcpyHostToDevice,
                              ctx->stream));
-  if (ctx->y1 <= ctx->y0) return LF_OK;
+  return LF_OK;
+}
+
+// lf_cull_prepare: this rank's share of the cull table for the launch lf_trace_ghosts(spp) is about to make, and nothing
+// else (the host completes the table with its own all-gather, lf_cull_commit takes it over)
+lf_status lfk_cull_prepare(lf_ctx* ctx, int spp) {
+  lf_status st = march_upload(ctx, spp);
+  if (st != LF_OK) return st;
+  const int G = march_strata(spp);
+  ctx->cull_hash_pending = 0;
+  if (!lf_cull_applies(ctx, G)) return LF_OK;      // (the launch will march everything: nothing to share)
+  ctx->cull_prepare_only = true;
+  st = lfk_cull_prepass(ctx, G, spp);
+  ctx->cull_prepare_only = false;
+  return st;
+}
+
+lf_status lfk_march(lf_ctx* ctx, int spp, uint64_t key) {
+  const LfApertureDev& m = ctx->ap[LF_APERTURE_STARBURST];
+  {
+    const lf_status st = march_upload(ctx, spp);
+    if (st != LF_OK) return st;
+  }
+  if (ctx->y1 <= ctx->y0) {
+    // no rows of this context's own -- but a table shared through the communicator is completed by a COLLECTIVE:
+    // every rank takes part, whatever it renders
+    if (ctx->cull_share_how == 1 && ctx->cull_share_n > 1 && lf_cull_applies(ctx, march_strata(spp)))
+      return lfk_cull_prepass(ctx, march_strata(spp), spp);
+    return LF_OK;
+  }
   MarchArgs a;
   a.mw = m.w; a.mh = m.h; a.W = ctx->W; a.H = ctx->H; a.y0 = ctx->y0; a.y1 = ctx->y1;
   a.spp = spp;
-  a.G = (int)std::floor(std::sqrt((double)spp));
-  while ((a.G + 1) * (a.G + 1) <= spp) a.G++;
-  while (a.G * a.G > spp) a.G--;
+  a.G = march_strata(spp);
   a.inv_G = 1.0f / (float)a.G;
   a.sub_bits = ctx->march_sub_bits;
   a.inv_sub = 1.0f / (float)(1 << a.sub_bits);

@@ -64,6 +64,18 @@ def gather_frame(frame, W, H, rank, world, dist, elems_per_pixel=3, scratch=None
     v.copy_(recv.permute(1, 0, 2))
 
 
+def complete_cull_table(table, rank, world, dist):
+    """The cull pre-pass shared between the ranks (include/lensflare.h, lf_set_cull_share): `table` is the flat table
+    of lf_cull_table_view -- `world` equal slabs, this rank's slab built (lf_cull_prepare), the others still zero.
+    ONE in-place all-gather completes it everywhere; lf_cull_commit comes next.  An empty table (this launch does
+    not cull: the same on every rank, the inputs are the same) needs nothing."""
+    if world == 1 or table.numel() == 0:
+        return
+    k = table.numel() // world
+    assert k * world == table.numel(), "the table is not made of equal slabs"
+    dist.all_gather_into_tensor(table, table[rank * k:(rank + 1) * k])
+
+
 # ---- one rank per GPU: who starts them --------------------------------------------------------------
 # The reference scales out inside its host: start_raytracing() spawns numWorkerThreads std::threads over
 # one tile queue (raytraced_renderer.cpp:352-354).  Here a rank is a PROCESS (one per GPU), so something has

@@ -369,14 +369,15 @@ def test_scene_through_the_lens_from_the_reference_surface(tmp_path):
     # divides by pi itself: the last bit of a shaded value may differ, nothing else)
     assert np.allclose(sample, want, rtol=1e-12, atol=0)
     # Camera::lensRadius > 0 (the reference's switch for its thin-lens stub, the -b flag): the focus follows
-    # Camera::focalDistance -- the frame of a lens refocused at 4.2 units (lf_focus_lens), ghosts included
+    # Camera::focalDistance, counted from the camera position = the entrance pupil's centre -- the frame of a lens
+    # refocused at 4.2 units (lf_focus_lens_from_pupil), ghosts included
     sample_f, ghost_f, _ = run({}, "focused", focus="4.2 0.01")
     lf = pkg.LensFlare(0)
     lf.set_frame(case.W, case.H)
     lf.set_aperture(pkg.APERTURE_STARBURST, load_texels("pentbig500_14.png"))
     lf.set_aperture(pkg.APERTURE_GHOST, load_texels(m["ghost_aperture"]))
     lf.load_lens_file(lens_path)
-    sensor_mm = lf.focus_lens(4.2 / wpm)
+    sensor_mm = lf.focus_lens_from_pupil(4.2 / wpm)
     assert sensor_mm > 36.2                                   # the file's back focal distance is 36.106 (infinity)
     lf.set_camera(m["c2w"], m["cam_pos"], m["hFov"], m["vFov"])
     lf.set_sampling(32, 0.05, 0.01, 100.0)

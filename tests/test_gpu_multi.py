@@ -354,3 +354,117 @@ def test_a_poisoned_context_refuses_communicator_calls_and_still_renders(pkg):
     assert np.array_equal(lf.read_buffer(pkg.SAMPLE_BUFFER), before)
     lf.close()
     assert getattr(lf, "leaked", None) is False     # no call was left inside: freed
+
+
+@pytest.mark.parametrize("n,W,H,spp", [(8, 1920, 1080, 16), (4, 1920, 1080, 16), (3, 1920, 1080, 16), (8, 3840, 2160, 4), (7, 1900, 1000, 9)])
+def test_shared_cull_prepass_is_the_table_built_alone(pkg, monkeypatch, n, W, H, spp):
+    """The pre-pass shared between the ranks (lf_set_cull_share): n contexts on device 0, each builds
+    the slab of table rows of the blocks b with b % n == rank (lf_cull_prepare), the test plays the all-gather (slab r
+    of rank r into everybody's table, what ncclAllGather / sharding.complete_cull_table deliver), lf_cull_commit, then
+    every rank marches its tile rows.  The table every rank ends with (lf_get_cull_table, block order) is the one a
+    single context builds alone, the started fraction too, the gathered frame and the summed counters are the
+    single-context frame's -- bit for bit; block counts that n does not divide (the last slabs are padded)."""
+    import torch
+    monkeypatch.setenv("LF_CULL_FORCE", "1")      # (few samples, a wide table: the launch would take the path tree by itself)
+    lens = pkg.load_lens_file("dgauss11.lens")
+    mask = load_texels("pentbig500_14.png")
+
+    class View:
+        def __init__(self, ptr, count):
+            self.__cuda_array_interface__ = {"shape": (count,), "typestr": "<i8", "data": (ptr, False), "version": 2}
+
+    def setup(lf):
+        lf.set_frame(W, H)
+        _setup(pkg, lf, lens, mask)
+        lf.set_march_culling(2)
+        lf.reset_counters()
+
+    one = pkg.LensFlare(0)
+    setup(one)
+    one.trace_ghosts(spp, 9)
+    assert one.cull_info()["culled"]
+    want, want_cnt, want_tab, want_frac = one.read_buffer(pkg.GHOST_BUFFER), one.counters(), one.cull_table(), one.cull_started_fraction()
+    info = one.cull_info()
+    one.close()
+    assert want.max() > 0 and ((info["blocks_x"] * info["blocks_y"]) % n != 0 or n == 3)   # (n = 3 divides the 510 blocks: no padding)
+    ranks = [pkg.LensFlare(0) for _ in range(n)]
+    views = []
+    for r, lf in enumerate(ranks):
+        setup(lf)
+        lf.set_row_interleave(r, n)
+        lf.set_cull_share(r, n)
+        with pytest.raises(pkg.LensFlareError):          # a shared table must be completed before the launch
+            lf.trace_ghosts(spp, 9)
+        lf.cull_prepare(spp)
+        ptr, total, per_rank = lf.cull_table_view()
+        assert total == per_rank * n and per_rank % (info["cells"] + 1) == 0
+        views.append(torch.as_tensor(View(ptr, total), device="cuda:0"))
+    k = views[0].numel() // n
+    full = torch.cat([views[r][r * k:(r + 1) * k] for r in range(n)])
+    for r in range(n):                                     # (a rank's table holds its own slab and zeros before the exchange)
+        own = views[r].clone(); own[r * k:(r + 1) * k] = 0
+        assert not own.any()
+        views[r].copy_(full)
+    torch.cuda.synchronize()
+    got = np.zeros_like(want)
+    total_cnt = {}
+    for r, lf in enumerate(ranks):
+        lf.cull_commit()
+        lf.trace_ghosts(spp, 9)
+        assert lf.cull_info()["culled"] and lf.cull_started_fraction() == want_frac
+        assert np.array_equal(lf.cull_table(), want_tab)
+        own = (np.arange(H) // 8) % n == r
+        got[own] = lf.read_buffer(pkg.GHOST_BUFFER)[own]
+        for key, v in lf.counters().items():
+            total_cnt[key] = total_cnt.get(key, 0) + v
+    assert np.array_equal(got, want)
+    assert total_cnt == want_cnt
+    # the next launch needs its own prepare / commit (mode 2 rebuilds): refused without
+    with pytest.raises(pkg.LensFlareError):
+        ranks[0].trace_ghosts(spp, 9)
+    ranks[0].set_cull_share(0, 1)                          # sharing off: the rank builds the whole table again
+    ranks[0].set_row_interleave(0, 1)
+    ranks[0].trace_ghosts(spp, 9)
+    assert np.array_equal(ranks[0].read_buffer(pkg.GHOST_BUFFER), want) and np.array_equal(ranks[0].cull_table(), want_tab)
+    for lf in ranks:
+        lf.close()
+
+
+def test_table_all_gather_through_the_communicator(pkg, monkeypatch):
+    """lf_comm_share_cull: the in-place ncclAllGather of table slabs on the communicator's stream, between pre-pass and
+    march -- with the one rank a one-GPU box can form (LF_COMM_FORCE_EXCHANGE runs the collective all the same, as for
+    the frame's exchange): the RCCL call, the stream hand-over and the launch order are the multi-rank ones, the frame
+    is the plain one; frames in a row with the frame's own asynchronous exchange in between (one stream carries every
+    RCCL call); refused without a communicator, switched off by lf_comm_abort."""
+    if not pkg.comm_available():
+        pytest.skip("librccl.so.1 not loadable")
+    monkeypatch.setenv("LF_COMM_FORCE_EXCHANGE", "1")
+    monkeypatch.setenv("LF_CULL_FORCE", "1")
+    lens = pkg.load_lens_file("dgauss11.lens")
+    mask = load_texels("pentbig500_14.png")
+    W, H, spp = 1920, 1080, 16
+    plain = pkg.LensFlare(0)
+    plain.set_frame(W, H)
+    _setup(pkg, plain, lens, mask)
+    plain.set_march_culling(2)
+    _frame(plain, spp, 9)
+    want, want_tab = plain.read_buffer(pkg.SAMPLE_BUFFER), plain.cull_table()
+    plain.close()
+    lf = pkg.LensFlare(0)
+    lf.set_frame(W, H)
+    _setup(pkg, lf, lens, mask)
+    lf.set_march_culling(2)
+    with pytest.raises(pkg.LensFlareError):
+        lf.comm_share_cull(True)                       # no communicator yet
+    lf.comm_init_rank(1, 0, pkg.comm_unique_id())
+    lf.comm_share_cull(True)
+    for _ in range(3):
+        _frame(lf, spp, 9)
+        lf.comm_gather_async(pkg.SAMPLE_BUFFER)
+    lf.comm_wait()
+    assert lf.cull_info()["culled"]
+    assert np.array_equal(lf.read_buffer(pkg.SAMPLE_BUFFER), want) and np.array_equal(lf.cull_table(), want_tab)
+    lf.comm_abort()
+    _frame(lf, spp, 9)                                  # the communicator is gone: the rank builds its table alone
+    assert np.array_equal(lf.read_buffer(pkg.SAMPLE_BUFFER), want)
+    lf.close()

@@ -283,3 +283,45 @@ def test_a_call_that_returns_after_the_deadline_publishes_nothing():
     def raises():
         raise boom
     assert sharding.call_with_deadline(raises, 5.0) == (True, boom)
+
+
+def _table_worker(rank, world, port, blocks, row_entries, out_dir):
+    import torch
+    import torch.distributed as dist
+    sys.path.insert(0, ROOT)
+    import __graft_entry__ as g
+    g.load_package()
+    from lens_flare_amd import sharding
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    nb = (blocks + world - 1) // world                     # rows per slab: equal slabs, the last ones padded
+    table = torch.zeros(nb * world * row_entries, dtype=torch.int64)
+    rows = table.view(nb * world, row_entries)
+    for b in range(rank, blocks, world):                   # the blocks this rank builds, at lf_cull_row_of_block(b)
+        rows[(b % world) * nb + b // world] = torch.arange(row_entries, dtype=torch.int64) + 1000 * (b + 1)
+    sharding.complete_cull_table(table, rank, world, dist)
+    np.save(os.path.join(out_dir, f"table_{rank}.npy"), table.numpy())
+    empty = torch.zeros(0, dtype=torch.int64)              # a launch that does not cull: nothing to exchange, no collective
+    sharding.complete_cull_table(empty, rank, world, dist)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world,blocks", [(2, 7), (3, 10)])
+def test_shared_cull_table_is_completed_by_one_all_gather(world, blocks, tmp_path):
+    """The host-owned exchange of the shared pre-pass (lf_set_cull_share; bench.py's torch / rehearsal modes): every
+    rank holds its slab of rows (blocks dealt round robin, rows of one rank together), ONE in-place all-gather of equal
+    slabs -- the layout lf_cull_table_view hands out -- and every rank holds every block's row where
+    lf_cull_row_of_block puts it, the padding rows of the short slabs still zero."""
+    import torch.multiprocessing as mp
+    row_entries = 5
+    port = _free_port()
+    mp.spawn(_table_worker, args=(world, port, blocks, row_entries, str(tmp_path)), nprocs=world, join=True)
+    nb = (blocks + world - 1) // world
+    want = np.zeros((nb * world, row_entries), np.int64)
+    for b in range(blocks):
+        want[(b % world) * nb + b // world] = np.arange(row_entries) + 1000 * (b + 1)
+    assert (want.sum(axis=1) == 0).sum() == nb * world - blocks
+    for r in range(world):
+        assert np.array_equal(np.load(tmp_path / f"table_{r}.npy").reshape(nb * world, row_entries), want)
