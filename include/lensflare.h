@@ -367,6 +367,11 @@ const char* lf_group_last_error(const lf_group* g);
 lf_status lf_group_set_frame(lf_group* g, int width, int height);
 lf_status lf_group_for_each(lf_group* g, lf_group_fn fn, void* user);
 lf_status lf_group_gather(lf_group* g, int which);
+/* the cull pre-pass of the group's next lf_trace_ghosts(spp) shared between its devices (see lf_set_cull_share): every
+ * context builds its slab, one all-gather, every context takes the table over.  Call it before the lf_group_for_each
+ * that renders, once per launch; without it every device builds the whole table (until lf_group_share_cull has been
+ * used once: from then on a launch without it is refused, like any launch of a host-shared table). */
+lf_status lf_group_share_cull(lf_group* g, int spp);
 
 /* ---------------------------------------------------------------- geometric lens --------- */
 /* The north-star path: real ray march through spherical interfaces.  The reference has no

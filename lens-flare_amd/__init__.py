@@ -47,7 +47,7 @@ ABI_SYMBOLS = [
     "lf_comm_destroy", "lf_comm_available", "lf_comm_info", "lf_comm_test", "lf_comm_abort",
     "lf_comm_set_exchange_precision", "lf_comm_poison", "lf_comm_is_poisoned", "lf_comm_exchange_plan",
     "lf_group_create", "lf_group_destroy", "lf_group_size", "lf_group_ctx", "lf_group_last_error",
-    "lf_group_set_frame", "lf_group_for_each", "lf_group_gather",
+    "lf_group_set_frame", "lf_group_for_each", "lf_group_gather", "lf_group_share_cull",
 ]
 
 
@@ -891,6 +891,10 @@ class LensFlareGroup:
 
     def gather(self, which):
         self._ck(self.lib.lf_group_gather(self.g, int(which)))
+
+    def share_cull(self, spp):
+        """the pre-pass of the next trace_ghosts(spp) shared between the group's devices"""
+        self._ck(self.lib.lf_group_share_cull(self.g, int(spp)))
 
     def close(self):
         if self.g:

@@ -625,4 +625,64 @@ lf_status lf_group_gather(lf_group* g, int which) {
   return LF_OK;
 }
 
+// The cull pre-pass of the group's next lf_trace_ghosts(spp), shared between its devices: every context builds its
+// slab (one host thread per device), ONE in-place all-gather of slabs -- ncclAllGather inside a group call, or the
+// peer-copy stand-in of a rehearsal group -- and every context takes the completed table over.  The host calls it
+// before the lf_group_for_each that renders (same inputs on every context, as for any launch of a group).
+lf_status lf_group_share_cull(lf_group* g, int spp) {
+  if (!g || spp < 1) return LF_ERR_INVALID;
+  const int n = (int)g->ctx.size();
+  if (n == 1) return LF_OK;
+  for (int r = 0; r < n; r++) {
+    const lf_status st = lf_set_cull_share(g->ctx[r], r, n);
+    if (st != LF_OK) { g->err = lf_last_error(g->ctx[r]); return st; }
+  }
+  struct Arg { int spp; } arg{spp};
+  lf_status st = lf_group_for_each(g, [](lf_ctx* c, int, void* u) { return lf_cull_prepare(c, ((Arg*)u)->spp); }, &arg);
+  if (st != LF_OK) return st;
+  std::vector<void*> dev(n, nullptr);
+  uint64_t entries = 0, per = 0;
+  for (int r = 0; r < n; r++) {
+    uint64_t e = 0, p = 0;
+    st = lf_cull_table_view(g->ctx[r], &dev[r], &e, &p);
+    if (st != LF_OK) { g->err = lf_last_error(g->ctx[r]); return st; }
+    if (r == 0) { entries = e; per = p; }
+    else if (e != entries || p != per) { g->err = "the contexts of a group disagree about the cull table (different inputs?)"; return LF_ERR_STATE; }
+  }
+  if (entries != 0) {
+    if (g->rccl) {
+      Rccl* rc = rccl();
+      ncclResult_t e = rc->GroupStart();
+      if (e != ncclSuccess) { g->err = std::string("ncclGroupStart: ") + rc->GetErrorString(e); return LF_ERR_HIP; }
+      for (int r = 0; r < n; r++) {
+        lf_ctx* c = g->ctx[r];
+        if (hipSetDevice(c->device) != hipSuccess) { (void)rc->GroupEnd(); g->err = "hipSetDevice"; return LF_ERR_HIP; }
+        unsigned long long* base = (unsigned long long*)dev[r];
+        e = rc->AllGather(base + (size_t)r * per, base, (size_t)per, ncclUint64, (ncclComm_t)c->comm, c->stream);
+        if (e != ncclSuccess) { (void)rc->GroupEnd(); g->err = std::string("ncclAllGather (cull table): ") + rc->GetErrorString(e); return LF_ERR_HIP; }
+      }
+      e = rc->GroupEnd();
+      if (e != ncclSuccess) { g->err = std::string("ncclGroupEnd: ") + rc->GetErrorString(e); return LF_ERR_HIP; }
+    } else {
+      // rehearsal: what the all-gather delivers, with peer copies (lf_cull_table_view has synchronised every stream)
+      for (int r = 0; r < n; r++) {
+        lf_ctx* c = g->ctx[r];
+        if (hipSetDevice(c->device) != hipSuccess) { g->err = "hipSetDevice"; return LF_ERR_HIP; }
+        for (int q = 0; q < n; q++) {
+          if (q == r) continue;
+          const hipError_t he = hipMemcpyPeerAsync((unsigned long long*)dev[r] + (size_t)q * per, c->device,
+                                                   (unsigned long long*)dev[q] + (size_t)q * per, g->ctx[q]->device,
+                                                   (size_t)per * sizeof(unsigned long long), c->stream);
+          if (he != hipSuccess) { g->err = std::string("hipMemcpyPeerAsync: ") + hipGetErrorString(he); return LF_ERR_HIP; }
+        }
+      }
+      for (int r = 0; r < n; r++) {      // (a slab must not be overwritten... none is: every context only READS the others' own slabs)
+        (void)hipSetDevice(g->ctx[r]->device);
+        if (hipStreamSynchronize(g->ctx[r]->stream) != hipSuccess) { g->err = "hipStreamSynchronize"; return LF_ERR_HIP; }
+      }
+    }
+  }
+  return lf_group_for_each(g, [](lf_ctx* c, int, void*) { return lf_cull_commit(c); }, nullptr);
+}
+
 }  // extern "C"

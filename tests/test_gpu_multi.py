@@ -468,3 +468,36 @@ def test_table_all_gather_through_the_communicator(pkg, monkeypatch):
     _frame(lf, spp, 9)                                  # the communicator is gone: the rank builds its table alone
     assert np.array_equal(lf.read_buffer(pkg.SAMPLE_BUFFER), want)
     lf.close()
+
+
+@pytest.mark.parametrize("n", [2, 7])
+def test_group_shares_the_cull_prepass(pkg, monkeypatch, n):
+    """lf_group_share_cull (one process, n devices; here n contexts on device 0, whose all-gather is the peer-copy
+    stand-in): every context builds its slab, the group completes the table, the gathered 1080p frame is the
+    single-context frame, bit for bit; a frame later without the call is refused (mode 2: the table is per launch)."""
+    monkeypatch.setenv("LF_CULL_FORCE", "1")
+    lens = pkg.load_lens_file("dgauss11.lens")
+    mask = load_texels("pentbig500_14.png")
+    W, H, spp = 1920, 1080, 16
+    one = pkg.LensFlare(0)
+    one.set_frame(W, H)
+    _setup(pkg, one, lens, mask)
+    one.set_march_culling(2)
+    _frame(one, spp, 9)
+    want, want_tab = one.read_buffer(pkg.SAMPLE_BUFFER), one.cull_table()
+    one.close()
+    grp = pkg.LensFlareGroup([0] * n)
+    grp.set_frame(W, H)
+    for r in grp.ranks:
+        _setup(pkg, r, lens, mask)
+        r.set_march_culling(2)
+    for _ in range(2):
+        grp.share_cull(spp)
+        grp.for_each(lambda lf, rank: _frame(lf, spp, 9))
+        grp.gather(pkg.SAMPLE_BUFFER)
+    for lf in grp.ranks:
+        assert lf.cull_info()["culled"]
+        assert np.array_equal(lf.read_buffer(pkg.SAMPLE_BUFFER), want) and np.array_equal(lf.cull_table(), want_tab)
+    with pytest.raises(pkg.LensFlareError):
+        grp.for_each(lambda lf, rank: _frame(lf, spp, 9))
+    grp.close()
