@@ -88,6 +88,8 @@ int main(int argc, char** argv) {
   for (int r = 0; r < lf_group_size(g); r++)
     if (setup(lf_group_ctx(g, r), j) != LF_OK || lf_reset_counters(lf_group_ctx(g, r)) != LF_OK)
       return fail("setup", lf_last_error(lf_group_ctx(g, r)));
+  // the cull pre-pass of this launch, shared between the devices (each builds 1 / n of the table, one all-gather)
+  if (lf_group_share_cull(g, j.spp) != LF_OK) return fail("lf_group_share_cull", lf_group_last_error(g));
   if (lf_group_for_each(g, render_share, &j) != LF_OK) return fail("lf_group_for_each", lf_group_last_error(g));
   if (lf_group_gather(g, 0) != LF_OK) return fail("lf_group_gather", lf_group_last_error(g));
   lf_counters sum;
