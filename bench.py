@@ -631,6 +631,25 @@ def main():
             dist.barrier()
             torch.cuda.synchronize()
 
+    if cull_share == "rccl (C ABI)":
+        # The first frame whose cull table is completed by the communicator (the in-place all-gather of table slabs
+        # inside lf_trace_ghosts): under the same deadline and the same joint verdict as the first exchange -- a rank
+        # whose peers never arrive gives up, everybody aborts, and frame and table fall back to torch.distributed together.
+        all_ok, bad = sharding.first_exchange(dist, one_frame, lf.comm_test,
+                                              timeout_s=float(os.environ.get("LF_BENCH_COMM_TIMEOUT", "120")), on_expire=lf.comm_poison)
+        if not all_ok:
+            try:
+                lf.comm_abort()
+            except Exception:  # noqa: BLE001
+                pass
+            gather_mode = "torch"
+            gather_note = "C-ABI RCCL table exchange failed (" + "; ".join(bad) + "): torch.distributed nccl exchange of frame and table"
+            nccl_group = dist.new_group(backend="nccl")
+            lf.set_row_interleave(rank, world)
+            lf.set_cull_share(rank, world)
+            cull_share = "torch.distributed nccl"
+            ptr, nbytes = lf.device_buffer(pkg.SAMPLE_BUFFER)
+            frame_t = torch.as_tensor(DevView(ptr, nbytes // 8), device=f"cuda:{local}")
     for _ in range(args.warmup):
         one_frame()
     barrier()
