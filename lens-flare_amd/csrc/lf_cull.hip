@@ -111,7 +111,13 @@ __device__ __forceinline__ void virtual_event(Ray& r, const LfProgRow& w, float 
 // Work: `items` = this level's list for the path (cell index = block * P * P + cell; null = every box of the
 // level); a box that cannot be ruled out appends its four children to `next` (cells of 2P) or, on the last
 // level, sets the path's bit in the table.
-__global__ __launch_bounds__(256) void k_cull_level(const LfLensDev* __restrict__ lens,
+#ifndef LF_CULL_WAVES
+#define LF_CULL_WAVES 3      // waves per SIMD: 2 / 3 / 4 -> 8.6 / 7.15 / 18.8 ms on the bench frame (193 / 168 / 128 VGPR)
+#endif
+#ifndef LF_CULL_WG
+#define LF_CULL_WG 64        // lanes per workgroup: 256 / 128 / 64 -> 7.18 / 7.11 / 6.95 ms (a wave of decided boxes frees its slot at once)
+#endif
+__global__ __launch_bounds__(LF_CULL_WG, LF_CULL_WAVES) void k_cull_level(const LfLensDev* __restrict__ lens,
                                                     const LfPairsDev* __restrict__ pairs,
                                                     const int* __restrict__ seq_table,
                                                     const LfProgRow* __restrict__ rec_table, CullLevelArgs a,
@@ -1091,8 +1097,8 @@ lf_status lfk_cull_prepass(lf_ctx* ctx, int G, int spp) {
     k.list_stride = a.last ? in_stride : out_stride;
 
     // (two strides are needed when reading AND writing: the input's travels in `items_stride`)
-    const dim3 grid((unsigned)((n_items + 255) / 256), (unsigned)a.n_paths);
-    hipLaunchKernelGGL(k_cull_level, grid, dim3(256), 0, ctx->stream, ctx->lens_dev, ctx->pairs_dev,
+    const dim3 grid((unsigned)((n_items + LF_CULL_WG - 1) / LF_CULL_WG), (unsigned)a.n_paths);
+    hipLaunchKernelGGL(k_cull_level, grid, dim3(LF_CULL_WG), 0, ctx->stream, ctx->lens_dev, ctx->pairs_dev,
                        (const int*)(ctx->prog_dev + ctx->prog_seq_off), (const LfProgRow*)(ctx->prog_dev + ctx->prog_rec_off),
                        k, items, lv == 0 ? nullptr : ctx->cull_counts + (size_t)(lv - 1) * kCullMaxPaths, in_stride, next,
                        ctx->cull_counts + (size_t)lv * kCullMaxPaths, ctx->cull_dev, stats_dev);
