@@ -409,16 +409,27 @@ def main():
     # aborts together, the exchange falls back to the host staging) on real hardware.
     rehearsal_rccl = os.environ.get("LF_BENCH_REHEARSAL") == "rccl"
     rehearsal = os.environ.get("LF_BENCH_REHEARSAL") == "1" or rehearsal_rccl
-    gather_mode = "none" if world == 1 else ("cabi" if rehearsal_rccl else "host" if rehearsal
-                                             else os.environ.get("LF_BENCH_GATHER", "cabi"))
+    # LF_BENCH_SOLO_COMM=1 (tests): ONE rank goes through everything N ranks go through -- gloo control plane, the
+    # C ABI's communicator (RCCL forms one of a single rank), the first exchange under its deadline, the shared cull
+    # table's all-gather and the frame's -- with LF_COMM_FORCE_EXCHANGE making the library run its collectives even
+    # so.  What a one-GPU box can rehearse of `bench.py --gpus N` beyond the fallbacks of LF_BENCH_REHEARSAL.
+    solo = world == 1 and os.environ.get("LF_BENCH_SOLO_COMM") == "1"
+    if solo:
+        os.environ["LF_COMM_FORCE_EXCHANGE"] = "1"
+    multi = world > 1 or solo
+    gather_mode = "none" if not multi else ("cabi" if rehearsal_rccl else "host" if rehearsal
+                                            else os.environ.get("LF_BENCH_GATHER", "cabi"))
     local = local % max(1, torch.cuda.device_count()) if rehearsal else local
     if local >= torch.cuda.device_count():
         raise SystemExit(f"rank {rank}: local rank {local} has no GPU (this node shows {torch.cuda.device_count()}); "
                          "LF_BENCH_REHEARSAL=1 lets several ranks share GPU 0")
     torch.cuda.set_device(local)
     nccl_group = None
-    if world > 1:
+    if multi:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        if solo:
+            os.environ.setdefault("MASTER_PORT", str(sharding.free_port()))
+            os.environ.setdefault("RANK", "0"); os.environ.setdefault("WORLD_SIZE", "1")
         import datetime
         # (the control plane's own deadline: a rank that died takes its peers' next gloo collective down
         # with an error after 10 minutes instead of the default half hour)
@@ -560,7 +571,7 @@ def main():
     # through the C ABI's communicator where that stands, through the exchange the frame itself falls back to otherwise.
     # LF_BENCH_CULL_SHARE=0: every rank builds the whole table (A/B).
     cull_share = None
-    if world > 1 and cull_mode != 0 and os.environ.get("LF_BENCH_CULL_SHARE", "1") != "0":
+    if multi and cull_mode != 0 and os.environ.get("LF_BENCH_CULL_SHARE", "1") != "0":
         if gather_mode == "cabi":
             lf.comm_share_cull(True)
             cull_share = "rccl (C ABI)"
@@ -627,7 +638,7 @@ def main():
     def barrier():
         lf.synchronize()
         torch.cuda.synchronize()
-        if world > 1:
+        if multi:
             dist.barrier()
             torch.cuda.synchronize()
 
@@ -738,7 +749,7 @@ def main():
             "exchange_ms": xchg_ms / max(n_xchg, 1), "scene_ms": scene_ms / max(n_scene, 1) if n_scene else 0.0,
             "wall_ms_per_step": dt / args.steps * 1e3, "rccl_nranks": rccl_nranks, "rccl_rank": rccl_rank}
     per_rank = [mine]
-    if world > 1:
+    if multi:
         tot = ev.clone()
         dist.all_reduce(tot[:-1], op=dist.ReduceOp.SUM)
         mx = ev[-1:].clone()
@@ -930,7 +941,7 @@ def main():
         }
         print(json.dumps(out), flush=True)
     lf.close()
-    if world > 1:
+    if multi:
         dist.destroy_process_group()
 
 

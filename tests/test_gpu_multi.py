@@ -501,3 +501,32 @@ def test_group_shares_the_cull_prepass(pkg, monkeypatch, n):
     with pytest.raises(pkg.LensFlareError):
         grp.for_each(lambda lf, rank: _frame(lf, spp, 9))
     grp.close()
+
+
+def test_bench_goes_through_the_multi_rank_bring_up_with_one_rank(pkg):
+    """`bench.py --gpus N` as far as one GPU can take it (LF_BENCH_SOLO_COMM=1): gloo control plane, communicator id,
+    ncclCommInitRank and the first exchange under their deadlines, lf_comm_share_cull, the first frame with a
+    communicator-completed cull table under the deadline, the timed frames with table and frame all-gathers -- and the
+    JSON line says so: the C ABI's exchange, the pre-pass shared through RCCL, the single-GPU frame's event count."""
+    import json
+    import os
+    import subprocess
+    import sys
+    if not pkg.comm_available():
+        pytest.skip("librccl.so.1 not loadable")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, LF_BENCH_SOLO_COMM="1", LF_BENCH_COMM_TIMEOUT="120")
+    env.pop("LF_CULL_FORCE", None)
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--steps", "2", "--warmup", "1", "--no-cpu", "--config", "c2"],
+                       capture_output=True, text=True, timeout=600, env=env, cwd=root)
+    assert r.returncode == 0, r.stderr[-3000:]
+    line = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+    assert line["config"]["gather_mode"] == "cabi" and line["config"]["gather_note"] is None
+    assert line["culling"]["culled"] and line["culling"]["prepass_shared_between_ranks"] == "rccl (C ABI)"
+    assert line["rccl_nranks"] == 1 and line["n_gpus"] == 1
+    plain = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--steps", "2", "--warmup", "1", "--no-cpu", "--config", "c2"],
+                           capture_output=True, text=True, timeout=600, env={k: v for k, v in env.items() if k != "LF_BENCH_SOLO_COMM"}, cwd=root)
+    assert plain.returncode == 0, plain.stderr[-3000:]
+    want = json.loads([l for l in plain.stdout.splitlines() if l.startswith("{")][-1])
+    assert line["config"]["events_executed_per_frame"] == want["config"]["events_executed_per_frame"]
+    assert line["culling"]["started_fraction"] == want["culling"]["started_fraction"]
