@@ -316,3 +316,11 @@ def test_random_frames_culled_equals_full(pkg, forced):
     print(s)
     assert s["compared"] == 80 and s["culled_kernel_ran"] == 80 and s["frames_with_light"] > 60
     assert s["frames_differing"] == 0, [c for c in r["cases"] if c.get("BAD")]
+
+
+def test_the_drivers_smoke_entry():
+    """__graft_entry__.smoke(): what the driver runs before the bench -- the flare layer against the real reference's
+    golden frame, the march against the float32 oracle, the lens-imaged flat field, and the culled default launch of a
+    1920-pixel-wide frame against the full enumeration."""
+    import __graft_entry__ as g
+    g.smoke()
