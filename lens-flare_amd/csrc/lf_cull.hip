@@ -65,6 +65,9 @@ struct CullLevelArgs {
   float sx, sy, rho;       // the sun's direction (x, y) and the lobe's radius in direction space
   float margin;            // footprint inflation at this level
   float geo_margin;        // ... of the zonotope's generators alone (experiments: LF_CULL_GEO_MARGIN)
+  int strict;              // footprint tests: 0 every box, 1 only boxes with EVERY sample alive, 2 not for boxes that lost samples to total reflection
+  int strict_lost;         // "all samples end here" by a scalar zonotope bound instead of the range rule
+  float lobe_k;            // the footprint in direction space once more inflated for the lobe test (third order: a small lobe sees it)
   int slack_mode;          // experiments: LF_CULL_SLACK (1: second order summed over the four axes + twice the corners' cross terms)
   int keep_partial;        // a box that lost samples (total reflection, a missed sphere) is never dropped by the lobe test
   float lost_rel, lost_abs;  // "every sample ends here" drops a box only beyond this margin (see firmly_lost)
@@ -192,6 +195,8 @@ __global__ __launch_bounds__(LF_CULL_WG, LF_CULL_WAVES) void k_cull_level(const 
   // is steep there, and its footprints are inflated twice as much.
   unsigned live = kAll;
   bool culled = !valid, keep = false, partial = false;
+  bool tir_partial = false;     // some sample of the box ended by TOTAL REFLECTION: next to that boundary the refracted ray is grazing and
+                                // the map unbounded -- what is left of the box cannot be bounded by the samples left (strict = 2)
   int why = 0;
   // Footprint of the box in a plane (an interface's, or direction space).  With every sample in use the
   // image of the box is modelled as a ZONOTOPE: centre c + the four generators g1, g2 (half the cell along the
@@ -287,6 +292,10 @@ __global__ __launch_bounds__(LF_CULL_WG, LF_CULL_WAVES) void k_cull_level(const 
       delta_of[w] = j == 0 ? x.delta[0] : j == 1 ? x.delta[1] : x.delta[2];
     }
     unsigned hit = 0u, okm = 0u;
+    const unsigned live_before = live;
+    // A ray goes on iff it meets the sphere (disc >= 0) and is not totally reflected ((n' cos t')^2 = disc + delta >= 0):
+    // iff p = disc + min(0, delta) >= 0 -- ONE smooth scalar for both ways of ending (a mirror: p = disc)
+    float pv[kCullSamples];
     // the total-reflection margins (virtual_event) of the samples that reach the interface: their range over the
     // box, and the one nearest to going on among those that end here by total reflection
     float t_max = -2.0f, t_min = 2.0f, t_lost = -2.0f;
@@ -300,27 +309,49 @@ __global__ __launch_bounds__(LF_CULL_WG, LF_CULL_WAVES) void k_cull_level(const 
         r[t].px = hx; r[t].py = hy; r[t].hz = 0.0f;
         ok = hx == hx && hy == hy;
         if (ok) hit |= 1u << t;
+        pv[t] = 1.0f;
       } else {
         float disc, tir;
         virtual_event(r[t], wr, cn22_of[w], rn2_of[w], delta_of[w], (kind & LF_EV_REFLECT) != 0, (kind & LF_EV_FLAT) != 0, disc, tir);
+        pv[t] = (kind & LF_EV_REFLECT) ? disc : disc + fminf(0.0f, delta_of[w]);
         const bool reaches = disc >= 0.0f;
         if (reaches) hit |= 1u << t;                // (a totally reflected ray did reach the interface)
         ok = reaches && tir >= 0.0f;
         if (reaches && ((live >> t) & 1u)) {
           t_max = fmaxf(t_max, tir); t_min = fminf(t_min, tir);
-          if (tir < 0.0f) t_lost = fmaxf(t_lost, tir);
+          if (tir < 0.0f) { t_lost = fmaxf(t_lost, tir); tir_partial = true; }
         }
       }
       if (ok) okm |= 1u << t;
     }
     hit &= live;
-    // "Every sample ends here" drops the box only with a margin.  A sample that finds NO intersection needs none:
-    // what lies between it and a sample that does hit meets the sphere further out than the clear aperture reaches.
-    // Total reflection happens INSIDE the clear aperture (the steep rear surface of the front group), and a sliver
-    // of the box may go on between samples that all end: the box is dropped only if even the sample nearest to
-    // going on is further from it than the margins vary over the box (found by comparing with the full
-    // enumeration on frames with larger blocks: pair (3, 7), profiles/r05_march_variants.txt).
-    const bool firmly_lost = t_lost < -1.5f || t_lost < -(fmaf(a.lost_rel, t_max - t_min, a.lost_abs));
+    // "Every ray of the box ends here".  Round 5 first dropped such a box when even the sample nearest to going on was
+    // further from it than half the range of the margins over the box (a rule fitted to the double Gauss: pair (3, 7),
+    // profiles/r05_march_variants.txt) -- a draw of 6000 random frames with a second design family (a Cooke triplet,
+    // steeper surfaces) found 14 frames where a sliver between the samples went on.  Now (strict_lost, the default):
+    // the LARGEST value p can take over the box, bounded from its 15 samples like a footprint -- centre + the four
+    // central-difference generators (x the footprints' inflation) + the second order of the four axes summed + twice
+    // what the corners deviate by beyond that + how far the ends of the spectrum move the centre -- must stay below
+    // zero; and only a box that had lost no sample before is bounded by its samples at all.
+    bool firmly_lost = t_lost < -1.5f || t_lost < -(fmaf(a.lost_rel, t_max - t_min, a.lost_abs));
+    if (a.strict_lost) {
+      auto upper = [&](const float* v) {
+        const float ga = 0.5f * (v[5] - v[3]), gb = 0.5f * (v[7] - v[1]), gx = 0.5f * (v[9] - v[10]), gy = 0.5f * (v[11] - v[12]);
+        const float da = fabsf(0.5f * (v[5] + v[3]) - v[4]), db = fabsf(0.5f * (v[7] + v[1]) - v[4]);
+        const float dx = fabsf(0.5f * (v[9] + v[10]) - v[4]), dy = fabsf(0.5f * (v[11] + v[12]) - v[4]);
+        const float second = (da + db) + (dx + dy);
+        float cross = 0.0f;
+#pragma unroll
+        for (int t = 0; t < 9; t += 2) {
+          if (t == 4) continue;
+          const float at = (float)(t % 3 - 1), bt = (float)(t / 3 - 1);
+          cross = fmaxf(cross, fabsf((v[t] - v[4]) - fmaf(at, ga + gx, bt * (gb + gy))) - second);
+        }
+        const float disp = fmaxf(fabsf(v[13] - v[4]), fabsf(v[14] - v[4]));
+        return v[4] + fmaf(a.geo_margin, (fabsf(ga) + fabsf(gb)) + (fabsf(gx) + fabsf(gy)), second + fmaf(2.0f, fmaxf(cross, 0.0f), a.margin * disp));
+      };
+      firmly_lost = live_before == kAll && !(kind & LF_EV_STOP) && upper(pv) < -1.0e-4f;
+    }
     const Foot f = footprint(false, hit, 1e-3f);
     live &= okm;
     if (!culled && !keep) {
@@ -331,8 +362,9 @@ __global__ __launch_bounds__(LF_CULL_WG, LF_CULL_WAVES) void k_cull_level(const 
         const float cx = f.cx, cy = f.cy;
         const float cr = lf_sqrt(fmaf(cx, cx, cy * cy));
         const float icr = cr > 0.0f ? lf_rcp(cr) : 0.0f;
-        if (cr - extent(f, cx * icr, cy * icr) > lf_sqrt(wr.h2) && !(a.disable & 1)) { culled = true; why = 4; }   // wholly outside the clear aperture
-        else if (kind & LF_EV_STOP) {
+        const bool bounded = a.strict == 0 || f.zono || (a.strict == 2 && !tir_partial);   // (STRICT: a box that lost samples is not bounded by the ones left)
+        if (bounded && cr - extent(f, cx * icr, cy * icr) > lf_sqrt(wr.h2) && !(a.disable & 1)) { culled = true; why = 4; }   // wholly outside the clear aperture
+        else if (bounded && (kind & LF_EV_STOP)) {
           // ... or on closed cells of the mask: texel coordinate = (h / stop_h + 1) / 2 of the mask's width
           const float s = 0.5f * (float)kCullOcc;
           const float radx = extent(f, 1.0f, 0.0f), rady = extent(f, 0.0f, 1.0f);
@@ -361,8 +393,8 @@ __global__ __launch_bounds__(LF_CULL_WG, LF_CULL_WAVES) void k_cull_level(const 
     const float ex = a.sx - f.cx, ey = a.sy - f.cy;
     const float dist = lf_sqrt(fmaf(ex, ex, ey * ey));
     const float id = dist > 0.0f ? lf_rcp(dist) : 0.0f;
-    if (partial && a.keep_partial) { keep = true; why = 1; }
-    else if (dist - extent(f, ex * id, ey * id) > a.rho && !(a.disable & 4)) { culled = true; why = 6; }
+    if (partial && (a.keep_partial || a.strict == 1 || (a.strict == 2 && tir_partial))) { keep = true; why = 1; }
+    else if (dist - a.lobe_k * extent(f, ex * id, ey * id) > a.rho && !(a.disable & 4)) { culled = true; why = 6; }
     else { keep = true; why = partial ? 1 : 3; }
   }
   if (stats && valid && why) atomicAdd(&stats[why], 1ull);
@@ -994,7 +1026,10 @@ lf_status lfk_cull_prepass(lf_ctx* ctx, int G, int spp) {
   a.keep_partial = std::getenv("LF_CULL_KEEP_PARTIAL") ? std::atoi(std::getenv("LF_CULL_KEEP_PARTIAL")) : 0;
   a.lost_rel = std::getenv("LF_CULL_LOST_REL") ? (float)std::atof(std::getenv("LF_CULL_LOST_REL")) : 0.5f;
   a.lost_abs = std::getenv("LF_CULL_LOST_ABS") ? (float)std::atof(std::getenv("LF_CULL_LOST_ABS")) : 0.002f;
-  a.slack_mode = std::getenv("LF_CULL_SLACK") ? std::atoi(std::getenv("LF_CULL_SLACK")) : 0;
+  a.strict = std::getenv("LF_CULL_STRICT") ? std::atoi(std::getenv("LF_CULL_STRICT")) : 2;
+  a.lobe_k = std::getenv("LF_CULL_LOBE_K") ? (float)std::atof(std::getenv("LF_CULL_LOBE_K")) : 1.2f;
+  a.strict_lost = std::getenv("LF_CULL_STRICT_LOST") ? std::atoi(std::getenv("LF_CULL_STRICT_LOST")) : 1;
+  a.slack_mode = std::getenv("LF_CULL_SLACK") ? std::atoi(std::getenv("LF_CULL_SLACK")) : 1;
   a.disable = std::getenv("LF_CULL_DISABLE") ? std::atoi(std::getenv("LF_CULL_DISABLE")) : 0;
   // the levels: P_final, halved while it stays even and >= 8 (a coarser box is too curved for 13 rays to bound)
   int levels[8], n_levels = 0;

@@ -70,9 +70,24 @@ def draw_mask():
     return k, synthetic_mask(k)
 
 
+def triplet():
+    """A Cooke-type triplet, f ~ 50 mm, f/4.5 (after the classic tabulations; indices C / d / F synthesised from n_d and
+    the Abbe number like data/dgauss11.lens): ANOTHER design family -- 7 interfaces, the stop behind the negative element,
+    steeper relative curvatures.  The back focal distance is set by lf_focus_lens (paraxial focus at infinity)."""
+    def glass(nd, V):
+        return [nd - 0.3 * (nd - 1) / V, nd, nd + 0.7 * (nd - 1) / V]
+    air, sk16, f2 = [1.0, 1.0, 1.0], glass(1.6204, 60.3), glass(1.6200, 36.4)
+    rows = [(21.25, 4.0, sk16, 8.0), (-158.6, 5.9, air, 8.0), (-20.25, 1.5, f2, 6.0), (20.25, 2.0, air, 6.0),
+            (0.0, 3.0, [0.0, 0.0, 0.0], 5.0), (141.0, 3.5, sk16, 7.0), (-17.47, 42.0, air, 7.0)]
+    return {"n": len(rows), "stop": 4, "radius": np.array([r[0] for r in rows], np.float32),
+            "thickness": np.array([r[1] for r in rows], np.float32),
+            "ior": np.array([[r[2][l] for r in rows] for l in range(3)], np.float32),
+            "semi_aperture": np.array([r[3] for r in rows], np.float32), "sensor_width_mm": 36.0}
+
+
 def draw_lens():
-    name = ["dgauss11.lens", "dgauss11.lens", "dgauss11_8lambda.lens"][int(rng.integers(3))]
-    lens = dict(pkg.load_lens_file(name))
+    name = ["dgauss11.lens", "dgauss11.lens", "dgauss11_8lambda.lens", "triplet"][int(rng.integers(4))]
+    lens = triplet() if name == "triplet" else dict(pkg.load_lens_file(name))
     how = ["as_is", "as_is", "scaled", "bent", "stop_moved"][int(rng.integers(5))]
     if how == "scaled":                               # the same design at another focal length
         k = rng.uniform(0.7, 1.4)
@@ -90,7 +105,7 @@ def draw_lens():
     return name, how, lens
 
 
-def run(N, SEED, log=sys.stderr):
+def run(N, SEED, log=sys.stderr, only=None, hook=None):
     """-> {"summary": ..., "cases": [...]}"""
     global rng
     rng = np.random.default_rng(SEED)
@@ -114,41 +129,50 @@ def run(N, SEED, log=sys.stderr):
         stride, bits = int([1, 2, 4, 8, 8][int(rng.integers(5))]), int([0, 1, 2, 4, 6, 6, 8][int(rng.integers(7))])
         rec = {"case": case, "lens": lname, "how": how, "mask": mname, "W": W, "H": H, "spp": spp, "sun": sun, "alpha": alpha,
                "block_mm": 64.0 * float(lens["sensor_width_mm"]) / W, "stride": stride, "subcell_bits": bits}
+        # every draw of the case BEFORE anything runs: a case can be replayed alone (only=[...]) from the same stream
+        focus_mm = float(rng.uniform(300.0, 5000.0)) if rng.random() < 0.3 else None
+        n_if, stop = int(lens["n"]), int(lens["stop"])
+        sel, primary = None, True
+        if rng.random() >= 0.6:
+            allp = [(j, i) for i in range(n_if) for j in range(i) if i != stop and j != stop]
+            k = int(rng.integers(1, len(allp)))
+            sel = [allp[i] for i in rng.choice(len(allp), k, replace=False)]
+            primary = bool(rng.random() < 0.7)
+        band = None
+        if rng.random() < 0.2:
+            y0 = int(rng.integers(0, H // 2)) & ~7
+            band = (y0, int(min(H, y0 + int(rng.integers(8, H)))))
+        deal = None
+        if rng.random() < 0.2:
+            per = int(rng.integers(2, 9))
+            deal = (int(rng.integers(per)), per)
+        key = int(rng.integers(1, 2 ** 40))
+        if focus_mm is not None:
+            rec["focus_mm"] = focus_mm
+        rec["pairs"] = "all" if sel is None else len(sel)
+        if only is not None and case not in only:
+            continue
         try:
             lf.set_frame(W, H)
             lf.set_aperture(pkg.APERTURE_STARBURST, mask)
             lf.set_lens(lens)
+            if lname == "triplet":
+                lf.focus_lens(0.0)                    # the sensor at the paraxial focus of an object at infinity
             if lname.endswith("8lambda.lens"):
                 lam, _ = pkg.spectral_weights(lens["lambda_nm"])
                 lf.set_lambda_rgb(lam)
-            if rng.random() < 0.3:
-                rec["focus_mm"] = float(rng.uniform(300.0, 5000.0))
-                lf.focus_lens(rec["focus_mm"])
+            if focus_mm is not None:
+                lf.focus_lens(focus_mm)
             lf.set_sun(sun, [1.0, 0.9, 0.5], alpha)
-            n_if = int(lens["n"])
-            pick = rng.random()
-            if pick < 0.6:
-                lf.set_ghost_pairs(None, True)
-                rec["pairs"] = "all"
-            else:
-                allp = [(j, i) for i in range(n_if) for j in range(i) if i != int(lens["stop"]) and j != int(lens["stop"])]
-                k = int(rng.integers(1, len(allp)))
-                sel = [allp[i] for i in rng.choice(len(allp), k, replace=False)]
-                lf.set_ghost_pairs(sel, bool(rng.random() < 0.7))
-                rec["pairs"] = k
+            lf.set_ghost_pairs(sel, primary)
             lf.set_tile_stride(stride)
             lf.set_pupil_subcells(bits)
-            if rng.random() < 0.2:
-                y0 = int(rng.integers(0, H // 2)) & ~7
-                lf.set_band(y0, int(min(H, y0 + int(rng.integers(8, H)))))
-            else:
-                lf.set_band(0, H)
-            if rng.random() < 0.2:
-                per = int(rng.integers(2, 9))
-                lf.set_row_interleave(int(rng.integers(per)), per)
-            else:
-                lf.set_row_interleave(0, 1)
-            key = int(rng.integers(1, 2 ** 40))
+            lf.set_band(*(band or (0, H)))
+            lf.set_row_interleave(*(deal or (0, 1)))
+            if hook is not None:                       # (diagnosis: the case is set up, the caller takes over)
+                hook(lf, rec, dict(spp=spp, key=key, sel=sel, primary=primary, lens=lens, mask=mask))
+                out.append(rec)
+                continue
             res = {}
             for mode in (0, 2):
                 lf.set_march_culling(mode)
@@ -170,7 +194,7 @@ def run(N, SEED, log=sys.stderr):
             print(json.dumps(rec), file=log, flush=True)
     lf.close()
     done = [r for r in out if "culled" in r]
-    summary = {"seed": SEED, "cases": N, "compared": len(done), "refused": N - len(done),
+    summary = {"seed": SEED, "cases": N, "compared": len(done), "refused": len(out) - len(done),
                "culled_kernel_ran": sum(1 for r in done if r["culled"]), "frames_differing": bad,
                "lit_rays_compared": int(sum(r["lit_rays_full"] for r in done)),
                "frames_with_light": sum(1 for r in done if r["lit_rays_full"] > 0),
