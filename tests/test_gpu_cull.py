@@ -186,7 +186,7 @@ def test_eight_wavelengths_pair_subsets_bands_and_a_pupil_target(pkg, lf, forced
 def test_table_reuse_rebuild_and_the_automatic_choice(pkg, lf):
     lens = pkg.load_lens_file("dgauss11.lens")
     mask = load_texels("pentbig500_14.png")
-    W, H, spp = 1280, 720, 64
+    W, H, spp = 1920, 1080, 256
     _setup(pkg, lf, lens, W, H, [0.03, 0.02, -1.0], 0.05, mask)
     lf.timing_reset()
     lf.timing_enable(True)
