@@ -245,7 +245,7 @@ def test_bench_frame_culled_equals_full_on_other_suns(pkg, lf):
         g1, c1, info, g0, c0 = _both(pkg, lf, spp, 0x5EED)
         assert info["culled"]
         assert np.array_equal(g1, g0) and c1["rays_hit_light"] == c0["rays_hit_light"]
-        assert c1["rays_launched"] < 0.1 * c0["rays_launched"]
+        assert c1["rays_launched"] < 0.2 * c0["rays_launched"]
         print(f"sun {sun} alpha {alpha}: started {c1['rays_launched'] / c0['rays_launched']:.4f} of the rays, "
               f"reached the scene {c1['rays_reached_scene'] / c1['rays_launched']:.3f} (full: {c0['rays_reached_scene'] / c0['rays_launched']:.3f})")
 
