@@ -9,23 +9,31 @@
 // a handful of marched rays bound where the whole box can go -- on every diaphragm of the path and in
 // direction space when it leaves the lens.
 //
-//   k_cull_prepass   one 16-lane row per (sensor block, pupil cell, path): 13 rays (a 3 x 3 grid over the cell
-//                    at the block's centre + 4 at the cell's centre towards the block's edges) are marched
-//                    WITHOUT dying on a diaphragm; after every event the row forms the footprint of the box on
-//                    that interface -- centre sample +- (largest deviation over the cell + the deviations towards
-//                    the block's edges), inflated -- and drops the box when the footprint lies wholly outside
-//                    the clear aperture (the stop: outside its housing or on closed cells of the mask's occupancy
-//                    grid); at the end the same in direction space against the sun's lobe.  A box that loses a ray to
-//                    total reflection or a missed sphere is KEPT (nothing is known about it).  Result: per
-//                    (block, cell) a 64-bit mask of the paths that may contribute.
+//   k_cull_level     the pre-pass, coarse to fine over the pupil square (levels P = 8 -> 16 -> 32 -> P_final, four
+//                    children per kept box, work lists per path): one LANE = one box (sensor block, pupil cell,
+//                    path) with its 15 rays in registers -- 13 at the middle wavelength (a 3 x 3 grid over the cell
+//                    whose corners sit on the block's corners, + the cell's centre at the block's +-x, +-y edges) and
+//                    the centre at both ends of the spectrum -- marched WITHOUT dying on a diaphragm.  After every
+//                    event the footprint of the box on that interface is a zonotope (centre + central-difference
+//                    generators along the two pupil and two sensor axes, inflated, + a measured second-order slack)
+//                    and the box is dropped when a separating axis puts it wholly outside the clear aperture (the
+//                    stop: outside its housing or on closed cells of the mask's occupancy grid); at the end the same
+//                    in direction space against the sun's lobe.  What the samples CANNOT bound is kept: a box that
+//                    lost samples to total reflection (the map is not Lipschitz next to that boundary), a box whose
+//                    samples all end unless the zonotope bound of the pass scalar stays below zero (see firmly_lost).
+//                    Result: per (block, cell) a 64-bit mask of the paths that may contribute.
 //   k_march_cull<K>  the march of exactly those paths: per wave tile and sample one scalar load tells which
 //                    paths to start; each is marched alone along its own event sequence, K wavelengths
-//                    together, WITH its Fresnel / aperture weight (almost every path that is started ends near
-//                    the lobe: the geometry-first / re-march split of k_march has nothing left to save), the
-//                    event arithmetic being lf_march_events.h's -- so a started ray is bit for bit the ray
-//                    k_march and the oracle march, and since an unstarted one contributes 0 the PIXELS are
-//                    those of the full enumeration.  Counters count what was started (the oracle follows the
+//                    together, geometry first and the Fresnel / aperture weight by a second march of the lanes that
+//                    reach the lobe, the event arithmetic being lf_march_events.h's -- so a started ray is bit for
+//                    bit the ray k_march and the oracle march, and since an unstarted one contributes 0 the PIXELS
+//                    are those of the full enumeration.  Counters count what was started (the oracle follows the
 //                    same table: oracle/lf_geo_oracle.c geo_set_cull).
+//   k_march_items<K> the same for sampling specifications without pupil sub-cells: (pixel, sample) items compacted
+//                    per path by ballot + an LDS prefix sum.
+// The bounds are second-order estimates from 15 rays with measured cushions, not proofs; what stands behind them is
+// the search for a counter-example (profiles/cull_fuzz.py, profiles/r05_march_variants.txt: an earlier, faster set of
+// rules lost lit rays on 27 of 6000 random frames and was replaced).
 //
 // No reference counterpart: the reference enumerates 13 fixed pairs per channel and draws each as one textured
 // quad (src/pathtracer/pathtracer.cpp:735-762, :452-508) -- its "cull" is that a quad covers few pixels.
@@ -191,8 +199,8 @@ __global__ __launch_bounds__(LF_CULL_WG, LF_CULL_WAVES) void k_cull_level(const 
     r[t] = Ray{X, Y, 0.0f, 0.0f, s0.dx * ns, s0.dy * ns, s0.dz * ns, 0.0f, 0.0f};
   }
   // `live`: bit t = sample t is still on the path (not lost to a missed sphere or to total reflection).  A box
-  // that has lost samples is PARTIAL: what is left of it lies next to a region where the path ends, the map
-  // is steep there, and its footprints are inflated twice as much.
+  // that has lost samples is PARTIAL: what is left of it lies next to a region where the path ends.  Lost to a missed
+  // sphere: ball footprints, inflated twice as much; lost to total reflection: not bounded at all (tir_partial).
   unsigned live = kAll;
   bool culled = !valid, keep = false, partial = false;
   bool tir_partial = false;     // some sample of the box ended by TOTAL REFLECTION: next to that boundary the refracted ray is grazing and
