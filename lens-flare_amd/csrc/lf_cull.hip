@@ -358,7 +358,8 @@ __global__ __launch_bounds__(LF_CULL_WG, LF_CULL_WAVES) void k_cull_level(const 
         const float disp = fmaxf(fabsf(v[13] - v[4]), fabsf(v[14] - v[4]));
         return v[4] + fmaf(a.geo_margin, (fabsf(ga) + fabsf(gb)) + (fabsf(gx) + fabsf(gy)), second + fmaf(2.0f, fmaxf(cross, 0.0f), a.margin * disp));
       };
-      firmly_lost = live_before == kAll && !(kind & LF_EV_STOP) && upper(pv) < -1.0e-4f;
+      // (only a box whose samples all end at THIS event asks)
+      firmly_lost = live_before == kAll && (okm & kAll) == 0u && !(kind & LF_EV_STOP) && upper(pv) < -1.0e-4f;
     }
     const Foot f = footprint(false, hit, 1e-3f);
     live &= okm;
