@@ -85,9 +85,26 @@ def triplet():
             "semi_aperture": np.array([r[3] for r in rows], np.float32), "sensor_width_mm": 36.0}
 
 
+def retrofocus():
+    """A retrofocus arrangement (negative meniscus in front of a positive group, f ~ 65 mm, 9 interfaces): a THIRD family --
+    strongly diverging front element, long paths between the groups.  Same index synthesis as the triplet."""
+    def glass(nd, V):
+        return [nd - 0.3 * (nd - 1) / V, nd, nd + 0.7 * (nd - 1) / V]
+    air, bk7, sk16, f2 = [1.0, 1.0, 1.0], glass(1.5168, 64.2), glass(1.6204, 60.3), glass(1.6200, 36.4)
+    rows = [(60.0, 2.0, bk7, 14.0), (18.0, 14.0, air, 11.0), (35.0, 5.0, sk16, 9.0), (-45.0, 3.0, air, 9.0),
+            (0.0, 3.0, [0.0, 0.0, 0.0], 5.0), (-25.0, 1.5, f2, 6.0), (30.0, 1.0, air, 6.0), (80.0, 4.0, sk16, 7.0), (-20.0, 40.0, air, 7.0)]
+    return {"n": len(rows), "stop": 4, "radius": np.array([r[0] for r in rows], np.float32),
+            "thickness": np.array([r[1] for r in rows], np.float32),
+            "ior": np.array([[r[2][l] for r in rows] for l in range(3)], np.float32),
+            "semi_aperture": np.array([r[3] for r in rows], np.float32), "sensor_width_mm": 36.0}
+
+
+FAMILIES = 4      # (run(..., families=5) adds the retrofocus; 4 keeps the stream of the recorded draws: tests ONCE_LOST)
+
+
 def draw_lens():
-    name = ["dgauss11.lens", "dgauss11.lens", "dgauss11_8lambda.lens", "triplet"][int(rng.integers(4))]
-    lens = triplet() if name == "triplet" else dict(pkg.load_lens_file(name))
+    name = ["dgauss11.lens", "dgauss11.lens", "dgauss11_8lambda.lens", "triplet", "retrofocus"][int(rng.integers(FAMILIES))]
+    lens = triplet() if name == "triplet" else retrofocus() if name == "retrofocus" else dict(pkg.load_lens_file(name))
     how = ["as_is", "as_is", "scaled", "bent", "stop_moved"][int(rng.integers(5))]
     if how == "scaled":                               # the same design at another focal length
         k = rng.uniform(0.7, 1.4)
@@ -105,10 +122,11 @@ def draw_lens():
     return name, how, lens
 
 
-def run(N, SEED, log=sys.stderr, only=None, hook=None):
+def run(N, SEED, log=sys.stderr, only=None, hook=None, families=4):
     """-> {"summary": ..., "cases": [...]}"""
-    global rng
+    global rng, FAMILIES
     rng = np.random.default_rng(SEED)
+    FAMILIES = families
     lf = pkg.LensFlare(0)
     out, bad = [], 0
     t0 = time.time()
@@ -156,7 +174,7 @@ def run(N, SEED, log=sys.stderr, only=None, hook=None):
             lf.set_frame(W, H)
             lf.set_aperture(pkg.APERTURE_STARBURST, mask)
             lf.set_lens(lens)
-            if lname == "triplet":
+            if lname in ("triplet", "retrofocus"):
                 lf.focus_lens(0.0)                    # the sensor at the paraxial focus of an object at infinity
             if lname.endswith("8lambda.lens"):
                 lam, _ = pkg.spectral_weights(lens["lambda_nm"])
@@ -205,6 +223,7 @@ def run(N, SEED, log=sys.stderr, only=None, hook=None):
 
 
 if __name__ == "__main__":
-    r = run(int(sys.argv[1]) if len(sys.argv) > 1 else 200, int(sys.argv[2]) if len(sys.argv) > 2 else 20261004)
+    r = run(int(sys.argv[1]) if len(sys.argv) > 1 else 200, int(sys.argv[2]) if len(sys.argv) > 2 else 20261004,
+            families=int(sys.argv[3]) if len(sys.argv) > 3 else 4)
     print(json.dumps(r, indent=1))
     print("SUMMARY", json.dumps(r["summary"]), file=sys.stderr)
