@@ -234,7 +234,7 @@ lf_status lf_destroy(lf_ctx* ctx) {
                   ctx->prog_dev, ctx->sun_lights_dev,
                   ctx->scene_dev.nodes, ctx->scene_dev.prims, ctx->scene_dev.normals, ctx->scene_dev.materials,
                   ctx->scene_dev.lights, ctx->env_block, ctx->probe_dev, ctx->scene_counters_dev,
-                  ctx->primary_dev, ctx->cull_dev, ctx->cull_list[0], ctx->cull_list[1], ctx->cull_counts};
+                  ctx->primary_dev, ctx->cull_dev, ctx->cull_list[0], ctx->cull_list[1], ctx->cull_counts, ctx->cull_popc_dev};
   for (void* p : ptrs) if (p) (void)hipFree(p);
   if (ctx->own_stream && ctx->stream) (void)hipStreamDestroy(ctx->stream);
   delete ctx;
