@@ -141,6 +141,8 @@ def run(N, SEED, log=sys.stderr, only=None, hook=None, families=4):
         blk = rng.uniform(0.6, 1.8)
         lens["sensor_width_mm"] = np.float32(min(48.0, blk * W / 64.0))
         spp = int([4, 9, 16, 16, 36, 50, 64, 100, 200, 256][int(rng.integers(10))]) if not big else int([4, 16][int(rng.integers(2))])
+        if os.environ.get("FUZZ_SPP"):                 # (every frame at one sample count: more rays per frame, the same stream otherwise)
+            spp = int(os.environ["FUZZ_SPP"]) if not big else min(64, int(os.environ["FUZZ_SPP"]))
         half = 0.5 * float(lens["sensor_width_mm"]) / 50.0
         sun = [float(rng.uniform(-1.1, 1.1) * half), float(rng.uniform(-1.1, 1.1) * half * H / W), -1.0]
         alpha = float(np.exp(rng.uniform(np.log(0.003), np.log(0.16))))
