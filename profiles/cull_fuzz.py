@@ -133,7 +133,7 @@ def run(N, SEED, log=sys.stderr, only=None, hook=None, families=4):
     for case in range(N):
         lname, how, lens = draw_lens()
         mname, mask = draw_mask()
-        big = rng.random() < 0.08
+        big = rng.random() < 0.08 or os.environ.get("FUZZ_BIG") == "1"      # (FUZZ_BIG=1: every frame 4K)
         W, H = [(1920, 1080), (1920, 1080), (1920, 1080), (1280, 720), (1900, 1000), (2560, 1440)][int(rng.integers(6))]
         if big:
             W, H = 3840, 2160
