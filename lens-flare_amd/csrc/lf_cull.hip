@@ -19,7 +19,7 @@
 //                    and the box is dropped when a separating axis puts it wholly outside the clear aperture (the
 //                    stop: outside its housing or on closed cells of the mask's occupancy grid); at the end the same
 //                    in direction space against the sun's lobe.  What the samples CANNOT bound is kept: a box that
-//                    lost samples to total reflection (the map is not Lipschitz next to that boundary), a box whose
+//                    lost samples (to total reflection or a missed sphere: the map is not Lipschitz at that edge), a box whose
 //                    samples all end unless the zonotope bound of the pass scalar stays below zero (see firmly_lost).
 //                    Result: per (block, cell) a 64-bit mask of the paths that may contribute.
 //   k_march_cull<K>  the march of exactly those paths: per wave tile and sample one scalar load tells which
@@ -73,7 +73,9 @@ struct CullLevelArgs {
   float sx, sy, rho;       // the sun's direction (x, y) and the lobe's radius in direction space
   float margin;            // footprint inflation at this level
   float geo_margin;        // ... of the zonotope's generators alone (experiments: LF_CULL_GEO_MARGIN)
-  int strict;              // footprint tests: 0 every box, 1 only boxes with EVERY sample alive, 2 not for boxes that lost samples to total reflection
+  int strict;              // footprint tests: 0 every box, 1 (shipped) only boxes with EVERY sample alive, 2 not for boxes that lost samples to
+                           // total reflection (a missed sphere has the same square-root edge: two frames of a harsher random draw, wide
+                           // suns on a perturbed 8-wavelength prescription, lost 19 and 213 lit rays under 2)
   int strict_lost;         // "all samples end here" by a scalar zonotope bound instead of the range rule
   float lobe_k;            // the footprint in direction space once more inflated for the lobe test (third order: a small lobe sees it)
   int slack_mode;          // experiments: LF_CULL_SLACK (1: second order summed over the four axes + twice the corners' cross terms)
@@ -199,8 +201,9 @@ __global__ __launch_bounds__(LF_CULL_WG, LF_CULL_WAVES) void k_cull_level(const 
     r[t] = Ray{X, Y, 0.0f, 0.0f, s0.dx * ns, s0.dy * ns, s0.dz * ns, 0.0f, 0.0f};
   }
   // `live`: bit t = sample t is still on the path (not lost to a missed sphere or to total reflection).  A box
-  // that has lost samples is PARTIAL: what is left of it lies next to a region where the path ends.  Lost to a missed
-  // sphere: ball footprints, inflated twice as much; lost to total reflection: not bounded at all (tir_partial).
+  // that has lost samples is PARTIAL: what is left of it lies next to a region where the path ends -- total reflection or
+  // the rim of a sphere, either way a square-root edge where the map is not Lipschitz -- and is not bounded by the samples
+  // left: no footprint test drops it (strict = 1; the ball footprints below serve strict = 0 / 2, experiments).
   unsigned live = kAll;
   bool culled = !valid, keep = false, partial = false;
   bool tir_partial = false;     // some sample of the box ended by TOTAL REFLECTION: next to that boundary the refracted ray is grazing and
@@ -1035,7 +1038,7 @@ lf_status lfk_cull_prepass(lf_ctx* ctx, int G, int spp) {
   a.keep_partial = std::getenv("LF_CULL_KEEP_PARTIAL") ? std::atoi(std::getenv("LF_CULL_KEEP_PARTIAL")) : 0;
   a.lost_rel = std::getenv("LF_CULL_LOST_REL") ? (float)std::atof(std::getenv("LF_CULL_LOST_REL")) : 0.5f;
   a.lost_abs = std::getenv("LF_CULL_LOST_ABS") ? (float)std::atof(std::getenv("LF_CULL_LOST_ABS")) : 0.002f;
-  a.strict = std::getenv("LF_CULL_STRICT") ? std::atoi(std::getenv("LF_CULL_STRICT")) : 2;
+  a.strict = std::getenv("LF_CULL_STRICT") ? std::atoi(std::getenv("LF_CULL_STRICT")) : 1;
   a.lobe_k = std::getenv("LF_CULL_LOBE_K") ? (float)std::atof(std::getenv("LF_CULL_LOBE_K")) : 1.2f;
   a.strict_lost = std::getenv("LF_CULL_STRICT_LOST") ? std::atoi(std::getenv("LF_CULL_STRICT_LOST")) : 1;
   a.slack_mode = std::getenv("LF_CULL_SLACK") ? std::atoi(std::getenv("LF_CULL_SLACK")) : 1;

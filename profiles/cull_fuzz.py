@@ -99,6 +99,7 @@ def retrofocus():
             "semi_aperture": np.array([r[3] for r in rows], np.float32), "sensor_width_mm": 36.0}
 
 
+HARSH = os.environ.get("FUZZ_HARSH") == "1"     # wider perturbations of the prescriptions, wider suns (the same number of draws)
 FAMILIES = 4      # (run(..., families=5) adds the retrofocus; 4 keeps the stream of the recorded draws: tests ONCE_LOST)
 
 
@@ -107,16 +108,17 @@ def draw_lens():
     lens = triplet() if name == "triplet" else retrofocus() if name == "retrofocus" else dict(pkg.load_lens_file(name))
     how = ["as_is", "as_is", "scaled", "bent", "stop_moved"][int(rng.integers(5))]
     if how == "scaled":                               # the same design at another focal length
-        k = rng.uniform(0.7, 1.4)
+        k = rng.uniform(0.5, 2.0) if HARSH else rng.uniform(0.7, 1.4)
         for key in ("radius", "thickness", "semi_aperture"):
             lens[key] = (np.asarray(lens[key], np.float32) * np.float32(k)).astype(np.float32)
     elif how == "bent":                               # every curvature off by up to 3 %: another aberration balance
         r = np.asarray(lens["radius"], np.float32).copy()
-        r *= (1.0 + rng.uniform(-0.03, 0.03, r.shape)).astype(np.float32)
+        b = 0.08 if HARSH else 0.03
+        r *= (1.0 + rng.uniform(-b, b, r.shape)).astype(np.float32)
         lens["radius"] = r
     elif how == "stop_moved":                         # the diaphragm 1 mm towards the front or the rear group
         t = np.asarray(lens["thickness"], np.float32).copy()
-        s, d = int(lens["stop"]), np.float32(rng.uniform(-1.0, 1.0))
+        s, d = int(lens["stop"]), np.float32(rng.uniform(-2.5, 2.5) if HARSH else rng.uniform(-1.0, 1.0))
         t[s - 1] += d; t[s] -= d
         lens["thickness"] = t
     return name, how, lens
@@ -145,7 +147,7 @@ def run(N, SEED, log=sys.stderr, only=None, hook=None, families=4):
             spp = int(os.environ["FUZZ_SPP"]) if not big else min(64, int(os.environ["FUZZ_SPP"]))
         half = 0.5 * float(lens["sensor_width_mm"]) / 50.0
         sun = [float(rng.uniform(-1.1, 1.1) * half), float(rng.uniform(-1.1, 1.1) * half * H / W), -1.0]
-        alpha = float(np.exp(rng.uniform(np.log(0.003), np.log(0.16))))
+        alpha = float(np.exp(rng.uniform(np.log(0.003), np.log(0.3 if HARSH else 0.16))))
         stride, bits = int([1, 2, 4, 8, 8][int(rng.integers(5))]), int([0, 1, 2, 4, 6, 6, 8][int(rng.integers(7))])
         rec = {"case": case, "lens": lname, "how": how, "mask": mname, "W": W, "H": H, "spp": spp, "sun": sun, "alpha": alpha,
                "block_mm": 64.0 * float(lens["sensor_width_mm"]) / W, "stride": stride, "subcell_bits": bits}
