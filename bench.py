@@ -815,8 +815,10 @@ def main():
         if pmc:
             same = pmc.get("source_sha") == source_sha()
             roof["pmc_matches_shipped_sources"] = same
-            vi = pmc["valu_wave_instr_per_executed_event"]
-            si = pmc["scalar_instr_per_executed_event"]
+            # (a record of a configuration whose launch took the other kernel holds no counters of this one: priced as absent)
+            vi = pmc.get("valu_wave_instr_per_executed_event")
+            si = pmc.get("scalar_instr_per_executed_event")
+        if pmc and vi and si:
             roof["achieved"] = ev_rate_gpu * vi
             roof["frac"] = roof["achieved"] / VALU_PEAK
             roof["frac_of_practical"] = roof["achieved"] / VALU_PRACTICAL

@@ -404,7 +404,7 @@ struct lf_ctx {
   // weight, the tree shares legs and lets rays die early (measured crossover on the 1080p frame: a sun of 0.2 rad
   // starts 17 % and ties, profiles/r05_march_variants.txt).  lf_set_march_culling's mode stays what it is; the
   // launch just takes the other kernel.
-  double cull_max_fraction = 0.12;
+  double cull_max_fraction = 0.10;             // + 1.6 / paths: see lfk_march
   uint64_t cull_hash = 0;                      // of the inputs the resident table was built from (0 = none)
   int cull_bx = 0, cull_by = 0, cull_cells = 0, cull_G = 0, cull_P = 0, cull_blk_log2 = 6;
   float cull_margin = 1.25f;                   // footprint inflation of the pre-pass (LF_CULL_MARGIN: experiments)

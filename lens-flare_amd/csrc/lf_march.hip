@@ -1265,7 +1265,11 @@ lf_status lfk_march(lf_ctx* ctx, int spp, uint64_t key) {
     lf_status st = lfk_cull_prepass(ctx, a.G, spp);
     if (st != LF_OK) return st;
     // a table that starts most of everything (a very wide sun, a handful of samples): the path tree is faster
-    if (ctx->cull_started_fraction > ctx->cull_max_fraction && !std::getenv("LF_CULL_FORCE")) ctx->last_march_culled = false;
+    // Where the two kernels meet: the path tree executes ~(22 + 1.4 n) events per sample and wavelength for n paths
+    // (shared legs: 85 at n = 46, 53 at n = 21), the culled march ~10.5 per STARTED path plus a pre-pass worth 0.3 of
+    // its time -- equal at a started fraction of 0.10 + 1.6 / n (0.135 at 46 paths, 0.18 at 21: measured on c3 / c2).
+    const double meet = std::min(0.5, ctx->cull_max_fraction + 1.6 / (double)std::max(1, ctx->pairs.n));
+    if (ctx->cull_started_fraction > meet && !std::getenv("LF_CULL_FORCE")) ctx->last_march_culled = false;
   }
   if (ctx->last_march_culled) {
     lf_status st = lfk_march_culled(ctx, a, blocks, dyn_lds);
