@@ -345,3 +345,22 @@ def test_the_frames_that_once_lost_lit_rays(pkg, forced):
     assert s["compared"] == len(ONCE_LOST) and s["culled_kernel_ran"] == len(ONCE_LOST)
     assert s["frames_differing"] == 0, [c for c in r["cases"] if c.get("BAD")]
     assert sum(1 for c in r["cases"] if c["lens"] == "triplet") == 23
+
+
+def test_the_frames_past_a_spheres_rim(pkg, forced):
+    """... and the two of the harsher draw (FUZZ_HARSH=1 profiles/cull_fuzz.py 4000 1234567 5: suns of 10 and 15 degrees on
+    perturbed 8-wavelength prescriptions, tables that start 27 %): boxes that had lost samples past a sphere's rim, bounded by
+    the samples left, dropped with 213 and 19 lit rays.  A box that lost any sample is bounded by nothing now."""
+    import os
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "profiles"))
+    import cull_fuzz
+    was = cull_fuzz.HARSH
+    cull_fuzz.HARSH = True
+    try:
+        r = cull_fuzz.run(3331, 1234567, log=None, only={3328, 3330}, families=5)
+    finally:
+        cull_fuzz.HARSH = was
+    s = r["summary"]
+    assert s["compared"] == 2 and s["culled_kernel_ran"] == 2 and s["frames_differing"] == 0, r["cases"]
+    assert all(c["lens"] == "dgauss11_8lambda.lens" and c["alpha"] > 0.15 and c["lit_rays_full"] > 5e8 for c in r["cases"])
