@@ -265,8 +265,10 @@ def cpu_baseline(config, W, H, target_s):
                       f"oracle/lf_geo_oracle.c; the reference has no geometric lens to time"}
 
 
-def reference_flare_path(pkg, budget_s):
-    """Side data (never `value`): the REAL reference's own CPU renderer (oracle/_ref/ref_dump, the
+def reference_flare_path(pkg, budget_s, gpu_leg=True):
+    """gpu_leg=False: the CPU runs only (child processes of the reference's binary: started BEFORE this process
+    touches the GPU); reference_flare_path_gpu adds the device's frame later.
+    Side data (never `value`): the REAL reference's own CPU renderer (oracle/_ref/ref_dump, the
     reference hot path compiled from its own sources) per BASELINE.md section 3 -- the 1080p frame with
     final_apertures/pentbig500_14.png (340x350 bbox: a crop, the whole frame is ~4 core-hours) and
     with apertures/pentbiglines.png (80x78 bbox), on 1 thread and on all host cores (the reference's
@@ -329,7 +331,21 @@ def reference_flare_path(pkg, budget_s):
                           "tN": {"threads": cores, "pixels": nn, "seconds": tn, "terms_per_s": nn * bbox / tn,
                                  "whole_1080p_frame_s_extrapolated": tn * W * H / nn}})
         out["frames"] = cases
-        # the same 1080p frame (paraxial ghosts + starburst + falloff + compose) through the C ABI
+        out["_gpu_args"] = (W, H, hf, vf, light)
+        if gpu_leg:
+            reference_flare_path_gpu(pkg, out)
+        return out
+    except Exception as e:  # noqa: BLE001
+        out["error"] = str(e)
+        return out
+
+
+def reference_flare_path_gpu(pkg, out):
+    """the same 1080p frame (paraxial ghosts + starburst + falloff + compose) through the C ABI"""
+    if not out or "_gpu_args" not in out:
+        return out
+    W, H, hf, vf, light = out.pop("_gpu_args")
+    try:
         lf = pkg.LensFlare(0)
         lf.set_frame(W, H)
         lf.set_params(1, 25.0, 1.0)
@@ -386,14 +402,23 @@ def main():
         # torch.cuda nor made any HIP call, and it never execs.
         raise SystemExit(sharding.self_launch(os.path.abspath(__file__), sys.argv[1:], args.gpus))
 
-    import torch
-    import torch.distributed as dist
-
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
     if args.gpus > 1 and world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: the launcher's rank count and --gpus must agree")
+    # The CPU legs (the oracle's pinned child processes, the real reference's binary) run BEFORE this process makes its
+    # first GPU call: fresh children of a process without HIP / ROCr / gloo threads competing with their pinned teams --
+    # and never from under a profiler's preload (rocprofv3 initialises the GPU in every process it preloads into).
+    cpu, ref_path = None, None
+    profiled = any(k.startswith("ROCPROFILER_") or k.startswith("ROCPROF_") for k in os.environ) or \
+        "rocprof" in os.environ.get("LD_PRELOAD", "")
+    if rank == 0 and world == 1 and not args.no_cpu and not profiled:
+        cpu = cpu_baseline(args.config, W, H, args.cpu_seconds)
+        ref_path = reference_flare_path(pkg, args.ref_seconds, gpu_leg=False)
+
+    import torch
+    import torch.distributed as dist
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the hot path has no CPU fallback")
     # Control plane (rendezvous, the RCCL id, barriers, the final sums): torch.distributed over gloo.
@@ -411,11 +436,11 @@ def main():
     rehearsal = os.environ.get("LF_BENCH_REHEARSAL") == "1" or rehearsal_rccl
     # LF_BENCH_SOLO_COMM=1 (tests): ONE rank goes through everything N ranks go through -- gloo control plane, the
     # C ABI's communicator (RCCL forms one of a single rank), the first exchange under its deadline, the shared cull
-    # table's all-gather and the frame's -- with LF_COMM_FORCE_EXCHANGE making the library run its collectives even
+    # table's all-gather and the frame's -- with the test knob comm_force_exchange making the library run its collectives even
     # so.  What a one-GPU box can rehearse of `bench.py --gpus N` beyond the fallbacks of LF_BENCH_REHEARSAL.
     solo = world == 1 and os.environ.get("LF_BENCH_SOLO_COMM") == "1"
     if solo:
-        os.environ["LF_COMM_FORCE_EXCHANGE"] = "1"
+        pkg.test_knob_default("comm_force_exchange", 1)     # (the library's collectives run with one rank as well)
     multi = world > 1 or solo
     gather_mode = "none" if not multi else ("cabi" if rehearsal_rccl else "host" if rehearsal
                                             else os.environ.get("LF_BENCH_GATHER", "cabi"))
@@ -446,10 +471,8 @@ def main():
     sun = sun_direction(lens, efl, W, H)
     pairs = pair_list(lens, cfg["pairs"])
 
-    cpu, ref_path = None, None
-    if rank == 0 and world == 1 and not args.no_cpu:
-        cpu = cpu_baseline(args.config, W, H, args.cpu_seconds)
-        ref_path = reference_flare_path(pkg, args.ref_seconds)
+    if ref_path is not None:
+        reference_flare_path_gpu(pkg, ref_path)        # (the device's frame beside the reference's CPU runs above)
 
     lf = pkg.LensFlare(local)
     lf.set_frame(W, H)
@@ -679,6 +702,9 @@ def main():
 
     cnt = lf.counters()
     stats = lf.march_stats()
+    audit = lf.cull_audit()                      # what the timed frames' cull tables dropped, sampled (lf_set_cull_audit)
+    n_audit, audit_ms = lf.timing_get("cull_audit")
+    cull_reason = lf.cull_reason()
     # other sampling specifications, timed beside the default (N = 1 only, outside the timed region).  The
     # default since round 4: 64 x 64 pupil sub-cells per stratum shared by a wave whose pixel columns are 8
     # apart (tile correlation 7.4; profiles/r04_tile_stride.json).  Rounds 1-3: 4 x 4 sub-cells over 8 x 8
@@ -711,21 +737,29 @@ def main():
                                                                "tile_correlation": {"value": 7.4, "recorded_in": "profiles/r04_tile_stride.json"}}
         # the same frame without the cull (identical pixels): every sample marches every path through the path tree
         # (the round-4 frame), and with the cull table kept between frames
+        culled_frame = lf.read_buffer(pkg.GHOST_BUFFER) if cull_mode != 0 else None     # (the default frame, as just timed)
         for name, mode in (("full_enumeration_path_tree", 0), ("culled_table_reused", 1)):
             if mode != cull_mode:
                 lf.set_march_culling(mode)
                 ms_v, ev_v = timed_variant()
                 sampling_variants[name] = {"ms_per_step": ms_v, "executed_events_per_s": ev_v / (ms_v * 1e-3),
                                            "executed_events_per_frame": ev_v}
+                if mode == 0 and culled_frame is not None:
+                    # THIS run's comparison: the culled frame against the full enumeration of the same samples
+                    full_frame = lf.read_buffer(pkg.GHOST_BUFFER)
+                    sampling_variants[name]["culled_frame_values_differing"] = int((full_frame != culled_frame).sum())
+                    sampling_variants[name]["lit_values"] = int((full_frame > 0).sum())
+                    del full_frame
+        del culled_frame
         lf.set_march_culling(cull_mode)
         if cull_mode != 0 and lf.cull_info()["culled"]:
             # SURVEY 8d's unit event (intersect + refract / reflect + Fresnel) on EVERY executed event: k_march_cull<K, true>,
             # the same pixels (tests/test_gpu_cull.py::test_weight_on_every_event_is_the_same_frame), timed by this run
-            os.environ["LF_CULL_WEIGHTS_FIRST"] = "1"
+            lf.test_knob("cull_weights_first", 1)
             try:
                 ms_v, ev_v = timed_variant()
             finally:
-                del os.environ["LF_CULL_WEIGHTS_FIRST"]
+                lf.test_knob("cull_weights_first", 0)
             sampling_variants["every_event_weighted"] = {"ms_per_step": ms_v, "executed_events_per_s": ev_v / (ms_v * 1e-3),
                                                          "executed_events_per_frame": ev_v}
         sampling_variants["note"] = ("tile_correlation = 64 Var(mean of 8 x 8 adjacent pixels) / mean pixel variance on this frame "
@@ -892,21 +926,32 @@ def main():
             # inside the sun's lobe per second of the WHOLE frame.  equal_variance: the culled frame's pixels are the
             # round-4 default's bit for bit (same estimator, same samples), so its variance ratio is exactly 1 and
             # the frame time at equal variance is the frame time.
-            "culling": {"mode": cull_mode, "culled": cull_info["culled"], "prepass_shared_between_ranks": cull_share,
+            "culling": {"mode": cull_mode, "culled": cull_info["culled"], "reason": cull_reason,
+                        "prepass_shared_between_ranks": cull_share,
                         "prepass_ms_per_frame": cull_ms / args.steps, "prepass_builds": n_cull,
                         "started_fraction": cull_frac,
                         "table": {k: cull_info[k] for k in ("blocks_x", "blocks_y", "cells", "G", "P", "block_px")},
-                        "note": "started_fraction = of all (64 x 64 pixel block, pupil cell, path) combinations, the part the march starts; "
-                                "ghost_buffer is bit-identical to the full enumeration (tests/test_gpu_cull.py)"},
+                        # the audit of every table the timed frames built: rays of the boxes the table does NOT start,
+                        # marched with the march's events; one that reaches the light refutes the table (the launch then
+                        # marches everything).  Inside ms_per_step.
+                        "audit": {"rays_per_frame": audit["rays"] / args.steps, "lit": audit["lit"],
+                                  "launches_refuted": audit["launches_refuted"], "ms_per_frame": audit_ms / args.steps,
+                                  "launches": n_audit},
+                        "note": "started_fraction = of all (block, pupil cell, path) combinations, the part the march starts; the "
+                                "pre-pass bounds are second-order estimates (DESIGN.md section 5), compared with the full enumeration "
+                                "in tests/test_gpu_cull.py and, for this run's frame, under equal_variance below"},
             "light": {"rays_reaching_scene_per_s": fate_tot["rays_reached_scene"] / dt,
                       "rays_hitting_light_per_s": fate_tot["rays_hit_light"] / dt,
                       "reached_scene_fraction_of_started": fate_tot["rays_reached_scene"] / fate_tot["rays_launched"] if fate_tot["rays_launched"] else None,
                       "hit_light_fraction_of_started": fate_tot["rays_hit_light"] / fate_tot["rays_launched"] if fate_tot["rays_launched"] else None},
             "equal_variance": None if args.config != "c3" or world != 1 else {
-                "variance_ratio_vs_r04_default_at_equal_spp": 1.0,
+                # 1.0 only where THIS run compared the culled frame with the full enumeration of the same samples and found
+                # no value differing (sampling_variants.full_enumeration_path_tree); None where it did not compare (--no-cpu)
+                "variance_ratio_vs_r04_default_at_equal_spp": 1.0 if (sampling_variants or {}).get("full_enumeration_path_tree", {}).get("culled_frame_values_differing") == 0 else None,
+                "culled_frame_values_differing_this_run": (sampling_variants or {}).get("full_enumeration_path_tree", {}).get("culled_frame_values_differing"),
                 "ms_per_frame_equal_variance": dt / args.steps * 1e3,
                 "r04_ms_per_frame": R04_C3_MS, "ratio_to_r04": dt / args.steps * 1e3 / R04_C3_MS,
-                "basis": "identical pixels: the cull removes only paths that contribute exactly 0 (same samples, same arithmetic)",
+                "basis": "the culled frame's pixels against the full enumeration's, compared by this run (same samples, same arithmetic)",
                 # the events the SAME frame costs when every sample marches every path (this run's path-tree leg), per
                 # second of the shipped frame: the rate at which the full enumeration's work is disposed of -- for
                 # comparison with round 4's `value` only, it is NOT `value` (which counts executed events)

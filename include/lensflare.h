@@ -483,14 +483,22 @@ lf_status lf_trace_ghosts(lf_ctx* ctx, int spp, uint64_t key);
 /* PATH CULLING (round 5; no reference counterpart -- the reference enumerates 13 fixed pairs per channel and
  * draws each as one quad, pathtracer.cpp:735-762, :452-508).  lf_trace_ghosts does not start a path where it
  * cannot carry light: a pre-pass bounds, for every block of 64 x 64 sensor pixels (128 x 128 where that is still
- * <= 1.25 mm on the sensor and the launch has few samples: 4K below 256 spp x 3 wavelengths), every cell of the pupil square and every selected path, where the rays of that 4-D box can go -- on each diaphragm of the path and in
- * direction space at the exit -- and the march starts only the paths whose box may end inside the sun's lobe.
- * A path that is not started would have contributed exactly 0, so ghost_buffer is the buffer of the full
- * enumeration BIT FOR BIT; lf_counters / lf_get_executed_events count the rays that were started.
+ * <= 1.25 mm on the sensor and the launch has few samples: 4K below 256 spp x 3 wavelengths; 32 or 16 where 64 pixels
+ * are more than 1.8 mm: frames narrower than 1280 pixels on 36 mm), every cell of the pupil square and every selected
+ * path, where the rays of that 4-D box can go -- on each diaphragm of the path and in direction space at the exit --
+ * and the march starts only the paths whose box may end inside the sun's lobe.  A path that is not started adds
+ * exactly 0 IF the bound is right, and then ghost_buffer is the buffer of the full enumeration bit for bit.
+ * WHAT STANDS BEHIND THE BOUND: it is a second-order estimate from 15 marched rays per box (DESIGN.md section 5 states the
+ * assumption: the third order of the bundle's map is small against the measured second order away from the edges
+ * where a ray ends, and boxes touching such an edge are never dropped), checked against the full enumeration on whole
+ * frames and on 39 000 random frames of three design families (double Gauss, Cooke triplet, their 8-wavelength forms:
+ * scaled 0.5 .. 2, bent 8 %, refocused, suns of 0.17 .. 17 degrees over the field, blocks of 0.6 .. 1.8 mm) -- and, on
+ * EVERY launch, audited: lf_set_cull_audit below.  A host that wants the enumeration itself: mode 0.
+ * lf_counters / lf_get_executed_events count the rays that were started.
  *   mode 1 (default): on; the table is reused while lens, pairs, sun, frame, pupil disc, mask and sample
  *                     count are unchanged.   2: on, rebuilt at every lf_trace_ghosts.
  *   mode 0: off -- every sample marches every selected path (rounds 1-4; the shared-leg path tree).
- * Applies to at most 64 paths and 4096 samples per pixel; beyond, lf_trace_ghosts marches everything.
+ * Applies to at most 128 paths and 4096 samples per pixel; beyond, lf_trace_ghosts marches everything (lf_get_cull_reason says why).
  * lf_get_cull_info: {mode, did the last lf_trace_ghosts cull, blocks_x, blocks_y, cells per block (the pupil
  * strata G x G), G, pre-pass cells per axis, block size in pixels}.  lf_get_cull_table: the masks the last
  * launch used, [blocks_y * blocks_x][cells + 1] (block side = info[7] pixels; bit q = path q of the selection in lf_set_ghost_pairs order,
@@ -504,6 +512,46 @@ lf_status lf_get_cull_table(lf_ctx* ctx, uint64_t* out, size_t n_entries);
  * shares legs and lets rays die early; the culled march starts each path alone): a very wide sun or a handful of
  * samples per pixel. */
 lf_status lf_get_cull_started_fraction(lf_ctx* ctx, double* fraction);
+/* WHY the last lf_trace_ghosts did, or did not, cull (informational: lf_trace_ghosts returns LF_OK either way and the
+ * pixels are the same -- what changes is the time: the path tree marches every path of every sample). */
+typedef enum {
+  LF_CULL_APPLIED = 0,              /* the culled march ran */
+  LF_CULL_OFF = 1,                  /* lf_set_march_culling(0) */
+  LF_CULL_NO_STOP = 2,              /* the prescription has no stop: nothing bounds a pupil cell */
+  LF_CULL_TOO_MANY_PATHS = 3,       /* more than 128 selected paths */
+  LF_CULL_TOO_MANY_SAMPLES = 4,     /* more than 4096 samples per pixel (64 x 64 strata) */
+  LF_CULL_BLOCK_TOO_LARGE = 5,      /* even a block of 16 x 16 pixels is more than 1.8 mm on this sensor */
+  LF_CULL_TABLE_TOO_FULL = 6,       /* the table starts more than 0.10 + 1.6 / paths of everything: the path tree is faster */
+  LF_CULL_AUDIT_REFUTED = 7,        /* an audit ray of a dropped box reached the light: the table was not used (see below) */
+  LF_CULL_DISPERSION = 8            /* the index columns are not monotonic in the wavelength: the two ends of the spectrum
+                                       do not bracket what lies between, the pre-pass's dispersion bound does not hold */
+} lf_cull_reason;
+lf_status lf_get_cull_reason(lf_ctx* ctx, int* reason);
+/* THE AUDIT.  The pre-pass's bounds are second-order estimates from 15 rays per box: conservative on every
+ * frame anyone has compared with the full enumeration, but not a proof.  Every table is therefore checked where it is
+ * used: for each (block, cell, path) combination it does NOT start, `rays_per_dropped_box` rays of that box (a random
+ * point of the block, a random point of the pupil cell, one of the launch's wavelengths) are marched with the march's
+ * own events; one that ends inside the sun's lobe refutes the table -- the launch marches every path of every sample
+ * instead (same pixels as always, the path tree's time), lf_get_cull_reason says LF_CULL_AUDIT_REFUTED and the counters
+ * below say how often.  Default 1 ray (0.9 ms on the 1080p bench frame); 0 switches the audit off.
+ * lf_get_cull_audit: rays marched / rays that reached the light / launches refuted, since lf_reset_counters. */
+lf_status lf_set_cull_audit(lf_ctx* ctx, int rays_per_dropped_box);
+lf_status lf_get_cull_audit(lf_ctx* ctx, uint64_t* rays, uint64_t* lit, int* launches_refuted);
+/* TEST HOOK -- not for hosts.  The switches the test suite and bench.py's A/B legs need, by name (no environment
+ * variable changes what this library computes):
+ *   "cull_force" 0/1            keep the culled march whatever the table starts (small test frames)
+ *   "cull_weights_first" 0/1    the Fresnel / mask weight on EVERY executed event (SURVEY 8d's unit), same pixels
+ *   "cull_general_kernel" 0/1   build the table with the kernel that takes its rules as arguments (must give the shipped one's table)
+ *   "cull_strict", "cull_strict_lost", "cull_slack", "cull_keep_partial", "cull_disable", "cull_margin", "cull_lobe_k",
+ *   "cull_lost_rel", "cull_lost_abs"   the pre-pass rules round 5 REPLACED (they lose lit rays on some prescriptions:
+ *                               what the audit is shown to catch, tests/test_gpu_cull.py)
+ *   "scene_compact" -1/0/1      k_scene_lens's ray compaction: by the tree's size / off / on
+ *   "scene_lens_strided" -1/0/1 k_scene_lens's wave tile: by the tree's size / 8 x 8 neighbours / the march's strided tile
+ *   "bvh_median" 0/1, "bvh_leaf" 1..4   the scene tree of the next lf_set_scene: median splits (round 2), primitives per leaf
+ *   "comm_force_exchange" 0/1   run the collectives with a single rank as well
+ * Unknown names are refused.  ctx == NULL: the value becomes the default of every context created afterwards (a
+ * test that cannot reach the contexts a helper creates); 0 takes the default away. */
+lf_status lf_test_knob(lf_ctx* ctx, const char* name, double value);
 /* THE PRE-PASS OF A MULTI-GPU FRAME, SHARED.  The table covers the whole frame (a block of 64 sensor rows holds tile
  * rows of every rank), so N ranks that each build all of it spend the same time on it as one GPU does: the part of a
  * frame that does not shrink with N.  Shared, rank r builds the rows of the blocks b with b % N == r (dealt round

@@ -35,7 +35,7 @@ ABI_SYMBOLS = [
     "lf_set_direct_hemisphere_sample", "lf_collada_check", "lf_render_scene_term",
     "lf_generate_ghost_buffer", "lf_render_flare_layer", "lf_read_tile", "lf_read_pixel",
     "lf_write_to_framebuffer", "lf_save_image_rgba", "lf_device_buffer", "lf_set_lens", "lf_set_lambda_rgb", "lf_set_sun",
-    "lf_set_sun_from_flares", "lf_paraxial_efl", "lf_paraxial_image_scale", "lf_set_ghost_pairs", "lf_set_pupil_subcells", "lf_set_tile_stride", "lf_trace_ghosts", "lf_set_march_culling", "lf_get_cull_info", "lf_get_cull_table", "lf_get_cull_started_fraction", "lf_comm_share_cull", "lf_set_cull_share", "lf_cull_prepare", "lf_cull_table_view", "lf_cull_commit", "lf_get_march_fix_bits", "lf_generate_lens_rays", "lf_get_counters", "lf_reset_counters", "lf_get_executed_events", "lf_get_march_stats", "lf_native_sqrt", "lf_native_rcp", "lf_set_starburst_spectrum", "lf_load_collada", "lf_march_tables",
+    "lf_set_sun_from_flares", "lf_paraxial_efl", "lf_paraxial_image_scale", "lf_set_ghost_pairs", "lf_set_pupil_subcells", "lf_set_tile_stride", "lf_trace_ghosts", "lf_set_march_culling", "lf_get_cull_info", "lf_get_cull_table", "lf_get_cull_started_fraction", "lf_get_cull_reason", "lf_set_cull_audit", "lf_get_cull_audit", "lf_test_knob", "lf_comm_share_cull", "lf_set_cull_share", "lf_cull_prepare", "lf_cull_table_view", "lf_cull_commit", "lf_get_march_fix_bits", "lf_generate_lens_rays", "lf_get_counters", "lf_reset_counters", "lf_get_executed_events", "lf_get_march_stats", "lf_native_sqrt", "lf_native_rcp", "lf_set_starburst_spectrum", "lf_load_collada", "lf_march_tables",
     "lf_timing_enable", "lf_timing_reset", "lf_timing_get",
     "lf_clear_ghost_buffer", "lf_draw_ghost", "lf_rasterize_textured_triangle", "lf_fill_textured_pixel",
     "lf_shift_vertex", "lf_compute_phase", "lf_irradiance_falloff", "lf_scene_trace_ray", "lf_scene_shade",
@@ -49,6 +49,16 @@ ABI_SYMBOLS = [
     "lf_group_create", "lf_group_destroy", "lf_group_size", "lf_group_ctx", "lf_group_last_error",
     "lf_group_set_frame", "lf_group_for_each", "lf_group_gather", "lf_group_share_cull",
 ]
+
+
+def test_knob_default(name, value):
+    """TEST HOOK: lf_test_knob(NULL, ...) -- the knob's value for every context created from now on (0: none)"""
+    st = load_library().lf_test_knob(None, name.encode(), C.c_double(float(value)))
+    if st != 0:
+        raise LensFlareError(st, "lf_test_knob")
+
+
+test_knob_default.__test__ = False      # (not a test, whatever pytest thinks of the name)
 
 
 def paraxial_exit_pupil(lens, lam=None):
@@ -621,7 +631,31 @@ class LensFlare:
     def cull_info(self):
         v = (C.c_int * 8)()
         self._ck(self.lib.lf_get_cull_info(self.ctx, v))
-        return dict(mode=v[0], culled=bool(v[1]), blocks_x=v[2], blocks_y=v[3], cells=v[4], G=v[5], P=v[6], block_px=v[7])
+        return dict(mode=v[0], culled=bool(v[1]), blocks_x=v[2], blocks_y=v[3], cells=v[4], G=v[5], P=v[6], block_px=v[7],
+                    reason=self.cull_reason())
+
+    CULL_REASONS = ("applied", "off", "no_stop", "too_many_paths", "too_many_samples", "block_too_large", "table_too_full",
+                    "audit_refuted", "dispersion_not_monotonic")
+
+    def cull_reason(self):
+        """why the last trace_ghosts did (not) cull: one of CULL_REASONS (lf_cull_reason)"""
+        r = C.c_int()
+        self._ck(self.lib.lf_get_cull_reason(self.ctx, C.byref(r)))
+        return self.CULL_REASONS[r.value]
+
+    def set_cull_audit(self, rays_per_dropped_box=1):
+        """rays marched per (block, cell, path) combination the cull table does not start (0 = no audit)"""
+        self._ck(self.lib.lf_set_cull_audit(self.ctx, int(rays_per_dropped_box)))
+
+    def cull_audit(self):
+        """{rays, lit, launches_refuted} since reset_counters: the audit of what the cull tables dropped"""
+        r, l, n = C.c_uint64(), C.c_uint64(), C.c_int()
+        self._ck(self.lib.lf_get_cull_audit(self.ctx, C.byref(r), C.byref(l), C.byref(n)))
+        return dict(rays=r.value, lit=l.value, launches_refuted=n.value)
+
+    def test_knob(self, name, value):
+        """TEST HOOK (lensflare.h lf_test_knob): the suite's and the bench's A/B switches, by name"""
+        self._ck(self.lib.lf_test_knob(self.ctx, name.encode(), C.c_double(float(value))))
 
     def cull_started_fraction(self):
         f = C.c_double(0.0)

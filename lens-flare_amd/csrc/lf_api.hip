@@ -72,7 +72,7 @@ void lf_timing_end(lf_ctx* ctx, int kernel, hipEvent_t start, hipStream_t stream
 namespace {
 
 const char* kKernelNames[LFK_COUNT] = {"march", "flare_layer", "ghost_raster", "dft",
-                                       "frame_setup", "tonemap", "exchange", "scene_term", "cull_prepass"};
+                                       "frame_setup", "tonemap", "exchange", "scene_term", "cull_prepass", "cull_audit"};
 
 // the reference's hard-coded prescription (pathtracer.cpp:541-556); literals narrowed to float
 // where the reference narrows them
@@ -166,6 +166,10 @@ int lf_abi_version(void) { return LF_ABI_VERSION; }
 
 const char* lf_last_error(const lf_ctx* ctx) { return ctx ? ctx->err.c_str() : "null context"; }
 
+// lf_test_knob's process-wide defaults (see there)
+static std::mutex g_knob_mu;
+static std::vector<std::pair<std::string, double>> g_knob_defaults;
+
 lf_status lf_create(lf_ctx** out, int device) {
   if (!out) return LF_ERR_INVALID;
   *out = nullptr;
@@ -178,7 +182,11 @@ lf_status lf_create(lf_ctx** out, int device) {
     // launch with an opaque HIP error (LF_ALLOW_ANY_ARCH=1: for experiments with a fat binary)
     hipDeviceProp_t prop;
     if (hipGetDeviceProperties(&prop, device) != hipSuccess) return LF_ERR_NO_DEVICE;
-    if (std::strncmp(prop.gcnArchName, "gfx950", 6) != 0 && !std::getenv("LF_ALLOW_ANY_ARCH")) return LF_ERR_NO_DEVICE;
+    bool any_arch = false;
+#ifdef LF_EXPERIMENTS
+    any_arch = std::getenv("LF_ALLOW_ANY_ARCH") != nullptr;
+#endif
+    if (std::strncmp(prop.gcnArchName, "gfx950", 6) != 0 && !any_arch) return LF_ERR_NO_DEVICE;
   }
   lf_ctx* ctx = new lf_ctx();
   ctx->device = device;
@@ -187,11 +195,13 @@ lf_status lf_create(lf_ctx** out, int device) {
     return LF_ERR_HIP;
   }
   ctx->own_stream = true;
-  // tuning knob for experiments only (changes the sampling pattern; the oracles / tests use the default, 6)
+#ifdef LF_EXPERIMENTS
+  // (changes the sampling pattern; the oracles / tests use the default, 6)
   if (const char* sb = std::getenv("LF_MARCH_SUB_BITS")) {
     int v = std::atoi(sb);
     if (v >= 0 && v <= 8) ctx->march_sub_bits = v;
   }
+#endif
   default_paraxial_lens(ctx->pl);
   bool ok = hipMalloc((void**)&ctx->flares, sizeof(LfFlares)) == hipSuccess &&
             hipMalloc((void**)&ctx->ghosts, sizeof(LfGhostList)) == hipSuccess &&
@@ -209,6 +219,11 @@ lf_status lf_create(lf_ctx** out, int device) {
   (void)hipMemset(ctx->counters_dev, 0, kMarchCounterSlots * sizeof(unsigned long long));
   (void)hipMemset(ctx->scene_counters_dev, 0, kSceneCounters * sizeof(unsigned long long));
   if (upload_paraxial(ctx) != LF_OK) { lf_destroy(ctx); return LF_ERR_HIP; }
+  {
+    std::vector<std::pair<std::string, double>> defaults;
+    { std::lock_guard<std::mutex> lock(g_knob_mu); defaults = g_knob_defaults; }
+    for (const auto& kv : defaults) (void)lf_test_knob(ctx, kv.first.c_str(), kv.second);
+  }
   *out = ctx;
   return LF_OK;
 }
@@ -953,10 +968,10 @@ lf_status lf_cull_commit(lf_ctx* ctx) {
   if (ctx->cull_share_how != 2) return lf_fail(ctx, LF_ERR_STATE, "lf_cull_commit without lf_set_cull_share(rank, nranks > 1)");
   if (ctx->cull_hash_pending == 0) return LF_OK;
   LF_HIP(ctx, hipSetDevice(ctx->device));
-  const lf_status st = lfk_cull_finish(ctx);
-  if (st != LF_OK) return st;
-  ctx->cull_hash = ctx->cull_hash_pending;
+  const uint64_t h = ctx->cull_hash_pending;
   ctx->cull_hash_pending = 0;
+  const lf_status st = lfk_cull_finish(ctx, h);
+  if (st != LF_OK) return st;
   ctx->cull_fresh = true;
   return LF_OK;
 }
@@ -967,6 +982,68 @@ lf_status lf_get_cull_info(lf_ctx* ctx, int info[8]) {
   info[1] = ctx->last_march_culled ? 1 : 0;
   info[2] = ctx->cull_bx; info[3] = ctx->cull_by; info[4] = ctx->cull_cells; info[5] = ctx->cull_G; info[6] = ctx->cull_P;
   info[7] = 1 << ctx->cull_blk_log2;
+  return LF_OK;
+}
+
+lf_status lf_get_cull_reason(lf_ctx* ctx, int* reason) {
+  if (!ctx || !reason) return LF_ERR_INVALID;
+  *reason = ctx->cull_reason;
+  return LF_OK;
+}
+
+lf_status lf_set_cull_audit(lf_ctx* ctx, int rays_per_dropped_box) {
+  if (!ctx) return LF_ERR_INVALID;
+  if (rays_per_dropped_box < 0 || rays_per_dropped_box > 255) return lf_fail(ctx, LF_ERR_INVALID, "cull audit: 0 (off) .. 255 rays per dropped box");
+  if (rays_per_dropped_box != ctx->cull_audit_density) ctx->cull_hash = 0;     // (a resident table was audited at the other density)
+  ctx->cull_audit_density = rays_per_dropped_box;
+  return LF_OK;
+}
+
+lf_status lf_get_cull_audit(lf_ctx* ctx, uint64_t* rays, uint64_t* lit, int* launches_refuted) {
+  if (!ctx) return LF_ERR_INVALID;
+  if (rays) *rays = ctx->cull_audit_rays;
+  if (lit) *lit = ctx->cull_audit_lit;
+  if (launches_refuted) *launches_refuted = ctx->cull_audit_tripped;
+  return LF_OK;
+}
+
+// TEST HOOK (lensflare.h): the switches of the test suite and of bench.py's A/B legs, by name
+// (ctx == null: the value becomes the default of every context created afterwards -- a test that cannot reach the
+// contexts a helper creates; value 0 of a 0/1 knob takes the default away again)
+lf_status lf_test_knob(lf_ctx* ctx, const char* name, double value) {
+  if (!name) return LF_ERR_INVALID;
+  if (!ctx) {
+    std::lock_guard<std::mutex> lock(g_knob_mu);
+    for (size_t i = 0; i < g_knob_defaults.size(); i++)
+      if (g_knob_defaults[i].first == name) { g_knob_defaults.erase(g_knob_defaults.begin() + (long)i); break; }
+    if (value != 0.0) g_knob_defaults.emplace_back(name, value);
+    return LF_OK;
+  }
+  const std::string n(name);
+  const int iv = (int)value;
+  lf_ctx::CullRules& R = ctx->cull_rules;
+  bool rules = true;
+  if (n == "cull_force") { ctx->cull_force = iv != 0; return LF_OK; }
+  if (n == "cull_weights_first") { ctx->cull_weights_first = iv != 0; return LF_OK; }
+  if (n == "scene_compact") { ctx->scene_compact = iv < 0 ? -1 : iv != 0; return LF_OK; }
+  if (n == "comm_force_exchange") { ctx->comm_force_exchange = iv != 0; return LF_OK; }
+  if (n == "scene_lens_strided") { ctx->scene_lens_strided = iv < 0 ? -1 : iv != 0; return LF_OK; }
+  if (n == "bvh_median") { ctx->bvh_median = iv != 0; return LF_OK; }
+  if (n == "bvh_leaf") { ctx->bvh_leaf_max = iv; return LF_OK; }
+  if (n == "cull_general_kernel") { if (!iv) R = lf_ctx::CullRules(); ctx->cull_rules_custom = iv != 0; }
+  else if (n == "cull_strict") R.strict = iv;
+  else if (n == "cull_strict_lost") R.strict_lost = iv;
+  else if (n == "cull_slack") R.slack_mode = iv;
+  else if (n == "cull_keep_partial") R.keep_partial = iv;
+  else if (n == "cull_disable") R.disable = iv;
+  else if (n == "cull_margin") R.margin = (float)value;
+  else if (n == "cull_lobe_k") R.lobe_k = (float)value;
+  else if (n == "cull_lost_rel") R.lost_rel = (float)value;
+  else if (n == "cull_lost_abs") R.lost_abs = (float)value;
+  else rules = false;
+  if (!rules) return lf_fail(ctx, LF_ERR_INVALID, "lf_test_knob: unknown knob '" + n + "'");
+  if (n != "cull_general_kernel") ctx->cull_rules_custom = true;
+  ctx->cull_hash = 0;
   return LF_OK;
 }
 
@@ -1446,6 +1523,7 @@ lf_status lf_get_march_stats(lf_ctx* ctx, uint64_t out[4]) {
   LF_HIP(ctx, hipStreamSynchronize(ctx->stream));
   LF_HIP(ctx, hipMemcpy(c, ctx->counters_dev, sizeof(c), hipMemcpyDeviceToHost));
   out[0] = c[7]; out[1] = c[8]; out[2] = c[9]; out[3] = 0;
+#ifdef LF_EXPERIMENTS
   if (std::getenv("LF_MARCH_PRINT_HIST")) {   // instrumented builds only (LF_MARCH_LIVE_HIST / _PAIR_STATS): the slots stay 0 otherwise
     static const char* kinds[3] = {"refraction", "mirror_or_flat", "stop"};
     for (int k = 0; k < 3; k++) {
@@ -1458,12 +1536,14 @@ lf_status lf_get_march_stats(lf_ctx* ctx, uint64_t out[4]) {
         std::fprintf(stderr, "PAIR_STAT %d %d %d %llu %llu %llu\n", q, ctx->pairs.ij[q][0], ctx->pairs.ij[q][1],
                      c[kMarchPairSlot + q], c[kMarchPairSlot + 64 + q], c[kMarchPairSlot + 128 + q]);
   }
+#endif
   return LF_OK;
 }
 
 lf_status lf_reset_counters(lf_ctx* ctx) {
   if (!ctx) return LF_ERR_INVALID;
   LF_HIP(ctx, hipMemsetAsync(ctx->counters_dev, 0, kMarchCounterSlots * sizeof(unsigned long long), ctx->stream));
+  ctx->cull_audit_rays = 0; ctx->cull_audit_lit = 0; ctx->cull_audit_tripped = 0;
   return LF_OK;
 }
 

@@ -130,7 +130,7 @@ __device__ __forceinline__ void virtual_event(Ray& r, const LfProgRow& w, float 
 #ifndef LF_CULL_WG
 #define LF_CULL_WG 64        // lanes per workgroup: 256 / 128 / 64 -> 7.18 / 7.11 / 6.95 ms (a wave of decided boxes frees its slot at once)
 #endif
-__global__ __launch_bounds__(LF_CULL_WG, LF_CULL_WAVES) void k_cull_level(const LfLensDev* __restrict__ lens,
+__global__ __launch_bounds__(LF_CULL_WG, LF_CULL_WAVES) void k_cull_level_general(const LfLensDev* __restrict__ lens,
                                                     const LfPairsDev* __restrict__ pairs,
                                                     const int* __restrict__ seq_table,
                                                     const LfProgRow* __restrict__ rec_table, CullLevelArgs a,
@@ -442,6 +442,303 @@ __global__ __launch_bounds__(LF_CULL_WG, LF_CULL_WAVES) void k_cull_level(const 
   }
 }
 
+// ---- the pre-pass as it ships ---------------------------------------------------------------------------
+// k_cull_level_general above evaluates whatever rules its arguments carry (a test's: lf_test_knob); the rules that SHIP
+// are one set, and most of what the general kernel computes they never look at.  Under them
+//   * a footprint is only ever taken over ALL 15 samples: a box that lost a sample is bounded by nothing (it is kept, or
+//     dropped by the pass-scalar bound of the event at which all its samples end), so there is no ball around the samples
+//     left, no reference sample other than the centre, no use-masks;
+//   * on a glass interface the footprint can drop a box only if the centre sample already lies outside the clear
+//     aperture (the test is  |c| - extent > h,  extent >= 0) -- a footprint is built only for the waves in which some
+//     lane's centre does (round 5 built one after every event of every box: 233 lane-instructions per marched
+//     ray-event against the march's 40); at the stop the mask's grid needs it for every box that got there whole;
+//   * the total-reflection margin is only a sign: no reciprocal.
+// Same expressions in the same order (the build is -ffp-contract=off): the table is the general kernel's BIT FOR BIT
+// (tests/test_gpu_cull.py test_the_shipped_kernel_is_the_general_one).
+__device__ __forceinline__ void cull_event(Ray& r, const LfProgRow& w, float cn22, float rn2, float delta, bool reflect, bool flat,
+                                           float& disc_out, bool& goes_on) {
+  const float oz = r.hz + w.dzv;
+  const float od = fmaf(r.px, r.dx, fmaf(r.py, r.dy, oz * r.dz));
+  const float oo = fmaf(oz, oz, fmaf(r.px, r.px, r.py * r.py));
+  const float Fh = fmaf(w.ch, oo, -oz);
+  const float G = fmaf(-w.curv, od, r.dz);
+  const float disc = fmaf(G, G, -(cn22 * Fh));
+  disc_out = disc;
+  const float sq = lf_sqrt(disc);
+  const float t = flat ? (Fh + Fh) * lf_rcp(fmaf(w.sgn, sq, G)) : fmaf(-w.sgn, sq, G) * rn2;
+  const float hx = fmaf(t, r.dx, r.px), hy = fmaf(t, r.dy, r.py), hz = fmaf(t, r.dz, oz);
+  if (reflect) {
+    goes_on = true;
+    const float m = sq * (w.c2 * w.sgn);
+    r.dx = fmaf(m, hx, r.dx); r.dy = fmaf(m, hy, r.dy); r.dz = fmaf(m, hz, fmaf(-2.0f * w.sgn, sq, r.dz));
+  } else {
+    const float k2 = disc + delta;
+    goes_on = k2 >= 0.0f;
+    const float gs = lf_sqrt(k2) - sq, gcs = gs * w.sc;
+    r.dx = fmaf(-gcs, hx, r.dx); r.dy = fmaf(-gcs, hy, r.dy); r.dz = fmaf(-gcs, hz, fmaf(w.sgn, gs, r.dz));
+  }
+  r.px = hx; r.py = hy; r.hz = hz;
+}
+
+// the shipped rules' constants (lf_ctx::CullRules' defaults: what k_cull_level_general is given when no test interferes)
+constexpr float kShipLobeK = 1.2f;
+
+// the footprint of a box whose 15 samples are all in use, in a plane (positions on an interface / directions at the exit):
+// centre, generators, the slack that sums the second order of the four axes + twice the corners' cross terms, and the ball
+struct ShipFoot { float cx, cy, g1x, g1y, g2x, g2y, gxx, gxy, gyx, gyy, slack, ball; };
+template <bool DIRS>
+__device__ __forceinline__ ShipFoot ship_footprint(const Ray (&r)[kCullSamples], float margin, float eps) {
+  auto vx = [&](int t) { return DIRS ? r[t].dx : r[t].px; };
+  auto vy = [&](int t) { return DIRS ? r[t].dy : r[t].py; };
+  ShipFoot f;
+  f.cx = vx(4); f.cy = vy(4);
+  f.g1x = 0.5f * (vx(5) - vx(3)); f.g1y = 0.5f * (vy(5) - vy(3));
+  f.g2x = 0.5f * (vx(7) - vx(1)); f.g2y = 0.5f * (vy(7) - vy(1));
+  f.gxx = 0.5f * (vx(9) - vx(10)); f.gxy = 0.5f * (vy(9) - vy(10));
+  f.gyx = 0.5f * (vx(11) - vx(12)); f.gyy = 0.5f * (vy(11) - vy(12));
+  float ru2 = 0.0f, rx2 = 0.0f, ry2 = 0.0f, rl2 = 0.0f;
+#pragma unroll
+  for (int t = 0; t < kCullSamples; t++) {
+    const float ex = vx(t) - f.cx, ey = vy(t) - f.cy;
+    const float d2 = fmaf(ex, ex, ey * ey);
+    if (t < 9) ru2 = fmaxf(ru2, d2);
+    else if (t < 11) rx2 = fmaxf(rx2, d2);
+    else if (t < 13) ry2 = fmaxf(ry2, d2);
+    else rl2 = fmaxf(rl2, d2);
+  }
+  const float ru = lf_sqrt(ru2), rl = lf_sqrt(rl2);
+  const float rx = lf_sqrt(rx2), ry = lf_sqrt(ry2);
+  f.ball = fmaf(margin, ((ru + rx) + ry) + rl, eps);
+  const float dax = 0.5f * (vx(5) + vx(3)) - vx(4), day = 0.5f * (vy(5) + vy(3)) - vy(4);
+  const float dbx = 0.5f * (vx(7) + vx(1)) - vx(4), dby = 0.5f * (vy(7) + vy(1)) - vy(4);
+  const float dxx = 0.5f * (vx(9) + vx(10)) - vx(4), dxy = 0.5f * (vy(9) + vy(10)) - vy(4);
+  const float dyx = 0.5f * (vx(11) + vx(12)) - vx(4), dyy = 0.5f * (vy(11) + vy(12)) - vy(4);
+  const float sx = (dax + dbx) + (dxx + dyx), sy = (day + dby) + (dxy + dyy);
+  float c2 = 0.0f;
+#pragma unroll
+  for (int t = 0; t < 9; t += 2) {
+    if (t == 4) continue;
+    const float at = (float)(t % 3 - 1), bt = (float)(t / 3 - 1);
+    const float mx = (vx(t) - vx(4)) - fmaf(at, f.g1x + f.gxx, bt * (f.g2x + f.gyx)) - sx;
+    const float my = (vy(t) - vy(4)) - fmaf(at, f.g1y + f.gxy, bt * (f.g2y + f.gyy)) - sy;
+    c2 = fmaxf(c2, fmaf(mx, mx, my * my));
+  }
+  const float sum2 = lf_sqrt(fmaf(dax, dax, day * day)) + lf_sqrt(fmaf(dbx, dbx, dby * dby)) +
+                     lf_sqrt(fmaf(dxx, dxx, dxy * dxy)) + lf_sqrt(fmaf(dyx, dyx, dyy * dyy));
+  f.slack = sum2 + fmaf(2.0f, lf_sqrt(c2), fmaf(margin, rl, eps));
+  return f;
+}
+__device__ __forceinline__ float ship_extent(const ShipFoot& f, float geo_margin, float nx, float ny) {
+  const float e = fabsf(fmaf(f.g1x, nx, f.g1y * ny)) + fabsf(fmaf(f.g2x, nx, f.g2y * ny)) +
+                  fabsf(fmaf(f.gxx, nx, f.gxy * ny)) + fabsf(fmaf(f.gyx, nx, f.gyy * ny));
+  return fminf(f.ball, fmaf(geo_margin, e, f.slack));
+}
+
+__global__ __launch_bounds__(LF_CULL_WG, LF_CULL_WAVES) void k_cull_level(const LfLensDev* __restrict__ lens,
+                                                    const LfPairsDev* __restrict__ pairs,
+                                                    const int* __restrict__ seq_table,
+                                                    const LfProgRow* __restrict__ rec_table, CullLevelArgs a,
+                                                    const unsigned* __restrict__ items,
+                                                    const unsigned* __restrict__ counts, unsigned items_stride,
+                                                    unsigned* __restrict__ next, unsigned* __restrict__ next_counts,
+                                                    unsigned long long* __restrict__ table,
+                                                    unsigned long long* __restrict__ stats) {
+  const int q = blockIdx.y;
+  const unsigned PP = (unsigned)(a.P * a.P);
+  const unsigned n_blk = (unsigned)(a.blocks_x * a.blocks_y);
+  const unsigned n_mine = (n_blk + (unsigned)a.share_n - 1u - (unsigned)a.share_rank) / (unsigned)a.share_n;
+  const unsigned n_items = items ? min(counts[q], items_stride) : n_mine * PP;
+  const unsigned i = blockIdx.x * blockDim.x + threadIdx.x;
+  if ((i & ~63u) >= n_items) return;
+  const bool valid = i < n_items;
+  const unsigned item = valid ? (items ? items[(size_t)q * items_stride + i]
+                                       : ((unsigned)a.share_rank + (unsigned)a.share_n * (i / PP)) * PP + i % PP) : 0u;
+  const int blk = (int)(item / PP), cell = (int)(item % PP);
+  const int ci = cell % a.P, cj = cell / a.P;
+  const int bx = blk % a.blocks_x, by = blk / a.blocks_x;
+
+  const float px0 = (float)(bx << a.blk_log2), px1 = fminf((float)a.W, (float)((bx + 1) << a.blk_log2));
+  const float py0 = (float)(by << a.blk_log2), py1 = fminf((float)a.H, (float)((by + 1) << a.blk_log2));
+  const float Xc = -((0.5f * (px0 + px1)) - a.half_w) * a.pitch, Yc = -((0.5f * (py0 + py1)) - a.half_h) * a.pitch;
+  const float hX = 0.5f * (px1 - px0) * a.pitch, hY = 0.5f * (py1 - py0) * a.pitch;
+  const float invP = 1.0f / (float)a.P;
+
+  const int n_ev = pairs->ev_cnt[q];
+  const int* const seq = seq_table + pairs->ev_off[q];
+  const int lane = (int)(threadIdx.x & 63u);
+  constexpr unsigned kAll = (1u << kCullSamples) - 1u;
+  const LfProgRow* recs_of[3];
+  int j_of[3];
+  float ns_of[3];
+#pragma unroll
+  for (int w = 0; w < 3; w++) {
+    const int l = a.lam[w], g = l / a.march_k;
+    j_of[w] = l - g * a.march_k;
+    recs_of[w] = rec_table + (size_t)g * (size_t)a.prog_recs;
+    ns_of[w] = lens->n_start[l];
+  }
+  // the box's 15 rays (the sample layout of k_cull_level_general)
+  Ray r[kCullSamples];
+#pragma unroll
+  for (int t = 0; t < kCullSamples; t++) {
+    float X = Xc, Y = Yc, fu = 0.5f, fv = 0.5f;
+    if (t < 9) {
+      fu = 0.5f * (float)(t % 3); fv = 0.5f * (float)(t / 3);
+      if ((t % 3) != 1 && (t / 3) != 1) { X = Xc + (float)(t % 3 - 1) * hX; Y = Yc + (float)(t / 3 - 1) * hY; }
+    }
+    else if (t == 9) X = Xc + hX;
+    else if (t == 10) X = Xc - hX;
+    else if (t == 11) Y = Yc + hY;
+    else if (t == 12) Y = Yc - hY;
+    const float ns = t == 13 ? ns_of[1] : t == 14 ? ns_of[2] : ns_of[0];
+    const float ua = ((float)ci + fu) * invP, ub = ((float)cj + fv) * invP;
+    const StartRay s0 = aim_at_pupil(X, Y, fmaf(2.0f, ua, -1.0f), fmaf(2.0f, ub, -1.0f), a.pupil_h, a.vz, a.geom_norm);
+    r[t] = Ray{X, Y, 0.0f, 0.0f, s0.dx * ns, s0.dy * ns, s0.dz * ns, 0.0f, 0.0f};
+  }
+  unsigned live = kAll;
+  bool culled = !valid, keep = false;
+  int why = 0;
+  for (int e = 0; e < n_ev; e++) {
+    if (__ballot(!culled && !keep) == 0ull) break;      // every box of the wave is decided
+    const unsigned se = (unsigned)*(const int __attribute__((address_space(4)))*)(seq + e);
+    const unsigned kind = se >> 16;
+    const LfProgRow wr = load_prec(recs_of[0], se & 0xffffu);
+    float cn22_of[3], rn2_of[3], delta_of[3];
+#pragma unroll
+    for (int w = 0; w < 3; w++) {
+      const LfProgRow x = w == 0 ? wr : load_prec(recs_of[w], se & 0xffffu);
+      const int j = j_of[w];
+      cn22_of[w] = j == 0 ? x.cn22[0] : j == 1 ? x.cn22[1] : x.cn22[2];
+      rn2_of[w] = j == 0 ? x.rn2[0] : j == 1 ? x.rn2[1] : x.rn2[2];
+      delta_of[w] = j == 0 ? x.delta[0] : j == 1 ? x.delta[1] : x.delta[2];
+    }
+    const bool stop = (kind & LF_EV_STOP) != 0u;
+    unsigned hit = 0u, okm = 0u;
+    const unsigned live_before = live;
+    float pv[kCullSamples];      // the pass scalar of every sample: p = disc + min(0, n'^2 - n^2) (see k_cull_level_general)
+#pragma unroll
+    for (int t = 0; t < kCullSamples; t++) {
+      const int w = t == 13 ? 1 : t == 14 ? 2 : 0;
+      bool ok;
+      if (stop) {
+        const float tt = -(r[t].hz + wr.dzv) * lf_rcp(r[t].dz);
+        const float hx = fmaf(tt, r[t].dx, r[t].px), hy = fmaf(tt, r[t].dy, r[t].py);
+        r[t].px = hx; r[t].py = hy; r[t].hz = 0.0f;
+        ok = hx == hx && hy == hy;
+        if (ok) hit |= 1u << t;
+        pv[t] = 1.0f;
+      } else {
+        float disc;
+        bool goes_on;
+        cull_event(r[t], wr, cn22_of[w], rn2_of[w], delta_of[w], (kind & LF_EV_REFLECT) != 0, (kind & LF_EV_FLAT) != 0, disc, goes_on);
+        pv[t] = (kind & LF_EV_REFLECT) ? disc : disc + fminf(0.0f, delta_of[w]);
+        const bool reaches = disc >= 0.0f;
+        if (reaches) hit |= 1u << t;
+        ok = reaches && goes_on;
+      }
+      if (ok) okm |= 1u << t;
+    }
+    hit &= live;
+    const bool undecided = !culled && !keep;
+    // "every ray of the box ends here": the zonotope bound of the pass scalar must stay below zero, on a box whole until now
+    const bool all_end = undecided && live_before == kAll && (okm & kAll) == 0u && !stop;
+    bool firmly_lost = false;
+    if (__ballot(all_end) != 0ull) {
+      const float* v = pv;
+      const float ga = 0.5f * (v[5] - v[3]), gb = 0.5f * (v[7] - v[1]), gx = 0.5f * (v[9] - v[10]), gy = 0.5f * (v[11] - v[12]);
+      const float da = fabsf(0.5f * (v[5] + v[3]) - v[4]), db = fabsf(0.5f * (v[7] + v[1]) - v[4]);
+      const float dx = fabsf(0.5f * (v[9] + v[10]) - v[4]), dy = fabsf(0.5f * (v[11] + v[12]) - v[4]);
+      const float second = (da + db) + (dx + dy);
+      float cross = 0.0f;
+#pragma unroll
+      for (int t = 0; t < 9; t += 2) {
+        if (t == 4) continue;
+        const float at = (float)(t % 3 - 1), bt = (float)(t / 3 - 1);
+        cross = fmaxf(cross, fabsf((v[t] - v[4]) - fmaf(at, ga + gx, bt * (gb + gy))) - second);
+      }
+      const float disp = fmaxf(fabsf(v[13] - v[4]), fabsf(v[14] - v[4]));
+      const float upper = v[4] + fmaf(a.geo_margin, (fabsf(ga) + fabsf(gb)) + (fabsf(gx) + fabsf(gy)), second + fmaf(2.0f, fmaxf(cross, 0.0f), a.margin * disp));
+      firmly_lost = all_end && upper < -1.0e-4f;
+    }
+    live &= okm;
+    // a footprint can drop a box only where every sample reached the interface AND (the stop's mask, or the centre sample
+    // outside the clear aperture)
+    const float cx = r[4].px, cy = r[4].py;
+    const float cr = lf_sqrt(fmaf(cx, cx, cy * cy));
+    const float h = lf_sqrt(wr.h2);
+    const bool whole = undecided && hit == kAll;
+    if (__ballot(whole && (stop || cr > h)) != 0ull) {
+      const ShipFoot f = ship_footprint<false>(r, a.margin, 1e-3f);
+      const float icr = cr > 0.0f ? lf_rcp(cr) : 0.0f;
+      if (whole && cr - ship_extent(f, a.geo_margin, cx * icr, cy * icr) > h) { culled = true; why = 4; }
+      else if (whole && stop) {
+        const float s = 0.5f * (float)kCullOcc;
+        const float radx = ship_extent(f, a.geo_margin, 1.0f, 0.0f), rady = ship_extent(f, a.geo_margin, 0.0f, 1.0f);
+        const int ix0 = max(0, (int)floorf(fmaf(cx - radx, a.inv_stop_h, 1.0f) * s));
+        const int ix1 = min(kCullOcc - 1, (int)floorf(fmaf(cx + radx, a.inv_stop_h, 1.0f) * s));
+        const int iy0 = max(0, (int)floorf(fmaf(cy - rady, a.inv_stop_h, 1.0f) * s));
+        const int iy1 = min(kCullOcc - 1, (int)floorf(fmaf(cy + rady, a.inv_stop_h, 1.0f) * s));
+        bool open = false;
+        if (ix0 <= ix1) {
+          const unsigned span = (ix1 - ix0 >= 31 ? 0xffffffffu : ((2u << (ix1 - ix0)) - 1u)) << ix0;
+          for (int iy = iy0; iy <= iy1; iy++) open = open || (a.occ[iy] & span) != 0u;
+        }
+        if (!open) { culled = true; why = 5; }
+      }
+    }
+    if (undecided && !culled) {
+      if (hit == 0u) {                                       // no sample reaches the interface
+        if (firmly_lost) { culled = true; why = 7; } else { keep = true; why = 2; }
+      }
+      else if (live == 0u && firmly_lost) { culled = true; why = 7; }   // every sample ends here, by a margin
+      else if (__popc(live & 0x1ffu) < 3) { keep = true; why = 2; }     // too little left to bound anything
+    }
+  }
+  if (!culled && !keep) {
+    // the path is complete.  A box that lost samples is bounded by nothing: kept.  A whole one: where can it point?
+    if (live != kAll) { keep = true; why = 1; }
+  }
+  if (__ballot(!culled && !keep) != 0ull) {
+    const ShipFoot f = ship_footprint<true>(r, a.margin, 2e-5f);
+    const float ex = a.sx - f.cx, ey = a.sy - f.cy;
+    const float dist = lf_sqrt(fmaf(ex, ex, ey * ey));
+    const float id = dist > 0.0f ? lf_rcp(dist) : 0.0f;
+    if (!culled && !keep) {
+      if (dist - kShipLobeK * ship_extent(f, a.geo_margin, ex * id, ey * id) > a.rho) { culled = true; why = 6; }
+      else { keep = true; why = 3; }
+    }
+  }
+  if (stats && valid && why) atomicAdd(&stats[why], 1ull);
+  const bool enabled = valid && keep;
+  if (a.last) {
+    if (valid && enabled) {
+      unsigned long long* row = table + lf_cull_row_of_block(blk, a.share_n, a.share_nb) * (size_t)(a.P * a.P + 1);
+      const unsigned long long bit = 1ull << q;
+      atomicOr(&row[cell], bit);
+      atomicOr(&row[a.P * a.P], bit);
+    }
+    const lanemask em = __ballot(valid && enabled);
+    if (em != 0ull && lane == (int)__builtin_ctzll(em)) atomicAdd(&next_counts[q], (unsigned)__popcll(em));
+  } else {
+    const lanemask em = __ballot(valid && enabled);
+    if (em != 0ull) {
+      unsigned base = 0u;
+      if (lane == (int)__builtin_ctzll(em)) base = atomicAdd(&next_counts[q], 4u * (unsigned)__popcll(em));
+      base = __shfl(base, (int)__builtin_ctzll(em));
+      if (valid && enabled) {
+        const unsigned at = base + 4u * (unsigned)__popcll(em & ((1ull << lane) - 1ull));
+        const unsigned P2 = 2u * (unsigned)a.P;
+        unsigned* out = next + (size_t)q * a.list_stride;
+        if (at + 3u < a.list_stride) {
+#pragma unroll
+          for (int c = 0; c < 4; c++)
+            out[at + c] = (unsigned)blk * (P2 * P2) + (unsigned)(2 * cj + (c >> 1)) * P2 + (unsigned)(2 * ci + (c & 1));
+        }
+      }
+    }
+  }
+}
+
 // ---- the march of the enabled paths ---------------------------------------------------------------------
 constexpr int kWgWaves = 8;
 constexpr int kListMax = 4096;   // samples of one tile's workgroup (spp / sgroups) listed at a time
@@ -639,16 +936,19 @@ void k_march_cull(const LfLensDev* __restrict__ lens, const LfPairsDev* __restri
   const bool active = x < a.W && y >= a.y0 && y < a.y1;
   const lanemask active_mask = __ballot(active);
   const unsigned p = (unsigned)y * (unsigned)a.W + (unsigned)x;
-  // the tile's cull row: its 64 columns and 8 rows lie inside one 64 x 64 block
+  // the tile's cull row: its columns and 8 rows lie inside one block -- unless the blocks are smaller than the tile
+  // (cull.multi: 16 / 32-pixel blocks of a small frame), where every lane has the row of its own pixel's block
   const int blk = ((trow * 8) >> cull.blk_log2) * cull.blocks_x + ((((tx >> a.xs) << (3 + a.xs))) >> cull.blk_log2);
   const unsigned long long* const crow = cull.table + lf_cull_row_of_block(blk, cull.share_n, cull.share_nb) * (size_t)(cull.cells + 1);
+  const int blk_lane = (min(y, a.H - 1) >> cull.blk_log2) * cull.blocks_x + (min(x, a.W - 1) >> cull.blk_log2);
+  const unsigned long long* const crow_lane = cull.multi ? cull.table + lf_cull_row_of_block(blk_lane, cull.share_n, cull.share_nb) * (size_t)(cull.cells + 1) : crow;
 
   const float pitch = lens->pitch, pupil_h = lens->pupil_h, geom_norm = lens->geom_norm;
   const float half_w = a.half_w, half_h = a.half_h, vz_u = a.vz;
   const int GG = a.G * a.G;
   // do the lanes of a wave aim a stratified sample at ONE cell of the table?  (they share a sub-cell of the stratum;
   // the table has m cells per stratum axis)
-  const bool per_lane = (1 << a.sub_bits) < cull.m;
+  const bool per_lane = (1 << a.sub_bits) < cull.m || cull.multi != 0;
 
   PathTally T;
 
@@ -696,7 +996,7 @@ void k_march_cull(const LfLensDev* __restrict__ lens, const LfPairsDev* __restri
       if (entry >= 0) { todo = crow[entry]; mine = todo; }
       else {
         const int fx = min(cull.P - 1, (int)(ua * (float)cull.P)), fy = min(cull.P - 1, (int)(ub * (float)cull.P));
-        mine = active ? crow[fy * cull.P + fx] : 0ull;
+        mine = active ? crow_lane[fy * cull.P + fx] : 0ull;
         unsigned lo = (unsigned)mine, hi = (unsigned)(mine >> 32);
         for (int off = 32; off > 0; off >>= 1) { lo |= __shfl_xor(lo, off); hi |= __shfl_xor(hi, off); }
         todo = ((unsigned long long)__builtin_amdgcn_readfirstlane(hi) << 32) | (unsigned long long)__builtin_amdgcn_readfirstlane(lo);
@@ -790,11 +1090,17 @@ void k_march_items(const LfLensDev* __restrict__ lens, const LfPairsDev* __restr
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int lane = tid & 63;
   const int n_paths = pairs->n;
-  const int blk = ((trow * 8) >> cull.blk_log2) * cull.blocks_x + ((((tx >> a.xs) << (3 + a.xs))) >> cull.blk_log2);
-  const unsigned long long* const crow = cull.table + lf_cull_row_of_block(blk, cull.share_n, cull.share_nb) * (size_t)(cull.cells + 1);
   const float pitch = lens->pitch, pupil_h = lens->pupil_h, geom_norm = lens->geom_norm;
   const float half_w = a.half_w, half_h = a.half_h, vz_u = a.vz;
   const int GG = a.G * a.G;
+  // the cull row of THIS lane's pixel (one block holds the whole tile unless the blocks are smaller than it: cull.multi)
+  const unsigned long long* crow;
+  {
+    const int lx = ((tx >> a.xs) << (3 + a.xs)) + ((lane & 7) << a.xs) + (tx & ((1 << a.xs) - 1)), ly = trow * 8 + (lane >> 3);
+    const int blk = cull.multi ? (min(ly, a.H - 1) >> cull.blk_log2) * cull.blocks_x + (min(lx, a.W - 1) >> cull.blk_log2)
+                               : ((trow * 8) >> cull.blk_log2) * cull.blocks_x + ((((tx >> a.xs) << (3 + a.xs))) >> cull.blk_log2);
+    crow = cull.table + lf_cull_row_of_block(blk, cull.share_n, cull.share_nb) * (size_t)(cull.cells + 1);
+  }
   // pixel `px` of the tile (the lane order of k_march / k_march_cull)
   auto pixel_of = [&](int px, int& x, int& y) {
     x = ((tx >> a.xs) << (3 + a.xs)) + ((px & 7) << a.xs) + (tx & ((1 << a.xs) - 1));
@@ -952,21 +1258,48 @@ uint64_t fnv(uint64_t h, const void* data, size_t n) {
 static int cull_m(const lf_ctx* ctx, int G) {
   (void)ctx;
   int m = 4;
-  if (const char* e = std::getenv("LF_CULL_M")) m = std::max(1, std::atoi(e));   // experiments only
+#ifdef LF_EXPERIMENTS
+  if (const char* e = std::getenv("LF_CULL_M")) m = std::max(1, std::atoi(e));
+#endif
   while (m > 1 && G * m > 128) m >>= 1;
   return m;
 }
 
-bool lf_cull_applies(const lf_ctx* ctx, int G) {
-  if (ctx->march_cull == 0) return false;
-  if (const char* e = std::getenv("LF_MARCH_CULL")) if (std::atoi(e) == 0) return false;   // experiments only
-  // a mask has 64 bits; the strata of more than 4096 samples per pixel would need a table of their own size; and a
-  // block must be SMALL on the sensor for 13 rays to bound it: 64 pixels <= 1.8 mm (the full-enumeration comparison
-  // finds the first skipped lit ray at blocks of 4.8 mm, none up to 3.6 mm: profiles/r05_cull_block_size.json) --
-  // frames narrower than 1280 pixels on a 36 mm sensor march everything, which costs them little
-  const double block_mm = (double)(1 << kCullBlockLog2) * (double)ctx->sensor_w_mm / (double)std::max(1, ctx->W);   // (the smallest block)
-  if (block_mm > kCullMaxBlockMm && !std::getenv("LF_CULL_ANY_BLOCK")) return false;
-  return ctx->pairs.n <= kCullMaxPaths && G >= 1 && G <= 64 && ctx->lens.stop >= 0;
+// Does the cull apply to this launch, and if not, why (lf_get_cull_reason)
+int lf_cull_reason_of(const lf_ctx* ctx, int G) {
+  if (ctx->march_cull == 0) return LF_CULL_OFF;
+#ifdef LF_EXPERIMENTS
+  if (const char* e = std::getenv("LF_MARCH_CULL")) if (std::atoi(e) == 0) return LF_CULL_OFF;
+#endif
+  if (ctx->lens.stop < 0) return LF_CULL_NO_STOP;
+  if (!ctx->lens_lambda_monotonic) return LF_CULL_DISPERSION;
+  if (ctx->pairs.n > kCullMaxPaths) return LF_CULL_TOO_MANY_PATHS;
+  if (G < 1 || G > 64) return LF_CULL_TOO_MANY_SAMPLES;
+  // a block must be SMALL on the sensor for 15 rays to bound it: <= 1.8 mm (the full-enumeration comparison finds no
+  // skipped lit ray up to 7.2 mm blocks, profiles/r05_cull_block_size.json) -- frames narrower than 1280 pixels on a
+  // 36 mm sensor take blocks of 32 or 16 pixels (lf_cull_block_log2)
+  if (lf_cull_block_log2(ctx, 1, 1) < 0) return LF_CULL_BLOCK_TOO_LARGE;
+  return LF_CULL_APPLIED;
+}
+bool lf_cull_applies(const lf_ctx* ctx, int G) { return lf_cull_reason_of(ctx, G) == LF_CULL_APPLIED; }
+
+// log2 of the side of a cull block in pixels for this frame: 6 (64 pixels) where that is <= kCullMaxBlockMm on the sensor;
+// 7 where 128 are still <= kCullBigBlockMm AND the launch has few samples (measured at 4K: 256 spp x 3 wavelengths tie, 1024 x 8
+// lose: profiles/r05_march_variants.txt); 5 or 4 (32 / 16 pixels) where 64 are too large (a frame narrower than 1280
+// pixels on 36 mm): a wave tile, (8 << xs) pixels wide, then spans several blocks and its lanes look their rows up one by
+// one (LfCullArgs::multi); -1: even 16 pixels are too large.
+int lf_cull_block_log2(const lf_ctx* ctx, int spp, int n_lambda) {
+  const double mm_per_px = (double)ctx->sensor_w_mm / (double)std::max(1, ctx->W);
+  int lg = kCullBlockLog2;
+  while (lg > 4 && (double)(1 << lg) * mm_per_px > kCullMaxBlockMm) lg--;
+  if ((double)(1 << lg) * mm_per_px > kCullMaxBlockMm) return -1;
+  if (lg == kCullBlockLog2 && (double)(2 << lg) * mm_per_px <= kCullBigBlockMm && (long long)spp * n_lambda < 768) {
+#ifdef LF_EXPERIMENTS
+    if (std::getenv("LF_CULL_SMALL_BLOCKS")) return lg;
+#endif
+    return lg + 1;
+  }
+  return lg;
 }
 
 // set bits of the table's cells (not of the union entries): the (block, cell, path) combinations the march will start
@@ -980,36 +1313,155 @@ __global__ void k_cull_popcount(const unsigned long long* __restrict__ table, si
   if ((threadIdx.x & 63u) == 0u && sum) atomicAdd(out, sum);
 }
 
+// ---- the audit: what the table drops, sampled -----------------------------------------------------------------------
+// The pre-pass's bounds are estimates (see the head of this file): what stands behind them is a search for counter-examples,
+// and a search covers the prescriptions it drew.  So every table is also CHECKED where it is used: for every (block, cell,
+// path) combination it does not start, `density` rays of that box -- a random pixel position in the block, a random point of
+// the pupil cell, one of the launch's wavelengths; Philox keyed by the launch -- are marched as the march would (geometry
+// only, real apertures), and a ray that ends inside the sun's lobe REFUTES the table: the launch marches everything
+// (k_march, the path tree) and says so (lf_get_cull_audit, lf_get_cull_reason).  One wave = 64 cells of one block, the
+// paths one after the other (wave-uniform event sequence, rows through the scalar cache, lanes whose cell starts the
+// path idle): ~10 events per ray, 8.8e7 rays on the bench frame.
+constexpr unsigned kDomainAudit = 0x0a0d17c5u;
+struct CullAuditArgs {
+  int W, H;
+  float pitch, half_w, half_h;
+  int blocks_x, blocks_y, blk_log2, share_n, share_nb;
+  int P, n_paths, n_lambda, march_k, prog_recs;
+  float pupil_h, vz, geom_norm, inv_stop_h, lobe_thr;
+  int mw, mh;
+  uint2 key;
+  int density;
+};
+__global__ __launch_bounds__(256) void k_cull_audit(const LfLensDev* __restrict__ lens, const LfPairsDev* __restrict__ pairs,
+                                                    const int* __restrict__ seq_table, const LfProgRow* __restrict__ rec_table,
+                                                    const float* __restrict__ mask, CullAuditArgs a,
+                                                    const unsigned long long* __restrict__ table,
+                                                    unsigned long long* __restrict__ out) {
+  const int blk = blockIdx.y;
+  const int cells = a.P * a.P;
+  const int cell = (int)(blockIdx.x * blockDim.x + threadIdx.x);
+  if ((cell & ~63) >= cells) return;
+  const bool valid = cell < cells;
+  const int lane = (int)(threadIdx.x & 63u);
+  const unsigned long long* const row = table + lf_cull_row_of_block(blk, a.share_n, a.share_nb) * (size_t)(cells + 1);
+  const unsigned long long bits = valid ? row[cell] : ~0ull;
+  const int ci = cell % a.P, cj = cell / a.P;
+  const int bx = blk % a.blocks_x, by = blk / a.blocks_x;
+  const float px0 = (float)(bx << a.blk_log2), px1 = fminf((float)a.W, (float)((bx + 1) << a.blk_log2));
+  const float py0 = (float)(by << a.blk_log2), py1 = fminf((float)a.H, (float)((by + 1) << a.blk_log2));
+  const float invP = 1.0f / (float)a.P;
+  const float sx = lens->sun_dir[0], sy = lens->sun_dir[1], sz = lens->sun_dir[2];
+  const float inv_1mc = lens->sun_inv_one_minus_cos, sun_ss = lens->sun_ss;
+  unsigned n_rays = 0u, n_lit = 0u;
+  for (int q = 0; q < a.n_paths; q++) {
+    const bool dropped = valid && ((bits >> q) & 1ull) == 0ull;
+    const lanemask todo = __ballot(dropped);
+    if (todo == 0ull) continue;
+    const int n_ev = pairs->ev_cnt[q];
+    const int* const seq = seq_table + pairs->ev_off[q];
+    for (int d = 0; d < a.density; d++) {
+      // the wavelength of this wave's rays: one per (block, 64 cells, path, repetition), so the rows stay scalar
+      const uint4 ru = philox4x32_10(make_uint4((unsigned)blk, blockIdx.x * 4u + (threadIdx.x >> 6), kDomainAudit, (unsigned)(q | (d << 8))), a.key);
+      const int l = (int)(__builtin_amdgcn_readfirstlane(ru.x) % (unsigned)a.n_lambda);
+      const int g = l / a.march_k, j = l - g * a.march_k;
+      const LfProgRow* const recs = rec_table + (size_t)g * (size_t)a.prog_recs;
+      const uint4 rnd = philox4x32_10(make_uint4((unsigned)(blk * cells + cell), (unsigned)(q | (d << 8)), kDomainAudit, 1u), a.key);
+      const float X = -((px0 + u01(rnd.x) * (px1 - px0)) - a.half_w) * a.pitch;
+      const float Y = -((py0 + u01(rnd.y) * (py1 - py0)) - a.half_h) * a.pitch;
+      const float ua = ((float)ci + u01(rnd.z)) * invP, ub = ((float)cj + u01(rnd.w)) * invP;
+      const StartRay s0 = aim_at_pupil(X, Y, fmaf(2.0f, ua, -1.0f), fmaf(2.0f, ub, -1.0f), a.pupil_h, a.vz, a.geom_norm);
+      const float ns = lens->n_start[l];
+      Ray r{X, Y, 0.0f, fmaf(X, X, Y * Y), s0.dx * ns, s0.dy * ns, s0.dz * ns, 1.0f, 1.0f};
+      lanemask alive = todo;
+      n_rays += dropped ? 1u : 0u;
+      for (int e = 0; e < n_ev && alive != 0ull; e++) {
+        const unsigned se = (unsigned)*(const int __attribute__((address_space(4)))*)(seq + e);
+        const LfProgRow wr = load_prec(recs, se & 0xffffu);
+        const unsigned kind = se >> 16;
+        if (kind & LF_EV_STOP) alive &= stop_event<false>(r, wr.dzv, wr.h2, a.inv_stop_h, mask, a.mw, a.mh);
+        else {
+          lanemask geom_ok;
+          const float cn22 = j == 0 ? wr.cn22[0] : j == 1 ? wr.cn22[1] : wr.cn22[2];
+          const float rn2 = j == 0 ? wr.rn2[0] : j == 1 ? wr.rn2[1] : wr.rn2[2];
+          const float delta = j == 0 ? wr.delta[0] : j == 1 ? wr.delta[1] : wr.delta[2];
+          alive &= surface_event<false>(r, wr.dzv, wr.curv, wr.ch, wr.c2, wr.sc, cn22, rn2, delta, wr.h2, (kind & LF_EV_REFLECT) != 0,
+                                        (kind & LF_EV_FLAT) != 0, wr.sgn, geom_ok);
+        }
+      }
+      if (alive == 0ull) continue;
+      const float cg = fmaf(r.dx, sx, fmaf(r.dy, sy, r.dz * sz));
+      const bool lit = ((alive >> lane) & 1ull) != 0ull && cg > a.lobe_thr && lobe_q(r.dx, r.dy, r.dz, sx, sy, sz, sun_ss, inv_1mc) < 1.0f;
+      n_lit += lit ? 1u : 0u;
+    }
+  }
+  unsigned long long v0 = n_rays, v1 = n_lit;
+  for (int o = 32; o > 0; o >>= 1) { v0 += __shfl_xor(v0, o); v1 += __shfl_xor(v1, o); }
+  if (lane == 0) {
+    if (v0) atomicAdd(&out[0], v0);
+    if (v1) atomicAdd(&out[1], v1);
+  }
+}
+
 // The table is complete (built here, or completed by an all-gather): what fraction of all (block, cell, path)
 // combinations it starts -- counted from the table itself, so that every rank of a shared table finds the same number
-// and takes the same kernel.
-lf_status lfk_cull_finish(lf_ctx* ctx) {
-  if (!ctx->cull_popc_dev) LF_HIP(ctx, hipMalloc((void**)&ctx->cull_popc_dev, sizeof(unsigned long long)));
-  LF_HIP(ctx, hipMemsetAsync(ctx->cull_popc_dev, 0, sizeof(unsigned long long), ctx->stream));
+// and takes the same kernel -- and what its audit says.  `hash`: of the inputs it was built from; published only here.
+lf_status lfk_cull_finish(lf_ctx* ctx, uint64_t hash) {
+  if (!ctx->cull_popc_dev) LF_HIP(ctx, hipMalloc((void**)&ctx->cull_popc_dev, 4 * sizeof(unsigned long long)));
+  LF_HIP(ctx, hipMemsetAsync(ctx->cull_popc_dev, 0, 4 * sizeof(unsigned long long), ctx->stream));
   const size_t rows = ctx->cull_share_nb > 0 ? (size_t)ctx->cull_share_nb * (size_t)std::max(1, ctx->cull_share_n_resident)
                                              : (size_t)ctx->cull_bx * ctx->cull_by;
   hipLaunchKernelGGL(k_cull_popcount, dim3(1024), dim3(256), 0, ctx->stream, ctx->cull_dev, rows, ctx->cull_cells, ctx->cull_popc_dev);
   LF_HIP(ctx, hipGetLastError());
-  unsigned long long on = 0ull;
-  LF_HIP(ctx, hipMemcpyAsync(&on, ctx->cull_popc_dev, sizeof(on), hipMemcpyDeviceToHost, ctx->stream));
+  if (ctx->cull_audit_density > 0) {
+    const LfLensDev& L = ctx->lens;
+    const LfApertureDev& m = ctx->ap[LF_APERTURE_STARBURST];
+    CullAuditArgs a;
+    std::memset(&a, 0, sizeof(a));
+    a.W = ctx->W; a.H = ctx->H; a.pitch = L.pitch; a.half_w = 0.5f * (float)ctx->W; a.half_h = 0.5f * (float)ctx->H;
+    a.blocks_x = ctx->cull_bx; a.blocks_y = ctx->cull_by; a.blk_log2 = ctx->cull_blk_log2;
+    a.share_n = ctx->cull_share_nb > 0 ? ctx->cull_share_n_resident : 1; a.share_nb = ctx->cull_share_nb;
+    a.P = ctx->cull_P; a.n_paths = ctx->pairs.n; a.n_lambda = L.n_lambda; a.march_k = ctx->march_k; a.prog_recs = ctx->pairs.prog_recs;
+    a.pupil_h = L.pupil_h; a.vz = L.pupil_z - L.z_sensor; a.geom_norm = L.geom_norm; a.inv_stop_h = 1.0f / L.stop_h;
+    a.lobe_thr = lf_march_lobe_thr(L);
+    a.mw = m.w; a.mh = m.h;
+    const uint64_t k = (ctx->cull_audit_seq++) * 0x9e3779b97f4a7c15ull ^ hash;
+    a.key = make_uint2((unsigned)k, (unsigned)(k >> 32));
+    a.density = ctx->cull_audit_density;
+    const dim3 grid((unsigned)((ctx->cull_cells + 255) / 256), (unsigned)(ctx->cull_bx * ctx->cull_by));
+    hipEvent_t ev = lf_timing_begin(ctx, LFK_CULL_AUDIT);
+    hipLaunchKernelGGL(k_cull_audit, grid, dim3(256), 0, ctx->stream, ctx->lens_dev, ctx->pairs_dev,
+                       (const int*)(ctx->prog_dev + ctx->prog_seq_off), (const LfProgRow*)(ctx->prog_dev + ctx->prog_rec_off),
+                       m.texels, a, ctx->cull_dev, ctx->cull_popc_dev + 1);
+    lf_timing_end(ctx, LFK_CULL_AUDIT, ev);
+    LF_HIP(ctx, hipGetLastError());
+  }
+  unsigned long long got[4] = {0ull, 0ull, 0ull, 0ull};
+  LF_HIP(ctx, hipMemcpyAsync(got, ctx->cull_popc_dev, sizeof(got), hipMemcpyDeviceToHost, ctx->stream));
   LF_HIP(ctx, hipStreamSynchronize(ctx->stream));
-  ctx->cull_started_fraction = (double)on / ((double)ctx->cull_bx * ctx->cull_by * (double)ctx->cull_cells * (double)std::max(1, ctx->pairs.n));
+  // a bring-up call the host gave up on (lf_comm_poison) publishes nothing: the table it waited for may never have arrived
+  if (ctx->comm_poisoned.load()) return lf_fail(ctx, LF_ERR_STATE, "cull table: the communicator was abandoned while the table was being completed");
+  ctx->cull_started_fraction = (double)got[0] / ((double)ctx->cull_bx * ctx->cull_by * (double)ctx->cull_cells * (double)std::max(1, ctx->pairs.n));
+  ctx->cull_audit_rays += got[1];
+  ctx->cull_audit_lit += got[2];
+  ctx->cull_hash = hash;
+  ctx->cull_bad_hash = 0;
+  if (got[2] != 0ull) {          // an audit ray of a dropped box reached the light: this table is not used
+    ctx->cull_bad_hash = hash;
+    ctx->cull_audit_tripped++;
+  }
   return LF_OK;
 }
 
 lf_status lfk_cull_prepass(lf_ctx* ctx, int G, int spp) {
   const LfLensDev& L = ctx->lens;
+  const lf_ctx::CullRules& R = ctx->cull_rules;
   CullLevelArgs a;
   std::memset(&a, 0, sizeof(a));
   a.W = ctx->W; a.H = ctx->H;
   a.pitch = L.pitch; a.half_w = 0.5f * (float)ctx->W; a.half_h = 0.5f * (float)ctx->H;
-  a.blk_log2 = kCullBlockLog2;
-  // 128-pixel blocks -- a quarter of the pre-pass's boxes, a looser table (4K: 3.5 % started against 2.2 %) -- where
-  // they are still small on the sensor AND the march is short enough for the pre-pass to matter: measured at 4K,
-  // 256 spp x 3 wavelengths tie (139.8 / 139.3 ms), 1024 x 8 lose (1035 against 761 ms): profiles/r05_march_variants.txt
-  if ((double)(2 << kCullBlockLog2) * (double)ctx->sensor_w_mm / (double)std::max(1, ctx->W) <= kCullBigBlockMm &&
-      (long long)spp * L.n_lambda < 768 && !std::getenv("LF_CULL_SMALL_BLOCKS"))
-    a.blk_log2 = kCullBlockLog2 + 1;
+  a.blk_log2 = lf_cull_block_log2(ctx, spp, L.n_lambda);
+  if (a.blk_log2 < 0) return lf_fail(ctx, LF_ERR_STATE, "cull pre-pass: no block size applies (lf_cull_applies comes first)");
   a.blocks_x = (ctx->W + (1 << a.blk_log2) - 1) >> a.blk_log2;
   a.blocks_y = (ctx->H + (1 << a.blk_log2) - 1) >> a.blk_log2;
   // a table shared between ranks: this one builds the rows of the blocks b with b % n == rank (lf_cull_row_of_block)
@@ -1020,7 +1472,8 @@ lf_status lfk_cull_prepass(lf_ctx* ctx, int G, int spp) {
   const int m = cull_m(ctx, G);
   a.P_final = G * m;
   a.n_paths = ctx->pairs.n;
-  // dispersion is monotonic in the wavelength: the two ends of the spectrum bracket what lies between
+  // dispersion is monotonic in the wavelength's column (lf_derive_lens checks it; otherwise the launch does not cull:
+  // LF_CULL_DISPERSION): the two ends of the spectrum bracket what lies between
   a.lam[0] = (L.n_lambda - 1) / 2; a.lam[1] = 0; a.lam[2] = L.n_lambda - 1;
   a.march_k = ctx->march_k; a.prog_recs = ctx->pairs.prog_recs;
   a.pupil_h = L.pupil_h; a.vz = L.pupil_z - L.z_sensor; a.geom_norm = L.geom_norm;
@@ -1032,43 +1485,41 @@ lf_status lfk_cull_prepass(lf_ctx* ctx, int G, int spp) {
     const double thr = 1.0 - (1.0625 / (double)L.sun_inv_one_minus_cos) * (1.0 + 1e-6) - 4e-7;
     a.rho = (float)(std::sqrt(2.0 * (1.0 - thr)) * 1.001 + 1e-5);
   }
-  float margin = ctx->cull_margin;
-  if (const char* e = std::getenv("LF_CULL_MARGIN")) { const double v = std::atof(e); if (v > 0.0) margin = (float)v; }
   std::memcpy(a.occ, ctx->cull_occ, sizeof(a.occ));
-  a.keep_partial = std::getenv("LF_CULL_KEEP_PARTIAL") ? std::atoi(std::getenv("LF_CULL_KEEP_PARTIAL")) : 0;
-  a.lost_rel = std::getenv("LF_CULL_LOST_REL") ? (float)std::atof(std::getenv("LF_CULL_LOST_REL")) : 0.5f;
-  a.lost_abs = std::getenv("LF_CULL_LOST_ABS") ? (float)std::atof(std::getenv("LF_CULL_LOST_ABS")) : 0.002f;
-  a.strict = std::getenv("LF_CULL_STRICT") ? std::atoi(std::getenv("LF_CULL_STRICT")) : 1;
-  a.lobe_k = std::getenv("LF_CULL_LOBE_K") ? (float)std::atof(std::getenv("LF_CULL_LOBE_K")) : 1.2f;
-  a.strict_lost = std::getenv("LF_CULL_STRICT_LOST") ? std::atoi(std::getenv("LF_CULL_STRICT_LOST")) : 1;
-  a.slack_mode = std::getenv("LF_CULL_SLACK") ? std::atoi(std::getenv("LF_CULL_SLACK")) : 1;
-  a.disable = std::getenv("LF_CULL_DISABLE") ? std::atoi(std::getenv("LF_CULL_DISABLE")) : 0;
-  // the levels: P_final, halved while it stays even and >= 8 (a coarser box is too curved for 13 rays to bound)
+  a.keep_partial = R.keep_partial; a.lost_rel = R.lost_rel; a.lost_abs = R.lost_abs; a.strict = R.strict; a.lobe_k = R.lobe_k;
+  a.strict_lost = R.strict_lost; a.slack_mode = R.slack_mode; a.disable = R.disable;
+  // the levels: P_final, halved while it stays even and >= 8 (a coarser box is too curved for 15 rays to bound)
   int levels[8], n_levels = 0;
   {
     int P = a.P_final;
     levels[n_levels++] = P;
     int coarsest = 8;
-    if (const char* e = std::getenv("LF_CULL_P0")) coarsest = std::max(2, std::atoi(e));   // experiments only
+#ifdef LF_EXPERIMENTS
+    if (const char* e = std::getenv("LF_CULL_P0")) coarsest = std::max(2, std::atoi(e));
+#endif
     while (n_levels < 8 && P % 2 == 0 && P / 2 >= coarsest) { P /= 2; levels[n_levels++] = P; }
     std::reverse(levels, levels + n_levels);
   }
 
   // is the resident table the one these inputs give?
   uint64_t h = 0xcbf29ce484222325ull;
-  a.margin = margin;
+  a.margin = R.margin;
   h = fnv(h, &a, sizeof(a));
   h = fnv(h, levels, sizeof(int) * (size_t)n_levels);
   h = fnv(h, &L, sizeof(L));
   h = fnv(h, ctx->pairs.ij, sizeof(int) * 2 * (size_t)ctx->pairs.n);
   h = fnv(h, &ctx->mask_generation, sizeof(ctx->mask_generation));
+  h = fnv(h, &ctx->cull_rules_custom, sizeof(ctx->cull_rules_custom));
   if (h == 0) h = 1;
   const size_t nblk = (size_t)a.blocks_x * a.blocks_y;
   const size_t rows = (size_t)a.share_nb * (size_t)a.share_n;         // (= nblk unless shared: equal slabs, the last ones padded)
   const size_t row_entries = (size_t)a.P_final * a.P_final + 1;
   const size_t entries = rows * row_entries;
   // (mode 2 rebuilds at every launch -- except the table lf_cull_commit has just completed for this very launch)
-  const bool reuse = (ctx->march_cull == 1 || ctx->cull_fresh) && ctx->cull_dev && ctx->cull_hash == h && !std::getenv("LF_CULL_NO_REUSE");
+  bool reuse = (ctx->march_cull == 1 || ctx->cull_fresh) && ctx->cull_dev && ctx->cull_hash == h;
+#ifdef LF_EXPERIMENTS
+  if (std::getenv("LF_CULL_NO_REUSE")) reuse = false;
+#endif
   ctx->cull_fresh = false;
   ctx->cull_bx = a.blocks_x; ctx->cull_by = a.blocks_y; ctx->cull_cells = a.P_final * a.P_final; ctx->cull_G = G;
   ctx->cull_P = a.P_final; ctx->cull_m = m; ctx->cull_blk_log2 = a.blk_log2;
@@ -1088,9 +1539,9 @@ lf_status lfk_cull_prepass(lf_ctx* ctx, int G, int spp) {
   if (!ctx->cull_counts) LF_HIP(ctx, hipMalloc((void**)&ctx->cull_counts, 8 * kCullMaxPaths * sizeof(unsigned)));
   ctx->cull_hash = 0;
   unsigned long long* stats_dev = nullptr;
-  if (std::getenv("LF_CULL_STATS")) {
-    LF_HIP(ctx, hipMalloc((void**)&stats_dev, 32 * sizeof(unsigned long long)));
-  }
+#ifdef LF_EXPERIMENTS
+  if (std::getenv("LF_CULL_STATS")) LF_HIP(ctx, hipMalloc((void**)&stats_dev, 32 * sizeof(unsigned long long)));
+#endif
   hipEvent_t ev = lf_timing_begin(ctx, LFK_CULL);
   LF_HIP(ctx, hipMemsetAsync(ctx->cull_dev, 0, entries * sizeof(unsigned long long), ctx->stream));
   LF_HIP(ctx, hipMemsetAsync(ctx->cull_counts, 0, 8 * kCullMaxPaths * sizeof(unsigned), ctx->stream));
@@ -1098,21 +1549,12 @@ lf_status lfk_cull_prepass(lf_ctx* ctx, int G, int spp) {
   for (int lv = 0; lv < n_levels; lv++) {
     a.P = levels[lv];
     a.last = lv + 1 == n_levels ? 1 : 0;
-    // coarse boxes are more curved than 13 rays show: more inflation the larger the pupil cell
-    // The ball of a box that lost samples and the dispersion slack grow with the level; the zonotope's generators are
-    // inflated by the same factor at every level: lowered one level at a time, each loses its first lit ray between
-    // x 0.9 and x 1.0 (a zonotope is EXACT for the linear part of the map, the measured slack covers the rest), so
-    // x 1.25 keeps the same factor 1.3 everywhere -- the x 2 / 1.4 / 1.15 the coarse levels carried until then cost
-    // 1.6 ms of pre-pass and bought nothing on any frame of the scans (profiles/r05_march_variants.txt)
-    a.margin = margin * (a.P >= 64 ? 1.0f : a.P >= 32 ? 1.15f : a.P >= 16 ? 1.4f : 2.0f);
-    a.geo_margin = margin;
-    if (const char* e = std::getenv("LF_CULL_GEO_MARGIN")) a.geo_margin = (float)std::atof(e) * (a.P >= 64 ? 1.0f : a.P >= 32 ? 1.15f : a.P >= 16 ? 1.4f : 2.0f);
-    if (const char* e = std::getenv("LF_CULL_LEVEL_MARGINS")) {   // "m8,m16,m32": absolute generator margins of the coarse levels
-      float m8 = 0, m16 = 0, m32 = 0;
-      if (std::sscanf(e, "%f,%f,%f", &m8, &m16, &m32) == 3 && !a.last) a.geo_margin = a.P >= 32 ? m32 : a.P >= 16 ? m16 : m8;
-    }
-    if (const char* e = std::getenv("LF_CULL_GEO_MARGIN_LAST")) { if (a.last) a.geo_margin = (float)std::atof(e); }
-    if (const char* e = std::getenv("LF_CULL_GEO_MARGIN_COARSE")) { if (!a.last) a.geo_margin = (float)std::atof(e) * (a.P >= 64 ? 1.0f : a.P >= 32 ? 1.15f : a.P >= 16 ? 1.4f : 2.0f); }
+    // The ball and the dispersion slack grow with the level (a coarse box is more curved than 15 rays show); the zonotope's
+    // generators are inflated by the same factor at every level: lowered one level at a time, each loses its first lit ray
+    // between x 0.9 and x 1.0 (a zonotope is EXACT for the linear part of the map, the measured slack covers the rest:
+    // profiles/r05_march_variants.txt)
+    a.margin = R.margin * (a.P >= 64 ? 1.0f : a.P >= 32 ? 1.15f : a.P >= 16 ? 1.4f : 2.0f);
+    a.geo_margin = R.margin;
     const size_t n_mine = (nblk + (size_t)a.share_n - 1 - (size_t)a.share_rank) / (size_t)a.share_n;   // blocks this rank builds
     const size_t n_items = lv == 0 ? n_mine * (size_t)a.P * a.P : (size_t)max_items;
     if (n_items == 0) break;
@@ -1145,13 +1587,16 @@ lf_status lfk_cull_prepass(lf_ctx* ctx, int G, int spp) {
 
     // (two strides are needed when reading AND writing: the input's travels in `items_stride`)
     const dim3 grid((unsigned)((n_items + LF_CULL_WG - 1) / LF_CULL_WG), (unsigned)a.n_paths);
-    hipLaunchKernelGGL(k_cull_level, grid, dim3(LF_CULL_WG), 0, ctx->stream, ctx->lens_dev, ctx->pairs_dev,
-                       (const int*)(ctx->prog_dev + ctx->prog_seq_off), (const LfProgRow*)(ctx->prog_dev + ctx->prog_rec_off),
-                       k, items, lv == 0 ? nullptr : ctx->cull_counts + (size_t)(lv - 1) * kCullMaxPaths, in_stride, next,
-                       ctx->cull_counts + (size_t)lv * kCullMaxPaths, ctx->cull_dev, stats_dev);
+#define LF_LAUNCH_LEVEL(KERNEL)                                                                                                     \
+    hipLaunchKernelGGL(KERNEL, grid, dim3(LF_CULL_WG), 0, ctx->stream, ctx->lens_dev, ctx->pairs_dev,                                 \
+                       (const int*)(ctx->prog_dev + ctx->prog_seq_off), (const LfProgRow*)(ctx->prog_dev + ctx->prog_rec_off),        \
+                       k, items, lv == 0 ? nullptr : ctx->cull_counts + (size_t)(lv - 1) * kCullMaxPaths, in_stride, next,           \
+                       ctx->cull_counts + (size_t)lv * kCullMaxPaths, ctx->cull_dev, stats_dev)
+    if (ctx->cull_rules_custom) LF_LAUNCH_LEVEL(k_cull_level_general); else LF_LAUNCH_LEVEL(k_cull_level);
+#undef LF_LAUNCH_LEVEL
     LF_HIP(ctx, hipGetLastError());
     a.list_stride = out_stride;
-    if (stats_dev) {   // experiments only: why the boxes of this level ended as they did, per tested wavelength
+    if (stats_dev) {   // experiments only: why the boxes of this level ended as they did
       unsigned long long hs[32];
       LF_HIP(ctx, hipStreamSynchronize(ctx->stream));
       std::fprintf(stderr, "CULL_LEVEL P %d items_per_path_max %zu ms %.3f\n", a.P, n_items,
@@ -1170,8 +1615,8 @@ lf_status lfk_cull_prepass(lf_ctx* ctx, int G, int spp) {
       for (int q = 0; q < a.n_paths; q++) max_items = std::max(max_items, std::min(cnt[q], out_stride));
     }
   }
-  // (LF_COMM_FORCE_EXCHANGE: tests only -- the collective also with a single rank, as lf_comm_gather does)
-  if (ctx->cull_share_how == 1 && (shared || std::getenv("LF_COMM_FORCE_EXCHANGE"))) {
+  // (comm_force_exchange: tests only -- the collective also with a single rank, as lf_comm_gather does)
+  if (ctx->cull_share_how == 1 && (shared || ctx->comm_force_exchange)) {
     // every rank has built its slab: one in-place all-gather completes the table everywhere
     const lf_status st = lf_comm_allgather_u64_inplace(ctx, ctx->cull_dev, (size_t)a.share_nb * row_entries);
     if (st != LF_OK) return st;
@@ -1182,12 +1627,7 @@ lf_status lfk_cull_prepass(lf_ctx* ctx, int G, int spp) {
     ctx->cull_hash_pending = h;
     return LF_OK;
   }
-  {
-    const lf_status st = lfk_cull_finish(ctx);
-    if (st != LF_OK) return st;
-  }
-  ctx->cull_hash = h;
-  return LF_OK;
+  return lfk_cull_finish(ctx, h);
 }
 
 lf_status lfk_march_culled(lf_ctx* ctx, const MarchArgs& a, size_t blocks, size_t dyn_lds) {
@@ -1196,6 +1636,7 @@ lf_status lfk_march_culled(lf_ctx* ctx, const MarchArgs& a, size_t blocks, size_
   c.table = ctx->cull_dev; c.blocks_x = ctx->cull_bx; c.blocks_y = ctx->cull_by; c.cells = ctx->cull_cells;
   c.share_n = ctx->cull_share_nb > 0 ? ctx->cull_share_n_resident : 1; c.share_nb = ctx->cull_share_nb;
   c.blk_log2 = ctx->cull_blk_log2;
+  c.multi = ctx->cull_blk_log2 < 3 + a.xs ? 1 : 0;
   c.P = ctx->cull_P; c.m = ctx->cull_m; c.m_shift = ctx->cull_m == 4 ? 2 : ctx->cull_m == 2 ? 1 : 0;
   hipEvent_t ev = lf_timing_begin(ctx, LFK_MARCH);
 #define LF_LAUNCH_CULL1(KK, WW)                                                                               \
@@ -1211,11 +1652,13 @@ lf_status lfk_march_culled(lf_ctx* ctx, const MarchArgs& a, size_t blocks, size_
                      (const LfWeightRow*)(ctx->prog_dev + ctx->prog_wrec_off), m.texels, a, c, ctx->ghost,   \
                      ctx->accum, ctx->counters_dev)
 #define LF_LAUNCH_CULL(KK) do { if (items) LF_LAUNCH_ITEMS(KK); else if (weights_first) LF_LAUNCH_CULL1(KK, true); else LF_LAUNCH_CULL1(KK, false); } while (0)
-  const bool weights_first = std::getenv("LF_CULL_WEIGHTS_FIRST") != nullptr;   // experiments only
+  const bool weights_first = ctx->cull_weights_first;   // (lf_test_knob: the weight on every executed event)
   // every pixel its own pupil point (no sub-cells at all): the compacted march.  (2 x 2 sub-cells, where the lanes of a
   // wave still look their cells up one by one, stay with k_march_cull: 48 against 59 ms on the bench frame)
   bool items = ctx->march_sub_bits == 0;
-  if (const char* e = std::getenv("LF_CULL_ITEMS")) items = std::atoi(e) != 0;   // experiments only
+#ifdef LF_EXPERIMENTS
+  if (const char* e = std::getenv("LF_CULL_ITEMS")) items = std::atoi(e) != 0;
+#endif
   switch (ctx->march_k) {
     case 1: LF_LAUNCH_CULL(1); break;
     case 2: LF_LAUNCH_CULL(2); break;

@@ -195,7 +195,7 @@ ExchangePlan exchange_plan(lf_ctx* ctx, int world) {
 }
 
 // tests only: run the whole exchange (pack, all-gather, unpack) even with a single rank
-bool force_exchange() { return std::getenv("LF_COMM_FORCE_EXCHANGE") != nullptr; }
+bool force_exchange(const lf_ctx* ctx) { return ctx->comm_force_exchange; }   // (lf_test_knob)
 
 }  // namespace
 
@@ -312,7 +312,7 @@ lf_status lf_comm_gather(lf_ctx* ctx, int which) {
   const int world = ctx->comm_nranks, rank = ctx->comm_rank;
   lf_status st = check_gather_args(ctx, which, world);
   if (st != LF_OK) return st;
-  if (world == 1 && !force_exchange()) return LF_OK;
+  if (world == 1 && !force_exchange(ctx)) return LF_OK;
   Rccl* r = rccl();
   LF_HIP(ctx, hipSetDevice(ctx->device));
   if ((st = lf_comm_join(ctx)) != LF_OK) return st;     // an asynchronous exchange uses the same staging
@@ -343,7 +343,7 @@ lf_status lf_comm_gather_async(lf_ctx* ctx, int which) {
   const int world = ctx->comm_nranks, rank = ctx->comm_rank;
   lf_status st = check_gather_args(ctx, which, world);
   if (st != LF_OK) return st;
-  if (world == 1 && !force_exchange()) return LF_OK;
+  if (world == 1 && !force_exchange(ctx)) return LF_OK;
   Rccl* r = rccl();
   LF_HIP(ctx, hipSetDevice(ctx->device));
   if (!ctx->comm_stream) {

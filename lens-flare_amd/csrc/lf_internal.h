@@ -5,6 +5,7 @@
 #include <hip/hip_runtime.h>
 
 #include <atomic>
+#include <cmath>
 #include <cstdint>
 #include <mutex>
 #include <string>
@@ -211,7 +212,7 @@ enum { LF_EV_REST1 = 8, LF_EV_SAVE0 = 0x10, LF_EV_SAVE1 = 0x20, LF_EV_END = 0x40
 // sensor blocks of 2^6 = 64 or 2^7 = 128 pixels a side (lf_cull_block_log2): a wave tile of any stride lies inside one;
 // 128 where that is still <= 1.25 mm on the sensor (4K on 36 mm: the blocks of 1080p in millimetres, a quarter of the
 // pre-pass's boxes) and the launch has few samples (lfk_cull_prepass)
-constexpr int kCullBlockLog2 = 6;
+constexpr int kCullBlockLog2 = 6;          // ... 5 or 4 (32 / 16 pixels) on frames whose 64 pixels are too large on the sensor
 constexpr double kCullBigBlockMm = 1.25;
 constexpr int kCullMaxPaths = 64;        // bits of a mask
 constexpr double kCullMaxBlockMm = 1.8;  // a block may be this large on the sensor at most (lf_cull_applies)
@@ -226,6 +227,7 @@ __host__ __device__ inline size_t lf_cull_row_of_block(int b, int share_n, int s
 struct LfCullArgs {
   const unsigned long long* table;   // [rows][cells + 1], row = lf_cull_row_of_block(block); null = every path everywhere
   int blocks_x, blocks_y;
+  int multi;                          // a wave tile spans several blocks (blocks of 16 / 32 pixels under a 64-pixel tile): rows per lane
   int share_n, share_nb;              // see lf_cull_row_of_block
   int blk_log2;                       // log2 of a block's side in pixels
   int cells;                          // P * P, P = G * m cells per axis of the pupil square
@@ -276,7 +278,7 @@ constexpr int kSceneCounters = 4;
 
 // ---- timing ---------------------------------------------------------------------------------
 enum LfKernelId { LFK_MARCH = 0, LFK_FLARE_LAYER, LFK_GHOST_RASTER, LFK_DFT, LFK_FRAME_SETUP,
-                  LFK_TONEMAP, LFK_EXCHANGE, LFK_SCENE, LFK_CULL, LFK_COUNT };
+                  LFK_TONEMAP, LFK_EXCHANGE, LFK_SCENE, LFK_CULL, LFK_CULL_AUDIT, LFK_COUNT };
 
 struct LfTimedLaunch { int kernel; hipEvent_t start, stop; };
 
@@ -407,7 +409,31 @@ struct lf_ctx {
   double cull_max_fraction = 0.10;             // + 1.6 / paths: see lfk_march
   uint64_t cull_hash = 0;                      // of the inputs the resident table was built from (0 = none)
   int cull_bx = 0, cull_by = 0, cull_cells = 0, cull_G = 0, cull_P = 0, cull_blk_log2 = 6;
-  float cull_margin = 1.25f;                   // footprint inflation of the pre-pass (LF_CULL_MARGIN: experiments)
+  // The pre-pass's rules.  What ships is ONE set (lf_cull.hip k_cull_level, constants in the kernel); a test may install
+  // another through lf_test_knob ("cull_strict", ...: the rules round 5 replaced, kept to show what the audit is for) --
+  // the table is then built by k_cull_level_general, which reads them from here.
+  struct CullRules {
+    float margin = 1.25f;        // footprint inflation
+    int strict = 1, strict_lost = 1, slack_mode = 1, keep_partial = 0, disable = 0;
+    float lobe_k = 1.2f, lost_rel = 0.5f, lost_abs = 0.002f;
+  } cull_rules;
+  bool cull_rules_custom = false;              // a test installed rules / asked for the general kernel (lf_test_knob)
+  bool cull_force = false;                     // lf_test_knob("cull_force"): the culled kernel whatever the table starts
+  bool cull_weights_first = false;             // lf_test_knob("cull_weights_first"): k_march_cull<K, true>
+  int scene_compact = -1;                      // lf_test_knob("scene_compact"): -1 = by the tree's size, 0 / 1 forced
+  bool comm_force_exchange = false;            // lf_test_knob("comm_force_exchange"): the collectives also with one rank
+  int scene_lens_strided = -1;                 // lf_test_knob("scene_lens_strided"): k_scene_lens's wave tile: -1 by the tree's size, 0 / 1
+  bool bvh_median = false;                     // lf_test_knob("bvh_median"): the round-2 median-split tree (A/B of the SAH tree)
+  int bvh_leaf_max = 2;                        // lf_test_knob("bvh_leaf"): primitives per leaf at most (1 .. 4)
+  // the audit of what the table drops (lf_cull.hip k_cull_audit): rays per dropped (block, cell, path), 0 = off
+  int cull_audit_density = 1;
+  unsigned long long* cull_audit_dev = nullptr;   // {rays, lit} of the table being completed
+  unsigned long long cull_audit_rays = 0, cull_audit_lit = 0;   // since lf_reset_counters
+  int cull_audit_tripped = 0;                  // launches since lf_reset_counters whose table an audit ray refuted
+  uint64_t cull_bad_hash = 0;                  // the resident table was refuted: its launches march everything
+  int cull_reason = 0;                         // why the last launch did (not) cull: lf_cull_reason
+  uint64_t cull_audit_seq = 0;                 // tables audited by this context: keys the audit's rays
+  bool lens_lambda_monotonic = true;           // every glass disperses the same way along the wavelength columns (lf_derive_lens)
   unsigned cull_occ[kCullOcc] = {};            // occupancy of the stop mask (host, lf_set_aperture)
   uint64_t mask_generation = 0;                // bumped by lf_set_aperture(STARBURST)
   bool last_march_culled = false;              // what the last lf_trace_ghosts ran
@@ -455,6 +481,17 @@ void lf_timing_end(lf_ctx* ctx, int kernel, hipEvent_t start, hipStream_t stream
       return lf_fail(ctx, LF_ERR_HIP, std::string(#expr) + ": " + hipGetErrorString(e_));     \
   } while (0)
 
+// candidate selection of the march (the contract, the same expression in oracle/lf_geo_oracle.c): d.s above
+// 1 - 1.0625 (1 - cos alpha) - 4e-7 MAY lie inside the lobe.  The 1/16 margin is relative, the 4e-7 absolute: the float
+// dot product of two unit vectors is only good to ~2e-7, so a relative margin alone loses part of a sub-milliradian
+// sun's lobe (1 - cos(0.8 mrad) = 3.2e-7).  Rounded down: float(thr) never exceeds thr.
+inline float lf_march_lobe_thr(const LfLensDev& L) {
+  const double thr = 1.0 - (1.0625 / (double)L.sun_inv_one_minus_cos) * (1.0 + 1e-6) - 4e-7;
+  float t = (float)thr;
+  if ((double)t > thr) t = std::nextafterf(t, -2.0f);
+  return t;
+}
+
 // the flare layer calls the reference's own pow() (exact) or its cheaper equivalents (fast): DESIGN.md section 3
 inline bool lf_flare_exact(const lf_ctx* ctx) {
   return ctx->flare_arithmetic == 1 || (ctx->flare_arithmetic == 0 && ctx->jitter_mode == 0);
@@ -491,8 +528,10 @@ int lf_march_fix_bits(const LfLensDev& L, int n_paths, int spp);
 // lf_cull.hip (a = the launch's arguments as lfk_march set them up: lf_march_common.h)
 namespace lfm { struct MarchArgs; }
 bool lf_cull_applies(const lf_ctx* ctx, int G);
+int lf_cull_reason_of(const lf_ctx* ctx, int G);                       // lf_cull_reason: LF_CULL_APPLIED or why not
+int lf_cull_block_log2(const lf_ctx* ctx, int spp, int n_lambda);      // log2 of a cull block's side in pixels (-1: none applies)
 lf_status lfk_cull_prepass(lf_ctx* ctx, int G, int spp);
-lf_status lfk_cull_finish(lf_ctx* ctx);
+lf_status lfk_cull_finish(lf_ctx* ctx, uint64_t hash);
 lf_status lfk_cull_prepare(lf_ctx* ctx, int spp);   // lf_march.hip          // the table is complete: count what it starts
 // lf_group.hip: in-place all-gather of equal slabs of u64 on the communicator's stream, ordered after what the main
 // stream has queued and before what it queues next

@@ -782,6 +782,20 @@ void lf_derive_lens(lf_ctx* ctx, int n, int stop, int n_lambda, const float* rad
     }
     L.n_start[l] = n_before;   // the medium between the last interface and the sensor
   }
+  // do all glasses disperse the same way along the wavelength columns?  (the cull's pre-pass brackets the spectrum by
+  // its first and last column: lf_cull.hip; a table with a column out of order marches everything instead)
+  ctx->lens_lambda_monotonic = true;
+  {
+    int way = 0;
+    for (int k = 0; k < n; k++)
+      for (int l = 0; l + 1 < n_lambda; l++) {
+        const float d = ior[(l + 1) * n + k] - ior[l * n + k];
+        if (k == stop || d == 0.0f) continue;
+        const int w = d > 0.0f ? 1 : -1;
+        if (way == 0) way = w;
+        else if (w != way) ctx->lens_lambda_monotonic = false;
+      }
+  }
   ctx->sensor_w_mm = sensor_w_mm;
   L.pitch = sensor_w_mm / (float)ctx->W;  // refreshed at every launch: the frame may be resized
   for (int k = 0; k < n; k++) ctx->raw_semi_ap[k] = semi_ap[k];
@@ -982,10 +996,12 @@ lf_status lf_build_march_tables(lf_ctx* ctx, std::vector<LfEventRow>& rows, std:
 // spot between sharing the scalar walk and keeping 6 waves per SIMD; four wavelengths go as 2 + 2.
 static int rays_per_lane(int n_lambda) {
   int k = n_lambda == 4 ? 2 : std::min(n_lambda, 3);
-  if (const char* kv = std::getenv("LF_MARCH_K")) {  // experiments only
+#ifdef LF_EXPERIMENTS
+  if (const char* kv = std::getenv("LF_MARCH_K")) {
     int v = std::atoi(kv);
     if (v >= 1 && v <= 3) k = v;
   }
+#endif
   return k;
 }
 
@@ -1181,17 +1197,7 @@ lf_status lfk_march(lf_ctx* ctx, int spp, uint64_t key) {
   a.vz = ctx->lens.pupil_z - ctx->lens.z_sensor;
   a.accumulate = ctx->ghost_accumulate ? 1 : 0;
   a.xs = ctx->march_xstride_log2;
-  {
-    // candidate selection (the contract, the same expression in oracle/lf_geo_oracle.c): d.s above
-    // 1 - 1.0625 (1 - cos alpha) - 4e-7 MAY lie inside the lobe.  The 1/16 margin is relative, the
-    // 4e-7 absolute: the float dot product of two unit vectors is only good to ~2e-7, so a relative
-    // margin alone (the round-1 float test (1 - d.s) * inv < 1.0625) loses part of a sub-milliradian
-    // sun's lobe (1 - cos(0.8 mrad) = 3.2e-7).  Rounded down: float(thr) never exceeds thr.
-    const double thr = 1.0 - (1.0625 / (double)ctx->lens.sun_inv_one_minus_cos) * (1.0 + 1e-6) - 4e-7;
-    float t = (float)thr;
-    if ((double)t > thr) t = std::nextafterf(t, -2.0f);
-    a.lobe_thr = t;
-  }
+  a.lobe_thr = lf_march_lobe_thr(ctx->lens);      // candidate selection (the contract: lf_internal.h)
   // tile rows (8 sensor rows each) of the band that belong to this context's interleave phase
   const int t_lo = ctx->y0 / 8, t_hi = (ctx->y1 + 7) / 8;  // [t_lo, t_hi)
   const int period = ctx->row_period, phase = ctx->row_phase;
@@ -1209,10 +1215,12 @@ lf_status lfk_march(lf_ctx* ctx, int spp, uint64_t key) {
   a.sgroups = 1;
   while (tiles * a.sgroups < 8000 && a.sgroups * 2 * 64 <= spp) a.sgroups *= 2;
   if (a.sgroups == 1 && tiles < 20000 && 2 * 64 <= spp) a.sgroups = 2;
-  if (const char* sgv = std::getenv("LF_MARCH_SGROUPS")) {  // experiments only
+#ifdef LF_EXPERIMENTS
+  if (const char* sgv = std::getenv("LF_MARCH_SGROUPS")) {
     int v = std::atoi(sgv);
     if (v >= 1 && v * 4 <= std::max(4, spp) && (v & (v - 1)) == 0) a.sgroups = v;
   }
+#endif
   a.n_tiles = (int)tiles;
   const size_t blocks = ((tiles + 63) / 64 * 64) * a.sgroups;
   if (blocks > 0x7fffffffull) return lf_fail(ctx, LF_ERR_INVALID, "band too large for one launch");
@@ -1226,7 +1234,9 @@ lf_status lfk_march(lf_ctx* ctx, int spp, uint64_t key) {
   // experiments only: unused dynamic LDS caps the workgroups a CU holds (occupancy sweeps,
   // profiles/r03_march_variants.txt)
   size_t dyn_lds = 0;
+#ifdef LF_EXPERIMENTS
   if (const char* dl = std::getenv("LF_MARCH_DYN_LDS")) dyn_lds = (size_t)std::max(0, std::atoi(dl));
+#endif
 #ifdef LF_MARCH_LIT_MAP
   static unsigned long long* lit_dev[8] = {};
   static size_t lit_n[8] = {};
@@ -1260,7 +1270,8 @@ lf_status lfk_march(lf_ctx* ctx, int spp, uint64_t key) {
     LF_HIP(ctx, hipGetLastError());
   }
   // the paths a pre-pass found able to reach the light (lf_cull.hip) -- or every path of every sample
-  ctx->last_march_culled = lf_cull_applies(ctx, a.G);
+  ctx->cull_reason = lf_cull_reason_of(ctx, a.G);
+  ctx->last_march_culled = ctx->cull_reason == LF_CULL_APPLIED;
   if (ctx->last_march_culled) {
     lf_status st = lfk_cull_prepass(ctx, a.G, spp);
     if (st != LF_OK) return st;
@@ -1269,7 +1280,10 @@ lf_status lfk_march(lf_ctx* ctx, int spp, uint64_t key) {
     // (shared legs: 85 at n = 46, 53 at n = 21), the culled march ~10.5 per STARTED path plus a pre-pass worth 0.3 of
     // its time -- equal at a started fraction of 0.10 + 1.6 / n (0.135 at 46 paths, 0.18 at 21: measured on c3 / c2).
     const double meet = std::min(0.5, ctx->cull_max_fraction + 1.6 / (double)std::max(1, ctx->pairs.n));
-    if (ctx->cull_started_fraction > meet && !std::getenv("LF_CULL_FORCE")) ctx->last_march_culled = false;
+    if (ctx->cull_started_fraction > meet && !ctx->cull_force) ctx->cull_reason = LF_CULL_TABLE_TOO_FULL;
+    // a table its audit refuted is not used, whatever a test asks for
+    if (ctx->cull_bad_hash != 0 && ctx->cull_bad_hash == ctx->cull_hash) ctx->cull_reason = LF_CULL_AUDIT_REFUTED;
+    ctx->last_march_culled = ctx->cull_reason == LF_CULL_APPLIED;
   }
   if (ctx->last_march_culled) {
     lf_status st = lfk_march_culled(ctx, a, blocks, dyn_lds);

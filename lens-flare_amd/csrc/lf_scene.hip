@@ -1030,11 +1030,9 @@ lf_status lf_set_scene(lf_ctx* ctx, int n_spheres, const double* spheres, const 
   std::vector<LfBvhNode> nodes;
   Box root = empty_box();
   if (!prims.empty()) {
-    const char* how = std::getenv("LF_BVH_SPLIT");   // "median": the round-2 tree (A/B measurements)
     int depth = 0;
-    bool sah = !(how && std::strcmp(how, "median") == 0);
-    const char* lm = std::getenv("LF_BVH_LEAF");
-    const int leaf_max = lm ? std::min(4, std::max(1, std::atoi(lm))) : 2;
+    bool sah = !ctx->bvh_median;                                       // (lf_test_knob: the round-2 tree, A/B measurements)
+    const int leaf_max = std::min(4, std::max(1, ctx->bvh_leaf_max));
     // the SAH may use 64 levels (a well-behaved scene needs ~log2(n) + a few); below them a subtree is
     // built by median splits: the host recursion is bounded by 64 + log2(n) frames whatever the scene, and a
     // tree that ends up deeper than the device's stack is rebuilt by median splits alone (below)
@@ -1310,13 +1308,12 @@ lf_status lf_render_scene_term(lf_ctx* ctx) {
                      ctx->row_phase, ctx->row_period, lens_mxs, lc, ctx->primary_dev,                      \
                      ctx->ap[LF_APERTURE_STARBURST].texels, ctx->scene_counters_dev, ctx->scene)
   // a small tree is resident in the caches whichever lanes walk it: the wave takes the march's strided tile (see the
-  // kernel); LF_SCENE_LENS_STRIDED = 0 / 1 forces the choice (measurements)
+  // kernel)
   int lens_mxs = ctx->scene_dev.n_prims <= kLensStridedMaxPrims ? lc.xs : 0;
-  if (const char* e = std::getenv("LF_SCENE_LENS_STRIDED")) lens_mxs = std::atoi(e) ? lc.xs : 0;
+  if (ctx->scene_lens_strided >= 0) lens_mxs = ctx->scene_lens_strided ? lc.xs : 0;     // (lf_test_knob)
   const int lens_tiles_x = ((ctx->W + (8 << lens_mxs) - 1) >> (3 + lens_mxs)) << lens_mxs;   // wave tiles along x
-  // (LF_SCENE_COMPACT=0: the round-4 kernel, one traversal per lane's own sample -- kept as the A/B of the tests)
-  const char* cenv = std::getenv("LF_SCENE_COMPACT");      // (read per call: the tests switch it between two frames)
-  const bool compact = !(cenv && atoi(cenv) == 0);
+  // (lf_test_knob("scene_compact", 0): the round-4 kernel, one traversal per lane's own sample -- kept as the A/B of the tests)
+  const bool compact = ctx->scene_compact != 0;
   if (lens && compact) { if (soft) LF_LAUNCH_SCENE_LENS(true); else LF_LAUNCH_SCENE_LENS(false); }
   else if (lens) { if (soft) LF_LAUNCH_SCENE(true, true); else LF_LAUNCH_SCENE(false, true); }
   else { if (soft) LF_LAUNCH_SCENE(true, false); else LF_LAUNCH_SCENE(false, false); }

@@ -358,7 +358,7 @@ static int g64_cull_bx = 0, g64_cull_cells = 0, g64_cull_shift = 6;
 void g64_set_cull(const uint64_t* table, int blocks_x, int blocks_y, int cells, int block_px) {
   (void)blocks_y;
   g64_cull = table; g64_cull_bx = blocks_x; g64_cull_cells = cells;
-  g64_cull_shift = block_px == 128 ? 7 : 6;
+  g64_cull_shift = block_px == 128 ? 7 : block_px == 32 ? 5 : block_px == 16 ? 4 : 6;
 }
 
 /* image, frag: W*H*3 doubles (rows [y0, y1) are written); counters: launched, events, clipped at

@@ -404,7 +404,7 @@ void geo_lens_samples(const geo_lens* L, int W, int H, int ns, const uint32_t ke
 
 /* The device's path culling (lens-flare_amd/csrc/lf_cull.hip, lf_get_cull_table): table[block][cell] = mask of the
  * paths the device STARTS for sample cell `cell` (its pupil stratum s < G*G, else entry `cells`) of the pixels of
- * sensor block (x / block_px, y / block_px), block_px = 64 or 128.  With a table installed geo_trace still marches EVERY path -- its pixels are the
+ * sensor block (x / block_px, y / block_px), block_px = 16, 32, 64 or 128.  With a table installed geo_trace still marches EVERY path -- its pixels are the
  * full enumeration's, so that equality with the device's pixels proves that nothing the device skipped could
  * have contributed -- but its counters count only the rays the device starts; culled_lit tallies skipped rays
  * that did reach the light (must stay 0). */
@@ -413,7 +413,7 @@ static int g_cull_bx = 0, g_cull_by = 0, g_cull_cells = 0, g_cull_shift = 6;
 static uint64_t g_culled_lit = 0;
 void geo_set_cull(const uint64_t* table, int blocks_x, int blocks_y, int cells, int block_px) {
   g_cull = table; g_cull_bx = blocks_x; g_cull_by = blocks_y; g_cull_cells = cells;
-  g_cull_shift = block_px == 128 ? 7 : 6;
+  g_cull_shift = block_px == 128 ? 7 : block_px == 32 ? 5 : block_px == 16 ? 4 : 6;
 }
 uint64_t geo_culled_lit(void) { return g_culled_lit; }
 

@@ -286,7 +286,7 @@ def _device_cull(cull, W, H, spp):
         G += 1
     while G * G > spp:
         G -= 1
-    want = {((H + bp - 1) // bp, (W + bp - 1) // bp, (G * m) ** 2 + 1): bp for bp in (128, 64) for m in (1, 2, 4)}
+    want = {((H + bp - 1) // bp, (W + bp - 1) // bp, (G * m) ** 2 + 1): bp for bp in (128, 64, 32, 16) for m in (1, 2, 4)}
     if auto and cull.shape not in want:
         return None      # the followed device's last launch was another frame (it did not render this one): count every ray
     assert cull.shape in want, f"cull table {cull.shape} is not the one of a {W}x{H} frame at {spp} spp {list(want)}: " \

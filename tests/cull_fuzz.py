@@ -8,9 +8,15 @@ cull_block_size.py.  This script draws frames those scans did not: random suns o
 prescriptions and the 8-wavelength one, cropped and enlarged sensors (cull blocks from 0.6 to 1.8 mm), pair subsets,
 every sampling specification, sample counts that are no squares, bands and the multi-GPU row deal -- and compares
 lf_trace_ghosts under lf_set_march_culling(2) with lf_set_march_culling(0) bit for bit, with the counter of rays that
-reached the light.  LF_CULL_FORCE=1 keeps the culled kernel where the launch would fall back to the path tree.
+reached the light.  The culled kernel is kept where the launch would fall back to the path tree (lf_test_knob
+cull_force).  TEST INFRASTRUCTURE (tests/test_gpu_cull.py draws from it; profiles/ only holds what it recorded).
 
-    LF_CULL_FORCE=1 python3 profiles/cull_fuzz.py [cases] [seed] > gpurun_out/r05_cull_fuzz.json
+    python3 tests/cull_fuzz.py [cases] [seed] [families] > gpurun_out/r06_cull_fuzz.json
+
+run(..., knobs=) installs pre-pass rules other than the shipped ones (lf_test_knob: the rules round 5 replaced),
+audit= the rays per dropped box of the launch's audit (0: the raw table is compared -- a search for rule failures;
+>= 1: what ships -- a refuted table sends the launch through the path tree, the frame must then be the enumeration's
+and the record says the audit fired), n_keys= how many keys each drawn frame is rendered with.
 """
 import json
 import os
@@ -124,12 +130,16 @@ def draw_lens():
     return name, how, lens
 
 
-def run(N, SEED, log=sys.stderr, only=None, hook=None, families=4):
+def run(N, SEED, log=sys.stderr, only=None, hook=None, families=4, knobs=None, audit=0, n_keys=1):
     """-> {"summary": ..., "cases": [...]}"""
     global rng, FAMILIES
     rng = np.random.default_rng(SEED)
     FAMILIES = families
     lf = pkg.LensFlare(0)
+    lf.test_knob("cull_force", 1)
+    for k, v in (knobs or {}).items():
+        lf.test_knob(k, v)
+    lf.set_cull_audit(audit)
     out, bad = [], 0
     t0 = time.time()
     for case in range(N):
@@ -195,17 +205,31 @@ def run(N, SEED, log=sys.stderr, only=None, hook=None, families=4):
                 hook(lf, rec, dict(spp=spp, key=key, sel=sel, primary=primary, lens=lens, mask=mask))
                 out.append(rec)
                 continue
-            res = {}
-            for mode in (0, 2):
-                lf.set_march_culling(mode)
-                lf.reset_counters()
-                lf.trace_ghosts(spp, key)
-                res[mode] = (lf.read_buffer(pkg.GHOST_BUFFER), lf.counters(), lf.cull_info()["culled"])
-            d = res[0][0] != res[2][0]
-            rec.update(culled=res[2][2], values_differing=int(d.sum()), lit_values=int((res[0][0] > 0).sum()),
-                       lit_rays_full=res[0][1]["rays_hit_light"], lit_rays_culled=res[2][1]["rays_hit_light"],
-                       started=res[2][1]["rays_launched"] / max(1, res[0][1]["rays_launched"]))
-            if rec["values_differing"] or rec["lit_rays_full"] != rec["lit_rays_culled"]:
+            rec.update(values_differing=0, lit_values=0, lit_rays_full=0, lit_rays_culled=0, audit_refuted=0, audit_lit=0, audit_rays=0,
+                       differing_unnoticed=0, differing_although_refuted=0)
+            for kk in range(n_keys):
+                res = {}
+                for mode in (0, 2):
+                    lf.set_march_culling(mode)
+                    lf.reset_counters()
+                    lf.trace_ghosts(spp, key + kk)
+                    res[mode] = (lf.read_buffer(pkg.GHOST_BUFFER), lf.counters(), lf.cull_info(), lf.cull_audit())
+                d = int((res[0][0] != res[2][0]).sum())
+                info, aud = res[2][2], res[2][3]
+                refuted = info["reason"] == "audit_refuted"
+                lost = d != 0 or res[0][1]["rays_hit_light"] != res[2][1]["rays_hit_light"]
+                rec["values_differing"] += d
+                rec["lit_values"] += int((res[0][0] > 0).sum())
+                rec["lit_rays_full"] += res[0][1]["rays_hit_light"]
+                rec["lit_rays_culled"] += res[2][1]["rays_hit_light"]
+                rec["audit_refuted"] += int(refuted)
+                rec["audit_lit"] += aud["lit"]
+                rec["audit_rays"] += aud["rays"]
+                rec["differing_unnoticed"] += int(lost and not refuted)
+                rec["differing_although_refuted"] += int(lost and refuted)
+                if kk == 0:
+                    rec.update(culled=info["culled"] or refuted, started=res[2][1]["rays_launched"] / max(1, res[0][1]["rays_launched"]))
+            if rec["values_differing"] or rec["lit_rays_full"] != rec["lit_rays_culled"] or (audit and not knobs and rec["audit_refuted"]):
                 bad += 1
                 rec["BAD"] = True
                 rec["key"] = key
@@ -218,6 +242,10 @@ def run(N, SEED, log=sys.stderr, only=None, hook=None, families=4):
     done = [r for r in out if "culled" in r]
     summary = {"seed": SEED, "cases": N, "compared": len(done), "refused": len(out) - len(done),
                "culled_kernel_ran": sum(1 for r in done if r["culled"]), "frames_differing": bad,
+               "audit_rays": int(sum(r["audit_rays"] for r in done)), "audit_lit": int(sum(r["audit_lit"] for r in done)),
+               "launches_refuted_by_the_audit": int(sum(r["audit_refuted"] for r in done)),
+               "launches_differing_unnoticed": int(sum(r["differing_unnoticed"] for r in done)),
+               "launches_differing_although_refuted": int(sum(r["differing_although_refuted"] for r in done)),
                "lit_rays_compared": int(sum(r["lit_rays_full"] for r in done)),
                "frames_with_light": sum(1 for r in done if r["lit_rays_full"] > 0),
                "started_min_median_max": [float(np.min([r["started"] for r in done])), float(np.median([r["started"] for r in done])),

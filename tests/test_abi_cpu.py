@@ -75,3 +75,23 @@ def test_null_context_is_refused_everywhere():
     assert len(fns) > 70
     for name in fns:
         assert getattr(lib, name)(*([C.c_void_p(0)] * 14)) == 1, name
+
+
+def test_no_environment_variable_changes_what_the_library_computes():
+    """Round 6: the experiment switches of rounds 1-5 (LF_CULL_*, LF_MARCH_*, LF_SCENE_*, LF_BVH_*, ...) are compiled only
+    into -DLF_EXPERIMENTS builds; what the tests and the bench need goes through lf_test_knob.  The shipped library holds
+    no such name and its sources read the environment only under that define."""
+    import subprocess
+    lib = os.path.join(ROOT, "lens-flare_amd", "liblensflare_hip.so")
+    names = subprocess.run(["strings", lib], capture_output=True, text=True, check=True).stdout.splitlines()
+    assert [n for n in names if re.fullmatch(r"LF_[A-Z0-9_]+", n)] == []
+    for f in sorted(os.listdir(os.path.join(ROOT, "lens-flare_amd", "csrc"))):
+        depth = 0
+        for line in open(os.path.join(ROOT, "lens-flare_amd", "csrc", f), errors="ignore"):
+            t = line.strip()
+            if t.startswith("#ifdef LF_EXPERIMENTS") or t.startswith("#ifdef LF_MARCH_LIT_MAP"):
+                depth += 1
+            elif t.startswith("#endif") and depth:
+                depth -= 1
+            elif "getenv(" in t and not t.startswith("//"):
+                assert depth > 0, (f, t)

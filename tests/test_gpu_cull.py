@@ -9,10 +9,15 @@ pupil.  What must hold, and is held here:
   * counters = the oracle's, restricted to the rays the device started (it reads the device's own table);
   * on frames where the table would start most of everything the launch takes the path tree by itself.
 
-The frames the oracle can afford are small.  A cull block (64 x 64 pixels) must be small ON THE SENSOR (<= 1.8 mm:
-lf_cull_applies), so the small frames here are CROPS: the bench's pixel pitch (36 mm / 1920) on a narrower sensor around
-the axis.  There the table starts more than the 12 % above which a launch takes the path tree by itself;
-LF_CULL_FORCE=1 (a test hook of lfk_march) keeps the culled kernel."""
+The frames the oracle can afford are small.  A cull block must be small ON THE SENSOR (<= 1.8 mm: lf_cull_block_log2), so
+the small frames here are CROPS: the bench's pixel pitch (36 mm / 1920) on a narrower sensor around the axis.  There the
+table starts more than the 12 % above which a launch takes the path tree by itself; the test knob cull_force
+(lf_test_knob, a hook of lfk_march) keeps the culled kernel.
+
+Round 6: the pre-pass kernel that ships (one rule set, a footprint only where a test can fire) builds the table of the
+kernel that takes its rules as arguments, bit for bit; every table is AUDITED (a ray per dropped box: lf_set_cull_audit)
+-- shown on the frames that lost light under the rules round 5 replaced; frames of 960 and 640 pixels cull with blocks of
+32 and 16; no environment variable changes what the library computes."""
 import numpy as np
 import pytest
 
@@ -39,8 +44,13 @@ def lf(pkg):
 
 
 @pytest.fixture()
-def forced(monkeypatch):
-    monkeypatch.setenv("LF_CULL_FORCE", "1")
+def forced(pkg, lf):
+    """the culled march whatever the table starts: on the module's context and on every context created meanwhile"""
+    lf.test_knob("cull_force", 1)
+    pkg.test_knob_default("cull_force", 1)
+    yield
+    lf.test_knob("cull_force", 0)
+    pkg.test_knob_default("cull_force", 0)
 
 
 def _crop(lens, W, pitch_of=1920):
@@ -219,11 +229,13 @@ def test_table_reuse_rebuild_and_the_automatic_choice(pkg, lf):
     assert lf.cull_table() is None
     with pytest.raises(pkg.LensFlareError):
         lf.set_march_culling(3)
-    # a frame whose blocks are large on the sensor (640 pixels on 36 mm: 3.6 mm): every path is marched
-    _setup(pkg, lf, lens, 640, 360, [0.03, 0.02, -1.0], 0.05, mask)
+    assert lf.cull_reason() == "table_too_full"
+    # a frame whose smallest blocks (16 pixels) are still large on the sensor (240 pixels on 36 mm: 2.4 mm): every path is marched
+    _setup(pkg, lf, lens, 240, 136, [0.03, 0.02, -1.0], 0.05, mask)
     lf.reset_counters()
     lf.trace_ghosts(4, 1)
-    assert not lf.cull_info()["culled"] and lf.counters()["rays_launched"] == 640 * 360 * 4 * 3 * 46
+    assert not lf.cull_info()["culled"] and lf.counters()["rays_launched"] == 240 * 136 * 4 * 3 * 46
+    assert lf.cull_reason() == "block_too_large"
     # no stop in the prescription: nothing to bound a pupil with -- every path is marched
     thin = pkg.load_lens_file("thinlens.lens")
     _setup(pkg, lf, thin, 64, 64, [0.0, 0.0, -1.0], 0.1, np.ones((8, 8), np.float32))
@@ -231,6 +243,10 @@ def test_table_reuse_rebuild_and_the_automatic_choice(pkg, lf):
     lf.trace_ghosts(4, 1)
     c = lf.counters()
     assert not lf.cull_info()["culled"] and ray_budget(lf, c, 64 * 64 * 4 * 3 * 2)
+    assert lf.cull_reason() == "no_stop"
+    lf.set_march_culling(0)
+    lf.trace_ghosts(4, 1)
+    assert lf.cull_reason() == "off"
     lf.set_march_culling(1)
 
 
@@ -282,8 +298,8 @@ def test_other_masks_focus_and_prescriptions_at_1080p(pkg, lf, mask_name, refocu
               f"{c1['rays_launched'] / c0['rays_launched']:.4f}, lit rays {c0['rays_hit_light']}")
 
 
-def test_weight_on_every_event_is_the_same_frame(pkg, lf, monkeypatch):
-    """k_march_cull<K, true> (LF_CULL_WEIGHTS_FIRST, bench.py's `every_event_weighted` leg): the Fresnel / mask weight
+def test_weight_on_every_event_is_the_same_frame(pkg, lf):
+    """k_march_cull<K, true> (lf_test_knob cull_weights_first, bench.py's `every_event_weighted` leg): the Fresnel / mask weight
     evaluated on EVERY executed event of every started ray -- SURVEY 8d's unit event -- instead of on a second march of
     the lanes that reach the lobe.  Same weights, same order of additions: the same pixels and counters."""
     lens = pkg.load_lens_file("dgauss11.lens")
@@ -291,31 +307,30 @@ def test_weight_on_every_event_is_the_same_frame(pkg, lf, monkeypatch):
     lf.set_march_culling(2)
     out = []
     for first in (False, True):
-        if first:
-            monkeypatch.setenv("LF_CULL_WEIGHTS_FIRST", "1")
+        lf.test_knob("cull_weights_first", first)
         lf.reset_counters()
         lf.trace_ghosts(64, 77)
         assert lf.cull_info()["culled"]
         c = lf.counters()
         out.append((lf.read_buffer(pkg.GHOST_BUFFER), {k: v for k, v in c.items() if not k.startswith("remarch")}))
+    lf.test_knob("cull_weights_first", 0)
     lf.set_march_culling(1)
     assert out[0][0].any() and np.array_equal(out[0][0], out[1][0])
     assert out[0][1] == out[1][1], (out[0][1], out[1][1])
 
 
 def test_random_frames_culled_equals_full(pkg, forced):
-    """profiles/cull_fuzz.py (2000 frames recorded in profiles/r05_cull_fuzz.json), a fresh draw of 160 here: random
-    masks, prescriptions, sensors, suns, pair subsets, sampling specifications and bands -- the culled kernel (forced)
-    against the full enumeration, pixels and the count of rays that reached the light."""
-    import os
-    import sys
-    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "profiles"))
+    """tests/cull_fuzz.py (the recorded draws: profiles/r05_cull_fuzz.json, r06_cull_fuzz.json), a fresh draw of 160 here:
+    random masks, prescriptions, sensors, suns, pair subsets, sampling specifications and bands -- the culled kernel
+    (forced) against the full enumeration, pixels and the count of rays that reached the light; and the launch's audit
+    (one ray per dropped box, as shipped) finds nothing to refute."""
     import cull_fuzz
-    r = cull_fuzz.run(160, 7, log=None)
+    r = cull_fuzz.run(160, 7, log=None, audit=1)
     s = r["summary"]
     print(s)
     assert s["compared"] == 160 and s["culled_kernel_ran"] == 160 and s["frames_with_light"] > 120
     assert s["frames_differing"] == 0, [c for c in r["cases"] if c.get("BAD")]
+    assert s["audit_rays"] > 1e8 and s["audit_lit"] == 0 and s["launches_refuted_by_the_audit"] == 0
 
 
 def test_the_drivers_smoke_entry():
@@ -331,14 +346,11 @@ ONCE_LOST = [191, 691, 1630, 1699, 1812, 2006, 2451, 3329, 3589, 3725, 3973, 406
 
 
 def test_the_frames_that_once_lost_lit_rays(pkg, forced):
-    """profiles/cull_fuzz.py 6000 424242 -- the draw that brought a second design family (a Cooke triplet) -- found 27 frames
+    """tests/cull_fuzz.py 6000 424242 -- the draw that brought a second design family (a Cooke triplet) -- found 27 frames
     on which the pre-pass of that day dropped boxes that carried light (1 to 507 lit rays of 1e5 ... 1e9): boxes bounded by
     the samples left after total reflection took the others, 'every sample ends here' decided by a range rule fitted to the
     double Gauss, second order in four axes at once against a small lobe (profiles/r05_march_variants.txt).  The same 27
     frames, replayed from the same stream, under the strict rules: the full enumeration, bit for bit."""
-    import os
-    import sys
-    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "profiles"))
     import cull_fuzz
     r = cull_fuzz.run(max(ONCE_LOST) + 1, 424242, log=None, only=set(ONCE_LOST))
     s = r["summary"]
@@ -348,12 +360,9 @@ def test_the_frames_that_once_lost_lit_rays(pkg, forced):
 
 
 def test_the_frames_past_a_spheres_rim(pkg, forced):
-    """... and the two of the harsher draw (FUZZ_HARSH=1 profiles/cull_fuzz.py 4000 1234567 5: suns of 10 and 15 degrees on
+    """... and the two of the harsher draw (FUZZ_HARSH=1 tests/cull_fuzz.py 4000 1234567 5: suns of 10 and 15 degrees on
     perturbed 8-wavelength prescriptions, tables that start 27 %): boxes that had lost samples past a sphere's rim, bounded by
     the samples left, dropped with 213 and 19 lit rays.  A box that lost any sample is bounded by nothing now."""
-    import os
-    import sys
-    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "profiles"))
     import cull_fuzz
     was = cull_fuzz.HARSH
     cull_fuzz.HARSH = True
@@ -364,3 +373,155 @@ def test_the_frames_past_a_spheres_rim(pkg, forced):
     s = r["summary"]
     assert s["compared"] == 2 and s["culled_kernel_ran"] == 2 and s["frames_differing"] == 0, r["cases"]
     assert all(c["lens"] == "dgauss11_8lambda.lens" and c["alpha"] > 0.15 and c["lit_rays_full"] > 5e8 for c in r["cases"])
+
+
+# ---- round 6 ------------------------------------------------------------------------------------------------------------
+# the rules round 5 REPLACED (range rule for "every sample ends here", boxes that lost samples bounded by the rest, second
+# order not summed over the axes, no extra factor on the lobe test): installed through the test hook only
+OLD_RULES = {"cull_strict": 0, "cull_strict_lost": 0, "cull_slack": 0, "cull_lobe_k": 1.0}
+
+
+def _table(pkg, lf, spp, key=1):
+    lf.set_march_culling(2)
+    lf.trace_ghosts(spp, key)
+    assert lf.cull_info()["culled"], lf.cull_reason()
+    return lf.cull_table(), lf.cull_started_fraction()
+
+
+@pytest.mark.parametrize("lens_name,W,H,spp,sun,alpha", [
+    ("dgauss11.lens", 1920, 1080, 256, [0.01533, 0.0069, -1.0], 0.05),         # the bench frame
+    ("dgauss11.lens", 1920, 1080, 64, [0.30, -0.17, -1.0], 0.05),
+    ("dgauss11_8lambda.lens", 3840, 2160, 1024, [0.01533, 0.0069, -1.0], 0.05),  # C5's table (the pre-pass only)
+    ("dgauss11_8lambda.lens", 1920, 1080, 36, [-0.15, 0.2, -1.0], 0.2),          # a wide sun: boxes lose samples
+    ("dgauss11.lens", 3840, 2160, 16, [0.05, 0.02, -1.0], 0.004)])               # 128-pixel blocks, a small lobe
+def test_the_shipped_kernel_is_the_general_one(pkg, lf, forced, lens_name, W, H, spp, sun, alpha):
+    """k_cull_level (the shipped rules hard-wired: a footprint only where a test can fire, no scratch) builds the table of
+    k_cull_level_general (the rules as arguments: round 5's kernel) bit for bit"""
+    lens = pkg.load_lens_file(lens_name)
+    lam = pkg.spectral_weights(lens["lambda_nm"])[0] if lens_name.endswith("8lambda.lens") else None
+    _setup(pkg, lf, lens, W, H, sun, alpha, load_texels("pentbig500_14.png"), lambda_rgb=lam)
+    lf.set_cull_audit(0)
+    try:
+        shipped, frac = _table_only(pkg, lf, spp)
+        lf.test_knob("cull_general_kernel", 1)
+        general, frac_g = _table_only(pkg, lf, spp)
+    finally:
+        lf.test_knob("cull_general_kernel", 0)
+        lf.set_cull_audit(1)
+        lf.set_march_culling(1)
+    assert shipped.any() and np.array_equal(shipped, general) and frac == frac_g
+    print(f"{lens_name} {W}x{H} {spp} spp: started {frac:.4f}")
+
+
+def _table_only(pkg, lf, spp):
+    """the table of the launch lf_trace_ghosts(spp) would make, without the march: one tile row is rendered"""
+    lf.set_band(0, 8)
+    try:
+        return _table(pkg, lf, spp)
+    finally:
+        lf.set_band(0, lf.H)
+
+
+def test_random_frames_shipped_kernel_is_the_general_one(pkg, forced):
+    """... and on 60 random frames (three design families, every kind of mask): the same tables"""
+    import cull_fuzz
+    tables = {}
+
+    def hook(lf, rec, case):
+        lf.set_cull_audit(0)
+        lf.set_march_culling(2)
+        lf.set_band(0, 8)
+        lf.set_row_interleave(0, 1)
+        lf.trace_ghosts(case["spp"], case["key"])
+        rec["culled"] = lf.cull_info()["culled"]
+        tables.setdefault(rec["case"], []).append(lf.cull_table())
+
+    cull_fuzz.run(60, 99, log=None, hook=hook, families=5)
+    cull_fuzz.run(60, 99, log=None, hook=hook, families=5, knobs={"cull_general_kernel": 1})
+    assert len(tables) == 60
+    for case, (a, b) in tables.items():
+        assert a is not None and np.array_equal(a, b), case
+
+
+def test_the_audit_costs_little_and_finds_nothing_on_the_bench_frame(pkg, lf):
+    """c3: 8.8e7 dropped (block, cell, path) combinations, one ray each, marched with the march's own events: none reaches
+    the light; under 2 ms"""
+    lens = pkg.load_lens_file("dgauss11.lens")
+    _setup(pkg, lf, lens, 1920, 1080, [0.01533, 0.0069, -1.0], 0.05, load_texels("pentbig500_14.png"))
+    lf.set_march_culling(2)
+    lf.reset_counters()
+    lf.timing_reset()
+    lf.timing_enable(True)
+    for k in range(3):
+        lf.trace_ghosts(256, 11 + k)
+    lf.synchronize()
+    n, ms = lf.timing_get("cull_audit")
+    lf.timing_enable(False)
+    a = lf.cull_audit()
+    print(f"audit: {a}, {ms / n:.3f} ms per frame; pre-pass {lf.timing_get('cull_prepass')}")
+    assert lf.cull_info()["culled"] and lf.cull_reason() == "applied"
+    assert n == 3 and a["lit"] == 0 and a["launches_refuted"] == 0
+    assert abs(a["rays"] / 3 - (1.0 - lf.cull_started_fraction()) * 30 * 17 * 4096 * 46) < 1.0
+    assert ms / n < 2.0
+    lf.set_march_culling(1)
+
+
+def test_the_audit_catches_the_rules_that_lost_light(pkg, forced):
+    """The 27 frames of ONCE_LOST under the rules round 5 replaced (installed through the test hook), 32 keys each, 8 audit
+    rays per dropped box: the audit refutes tables -- and a launch whose table it refuted is the full enumeration's frame
+    (it took the path tree); what it does not notice is counted, not hidden."""
+    import cull_fuzz
+    r = cull_fuzz.run(max(ONCE_LOST) + 1, 424242, log=None, only=set(ONCE_LOST), knobs=OLD_RULES, audit=8, n_keys=32)
+    s = r["summary"]
+    print(s)
+    lost = [c for c in r["cases"] if c["values_differing"] or c["lit_rays_full"] != c["lit_rays_culled"] or c["audit_refuted"]]
+    print("frames that lost light or were refuted:", [(c["case"], c["audit_refuted"], c["differing_unnoticed"]) for c in lost])
+    assert s["compared"] == len(ONCE_LOST)
+    assert s["launches_refuted_by_the_audit"] > 0 and s["audit_lit"] > 0
+    assert s["launches_differing_although_refuted"] == 0      # a refuted launch took the path tree: the enumeration's frame
+
+
+@pytest.mark.parametrize("W,H,block", [(1280, 720, 64), (960, 540, 32), (640, 360, 16)])
+def test_small_frames_cull_with_smaller_blocks(pkg, lf, W, H, block):
+    """frames narrower than 1280 pixels on the 36 mm sensor: blocks of 32 / 16 pixels (<= 1.8 mm), a wave tile (64 x 8 pixels)
+    spans several of them and its lanes look their rows up one by one -- culled = full enumeration, every sampling default"""
+    lens = pkg.load_lens_file("dgauss11.lens")
+    mask = load_texels("pentbig500_14.png")
+    for sun, alpha, spp in (([0.01533, 0.0069, -1.0], 0.05, 64), ([0.12, -0.08, -1.0], 0.03, 16)):
+        _setup(pkg, lf, lens, W, H, sun, alpha, mask)
+        g1, c1, info, g0, c0 = _both(pkg, lf, spp, 0xB10C + W)
+        assert info["culled"] and info["block_px"] == block and info["blocks_x"] == (W + block - 1) // block, (info, lf.cull_reason())
+        assert np.array_equal(g1, g0) and c1["rays_hit_light"] == c0["rays_hit_light"] > 0
+        assert c1["rays_launched"] < 0.3 * c0["rays_launched"]
+        print(f"{W}x{H} blocks of {block}: started {c1['rays_launched'] / c0['rays_launched']:.4f}")
+    # ... and against the oracle on a crop with 16-pixel blocks (its table lookup follows the block size)
+    lf.test_knob("cull_force", 1)
+    try:
+        Wc, Hc, spp = 80, 48, 16
+        crop = dict(lens)
+        crop["sensor_width_mm"] = 36.0 * Wc / 640
+        _setup(pkg, lf, crop, Wc, Hc, [0.03, 0.02, -1.0], 0.05, mask)
+        g1, c1, info, g0, c0 = _both(pkg, lf, spp, 5)
+        assert info["culled"] and info["block_px"] == 16 and np.array_equal(g1, g0)
+        lf.set_march_culling(2)
+        lf.reset_counters()
+        lf.trace_ghosts(spp, 5)
+        og, oc = lfo.geo_trace(crop, Wc, Hc, 0, Hc, spp, 5, None, True, mask, [0.03, 0.02, -1.0], RAD, 0.05, n_threads=16)
+        assert np.array_equal(g1, og) and oc == c1 and lfo.last_culled_lit == 0
+    finally:
+        lf.test_knob("cull_force", 0)
+        lf.set_march_culling(1)
+
+
+def test_a_prescription_whose_index_columns_are_out_of_order_marches_everything(pkg, lf):
+    """the pre-pass brackets the spectrum by the first and the last index column: a table with a column out of order
+    (lf_set_lens accepts any) is not culled -- and says why"""
+    lens = dict(pkg.load_lens_file("dgauss11.lens"))
+    ior = np.array(lens["ior"], np.float32)
+    ior[[1, 2]] = ior[[2, 1]]                      # C, F, d: d lies BETWEEN the two ends in index, not at the end
+    lens["ior"] = ior
+    _setup(pkg, lf, lens, 1920, 64, [0.01533, 0.0069, -1.0], 0.05, load_texels("pentbig500_14.png"))
+    lf.reset_counters()
+    lf.trace_ghosts(4, 1)
+    assert not lf.cull_info()["culled"] and lf.cull_reason() == "dispersion_not_monotonic"
+    assert lf.counters()["rays_launched"] == 1920 * 64 * 4 * 3 * 46

@@ -507,9 +507,9 @@ def test_aiming_the_lens_camera_at_the_exit_pupil(pkg, lf, sqrt_table):
 
 
 @pytest.mark.parametrize("what", ["delta_one_lambda", "adaptive_batches", "per_wavelength", "area_light", "odd_rows"])
-def test_compacted_scene_rays_equal_the_per_lane_kernel(pkg, lf, what, monkeypatch):
+def test_compacted_scene_rays_equal_the_per_lane_kernel(pkg, lf, what):
     """Round 5: k_scene_lens queues the samples that LEFT the lens and walks the tree with full waves; every pixel
-    must see the additions of k_scene_term<.., true> (one traversal per lane's own sample, LF_SCENE_COMPACT=0) in
+    must see the additions of k_scene_term<.., true> (one traversal per lane's own sample, lf_test_knob scene_compact 0) in
     the same order: frames and counters bit for bit -- with and without the adaptive early-out (lanes leaving at
     batch ends), one ray per wavelength (several entries per sample), sampled lights (Philox counters of the
     OWNER's pixel and sample), frame edges and the multi-GPU row deal."""
@@ -530,14 +530,18 @@ def test_compacted_scene_rays_equal_the_per_lane_kernel(pkg, lf, what, monkeypat
     if what == "odd_rows":
         lf.set_row_interleave(1, 2)
     frames, counters = [], []
-    for compact, strided in (("1", "1"), ("0", "0"), ("1", "0")):      # (the wave's pixels: the march's strided tile / 8 x 8 adjacent)
-        monkeypatch.setenv("LF_SCENE_COMPACT", compact)
-        monkeypatch.setenv("LF_SCENE_LENS_STRIDED", strided)
-        lf.set_scene_term(np.zeros((H, W, 3)))
-        lf.reset_scene_counters()
-        lf.render_scene_term()
-        frames.append(lf.read_buffer(pkg.SCENE_BUFFER))
-        counters.append(lf.scene_counters())
+    try:
+        for compact, strided in ((1, 1), (0, 0), (1, 0)):      # (the wave's pixels: the march's strided tile / 8 x 8 adjacent)
+            lf.test_knob("scene_compact", compact)
+            lf.test_knob("scene_lens_strided", strided)
+            lf.set_scene_term(np.zeros((H, W, 3)))
+            lf.reset_scene_counters()
+            lf.render_scene_term()
+            frames.append(lf.read_buffer(pkg.SCENE_BUFFER))
+            counters.append(lf.scene_counters())
+    finally:
+        lf.test_knob("scene_compact", -1)
+        lf.test_knob("scene_lens_strided", -1)
     assert (frames[0].max(axis=-1) > 1e-3).mean() > 0.1
     for k in (1, 2):
         assert np.array_equal(frames[0], frames[k]), (k, np.abs(frames[0] - frames[k]).max())

@@ -57,13 +57,28 @@ def test_single_rank_communicator(pkg):
     lf.close()
 
 
-def test_async_exchange_pipeline_of_frames(pkg, monkeypatch):
+@pytest.fixture()
+def force_exchange(pkg):
+    """the collectives run with a single rank as well (lf_test_knob comm_force_exchange), for every context created meanwhile"""
+    pkg.test_knob_default("comm_force_exchange", 1)
+    yield
+    pkg.test_knob_default("comm_force_exchange", 0)
+
+
+@pytest.fixture()
+def cull_forced(pkg):
+    """the culled march whatever the table starts (lf_test_knob cull_force), for every context created meanwhile"""
+    pkg.test_knob_default("cull_force", 1)
+    yield
+    pkg.test_knob_default("cull_force", 0)
+
+
+def test_async_exchange_pipeline_of_frames(pkg, force_exchange):
     """lf_comm_gather_async: pack / ncclAllGather / unpack on the second stream while the next frame
-    is rendered on the first.  With LF_COMM_FORCE_EXCHANGE the whole path runs on a communicator of
+    is rendered on the first.  With the test knob comm_force_exchange the whole path runs on a communicator of
     one (RCCL copies the rank's slots to itself, the unpack skips them): a sequence of DIFFERENT
     frames queued back to back, each exchanged asynchronously, must leave exactly the last frame --
     and every read in between must see the frame that was current, whole."""
-    monkeypatch.setenv("LF_COMM_FORCE_EXCHANGE", "1")
     lens = pkg.load_lens_file("dgauss11.lens")
     mask = load_texels("pentbig500_14.png")
     W, H = 96, 56
@@ -166,7 +181,7 @@ def test_cpp_host_drives_a_group(pkg, tmp_path):
     assert "3 devices" in r.stdout
 
 
-def test_communicator_introspection_deadline_test_and_abort(pkg, monkeypatch):
+def test_communicator_introspection_deadline_test_and_abort(pkg):
     """What bench.py's bring-up relies on (round 3): lf_comm_available before any blocking call,
     lf_comm_info = what RCCL itself reports (ncclCommCount / ncclCommUserRank), lf_comm_test = the
     non-blocking completion query behind the first exchange's deadline, lf_comm_abort = the way out of
@@ -183,7 +198,7 @@ def test_communicator_introspection_deadline_test_and_abort(pkg, monkeypatch):
     assert lf.comm_info() == (1, 0)
     _frame(lf, 8, 3)
     want = lf.read_buffer(pkg.SAMPLE_BUFFER)
-    monkeypatch.setenv("LF_COMM_FORCE_EXCHANGE", "1")
+    lf.test_knob("comm_force_exchange", 1)
     lf.timing_reset()
     lf.timing_enable(True)
     lf.comm_gather_async(pkg.SAMPLE_BUFFER)
@@ -357,7 +372,7 @@ def test_a_poisoned_context_refuses_communicator_calls_and_still_renders(pkg):
 
 
 @pytest.mark.parametrize("n,W,H,spp", [(8, 1920, 1080, 16), (4, 1920, 1080, 16), (3, 1920, 1080, 16), (8, 3840, 2160, 4), (7, 1900, 1000, 9)])
-def test_shared_cull_prepass_is_the_table_built_alone(pkg, monkeypatch, n, W, H, spp):
+def test_shared_cull_prepass_is_the_table_built_alone(pkg, cull_forced, n, W, H, spp):
     """The pre-pass shared between the ranks (lf_set_cull_share): n contexts on device 0, each builds
     the slab of table rows of the blocks b with b % n == rank (lf_cull_prepare), the test plays the all-gather (slab r
     of rank r into everybody's table, what ncclAllGather / sharding.complete_cull_table deliver), lf_cull_commit, then
@@ -365,7 +380,7 @@ def test_shared_cull_prepass_is_the_table_built_alone(pkg, monkeypatch, n, W, H,
     single context builds alone, the started fraction too, the gathered frame and the summed counters are the
     single-context frame's -- bit for bit; block counts that n does not divide (the last slabs are padded)."""
     import torch
-    monkeypatch.setenv("LF_CULL_FORCE", "1")      # (few samples, a wide table: the launch would take the path tree by itself)
+    # (cull_forced: few samples, a wide table -- the launch would take the path tree by itself)
     lens = pkg.load_lens_file("dgauss11.lens")
     mask = load_texels("pentbig500_14.png")
 
@@ -430,16 +445,14 @@ def test_shared_cull_prepass_is_the_table_built_alone(pkg, monkeypatch, n, W, H,
         lf.close()
 
 
-def test_table_all_gather_through_the_communicator(pkg, monkeypatch):
+def test_table_all_gather_through_the_communicator(pkg, force_exchange, cull_forced):
     """lf_comm_share_cull: the in-place ncclAllGather of table slabs on the communicator's stream, between pre-pass and
-    march -- with the one rank a one-GPU box can form (LF_COMM_FORCE_EXCHANGE runs the collective all the same, as for
+    march -- with the one rank a one-GPU box can form (the test knob comm_force_exchange runs the collective all the same, as for
     the frame's exchange): the RCCL call, the stream hand-over and the launch order are the multi-rank ones, the frame
     is the plain one; frames in a row with the frame's own asynchronous exchange in between (one stream carries every
     RCCL call); refused without a communicator, switched off by lf_comm_abort."""
     if not pkg.comm_available():
         pytest.skip("librccl.so.1 not loadable")
-    monkeypatch.setenv("LF_COMM_FORCE_EXCHANGE", "1")
-    monkeypatch.setenv("LF_CULL_FORCE", "1")
     lens = pkg.load_lens_file("dgauss11.lens")
     mask = load_texels("pentbig500_14.png")
     W, H, spp = 1920, 1080, 16
@@ -471,11 +484,10 @@ def test_table_all_gather_through_the_communicator(pkg, monkeypatch):
 
 
 @pytest.mark.parametrize("n", [2, 7])
-def test_group_shares_the_cull_prepass(pkg, monkeypatch, n):
+def test_group_shares_the_cull_prepass(pkg, cull_forced, n):
     """lf_group_share_cull (one process, n devices; here n contexts on device 0, whose all-gather is the peer-copy
     stand-in): every context builds its slab, the group completes the table, the gathered 1080p frame is the
     single-context frame, bit for bit; a frame later without the call is refused (mode 2: the table is per launch)."""
-    monkeypatch.setenv("LF_CULL_FORCE", "1")
     lens = pkg.load_lens_file("dgauss11.lens")
     mask = load_texels("pentbig500_14.png")
     W, H, spp = 1920, 1080, 16
@@ -516,7 +528,6 @@ def test_bench_goes_through_the_multi_rank_bring_up_with_one_rank(pkg):
         pytest.skip("librccl.so.1 not loadable")
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     env = dict(os.environ, LF_BENCH_SOLO_COMM="1", LF_BENCH_COMM_TIMEOUT="120")
-    env.pop("LF_CULL_FORCE", None)
     r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--steps", "2", "--warmup", "1", "--no-cpu", "--config", "c2"],
                        capture_output=True, text=True, timeout=600, env=env, cwd=root)
     assert r.returncode == 0, r.stderr[-3000:]

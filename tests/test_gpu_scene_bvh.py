@@ -168,26 +168,19 @@ def test_every_tree_renders_the_same_frame(pkg):
     triangles = [tuple(t) + tuple(n) + ("d", 0.4, 0.6, 0.5) for t, n in zip(tris, nrm)]
     lights = [[0.0, 0.3, 0.9, 0.3, 1.0, 1.0, 1.0], [1.0, 0.0, 3.0, -4.0, 20.0, 20.0, 20.0]]
     frames = {}
-    saved = {k: os.environ.get(k) for k in ("LF_BVH_SPLIT", "LF_BVH_LEAF")}
-    try:
-        for split in ("sah", "median"):
-            for leaf in ("1", "2", "4"):
-                os.environ["LF_BVH_SPLIT"], os.environ["LF_BVH_LEAF"] = split, leaf
-                lf = pkg.LensFlare(0)
-                lf.set_frame(160, 96)
-                lf.set_params(4, 25.0, 1.0)
-                lf.set_camera(np.eye(3), [0.0, 0.0, 2.0], 60.0, 38.0)
-                lf.set_scene(spheres, triangles, lights)
-                lf.set_jitter_counter(5)
-                lf.render_scene_term()
-                frames[(split, leaf)] = lf.read_buffer(pkg.SCENE_BUFFER)
-                lf.close()
-    finally:
-        for k, v in saved.items():
-            if v is None:
-                os.environ.pop(k, None)
-            else:
-                os.environ[k] = v
+    for split in ("sah", "median"):
+        for leaf in ("1", "2", "4"):
+            lf = pkg.LensFlare(0)
+            lf.test_knob("bvh_median", split == "median")       # (the tree of the next set_scene)
+            lf.test_knob("bvh_leaf", int(leaf))
+            lf.set_frame(160, 96)
+            lf.set_params(4, 25.0, 1.0)
+            lf.set_camera(np.eye(3), [0.0, 0.0, 2.0], 60.0, 38.0)
+            lf.set_scene(spheres, triangles, lights)
+            lf.set_jitter_counter(5)
+            lf.render_scene_term()
+            frames[(split, leaf)] = lf.read_buffer(pkg.SCENE_BUFFER)
+            lf.close()
     ref = frames[("sah", "2")]
     assert (ref.max(axis=-1) > 0).mean() > 0.15
     for k, f in frames.items():

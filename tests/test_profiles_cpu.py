@@ -16,11 +16,9 @@ def test_every_profile_json_parses():
 
 
 def test_the_random_search_draws_what_it_says():
-    """profiles/cull_fuzz.py without a device: its two synthetic design families are lenses (positive focal length, a stop
+    """tests/cull_fuzz.py without a device: its two synthetic design families are lenses (positive focal length, a stop
     inside, more than one glass), its masks have open and closed texels, and the stream of draws that found the 27 frames
     of tests/test_gpu_cull.py ONCE_LOST still starts the same way (the replay depends on it)."""
-    import sys
-    sys.path.insert(0, os.path.join(ROOT, "profiles"))
     import numpy as np
     import cull_fuzz
     for make, n in ((cull_fuzz.triplet, 7), (cull_fuzz.retrofocus, 9)):
