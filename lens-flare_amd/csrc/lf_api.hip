@@ -1057,6 +1057,8 @@ lf_status lf_get_cull_table(lf_ctx* ctx, uint64_t* out, size_t n_entries) {
   if (!ctx || !out) return LF_ERR_INVALID;
   if (!ctx->last_march_culled || !ctx->cull_dev || ctx->cull_hash == 0)
     return lf_fail(ctx, LF_ERR_STATE, "lf_get_cull_table: the last lf_trace_ghosts did not cull (or none has run)");
+  if (ctx->cull_chunks > 1)
+    return lf_fail(ctx, LF_ERR_STATE, "lf_get_cull_table: the last lf_trace_ghosts marched more than 64 paths in two launches, each with its own table");
   const size_t n = (size_t)ctx->cull_bx * ctx->cull_by * (size_t)(ctx->cull_cells + 1);
   if (n_entries != n) return lf_fail(ctx, LF_ERR_INVALID, "lf_get_cull_table: size must be blocks_x * blocks_y * (cells + 1)");
   LF_HIP(ctx, hipSetDevice(ctx->device));

@@ -410,6 +410,9 @@ __global__ __launch_bounds__(LF_CULL_WG, LF_CULL_WAVES) void k_cull_level_genera
     else { keep = true; why = partial ? 1 : 3; }
   }
   if (stats && valid && why) atomicAdd(&stats[why], 1ull);
+  // (measurements only, UNSAFE -- what the boxes nothing bounds cost the march: disable bit 4 drops the boxes kept with too few
+  // samples left on the last level, bit 5 those kept because they had lost samples)
+  if (a.last && (((a.disable & 16) && why == 2) || ((a.disable & 32) && why == 1))) keep = false;
   const bool enabled = valid && keep;
   if (a.last) {
     if (valid && enabled) {
@@ -1273,7 +1276,9 @@ int lf_cull_reason_of(const lf_ctx* ctx, int G) {
 #endif
   if (ctx->lens.stop < 0) return LF_CULL_NO_STOP;
   if (!ctx->lens_lambda_monotonic) return LF_CULL_DISPERSION;
-  if (ctx->pairs.n > kCullMaxPaths) return LF_CULL_TOO_MANY_PATHS;
+  // (a mask has 64 bits; up to 128 paths go in two launches over the halves of the selection: lfk_march -- with a table
+  // of this context's own)
+  if (ctx->pairs.n > 2 * kCullMaxPaths || (ctx->pairs.n > kCullMaxPaths && ctx->cull_share_how != 0)) return LF_CULL_TOO_MANY_PATHS;
   if (G < 1 || G > 64) return LF_CULL_TOO_MANY_SAMPLES;
   // a block must be SMALL on the sensor for 15 rays to bound it: <= 1.8 mm (the full-enumeration comparison finds no
   // skipped lit ray up to 7.2 mm blocks, profiles/r05_cull_block_size.json) -- frames narrower than 1280 pixels on a

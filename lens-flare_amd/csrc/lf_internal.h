@@ -432,6 +432,7 @@ struct lf_ctx {
   int cull_audit_tripped = 0;                  // launches since lf_reset_counters whose table an audit ray refuted
   uint64_t cull_bad_hash = 0;                  // the resident table was refuted: its launches march everything
   int cull_reason = 0;                         // why the last launch did (not) cull: lf_cull_reason
+  int cull_chunks = 1;                         // launches the last lf_trace_ghosts split its selection into (> 64 paths: 2)
   uint64_t cull_audit_seq = 0;                 // tables audited by this context: keys the audit's rays
   bool lens_lambda_monotonic = true;           // every glass disperses the same way along the wavelength columns (lf_derive_lens)
   unsigned cull_occ[kCullOcc] = {};            // occupancy of the stop mask (host, lf_set_aperture)

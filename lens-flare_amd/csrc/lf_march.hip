@@ -1135,7 +1135,7 @@ static int march_strata(int spp) {
 }
 
 // what a launch uploads before anything runs: the event program, the lens (with the launch's fixed-point grid), the paths
-static lf_status march_upload(lf_ctx* ctx, int spp) {
+static lf_status march_upload(lf_ctx* ctx, int spp, int total_paths = 0) {
   ctx->lens.pitch = ctx->sensor_w_mm / (float)ctx->W;
   if (ctx->events_dirty) {
     lf_status st = build_event_table(ctx);
@@ -1145,7 +1145,7 @@ static lf_status march_upload(lf_ctx* ctx, int spp) {
     // the launch's fixed-point grid: the kernels scale by the literal 2^36 and back by 2^-36, the device's sun_radiance
     // carries 2^(bits - 36) (exact: a power of two) and k_scale_rows takes it out of the rows the launch wrote --
     // together (u64)(v 2^bits) and back, as the contract says
-    const int bits = lf_march_fix_bits(ctx->lens, ctx->pairs.n, spp);
+    const int bits = lf_march_fix_bits(ctx->lens, total_paths > 0 ? total_paths : ctx->pairs.n, spp);
     ctx->march_fix_bits = bits;
     LfLensDev up = ctx->lens;
     for (int c = 0; c < 3; c++) up.sun_radiance[c] = std::ldexp(ctx->lens.sun_radiance[c], bits - 36);
@@ -1171,10 +1171,14 @@ lf_status lfk_cull_prepare(lf_ctx* ctx, int spp) {
   return st;
 }
 
-lf_status lfk_march(lf_ctx* ctx, int spp, uint64_t key) {
+// one launch of the march over the selection ctx->pairs holds.  A selection of more than 64 paths (a mask's bits) is
+// marched culled in TWO such launches over its halves (lfk_march below): chunk c of n_chunks, the fixed-point grid sized
+// for all total_paths, the integer sums of both halves in `accum` (exact, so the frame is the one launch's), converted
+// once after the last.
+static lf_status march_launch(lf_ctx* ctx, int spp, uint64_t key, int chunk, int n_chunks, int total_paths) {
   const LfApertureDev& m = ctx->ap[LF_APERTURE_STARBURST];
   {
-    const lf_status st = march_upload(ctx, spp);
+    const lf_status st = march_upload(ctx, spp, total_paths);
     if (st != LF_OK) return st;
   }
   if (ctx->y1 <= ctx->y0) {
@@ -1221,15 +1225,17 @@ lf_status lfk_march(lf_ctx* ctx, int spp, uint64_t key) {
     if (v >= 1 && v * 4 <= std::max(4, spp) && (v & (v - 1)) == 0) a.sgroups = v;
   }
 #endif
+  if (n_chunks > 1) a.sgroups = std::max(a.sgroups, 2);      // (the halves meet in the integer accumulator)
   a.n_tiles = (int)tiles;
   const size_t blocks = ((tiles + 63) / 64 * 64) * a.sgroups;
   if (blocks > 0x7fffffffull) return lf_fail(ctx, LF_ERR_INVALID, "band too large for one launch");
   const size_t n_acc = (size_t)ctx->W * ctx->H_alloc * 3;
   if (a.sgroups > 1) {
     if (!ctx->accum) LF_HIP(ctx, hipMalloc((void**)&ctx->accum, n_acc * sizeof(unsigned long long)));
-    LF_HIP(ctx, hipMemsetAsync(ctx->accum + (size_t)ctx->y0 * ctx->W * 3, 0,
-                               (size_t)(ctx->y1 - ctx->y0) * ctx->W * 3 * sizeof(unsigned long long),
-                               ctx->stream));
+    if (chunk == 0)
+      LF_HIP(ctx, hipMemsetAsync(ctx->accum + (size_t)ctx->y0 * ctx->W * 3, 0,
+                                 (size_t)(ctx->y1 - ctx->y0) * ctx->W * 3 * sizeof(unsigned long long),
+                                 ctx->stream));
   }
   // experiments only: unused dynamic LDS caps the workgroups a CU holds (occupancy sweeps,
   // profiles/r03_march_variants.txt)
@@ -1264,7 +1270,7 @@ lf_status lfk_march(lf_ctx* ctx, int spp, uint64_t key) {
 #endif
   const int fix_shift = 36 - ctx->march_fix_bits;       // != 0: an HDR launch (see k_scale_rows)
   const size_t band_px = (size_t)(ctx->y1 - ctx->y0) * ctx->W;
-  if (fix_shift != 0 && a.accumulate) {                   // what the buffer holds joins the launch's grid, exactly
+  if (fix_shift != 0 && a.accumulate && chunk == 0) {     // what the buffer holds joins the launch's grid, exactly
     hipLaunchKernelGGL(k_scale_rows, dim3((unsigned)((band_px + 255) / 256)), dim3(256), 0, ctx->stream, ctx->ghost, a,
                        std::ldexp(1.0, -fix_shift));
     LF_HIP(ctx, hipGetLastError());
@@ -1306,6 +1312,7 @@ lf_status lfk_march(lf_ctx* ctx, int spp, uint64_t key) {
   lf_timing_end(ctx, LFK_MARCH, ev);
   LF_HIP(ctx, hipGetLastError());
   }
+  if (chunk + 1 < n_chunks) return LF_OK;                 // (the other half of the selection follows)
   if (a.sgroups > 1) {
     const size_t px = (size_t)(ctx->y1 - ctx->y0) * ctx->W;
     hipLaunchKernelGGL(k_march_finish, dim3((unsigned)((px + 255) / 256)), dim3(256), 0, ctx->stream,
@@ -1318,6 +1325,38 @@ lf_status lfk_march(lf_ctx* ctx, int spp, uint64_t key) {
     LF_HIP(ctx, hipGetLastError());
   }
   return LF_OK;
+}
+
+lf_status lfk_march(lf_ctx* ctx, int spp, uint64_t key) {
+  const int n = ctx->pairs.n;
+  ctx->cull_chunks = 1;
+  // more paths than a mask has bits: the culled march in two launches over the halves of the selection (each with its own
+  // table), where the cull applies at all and the table is this context's own
+  if (n <= kCullMaxPaths || n > 2 * kCullMaxPaths || ctx->cull_share_how != 0 || ctx->y1 <= ctx->y0 ||
+      lf_cull_reason_of(ctx, march_strata(spp)) != LF_CULL_APPLIED)
+    return march_launch(ctx, spp, key, 0, 1, n);
+  const LfPairsDev full = ctx->pairs;
+  lf_status st = LF_OK;
+  bool culled = true;
+  int reason = LF_CULL_APPLIED;
+  const int half = (n + 1) / 2;
+  for (int c = 0; c < 2 && st == LF_OK; c++) {
+    LfPairsDev P;
+    std::memset(&P, 0, sizeof(P));
+    const int q0 = c == 0 ? 0 : half, q1 = c == 0 ? half : n;
+    for (int q = q0; q < q1; q++) { P.ij[P.n][0] = full.ij[q][0]; P.ij[P.n][1] = full.ij[q][1]; P.n++; }
+    ctx->pairs = P;
+    ctx->events_dirty = true;
+    st = march_launch(ctx, spp, key, c, 2, n);
+    culled = culled && ctx->last_march_culled;
+    if (ctx->cull_reason != LF_CULL_APPLIED) reason = ctx->cull_reason;
+  }
+  ctx->pairs = full;
+  ctx->events_dirty = true;
+  ctx->cull_chunks = 2;
+  ctx->last_march_culled = culled;
+  ctx->cull_reason = reason;
+  return st;
 }
 
 lf_status lfk_native_sqrt(lf_ctx* ctx, const float* d_x, float* d_y, size_t n) {

@@ -103,6 +103,8 @@ typedef struct {
   double w_pot;  /* weight if every fragile decision passes (upper bound for texel choices) */
   int fragile;
   int dead;      /* 0 alive, else cause: 1 mask/stop, 2 aperture/miss, 3 total reflection */
+  int cause;     /* why fragile, bits: 1 the rim of a clear aperture / of the stop's housing, 2 a mask texel's edge,
+                    4 the critical angle, 8 a grazing miss of a sphere */
 } g64_ray;
 
 /* one spherical (or flat) glass interface: refraction or mirror reflection */
@@ -120,7 +122,7 @@ static void glass(const g64_lens* L, const g64_system* S, int lam, int k, int mi
       if (!r->dead) r->dead = 2;
       /* a grazing miss within rounding distance cannot be followed further: charge the whole
        * weight it carried as the fragile bound (rare: the clear apertures cut in long before) */
-      if (disc > -L->eps_mm * fabs(R)) r->fragile = 2;
+      if (disc > -L->eps_mm * fabs(R)) { r->fragile = 2; r->cause |= 8; }
       r->w = 0.0;
       return;
     }
@@ -131,7 +133,7 @@ static void glass(const g64_lens* L, const g64_system* S, int lam, int k, int mi
   }
   const vec hit = add(r->o, scale(r->d, t));
   const double rho = sqrt(hit.x * hit.x + hit.y * hit.y);
-  if (fabs(rho - h) < L->eps_mm) r->fragile = 1;
+  if (fabs(rho - h) < L->eps_mm) { r->fragile = 1; r->cause |= 1; }
   if (rho > h) {
     if (!r->dead) r->dead = 2;
     if (!r->fragile) { r->w = 0.0; return; }
@@ -147,7 +149,7 @@ static void glass(const g64_lens* L, const g64_system* S, int lam, int k, int mi
   const double eta = n1 / n2;
   const double sin2_t = eta * eta * (1.0 - cos_i * cos_i);
   const int tir = sin2_t > 1.0;
-  if (fabs(1.0 - sin2_t) < L->eps_cos) r->fragile = 1;
+  if (fabs(1.0 - sin2_t) < L->eps_cos) { r->fragile = 1; r->cause |= 4; }
   double reflectance = 1.0, cos_t = 0.0;
   if (!tir) {
     cos_t = sqrt(1.0 - sin2_t);
@@ -180,7 +182,7 @@ static void stop_plane(const g64_lens* L, const g64_system* S, int k, const floa
   const vec hit = add(r->o, scale(r->d, t));
   const double h = L->semi_ap[k];
   const double rho = sqrt(hit.x * hit.x + hit.y * hit.y);
-  if (fabs(rho - h) < L->eps_mm) r->fragile = 1;
+  if (fabs(rho - h) < L->eps_mm) { r->fragile = 1; r->cause |= 1; }
   int outside = rho > h;
   const double fu = (hit.x / h + 1.0) * (0.5 * mw), fv = (hit.y / h + 1.0) * (0.5 * mh);
   int ix = (int)fu, iy = (int)fv; /* truncation, like the specification's (int) cast */
@@ -204,7 +206,7 @@ static void stop_plane(const g64_lens* L, const g64_system* S, int k, const floa
       if (b > a_max) a_max = b;
       if (b < a_min) a_min = b;
     }
-  if (a_max != a_min) r->fragile = 1;
+  if (a_max != a_min) { r->fragile = 1; r->cause |= 2; }
   if (outside || !(a > 0.0)) {
     if (!r->dead) r->dead = 1;
     r->w = 0.0;
@@ -355,6 +357,10 @@ static double sample_ray(const g64_lens* L, const g64_system* S, int W, int H, i
  * counters count the rays the device starts (block = 64 x 64 pixels, entry = the sample's pupil stratum). */
 static const uint64_t* g64_cull = NULL;
 static int g64_cull_bx = 0, g64_cull_cells = 0, g64_cull_shift = 6;
+/* W * H * 4 doubles (or NULL): per pixel, the fragile rays' potential weight (summed over the channels, / spp) by cause --
+ * aperture rim, mask texel edge, critical angle, grazing miss: what tests/test_gpu_march_f64.py tabulates */
+static double* g64_cause = NULL;
+void g64_set_cause_buffer(double* buf) { g64_cause = buf; }
 void g64_set_cull(const uint64_t* table, int blocks_x, int blocks_y, int cells, int block_px) {
   (void)blocks_y;
   g64_cull = table; g64_cull_bx = blocks_x; g64_cull_cells = cells;
@@ -412,7 +418,7 @@ void g64_trace(const g64_lens* L, int W, int H, int y0, int y1, int spp, const u
         for (int lam = 0; lam < L->n_lambda; lam++)
           for (int q = 0; q < n_pairs; q++) {
             uint64_t* const c = (q >= 64 || ((started >> q) & 1u)) ? counted : skipped;
-            g64_ray r = {o, d, w0, w0, 0, 0};
+            g64_ray r = {o, d, w0, w0, 0, 0, 0};
             c[0]++;
             c[1] += (uint64_t)follow(L, &S, lam, pairs[2 * q], pairs[2 * q + 1], mask, mw, mh, &r);
             if (r.fragile) c[7]++;
@@ -432,6 +438,10 @@ void g64_trace(const g64_lens* L, int W, int H, int y0, int y1, int spp, const u
               const double colour = L->sun_radiance[ch] * L->lambda_rgb[lam][ch];
               if (!r.dead) sum[ch] += r.w * shade * colour;
               if (r.fragile) fsum[ch] += r.w_pot * shade * colour;
+              /* ... and by cause (a ray with several: each of them), if the caller asked (g64_set_cause_buffer) */
+              if (r.fragile && g64_cause)
+                for (int k = 0; k < 4; k++)
+                  if (r.cause & (1 << k)) g64_cause[4 * (size_t)p + k] += r.w_pot * shade * colour / spp;
             }
           }
       }

@@ -554,11 +554,18 @@ G64_COUNTERS = ("rays_launched", "surface_events", "rays_clipped_stop", "rays_vi
                 "rays_reached_scene", "rays_hit_light", "rays_fragile")
 
 
+g64_last_causes = None
+G64_CAUSES = ("aperture_rim", "mask_texel_edge", "critical_angle", "grazing_miss")
+
+
 def g64_trace(lens, W, H, y0, y1, spp, key, pairs, include_primary, mask, sun_dir, sun_radiance,
-              sun_angular_radius, n_threads=8, lambda_rgb=None, sub_bits=6, cull=None, **eps):
+              sun_angular_radius, n_threads=8, lambda_rgb=None, sub_bits=6, cull=None, causes=False, **eps):
     """-> (image, frag, counters): image / frag are H x W x 3; a faithful float32 evaluation of the
     same estimator satisfies |pixel32 - image| <= tol * image + frag (see lf_geo_f64.c).  cull: a table from
-    LensFlare.cull_table() -- the image stays the full enumeration's, the counters count the rays the device starts."""
+    LensFlare.cull_table() -- the image stays the full enumeration's, the counters count the rays the device starts.
+    causes=True: g64_last_causes = H x W x 4, the fragile weight per pixel (summed over the channels) by cause --
+    aperture rim, mask texel edge, critical angle, grazing miss of a sphere."""
+    global g64_last_causes
     L = g64_lens(lens, sun_dir, sun_radiance, sun_angular_radius, lambda_rgb, **eps)
     table = _device_cull(cull, W, H, spp) if cull is not None else None
     if pairs is None:
@@ -576,12 +583,15 @@ def g64_trace(lens, W, H, y0, y1, spp, key, pairs, include_primary, mask, sun_di
     if table is not None:
         table, block_px = table
         lib().g64_set_cull(_p(table, C.c_uint64), table.shape[1], table.shape[0], table.shape[2] - 1, block_px)
+    g64_last_causes = np.zeros((H, W, 4), np.float64) if causes else None
+    lib().g64_set_cause_buffer(_p(g64_last_causes, C.c_double) if causes else None)
     try:
         lib().g64_trace(C.byref(L), W, H, y0, y1, spp, k, int(sub_bits), _p(pairs, C.c_int), len(pairs),
                         _p(mask, C.c_float), mask.shape[1], mask.shape[0], _p(image, C.c_double),
                         _p(frag, C.c_double), cnt, n_threads)
     finally:
         lib().g64_set_cull(None, 0, 0, 0, 64)
+        lib().g64_set_cause_buffer(None)
     return image, frag, dict(zip(G64_COUNTERS, (int(v) for v in cnt)))
 
 

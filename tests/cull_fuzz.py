@@ -239,7 +239,7 @@ def run(N, SEED, log=sys.stderr, only=None, hook=None, families=4, knobs=None, a
         if log:
             print(json.dumps(rec), file=log, flush=True)
     lf.close()
-    done = [r for r in out if "culled" in r]
+    done = [r for r in out if "started" in r]
     summary = {"seed": SEED, "cases": N, "compared": len(done), "refused": len(out) - len(done),
                "culled_kernel_ran": sum(1 for r in done if r["culled"]), "frames_differing": bad,
                "audit_rays": int(sum(r["audit_rays"] for r in done)), "audit_lit": int(sum(r["audit_lit"] for r in done)),
