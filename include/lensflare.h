@@ -541,6 +541,7 @@ lf_status lf_get_cull_audit(lf_ctx* ctx, uint64_t* rays, uint64_t* lit, int* lau
  * variable changes what this library computes):
  *   "cull_force" 0/1            keep the culled march whatever the table starts (small test frames)
  *   "cull_weights_first" 0/1    the Fresnel / mask weight on EVERY executed event (SURVEY 8d's unit), same pixels
+ *   "cull_no_prefix" 0/1        every started path marched alone from the sensor (round 5's culled march), same pixels
  *   "cull_general_kernel" 0/1   build the table with the kernel that takes its rules as arguments (must give the shipped one's table)
  *   "cull_strict", "cull_strict_lost", "cull_slack", "cull_keep_partial", "cull_disable", "cull_margin", "cull_lobe_k",
  *   "cull_lost_rel", "cull_lost_abs"   the pre-pass rules round 5 REPLACED (they lose lit rays on some prescriptions:

@@ -1025,6 +1025,7 @@ lf_status lf_test_knob(lf_ctx* ctx, const char* name, double value) {
   bool rules = true;
   if (n == "cull_force") { ctx->cull_force = iv != 0; return LF_OK; }
   if (n == "cull_weights_first") { ctx->cull_weights_first = iv != 0; return LF_OK; }
+  if (n == "cull_no_prefix") { ctx->cull_no_prefix = iv != 0; return LF_OK; }
   if (n == "scene_compact") { ctx->scene_compact = iv < 0 ? -1 : iv != 0; return LF_OK; }
   if (n == "comm_force_exchange") { ctx->comm_force_exchange = iv != 0; return LF_OK; }
   if (n == "scene_lens_strided") { ctx->scene_lens_strided = iv < 0 ? -1 : iv != 0; return LF_OK; }

@@ -749,6 +749,7 @@ constexpr int kListMax = 4096;   // samples of one tile's workgroup (spp / sgrou
 // what a wave tallies while it marches (slots of lf_counters / lf_get_march_stats)
 struct PathTally {
   unsigned long long n_rays = 0, events = 0, n_clip = 0, n_vign = 0, n_tir = 0, n_scene = 0, n_rm_lane = 0, n_rm_rows = 0;
+  unsigned long long executed = 0;   // rows really executed (a row of the common leg once): march_started_set; march_started_path: = events
   unsigned n_light = 0;   // per lane
 };
 
@@ -843,6 +844,7 @@ __device__ __forceinline__ void march_started_path(const LfLensDev* __restrict__
       ev32 += nlive;       // events completed: one per ray still alive after the row
     }
     T.events += ev32;
+    T.executed += ev32;
     if (nlive == 0u) continue;
     // ---- the path is complete for nlive rays --------------------------------------------------
     T.n_scene += nlive;
@@ -903,12 +905,194 @@ __device__ __forceinline__ void march_started_path(const LfLensDev* __restrict__
   }
 }
 
+// ---- the started paths of ONE sample, their common leg marched once (round 6) ----------------------------------------
+// Every path starts with the same leg from the sensor towards the scene -- the primary path's events -- and leaves it at
+// its first mirror i after N - 1 - i of them (the primary path never does).  march_started_path marches that leg again for
+// every started path; the paths a sample starts, though, are few and MOST of what they execute is this leg (a pair (i, j)
+// of the 11-interface lens: 10 - i of its 11 + 2 (j - i) events, and the rays that end early end in it).  Here the wave
+// keeps ONE running state of the common leg: the started paths are taken in the order of their first mirrors, rear ones
+// first (= descending path index: the selection lists pairs by (i, j) ascending with the primary path in front; the host
+// checks it, LfCullArgs::prefix_ok), the leg is extended to where the next path leaves it, the path's own events run on a
+// copy.  The arithmetic on a ray is the same events in the same order: pixels and counters are those of every path
+// marched alone -- a row of the common leg counts once for every started path that shares it (the paths not yet done) --
+// while the rows EXECUTED fall by the shared part (the device's executed-events counter, slot 7).
+// Geometry first (W1 = false): a lane that ends inside the lobe marches its path again, alone, with the weight, as before.
+template <int K>
+__device__ __forceinline__ void march_started_set(const LfLensDev* __restrict__ lens, const LfPairsDev* __restrict__ pairs,
+                                                  const int* __restrict__ seq_table, const LfProgRow* __restrict__ rec_table,
+                                                  const LfWeightRow* __restrict__ wrec_table, const float* __restrict__ mask,
+                                                  const MarchArgs& a, unsigned long long todo, lanemask active_mask, float X, float Y,
+                                                  const StartRay& s0, int lane, unsigned long long* __restrict__ s_acc,
+                                                  const int2* __restrict__ s_meta, PathTally& T) {
+  const int n_lambda = lens->n_lambda, prog_recs = pairs->prog_recs;
+  const int n_groups = (n_lambda + K - 1) / K;
+  const float inv_stop_h = a.inv_stop_h, lobe_thr = a.lobe_thr;
+  const float sx = lens->sun_dir[0], sy = lens->sun_dir[1], sz = lens->sun_dir[2];
+  const float inv_1mc = lens->sun_inv_one_minus_cos, sun_ss = lens->sun_ss;
+  const unsigned n_started = (unsigned)__popcll(todo);
+  for (int g = 0; g < n_groups; g++) {
+    const LfProgRow* const recs = rec_table + (size_t)g * (size_t)prog_recs;
+    const LfWeightRow* const wrecs = wrec_table + (size_t)g * (size_t)prog_recs;
+    // ONE running state: the common leg while it is common, then the path that left it -- whose start (the leg's state at
+    // the fork) is parked in p and taken back when the path is done
+    Ray r[K], p[K];
+    lanemask alive[K], palive[K];
+    unsigned nlive = 0u, pn = 0u;
+#pragma unroll
+    for (int j = 0; j < K; j++) {
+      r[j] = Ray{X, Y, 0.0f, fmaf(X, X, Y * Y), s0.dx, s0.dy, s0.dz, s0.w0, 1.0f};
+      const float ns = lens->n_start[min(g * K + j, n_lambda - 1)];
+      r[j].dx *= ns; r[j].dy *= ns; r[j].dz *= ns;
+      alive[j] = (g * K + j < n_lambda) ? active_mask : 0ull;
+      nlive += (unsigned)__popcll(alive[j]);
+      p[j] = r[j]; palive[j] = alive[j];
+    }
+    T.n_rays += (unsigned long long)nlive * n_started;
+    int depth = 0;            // events of the common leg done
+    unsigned long long left = todo;
+    while (left != 0ull && nlive != 0u) {
+      const int q = 63 - __builtin_clzll(left);
+      left &= ~(1ull << q);
+      // (the path's events and where it leaves the common leg: from the workgroup's LDS copy, not three dependent scalar loads)
+      const int2 meta = s_meta[q];
+      const int n_ev = meta.x >> 16, L = meta.x & 0xffff;
+      const int* const seq = seq_table + meta.y;
+      unsigned mult = (unsigned)__popcll(left) + 1u;               // this path and those still to come share the leg so far
+      bool forked = false;
+      unsigned seg = 0u;                 // sum of the rays alive after each row of the current segment (leg / path)
+      unsigned long long ev_logical = 0ull;
+      unsigned ev_exec = 0u;
+      unsigned se = depth < n_ev ? (unsigned)*(const int __attribute__((address_space(4)))*)(seq + depth) : 0u;
+      for (int e = depth; e < n_ev && nlive != 0u; e++) {
+        if (e == L) {      // the path leaves the common leg: park the leg
+#pragma unroll
+          for (int j = 0; j < K; j++) { p[j] = r[j]; palive[j] = alive[j]; }
+          pn = nlive; forked = true;
+          ev_logical = (unsigned long long)seg * mult; ev_exec = seg; seg = 0u; mult = 1u;
+        }
+        const unsigned cur = se;
+        if (e + 1 < n_ev) se = (unsigned)*(const int __attribute__((address_space(4)))*)(seq + e + 1);
+        const LfProgRow wr = load_prec(recs, cur & 0xffffu);
+        const unsigned kind = cur >> 16;
+        lanemask okv[K], gv[K], died = 0ull;
+        if (kind & LF_EV_STOP) {
+#pragma unroll
+          for (int j = 0; j < K; j++) {
+            if (K > 1 && __builtin_expect(alive[j] == 0ull, 0)) { okv[j] = 0ull; gv[j] = 0ull; continue; }
+            okv[j] = stop_event<false>(r[j], wr.dzv, wr.h2, inv_stop_h, mask, a.mw, a.mh);
+            gv[j] = okv[j];
+            died |= alive[j] & ~okv[j];
+          }
+          if (__builtin_expect(died != 0ull, 0)) {
+#pragma unroll
+            for (int j = 0; j < K; j++) {
+              const unsigned nd = (unsigned)__popcll(alive[j] & ~okv[j]);
+              T.n_clip += (unsigned long long)nd * mult; nlive -= nd; alive[j] &= okv[j];
+            }
+          }
+        } else {
+#pragma unroll
+          for (int j = 0; j < K; j++) {
+            if (K > 1 && __builtin_expect(alive[j] == 0ull, 0)) { okv[j] = 0ull; gv[j] = 0ull; continue; }
+            okv[j] = surface_event<false>(r[j], wr.dzv, wr.curv, wr.ch, wr.c2, wr.sc, wr.cn22[j], wr.rn2[j], wr.delta[j], wr.h2,
+                                          (kind & LF_EV_REFLECT) != 0, (kind & LF_EV_FLAT) != 0, wr.sgn, gv[j]);
+            died |= alive[j] & ~okv[j];
+          }
+          if (__builtin_expect(died != 0ull, 0)) {
+#pragma unroll
+            for (int j = 0; j < K; j++) {
+              T.n_vign += (unsigned long long)__popcll(alive[j] & ~gv[j]) * mult;
+              T.n_tir += (unsigned long long)__popcll(alive[j] & gv[j] & ~okv[j]) * mult;
+              nlive -= (unsigned)__popcll(alive[j] & ~okv[j]);
+              alive[j] &= okv[j];
+            }
+          }
+        }
+        seg += nlive;       // events completed: one per ray still alive after the row
+      }
+      // ... counted once for every logical path that shares the row (the leg's rows: `mult` paths), and once as executed
+      T.events += ev_logical + (unsigned long long)seg * mult;
+      T.executed += ev_exec + seg;
+      if (!forked && L < n_ev) break;       // the common leg ended for every lane before path q left it: so did every path still to come
+      if (nlive != 0u) {
+        // ---- the path is complete for nlive rays (as march_started_path) ---------------------------------
+        T.n_scene += nlive;
+        lanemask lit[K], lit_any = 0ull;
+#pragma unroll
+        for (int j = 0; j < K; j++) {
+          const float cg = fmaf(r[j].dx, sx, fmaf(r[j].dy, sy, r[j].dz * sz));
+          lit[j] = alive[j] & __ballot(cg > lobe_thr);
+          lit_any |= lit[j];
+        }
+        if (lit_any != 0ull) {
+          for (int j = 0; j < K; j++) {        // not unrolled: one copy of the weighted march
+            lanemask lj = lit[0];
+#pragma unroll
+            for (int jj = 1; jj < K; jj++) lj = (j == jj) ? lit[jj] : lj;
+            if (lj == 0ull) continue;
+            const int l = g * K + j;
+            // the path again, alone and with its weight: the same arithmetic on the ray, so the same ray bit for bit
+            Ray rw = Ray{X, Y, 0.0f, fmaf(X, X, Y * Y), s0.dx, s0.dy, s0.dz, s0.w0, 1.0f};
+            { const float ns = lens->n_start[l]; rw.dx *= ns; rw.dy *= ns; rw.dz *= ns; }
+            T.n_rm_lane += (unsigned long long)((unsigned)n_ev * (unsigned)__popcll(lj));
+            T.n_rm_rows += (unsigned)n_ev;
+            const int* w = seq;
+            for (int rem = n_ev; rem > 0; --rem, ++w) {
+              const unsigned se2 = (unsigned)*(const int __attribute__((address_space(4)))*)(w);
+              const LfProgRow wr = load_prec(recs, se2 & 0xffffu);
+              const LfWeightRow ww = load_wrec(wrecs, se2 & 0xffffu);
+              const unsigned wfl = se2 >> 16;
+              const float w_cn22 = j == 0 ? wr.cn22[0] : j == 1 ? wr.cn22[1] : wr.cn22[2];
+              const float w_rn2 = j == 0 ? wr.rn2[0] : j == 1 ? wr.rn2[1] : wr.rn2[2];
+              const float w_delta = j == 0 ? wr.delta[0] : j == 1 ? wr.delta[1] : wr.delta[2];
+              const float w_fs = j == 0 ? ww.fs[0] : j == 1 ? ww.fs[1] : ww.fs[2];
+              const float w_fo = j == 0 ? ww.fo[0] : j == 1 ? ww.fo[1] : ww.fo[2];
+              const float w_fi = j == 0 ? ww.fi[0] : j == 1 ? ww.fi[1] : ww.fi[2];
+              if (wfl & LF_EV_STOP) {
+                (void)stop_event<true>(rw, wr.dzv, wr.h2, inv_stop_h, mask, a.mw, a.mh);
+              } else {
+                lanemask geom_ok;
+                (void)surface_event<true>(rw, wr.dzv, wr.curv, wr.ch, wr.c2, wr.sc, w_cn22, w_rn2, w_delta, wr.h2,
+                                          (wfl & LF_EV_REFLECT) != 0, (wfl & LF_EV_FLAT) != 0, wr.sgn, geom_ok, w_fs, w_fo, w_fi);
+              }
+            }
+            const float qq = lobe_q(rw.dx, rw.dy, rw.dz, sx, sy, sz, sun_ss, inv_1mc);
+            const float om = 1.0f - qq;
+            float contrib = __fdiv_rn(rw.wn, rw.wd) * (om * om);
+            contrib = (((lj >> lane) & 1ull) != 0ull && qq < 1.0f && contrib > 0.0f) ? contrib : 0.0f;
+            T.n_light += contrib > 0.0f ? 1u : 0u;
+#pragma unroll
+            for (int c = 0; c < 3; c++) {
+              const float v = contrib * (lens->sun_radiance[c] * lens->lambda_rgb[l][c]);
+              const unsigned long long fx = (unsigned long long)(v * 68719476736.0f);
+              if (fx) atomicAdd(&s_acc[lane * 3 + c], fx);
+            }
+          }
+        }
+      }
+      if (!forked) break;                     // (the primary path: the common leg to its end, nothing after it)
+      // back to the common leg where path q left it
+#pragma unroll
+      for (int j = 0; j < K; j++) { r[j] = p[j]; alive[j] = palive[j]; }
+      nlive = pn;
+      depth = L;
+    }
+  }
+}
+
 // W1: the first (and then only) march of a started path carries its Fresnel / aperture weight.  false = geometry first,
 // and the path is marched again with the weight, one wavelength at a time, only where a lane ended inside the lobe
 // pre-test (k_march's scheme: 6 % of the STARTED rays are lit on the bench frame, so the weight's 17 of 44 vector
 // instructions per event are mostly wasted in the first march: measured in profiles/r05_march_variants.txt).
-template <int K, bool W1>
-__global__ __launch_bounds__(64 * kWgWaves, (K == 1 ? 8 : 6))
+// SHARED: the wave looks ONE table entry up per sample (its lanes share the sample's pupil sub-cell, a block holds the whole
+// tile) and the started paths' common leg is marched once (march_started_set); otherwise (independent pixels, blocks smaller
+// than a wave tile, the weight on every event, a selection out of order) every started path is marched alone.
+#ifndef LF_SHARED_WAVES
+#define LF_SHARED_WAVES 6     // waves per SIMD of the shared-leg kernel with K > 1 (two ray states per lane: 80 VGPR, a few spilled;
+                              // a workgroup holds 2 waves per SIMD, so 5 runs as 4: 47 ms against 38 on the bench frame)
+#endif
+template <int K, bool W1, bool SHARED>
+__global__ __launch_bounds__(64 * kWgWaves, (K == 1 ? 8 : SHARED ? LF_SHARED_WAVES : 6))
 void k_march_cull(const LfLensDev* __restrict__ lens, const LfPairsDev* __restrict__ pairs,
                   const int* __restrict__ seq_table, const LfProgRow* __restrict__ rec_table,
                   const LfWeightRow* __restrict__ wrec_table, const float* __restrict__ mask, MarchArgs a,
@@ -918,10 +1102,15 @@ void k_march_cull(const LfLensDev* __restrict__ lens, const LfPairsDev* __restri
   __shared__ unsigned long long s_cnt[kMarchCounters];
   __shared__ int s_next, s_nlist;
   __shared__ unsigned short s_list[kListMax];
+  __shared__ int2 s_meta[SHARED ? kCullMaxPaths : 1];      // per path: events << 16 | events of the common leg; first row of its sequence
   const int tid = threadIdx.x;
   if (tid < 64 * 3) s_acc[tid] = 0ull;
   if (tid < kMarchCounters) s_cnt[tid] = 0ull;
   if (tid == 0) { s_next = 0; s_nlist = 0; }
+  if (SHARED && tid < pairs->n && tid < kCullMaxPaths) {
+    const int n_ev = pairs->ev_cnt[tid], i1 = pairs->ij[tid][0];
+    s_meta[tid] = make_int2((n_ev << 16) | (i1 < 0 ? n_ev : lens->n_surf - 1 - i1), pairs->ev_off[tid]);
+  }
   __syncthreads();
 
   // tile of the workgroup: as k_march (XCD-aware slot swizzle, wave tile = 8 rows x 8 columns 2^xs apart)
@@ -951,7 +1140,7 @@ void k_march_cull(const LfLensDev* __restrict__ lens, const LfPairsDev* __restri
   const int GG = a.G * a.G;
   // do the lanes of a wave aim a stratified sample at ONE cell of the table?  (they share a sub-cell of the stratum;
   // the table has m cells per stratum axis)
-  const bool per_lane = (1 << a.sub_bits) < cull.m || cull.multi != 0;
+  const bool per_lane = (1 << a.sub_bits) < cull.m;
 
   PathTally T;
 
@@ -962,7 +1151,8 @@ void k_march_cull(const LfLensDev* __restrict__ lens, const LfPairsDev* __restri
     for (int k = tid; k < chunk_n; k += 64 * kWgWaves) {
       const int s = sg + (chunk0 + k) * a.sgroups;
       bool work = true;     // (a sample whose lanes look their cells up one by one is listed: the sample loop finds out)
-      if (s < GG && !per_lane) {
+      if (s >= GG && !cull.multi) work = crow[cull.cells] != 0ull;
+      if (s < GG && !per_lane && !cull.multi) {
         // the table cell of the sub-cell the wave's lanes all aim sample s at (the draw of the sample loop below)
         const uint4 r2 = philox4x32_10(make_uint4(tile_id, (unsigned)s, kDomainSubcell, 0u), a.key);
         const unsigned sxi = a.sub_bits ? (r2.x >> (32 - a.sub_bits)) : 0u, syi = a.sub_bits ? (r2.y >> (32 - a.sub_bits)) : 0u;
@@ -994,22 +1184,30 @@ void k_march_cull(const LfLensDev* __restrict__ lens, const LfPairsDev* __restri
         if (!per_lane) entry = (cy * cull.m + (int)((syi << cull.m_shift) >> a.sub_bits)) * cull.P + cx * cull.m + (int)((sxi << cull.m_shift) >> a.sub_bits);
       }
       // the paths to start: one scalar load for the wave -- or, where the lanes aim at different cells of the table
-      // (independent pixels, an unstratified sample), each lane's own mask and their union
+      // (independent pixels), each lane's own mask and their union.  An unstratified sample (s >= G * G: a sample count
+      // that is no square) takes the block's union entry.
+      if (s >= GG) entry = cull.cells;
+      const float pa0 = fmaf(2.0f, ua, -1.0f), pb0 = fmaf(2.0f, ub, -1.0f);
+      const float X = -(((float)x + jx) - half_w) * pitch;
+      const float Y = -(((float)y + jy) - half_h) * pitch;
+      if (SHARED) {
+        const unsigned long long todo = crow[entry];
+        if (todo == 0ull) continue;
+        const StartRay s0 = aim_at_pupil(X, Y, pa0, pb0, pupil_h, vz_u, geom_norm);
+        march_started_set<K>(lens, pairs, seq_table, rec_table, wrec_table, mask, a, todo, active_mask, X, Y, s0, lane, s_acc, s_meta, T);
+        continue;
+      }
       unsigned long long mine, todo;
-      if (entry >= 0) { todo = crow[entry]; mine = todo; }
+      if (entry >= 0 && !cull.multi) { todo = crow[entry]; mine = todo; }
       else {
         const int fx = min(cull.P - 1, (int)(ua * (float)cull.P)), fy = min(cull.P - 1, (int)(ub * (float)cull.P));
-        mine = active ? crow_lane[fy * cull.P + fx] : 0ull;
+        mine = active ? crow_lane[entry >= 0 ? entry : fy * cull.P + fx] : 0ull;
         unsigned lo = (unsigned)mine, hi = (unsigned)(mine >> 32);
         for (int off = 32; off > 0; off >>= 1) { lo |= __shfl_xor(lo, off); hi |= __shfl_xor(hi, off); }
         todo = ((unsigned long long)__builtin_amdgcn_readfirstlane(hi) << 32) | (unsigned long long)__builtin_amdgcn_readfirstlane(lo);
-        if (todo == 0ull) continue;
       }
-      const float pa = fmaf(2.0f, ua, -1.0f), pb = fmaf(2.0f, ub, -1.0f);
-      const float X = -(((float)x + jx) - half_w) * pitch;
-      const float Y = -(((float)y + jy) - half_h) * pitch;
-      const StartRay s0 = aim_at_pupil(X, Y, pa, pb, pupil_h, vz_u, geom_norm);
-
+      if (todo == 0ull) continue;
+      const StartRay s0 = aim_at_pupil(X, Y, pa0, pb0, pupil_h, vz_u, geom_norm);
       unsigned long long left_q = todo;
       while (left_q != 0ull) {
         const int q = __builtin_ctzll(left_q);
@@ -1028,7 +1226,7 @@ void k_march_cull(const LfLensDev* __restrict__ lens, const LfPairsDev* __restri
   {
     unsigned long long v6 = T.n_light;
     for (int off = 32; off > 0; off >>= 1) v6 += __shfl_down(v6, off);
-    const unsigned long long vals[kMarchCounters] = {T.n_rays, T.events, T.n_clip, T.n_vign, T.n_tir, T.n_scene, v6, T.events, T.n_rm_lane, T.n_rm_rows};
+    const unsigned long long vals[kMarchCounters] = {T.n_rays, T.events, T.n_clip, T.n_vign, T.n_tir, T.n_scene, v6, T.executed, T.n_rm_lane, T.n_rm_rows};
     if (lane == 0) {
 #pragma unroll
       for (int i = 0; i < kMarchCounters; i++)
@@ -1134,6 +1332,7 @@ void k_march_items(const LfLensDev* __restrict__ lens, const LfPairsDev* __restr
     const int s = sg + k_global * a.sgroups;
     float ua, ub, jx, jy;
     pupil_point(x, y, s, ua, ub, jx, jy);
+    if (s >= GG) return crow[cull.cells];           // an unstratified sample: the block's union entry
     const int fx = min(cull.P - 1, (int)(ua * (float)cull.P)), fy = min(cull.P - 1, (int)(ub * (float)cull.P));
     return crow[fy * cull.P + fx];
   };
@@ -1220,7 +1419,7 @@ void k_march_items(const LfLensDev* __restrict__ lens, const LfPairsDev* __restr
   {
     unsigned long long v6 = T.n_light;
     for (int off = 32; off > 0; off >>= 1) v6 += __shfl_down(v6, off);
-    const unsigned long long vals[kMarchCounters] = {T.n_rays, T.events, T.n_clip, T.n_vign, T.n_tir, T.n_scene, v6, T.events, T.n_rm_lane, T.n_rm_rows};
+    const unsigned long long vals[kMarchCounters] = {T.n_rays, T.events, T.n_clip, T.n_vign, T.n_tir, T.n_scene, v6, T.executed, T.n_rm_lane, T.n_rm_rows};
     if (lane == 0) {
 #pragma unroll
       for (int i = 0; i < kMarchCounters; i++)
@@ -1642,10 +1841,18 @@ lf_status lfk_march_culled(lf_ctx* ctx, const MarchArgs& a, size_t blocks, size_
   c.share_n = ctx->cull_share_nb > 0 ? ctx->cull_share_n_resident : 1; c.share_nb = ctx->cull_share_nb;
   c.blk_log2 = ctx->cull_blk_log2;
   c.multi = ctx->cull_blk_log2 < 3 + a.xs ? 1 : 0;
+  // the started paths' common leg is marched once (march_started_set) if a higher path index never leaves it later:
+  // the primary path in front, the pairs by ascending first mirror -- the order lf_set_ghost_pairs(NULL) and any sorted list give
+  c.prefix_ok = 1;
+  for (int q = 1; q < ctx->pairs.n; q++) {
+    const int ia = ctx->pairs.ij[q - 1][0], ib = ctx->pairs.ij[q][0];
+    if (ib < 0 || (ia >= 0 && ib < ia)) c.prefix_ok = 0;
+  }
+  if (ctx->cull_no_prefix) c.prefix_ok = 0;
   c.P = ctx->cull_P; c.m = ctx->cull_m; c.m_shift = ctx->cull_m == 4 ? 2 : ctx->cull_m == 2 ? 1 : 0;
   hipEvent_t ev = lf_timing_begin(ctx, LFK_MARCH);
-#define LF_LAUNCH_CULL1(KK, WW)                                                                               \
-  hipLaunchKernelGGL((k_march_cull<KK, WW>), dim3((unsigned)blocks), dim3(64 * kWgWaves), dyn_lds, ctx->stream, ctx->lens_dev, \
+#define LF_LAUNCH_CULL1(KK, WW, SS)                                                                           \
+  hipLaunchKernelGGL((k_march_cull<KK, WW, SS>), dim3((unsigned)blocks), dim3(64 * kWgWaves), dyn_lds, ctx->stream, ctx->lens_dev, \
                      ctx->pairs_dev, (const int*)(ctx->prog_dev + ctx->prog_seq_off),                         \
                      (const LfProgRow*)(ctx->prog_dev + ctx->prog_rec_off),                                  \
                      (const LfWeightRow*)(ctx->prog_dev + ctx->prog_wrec_off), m.texels, a, c, ctx->ghost,   \
@@ -1656,7 +1863,8 @@ lf_status lfk_march_culled(lf_ctx* ctx, const MarchArgs& a, size_t blocks, size_
                      (const LfProgRow*)(ctx->prog_dev + ctx->prog_rec_off),                                  \
                      (const LfWeightRow*)(ctx->prog_dev + ctx->prog_wrec_off), m.texels, a, c, ctx->ghost,   \
                      ctx->accum, ctx->counters_dev)
-#define LF_LAUNCH_CULL(KK) do { if (items) LF_LAUNCH_ITEMS(KK); else if (weights_first) LF_LAUNCH_CULL1(KK, true); else LF_LAUNCH_CULL1(KK, false); } while (0)
+#define LF_LAUNCH_CULL(KK) do { if (items) LF_LAUNCH_ITEMS(KK); else if (weights_first) LF_LAUNCH_CULL1(KK, true, false); \
+                                else if (shared_leg) LF_LAUNCH_CULL1(KK, false, true); else LF_LAUNCH_CULL1(KK, false, false); } while (0)
   const bool weights_first = ctx->cull_weights_first;   // (lf_test_knob: the weight on every executed event)
   // every pixel its own pupil point (no sub-cells at all): the compacted march.  (2 x 2 sub-cells, where the lanes of a
   // wave still look their cells up one by one, stay with k_march_cull: 48 against 59 ms on the bench frame)
@@ -1664,6 +1872,8 @@ lf_status lfk_march_culled(lf_ctx* ctx, const MarchArgs& a, size_t blocks, size_
 #ifdef LF_EXPERIMENTS
   if (const char* e = std::getenv("LF_CULL_ITEMS")) items = std::atoi(e) != 0;
 #endif
+  // one table entry per (wave tile, sample) and a selection in order: the started paths' common leg once (march_started_set)
+  const bool shared_leg = c.prefix_ok && !c.multi && (1 << a.sub_bits) >= c.m;
   switch (ctx->march_k) {
     case 1: LF_LAUNCH_CULL(1); break;
     case 2: LF_LAUNCH_CULL(2); break;

@@ -227,6 +227,7 @@ __host__ __device__ inline size_t lf_cull_row_of_block(int b, int share_n, int s
 struct LfCullArgs {
   const unsigned long long* table;   // [rows][cells + 1], row = lf_cull_row_of_block(block); null = every path everywhere
   int blocks_x, blocks_y;
+  int prefix_ok;                      // the selection's order lets the started paths share their common leg (march_started_set)
   int multi;                          // a wave tile spans several blocks (blocks of 16 / 32 pixels under a 64-pixel tile): rows per lane
   int share_n, share_nb;              // see lf_cull_row_of_block
   int blk_log2;                       // log2 of a block's side in pixels
@@ -420,6 +421,7 @@ struct lf_ctx {
   bool cull_rules_custom = false;              // a test installed rules / asked for the general kernel (lf_test_knob)
   bool cull_force = false;                     // lf_test_knob("cull_force"): the culled kernel whatever the table starts
   bool cull_weights_first = false;             // lf_test_knob("cull_weights_first"): k_march_cull<K, true>
+  bool cull_no_prefix = false;                 // lf_test_knob("cull_no_prefix"): every started path marched alone from the sensor (round 5)
   int scene_compact = -1;                      // lf_test_knob("scene_compact"): -1 = by the tree's size, 0 / 1 forced
   bool comm_force_exchange = false;            // lf_test_knob("comm_force_exchange"): the collectives also with one rank
   int scene_lens_strided = -1;                 // lf_test_knob("scene_lens_strided"): k_scene_lens's wave tile: -1 by the tree's size, 0 / 1

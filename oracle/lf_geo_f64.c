@@ -398,7 +398,9 @@ void g64_trace(const g64_lens* L, int W, int H, int y0, int y1, int spp, const u
           /* P = G m table cells per axis; the cell of the sub-cell the pixel's wave tile aims sample s at */
           int entry = g64_cull_cells;
           const int P = (int)(sqrt((double)g64_cull_cells) + 0.5), m = P / G;
-          if (s >= GG || (1 << sub_bits) < m) {   /* the cell of the pixel's own pupil point (the device: in float) */
+          if (s >= GG) {
+            entry = g64_cull_cells;                 /* an unstratified sample: the block's union entry */
+          } else if ((1 << sub_bits) < m) {         /* the cell of the pixel's own pupil point (the device: in float) */
             int fx = (int)(t64_ua * P), fy = (int)(t64_ub * P);
             if (fx > P - 1) fx = P - 1;
             if (fy > P - 1) fy = P - 1;

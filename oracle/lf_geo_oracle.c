@@ -468,11 +468,13 @@ void geo_trace(const geo_lens* L, int W, int H, int y0, int y1, int spp, const u
         if (g_cull) {
           /* The table cell of the pupil point the sample aims at; P = G m cells per axis.  A stratified sample of a
            * specification with at least m sub-cells per stratum axis: the cell of the sub-cell (sxi, syi) the pixel's
-           * wave tile drew (one scalar lookup per wave on the device).  Otherwise -- independent pixels, an
-           * unstratified sample -- the cell that holds the pixel's own point: floor(ua P), floor(ub P) in float. */
+           * wave tile drew (one scalar lookup per wave on the device).  Independent pixels: the cell that holds the
+           * pixel's own point, floor(ua P), floor(ub P) in float.  An unstratified sample (s >= G * G): the union entry. */
           int entry = g_cull_cells;
           const int G = strata(spp), P = (int)(sqrt((double)g_cull_cells) + 0.5), m = P / G;
-          if (s >= GG || (1 << g_sub_bits) < m) {
+          if (s >= GG) {
+            entry = g_cull_cells;              /* an unstratified sample: the block's union entry */
+          } else if ((1 << g_sub_bits) < m) {
             int fx = (int)(t_ua * (float)P), fy = (int)(t_ub * (float)P);
             if (fx > P - 1) fx = P - 1;
             if (fy > P - 1) fy = P - 1;

@@ -26,10 +26,16 @@ lf.set_ghost_pairs(None, True)
 lf.set_march_culling(2)
 lf.set_cull_audit(0)
 out = {}
-for name, knobs in (("shipped", {}), ("general_kernel_same_rules", {"cull_general_kernel": 1}),
+only = sys.argv[1:]
+for name, knobs in (("shipped", {}), ("every_started_path_alone_round5_march", {"cull_no_prefix": 1}), ("general_kernel_same_rules", {"cull_general_kernel": 1}),
                     ("UNSAFE_too_few_samples_dropped", {"cull_disable": 16}),
-                    ("UNSAFE_lost_samples_dropped", {"cull_disable": 32}), ("UNSAFE_both_dropped", {"cull_disable": 48})):
+                    ("UNSAFE_lost_samples_dropped", {"cull_disable": 32}), ("UNSAFE_both_dropped", {"cull_disable": 48}),
+                    ("UNPROVEN_lobe_k_1", {"cull_lobe_k": 1.0}), ("UNPROVEN_lobe_k_1_margin_1", {"cull_lobe_k": 1.0, "cull_margin": 1.0}),
+                    ("UNPROVEN_margin_1", {"cull_margin": 1.0})):
+    if only and name not in only:
+        continue
     lf.test_knob("cull_general_kernel", 0)
+    lf.test_knob("cull_no_prefix", 0)
     for k, v in knobs.items():
         lf.test_knob(k, v)
     lf.trace_ghosts(spp, 1)

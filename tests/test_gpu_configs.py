@@ -158,7 +158,9 @@ def test_c3_full_spp_frame(pkg, lf):
     executed = lf.executed_events()
     assert lf.cull_info()["culled"] and ray_budget(lf, cnt, W * H * spp * 3 * 46)
     assert cnt["rays_launched"] == cnt["rays_clipped_stop"] + cnt["rays_vignetted"] + cnt["rays_tir"] + cnt["rays_reached_scene"]
-    assert cnt["surface_events"] == executed                 # the culled march: every started path on its own
+    # the culled march: the started paths of a sample share their common leg from the sensor (round 6: march_started_set)
+    assert 0.4 * cnt["surface_events"] < executed < 0.9 * cnt["surface_events"]
+    print(f"c3: {cnt['surface_events']:.4g} events of started paths, {executed:.4g} executed (the common leg once per sample)")
     whole = lf.read_buffer(pkg.GHOST_BUFFER)
     # ... and the same frame with EVERY path of every sample marched (the path tree, rounds 1-4): the whole
     # 1920 x 1080 x 256 spp frame is identical, bit for bit -- what the cull skipped added nothing

@@ -108,7 +108,18 @@ def test_culled_march_is_the_full_enumeration_and_the_oracle(pkg, lf, forced, W,
     lf.set_march_culling(2)
     lf.reset_counters()
     lf.trace_ghosts(spp, key)
-    assert lf.executed_events() == c1["surface_events"]             # each started path marched on its own
+    assert 0 < lf.executed_events() <= c1["surface_events"]         # (the started paths of a sample share their common leg)
+    # ... and every started path marched alone from the sensor (round 5's march, lf_test_knob): the same frame and counters
+    lf.test_knob("cull_no_prefix", 1)
+    try:
+        lf.reset_counters()
+        lf.trace_ghosts(spp, key)
+        assert np.array_equal(lf.read_buffer(pkg.GHOST_BUFFER), g1) and lf.counters() == c1
+        assert lf.executed_events() == c1["surface_events"]
+    finally:
+        lf.test_knob("cull_no_prefix", 0)
+    lf.reset_counters()
+    lf.trace_ghosts(spp, key)
     og, oc = lfo.geo_trace(lens, W, H, 0, H, spp, key, None, True, mask, sun, RAD, alpha, n_threads=16)
     assert lfo.last_culled_lit == 0
     assert np.array_equal(g1, og) and oc == c1
@@ -481,7 +492,7 @@ def test_the_audit_catches_the_rules_that_lost_light(pkg, forced):
     assert s["launches_differing_although_refuted"] == 0      # a refuted launch took the path tree: the enumeration's frame
 
 
-@pytest.mark.parametrize("W,H,block", [(1280, 720, 64), (960, 540, 32), (640, 360, 16)])
+@pytest.mark.parametrize("W,H,block", [(1280, 720, 64), (960, 540, 32), (640, 360, 32), (400, 224, 16)])
 def test_small_frames_cull_with_smaller_blocks(pkg, lf, forced, W, H, block):
     """frames narrower than 1280 pixels on the 36 mm sensor: blocks of 32 / 16 pixels (<= 1.8 mm), a wave tile (64 x 8 pixels)
     spans several of them and its lanes look their rows up one by one -- culled = full enumeration, every sampling default"""
@@ -500,13 +511,14 @@ def test_small_frames_cull_with_smaller_blocks(pkg, lf, forced, W, H, block):
     try:
         Wc, Hc, spp = 80, 48, 16
         crop = dict(lens)
-        crop["sensor_width_mm"] = 36.0 * Wc / 640
+        crop["sensor_width_mm"] = 36.0 * Wc / 400       # (0.09 mm per pixel: 32 pixels would be 2.9 mm, 16 are 1.44)
         _setup(pkg, lf, crop, Wc, Hc, [0.03, 0.02, -1.0], 0.05, mask)
         g1, c1, info, g0, c0 = _both(pkg, lf, spp, 5)
         assert info["culled"] and info["block_px"] == 16 and np.array_equal(g1, g0)
         lf.set_march_culling(2)
         lf.reset_counters()
         lf.trace_ghosts(spp, 5)
+        lfo.geo_follow_device(lf)          # (the smoke test above ends with the oracle following no device)
         og, oc = lfo.geo_trace(crop, Wc, Hc, 0, Hc, spp, 5, None, True, mask, [0.03, 0.02, -1.0], RAD, 0.05, n_threads=16)
         assert np.array_equal(g1, og) and oc == c1 and lfo.last_culled_lit == 0
     finally:
