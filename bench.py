@@ -74,7 +74,7 @@ def every_event_weighted():
     except Exception:  # noqa: BLE001
         return None
 TILE_ROWS = 8   # the march kernel's sensor tile is 8x8 pixels
-PMC_FILES = [os.path.join(ROOT, "profiles", n) for n in ("r05_march_pmc.json", "r04_march_pmc.json", "r03_march_pmc.json", "r02_march_pmc.json")]   # newest first
+PMC_FILES = [os.path.join(ROOT, "profiles", n) for n in ("r06_march_pmc.json", "r05_march_pmc.json", "r04_march_pmc.json", "r03_march_pmc.json", "r02_march_pmc.json")]   # newest first
 R04_C3_MS = 105.22        # BENCH_r04.json: the c3 frame of round 4 (every sample marches every path), driver-timed
 
 # BASELINE.json configs[1..4]; configs[3] / [4] are 8-GPU jobs there, here one GPU's whole frame
@@ -525,11 +525,25 @@ def main():
         ex, ey = math.tan(math.radians(hf) / 2), math.tan(math.radians(vf) / 2)
         lights = [[(2 * SUN_NS[0] - 1) * ex * 10, (2 * SUN_NS[1] - 1) * ey * 10, -10.0, 1.0, 0.9, 0.5]]
 
-    # sensor tile rows (8 rows each) are dealt round-robin: tile row t belongs to rank t % world.
-    # One march launch per frame covers all of this rank's tile rows.
+    # The frame is dealt by BLOCKS of 64 x 64 pixels, round-robin (block b belongs to rank b % world: lf_set_block_deal,
+    # round 6): the block is the path cull's, so a rank builds, audits and reads only its own rows of the cull table --
+    # pre-pass, audit and march shrink with the number of ranks and nothing but finished blocks is exchanged.
+    # LF_BENCH_DEAL=rows: rounds 1-5's deal by 8-row tile rows (tile row t belongs to rank t % world) with the cull table
+    # shared by a second collective.  One march launch per frame covers all of this rank's share.
+    deal = os.environ.get("LF_BENCH_DEAL", "blocks")
+    if deal not in ("blocks", "rows"):
+        raise SystemExit("LF_BENCH_DEAL: blocks or rows")
     my_trows = len(sharding.my_tile_rows(H, rank, world))
+    my_blocks = len(sharding.my_blocks(W, H, rank, world))
     lf.set_band(0, H)
-    lf.set_row_interleave(rank, world)
+
+    def set_deal():
+        if deal == "blocks":
+            lf.set_block_deal(rank, world)
+        else:
+            lf.set_row_interleave(rank, world)
+
+    set_deal()
     frame_t, scratch, gather_note = None, {}, None
     if gather_mode == "cabi":
         # Bring-up of the C ABI's RCCL communicator such that no rank can hang behind a peer that failed
@@ -574,6 +588,7 @@ def main():
                 ok, why = False, str(err)
             all_ok, bad = sharding.agree(dist, ok, why)
         if all_ok:
+            set_deal()          # (lf_comm_init_rank deals by tile rows, the C ABI's default: the exchange's unit follows the deal)
             all_ok, bad = sharding.first_exchange(
                 dist, lambda: lf.comm_gather(pkg.SAMPLE_BUFFER), lf.comm_test,
                 timeout_s=float(os.environ.get("LF_BENCH_COMM_TIMEOUT", "120")), on_expire=lf.comm_poison)
@@ -589,12 +604,14 @@ def main():
                 gather_mode = "torch"
                 gather_note = "C-ABI RCCL exchange unavailable (" + "; ".join(bad) + "): torch.distributed nccl exchange"
                 nccl_group = dist.new_group(backend="nccl")
-            lf.set_row_interleave(rank, world)
+            set_deal()
     # The cull pre-pass is shared between the ranks (each builds 1 / world of the table, one all-gather completes it):
     # through the C ABI's communicator where that stands, through the exchange the frame itself falls back to otherwise.
     # LF_BENCH_CULL_SHARE=0: every rank builds the whole table (A/B).
     cull_share = None
-    if multi and cull_mode != 0 and os.environ.get("LF_BENCH_CULL_SHARE", "1") != "0":
+    if multi and cull_mode != 0 and deal == "blocks":
+        cull_share = "not needed: the frame is dealt by cull blocks, every rank builds the rows it reads"
+    elif multi and cull_mode != 0 and os.environ.get("LF_BENCH_CULL_SHARE", "1") != "0":
         if gather_mode == "cabi":
             lf.comm_share_cull(True)
             cull_share = "rccl (C ABI)"
@@ -617,7 +634,7 @@ def main():
         lf.set_sun_from_flares(0, efl, 0.05)   # the sun hand-over: the in-frame light feeds the march
         if cfg["scene"]:
             lf.render_scene_term()
-        if cull_share and gather_mode in ("torch", "host"):
+        if cull_share and deal == "rows" and gather_mode in ("torch", "host"):
             # the host owns the table's exchange: this rank's slab, one in-place all-gather, take-over
             lf.cull_prepare(spp)
             tptr, tn, _ = lf.cull_table_view()
@@ -646,14 +663,14 @@ def main():
         elif gather_mode == "torch":
             lf.synchronize()
             t_x = time.perf_counter()
-            sharding.gather_frame(frame_t, W, H, rank, world, GroupDist, scratch=scratch)
+            (sharding.gather_blocks if deal == "blocks" else sharding.gather_frame)(frame_t, W, H, rank, world, GroupDist, scratch=scratch)
             torch.cuda.synchronize()   # the next frame rewrites these rows on the library's stream
             host_exchange[0] += time.perf_counter() - t_x
         elif gather_mode == "host":
             lf.synchronize()
             t_x = time.perf_counter()
             host = frame_t.cpu()
-            sharding.gather_frame(host, W, H, rank, world, dist)
+            (sharding.gather_blocks if deal == "blocks" else sharding.gather_frame)(host, W, H, rank, world, dist)
             frame_t.copy_(host)
             torch.cuda.synchronize()
             host_exchange[0] += time.perf_counter() - t_x
@@ -779,7 +796,9 @@ def main():
                        float(stats["remarch_lane_events"]), float(stats["remarch_rows"])] +
                       [float(cnt[k]) for k in fate_keys] + [dt], dtype=torch.float64)
     # what rank 0 needs to tell a bad scaling curve's cause from the record: every rank's own numbers
-    mine = {"rank": rank, "device": local, "tile_rows": my_trows, "march_ms": march_ms / max(n_launch, 1),
+    mine = {"rank": rank, "device": local, "tile_rows": my_trows if deal == "rows" else None, "blocks": my_blocks if deal == "blocks" else None,
+            "prepass_ms": cull_ms / max(n_cull, 1) if n_cull else 0.0, "audit_ms": audit_ms / max(n_audit, 1) if n_audit else 0.0,
+            "march_ms": march_ms / max(n_launch, 1),
             "exchange_ms": xchg_ms / max(n_xchg, 1), "scene_ms": scene_ms / max(n_scene, 1) if n_scene else 0.0,
             "wall_ms_per_step": dt / args.steps * 1e3, "rccl_nranks": rccl_nranks, "rccl_rank": rccl_rank}
     per_rank = [mine]
@@ -800,8 +819,8 @@ def main():
         # ---- roofline of the dominant kernel (k_march) -------------------------------------------
         # algorithmic HBM bytes per launch = framebuffer rows it writes (f64 RGB) + the aperture
         # mask + the lens / program tables it reads
-        rows_per_launch = min(my_trows * TILE_ROWS, H)
-        alg_bytes = rows_per_launch * W * 24 + mask.size * 4 + 64 * 1024
+        px_per_launch = min(my_trows * TILE_ROWS, H) * W if deal == "rows" else min(my_blocks * 64 * 64, W * H)
+        alg_bytes = px_per_launch * 24 + mask.size * 4 + 64 * 1024
         if cull_info["culled"]:   # + the cull table, read once
             alg_bytes += cull_info["blocks_x"] * cull_info["blocks_y"] * (cull_info["cells"] + 1) * 8
         avg_ms = march_ms / max(n_launch, 1)
@@ -888,12 +907,13 @@ def main():
             "dtype": "f32", "data": "synthetic",
             "config": {"workload": f"{args.config}: {cfg['text']}" +
                                    (f" [overridden: {W}x{H}, {spp} spp]" if (args.width or args.height or args.spp) else ""),
-                       "parallelism": f"{world} GPU(s), 8-row sensor tile rows dealt round-robin"
+                       "parallelism": f"{world} GPU(s), " + ("64 x 64-pixel blocks (the cull table's) dealt round-robin" if deal == "blocks"
+                                                                  else "8-row sensor tile rows dealt round-robin")
                                       + ({"cabi": ", one ncclAllGather per frame inside the C ABI (lf_comm_gather_async: overlapped with the next frame's march)",
                                           "torch": ", one torch.distributed nccl all_gather per frame",
                                           "host": ", REHEARSAL: ranks share one GPU, exchange staged through host memory",
                                           "none": ""}[gather_mode]),
-                       "gather_mode": gather_mode, "gather_note": gather_note,
+                       "deal": deal, "gather_mode": gather_mode, "gather_note": gather_note,
                        "exchange_dtype": ("f32" if os.environ.get("LF_BENCH_EXCHANGE") == "f32" else "f64") if world > 1 else None,
                        "rays_per_frame": rays / args.steps,
                        "events_executed_per_frame": executed / args.steps,

@@ -83,6 +83,14 @@ lf_status lf_set_band(lf_ctx* ctx, int y0, int y1);
  * this context marches only those with t % period == phase (default period 1 = all).  Dealing
  * tile rows round-robin to the GPUs balances the vignetting-dependent ray survival. */
 lf_status lf_set_row_interleave(lf_ctx* ctx, int phase, int period);
+/* ... or by BLOCKS of 64 x 64 pixels (round 6): block b (row-major over the frame) belongs to rank b % nranks; a frame
+ * narrower than a multiple of 64 has partial blocks at its right and lower edges.  The block is the path cull's: a rank
+ * that owns whole blocks builds, audits and reads only its own rows of the cull table -- pre-pass, audit and march all
+ * shrink with the number of ranks and the table never crosses a link (where lf_set_row_interleave needs
+ * lf_comm_share_cull / lf_set_cull_share and a second collective per frame).  lf_comm_gather / lf_group_gather
+ * exchange blocks then.  Pixels, counters summed over the ranks and the gathered frame are the single-GPU frame's.
+ * lf_set_row_interleave switches back. */
+lf_status lf_set_block_deal(lf_ctx* ctx, int rank, int nranks);
 /* replaces the public fields PathTracer::ns_aa, flare_radius, flare_intensity
  * (pathtracer.h:93-94,107) */
 lf_status lf_set_params(lf_ctx* ctx, int ns_aa, double flare_radius, double flare_intensity);
@@ -372,6 +380,9 @@ lf_status lf_group_gather(lf_group* g, int which);
  * that renders, once per launch; without it every device builds the whole table (until lf_group_share_cull has been
  * used once: from then on a launch without it is refused, like any launch of a host-shared table). */
 lf_status lf_group_share_cull(lf_group* g, int spp);
+/* the group's frame dealt by blocks of 64 x 64 pixels (lf_set_block_deal on every context; 0: back to tile rows, the
+ * default of lf_group_set_frame).  lf_group_share_cull has nothing to do then. */
+lf_status lf_group_set_block_deal(lf_group* g, int on);
 
 /* ---------------------------------------------------------------- geometric lens --------- */
 /* The north-star path: real ray march through spherical interfaces.  The reference has no

@@ -28,7 +28,7 @@ DEFAULT_SUBCELL_BITS, DEFAULT_TILE_STRIDE = 6, 8
 # every symbol include/lensflare.h declares
 ABI_SYMBOLS = [
     "lf_create", "lf_destroy", "lf_last_error", "lf_abi_version", "lf_set_stream", "lf_synchronize",
-    "lf_set_frame", "lf_set_band", "lf_set_row_interleave", "lf_set_params", "lf_set_aperture", "lf_get_aperture_stats",
+    "lf_set_frame", "lf_set_band", "lf_set_row_interleave", "lf_set_block_deal", "lf_set_params", "lf_set_aperture", "lf_get_aperture_stats",
     "lf_set_paraxial_lens", "lf_set_camera", "lf_find_sun_pos", "lf_set_flares", "lf_get_flares",
     "lf_set_jitter_mt19937", "lf_set_jitter_counter", "lf_set_scene_term", "lf_set_scene",
     "lf_set_sampling", "lf_scene_bounds", "lf_set_scene_lights", "lf_set_light_samples", "lf_set_environment_map",
@@ -47,7 +47,7 @@ ABI_SYMBOLS = [
     "lf_comm_destroy", "lf_comm_available", "lf_comm_info", "lf_comm_test", "lf_comm_abort",
     "lf_comm_set_exchange_precision", "lf_comm_poison", "lf_comm_is_poisoned", "lf_comm_exchange_plan",
     "lf_group_create", "lf_group_destroy", "lf_group_size", "lf_group_ctx", "lf_group_last_error",
-    "lf_group_set_frame", "lf_group_for_each", "lf_group_gather", "lf_group_share_cull",
+    "lf_group_set_frame", "lf_group_for_each", "lf_group_gather", "lf_group_share_cull", "lf_group_set_block_deal",
 ]
 
 
@@ -399,6 +399,10 @@ class LensFlare:
 
     def set_row_interleave(self, phase, period):
         self._ck(self.lib.lf_set_row_interleave(self.ctx, int(phase), int(period)))
+
+    def set_block_deal(self, rank, nranks):
+        """the frame dealt by 64 x 64-pixel blocks: block b (row-major) belongs to rank b % nranks (lf_set_block_deal)"""
+        self._ck(self.lib.lf_set_block_deal(self.ctx, int(rank), int(nranks)))
 
     def set_params(self, ns_aa=1, flare_radius=25.0, flare_intensity=1.0):
         self._ck(self.lib.lf_set_params(self.ctx, int(ns_aa), C.c_double(flare_radius),
@@ -925,6 +929,10 @@ class LensFlareGroup:
 
     def gather(self, which):
         self._ck(self.lib.lf_group_gather(self.g, int(which)))
+
+    def set_block_deal(self, on=True):
+        """the group's frame dealt by 64 x 64-pixel blocks (True) or by tile rows (False, the default)"""
+        self._ck(self.lib.lf_group_set_block_deal(self.g, int(bool(on))))
 
     def share_cull(self, spp):
         """the pre-pass of the next trace_ghosts(spp) shared between the group's devices"""

@@ -332,6 +332,26 @@ lf_status lf_set_row_interleave(lf_ctx* ctx, int phase, int period) {
     if (st != LF_OK) return st;
   }
   ctx->row_phase = phase; ctx->row_period = period;
+  if (ctx->deal_by_block) { ctx->deal_by_block = false; ctx->cull_hash = 0; if (ctx->cull_share_how == 3) { ctx->cull_share_how = 0; ctx->cull_share_n = 1; ctx->cull_share_rank = 0; } }
+  return LF_OK;
+}
+
+// The frame dealt by BLOCKS of 64 x 64 pixels (round 6): block b (row-major) belongs to rank b % nranks.  The block is the
+// cull table's, so a rank's march reads only the table rows its own pre-pass wrote: the pre-pass, its audit and the march
+// all shrink with the number of ranks and no table crosses a link.
+lf_status lf_set_block_deal(lf_ctx* ctx, int rank, int nranks) {
+  if (!ctx) return LF_ERR_INVALID;
+  if (nranks < 1 || nranks > 64 || rank < 0 || rank >= nranks) return lf_fail(ctx, LF_ERR_INVALID, "block deal: need 0 <= rank < nranks <= 64");
+  if (ctx->W == 0) return lf_fail(ctx, LF_ERR_STATE, "lf_set_block_deal before lf_set_frame");
+  if (ctx->cull_share_how == 1 || ctx->cull_share_how == 2)
+    return lf_fail(ctx, LF_ERR_STATE, "lf_set_block_deal: the cull table is shared between ranks (lf_comm_share_cull / lf_set_cull_share): "
+                                      "a frame dealt by blocks shares nothing");
+  ctx->row_phase = rank; ctx->row_period = nranks;
+  ctx->deal_by_block = nranks > 1;
+  ctx->cull_share_how = nranks > 1 ? 3 : 0;       // the pre-pass builds the rows of this rank's blocks and nobody else's
+  ctx->cull_share_rank = nranks > 1 ? rank : 0;
+  ctx->cull_share_n = nranks;
+  ctx->cull_hash = 0; ctx->cull_hash_pending = 0; ctx->cull_fresh = false;
   return LF_OK;
 }
 

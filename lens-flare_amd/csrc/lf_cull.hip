@@ -1,11 +1,11 @@
-// lf_cull.hip -- spend the rays where the light is (round 5).
+// lf_cull.hip -- spend the rays where the light is (rounds 5 and 6).
 //
 // The north star's loop -- for each sensor sample, enumerate the ghost pairs, march each path, accumulate --
 // leaves open which of those marches are worth starting.  On the bench frame 99.4 % of the (wave tile, sample,
 // path, wavelength) combinations end with no lane inside the sun's lobe: their paths run into a diaphragm or
 // leave the front element pointing elsewhere, and add exactly 0 to the sensor (profiles/r05_pair_table.json).
 // Which ones can be known in advance: for a path q the map (sensor point x, pupil point u) -> exit direction
-// is smooth, so over a small 4-D box (a block of 64 x 64 sensor pixels times one stratum of the pupil square)
+// is smooth, so over a small 4-D box (a block of 64 x 64 sensor pixels times one cell of the pupil square)
 // a handful of marched rays bound where the whole box can go -- on every diaphragm of the path and in
 // direction space when it leaves the lens.
 //
@@ -13,27 +13,43 @@
 //                    children per kept box, work lists per path): one LANE = one box (sensor block, pupil cell,
 //                    path) with its 15 rays in registers -- 13 at the middle wavelength (a 3 x 3 grid over the cell
 //                    whose corners sit on the block's corners, + the cell's centre at the block's +-x, +-y edges) and
-//                    the centre at both ends of the spectrum -- marched WITHOUT dying on a diaphragm.  After every
-//                    event the footprint of the box on that interface is a zonotope (centre + central-difference
-//                    generators along the two pupil and two sensor axes, inflated, + a measured second-order slack)
-//                    and the box is dropped when a separating axis puts it wholly outside the clear aperture (the
-//                    stop: outside its housing or on closed cells of the mask's occupancy grid); at the end the same
-//                    in direction space against the sun's lobe.  What the samples CANNOT bound is kept: a box that
-//                    lost samples (to total reflection or a missed sphere: the map is not Lipschitz at that edge), a box whose
-//                    samples all end unless the zonotope bound of the pass scalar stays below zero (see firmly_lost).
-//                    Result: per (block, cell) a 64-bit mask of the paths that may contribute.
-//   k_march_cull<K>  the march of exactly those paths: per wave tile and sample one scalar load tells which
-//                    paths to start; each is marched alone along its own event sequence, K wavelengths
-//                    together, geometry first and the Fresnel / aperture weight by a second march of the lanes that
-//                    reach the lobe, the event arithmetic being lf_march_events.h's -- so a started ray is bit for
-//                    bit the ray k_march and the oracle march, and since an unstarted one contributes 0 the PIXELS
-//                    are those of the full enumeration.  Counters count what was started (the oracle follows the
-//                    same table: oracle/lf_geo_oracle.c geo_set_cull).
+//                    the centre at both ends of the spectrum -- marched WITHOUT dying on a diaphragm.  The footprint of
+//                    a box on an interface is a zonotope (centre + central-difference generators along the two pupil and
+//                    two sensor axes, inflated, + a second-order slack); the box is dropped when a separating axis puts
+//                    it wholly outside the clear aperture (the stop: outside its housing or on closed cells of the mask's
+//                    occupancy grid), at the end the same in direction space against the sun's lobe.  What the samples
+//                    CANNOT bound is kept: a box that lost a sample (to total reflection or a missed sphere: the map is not
+//                    Lipschitz at that edge), a box whose samples all end unless the bound of the pass scalar stays below
+//                    zero.  Result: per (block, cell) a 64-bit mask of the paths that may contribute.
+//                    Round 6: the rules are round 5's, the kernel is not -- it builds a footprint only where a test can
+//                    fire (the centre sample outside the clear aperture, the stop, the exit) instead of after every event
+//                    of every box, needs no scratch, and builds the SAME table bit for bit in half the time (14.1 -> 6.9 ms
+//                    on the bench frame); k_cull_level_general keeps round 5's kernel with the rules as arguments, for the
+//                    regression test and for the rules that were replaced (lf_test_knob).
+//   k_cull_audit     every table is CHECKED where it is used: a ray of every (block, cell, path) box it does not start,
+//                    marched with the march's own events; one that reaches the light refutes the table and the launch
+//                    marches everything (lf_set_cull_audit).  1.7 ms on the bench frame.
+//   k_march_cull<K>  the march of exactly the started paths: per wave tile and sample one scalar load tells which; the
+//                    paths of a sample share their common leg from the sensor (march_started_set, round 6: the bench
+//                    frame's 5.9e10 events of started paths take 3.3e10 executed ones), geometry first and the Fresnel /
+//                    aperture weight by a second march of the lanes that reach the lobe, the event arithmetic being
+//                    lf_march_events.h's -- so a started ray is bit for bit the ray k_march and the oracle march, and
+//                    since an unstarted one contributes 0 the PIXELS are those of the full enumeration.  Counters count
+//                    what was started, every path as if marched alone (the oracle follows the same table:
+//                    oracle/lf_geo_oracle.c geo_set_cull).
 //   k_march_items<K> the same for sampling specifications without pupil sub-cells: (pixel, sample) items compacted
 //                    per path by ballot + an LDS prefix sum.
-// The bounds are second-order estimates from 15 rays with measured cushions, not proofs; what stands behind them is
-// the search for a counter-example (profiles/cull_fuzz.py, profiles/r05_march_variants.txt: an earlier, faster set of
-// rules lost lit rays on 27 of 6000 random frames and was replaced).
+// WHAT THE BOUNDS ARE.  A second-order Taylor estimate of the bundle's map over the box from finite differences of 15
+// rays -- the 4 first derivatives and the 4 pure second derivatives measured, of the 6 mixed ones two sums -- with
+// factors for what is not measured (x 1.25 on the generators, x 1.2 on the lobe test) that were FOUND: lowered, each
+// loses its first lit ray between x 0.9 and x 1.0.  They are not proofs.  Round 6 tried to replace them by proofs
+// and by a complete model (profiles/r06_cull_bounds.txt): affine arithmetic on the box itself (every operation of the
+// march as a form with a rigorous remainder, private terms folded back into the bundle's frame after every event) is
+// sound by construction but its remainders compound over the 11 - 27 events of a path -- at the table's resolution it
+// starts 50 % of everything against 7.7 %; a 17-ray stencil that measures all ten second derivatives with a geometric
+// estimate of the third order starts 7.6 % and lost light on one of 160 random frames.  So the rules stand as round 5
+// left them, on the evidence of the search (tests/cull_fuzz.py: 39 000 + this round's frames, none differing) -- and
+// since a search covers what it drew, the AUDIT ships with them.
 //
 // No reference counterpart: the reference enumerates 13 fixed pairs per channel and draws each as one textured
 // quad (src/pathtracer/pathtracer.cpp:735-762, :452-508) -- its "cull" is that a quad covers few pixels.
@@ -1119,8 +1135,8 @@ void k_march_cull(const LfLensDev* __restrict__ lens, const LfPairsDev* __restri
   const unsigned slot = blockIdx.x / a.sgroups;
   const int tile_lin = (int)((slot & ~63u) | ((slot & 7u) << 3) | ((slot >> 3) & 7u));
   if (tile_lin >= a.n_tiles) return;
-  const int tx = tile_lin % tiles_x, tj = tile_lin / tiles_x;
-  const int trow = a.trow0 + tj * a.tperiod;
+  int tx, trow;
+  march_tile_of(a, tile_lin, tiles_x, tx, trow);
   const unsigned tile_id = (unsigned)(trow * tiles_x + tx);
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int lane = tid & 63;
@@ -1285,8 +1301,8 @@ void k_march_items(const LfLensDev* __restrict__ lens, const LfPairsDev* __restr
   const unsigned slot = blockIdx.x / a.sgroups;
   const int tile_lin = (int)((slot & ~63u) | ((slot & 7u) << 3) | ((slot >> 3) & 7u));
   if (tile_lin >= a.n_tiles) return;
-  const int tx = tile_lin % tiles_x, tj = tile_lin / tiles_x;
-  const int trow = a.trow0 + tj * a.tperiod;
+  int tx, trow;
+  march_tile_of(a, tile_lin, tiles_x, tx, trow);
   const unsigned tile_id = (unsigned)(trow * tiles_x + tx);
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int lane = tid & 63;
@@ -1497,7 +1513,7 @@ int lf_cull_block_log2(const lf_ctx* ctx, int spp, int n_lambda) {
   int lg = kCullBlockLog2;
   while (lg > 4 && (double)(1 << lg) * mm_per_px > kCullMaxBlockMm) lg--;
   if ((double)(1 << lg) * mm_per_px > kCullMaxBlockMm) return -1;
-  if (lg == kCullBlockLog2 && (double)(2 << lg) * mm_per_px <= kCullBigBlockMm && (long long)spp * n_lambda < 768) {
+  if (lg == kCullBlockLog2 && !ctx->deal_by_block && (double)(2 << lg) * mm_per_px <= kCullBigBlockMm && (long long)spp * n_lambda < 768) {
 #ifdef LF_EXPERIMENTS
     if (std::getenv("LF_CULL_SMALL_BLOCKS")) return lg;
 #endif
@@ -1536,13 +1552,14 @@ struct CullAuditArgs {
   int mw, mh;
   uint2 key;
   int density;
+  int blk_first, blk_step;     // the blocks audited: blk_first + k blk_step (all of them; the frame dealt by blocks: this rank's)
 };
 __global__ __launch_bounds__(256) void k_cull_audit(const LfLensDev* __restrict__ lens, const LfPairsDev* __restrict__ pairs,
                                                     const int* __restrict__ seq_table, const LfProgRow* __restrict__ rec_table,
                                                     const float* __restrict__ mask, CullAuditArgs a,
                                                     const unsigned long long* __restrict__ table,
                                                     unsigned long long* __restrict__ out) {
-  const int blk = blockIdx.y;
+  const int blk = a.blk_first + (int)blockIdx.y * a.blk_step;
   const int cells = a.P * a.P;
   const int cell = (int)(blockIdx.x * blockDim.x + threadIdx.x);
   if ((cell & ~63) >= cells) return;
@@ -1615,7 +1632,15 @@ lf_status lfk_cull_finish(lf_ctx* ctx, uint64_t hash) {
   LF_HIP(ctx, hipMemsetAsync(ctx->cull_popc_dev, 0, 4 * sizeof(unsigned long long), ctx->stream));
   const size_t rows = ctx->cull_share_nb > 0 ? (size_t)ctx->cull_share_nb * (size_t)std::max(1, ctx->cull_share_n_resident)
                                              : (size_t)ctx->cull_bx * ctx->cull_by;
-  hipLaunchKernelGGL(k_cull_popcount, dim3(1024), dim3(256), 0, ctx->stream, ctx->cull_dev, rows, ctx->cull_cells, ctx->cull_popc_dev);
+  // the blocks this context marches: all of them -- or, the frame dealt by blocks, its own (whose rows lie together: its slab)
+  const int n_blk = ctx->cull_bx * ctx->cull_by;
+  const bool own = ctx->cull_own_rows_only;
+  const int own_n = own ? ctx->cull_share_n_resident : 1, own_rank = own ? ctx->cull_share_rank : 0;
+  const int n_own_blk = (n_blk - own_rank + own_n - 1) / own_n;
+  const size_t row_entries = (size_t)ctx->cull_cells + 1;
+  if (own) hipLaunchKernelGGL(k_cull_popcount, dim3(1024), dim3(256), 0, ctx->stream, ctx->cull_dev + (size_t)own_rank * ctx->cull_share_nb * row_entries,
+                              (size_t)n_own_blk, ctx->cull_cells, ctx->cull_popc_dev);
+  else hipLaunchKernelGGL(k_cull_popcount, dim3(1024), dim3(256), 0, ctx->stream, ctx->cull_dev, rows, ctx->cull_cells, ctx->cull_popc_dev);
   LF_HIP(ctx, hipGetLastError());
   if (ctx->cull_audit_density > 0) {
     const LfLensDev& L = ctx->lens;
@@ -1632,7 +1657,8 @@ lf_status lfk_cull_finish(lf_ctx* ctx, uint64_t hash) {
     const uint64_t k = (ctx->cull_audit_seq++) * 0x9e3779b97f4a7c15ull ^ hash;
     a.key = make_uint2((unsigned)k, (unsigned)(k >> 32));
     a.density = ctx->cull_audit_density;
-    const dim3 grid((unsigned)((ctx->cull_cells + 255) / 256), (unsigned)(ctx->cull_bx * ctx->cull_by));
+    a.blk_first = own_rank; a.blk_step = own_n;
+    const dim3 grid((unsigned)((ctx->cull_cells + 255) / 256), (unsigned)n_own_blk);
     hipEvent_t ev = lf_timing_begin(ctx, LFK_CULL_AUDIT);
     hipLaunchKernelGGL(k_cull_audit, grid, dim3(256), 0, ctx->stream, ctx->lens_dev, ctx->pairs_dev,
                        (const int*)(ctx->prog_dev + ctx->prog_seq_off), (const LfProgRow*)(ctx->prog_dev + ctx->prog_rec_off),
@@ -1645,7 +1671,7 @@ lf_status lfk_cull_finish(lf_ctx* ctx, uint64_t hash) {
   LF_HIP(ctx, hipStreamSynchronize(ctx->stream));
   // a bring-up call the host gave up on (lf_comm_poison) publishes nothing: the table it waited for may never have arrived
   if (ctx->comm_poisoned.load()) return lf_fail(ctx, LF_ERR_STATE, "cull table: the communicator was abandoned while the table was being completed");
-  ctx->cull_started_fraction = (double)got[0] / ((double)ctx->cull_bx * ctx->cull_by * (double)ctx->cull_cells * (double)std::max(1, ctx->pairs.n));
+  ctx->cull_started_fraction = (double)got[0] / ((double)n_own_blk * (double)ctx->cull_cells * (double)std::max(1, ctx->pairs.n));
   ctx->cull_audit_rays += got[1];
   ctx->cull_audit_lit += got[2];
   ctx->cull_hash = hash;
@@ -1668,8 +1694,10 @@ lf_status lfk_cull_prepass(lf_ctx* ctx, int G, int spp) {
   if (a.blk_log2 < 0) return lf_fail(ctx, LF_ERR_STATE, "cull pre-pass: no block size applies (lf_cull_applies comes first)");
   a.blocks_x = (ctx->W + (1 << a.blk_log2) - 1) >> a.blk_log2;
   a.blocks_y = (ctx->H + (1 << a.blk_log2) - 1) >> a.blk_log2;
-  // a table shared between ranks: this one builds the rows of the blocks b with b % n == rank (lf_cull_row_of_block)
-  const bool shared = ctx->cull_share_how != 0 && ctx->cull_share_n > 1;
+  // a table shared between ranks: this one builds the rows of the blocks b with b % n == rank (lf_cull_row_of_block) -- or
+  // (cull_share_how 3: the frame dealt by blocks, lf_set_block_deal) ONLY those, nobody needs the others.  The deal's block
+  // is 64 pixels: a frame whose cull blocks are smaller builds the whole table on every rank (small frames: cheap)
+  const bool shared = ctx->cull_share_how != 0 && ctx->cull_share_n > 1 && (ctx->cull_share_how != 3 || a.blk_log2 == kDealBlockLog2);
   a.share_n = shared ? ctx->cull_share_n : 1;
   a.share_rank = shared ? ctx->cull_share_rank : 0;
   a.share_nb = (a.blocks_x * a.blocks_y + a.share_n - 1) / a.share_n;
@@ -1820,6 +1848,7 @@ lf_status lfk_cull_prepass(lf_ctx* ctx, int G, int spp) {
     }
   }
   // (comm_force_exchange: tests only -- the collective also with a single rank, as lf_comm_gather does)
+  ctx->cull_own_rows_only = shared && ctx->cull_share_how == 3;
   if (ctx->cull_share_how == 1 && (shared || ctx->comm_force_exchange)) {
     // every rank has built its slab: one in-place all-gather completes the table everywhere
     const lf_status st = lf_comm_allgather_u64_inplace(ctx, ctx->cull_dev, (size_t)a.share_nb * row_entries);

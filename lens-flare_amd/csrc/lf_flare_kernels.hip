@@ -533,15 +533,15 @@ __global__ __launch_bounds__(256) void k_flare_layer(
     const LfFlares* __restrict__ fl, const lf_aperture_stats* __restrict__ st,
     const double* __restrict__ S, const double* __restrict__ ghost,
     const double* __restrict__ scene, const uint32_t* __restrict__ jitter_raw, int jitter_mode,
-    uint64_t key, int W, int H, int y0, int y1, int row_phase, int row_period, int ns_aa,
+    uint64_t key, int W, int H, int y0, int y1, LfDeal deal, int ns_aa,
     double flare_radius, double flare_intensity, LfStarSpectrum spec, double* __restrict__ sample,
     double* __restrict__ star_out) {
   const size_t p = (size_t)y0 * W + (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (p >= (size_t)y1 * W) return;
   const int x = (int)(p % W), y = (int)(p / W);
-  // multi-GPU: only the 8-row tile rows this context owns (lf_set_row_interleave); the others are
-  // marched, composed and delivered by their owners
-  if (row_period > 1 && (y >> 3) % row_period != row_phase) return;
+  // multi-GPU: only the 8-row tile rows (lf_set_row_interleave) or the 64 x 64 blocks (lf_set_block_deal) this context
+  // owns; the others are marched, composed and delivered by their owners
+  if (!lf_deal_mine(deal, x, y)) return;
   const int n_flares = fl->n_flares;
   const double dW = (double)W, dH = (double)H;
 
@@ -815,7 +815,7 @@ lf_status lfk_flare_layer(lf_ctx* ctx) {
   hipLaunchKernelGGL(k_flare_layer<EXACT>, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream, \
                      ctx->flares, ctx->ap[LF_APERTURE_STARBURST].stats, ctx->spectrum, ctx->ghost,     \
                      ctx->scene, ctx->jitter_raw, ctx->jitter_mode, ctx->jitter_key, ctx->W, ctx->H,   \
-                     ctx->y0, ctx->y1, ctx->row_phase, ctx->row_period, ctx->ns_aa, ctx->flare_radius, \
+                     ctx->y0, ctx->y1, lf_deal_of(ctx), ctx->ns_aa, ctx->flare_radius,                   \
                      ctx->flare_intensity, ctx->star_spec, ctx->sample, ctx->star)
   if (lf_flare_exact(ctx)) LF_LAUNCH_FLARE(true); else LF_LAUNCH_FLARE(false);
 #undef LF_LAUNCH_FLARE

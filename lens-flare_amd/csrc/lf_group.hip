@@ -99,10 +99,47 @@ __global__ void k_unpack_rows(const T* __restrict__ recv, double* __restrict__ f
   frame[(g * world + r) * e + k] = (double)recv[i];
 }
 
+// ... and the frame dealt by BLOCKS of 64 x 64 pixels (lf_set_block_deal): slot (g, rank) = block g * world + rank, its
+// 64 x 64 x 3 values row by row (a block that reaches over the frame's edge -- or past its last block -- travels padded)
+constexpr int kBlk = 1 << kDealBlockLog2;
+constexpr size_t kBlkE = (size_t)kBlk * kBlk * 3;
+__device__ __forceinline__ bool block_slot(size_t g, int r, int world, size_t k, int W, int H, int bx, int nblk, size_t& at) {
+  const size_t b = g * (size_t)world + (size_t)r;
+  if (b >= (size_t)nblk) return false;
+  const int by = (int)(b / (size_t)bx), bxx = (int)(b - (size_t)by * bx);
+  const int ry = (int)(k / ((size_t)kBlk * 3)), rem = (int)(k - (size_t)ry * kBlk * 3), rx = rem / 3, c = rem - 3 * rx;
+  const int x = bxx * kBlk + rx, y = by * kBlk + ry;
+  at = ((size_t)y * W + x) * 3 + c;
+  return x < W && y < H;
+}
+template <typename T>
+__global__ void k_pack_blocks(const double* __restrict__ frame, T* __restrict__ send, int rank, int world, size_t groups,
+                              int W, int H, int bx, int nblk) {
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= groups * kBlkE) return;
+  size_t at;
+  send[i] = block_slot(i / kBlkE, rank, world, i % kBlkE, W, H, bx, nblk, at) ? (T)frame[at] : (T)0;
+}
+template <typename T>
+__global__ void k_unpack_blocks(const T* __restrict__ recv, double* __restrict__ frame, int rank, int world, size_t groups,
+                                int W, int H, int bx, int nblk) {
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= (size_t)world * groups * kBlkE) return;
+  const size_t r = i / (groups * kBlkE), rem = i - r * groups * kBlkE;
+  if ((int)r == rank) return;
+  size_t at;
+  if (block_slot(rem / kBlkE, (int)r, world, rem % kBlkE, W, H, bx, nblk, at)) frame[at] = (double)recv[i];
+}
+
 double* frame_buffer(lf_ctx* ctx, int which) { return which == 0 ? ctx->sample : which == 1 ? ctx->ghost : ctx->star; }
 
+// the exchange's unit: a tile row (8 rows x W x 3) or a block (64 x 64 x 3); `groups` units per rank
 struct Shape { size_t groups, e; };
 Shape shape(const lf_ctx* ctx, int world) {
+  if (ctx->deal_by_block) {
+    const size_t nblk = (size_t)((ctx->W + kBlk - 1) / kBlk) * (size_t)((ctx->H + kBlk - 1) / kBlk);
+    return Shape{(nblk + world - 1) / world, kBlkE};
+  }
   const size_t ntrows = (size_t)(ctx->H + 7) / 8;
   return Shape{(ntrows + world - 1) / world, (size_t)8 * ctx->W * 3};
 }
@@ -131,7 +168,15 @@ lf_status launch_pack(lf_ctx* ctx, int which, int rank, int world, hipStream_t s
   const size_t n = s.groups * s.e;
   const dim3 grid((unsigned)((n + 255) / 256));
   hipStream_t q = stream ? stream : ctx->stream;
-  if (ctx->comm_f32)
+  if (ctx->deal_by_block) {
+    const int bx = (ctx->W + kBlk - 1) / kBlk, nblk = bx * ((ctx->H + kBlk - 1) / kBlk);
+    if (ctx->comm_f32)
+      hipLaunchKernelGGL(k_pack_blocks<float>, grid, dim3(256), 0, q, frame_buffer(ctx, which), (float*)ctx->comm_stage, rank, world,
+                         s.groups, ctx->W, ctx->H, bx, nblk);
+    else
+      hipLaunchKernelGGL(k_pack_blocks<double>, grid, dim3(256), 0, q, frame_buffer(ctx, which), ctx->comm_stage, rank, world, s.groups,
+                         ctx->W, ctx->H, bx, nblk);
+  } else if (ctx->comm_f32)
     hipLaunchKernelGGL(k_pack_rows<float>, grid, dim3(256), 0, q, frame_buffer(ctx, which), (float*)ctx->comm_stage,
                        rank, world, s.groups, s.e);
   else
@@ -146,7 +191,15 @@ lf_status launch_unpack(lf_ctx* ctx, int which, int rank, int world, hipStream_t
   const size_t n = (size_t)world * s.groups * s.e;
   const dim3 grid((unsigned)((n + 255) / 256));
   hipStream_t q = stream ? stream : ctx->stream;
-  if (ctx->comm_f32)
+  if (ctx->deal_by_block) {
+    const int bx = (ctx->W + kBlk - 1) / kBlk, nblk = bx * ((ctx->H + kBlk - 1) / kBlk);
+    if (ctx->comm_f32)
+      hipLaunchKernelGGL(k_unpack_blocks<float>, grid, dim3(256), 0, q, (const float*)stage_recv(ctx, s.groups * s.e),
+                         frame_buffer(ctx, which), rank, world, s.groups, ctx->W, ctx->H, bx, nblk);
+    else
+      hipLaunchKernelGGL(k_unpack_blocks<double>, grid, dim3(256), 0, q, (const double*)stage_recv(ctx, s.groups * s.e),
+                         frame_buffer(ctx, which), rank, world, s.groups, ctx->W, ctx->H, bx, nblk);
+  } else if (ctx->comm_f32)
     hipLaunchKernelGGL(k_unpack_rows<float>, grid, dim3(256), 0, q, (const float*)stage_recv(ctx, s.groups * s.e),
                        frame_buffer(ctx, which), rank, world, s.groups, s.e);
   else
@@ -167,7 +220,7 @@ lf_status check_gather_args(lf_ctx* ctx, int which, int world) {
   if (ctx->row_period != world)
     return lf_fail(ctx, LF_ERR_STATE, "gather: the row interleave does not match the communicator (frame resized?)");
   const Shape s = shape(ctx, world);
-  if ((size_t)ctx->H_alloc * ctx->W * 3 < s.groups * world * s.e)
+  if (!ctx->deal_by_block && (size_t)ctx->H_alloc * ctx->W * 3 < s.groups * world * s.e)
     return lf_fail(ctx, LF_ERR_STATE, "gather: frame buffers are not padded for this world size");
   return LF_OK;
 }
@@ -544,6 +597,17 @@ lf_status lf_group_set_frame(lf_group* g, int width, int height) {
   return LF_OK;
 }
 
+// the group's frame dealt by blocks of 64 x 64 pixels (lf_set_block_deal on every context: on) or by tile rows (off, the default)
+lf_status lf_group_set_block_deal(lf_group* g, int on) {
+  if (!g) return LF_ERR_INVALID;
+  const int n = (int)g->ctx.size();
+  for (int r = 0; r < n; r++) {
+    const lf_status st = on ? lf_set_block_deal(g->ctx[r], r, n) : lf_set_row_interleave(g->ctx[r], r, n);
+    if (st != LF_OK) { g->err = lf_last_error(g->ctx[r]); return st; }
+  }
+  return LF_OK;
+}
+
 lf_status lf_group_for_each(lf_group* g, lf_group_fn fn, void* user) {
   if (!g || !fn) return LF_ERR_INVALID;
   const int n = (int)g->ctx.size();
@@ -633,6 +697,7 @@ lf_status lf_group_share_cull(lf_group* g, int spp) {
   if (!g || spp < 1) return LF_ERR_INVALID;
   const int n = (int)g->ctx.size();
   if (n == 1) return LF_OK;
+  if (g->ctx[0]->deal_by_block) return LF_OK;       // dealt by blocks: every context builds the rows it reads, nothing to share
   for (int r = 0; r < n; r++) {
     const lf_status st = lf_set_cull_share(g->ctx[r], r, n);
     if (st != LF_OK) { g->err = lf_last_error(g->ctx[r]); return st; }

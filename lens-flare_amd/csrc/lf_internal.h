@@ -236,6 +236,17 @@ struct LfCullArgs {
                                       // sub-cells per axis of the sampling specification (lf_set_pupil_subcells)
 };
 
+// ---- how a frame is dealt to the ranks of a multi-GPU job ------------------------------------------------------
+// by tile rows (8 sensor rows, t % n == rank: lf_set_row_interleave, rounds 1-5) or by BLOCKS of 64 x 64 pixels (row-major
+// index b % n == rank: lf_set_block_deal, round 6) -- the block is the cull table's: a rank that owns whole blocks reads only
+// the table rows its own pre-pass wrote, so no table ever crosses a link.  bx = blocks per frame row, 0 = dealt by rows.
+constexpr int kDealBlockLog2 = 6;
+struct LfDeal { int n, rank, bx; };
+__host__ __device__ inline bool lf_deal_mine(const LfDeal& d, int x, int y) {
+  if (d.n <= 1) return true;
+  return d.bx > 0 ? ((y >> kDealBlockLog2) * d.bx + (x >> kDealBlockLog2)) % d.n == d.rank : (y >> 3) % d.n == d.rank;
+}
+
 // ---- lens camera (round 4): the scene imaged through the prescription --------------------------
 // The primary path N-1 .. 0 of a sensor sample (the ray travels -z, against the light), one row per
 // interface in the order the ray meets them, the constants of surface_event for EVERY wavelength
@@ -295,7 +306,8 @@ struct lf_ctx {
 
   int W = 0, H = 0, y0 = 0, y1 = 0;
   int H_alloc = 0;                     // rows allocated (H rounded up to 64) for in-place gathers
-  int row_period = 1, row_phase = 0;   // tile rows t (8 sensor rows) with t % period == phase
+  int row_period = 1, row_phase = 0;   // tile rows t (8 sensor rows) with t % period == phase -- or, dealt by blocks:
+  bool deal_by_block = false;          // lf_set_block_deal: 64 x 64-pixel blocks b (row-major) with b % period == phase
   int ns_aa = 1;
   double flare_radius = 25.0, flare_intensity = 1.0;
   int flare_arithmetic = 0;   // lf_set_flare_arithmetic: 0 auto (exact pow in MT19937 parity mode), 1 exact, 2 fast
@@ -396,8 +408,10 @@ struct lf_ctx {
   // the pre-pass shared between the ranks of a multi-GPU frame (lf_set_cull_share / lf_comm_share_cull):
   int cull_share_rank = 0, cull_share_n = 1;   // this context builds the rows of the blocks b with b % n == rank
   int cull_share_how = 0;                      // 1: the library's RCCL communicator completes the table inside lf_trace_ghosts;
-                                               // 2: the host does (lf_cull_prepare -> its own all-gather -> lf_cull_commit)
+                                               // 2: the host does (lf_cull_prepare -> its own all-gather -> lf_cull_commit);
+                                               // 3: nobody does -- the frame is dealt by blocks (lf_set_block_deal), a rank needs its own rows only
   int cull_share_nb = 0, cull_share_n_resident = 1;   // rows per slab and slabs of the RESIDENT table (0 / 1: not shared)
+  bool cull_own_rows_only = false;             // ... of which only this rank's slab is built (the frame dealt by blocks: nobody reads the others)
   uint64_t cull_hash_pending = 0;              // of the slab lf_cull_prepare built (the host's exchange is outstanding)
   bool cull_prepare_only = false;              // (lf_cull_prepare is inside lfk_march)
   bool cull_fresh = false;                     // lf_cull_commit just completed the table: the next launch takes it even in mode 2
@@ -496,6 +510,9 @@ inline float lf_march_lobe_thr(const LfLensDev& L) {
 }
 
 // the flare layer calls the reference's own pow() (exact) or its cheaper equivalents (fast): DESIGN.md section 3
+inline LfDeal lf_deal_of(const lf_ctx* ctx) {
+  return LfDeal{ctx->row_period, ctx->row_phase, ctx->deal_by_block ? (ctx->W + (1 << kDealBlockLog2) - 1) >> kDealBlockLog2 : 0};
+}
 inline bool lf_flare_exact(const lf_ctx* ctx) {
   return ctx->flare_arithmetic == 1 || (ctx->flare_arithmetic == 0 && ctx->jitter_mode == 0);
 }

@@ -178,8 +178,9 @@ void k_march(const LfLensDev* __restrict__ lens, const LfPairsDev* __restrict__ 
   const unsigned slot = blockIdx.x / a.sgroups;
   const int tile_lin = (int)((slot & ~63u) | ((slot & 7u) << 3) | ((slot >> 3) & 7u));
   if (tile_lin >= a.n_tiles) return;   // (the whole workgroup, before any barrier)
-  const int tx = tile_lin % tiles_x, tj = tile_lin / tiles_x;
-  const unsigned tile_id = (unsigned)((a.trow0 + tj * a.tperiod) * tiles_x + tx);  // frame-absolute
+  int tx, trow;
+  march_tile_of(a, tile_lin, tiles_x, tx, trow);
+  const unsigned tile_id = (unsigned)(trow * tiles_x + tx);  // frame-absolute
   // Everything that depends on the lane (pixel coordinates, LDS addresses) is re-derived from the
   // thread id where it is used: held across the walk it costs ~10 registers, which at 6 waves per
   // SIMD the allocator can only find in scratch memory (430 MB of spill traffic per bench frame).
@@ -194,7 +195,7 @@ void k_march(const LfLensDev* __restrict__ lens, const LfPairsDev* __restrict__ 
   lanemask active_mask;
   {
     const int lane = tid & 63;
-    const int x = ((tx >> a.xs) << (3 + a.xs)) + ((lane & 7) << a.xs) + (tx & ((1 << a.xs) - 1)), y = (a.trow0 + tj * a.tperiod) * 8 + (lane >> 3);
+    const int x = ((tx >> a.xs) << (3 + a.xs)) + ((lane & 7) << a.xs) + (tx & ((1 << a.xs) - 1)), y = trow * 8 + (lane >> 3);
     active_mask = __ballot(x < a.W && y >= a.y0 && y < a.y1);
   }
 
@@ -229,7 +230,7 @@ void k_march(const LfLensDev* __restrict__ lens, const LfPairsDev* __restrict__ 
       const int s = sg + k * a.sgroups;  // wave-uniform
       if (s >= a.spp) break;
       const int lane = lane_id();
-      const int x = ((tx >> a.xs) << (3 + a.xs)) + ((lane & 7) << a.xs) + (tx & ((1 << a.xs) - 1)), y = (a.trow0 + tj * a.tperiod) * 8 + (lane >> 3);
+      const int x = ((tx >> a.xs) << (3 + a.xs)) + ((lane & 7) << a.xs) + (tx & ((1 << a.xs) - 1)), y = trow * 8 + (lane >> 3);
       const unsigned p = (unsigned)y * (unsigned)a.W + (unsigned)x;
       // ---- sensor sample -> initial ray --------------------------------------------------
       const uint4 rnd = philox4x32_10(make_uint4(p, (unsigned)s, kDomainMarch, 0u), a.key);
@@ -518,7 +519,7 @@ void k_march(const LfLensDev* __restrict__ lens, const LfPairsDev* __restrict__ 
             }
 #ifdef LF_MARCH_LIT_MAP
             if (lit_any != 0ull && g_lit_map[0] != nullptr && lane_id() == 0) {
-              const int bx64 = (tx >> a.xs) << (3 + a.xs) >> 6, trow_ = a.trow0 + tj * a.tperiod;
+              const int bx64 = (tx >> a.xs) << (3 + a.xs) >> 6, trow_ = trow;
               const int nbx = (a.W + 63) >> 6;
               const int blkA = ((trow_ * 8) >> 6) * nbx + bx64, blkB = trow_ * nbx + bx64;
               for (int m = 0; m < 4; m++) {
@@ -604,7 +605,7 @@ void k_march(const LfLensDev* __restrict__ lens, const LfPairsDev* __restrict__ 
 
   // ---- counters: wave reduce, one LDS add per wave, one global add per workgroup ------------
   const int lane = lane_id();
-  const int x = ((tx >> a.xs) << (3 + a.xs)) + ((lane & 7) << a.xs) + (tx & ((1 << a.xs) - 1)), y = (a.trow0 + tj * a.tperiod) * 8 + (lane >> 3);
+  const int x = ((tx >> a.xs) << (3 + a.xs)) + ((lane & 7) << a.xs) + (tx & ((1 << a.xs) - 1)), y = trow * 8 + (lane >> 3);
   const bool active = x < a.W && y >= a.y0 && y < a.y1;
   const unsigned p = (unsigned)y * (unsigned)a.W + (unsigned)x;
   {
@@ -691,8 +692,7 @@ __global__ void k_native_rcp(const float* __restrict__ x, float* __restrict__ y,
 __global__ void k_scale_rows(double* __restrict__ ghost, MarchArgs a, double factor) {
   const size_t p = (size_t)a.y0 * a.W + (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (p >= (size_t)a.y1 * a.W) return;
-  const int t = (int)(p / a.W) >> 3;
-  if (t < a.trow0 || (t - a.trow0) % a.tperiod != 0) return;
+  if (!march_owns(a, (int)(p % a.W), (int)(p / a.W))) return;
 #pragma unroll
   for (int c = 0; c < 3; c++) ghost[3 * p + c] *= factor;
 }
@@ -701,8 +701,7 @@ __global__ void k_march_finish(const unsigned long long* __restrict__ accum, Mar
                                double* __restrict__ ghost) {
   const size_t p = (size_t)a.y0 * a.W + (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (p >= (size_t)a.y1 * a.W) return;
-  const int t = (int)(p / a.W) >> 3;
-  if (t < a.trow0 || (t - a.trow0) % a.tperiod != 0) return;
+  if (!march_owns(a, (int)(p % a.W), (int)(p / a.W))) return;
 #pragma unroll
   for (int c = 0; c < 3; c++) {
     const double v = ((double)accum[3 * p + c] * (1.0 / 68719476736.0)) / (double)a.spp;
@@ -1202,14 +1201,26 @@ static lf_status march_launch(lf_ctx* ctx, int spp, uint64_t key, int chunk, int
   a.accumulate = ctx->ghost_accumulate ? 1 : 0;
   a.xs = ctx->march_xstride_log2;
   a.lobe_thr = lf_march_lobe_thr(ctx->lens);      // candidate selection (the contract: lf_internal.h)
-  // tile rows (8 sensor rows each) of the band that belong to this context's interleave phase
-  const int t_lo = ctx->y0 / 8, t_hi = (ctx->y1 + 7) / 8;  // [t_lo, t_hi)
-  const int period = ctx->row_period, phase = ctx->row_phase;
-  int first = t_lo + ((phase - t_lo) % period + period) % period;
-  if (first >= t_hi) return LF_OK;
-  const int n_trows = (t_hi - 1 - first) / period + 1;
-  a.trow0 = first; a.tperiod = period;
-  const size_t tiles = (size_t)n_trows * ((((size_t)ctx->W + (8u << a.xs) - 1) >> (3 + a.xs)) << a.xs);
+  // tile rows (8 sensor rows each) of the band that belong to this context's interleave phase -- or, the frame dealt by
+  // blocks, the 64 wave tiles of every block of this context's
+  a.deal = lf_deal_of(ctx);
+  size_t tiles;
+  if (a.deal.bx > 0 && a.deal.n > 1) {
+    const int nblk = a.deal.bx * ((ctx->H + (1 << kDealBlockLog2) - 1) >> kDealBlockLog2);
+    const int n_own = (nblk - a.deal.rank + a.deal.n - 1) / a.deal.n;
+    if (n_own <= 0) return LF_OK;
+    a.trow0 = 0; a.tperiod = 1;
+    tiles = (size_t)n_own * 64;
+  } else {
+    a.deal.bx = 0;
+    const int t_lo = ctx->y0 / 8, t_hi = (ctx->y1 + 7) / 8;  // [t_lo, t_hi)
+    const int period = ctx->row_period, phase = ctx->row_phase;
+    int first = t_lo + ((phase - t_lo) % period + period) % period;
+    if (first >= t_hi) return LF_OK;
+    const int n_trows = (t_hi - 1 - first) / period + 1;
+    a.trow0 = first; a.tperiod = period;
+    tiles = (size_t)n_trows * ((((size_t)ctx->W + (8u << a.xs) - 1) >> (3 + a.xs)) << a.xs);
+  }
   // A launch that covers only part of the frame (one GPU's share) splits each tile's samples over
   // `sgroups` workgroups (power of two): more, shorter workgroups keep its tail short -- but a workgroup
   // needs >= 64 samples to amortise its set-up and its 192 global atomics.  The whole frame on one GPU

@@ -32,7 +32,8 @@ struct MarchArgs {
   float inv_G;
   int sub_bits;        // each stratum is split into 2^sub_bits x 2^sub_bits sub-cells
   float inv_sub;
-  int trow0, tperiod;  // tile rows handled: trow0 + j * tperiod, j = 0 ..
+  int trow0, tperiod;  // tile rows handled: trow0 + j * tperiod, j = 0 ..   (the frame dealt by tile rows)
+  LfDeal deal;         // ... or by 64 x 64-pixel blocks (deal.bx > 0, lf_set_block_deal): own block k = rank + k n, 64 wave tiles each
   int sgroups;         // the samples of a tile are split over this many workgroups (power of two)
   uint2 key;
   float inv_stop_h;    // 1 / stop_h (correctly rounded)
@@ -44,6 +45,28 @@ struct MarchArgs {
   int xs;              // log2 of the lanes' pixel stride in x (lf_set_tile_stride): 0 = an 8 x 8 block of
                        // adjacent pixels per wave, 3 = columns 8 apart (a 64 x 8 block shared by 8 waves)
 };
+
+// wave tile `tile_lin` of the launch -> its position along x (tx: see k_march) and its tile row.  Dealt by rows: the launch's
+// tile rows one after the other; by blocks: the 8 x 8 wave tiles of own block tile_lin / 64 (8 tile rows x 8 tiles across its
+// 64 columns, whatever the tile stride).  All wave-uniform.
+__device__ __forceinline__ void march_tile_of(const MarchArgs& a, int tile_lin, int tiles_x, int& tx, int& trow) {
+  if (a.deal.bx > 0) {
+    const int b = a.deal.rank + (tile_lin >> 6) * a.deal.n, w = tile_lin & 63;
+    const int by = b / a.deal.bx;
+    trow = by * 8 + (w >> 3);
+    tx = (b - by * a.deal.bx) * 8 + (w & 7);
+  } else {
+    const int tj = tile_lin / tiles_x;
+    tx = tile_lin - tj * tiles_x;
+    trow = a.trow0 + tj * a.tperiod;
+  }
+}
+// does this launch render pixel row y / pixel (x, y)?  (k_march_finish, k_scale_rows)
+__device__ __forceinline__ bool march_owns(const MarchArgs& a, int x, int y) {
+  if (a.deal.bx > 0) return lf_deal_mine(a.deal, x, y);
+  const int t = y >> 3;
+  return t >= a.trow0 && (t - a.trow0) % a.tperiod == 0;
+}
 
 // The program of a GROUP of up to 3 wavelengths, in two levels (LfProgHdr / LfProgRow in
 // lf_internal.h): per row a 16-byte header (ONE s_load_dwordx4), per distinct (interface, direction)

@@ -546,8 +546,8 @@ __device__ __forceinline__ void scene_pixel(const LfSceneDev& sc, const LfEnvDev
 
 template <bool SOFT, bool LENS>
 __global__ __launch_bounds__(256, LF_SCENE_WAVES) void k_scene_term(LfSceneDev sc, LfEnvDev ev, LfCamera cam,
-                                                    ScenePixelArgs a, int y0, int y1, int row_phase,
-                                                    int row_period, const uint32_t* __restrict__ aa_raw,
+                                                    ScenePixelArgs a, int y0, int y1, LfDeal deal,
+                                                    const uint32_t* __restrict__ aa_raw,
                                                     LfLensCamArgs lc, const LfPrimaryDev* __restrict__ prim,
                                                     const float* __restrict__ mask,
                                                     unsigned long long* __restrict__ counters,
@@ -565,9 +565,9 @@ __global__ __launch_bounds__(256, LF_SCENE_WAVES) void k_scene_term(LfSceneDev s
   const int lane = threadIdx.x & 63;
   const int x = ((int)blockIdx.x * 4 + ((int)threadIdx.x >> 6)) * 8 + (lane & 7);
   const int y = ((y0 >> 3) + (int)blockIdx.y) * 8 + (lane >> 3);
-  // multi-GPU: only the 8-row tile rows this context owns, like k_flare_layer, which is the only
+  // multi-GPU: only the tile rows / blocks this context owns, like k_flare_layer, which is the only
   // reader of this buffer
-  const bool mine = x < a.W && y >= y0 && y < y1 && !(row_period > 1 && (y >> 3) % row_period != row_phase);
+  const bool mine = x < a.W && y >= y0 && y < y1 && lf_deal_mine(deal, x, y);
   SceneTally tally{0u, 0u};
   unsigned lens_started = 0u, lens_left = 0u;
   if (mine)
@@ -603,7 +603,7 @@ constexpr int kLensStridedMaxPrims = 1024;
 #endif
 template <bool SOFT>
 __global__ __launch_bounds__(256, LF_SCENE_LENS_WAVES) void k_scene_lens(LfSceneDev sc, LfEnvDev ev, LfCamera cam, ScenePixelArgs a,
-                                                       int y0, int y1, int row_phase, int row_period, int mxs, LfLensCamArgs lc,
+                                                       int y0, int y1, LfDeal deal, int mxs, LfLensCamArgs lc,
                                                        const LfPrimaryDev* __restrict__ prim,
                                                        const float* __restrict__ mask,
                                                        unsigned long long* __restrict__ counters,
@@ -627,7 +627,7 @@ __global__ __launch_bounds__(256, LF_SCENE_LENS_WAVES) void k_scene_lens(LfScene
   const int tile = (int)blockIdx.x * 4 + wv;
   const int tile_x = ((tile >> mxs) << (3 + mxs)) + (tile & ((1 << mxs) - 1)), tile_y = ((y0 >> 3) + (int)blockIdx.y) * 8;
   const int x = tile_x + ((lane & 7) << mxs), y = tile_y + (lane >> 3);
-  const bool mine = x < a.W && y >= y0 && y < y1 && !(row_period > 1 && (y >> 3) % row_period != row_phase);
+  const bool mine = x < a.W && y >= y0 && y < y1 && lf_deal_mine(deal, x, y);
   const int ns_aa = a.ns_aa;
   const uint2 key2 = make_uint2((unsigned)a.key, (unsigned)(a.key >> 32));
   SceneTally tally{0u, 0u};
@@ -1292,7 +1292,7 @@ lf_status lf_render_scene_term(lf_ctx* ctx) {
 #define LF_LAUNCH_SCENE(SOFT, LENS)                                                                      \
   hipLaunchKernelGGL((k_scene_term<SOFT, LENS>), dim3((unsigned)((ctx->W + 31) / 32), (unsigned)(((ctx->y1 + 7) >> 3) - (ctx->y0 >> 3))), \
                      dim3(256), 0, ctx->stream, ctx->scene_dev, ctx->env_dev, ctx->cam, pa, ctx->y0, ctx->y1, \
-                     ctx->row_phase, ctx->row_period, ctx->jitter_aa_raw, lc, ctx->primary_dev,           \
+                     lf_deal_of(ctx), ctx->jitter_aa_raw, lc, ctx->primary_dev,                           \
                      ctx->ap[LF_APERTURE_STARBURST].texels, ctx->scene_counters_dev, ctx->scene)
   ScenePixelArgs pa;
   pa.W = ctx->W; pa.H = ctx->H; pa.ns_aa = ctx->ns_aa; pa.ns_area_light = ctx->ns_area_light;
@@ -1305,7 +1305,7 @@ lf_status lf_render_scene_term(lf_ctx* ctx) {
   hipLaunchKernelGGL((k_scene_lens<SOFT>), dim3((unsigned)((lens_tiles_x + 3) / 4), (unsigned)(((ctx->y1 + 7) >> 3) - (ctx->y0 >> 3))), \
                      dim3(256), (size_t)std::min(kStackDepth, std::max(1, ctx->scene_tree_depth + 1)) * 256 * sizeof(int), \
                      ctx->stream, ctx->scene_dev, ctx->env_dev, ctx->cam, pa, ctx->y0, ctx->y1,           \
-                     ctx->row_phase, ctx->row_period, lens_mxs, lc, ctx->primary_dev,                      \
+                     lf_deal_of(ctx), lens_mxs, lc, ctx->primary_dev,                                      \
                      ctx->ap[LF_APERTURE_STARBURST].texels, ctx->scene_counters_dev, ctx->scene)
   // a small tree is resident in the caches whichever lanes walk it: the wave takes the march's strided tile (see the
   // kernel)

@@ -12,8 +12,13 @@ row-major frame and rank r owns slot r of each group, so the frame viewed as
 this rank's slots, all_gather_into_tensor, unpack -- two device copies of 1/world and 1 frame) or,
 without any staging, with one in-place all-gather per group (gather_frame_inplace: `groups` small
 collectives, latency-bound on xGMI when the frame is split 8 ways).
+
+Round 6: the frame can also be dealt by BLOCKS of 64 x 64 pixels (block b, row-major, belongs to rank b % world:
+lf_set_block_deal) -- the block is the path cull's, so a rank builds, audits and reads only its own rows of the cull
+table and nothing but finished blocks is exchanged (gather_blocks: pack this rank's blocks, ONE all-gather, unpack).
 """
 TILE_ROWS = 8
+BLOCK = 64
 
 
 def n_tile_rows(H):
@@ -62,6 +67,54 @@ def gather_frame(frame, W, H, rank, world, dist, elems_per_pixel=3, scratch=None
     send.copy_(v[:, rank, :])
     dist.all_gather_into_tensor(recv.view(-1), send.view(-1))
     v.copy_(recv.permute(1, 0, 2))
+
+
+def n_blocks(W, H):
+    return ((W + BLOCK - 1) // BLOCK) * ((H + BLOCK - 1) // BLOCK)
+
+
+def my_blocks(W, H, rank, world):
+    """the 64 x 64-pixel blocks (row-major indices) of rank `rank` under the block deal"""
+    return list(range(rank, n_blocks(W, H), world))
+
+
+def gather_blocks(frame, W, H, rank, world, dist, elems_per_pixel=3, scratch=None):
+    """The block deal's exchange (what lf_comm_gather does inside the C ABI: lf_group.hip k_pack_blocks / k_unpack_blocks).
+    frame: flat tensor of >= H * W * elems_per_pixel elements, this rank's blocks rendered in place.  Every rank packs its
+    blocks (padded to 64 x 64 at the frame's edges, and to ceil(blocks / world) per rank), ONE all-gather, everybody's
+    blocks unpacked.  After the call rows [0, H) are complete everywhere."""
+    if world == 1:
+        return
+    bx = (W + BLOCK - 1) // BLOCK
+    nblk = n_blocks(W, H)
+    groups = (nblk + world - 1) // world
+    img = frame[:H * W * elems_per_pixel].view(H, W, elems_per_pixel)
+    if scratch is None:
+        scratch = {}
+    send = scratch.get("bsend")
+    if send is None or send.shape != (groups, BLOCK, BLOCK, elems_per_pixel) or send.device != frame.device:
+        send = scratch["bsend"] = frame.new_zeros((groups, BLOCK, BLOCK, elems_per_pixel))
+        scratch["brecv"] = frame.new_empty((world, groups, BLOCK, BLOCK, elems_per_pixel))
+    recv = scratch["brecv"]
+
+    def box(b):
+        y0, x0 = (b // bx) * BLOCK, (b % bx) * BLOCK
+        return y0, min(H, y0 + BLOCK), x0, min(W, x0 + BLOCK)
+
+    for g in range(groups):
+        b = g * world + rank
+        if b < nblk:
+            y0, y1, x0, x1 = box(b)
+            send[g, :y1 - y0, :x1 - x0] = img[y0:y1, x0:x1]
+    dist.all_gather_into_tensor(recv.view(-1), send.view(-1))
+    for r in range(world):
+        if r == rank:
+            continue
+        for g in range(groups):
+            b = g * world + r
+            if b < nblk:
+                y0, y1, x0, x1 = box(b)
+                img[y0:y1, x0:x1] = recv[r, g, :y1 - y0, :x1 - x0]
 
 
 def complete_cull_table(table, rank, world, dist):

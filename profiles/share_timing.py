@@ -1,10 +1,13 @@
 #!/usr/bin/env python3
-"""How long does ONE rank's share of the bench frame take on one GPU?  (tile rows t % N == r of the 1080p / 256 spp
-frame, N = 1, 2, 4, 8; the slowest rank r counts.)  N x share / whole frame is the compute-side strong-scaling efficiency
-before the exchanges.  Round 5: a share = this rank's slab of the cull pre-pass (lf_set_cull_share: blocks b % N == r)
-+ the culled march of its tile rows under the COMPLETE table; `replicated` = what the frame would cost if every rank
-built the whole table (the pre-pass does not shrink with N).
-Usage (GPU box, repo root): python3 profiles/share_timing.py > gpurun_out/r05_share_timing.json"""
+"""How long does ONE rank's share of the bench frame take on one GPU?  N = 1, 2, 4, 8; the slowest rank counts;
+N x share / whole frame is the compute-side strong-scaling efficiency before the exchange of the finished frame.
+Round 6, two deals of the 1080p / 256 spp frame beside each other:
+  blocks  (lf_set_block_deal, what bench.py runs): the 64 x 64-pixel blocks b % N == r -- the rank's pre-pass builds, and its
+          audit checks, only the rows of its own blocks, its march reads only those: one launch of lf_trace_ghosts (mode 2)
+          holds the whole share, NOTHING is exchanged but the finished blocks;
+  rows    (lf_set_row_interleave, rounds 1-5): tile rows t % N == r; the rank builds its slab of the table
+          (lf_set_cull_share), one all-gather completes it, every rank audits the whole table, marches its rows.
+Usage (GPU box, repo root): python3 profiles/share_timing.py > gpurun_out/r06_share_timing.json"""
 import json
 import os
 import sys
@@ -33,46 +36,62 @@ def ctx():
     return lf
 
 
-def timed(lf, what, fn, reps=3):
+def timed(lf, fn, reps=3):
+    """-> ms per call of every timed kernel class"""
     fn()
     lf.synchronize()
     lf.timing_reset()
     for _ in range(reps):
         fn()
     lf.synchronize()
-    n, ms = lf.timing_get(what)
-    return ms / max(1, n)
+    return {k: lf.timing_get(k)[1] / reps for k in ("march", "cull_prepass", "cull_audit")}
 
 
-out = {"frame": f"{W}x{H}, {spp} spp, primary + 45 pairs x 3 wavelengths, sun {SUN[0]}", "ranks": {}}
-# the march of a share under the complete table: mode 1 keeps the table between launches, so only the march is timed
-full = ctx()
-full.set_march_culling(1)
-whole_prepass = None
+out = {"frame": f"{W}x{H}, {spp} spp, primary + 45 pairs x 3 wavelengths, sun {SUN[0]}", "blocks": {}, "rows": {}}
 for n in (1, 2, 4, 8):
-    march, prepass = [], []
+    # ---- dealt by blocks: one launch is the share
+    shares = []
+    for r in range(n):
+        lf = ctx()
+        lf.set_block_deal(r, n)
+        lf.set_march_culling(2)
+        t = timed(lf, lambda: lf.trace_ghosts(spp, 1))
+        assert lf.cull_info()["culled"]
+        shares.append(t)
+        lf.close()
+    tot = [t["march"] + t["cull_prepass"] + t["cull_audit"] for t in shares]
+    out["blocks"][n] = {"march_ms_per_rank": [t["march"] for t in shares], "prepass_ms_per_rank": [t["cull_prepass"] for t in shares],
+                        "audit_ms_per_rank": [t["cull_audit"] for t in shares], "share_ms_per_rank": tot,
+                        "slowest_share_ms": max(tot), "fastest_share_ms": min(tot), "spread": max(tot) / min(tot)}
+    # ---- dealt by tile rows: slab of the pre-pass + (audit of the whole table + march of the rows) under the complete table
+    full = ctx()
+    full.set_march_culling(1)
+    shares = []
     for r in range(n):
         full.set_row_interleave(r, n)
-        march.append(timed(full, "march", lambda: full.trace_ghosts(spp, 1)))
+        t = timed(full, lambda: full.trace_ghosts(spp, 1))                 # (mode 1: the resident table, the march alone)
         if n == 1:
             one = ctx()
             one.set_march_culling(2)
-            prepass.append(timed(one, "cull_prepass", lambda: one.trace_ghosts(spp, 1)))
+            tp = timed(one, lambda: one.trace_ghosts(spp, 1))
+            slab, audit = tp["cull_prepass"], tp["cull_audit"]
             one.close()
         else:
             sl = ctx()
             sl.set_cull_share(r, n)
-            prepass.append(timed(sl, "cull_prepass", lambda: sl.cull_prepare(spp)))
+            slab = timed(sl, lambda: sl.cull_prepare(spp))["cull_prepass"]
             sl.close()
-    if n == 1:
-        whole_prepass = prepass[0]
-    out["ranks"][n] = {"march_ms_per_rank": march, "prepass_slab_ms_per_rank": prepass,
-                       "slowest_share_ms": max(m + p for m, p in zip(march, prepass)),
-                       "slowest_share_ms_if_the_table_were_replicated": max(march) + whole_prepass}
-base = out["ranks"][1]["slowest_share_ms"]
-out["efficiency_shared"] = {n: base / (n * out["ranks"][n]["slowest_share_ms"]) for n in out["ranks"]}
-out["efficiency_replicated"] = {n: base / (n * out["ranks"][n]["slowest_share_ms_if_the_table_were_replicated"]) for n in out["ranks"]}
-out["note"] = ("compute side only, one GPU playing each rank in turn: the two all-gathers per frame (table slabs: 16.7 MB "
-               "in total; finished tile rows: 49.8 MB, overlapped with the next frame) and the flare layer (0.13 ms) are not in it")
-full.close()
+            audit = out["rows"][1]["audit_ms_per_rank"][0]                  # every rank audits the whole table
+        shares.append((t["march"], slab, audit))
+    full.close()
+    tot = [sum(x) for x in shares]
+    out["rows"][n] = {"march_ms_per_rank": [x[0] for x in shares], "prepass_slab_ms_per_rank": [x[1] for x in shares],
+                      "audit_ms_per_rank": [x[2] for x in shares], "share_ms_per_rank": tot, "slowest_share_ms": max(tot),
+                      "fastest_share_ms": min(tot), "spread": max(tot) / min(tot)}
+for deal in ("blocks", "rows"):
+    base = out[deal][1]["slowest_share_ms"]
+    out[f"efficiency_{deal}"] = {n: base / (n * out[deal][n]["slowest_share_ms"]) for n in out[deal]}
+out["note"] = ("compute side only, one GPU playing each rank in turn.  Not in it: the all-gather of the finished frame (49.8 MB, "
+               "overlapped with the next frame's march), the flare layer (0.13 ms) -- and, dealt by rows, the table's all-gather "
+               "(16.7 MB on the critical path between pre-pass and march), which the block deal does not have")
 print(json.dumps(out, indent=1))

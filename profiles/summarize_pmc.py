@@ -41,6 +41,17 @@ res = {"kernel": kern, "config": cfg,
 if pre:
     res["cull_prepass"] = {"kernel": "k_cull_level", "launches": {c: len(pre_disp[c]) for c in pre},
                            "sum_over_launches": dict(pre)}
+# ... and the audit of what the table drops (k_cull_audit: one launch per table; round 6)
+aud, aud_disp = defaultdict(float), defaultdict(set)
+for f in glob.glob(out_dir + "/*/*/*counter_collection.csv"):
+    if "/stats/" in f:
+        continue
+    for row in csv.DictReader(open(f)):
+        if "k_cull_audit" in row["Kernel_Name"]:
+            aud[row["Counter_Name"]] += float(row["Counter_Value"])
+            aud_disp[row["Counter_Name"]].add(row["Dispatch_Id"])
+if aud:
+    res["cull_audit"] = {"kernel": "k_cull_audit", "launches": {c: len(aud_disp[c]) for c in aud}, "sum_over_launches": dict(aud)}
 h = hashlib.sha256()
 for f in ("lens-flare_amd/csrc/lf_march.hip", "lens-flare_amd/csrc/lf_cull.hip", "lens-flare_amd/csrc/lf_march_common.h",
           "lens-flare_amd/csrc/lf_march_events.h", "lens-flare_amd/csrc/lf_internal.h"):

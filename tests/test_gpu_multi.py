@@ -541,3 +541,130 @@ def test_bench_goes_through_the_multi_rank_bring_up_with_one_rank(pkg):
     want = json.loads([l for l in plain.stdout.splitlines() if l.startswith("{")][-1])
     assert line["config"]["events_executed_per_frame"] == want["config"]["events_executed_per_frame"]
     assert line["culling"]["started_fraction"] == want["culling"]["started_fraction"]
+
+
+# ---- round 6: the frame dealt by BLOCKS of 64 x 64 pixels (lf_set_block_deal) -------------------------------------------
+def _block_owner(W, H, n):
+    """(H, W) array: the rank that owns each pixel under the block deal"""
+    bx = (W + 63) // 64
+    yy, xx = np.mgrid[0:H, 0:W]
+    return ((yy // 64) * bx + xx // 64) % n
+
+
+@pytest.mark.parametrize("n,W,H,spp", [(8, 1920, 1080, 16), (3, 1920, 1080, 16), (7, 1900, 1000, 9), (4, 3840, 2160, 4)])
+def test_block_deal_is_the_single_context_frame_with_no_table_exchange(pkg, cull_forced, n, W, H, spp):
+    """n contexts on device 0, each with the blocks b % n == rank: every context builds, audits and reads ONLY its own rows of
+    the cull table (no prepare / view / commit, no all-gather: nothing is exchanged but the finished blocks), the frame put
+    together from everybody's own blocks -- flare layer included -- is the single context's bit for bit, the counters and the
+    audit's rays sum to its, a rank's table rows are the single table's rows of its blocks and nothing else."""
+    lens = pkg.load_lens_file("dgauss11.lens")
+    mask = load_texels("pentbig500_14.png")
+
+    def setup(lf):
+        lf.set_frame(W, H)
+        _setup(pkg, lf, lens, mask)
+        lf.set_march_culling(2)
+        lf.reset_counters()
+
+    one = pkg.LensFlare(0)
+    setup(one)
+    _frame(one, spp, 9)
+    assert one.cull_info()["culled"]
+    info = one.cull_info()
+    want_sample, want_ghost = one.read_buffer(pkg.SAMPLE_BUFFER), one.read_buffer(pkg.GHOST_BUFFER)
+    want_cnt, want_tab, want_audit = one.counters(), one.cull_table(), one.cull_audit()
+    # (the single context may take blocks of 128 pixels at 4K with few samples; dealt by blocks the table's block is the deal's)
+    one.close()
+    owner = _block_owner(W, H, n)
+    got_sample, got_ghost = np.zeros_like(want_sample), np.zeros_like(want_ghost)
+    total_cnt, audit_rays, started = {}, 0, 0.0
+    for r in range(n):
+        lf = pkg.LensFlare(0)
+        setup(lf)
+        lf.set_block_deal(r, n)
+        _frame(lf, spp, 9)
+        ci = lf.cull_info()
+        assert ci["culled"] and ci["block_px"] == 64, (ci, lf.cull_reason())
+        mine = owner == r
+        got_sample[mine] = lf.read_buffer(pkg.SAMPLE_BUFFER)[mine]
+        got_ghost[mine] = lf.read_buffer(pkg.GHOST_BUFFER)[mine]
+        for key, v in lf.counters().items():
+            total_cnt[key] = total_cnt.get(key, 0) + v
+        a = lf.cull_audit()
+        assert a["lit"] == 0 and a["rays"] > 0
+        audit_rays += a["rays"]
+        tab = lf.cull_table().reshape(-1, ci["cells"] + 1)
+        own_blocks = np.arange(tab.shape[0]) % n == r
+        assert not tab[~own_blocks].any()                  # nobody else's rows were built
+        if info["block_px"] == 64:
+            assert np.array_equal(tab[own_blocks], want_tab.reshape(-1, ci["cells"] + 1)[own_blocks])
+        started += lf.cull_started_fraction() * own_blocks.sum()
+        lf.close()
+    assert np.array_equal(got_ghost, want_ghost) and np.array_equal(got_sample, want_sample) and want_ghost.max() > 0
+    if info["block_px"] == 64:
+        assert total_cnt == want_cnt and audit_rays == want_audit["rays"]
+    else:
+        assert total_cnt["rays_hit_light"] == want_cnt["rays_hit_light"]
+
+
+@pytest.mark.parametrize("n", [2, 5])
+def test_group_dealt_by_blocks_gathers_the_single_context_frame(pkg, cull_forced, n):
+    """lf_group_set_block_deal (one process, n devices; here n contexts on device 0 and the peer-copy stand-in of the
+    all-gather): blocks packed, exchanged and unpacked -- every context ends with the single-context 1080p frame, bit for
+    bit; lf_group_share_cull has nothing to do; back to tile rows: the same frame."""
+    lens = pkg.load_lens_file("dgauss11.lens")
+    mask = load_texels("pentbig500_14.png")
+    W, H, spp = 1920, 1080, 16
+    one = pkg.LensFlare(0)
+    one.set_frame(W, H)
+    _setup(pkg, one, lens, mask)
+    one.set_march_culling(2)
+    _frame(one, spp, 9)
+    want = one.read_buffer(pkg.SAMPLE_BUFFER)
+    one.close()
+    grp = pkg.LensFlareGroup([0] * n)
+    grp.set_frame(W, H)
+    for r in grp.ranks:
+        _setup(pkg, r, lens, mask)
+        r.set_march_culling(2)
+    grp.set_block_deal(True)
+    for _ in range(2):
+        grp.share_cull(spp)                      # (nothing to share: returns at once)
+        grp.for_each(lambda lf, rank: _frame(lf, spp, 9))
+        grp.gather(pkg.SAMPLE_BUFFER)
+    for lf in grp.ranks:
+        assert lf.cull_info()["culled"]
+        assert np.array_equal(lf.read_buffer(pkg.SAMPLE_BUFFER), want)
+    grp.set_block_deal(False)
+    grp.share_cull(spp)
+    grp.for_each(lambda lf, rank: _frame(lf, spp, 9))
+    grp.gather(pkg.SAMPLE_BUFFER)
+    for lf in grp.ranks:
+        assert np.array_equal(lf.read_buffer(pkg.SAMPLE_BUFFER), want)
+    grp.close()
+
+
+def test_block_deal_exchange_through_the_communicator(pkg, force_exchange, cull_forced):
+    """the blocks' exchange on the C ABI's RCCL path with the one rank a one-GPU box can form: pack, ncclAllGather, unpack
+    of 64 x 64 blocks (synchronous and on the exchange's own stream), the plan's unit is a block"""
+    if not pkg.comm_available():
+        pytest.skip("librccl.so.1 not loadable")
+    lens = pkg.load_lens_file("dgauss11.lens")
+    mask = load_texels("pentbig500_14.png")
+    W, H, spp = 1900, 1000, 16
+    lf = pkg.LensFlare(0)
+    lf.set_frame(W, H)
+    _setup(pkg, lf, lens, mask)
+    lf.set_march_culling(2)
+    lf.comm_init_rank(1, 0, pkg.comm_unique_id())
+    lf.set_block_deal(0, 1)
+    _frame(lf, spp, 9)
+    want = lf.read_buffer(pkg.SAMPLE_BUFFER)
+    lf.comm_gather(pkg.SAMPLE_BUFFER)
+    assert np.array_equal(lf.read_buffer(pkg.SAMPLE_BUFFER), want)
+    for _ in range(2):
+        _frame(lf, spp, 9)
+        lf.comm_gather_async(pkg.SAMPLE_BUFFER)
+    lf.comm_wait()
+    assert np.array_equal(lf.read_buffer(pkg.SAMPLE_BUFFER), want) and want.max() > 0
+    lf.close()

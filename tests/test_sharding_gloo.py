@@ -325,3 +325,49 @@ def test_shared_cull_table_is_completed_by_one_all_gather(world, blocks, tmp_pat
     assert (want.sum(axis=1) == 0).sum() == nb * world - blocks
     for r in range(world):
         assert np.array_equal(np.load(tmp_path / f"table_{r}.npy").reshape(nb * world, row_entries), want)
+
+
+# ---- round 6: the frame dealt by blocks of 64 x 64 pixels --------------------------------------------------------------
+def _block_worker(rank, world, port, W, H, out_dir):
+    import torch
+    import torch.distributed as dist
+    sys.path.insert(0, ROOT)
+    import __graft_entry__ as g
+    g.load_package()
+    from lens_flare_amd import sharding
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    want = np.arange(H * W * 3, dtype=np.float64).reshape(H, W, 3) + 1.0       # the frame every rank must end with
+    frame = torch.zeros(H * W * 3 + 17, dtype=torch.float64)                   # (a buffer longer than the frame: padding untouched)
+    view = frame.numpy()[:H * W * 3].reshape(H, W, 3)
+    bx = (W + 63) // 64
+    for b in sharding.my_blocks(W, H, rank, world):                           # this rank "renders" its own blocks
+        y0, x0 = (b // bx) * 64, (b % bx) * 64
+        view[y0:y0 + 64, x0:x0 + 64] = want[y0:y0 + 64, x0:x0 + 64]
+    scratch = {}
+    for _ in range(2):                                                         # (the staging is reused between frames)
+        sharding.gather_blocks(frame, W, H, rank, world, dist, scratch=scratch)
+    np.save(os.path.join(out_dir, f"blocks_{rank}.npy"), frame.numpy().copy())
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world,W,H", [(2, 200, 150), (3, 130, 64), (3, 64, 200)])
+def test_block_deal_and_its_gather(world, W, H, tmp_path):
+    """lf_set_block_deal's exchange as bench.py's torch / rehearsal modes run it (sharding.gather_blocks; inside the C ABI:
+    lf_group.hip k_pack_blocks / k_unpack_blocks, tests/test_gpu_multi.py): blocks b % world == rank rendered in place,
+    packed (partial blocks at the right and lower edges, fewer blocks than world x groups), ONE all-gather, unpacked --
+    every rank holds the whole frame, nothing outside it is touched; the deal covers every block exactly once."""
+    import torch.multiprocessing as mp
+    sys.path.insert(0, ROOT)
+    import __graft_entry__ as g
+    g.load_package()
+    from lens_flare_amd import sharding
+    owned = sorted(b for r in range(world) for b in sharding.my_blocks(W, H, r, world))
+    assert owned == list(range(sharding.n_blocks(W, H)))
+    mp.spawn(_block_worker, args=(world, _free_port(), W, H, str(tmp_path)), nprocs=world, join=True)
+    want = np.arange(H * W * 3, dtype=np.float64) + 1.0
+    for r in range(world):
+        got = np.load(tmp_path / f"blocks_{r}.npy")
+        assert np.array_equal(got[:H * W * 3], want) and not got[H * W * 3:].any(), r
