@@ -528,19 +528,27 @@ def test_bench_goes_through_the_multi_rank_bring_up_with_one_rank(pkg):
         pytest.skip("librccl.so.1 not loadable")
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     env = dict(os.environ, LF_BENCH_SOLO_COMM="1", LF_BENCH_COMM_TIMEOUT="120")
-    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--steps", "2", "--warmup", "1", "--no-cpu", "--config", "c2"],
-                       capture_output=True, text=True, timeout=600, env=env, cwd=root)
-    assert r.returncode == 0, r.stderr[-3000:]
-    line = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
-    assert line["config"]["gather_mode"] == "cabi" and line["config"]["gather_note"] is None
-    assert line["culling"]["culled"] and line["culling"]["prepass_shared_between_ranks"] == "rccl (C ABI)"
-    assert line["rccl_nranks"] == 1 and line["n_gpus"] == 1
+    lines = {}
+    for deal in ("blocks", "rows"):
+        r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--steps", "2", "--warmup", "1", "--no-cpu", "--config", "c2"],
+                           capture_output=True, text=True, timeout=600, env=dict(env, LF_BENCH_DEAL=deal), cwd=root)
+        assert r.returncode == 0, r.stderr[-3000:]
+        line = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+        assert line["config"]["gather_mode"] == "cabi" and line["config"]["gather_note"] is None and line["config"]["deal"] == deal
+        assert line["culling"]["culled"] and line["culling"]["audit"]["lit"] == 0
+        assert line["rccl_nranks"] == 1 and line["n_gpus"] == 1
+        lines[deal] = line
+    # dealt by blocks (the default) nothing of the table is exchanged; dealt by rows the communicator completes it
+    assert lines["blocks"]["culling"]["prepass_shared_between_ranks"].startswith("not needed")
+    assert lines["rows"]["culling"]["prepass_shared_between_ranks"] == "rccl (C ABI)"
+    line = lines["blocks"]
     plain = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--steps", "2", "--warmup", "1", "--no-cpu", "--config", "c2"],
                            capture_output=True, text=True, timeout=600, env={k: v for k, v in env.items() if k != "LF_BENCH_SOLO_COMM"}, cwd=root)
     assert plain.returncode == 0, plain.stderr[-3000:]
     want = json.loads([l for l in plain.stdout.splitlines() if l.startswith("{")][-1])
-    assert line["config"]["events_executed_per_frame"] == want["config"]["events_executed_per_frame"]
-    assert line["culling"]["started_fraction"] == want["culling"]["started_fraction"]
+    for line in lines.values():
+        assert line["config"]["events_executed_per_frame"] == want["config"]["events_executed_per_frame"]
+        assert line["culling"]["started_fraction"] == want["culling"]["started_fraction"]
 
 
 # ---- round 6: the frame dealt by BLOCKS of 64 x 64 pixels (lf_set_block_deal) -------------------------------------------
