@@ -754,7 +754,11 @@ def main():
                                                                "tile_correlation": {"value": 7.4, "recorded_in": "profiles/r04_tile_stride.json"}}
         # the same frame without the cull (identical pixels): every sample marches every path through the path tree
         # (the round-4 frame), and with the cull table kept between frames
-        culled_frame = lf.read_buffer(pkg.GHOST_BUFFER) if cull_mode != 0 else None     # (the default frame, as just timed)
+        culled_frame = None
+        if cull_mode != 0:          # the default frame once more (the variants above left theirs in the buffer), as it was timed
+            one_frame()
+            lf.synchronize()
+            culled_frame = lf.read_buffer(pkg.GHOST_BUFFER)
         for name, mode in (("full_enumeration_path_tree", 0), ("culled_table_reused", 1)):
             if mode != cull_mode:
                 lf.set_march_culling(mode)

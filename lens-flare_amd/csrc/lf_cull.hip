@@ -971,8 +971,9 @@ __device__ __forceinline__ void march_started_set(const LfLensDev* __restrict__ 
       left &= ~(1ull << q);
       // (the path's events and where it leaves the common leg: from the workgroup's LDS copy, not three dependent scalar loads)
       const int2 meta = s_meta[q];
-      const int n_ev = meta.x >> 16, L = meta.x & 0xffff;
-      const int* const seq = seq_table + meta.y;
+      const int mx = __builtin_amdgcn_readfirstlane(meta.x);       // (q is wave-uniform: so are the path's lengths and rows)
+      const int n_ev = mx >> 16, L = mx & 0xffff;
+      const int* const seq = seq_table + __builtin_amdgcn_readfirstlane(meta.y);
       unsigned mult = (unsigned)__popcll(left) + 1u;               // this path and those still to come share the leg so far
       bool forked = false;
       unsigned seg = 0u;                 // sum of the rays alive after each row of the current segment (leg / path)
@@ -1107,8 +1108,9 @@ __device__ __forceinline__ void march_started_set(const LfLensDev* __restrict__ 
 #define LF_SHARED_WAVES 6     // waves per SIMD of the shared-leg kernel with K > 1 (two ray states per lane: 80 VGPR, a few spilled;
                               // a workgroup holds 2 waves per SIMD, so 5 runs as 4: 47 ms against 38 on the bench frame)
 #endif
-template <int K, bool W1, bool SHARED>
-__global__ __launch_bounds__(64 * kWgWaves, (K == 1 ? 8 : SHARED ? LF_SHARED_WAVES : 6))
+// MODE 0: every started path alone; 1 = SHARED (one table entry per wave and sample, the leg once: march_started_set)
+template <int K, bool W1, int MODE>
+__global__ __launch_bounds__(64 * kWgWaves, (K == 1 ? 8 : MODE == 1 ? LF_SHARED_WAVES : 6))
 void k_march_cull(const LfLensDev* __restrict__ lens, const LfPairsDev* __restrict__ pairs,
                   const int* __restrict__ seq_table, const LfProgRow* __restrict__ rec_table,
                   const LfWeightRow* __restrict__ wrec_table, const float* __restrict__ mask, MarchArgs a,
@@ -1118,12 +1120,12 @@ void k_march_cull(const LfLensDev* __restrict__ lens, const LfPairsDev* __restri
   __shared__ unsigned long long s_cnt[kMarchCounters];
   __shared__ int s_next, s_nlist;
   __shared__ unsigned short s_list[kListMax];
-  __shared__ int2 s_meta[SHARED ? kCullMaxPaths : 1];      // per path: events << 16 | events of the common leg; first row of its sequence
+  __shared__ int2 s_meta[MODE == 1 ? kCullMaxPaths : 1];      // per path: events << 16 | events of the common leg; first row of its sequence
   const int tid = threadIdx.x;
   if (tid < 64 * 3) s_acc[tid] = 0ull;
   if (tid < kMarchCounters) s_cnt[tid] = 0ull;
   if (tid == 0) { s_next = 0; s_nlist = 0; }
-  if (SHARED && tid < pairs->n && tid < kCullMaxPaths) {
+  if (MODE == 1 && tid < pairs->n && tid < kCullMaxPaths) {
     const int n_ev = pairs->ev_cnt[tid], i1 = pairs->ij[tid][0];
     s_meta[tid] = make_int2((n_ev << 16) | (i1 < 0 ? n_ev : lens->n_surf - 1 - i1), pairs->ev_off[tid]);
   }
@@ -1206,7 +1208,7 @@ void k_march_cull(const LfLensDev* __restrict__ lens, const LfPairsDev* __restri
       const float pa0 = fmaf(2.0f, ua, -1.0f), pb0 = fmaf(2.0f, ub, -1.0f);
       const float X = -(((float)x + jx) - half_w) * pitch;
       const float Y = -(((float)y + jy) - half_h) * pitch;
-      if (SHARED) {
+      if (MODE == 1) {
         const unsigned long long todo = crow[entry];
         if (todo == 0ull) continue;
         const StartRay s0 = aim_at_pupil(X, Y, pa0, pb0, pupil_h, vz_u, geom_norm);
@@ -1892,8 +1894,8 @@ lf_status lfk_march_culled(lf_ctx* ctx, const MarchArgs& a, size_t blocks, size_
                      (const LfProgRow*)(ctx->prog_dev + ctx->prog_rec_off),                                  \
                      (const LfWeightRow*)(ctx->prog_dev + ctx->prog_wrec_off), m.texels, a, c, ctx->ghost,   \
                      ctx->accum, ctx->counters_dev)
-#define LF_LAUNCH_CULL(KK) do { if (items) LF_LAUNCH_ITEMS(KK); else if (weights_first) LF_LAUNCH_CULL1(KK, true, false); \
-                                else if (shared_leg) LF_LAUNCH_CULL1(KK, false, true); else LF_LAUNCH_CULL1(KK, false, false); } while (0)
+#define LF_LAUNCH_CULL(KK) do { if (items) LF_LAUNCH_ITEMS(KK); else if (weights_first) LF_LAUNCH_CULL1(KK, true, 0); \
+                                else if (shared_leg) LF_LAUNCH_CULL1(KK, false, 1); else LF_LAUNCH_CULL1(KK, false, 0); } while (0)
   const bool weights_first = ctx->cull_weights_first;   // (lf_test_knob: the weight on every executed event)
   // every pixel its own pupil point (no sub-cells at all): the compacted march.  (2 x 2 sub-cells, where the lanes of a
   // wave still look their cells up one by one, stay with k_march_cull: 48 against 59 ms on the bench frame)
