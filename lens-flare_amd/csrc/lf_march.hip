@@ -1227,9 +1227,16 @@ static lf_status march_launch(lf_ctx* ctx, int spp, uint64_t key, int chunk, int
   // stays unsplit: the split is worth another 0.5 % there and costs 5x the HBM write traffic (atomics).
   // Measured per share of the 1080p bench frame (profiles/r03_share_timing.json): 1 / 2 / 2 / 2 groups
   // for 1, 1/2, 1/4, 1/8 of the frame.
+  // The culled march (round 6: the started paths' common leg once) prefers its tiles whole: per rank of the block deal,
+  // 1 / 2 / 4 / 8 groups: 4.86 / 4.91 / 5.35 / 6.52 ms for 1/8 of the bench frame, 9.09 / 9.38 / 10.4 / 12.7 for 1/4
+  // (profiles/r06_cull_bounds.txt) -- split only launches of a few hundred tiles.
   a.sgroups = 1;
-  while (tiles * a.sgroups < 8000 && a.sgroups * 2 * 64 <= spp) a.sgroups *= 2;
-  if (a.sgroups == 1 && tiles < 20000 && 2 * 64 <= spp) a.sgroups = 2;
+  if (lf_cull_reason_of(ctx, a.G) == LF_CULL_APPLIED) {
+    while (tiles * a.sgroups < 2000 && a.sgroups * 2 * 64 <= spp) a.sgroups *= 2;
+  } else {
+    while (tiles * a.sgroups < 8000 && a.sgroups * 2 * 64 <= spp) a.sgroups *= 2;
+    if (a.sgroups == 1 && tiles < 20000 && 2 * 64 <= spp) a.sgroups = 2;
+  }
 #ifdef LF_EXPERIMENTS
   if (const char* sgv = std::getenv("LF_MARCH_SGROUPS")) {
     int v = std::atoi(sgv);
