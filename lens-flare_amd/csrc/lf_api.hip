@@ -249,7 +249,8 @@ lf_status lf_destroy(lf_ctx* ctx) {
                   ctx->prog_dev, ctx->sun_lights_dev,
                   ctx->scene_dev.nodes, ctx->scene_dev.prims, ctx->scene_dev.normals, ctx->scene_dev.materials,
                   ctx->scene_dev.lights, ctx->env_block, ctx->probe_dev, ctx->scene_counters_dev,
-                  ctx->primary_dev, ctx->cull_dev, ctx->cull_list[0], ctx->cull_list[1], ctx->cull_counts, ctx->cull_popc_dev};
+                  ctx->primary_dev, ctx->cull_dev, ctx->cull_list[0], ctx->cull_list[1], ctx->cull_counts, ctx->cull_popc_dev,
+                  ctx->tail_acc, ctx->tail_done};
   for (void* p : ptrs) if (p) (void)hipFree(p);
   if (ctx->own_stream && ctx->stream) (void)hipStreamDestroy(ctx->stream);
   delete ctx;
@@ -1051,6 +1052,8 @@ lf_status lf_test_knob(lf_ctx* ctx, const char* name, double value) {
   if (n == "scene_lens_strided") { ctx->scene_lens_strided = iv < 0 ? -1 : iv != 0; return LF_OK; }
   if (n == "bvh_median") { ctx->bvh_median = iv != 0; return LF_OK; }
   if (n == "bvh_leaf") { ctx->bvh_leaf_max = iv; return LF_OK; }
+  if (n == "march_tail_tiles") { ctx->march_tail_tiles = iv; return LF_OK; }       // (-1: the default, one round of resident workgroups)
+  if (n == "march_tail_groups") { ctx->march_tail_groups = iv; return LF_OK; }     // (1: no split tail)
   if (n == "cull_general_kernel") { if (!iv) R = lf_ctx::CullRules(); ctx->cull_rules_custom = iv != 0; }
   else if (n == "cull_strict") R.strict = iv;
   else if (n == "cull_strict_lost") R.strict_lost = iv;

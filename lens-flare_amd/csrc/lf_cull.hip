@@ -734,9 +734,15 @@ __global__ __launch_bounds__(LF_CULL_WG, LF_CULL_WAVES) void k_cull_level(const 
       unsigned long long* row = table + lf_cull_row_of_block(blk, a.share_n, a.share_nb) * (size_t)(a.P * a.P + 1);
       const unsigned long long bit = 1ull << q;
       atomicOr(&row[cell], bit);
-      atomicOr(&row[a.P * a.P], bit);
     }
     const lanemask em = __ballot(valid && enabled);
+    // the row's summary word (its last): one atomic per wave and block, not per box (the lanes of a wave are boxes of ONE path)
+    for (lanemask todo = em; todo != 0ull;) {
+      const int first = (int)__builtin_ctzll(todo);
+      const int b0 = __shfl(blk, first);
+      if (lane == first) atomicOr(&table[lf_cull_row_of_block(b0, a.share_n, a.share_nb) * (size_t)(a.P * a.P + 1) + (size_t)(a.P * a.P)], 1ull << q);
+      todo &= ~__ballot(blk == b0);
+    }
     if (em != 0ull && lane == (int)__builtin_ctzll(em)) atomicAdd(&next_counts[q], (unsigned)__popcll(em));
   } else {
     const lanemask em = __ballot(valid && enabled);
@@ -1133,8 +1139,17 @@ void k_march_cull(const LfLensDev* __restrict__ lens, const LfPairsDev* __restri
 
   // tile of the workgroup: as k_march (XCD-aware slot swizzle, wave tile = 8 rows x 8 columns 2^xs apart)
   const int tiles_x = ((a.W + (8 << a.xs) - 1) >> (3 + a.xs)) << a.xs;
-  const int sg = blockIdx.x % a.sgroups;
-  const unsigned slot = blockIdx.x / a.sgroups;
+#ifdef LF_EXPERIMENTS
+  if (cull.wg_clock && tid == 0) cull.wg_clock[2 * (size_t)blockIdx.x] = wall_clock64();
+  struct ClockAtExit { unsigned long long* p; __device__ ~ClockAtExit() { if (p && threadIdx.x == 0) *p = wall_clock64(); } }
+      clock_at_exit{cull.wg_clock ? cull.wg_clock + 2 * (size_t)blockIdx.x + 1 : nullptr};
+#endif
+  // the launch's last tiles are split finer than the rest (a.tail_from): the grid ends on short workgroups
+  const unsigned n_head = (unsigned)a.tail_from * (unsigned)a.sgroups;
+  const bool tail = a.tail_groups > 1 && blockIdx.x >= n_head;
+  const int sgroups = tail ? a.tail_groups : a.sgroups;
+  const int sg = tail ? (int)((blockIdx.x - n_head) % (unsigned)sgroups) : (int)(blockIdx.x % (unsigned)sgroups);
+  const unsigned slot = tail ? (unsigned)a.tail_from + (blockIdx.x - n_head) / (unsigned)sgroups : blockIdx.x / (unsigned)sgroups;
   const int tile_lin = (int)((slot & ~63u) | ((slot & 7u) << 3) | ((slot >> 3) & 7u));
   if (tile_lin >= a.n_tiles) return;
   int tx, trow;
@@ -1162,12 +1177,12 @@ void k_march_cull(const LfLensDev* __restrict__ lens, const LfPairsDev* __restri
 
   PathTally T;
 
-  const int n_mine = (a.spp - sg + a.sgroups - 1) / a.sgroups;     // samples sg, sg + sgroups, ...
+  const int n_mine = (a.spp - sg + sgroups - 1) / sgroups;     // samples sg, sg + sgroups, ...
   for (int chunk0 = 0; chunk0 < n_mine; chunk0 += kListMax) {
     // ---- which of the tile's samples start any path at all (most do not) -----------------------------
     const int chunk_n = min(kListMax, n_mine - chunk0);
     for (int k = tid; k < chunk_n; k += 64 * kWgWaves) {
-      const int s = sg + (chunk0 + k) * a.sgroups;
+      const int s = sg + (chunk0 + k) * sgroups;
       bool work = true;     // (a sample whose lanes look their cells up one by one is listed: the sample loop finds out)
       if (s >= GG && !cull.multi) work = crow[cull.cells] != 0ull;
       if (s < GG && !per_lane && !cull.multi) {
@@ -1186,7 +1201,7 @@ void k_march_cull(const LfLensDev* __restrict__ lens, const LfPairsDev* __restri
       if (lane == 0) k = atomicAdd(&s_next, 1);
       k = __builtin_amdgcn_readfirstlane(k);
       if (k >= n_list) break;
-      const int s = sg + (chunk0 + (int)s_list[k]) * a.sgroups;       // wave-uniform
+      const int s = sg + (chunk0 + (int)s_list[k]) * sgroups;       // wave-uniform
       // ---- sensor sample -> initial ray (the expressions of k_march / sample_start) -----------------
       const uint4 rnd = philox4x32_10(make_uint4(p, (unsigned)s, kDomainMarch, 0u), a.key);
       const float jx = u01(rnd.x), jy = u01(rnd.y);
@@ -1254,6 +1269,32 @@ void k_march_cull(const LfLensDev* __restrict__ lens, const LfPairsDev* __restri
   __syncthreads();
   if (wave == 0 && lane < kMarchCounters && s_cnt[lane]) atomicAdd(&counters[lane], s_cnt[lane]);
 
+  if (tail) {
+    // a tile of the split tail: the integer sums of its workgroups meet in tail_acc; the LAST to arrive converts them (the same
+    // conversion as a whole tile's: the sums do not depend on who added what) and leaves sums and arrivals zero for the next launch
+    if (wave != 0) return;
+    const unsigned tt = slot - (unsigned)a.tail_from;
+    unsigned long long* const acc = cull.tail_acc + (size_t)tt * 192u;
+#pragma unroll
+    for (int c = 0; c < 3; c++)
+      if (s_acc[lane * 3 + c]) atomicAdd(&acc[lane * 3 + c], s_acc[lane * 3 + c]);
+    __threadfence();
+    int arrived = 0;
+    if (lane == 0) arrived = atomicAdd(&cull.tail_done[tt], 1);
+    arrived = __shfl(arrived, 0);
+    if (arrived != sgroups - 1) return;
+    __threadfence();
+#pragma unroll
+    for (int c = 0; c < 3; c++) {
+      const unsigned long long sum = atomicExch(&acc[lane * 3 + c], 0ull);
+      if (active) {
+        const double v = ((double)sum * (1.0 / 68719476736.0)) / (double)a.spp;
+        ghost[3 * (size_t)p + c] = a.accumulate ? ghost[3 * (size_t)p + c] + v : v;
+      }
+    }
+    if (lane == 0) atomicExch(&cull.tail_done[tt], 0);
+    return;
+  }
   if (wave == 0 && active) {
     if (a.sgroups == 1) {
 #pragma unroll
@@ -1865,8 +1906,10 @@ lf_status lfk_cull_prepass(lf_ctx* ctx, int G, int spp) {
   return lfk_cull_finish(ctx, h);
 }
 
-lf_status lfk_march_culled(lf_ctx* ctx, const MarchArgs& a, size_t blocks, size_t dyn_lds) {
+constexpr int kMarchTailTilesMax = 4096;
+lf_status lfk_march_culled(lf_ctx* ctx, const MarchArgs& a_in, size_t blocks, size_t dyn_lds) {
   const LfApertureDev& m = ctx->ap[LF_APERTURE_STARBURST];
+  MarchArgs a = a_in;
   LfCullArgs c;
   c.table = ctx->cull_dev; c.blocks_x = ctx->cull_bx; c.blocks_y = ctx->cull_by; c.cells = ctx->cull_cells;
   c.share_n = ctx->cull_share_nb > 0 ? ctx->cull_share_n_resident : 1; c.share_nb = ctx->cull_share_nb;
@@ -1905,6 +1948,45 @@ lf_status lfk_march_culled(lf_ctx* ctx, const MarchArgs& a, size_t blocks, size_
 #endif
   // one table entry per (wave tile, sample) and a selection in order: the started paths' common leg once (march_started_set)
   const bool shared_leg = c.prefix_ok && !c.multi && (1 << a.sub_bits) >= c.m;
+  // ---- the tail: a launch drains for as long as its last workgroups run -- 0.65 to 1.7 ms for a tile of the bench frame,
+  // during which the resident slots empty one by one (measured per workgroup, wall clock at start and end: half of the 768
+  // slots idle over the last 0.7 ms of a 5 ms launch, 1/8 of the frame).  The LAST tiles (half a round of resident
+  // workgroups) are therefore split over `tail_groups` workgroups each (samples sg, sg + groups, ...): the launch ends on
+  // workgroups a quarter as long.  Whole tiles write their pixels themselves, split ones meet in tail_acc (k_march_cull).
+  // 1/8, 1/4, 1/2 of the bench frame: 5.00 -> 4.83, 9.46 -> 9.32, 18.40 -> 18.34 ms; all of it: 36.5 -> 36.4; more groups or a
+  // longer tail cost more than they save (a split tile repeats the workgroup's set-up and ends on 8 waves waiting for one)
+  // (profiles/r06_cull_bounds.txt, 7.)
+  a.tail_from = 0; a.tail_groups = 1; c.tail_acc = nullptr; c.tail_done = nullptr;
+  if (!items && a.sgroups == 1 && !weights_first) {
+    hipDeviceProp_t prop;
+    LF_HIP(ctx, hipGetDeviceProperties(&prop, ctx->device));
+    const int resident = prop.multiProcessorCount * (ctx->march_k == 1 ? 4 : 3);     // workgroups of 8 waves at 8 / 6 waves per SIMD
+    int tail_tiles = ctx->march_tail_tiles >= 0 ? ctx->march_tail_tiles : resident / 2;
+    int groups = ctx->march_tail_groups >= 0 ? ctx->march_tail_groups : 4;
+    while (groups > 1 && groups * 32 > a.spp) groups /= 2;
+    const int tiles_pad = (a.n_tiles + 63) / 64 * 64;
+    tail_tiles = std::min(std::min(tail_tiles, kMarchTailTilesMax), tiles_pad) / 64 * 64;
+    if (groups > 1 && tail_tiles > 0) {
+      if (!ctx->tail_acc) {
+        LF_HIP(ctx, hipMalloc((void**)&ctx->tail_acc, (size_t)kMarchTailTilesMax * 192 * sizeof(unsigned long long)));
+        LF_HIP(ctx, hipMalloc((void**)&ctx->tail_done, (size_t)kMarchTailTilesMax * sizeof(int)));
+        LF_HIP(ctx, hipMemsetAsync(ctx->tail_acc, 0, (size_t)kMarchTailTilesMax * 192 * sizeof(unsigned long long), ctx->stream));
+        LF_HIP(ctx, hipMemsetAsync(ctx->tail_done, 0, (size_t)kMarchTailTilesMax * sizeof(int), ctx->stream));
+      }
+      a.tail_from = tiles_pad - tail_tiles; a.tail_groups = groups;
+      c.tail_acc = ctx->tail_acc; c.tail_done = ctx->tail_done;
+      blocks = (size_t)a.tail_from + (size_t)tail_tiles * groups;
+    }
+  }
+#ifdef LF_EXPERIMENTS
+  c.wg_clock = nullptr;
+  const char* clock_file = std::getenv("LF_MARCH_WG_CLOCK");
+  if (clock_file) {
+    LF_HIP(ctx, hipMalloc((void**)&c.wg_clock, blocks * 16));
+    LF_HIP(ctx, hipMemset(c.wg_clock, 0, blocks * 16));
+    LF_HIP(ctx, hipDeviceSynchronize());
+  }
+#endif
   switch (ctx->march_k) {
     case 1: LF_LAUNCH_CULL(1); break;
     case 2: LF_LAUNCH_CULL(2); break;
@@ -1915,5 +1997,14 @@ lf_status lfk_march_culled(lf_ctx* ctx, const MarchArgs& a, size_t blocks, size_
 #undef LF_LAUNCH_ITEMS
   lf_timing_end(ctx, LFK_MARCH, ev);
   LF_HIP(ctx, hipGetLastError());
+#ifdef LF_EXPERIMENTS
+  if (clock_file) {
+    LF_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    std::vector<unsigned long long> h(blocks * 2);
+    LF_HIP(ctx, hipMemcpy(h.data(), c.wg_clock, blocks * 16, hipMemcpyDeviceToHost));
+    if (FILE* f = std::fopen(clock_file, "wb")) { std::fwrite(h.data(), 8, h.size(), f); std::fclose(f); }
+    (void)hipFree(c.wg_clock);
+  }
+#endif
   return LF_OK;
 }

@@ -234,6 +234,11 @@ struct LfCullArgs {
   int cells;                          // P * P, P = G * m cells per axis of the pupil square
   int P, m, m_shift;                  // m (1, 2 or 4) table cells per axis inside one stratum; m = 2^m_shift <= the
                                       // sub-cells per axis of the sampling specification (lf_set_pupil_subcells)
+  unsigned long long* tail_acc;       // [tail tile][64 lanes][3]: where the workgroups of a split tail tile meet (MarchArgs::tail_from);
+  int* tail_done;                     // [tail tile] arrivals: the last one converts and clears both (all zero between launches)
+#ifdef LF_EXPERIMENTS
+  unsigned long long* wg_clock;       // [workgroup][2]: wall clock at its start / end (LF_MARCH_WG_CLOCK=<file>)
+#endif
 };
 
 // ---- how a frame is dealt to the ranks of a multi-GPU job ------------------------------------------------------
@@ -394,6 +399,9 @@ struct lf_ctx {
   LfPairsDev* pairs_dev = nullptr;
   unsigned long long* counters_dev = nullptr;  // kMarchCounterSlots x u64
   unsigned long long* accum = nullptr;         // W*H_alloc*3 fixed-point partial sums (split launches)
+  unsigned long long* tail_acc = nullptr;      // kMarchTailTilesMax x 192 sums + arrivals of the culled march's split tail (lf_cull.hip)
+  int* tail_done = nullptr;
+  int march_tail_tiles = -1, march_tail_groups = -1;   // lf_test_knob: the tail's size (-1: one round of resident workgroups) / split
   unsigned char* prog_dev = nullptr;           // the packed program: headers, then records (lf_march.hip pack_program)
   size_t prog_cap = 0, prog_rec_off = 0, prog_wrec_off = 0, prog_seq_off = 0;   // bytes; offsets of the records / weight records / pair sequences
   // path culling (lf_cull.hip): 0 = off (k_march walks every path of every sample), 1 = on, the table is reused

@@ -1230,7 +1230,7 @@ static lf_status march_launch(lf_ctx* ctx, int spp, uint64_t key, int chunk, int
   // The culled march (round 6: the started paths' common leg once) prefers its tiles whole: per rank of the block deal,
   // 1 / 2 / 4 / 8 groups: 4.86 / 4.91 / 5.35 / 6.52 ms for 1/8 of the bench frame, 9.09 / 9.38 / 10.4 / 12.7 for 1/4
   // (profiles/r06_cull_bounds.txt) -- split only launches of a few hundred tiles.
-  a.sgroups = 1;
+  a.sgroups = 1; a.tail_from = 0; a.tail_groups = 1;
   if (lf_cull_reason_of(ctx, a.G) == LF_CULL_APPLIED) {
     while (tiles * a.sgroups < 2000 && a.sgroups * 2 * 64 <= spp) a.sgroups *= 2;
   } else {

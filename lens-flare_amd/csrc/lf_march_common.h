@@ -35,6 +35,8 @@ struct MarchArgs {
   int trow0, tperiod;  // tile rows handled: trow0 + j * tperiod, j = 0 ..   (the frame dealt by tile rows)
   LfDeal deal;         // ... or by 64 x 64-pixel blocks (deal.bx > 0, lf_set_block_deal): own block k = rank + k n, 64 wave tiles each
   int sgroups;         // the samples of a tile are split over this many workgroups (power of two)
+  int tail_from, tail_groups;   // k_march_cull: the launch's LAST tiles (slots >= tail_from, a multiple of 64) split over tail_groups
+                       // workgroups each, so that the launch ends on short workgroups (0 / 1: no tail); the rest as `sgroups` says
   uint2 key;
   float inv_stop_h;    // 1 / stop_h (correctly rounded)
   float half_w, half_h;  // 0.5 * W, 0.5 * H

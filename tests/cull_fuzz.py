@@ -11,7 +11,8 @@ lf_trace_ghosts under lf_set_march_culling(2) with lf_set_march_culling(0) bit f
 reached the light.  The culled kernel is kept where the launch would fall back to the path tree (lf_test_knob
 cull_force).  TEST INFRASTRUCTURE (tests/test_gpu_cull.py draws from it; profiles/ only holds what it recorded).
 
-    python3 tests/cull_fuzz.py [cases] [seed] [families] > gpurun_out/r06_cull_fuzz.json
+    python3 tests/cull_fuzz.py [cases] [seed] [families] [audit] > gpurun_out/r06_cull_fuzz_<seed>.json
+    python3 tests/cull_fuzz.py reduce gpurun_out/r06_cull_fuzz_*.json > profiles/r06_cull_fuzz.json   (summaries + bad cases)
 
 run(..., knobs=) installs pre-pass rules other than the shipped ones (lf_test_knob: the rules round 5 replaced),
 audit= the rays per dropped box of the launch's audit (0: the raw table is compared -- a search for rule failures;
@@ -254,8 +255,25 @@ def run(N, SEED, log=sys.stderr, only=None, hook=None, families=4, knobs=None, a
     return {"summary": summary, "cases": out}
 
 
+def reduce(files):
+    """the draws' summaries and every case that differed: what profiles/ keeps of a run"""
+    draws, bad = [], []
+    for f in files:
+        d = json.load(open(f))
+        draws.append(dict(d["summary"], file=os.path.basename(f), env=d.get("env", {}), argv=d.get("argv")))
+        bad += [dict(c, file=os.path.basename(f)) for c in d["cases"] if c.get("BAD")]
+    return {"draws": draws, "frames": sum(x["compared"] for x in draws), "frames_differing": sum(x["frames_differing"] for x in draws),
+            "lit_rays_compared": sum(x["lit_rays_compared"] for x in draws), "audit_rays": sum(x.get("audit_rays", 0) for x in draws),
+            "audit_lit": sum(x.get("audit_lit", 0) for x in draws), "cases_that_differed": bad}
+
+
 if __name__ == "__main__":
+    if len(sys.argv) > 1 and sys.argv[1] == "reduce":
+        print(json.dumps(reduce(sys.argv[2:]), indent=1))
+        sys.exit(0)
     r = run(int(sys.argv[1]) if len(sys.argv) > 1 else 200, int(sys.argv[2]) if len(sys.argv) > 2 else 20261004,
-            families=int(sys.argv[3]) if len(sys.argv) > 3 else 4)
+            families=int(sys.argv[3]) if len(sys.argv) > 3 else 4, audit=int(sys.argv[4]) if len(sys.argv) > 4 else 0)
+    r["argv"] = sys.argv[1:]
+    r["env"] = {k: v for k, v in os.environ.items() if k.startswith("FUZZ_")}
     print(json.dumps(r, indent=1))
     print("SUMMARY", json.dumps(r["summary"]), file=sys.stderr)

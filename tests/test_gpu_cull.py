@@ -309,6 +309,50 @@ def test_other_masks_focus_and_prescriptions_at_1080p(pkg, lf, mask_name, refocu
               f"{c1['rays_launched'] / c0['rays_launched']:.4f}, lit rays {c0['rays_hit_light']}")
 
 
+def test_the_split_tail_is_the_same_frame(pkg, lf):
+    """k_march_cull splits the LAST tiles of a launch over several workgroups (MarchArgs::tail_from: the launch ends on short
+    workgroups; their integer sums meet in a small buffer the last arrival converts and clears).  Whatever the tail's size
+    and split (lf_test_knob march_tail_tiles / march_tail_groups; 0 / 1 = no tail): the same pixels and counters -- twice in
+    a row (the buffer is left clean), accumulating, with columns 8 apart, and for a share of the block deal."""
+    lens = pkg.load_lens_file("dgauss11.lens")
+    W, H, spp = 1920, 1080, 64
+    _setup(pkg, lf, lens, W, H, [0.12, 0.08, -1.0], 0.05, load_texels("pentbig500_14.png"))
+    lf.set_march_culling(2)
+
+    def frame(tiles, groups, accumulate=False):
+        lf.test_knob("march_tail_tiles", tiles)
+        lf.test_knob("march_tail_groups", groups)
+        lf.reset_counters()
+        if accumulate:
+            lf.clear_ghost_buffer()
+            lf.set_ghost_accumulate(True)
+            lf.trace_ghosts(spp, 5)
+        lf.trace_ghosts(spp, 7)
+        lf.set_ghost_accumulate(False)
+        assert lf.cull_info()["culled"]
+        return lf.read_buffer(pkg.GHOST_BUFFER), lf.counters(), lf.executed_events()
+    try:
+        for deal in (None, (1, 3)):
+            if deal:
+                lf.set_block_deal(*deal)
+            for stride in (1, 8):                # (8 = the default)
+                lf.set_tile_stride(stride)
+                g0, c0, e0 = frame(0, 1)
+                assert g0.any()
+                for tiles, groups in ((-1, -1), (-1, -1), (1024, 3), (4096, 2), (64, 2), (100000, 4)):
+                    g1, c1, e1 = frame(tiles, groups)
+                    assert np.array_equal(g1, g0) and c1 == c0 and e1 == e0, (deal, stride, tiles, groups)
+            ga, ca, _ = frame(0, 1, accumulate=True)
+            gb, cb, _ = frame(-1, -1, accumulate=True)
+            assert np.array_equal(ga, gb) and ca == cb and not np.array_equal(ga, g0)
+    finally:
+        lf.test_knob("march_tail_tiles", -1)
+        lf.test_knob("march_tail_groups", -1)
+        lf.set_tile_stride(8)
+        lf.set_block_deal(0, 1)
+        lf.set_march_culling(1)
+
+
 def test_weight_on_every_event_is_the_same_frame(pkg, lf):
     """k_march_cull<K, true> (lf_test_knob cull_weights_first, bench.py's `every_event_weighted` leg): the Fresnel / mask weight
     evaluated on EVERY executed event of every started ray -- SURVEY 8d's unit event -- instead of on a second march of
