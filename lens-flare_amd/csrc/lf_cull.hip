@@ -939,6 +939,21 @@ __device__ __forceinline__ void march_started_path(const LfLensDev* __restrict__
 // marched alone -- a row of the common leg counts once for every started path that shares it (the paths not yet done) --
 // while the rows EXECUTED fall by the shared part (the device's executed-events counter, slot 7).
 // Geometry first (W1 = false): a lane that ends inside the lobe marches its path again, alone, with the weight, as before.
+// one surface row for the K wavelengths of a group, its kind a compile-time constant -> the lanes that ended on it
+template <int K, bool REFLECT, bool FLAT>
+__device__ __forceinline__ lanemask surface_rows(Ray (&r)[K], const lanemask (&alive)[K], const LfProgRow& wr, lanemask (&okv)[K],
+                                                 lanemask (&gv)[K]) {
+  lanemask died = 0ull;
+#pragma unroll
+  for (int j = 0; j < K; j++) {
+    if (K > 1 && __builtin_expect(alive[j] == 0ull, 0)) { okv[j] = 0ull; gv[j] = 0ull; continue; }
+    okv[j] = surface_event<false>(r[j], wr.dzv, wr.curv, wr.ch, wr.c2, wr.sc, wr.cn22[j], wr.rn2[j], wr.delta[j], wr.h2,
+                                  REFLECT, FLAT, wr.sgn, gv[j]);
+    died |= alive[j] & ~okv[j];
+  }
+  return died;
+}
+
 template <int K>
 __device__ __forceinline__ void march_started_set(const LfLensDev* __restrict__ lens, const LfPairsDev* __restrict__ pairs,
                                                   const int* __restrict__ seq_table, const LfProgRow* __restrict__ rec_table,
@@ -985,8 +1000,10 @@ __device__ __forceinline__ void march_started_set(const LfLensDev* __restrict__ 
       unsigned seg = 0u;                 // sum of the rays alive after each row of the current segment (leg / path)
       unsigned long long ev_logical = 0ull;
       unsigned ev_exec = 0u;
-      unsigned se = depth < n_ev ? (unsigned)*(const int __attribute__((address_space(4)))*)(seq + depth) : 0u;
-      for (int e = depth; e < n_ev && nlive != 0u; e++) {
+      // (the sequence dword one row ahead, unconditionally: the table ends on a spare dword -- pack_program)
+      unsigned se = (unsigned)*(const int __attribute__((address_space(4)))*)(seq + depth);
+      int e = depth;
+      if (e < n_ev && nlive != 0u) for (;;) {
         if (e == L) {      // the path leaves the common leg: park the leg
 #pragma unroll
           for (int j = 0; j < K; j++) { p[j] = r[j]; palive[j] = alive[j]; }
@@ -994,11 +1011,16 @@ __device__ __forceinline__ void march_started_set(const LfLensDev* __restrict__ 
           ev_logical = (unsigned long long)seg * mult; ev_exec = seg; seg = 0u; mult = 1u;
         }
         const unsigned cur = se;
-        if (e + 1 < n_ev) se = (unsigned)*(const int __attribute__((address_space(4)))*)(seq + e + 1);
+        se = (unsigned)*(const int __attribute__((address_space(4)))*)(seq + e + 1);
         const LfProgRow wr = load_prec(recs, cur & 0xffffu);
         const unsigned kind = cur >> 16;
         lanemask okv[K], gv[K], died = 0ull;
-        if (kind & LF_EV_STOP) {
+        // (the scalar unit is what this loop waits for: the row's kind is decided ONCE for its K wavelengths -- curved glass
+        // crossed, by far the most frequent, first -- and the event inlined with its flags constant; a wave that lost its
+        // last ray leaves through the row counter, so that the row's end tests one thing)
+        if (__builtin_expect(kind == 0u, 1)) {
+          died = surface_rows<K, false, false>(r, alive, wr, okv, gv);
+        } else if (kind & LF_EV_STOP) {
 #pragma unroll
           for (int j = 0; j < K; j++) {
             if (K > 1 && __builtin_expect(alive[j] == 0ull, 0)) { okv[j] = 0ull; gv[j] = 0ull; continue; }
@@ -1006,32 +1028,29 @@ __device__ __forceinline__ void march_started_set(const LfLensDev* __restrict__ 
             gv[j] = okv[j];
             died |= alive[j] & ~okv[j];
           }
-          if (__builtin_expect(died != 0ull, 0)) {
-#pragma unroll
-            for (int j = 0; j < K; j++) {
-              const unsigned nd = (unsigned)__popcll(alive[j] & ~okv[j]);
-              T.n_clip += (unsigned long long)nd * mult; nlive -= nd; alive[j] &= okv[j];
-            }
-          }
+        } else if (kind & LF_EV_REFLECT) {
+          if (kind & LF_EV_FLAT) died = surface_rows<K, true, true>(r, alive, wr, okv, gv);
+          else died = surface_rows<K, true, false>(r, alive, wr, okv, gv);
         } else {
+          died = surface_rows<K, false, true>(r, alive, wr, okv, gv);
+        }
+        if (__builtin_expect(died != 0ull, 0)) {
+          // (a stop row: gv = okv, every ray it ends is clipped; a surface row: missed / outside the aperture, or totally reflected)
+          const bool stop_row = (kind & LF_EV_STOP) != 0;
 #pragma unroll
           for (int j = 0; j < K; j++) {
-            if (K > 1 && __builtin_expect(alive[j] == 0ull, 0)) { okv[j] = 0ull; gv[j] = 0ull; continue; }
-            okv[j] = surface_event<false>(r[j], wr.dzv, wr.curv, wr.ch, wr.c2, wr.sc, wr.cn22[j], wr.rn2[j], wr.delta[j], wr.h2,
-                                          (kind & LF_EV_REFLECT) != 0, (kind & LF_EV_FLAT) != 0, wr.sgn, gv[j]);
-            died |= alive[j] & ~okv[j];
+            const unsigned nd = (unsigned)__popcll(alive[j] & ~okv[j]);
+            const unsigned nv = (unsigned)__popcll(alive[j] & ~gv[j]);
+            T.n_clip += stop_row ? (unsigned long long)nd * mult : 0ull;
+            T.n_vign += stop_row ? 0ull : (unsigned long long)nv * mult;
+            T.n_tir += stop_row ? 0ull : (unsigned long long)(nd - nv) * mult;
+            nlive -= nd;
+            alive[j] &= okv[j];
           }
-          if (__builtin_expect(died != 0ull, 0)) {
-#pragma unroll
-            for (int j = 0; j < K; j++) {
-              T.n_vign += (unsigned long long)__popcll(alive[j] & ~gv[j]) * mult;
-              T.n_tir += (unsigned long long)__popcll(alive[j] & gv[j] & ~okv[j]) * mult;
-              nlive -= (unsigned)__popcll(alive[j] & ~okv[j]);
-              alive[j] &= okv[j];
-            }
-          }
+          if (nlive == 0u) e = n_ev;
         }
         seg += nlive;       // events completed: one per ray still alive after the row
+        if (++e >= n_ev) break;
       }
       // ... counted once for every logical path that shares the row (the leg's rows: `mult` paths), and once as executed
       T.events += ev_logical + (unsigned long long)seg * mult;
