@@ -810,9 +810,10 @@ __device__ __forceinline__ void march_started_path(const LfLensDev* __restrict__
     T.n_rays += nlive;
     unsigned ev32 = 0u;
     unsigned se = (unsigned)*(const int __attribute__((address_space(4)))*)(seq);
-    for (int e = 0; e < n_ev && nlive != 0u; e++) {
+    int e = 0;
+    if (n_ev > 0 && nlive != 0u) for (;;) {     // (the row's end tests ONE thing: a wave without rays leaves through the row counter)
       const unsigned cur = se;
-      if (e + 1 < n_ev) se = (unsigned)*(const int __attribute__((address_space(4)))*)(seq + e + 1);
+      se = (unsigned)*(const int __attribute__((address_space(4)))*)(seq + e + 1);     // (the table ends on a spare dword: pack_program)
       const LfProgRow wr = load_prec(recs, cur & 0xffffu);
       LfWeightRow ww;
       if (W1) ww = load_wrec(wrecs, cur & 0xffffu);
@@ -833,6 +834,7 @@ __device__ __forceinline__ void march_started_path(const LfLensDev* __restrict__
             const unsigned nd = (unsigned)__popcll(alive[j] & ~okv[j]);
             T.n_clip += nd; nlive -= nd; alive[j] &= okv[j];
           }
+          if (nlive == 0u) e = n_ev;
         }
       } else {
         if (kind == 0u) {          // refraction at a curved interface: the common row, straight-line
@@ -841,6 +843,14 @@ __device__ __forceinline__ void march_started_path(const LfLensDev* __restrict__
             if (K > 1 && __builtin_expect(alive[j] == 0ull, 0)) { okv[j] = 0ull; gv[j] = 0ull; continue; }
             okv[j] = surface_event<W1>(r[j], wr.dzv, wr.curv, wr.ch, wr.c2, wr.sc, wr.cn22[j], wr.rn2[j],
                                        wr.delta[j], wr.h2, false, false, wr.sgn, gv[j], ww.fs[j], ww.fo[j], ww.fi[j]);
+            died |= alive[j] & ~okv[j];
+          }
+        } else if (kind == (unsigned)LF_EV_REFLECT) {      // a curved mirror: two rows of every pair
+#pragma unroll
+          for (int j = 0; j < K; j++) {
+            if (K > 1 && __builtin_expect(alive[j] == 0ull, 0)) { okv[j] = 0ull; gv[j] = 0ull; continue; }
+            okv[j] = surface_event<W1>(r[j], wr.dzv, wr.curv, wr.ch, wr.c2, wr.sc, wr.cn22[j], wr.rn2[j],
+                                       wr.delta[j], wr.h2, true, false, wr.sgn, gv[j], ww.fs[j], ww.fo[j], ww.fi[j]);
             died |= alive[j] & ~okv[j];
           }
         } else {
@@ -861,9 +871,11 @@ __device__ __forceinline__ void march_started_path(const LfLensDev* __restrict__
             nlive -= (unsigned)__popcll(alive[j] & ~okv[j]);
             alive[j] &= okv[j];
           }
+          if (nlive == 0u) e = n_ev;
         }
       }
       ev32 += nlive;       // events completed: one per ray still alive after the row
+      if (++e >= n_ev) break;
     }
     T.events += ev32;
     T.executed += ev32;
