@@ -561,6 +561,9 @@ lf_status lf_get_cull_audit(lf_ctx* ctx, uint64_t* rays, uint64_t* lit, int* lau
  *   "scene_lens_strided" -1/0/1 k_scene_lens's wave tile: by the tree's size / 8 x 8 neighbours / the march's strided tile
  *   "bvh_median" 0/1, "bvh_leaf" 1..4   the scene tree of the next lf_set_scene: median splits (round 2), primitives per leaf
  *   "comm_force_exchange" 0/1   run the collectives with a single rank as well
+ *   "march_tail_tiles" n, "march_tail_groups" g   the culled march splits its LAST n wave tiles over g workgroups each so that a
+ *                               launch ends on short workgroups (-1 / -1: the default, half a round of resident workgroups x 4;
+ *                               0 / 1: no split); same pixels and counters whatever the values
  * Unknown names are refused.  ctx == NULL: the value becomes the default of every context created afterwards (a
  * test that cannot reach the contexts a helper creates); 0 takes the default away. */
 lf_status lf_test_knob(lf_ctx* ctx, const char* name, double value);
