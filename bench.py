@@ -474,56 +474,64 @@ def main():
     if ref_path is not None:
         reference_flare_path_gpu(pkg, ref_path)        # (the device's frame beside the reference's CPU runs above)
 
-    lf = pkg.LensFlare(local)
-    lf.set_frame(W, H)
-    lf.set_params(1, 25.0, 1.0)
-    lf.set_aperture(pkg.APERTURE_STARBURST, mask)       # stop mask + starburst spectrum (set-up)
-    lf.set_aperture(pkg.APERTURE_GHOST, mask)
-    lf.set_lens(lens)
-    if lambda_rgb is not None:
-        lf.set_lambda_rgb(lambda_rgb)
-    lf.set_ghost_pairs(pairs, True)
-    if os.environ.get("LF_BENCH_TILE_STRIDE"):      # experiments only (profiles/r04_march_variants.txt)
-        lf.set_tile_stride(int(os.environ["LF_BENCH_TILE_STRIDE"]))
-    if os.environ.get("LF_BENCH_SUBCELL_BITS"):
-        lf.set_pupil_subcells(int(os.environ["LF_BENCH_SUBCELL_BITS"]))
-    lf.set_jitter_counter(0x1e45f1a4e)
-    # Path culling (lf_cull.hip): the march starts only the paths a pre-pass found able to carry light from the sun to
-    # the tile through the sample's pupil cell; ghost_buffer is the full enumeration's, bit for bit.  Mode 2 = the
-    # table is REBUILT AT EVERY FRAME, so that the timed frame holds the whole cost (a host that renders the same
-    # sun again would take mode 1 and reuse it).  LF_BENCH_CULL=0: every sample marches every path (rounds 1-4).
     cull_mode = int(os.environ.get("LF_BENCH_CULL", "2"))
-    lf.set_march_culling(cull_mode)
-    if cfg["spectral"]:
-        lf.set_starburst_spectrum(star_scale, lambda_rgb)
-    # the camera has the lens' own field of view, so that the pinhole projection of find_sun_pos and
-    # the lens agree about where a direction lands on the sensor
-    hf = 2 * math.degrees(math.atan(0.5 * lens["sensor_width_mm"] / efl))
-    vf = 2 * math.degrees(math.atan(math.tan(math.radians(hf) / 2) * H / W))
-    if cfg["scene"]:
-        # C4: the scene file's own sun; camera looking at it so that it projects to SUN_NS
-        camera, suns = lf.load_collada(os.path.join(pkg.DATA, cfg["scene"]))
-        lights = suns[:1]
-        pos = np.array(camera["pos"], float) if camera else np.zeros(3)
-        if cfg.get("behind_mesh"):
-            # the mesh between the camera and the sun: it fills the middle of the frame (a scene-heavy
-            # frame), the sun's screen position does not depend on what lies in between
-            lo, hi, _ = lf.scene_bounds()
-            mid, ext = 0.5 * (lo + hi), float(np.linalg.norm(hi - lo))
-            to_sun = np.array(lights[0][:3], float) - mid
-            pos = mid - to_sun / np.linalg.norm(to_sun) * (1.5 * ext)
-        c2w = pkg.aim_camera(pos, lights[0][:3], SUN_NS, hf, vf)
-        lf.set_camera(c2w, pos, hf, vf)
-        # the scene through the lens: one primary path per sensor sample, as many samples as the march
-        # takes (LF_BENCH_SCENE_SPP / LF_BENCH_PINHOLE_SCENE: experiments), 1 scene unit = 1 m
-        scene_spp = int(os.environ.get("LF_BENCH_SCENE_SPP", spp))
-        lf.set_params(scene_spp, 25.0, 1.0)
-        if not os.environ.get("LF_BENCH_PINHOLE_SCENE"):
-            lf.set_lens_camera(1, 0.001, 0.0)
-    else:
-        lf.set_camera(np.eye(3), [0, 0, 0], hf, vf)
-        ex, ey = math.tan(math.radians(hf) / 2), math.tan(math.radians(vf) / 2)
-        lights = [[(2 * SUN_NS[0] - 1) * ex * 10, (2 * SUN_NS[1] - 1) * ey * 10, -10.0, 1.0, 0.9, 0.5]]
+
+    def build_context():
+        """-> (context, lights): everything the frame needs set on a FRESH context (also what a bring-up whose blocking call
+        never returned falls back to: the abandoned helper thread still stands in the old context, which is then left to it)"""
+        lf = pkg.LensFlare(local)
+        lf.set_frame(W, H)
+        lf.set_params(1, 25.0, 1.0)
+        lf.set_aperture(pkg.APERTURE_STARBURST, mask)       # stop mask + starburst spectrum (set-up)
+        lf.set_aperture(pkg.APERTURE_GHOST, mask)
+        lf.set_lens(lens)
+        if lambda_rgb is not None:
+            lf.set_lambda_rgb(lambda_rgb)
+        lf.set_ghost_pairs(pairs, True)
+        if os.environ.get("LF_BENCH_TILE_STRIDE"):      # experiments only (profiles/r04_march_variants.txt)
+            lf.set_tile_stride(int(os.environ["LF_BENCH_TILE_STRIDE"]))
+        if os.environ.get("LF_BENCH_SUBCELL_BITS"):
+            lf.set_pupil_subcells(int(os.environ["LF_BENCH_SUBCELL_BITS"]))
+        lf.set_jitter_counter(0x1e45f1a4e)
+        # Path culling (lf_cull.hip): the march starts only the paths a pre-pass found able to carry light from the sun to
+        # the tile through the sample's pupil cell; ghost_buffer is the full enumeration's, bit for bit.  Mode 2 = the
+        # table is REBUILT AT EVERY FRAME, so that the timed frame holds the whole cost (a host that renders the same
+        # sun again would take mode 1 and reuse it).  LF_BENCH_CULL=0: every sample marches every path (rounds 1-4).
+        lf.set_march_culling(cull_mode)
+        if cfg["spectral"]:
+            lf.set_starburst_spectrum(star_scale, lambda_rgb)
+        # the camera has the lens' own field of view, so that the pinhole projection of find_sun_pos and
+        # the lens agree about where a direction lands on the sensor
+        hf = 2 * math.degrees(math.atan(0.5 * lens["sensor_width_mm"] / efl))
+        vf = 2 * math.degrees(math.atan(math.tan(math.radians(hf) / 2) * H / W))
+        if cfg["scene"]:
+            # C4: the scene file's own sun; camera looking at it so that it projects to SUN_NS
+            camera, suns = lf.load_collada(os.path.join(pkg.DATA, cfg["scene"]))
+            lights = suns[:1]
+            pos = np.array(camera["pos"], float) if camera else np.zeros(3)
+            if cfg.get("behind_mesh"):
+                # the mesh between the camera and the sun: it fills the middle of the frame (a scene-heavy
+                # frame), the sun's screen position does not depend on what lies in between
+                lo, hi, _ = lf.scene_bounds()
+                mid, ext = 0.5 * (lo + hi), float(np.linalg.norm(hi - lo))
+                to_sun = np.array(lights[0][:3], float) - mid
+                pos = mid - to_sun / np.linalg.norm(to_sun) * (1.5 * ext)
+            c2w = pkg.aim_camera(pos, lights[0][:3], SUN_NS, hf, vf)
+            lf.set_camera(c2w, pos, hf, vf)
+            # the scene through the lens: one primary path per sensor sample, as many samples as the march
+            # takes (LF_BENCH_SCENE_SPP / LF_BENCH_PINHOLE_SCENE: experiments), 1 scene unit = 1 m
+            scene_spp = int(os.environ.get("LF_BENCH_SCENE_SPP", spp))
+            lf.set_params(scene_spp, 25.0, 1.0)
+            if not os.environ.get("LF_BENCH_PINHOLE_SCENE"):
+                lf.set_lens_camera(1, 0.001, 0.0)
+        else:
+            lf.set_camera(np.eye(3), [0, 0, 0], hf, vf)
+            ex, ey = math.tan(math.radians(hf) / 2), math.tan(math.radians(vf) / 2)
+            lights = [[(2 * SUN_NS[0] - 1) * ex * 10, (2 * SUN_NS[1] - 1) * ey * 10, -10.0, 1.0, 0.9, 0.5]]
+        lf.set_band(0, H)
+        return lf, lights
+
+    lf, lights = build_context()
 
     # The frame is dealt by BLOCKS of 64 x 64 pixels, round-robin (block b belongs to rank b % world: lf_set_block_deal,
     # round 6): the block is the path cull's, so a rank builds, audits and reads only its own rows of the cull table --
@@ -535,8 +543,6 @@ def main():
         raise SystemExit("LF_BENCH_DEAL: blocks or rows")
     my_trows = len(sharding.my_tile_rows(H, rank, world))
     my_blocks = len(sharding.my_blocks(W, H, rank, world))
-    lf.set_band(0, H)
-
     def set_deal():
         if deal == "blocks":
             lf.set_block_deal(rank, world)
@@ -597,6 +603,10 @@ def main():
                 lf.comm_abort()
             except Exception:  # noqa: BLE001
                 pass
+            if sharding.expired(bad):
+                # some rank's blocking call never came back: a helper thread still stands in that context (poisoned: it
+                # publishes nothing) -- every rank goes on with a fresh one, the old one is left to it, never freed
+                lf, lights = build_context()
             if rehearsal:
                 gather_mode = "host"
                 gather_note = "C-ABI RCCL exchange unavailable (" + "; ".join(bad) + "): exchange staged through the host (rehearsal)"
@@ -696,6 +706,8 @@ def main():
             gather_mode = "torch"
             gather_note = "C-ABI RCCL table exchange failed (" + "; ".join(bad) + "): torch.distributed nccl exchange of frame and table"
             nccl_group = dist.new_group(backend="nccl")
+            if sharding.expired(bad):      # (as above: the frame that never came back still stands in the old context)
+                lf, lights = build_context()
             lf.set_row_interleave(rank, world)
             lf.set_cull_share(rank, world)
             cull_share = "torch.distributed nccl"

@@ -246,6 +246,12 @@ def call_with_deadline(fn, timeout_s, on_expire=None):
     return False, None
 
 
+def expired(reasons):
+    """Did any rank's bring-up step end on its DEADLINE (agree()'s reasons)?  Then a helper thread of that rank was abandoned
+    inside its context (call_with_deadline): the context must not be used again -- every rank builds a fresh one."""
+    return any(("within the deadline" in r) or ("blocked for more than" in r) or ("did not complete within" in r) for r in reasons)
+
+
 def first_exchange(dist, enqueue, test, timeout_s=120.0, poll_s=0.01, clock=None, sleep=None, on_expire=None):
     """Run the first exchange of a fresh communicator so that NO rank can hang: `enqueue()` queues it
     (may raise, may block on the host: it runs under the deadline in a helper thread), `test()` says

@@ -549,6 +549,16 @@ def test_bench_goes_through_the_multi_rank_bring_up_with_one_rank(pkg):
     for line in lines.values():
         assert line["config"]["events_executed_per_frame"] == want["config"]["events_executed_per_frame"]
         assert line["culling"]["started_fraction"] == want["culling"]["started_fraction"]
+    # a bring-up call that does not come back within its deadline (here: a deadline nothing can meet): the helper thread is
+    # abandoned INSIDE the context, which is poisoned and never used again -- the bench goes on with a fresh context and the
+    # torch.distributed exchange, says so, and renders the same frame
+    late = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--steps", "2", "--warmup", "1", "--no-cpu", "--config", "c2"],
+                          capture_output=True, text=True, timeout=600, env=dict(env, LF_BENCH_COMM_TIMEOUT="0.000001"), cwd=root)
+    assert late.returncode == 0, late.stderr[-3000:]
+    line = json.loads([l for l in late.stdout.splitlines() if l.startswith("{")][-1])
+    assert line["config"]["gather_mode"] == "torch" and "deadline" in line["config"]["gather_note"]
+    assert line["config"]["events_executed_per_frame"] == want["config"]["events_executed_per_frame"]
+    assert line["culling"]["culled"] and line["culling"]["audit"]["lit"] == 0
 
 
 # ---- round 6: the frame dealt by BLOCKS of 64 x 64 pixels (lf_set_block_deal) -------------------------------------------

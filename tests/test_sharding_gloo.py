@@ -142,11 +142,16 @@ def test_one_rank_failing_alone_is_noticed_by_all(stage, tmp_path):
     mp.spawn(_bringup_worker, args=(world, _free_port(), str(tmp_path), fail_rank, stage), nprocs=world, join=True)
     logs = [json.load(open(tmp_path / f"log_{r}.json")) for r in range(world)]
     assert all(l == logs[0] for l in logs)                      # one verdict
+    # ... and one answer to "does a helper thread still stand in some rank's context?" (sharding.expired: bench.py then goes
+    # on with a FRESH context on every rank instead of the one the abandoned call may still write to)
+    expired = _sharding().expired
     if stage == "none":
         assert [x[:2] for x in logs[0]] == [["preflight", True], ["exchange", True]]
     elif stage == "preflight":
         assert logs[0] == [["preflight", False, ["rank 1: librccl.so.1 not found"]]]   # no exchange was attempted
+        assert not expired(logs[0][0][2])
     elif stage == "blocked":
+        assert expired(logs[0][1][2])
         # the two healthy ranks' enqueue blocks on the host for ever (their peer "died"): the helper
         # thread is abandoned at the deadline, every rank still reaches the verdict
         name, ok, bad = logs[0][1]
@@ -157,6 +162,7 @@ def test_one_rank_failing_alone_is_noticed_by_all(stage, tmp_path):
         assert name == "exchange" and not ok and len(bad) == world
         assert "rank 1: RuntimeError: LF_ERR_HIP: injected launch failure" in bad
         assert all("did not complete within" in b for b in bad if not b.startswith("rank 1"))
+        assert expired(bad) and not expired(["rank 1: RuntimeError: LF_ERR_HIP: injected launch failure"])
 
 
 # ---- `python bench.py --gpus N` starts its own ranks (round 5) ------------------------------------------
