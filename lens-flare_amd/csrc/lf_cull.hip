@@ -1355,9 +1355,10 @@ void k_march_cull(const LfLensDev* __restrict__ lens, const LfPairsDev* __restri
 // in LDS, so pixels and counters do not depend on the order: bit for bit the frame of k_march_cull and of the oracle.
 constexpr int kItemCap = 16384;      // items of a chunk (2 bytes each)
 constexpr int kItemChunk = 256;      // samples per chunk at most (8 bits of an item; the pixel takes 6)
+constexpr int kItemCellCache = 64;   // chunks of up to this many samples keep each (sample, pixel)'s table cell between the two listing passes
 
 template <int K>
-__global__ __launch_bounds__(64 * kWgWaves, (K == 1 ? 8 : 6))
+__global__ __launch_bounds__(64 * kWgWaves, 6)      // (42 KB of LDS lists: three workgroups per CU)
 void k_march_items(const LfLensDev* __restrict__ lens, const LfPairsDev* __restrict__ pairs,
                    const int* __restrict__ seq_table, const LfProgRow* __restrict__ rec_table,
                    const LfWeightRow* __restrict__ wrec_table, const float* __restrict__ mask, MarchArgs a,
@@ -1368,6 +1369,7 @@ void k_march_items(const LfLensDev* __restrict__ lens, const LfPairsDev* __restr
   __shared__ int s_pcount[kCullMaxPaths], s_poff[kCullMaxPaths + 1], s_goff[kCullMaxPaths + 1], s_pfill[kCullMaxPaths];
   __shared__ int s_next;
   __shared__ unsigned short s_items[kItemCap];
+  __shared__ unsigned short s_cell[kItemCellCache * 64];      // the table cell of every (sample of the chunk, pixel): count -> fill
   const int tid = threadIdx.x;
   if (tid < 64 * 3) s_acc[tid] = 0ull;
   if (tid < kMarchCounters) s_cnt[tid] = 0ull;
@@ -1419,16 +1421,18 @@ void k_march_items(const LfLensDev* __restrict__ lens, const LfPairsDev* __restr
     }
   };
   // the paths pixel (lane) starts for the chunk's k-th sample: the mask of the table cell that holds its pupil point
-  auto mask_of = [&](int k_global) -> unsigned long long {
+  // ... as the index of its table entry (cells = the block's union entry: an unstratified sample; 0xffff: no pixel there)
+  auto cell_of = [&](int k_global) -> unsigned {
     int x, y;
-    if (!pixel_of(lane, x, y)) return 0ull;
+    if (!pixel_of(lane, x, y)) return 0xffffu;
     const int s = sg + k_global * a.sgroups;
+    if (s >= GG) return (unsigned)cull.cells;
     float ua, ub, jx, jy;
     pupil_point(x, y, s, ua, ub, jx, jy);
-    if (s >= GG) return crow[cull.cells];           // an unstratified sample: the block's union entry
     const int fx = min(cull.P - 1, (int)(ua * (float)cull.P)), fy = min(cull.P - 1, (int)(ub * (float)cull.P));
-    return crow[fy * cull.P + fx];
+    return (unsigned)(fy * cull.P + fx);
   };
+  auto mask_at = [&](unsigned cell) -> unsigned long long { return cell == 0xffffu ? 0ull : crow[cell]; };
   auto wave_or = [](unsigned long long v) {
     unsigned lo = (unsigned)v, hi = (unsigned)(v >> 32);
     for (int off = 32; off > 0; off >>= 1) { lo |= __shfl_xor(lo, off); hi |= __shfl_xor(hi, off); }
@@ -1437,15 +1441,20 @@ void k_march_items(const LfLensDev* __restrict__ lens, const LfPairsDev* __restr
 
   PathTally T;
   const int n_mine = (a.spp - sg + a.sgroups - 1) / a.sgroups;     // samples sg, sg + sgroups, ...
-  int c0 = 0, ch = min(kItemChunk, n_mine);
+  // (the chunk to begin with: what the table's started fraction says fits the item list -- a chunk that does not fit is
+  // counted for nothing and halved)
+  int c0 = 0, ch = min(max(1, min(kItemChunk, cull.items_chunk0)), n_mine);
   while (c0 < n_mine) {
     const int chn = min(ch, n_mine - c0);
     // ---- count: how many (pixel, sample) items of this chunk start each path (a wave = one sample's 64 pixels) ---
     if (tid < kCullMaxPaths) { s_pcount[tid] = 0; s_pfill[tid] = 0; }
     if (tid == 0) s_next = 0;
     __syncthreads();
+    const bool cached = chn <= kItemCellCache;
     for (int k = wave; k < chn; k += kWgWaves) {
-      const unsigned long long mine = mask_of(c0 + k);
+      const unsigned cell = cell_of(c0 + k);
+      if (cached) s_cell[k * 64 + lane] = (unsigned short)cell;
+      const unsigned long long mine = mask_at(cell);
       unsigned long long u = wave_or(mine);
       while (u != 0ull) {
         const int q = __builtin_ctzll(u);
@@ -1469,7 +1478,7 @@ void k_march_items(const LfLensDev* __restrict__ lens, const LfPairsDev* __restr
     }
     // ---- fill: the items, sorted by path ------------------------------------------------------------------------
     for (int k = wave; k < chn; k += kWgWaves) {
-      const unsigned long long mine = mask_of(c0 + k);
+      const unsigned long long mine = mask_at(cached ? (unsigned)s_cell[k * 64 + lane] : cell_of(c0 + k));
       unsigned long long u = wave_or(mine);
       while (u != 0ull) {
         const int q = __builtin_ctzll(u);
@@ -1991,6 +2000,14 @@ lf_status lfk_march_culled(lf_ctx* ctx, const MarchArgs& a_in, size_t blocks, si
   // longer tail cost more than they save (a split tile repeats the workgroup's set-up and ends on 8 waves waiting for one)
   // (profiles/r06_cull_bounds.txt, 7.)
   a.tail_from = 0; a.tail_groups = 1; c.tail_acc = nullptr; c.tail_done = nullptr;
+  {
+    // k_march_items: a (sample, 64 pixels) wave lists about 64 x paths x the table's started fraction items; the chunk to begin
+    // with is the power of two of samples that fits the list with a third to spare (blocks differ)
+    const double per_sample = 64.0 * (double)std::max(1, ctx->pairs.n) * std::max(1e-4, ctx->cull_started_fraction) * 1.35;
+    int ch0 = 256;
+    while (ch0 > 1 && (double)ch0 * per_sample > (double)kItemCap) ch0 >>= 1;
+    c.items_chunk0 = ch0;
+  }
   if (!items && a.sgroups == 1 && !weights_first) {
     hipDeviceProp_t prop;
     LF_HIP(ctx, hipGetDeviceProperties(&prop, ctx->device));

@@ -236,6 +236,7 @@ struct LfCullArgs {
                                       // sub-cells per axis of the sampling specification (lf_set_pupil_subcells)
   unsigned long long* tail_acc;       // [tail tile][64 lanes][3]: where the workgroups of a split tail tile meet (MarchArgs::tail_from);
   int* tail_done;                     // [tail tile] arrivals: the last one converts and clears both (all zero between launches)
+  int items_chunk0;                   // k_march_items: samples per chunk to begin with (the host's estimate from the table's started fraction)
 #ifdef LF_EXPERIMENTS
   unsigned long long* wg_clock;       // [workgroup][2]: wall clock at its start / end (LF_MARCH_WG_CLOCK=<file>)
 #endif
