@@ -214,6 +214,16 @@ def _band_against_f64(pkg, lf, lens, W, H, y0, y1, spp, key, mask, lambda_rgb=No
     img = lf.read_tile(pkg.GHOST_BUFFER, 0, y0, W, y1)
     cnt = lf.counters()
     lf.set_band(0, H)
+    if x_window == "auto":
+        # the columns where the DEVICE's band holds anything at all (>= FLOOR / 4), +- 16: outside them nothing is lit in
+        # the device's frame -- and a frame that were dark where the tracer's is lit is what the whole-frame record
+        # (LF_LONG_CHECKS, profiles/r06_f64_whole_frame.log) would show
+        cols = np.where((img >= 0.25 * FLOOR).any(axis=(0, 2)))[0]
+        x_window = (max(0, int(cols.min()) - 16), min(W, int(cols.max()) + 17)) if cols.size else (W // 2 - 32, W // 2 + 32)
+        outside = np.ones(W, bool)
+        outside[x_window[0]:x_window[1]] = False
+        assert not (img[:, outside] >= 0.25 * FLOOR).any()
+        print(f"  rows {y0}..{y1}: columns {x_window[0]}..{x_window[1]} of {W} traced in float64", flush=True)
     if x_window is not None:
         # columns [x0, x1) only: the device marched the whole band (cheap), the float64 tracer the window;
         # pixels are compared inside it, the ray-fate counters (a whole-band property) are not
@@ -234,7 +244,7 @@ def _band_against_f64(pkg, lf, lens, W, H, y0, y1, spp, key, mask, lambda_rgb=No
         assert np.all(dev[lit] <= TOL * ref[lit] + 1.05 * frag[lit]), (dev[lit] / ref[lit]).max()
         assert np.all(dev[~lit] <= TOL * FLOOR + 1.05 * frag[~lit])
         rel = dev[lit] / ref[lit]
-        assert (rel <= TOL).mean() >= 0.98 and np.median(rel) < median_bar
+        assert rel.size == 0 or ((rel <= TOL).mean() >= 0.98 and np.median(rel) < median_bar)
         over = dev[lit] > TOL * ref[lit]
         if over.any():
             ratio = dev[lit][over] / frag[lit][over]
@@ -242,6 +252,8 @@ def _band_against_f64(pkg, lf, lens, W, H, y0, y1, spp, key, mask, lambda_rgb=No
             hist, _ = np.histogram(ratio, bins=[0, 0.25, 0.5, 0.75, 1.0, 1.05])
             print(f"  allowance: {int(over.sum())} of {int(lit.sum())} lit values outside 1e-4; deviation / fragile weight "
                   f"histogram {hist.tolist()}, max {ratio.max():.3f}; largest raw deviation {rel.max():.2e}")
+        if causes is not None:
+            _tally_causes(causes, lit, lit & (dev > TOL * ref), dev, frag, rel, lfo.g64_last_causes[y0:y1, x0:x1])
         return rel, int(over.sum()), c64
     rel = _check_against_f64(img, cnt, ref, frag, c64, min_lit=min_lit, median_bar=median_bar, culled=lf.cull_info()["culled"])
     lit = ref >= FLOOR
@@ -249,21 +261,25 @@ def _band_against_f64(pkg, lf, lens, W, H, y0, y1, spp, key, mask, lambda_rgb=No
     over = lit & (dev > TOL * ref)
     needed = int(over.sum())
     if causes is not None:
-        # the values that needed the fragile-ray allowance: how much of it, the largest raw deviation, and WHAT made their
-        # rays fragile (per value: the cause that carries most of its pixel's fragile weight)
-        causes["values"] = causes.get("values", 0) + int(lit.sum())
-        causes["needed"] = causes.get("needed", 0) + needed
-        causes["max_raw_rel"] = max(causes.get("max_raw_rel", 0.0), float(rel.max()) if rel.size else 0.0)
-        if needed:
-            ratio = dev[over] / frag[over]
-            hist, _ = np.histogram(ratio, bins=[0, 0.25, 0.5, 0.75, 1.0, 1.05])
-            causes["ratio_hist"] = (np.asarray(causes.get("ratio_hist", [0] * 5)) + hist).tolist()
-            causes["max_ratio"] = max(causes.get("max_ratio", 0.0), float(ratio.max()))
-            by = lfo.g64_last_causes[y0:y1]
-            dom = by.argmax(axis=2)[..., None].repeat(3, axis=2)[over]
-            for k, name in enumerate(lfo.G64_CAUSES):
-                causes[name] = causes.get(name, 0) + int((dom == k).sum())
+        _tally_causes(causes, lit, over, dev, frag, rel, lfo.g64_last_causes[y0:y1])
     return rel, needed, c64
+
+
+def _tally_causes(causes, lit, over, dev, frag, rel, by):
+    """the values that needed the fragile-ray allowance: how much of it, the largest raw deviation, and WHAT made their
+    rays fragile (per value: the cause that carries most of its pixel's fragile weight; `by`: rows x columns x cause)"""
+    needed = int(over.sum())
+    causes["values"] = causes.get("values", 0) + int(lit.sum())
+    causes["needed"] = causes.get("needed", 0) + needed
+    causes["max_raw_rel"] = max(causes.get("max_raw_rel", 0.0), float(rel.max()) if rel.size else 0.0)
+    if needed:
+        ratio = dev[over] / frag[over]
+        hist, _ = np.histogram(ratio, bins=[0, 0.25, 0.5, 0.75, 1.0, 1.05])
+        causes["ratio_hist"] = (np.asarray(causes.get("ratio_hist", [0] * 5)) + hist).tolist()
+        causes["max_ratio"] = max(causes.get("max_ratio", 0.0), float(ratio.max()))
+        dom = by.argmax(axis=2)[..., None].repeat(3, axis=2)[over]
+        for k, name in enumerate(lfo.G64_CAUSES):
+            causes[name] = causes.get(name, 0) + int((dom == k).sum())
 
 
 def test_c3_band_at_full_spp_against_the_independent_tracer(pkg, lf):
@@ -301,12 +317,15 @@ def test_c3_lit_band_of_40_rows_against_the_independent_tracer(pkg, lf):
 
 
 def test_c3_every_lit_band_against_the_independent_tracer(pkg, lf):
-    """rows 560..720 of the benchmark frame hold every lit value the whole-frame comparison found
-    (profiles/r05_f64_whole_frame.log) -- those four 40-row bands at the full 256 spp in the DEFAULT run (a minute each on
-    the GPU box's host CPUs), with what the driver's record should show: how many values needed the fragile-ray allowance,
-    how much of it (histogram of deviation / fragile weight), the largest raw deviation, and the cause of the fragility --
-    the rim of a clear aperture, the edge of a mask texel (the stop's mask is looked up nearest-texel: a hard edge at every
-    texel), the critical angle, a grazing miss."""
+    """every lit value of the benchmark frame in the DEFAULT run.  The whole-frame comparison
+    (profiles/r05_f64_whole_frame.log, r06_f64_whole_frame.log) finds them in rows 400..720 -- 159 000 values in EIGHT
+    40-row bands, not the four (560..720) the review named from the log's second half -- and in each band only in the few
+    hundred columns around the sun's image: the float64 tracer marches exactly those columns (where the device's band holds
+    anything at all, +- 16 px; a quarter of a minute per band instead of a minute), at the full 256 spp, with what the
+    driver's record should show: how many values needed the fragile-ray allowance, how much of it (histogram of deviation
+    / fragile weight), the largest raw deviation, and the cause of the fragility -- the rim of a clear aperture, the edge
+    of a mask texel (the stop's mask is looked up nearest-texel: a hard edge at every texel), the critical angle, a
+    grazing miss.  (Ray-fate counters are a whole-band property: test_c3_lit_band_of_40_rows compares them.)"""
     import json
     import time
     lens = pkg.load_lens_file("dgauss11.lens")
@@ -316,13 +335,13 @@ def test_c3_every_lit_band_against_the_independent_tracer(pkg, lf):
     rows = 40 if cores >= 128 else 8
     causes = {}
     t0 = time.time()
-    for y0 in range(560, 720, 40):
+    for y0 in range(400, 720, 40):
         rel, needed, c64 = _band_against_f64(pkg, lf, lens, W, H, y0, y0 + rows, spp, key, mask, min_lit=0, median_bar=1e-5,
-                                             causes=causes)
+                                             causes=causes, x_window="auto")
         print(f"c3 rows {y0}..{y0 + rows}: {rel.size} lit values, max rel {rel.max() if rel.size else 0:.2e}, allowance needed by "
               f"{needed}, {c64['rays_fragile']} fragile rays of {c64['rays_launched']} ({time.time() - t0:.0f} s)", flush=True)
     print("LIT BANDS:", json.dumps(causes), flush=True)
-    assert causes["values"] > (50000 if rows == 40 else 5000)
+    assert causes["values"] > (120000 if rows == 40 else 10000)
     assert causes["needed"] < 1e-3 * causes["values"] and causes.get("max_ratio", 0.0) <= 1.05
 
 
